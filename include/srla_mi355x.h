@@ -1,0 +1,184 @@
+/*
+ * srla_mi355x.h -- C ABI of libsrla_mi355x.so, the MI355X (gfx950) drop-in for the encode path
+ * of aikiriao/SRLA (codec version 18, format version 10).
+ *
+ * Part 1 re-declares, with identical names, signatures, struct layouts and error behaviour,
+ * the encoder API of the reference: every entry point cites the reference declaration it
+ * replaces (paths relative to the reference tree).  A program that links the reference's
+ * libsrlacodec.a for encoding can link this library instead; `srla -d` decodes the output
+ * bit-identically.
+ *
+ * Part 2 adds what a GPU implementation needs beyond the reference's interface: encoding from
+ * samples that already live in HBM, device selection, statistics, and a stage-level probe used
+ * by the parity tests.  Plain pointers and sizes only.
+ */
+#ifndef SRLA_MI355X_H_INCLUDED
+#define SRLA_MI355X_H_INCLUDED
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------------------------
+ * Part 1 -- the reference's encoder interface
+ * ---------------------------------------------------------------------------------------- */
+
+/* include/srla.h:7-22 */
+#define SRLA_FORMAT_VERSION         10
+#define SRLA_CODEC_VERSION          18
+#define SRLA_HEADER_SIZE            30
+#define SRLA_MAX_NUM_CHANNELS       8
+#define SRLA_MAX_COEFFICIENT_ORDER  255
+#define SRLA_MAX_LTP_ORDER          3
+#define SRLA_NUM_PARAMETER_PRESETS  7
+
+/* include/srla.h:29-38 */
+typedef enum SRLAApiResultTag {
+    SRLA_APIRESULT_OK = 0,
+    SRLA_APIRESULT_INVALID_ARGUMENT,
+    SRLA_APIRESULT_INVALID_FORMAT,
+    SRLA_APIRESULT_INSUFFICIENT_BUFFER,
+    SRLA_APIRESULT_INSUFFICIENT_DATA,
+    SRLA_APIRESULT_PARAMETER_NOT_SET,
+    SRLA_APIRESULT_DETECT_DATA_CORRUPTION,
+    SRLA_APIRESULT_NG
+} SRLAApiResult;
+
+/* include/srla.h:41-51 */
+struct SRLAHeader {
+    uint32_t format_version;
+    uint32_t codec_version;
+    uint16_t num_channels;
+    uint32_t num_samples;
+    uint32_t sampling_rate;
+    uint16_t bits_per_sample;
+    uint8_t  offset_lshift;
+    uint32_t max_num_samples_per_block;
+    uint8_t  preset;
+};
+
+/* include/srla_encoder.h:8-18 */
+struct SRLAEncodeParameter {
+    uint16_t num_channels;
+    uint16_t bits_per_sample;
+    uint32_t sampling_rate;
+    uint32_t min_num_samples_per_block;
+    uint32_t max_num_samples_per_block;
+    uint32_t num_lookahead_samples;
+    uint32_t ltp_order;
+    uint32_t num_svr_filter_learning_iteration;
+    uint8_t  preset;
+};
+
+/* include/srla_encoder.h:21-27 */
+struct SRLAEncoderConfig {
+    uint32_t max_num_channels;
+    uint32_t min_num_samples_per_block;
+    uint32_t max_num_samples_per_block;
+    uint32_t max_num_lookahead_samples;
+    uint32_t max_num_parameters;
+};
+
+/* include/srla_encoder.h:30 */
+struct SRLAEncoder;
+
+/* include/srla_encoder.h:33-34 -- invoked synchronously on the calling thread, once per
+ * look-ahead window, in stream order, with a pointer into the caller's output buffer */
+typedef void (*SRLAEncoder_EncodeBlockCallback)(
+    uint32_t num_samples, uint32_t progress_samples, const uint8_t *encoded_block_data, uint32_t block_data_size);
+
+/* include/srla_encoder.h:41-42 (libs/srla_encoder/src/srla_encoder.c:85) */
+SRLAApiResult SRLAEncoder_EncodeHeader(const struct SRLAHeader *header, uint8_t *data, uint32_t data_size);
+
+/* include/srla_encoder.h:45 (srla_encoder.c:468): size of the HOST handle only; device and
+ * pinned memory are owned by the library and sized from the same config at Create */
+int32_t SRLAEncoder_CalculateWorkSize(const struct SRLAEncoderConfig *config);
+
+/* include/srla_encoder.h:48 (srla_encoder.c:549) */
+struct SRLAEncoder *SRLAEncoder_Create(const struct SRLAEncoderConfig *config, void *work, int32_t work_size);
+
+/* include/srla_encoder.h:51 (srla_encoder.c:697) */
+void SRLAEncoder_Destroy(struct SRLAEncoder *encoder);
+
+/* include/srla_encoder.h:54-55 (srla_encoder.c:710) */
+SRLAApiResult SRLAEncoder_SetEncodeParameter(struct SRLAEncoder *encoder, const struct SRLAEncodeParameter *parameter);
+
+/* include/srla_encoder.h:58-60 (srla_encoder.c:1477) */
+SRLAApiResult SRLAEncoder_ComputeBlockSize(
+    struct SRLAEncoder *encoder, const int32_t *const *input, uint32_t num_samples, uint32_t *output_size);
+
+/* include/srla_encoder.h:63-66 (srla_encoder.c:1549) */
+SRLAApiResult SRLAEncoder_EncodeBlock(
+    struct SRLAEncoder *encoder, const int32_t *const *input, uint32_t num_samples,
+    uint8_t *data, uint32_t data_size, uint32_t *output_size);
+
+/* include/srla_encoder.h:69-72 (srla_encoder.c:1646) */
+SRLAApiResult SRLAEncoder_EncodeOptimalPartitionedBlock(
+    struct SRLAEncoder *encoder, const int32_t *const *input, uint32_t num_samples,
+    uint8_t *data, uint32_t data_size, uint32_t *output_size);
+
+/* include/srla_encoder.h:75-79 (srla_encoder.c:1701) */
+SRLAApiResult SRLAEncoder_EncodeWhole(
+    struct SRLAEncoder *encoder, const int32_t *const *input, uint32_t num_samples,
+    uint8_t *data, uint32_t data_size, uint32_t *output_size, SRLAEncoder_EncodeBlockCallback encode_callback);
+
+/* ------------------------------------------------------------------------------------------
+ * Part 2 -- MI355X extensions
+ * ---------------------------------------------------------------------------------------- */
+
+/* Select the HIP device used by encoders created afterwards on this thread's process
+ * (one process per GPU is the intended deployment; default device 0). Returns 0 on success. */
+int SRLAMI355X_SetDevice(int device_index);
+
+/* Number of host threads the bit-packer may use (default: min(hardware threads, 16)). */
+void SRLAMI355X_SetPackThreads(struct SRLAEncoder *encoder, uint32_t num_threads);
+
+/* EncodeWhole for samples already resident in HBM: d_input is a device pointer to planar
+ * int32 [num_channels][channel_stride] (channel_stride >= num_samples).  Output contract is
+ * SRLAEncoder_EncodeWhole's. */
+SRLAApiResult SRLAMI355X_EncodeWholeDevice(
+    struct SRLAEncoder *encoder, const int32_t *d_input, uint32_t channel_stride, uint32_t num_samples,
+    uint8_t *data, uint32_t data_size, uint32_t *output_size, SRLAEncoder_EncodeBlockCallback encode_callback);
+
+struct SRLAMI355XStats {
+    uint64_t num_windows;
+    uint64_t num_candidates;
+    uint64_t num_items;          /* analysed (candidate, channel variant) pairs          */
+    uint64_t num_blocks;         /* blocks written                                       */
+    uint64_t num_raw_blocks;
+    uint64_t num_silent_blocks;
+    uint64_t num_tie_items;      /* chosen items whose order choice was within libm tolerance */
+    uint64_t num_odd_items;      /* chosen items with an odd block length                */
+    uint64_t analyze_launches;
+    double   analyze_ms;         /* HIP-event time of the item-analysis kernel launches  */
+    double   price_ms;
+    double   gather_ms;
+    double   h2d_ms;
+    double   d2h_ms;
+    double   pack_ms;            /* host wall time in the bit-packer                     */
+    double   total_ms;           /* host wall time inside Encode*                        */
+    uint64_t analyzed_samples;   /* sum of item lengths                                  */
+};
+/* cumulative since Create or the last reset */
+void SRLAMI355X_GetStats(struct SRLAEncoder *encoder, struct SRLAMI355XStats *stats, int reset);
+
+/* Stage-level probe for the parity tests: analyses one block exactly as the block-division
+ * search would and returns every channel variant.  variants = num_channels (+2 when >= 2:
+ * [plain channels..., M, S]).  records: variants * SRLAMI355X_ITEM_RECORD_BYTES;
+ * residuals: variants * num_samples int32; debug: variants * SRLAMI355X_DEBUG_DOUBLES doubles
+ * (LPC lags, error variances, per-order length estimates, LTP lags); any may be NULL. */
+#define SRLAMI355X_ITEM_RECORD_BYTES 1344
+#define SRLAMI355X_DEBUG_DOUBLES     1040
+SRLAApiResult SRLAMI355X_ProbeBlock(
+    struct SRLAEncoder *encoder, const int32_t *const *input, uint32_t num_samples,
+    void *records, int32_t *residuals, double *debug);
+
+/* Library identification string ("srla-mi355x <version> gfx950 ..."). */
+const char *SRLAMI355X_Version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SRLA_MI355X_H_INCLUDED */

@@ -1,0 +1,138 @@
+/*
+ * device_layout.h -- records shared by the host runtime and the HIP kernels.
+ *
+ * Vocabulary (follows the reference's domain):
+ *   window     the look-ahead span the block-division search works on
+ *              (SRLAEncoder_EncodeWhole's loop, srla_encoder.c:1756-1783); one block when the
+ *              search is off (min == max block size)
+ *   candidate  one block [i*min, j*min) of a window that the search prices
+ *              (SearchOptimalBlockPartitions, srla_encoder.c:353-389)
+ *   item       one analysed channel variant of one candidate: a plain channel, or the M / S
+ *              signal of the first two channels (ComputeCoefficientsPerChannel, :966)
+ */
+#ifndef SRLA_DEVICE_LAYOUT_H
+#define SRLA_DEVICE_LAYOUT_H
+
+#include <stdint.h>
+
+#define SRLA_MAX_CH          8
+#define SRLA_MAX_ORDER       255
+#define SRLA_MAX_NODES       65      /* lookahead / min block + 1 */
+#define SRLA_MAX_PORDER      10      /* srla_coder.c:18 */
+#define SRLA_LTP_MIN_PERIOD  8
+#define SRLA_LTP_MAX_PERIOD  262
+#define SRLA_LTP_LAGS        (SRLA_LTP_MAX_PERIOD + 1)
+#define SRLA_BIG_WEIGHT      (1u << 24)
+
+enum { SRLA_BLOCK_COMPRESS = 0, SRLA_BLOCK_SILENT = 1, SRLA_BLOCK_RAW = 2 };
+enum { SRLA_CODE_RICE = 0, SRLA_CODE_RECURSIVE_RICE = 1, SRLA_CODE_ALLZERO = 2 };
+
+/* item flags */
+#define SRLA_ITEM_INPUT_ZERO   1u   /* every sample of the variant's input is zero            */
+#define SRLA_ITEM_ORDER_TIE    2u   /* order selection within the libm tolerance: host decides */
+#define SRLA_ITEM_LTP_TIE      4u   /* LTP tap within tolerance of a rounding boundary         */
+#define SRLA_ITEM_LTP_FAIL     8u   /* 3x3 Cholesky failed: the reference returns NG           */
+#define SRLA_ITEM_ODD_LENGTH   16u  /* odd block length: reference result is history dependent */
+
+/* Per block-length constants the host prepares with the host libm. */
+typedef struct SrlaGeom {
+    uint32_t n;            /* block length                                        */
+    uint32_t nfft;         /* next power of two >= n (lpc.c:346)                  */
+    uint32_t log2_nfft;
+    uint32_t max_porder;   /* min(trailing zeros of n, 10) (srla_coder.c:358-364) */
+    uint32_t fine_len;     /* n >> max_porder                                     */
+    uint32_t tw_off;       /* offset (in double2) of this nfft's twiddle tables   */
+    uint32_t pad0, pad1;
+    double welch_divisor;  /* 4 * pow(n - 1, -2)            (lpc.c:259)           */
+    double welch_comp;     /* 15(n-2)^3 / (8(n-1)(n-3)(..)) (lpc.c:283)           */
+    double acorr_norm;     /* 2.0 / n                       (lpc.c:335)           */
+} SrlaGeom;
+
+typedef struct SrlaItemDesc {
+    uint32_t sample_off;   /* first sample, relative to the job's input          */
+    uint32_t n;
+    uint32_t variant;      /* 0..nch-1 plain channel, nch = M, nch + 1 = S       */
+    uint32_t geom;         /* index into the SrlaGeom table                      */
+    uint64_t res_off;      /* element offset of this item's residual in scratch  */
+    int32_t  forced_order; /* -1, or the order the host arbitrated (tie path)    */
+    uint32_t pad;
+} SrlaItemDesc;
+
+/* What kernel A leaves per item (everything SRLAEncoderCoefficient carries + costs). */
+typedef struct SrlaItemResult {
+    int32_t  preemph_prev;
+    int32_t  preemph_coef;
+    uint32_t lpc_order;
+    uint32_t lpc_rshift;
+    uint32_t use_sum;
+    uint32_t ltp_period;
+    int32_t  ltp_coef[3];
+    uint32_t code_length;   /* bits of this channel inside a compress payload */
+    uint32_t res_code_type;
+    uint32_t res_porder;
+    uint32_t res_bits;
+    uint32_t flags;
+    uint32_t pad[2];
+    int8_t   lpc_coef[256];      /* reversed tap order, as written to the stream      */
+    uint8_t  kparam[1024];       /* Rice k / recursive-Rice k2 per partition of porder */
+} SrlaItemResult;               /* 64 + 256 + 1024 = 1344 bytes */
+
+typedef struct SrlaCandDesc {
+    uint32_t window;
+    uint32_t node_i, node_j;
+    uint32_t sample_off;
+    uint32_t n;
+    uint32_t item_base;     /* first item (variant 0) or 0xFFFFFFFF when not analysed (RAW by length) */
+    uint32_t pad0, pad1;
+} SrlaCandDesc;
+
+typedef struct SrlaWindowDesc {
+    uint32_t sample_off;
+    uint32_t n;
+    uint32_t cand_base;
+    uint32_t num_cands;
+    uint32_t num_nodes;
+    uint32_t block_base;    /* first slot of this window in the block table (num_nodes - 1 slots) */
+    uint32_t pad0, pad1;
+} SrlaWindowDesc;
+
+/* One encoded block as the host pack consumes it (kernel B output, stream order inside a window). */
+typedef struct SrlaBlockRecord {
+    uint32_t valid;         /* 0 = unused slot */
+    uint32_t sample_off;
+    uint32_t n;
+    uint32_t block_type;
+    uint32_t ch_method;
+    uint32_t bytes;         /* total block size incl. the 11-byte header */
+    uint32_t item[SRLA_MAX_CH];  /* item index per output channel (compress blocks) */
+    uint32_t pad[2];
+} SrlaBlockRecord;          /* 64 bytes */
+
+typedef struct SrlaJobParams {
+    uint32_t num_channels;
+    uint32_t bits_per_sample;
+    uint32_t offset_lshift;
+    uint32_t max_order;       /* preset's max_num_parameters */
+    uint32_t order_fixed;     /* preset 0: MAX_FIXED tactic   */
+    uint32_t ltp_order;       /* 0, 1, 3 */
+    uint32_t num_samples;     /* per channel, of the job's input */
+    uint32_t channel_stride;  /* elements between channel planes of the input */
+    uint32_t max_block;
+    uint32_t min_block;
+    uint32_t num_items;
+    uint32_t num_cands;
+    uint32_t num_windows;
+    uint32_t out_stride;      /* elements between channel planes of the gathered output */
+} SrlaJobParams;
+
+/* LDS carve-up of kernel A for one FFT-size group (bytes, 16-byte aligned); host decides overlays */
+typedef struct SrlaLdsPlan {
+    uint32_t y_off;        /* int32 [n]      pre-emphasised signal                         */
+    uint32_t fft_off;      /* double [nfft]  FFT buffer; later zig-zag residual u32 [n]    */
+    uint32_t lev_off;      /* double [4*(order+3)] Levinson scratch                        */
+    uint32_t means_off;    /* double [2^(max_porder+1)] partition means                    */
+    uint32_t small_off;    /* fixed-size scalars, lags, reductions                         */
+    uint32_t total;
+} SrlaLdsPlan;
+
+#endif /* SRLA_DEVICE_LAYOUT_H */

@@ -1,0 +1,919 @@
+/*
+ * host_encoder.cpp -- host runtime behind the SRLAEncoder_* C ABI (include/srla_mi355x.h).
+ *
+ * What runs where:
+ *   host    argument checking exactly as the reference API, stream header, splitting the stream
+ *           into look-ahead windows, the candidate/item tables of the block-division search,
+ *           host-libm constant tables, H2D/D2H staging, the multi-threaded bit pack.
+ *   device  everything between samples and (residuals, parameters, block partition): kernels.hip.
+ *
+ * A stream is processed as a sequence of jobs (ranges of whole windows).  Two job slots are
+ * kept in flight: while the GPU analyses job k+1 the host packs job k.  Windows carry no state
+ * from one to the next, so jobs are independent; only the offset left shift is a
+ * whole-stream quantity and is computed first.
+ *
+ * There is no CPU fallback: if no HIP device can be initialised every Encode* / ComputeBlockSize
+ * call fails with SRLA_APIRESULT_NG and a message on stderr.
+ */
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <map>
+#include <mutex>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <thread>
+#include <vector>
+
+#include "../../include/srla_mi355x.h"
+#include "device_layout.h"
+#include "host_pack.h"
+#include "host_tables.h"
+#include "kernels.h"
+
+#define SRLA_HANDLE_MAGIC 0x53524C41u /* 'SRLA' */
+#define SRLA_MAX_FFT      8192u       /* largest block the LDS-resident FFT handles */
+
+static_assert(sizeof(SrlaItemResult) == SRLAMI355X_ITEM_RECORD_BYTES, "record size");
+static_assert(SRLA_DBG_STRIDE == SRLAMI355X_DEBUG_DOUBLES, "debug stride");
+
+struct SRLAEncoder {
+    uint32_t magic;
+    uint8_t alloced_by_own;
+    void *work;
+    struct Impl *impl;
+};
+
+namespace {
+
+using Clock = std::chrono::steady_clock;
+inline double ms_since(Clock::time_point t0) { return std::chrono::duration<double, std::milli>(Clock::now() - t0).count(); }
+
+int g_device_index = 0;
+
+/* max LPC order per preset, libs/srla_internal/src/srla_internal.c:30-38 */
+const uint32_t kPresetOrder[SRLA_NUM_PARAMETER_PRESETS] = { 0, 8, 16, 32, 64, 128, 255 };
+
+#define HIP_OK(expr)                                                                               \
+    do {                                                                                           \
+        hipError_t e__ = (expr);                                                                   \
+        if (e__ != hipSuccess) {                                                                   \
+            fprintf(stderr, "[srla-mi355x] %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e__), \
+                    __FILE__, __LINE__);                                                           \
+            return false;                                                                          \
+        }                                                                                          \
+    } while (0)
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    bool ensure(size_t bytes)
+    {
+        if (bytes <= cap) return true;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        size_t want = bytes + bytes / 4 + 4096;
+        HIP_OK(hipMalloc(&p, want));
+        cap = want;
+        return true;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct PinBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    bool ensure(size_t bytes)
+    {
+        if (bytes <= cap) return true;
+        if (p) (void)hipHostFree(p);
+        p = nullptr; cap = 0;
+        size_t want = bytes + bytes / 4 + 4096;
+        HIP_OK(hipHostMalloc(&p, want, hipHostMallocDefault));
+        cap = want;
+        return true;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+/* ---- a tiny persistent thread pool for the bit pack ------------------------------------- */
+class Pool {
+public:
+    explicit Pool(unsigned n) : stop_(false), pending_(0)
+    {
+        for (unsigned i = 0; i + 1 < n; i++) workers_.emplace_back([this] { loop(); });
+    }
+    ~Pool()
+    {
+        { std::lock_guard<std::mutex> l(m_); stop_ = true; }
+        cv_.notify_all();
+        for (auto &t : workers_) t.join();
+    }
+    /* runs fn(i) for i in [0, count), the caller participates */
+    void parallel_for(uint32_t count, const std::function<void(uint32_t)> &fn)
+    {
+        if (count == 0) return;
+        if (workers_.empty() || count == 1) { for (uint32_t i = 0; i < count; i++) fn(i); return; }
+        {
+            std::lock_guard<std::mutex> l(m_);
+            fn_ = &fn; next_.store(0); count_ = count; pending_ = (unsigned)workers_.size(); gen_++;
+        }
+        cv_.notify_all();
+        run_chunk();
+        std::unique_lock<std::mutex> l(m_);
+        done_cv_.wait(l, [this] { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+    unsigned size() const { return (unsigned)workers_.size() + 1; }
+
+private:
+    void run_chunk()
+    {
+        for (;;) {
+            const uint32_t i = next_.fetch_add(1);
+            if (i >= count_) break;
+            (*fn_)(i);
+        }
+    }
+    void loop()
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> l(m_);
+                cv_.wait(l, [&] { return stop_ || gen_ != seen; });
+                if (stop_) return;
+                seen = gen_;
+            }
+            run_chunk();
+            {
+                std::lock_guard<std::mutex> l(m_);
+                if (--pending_ == 0) done_cv_.notify_all();
+            }
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex m_;
+    std::condition_variable cv_, done_cv_;
+    bool stop_;
+    const std::function<void(uint32_t)> *fn_ = nullptr;
+    std::atomic<uint32_t> next_{ 0 };
+    uint32_t count_ = 0;
+    unsigned pending_;
+    uint64_t gen_ = 0;
+};
+
+/* ---- one job: a range of whole windows -------------------------------------------------- */
+struct Group {
+    uint32_t nfft, first, count;
+    int rclass;
+    SrlaLdsPlan plan;
+};
+
+struct Job {
+    uint32_t s0 = 0, ns = 0;          /* sample range inside the stream */
+    std::vector<SrlaWindowDesc> windows;
+    std::vector<SrlaCandDesc> cands;
+    std::vector<SrlaItemDesc> items;
+    std::vector<Group> groups;
+    uint32_t num_slots = 0;
+    uint64_t res_elems = 0;
+    uint64_t analyzed_samples = 0;
+};
+
+struct Slot {
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[8] = {};
+    DevBuf d_input, d_items, d_cands, d_windows, d_results, d_res_ws, d_blocks, d_cand_bytes, d_out, d_chan, d_dbg;
+    PinBuf h_in, h_out, h_blocks, h_chan;
+    Job job;
+    bool busy = false;
+    bool used_h2d = false;
+};
+
+}  // namespace
+
+struct Impl {
+    SRLAEncoderConfig cfg{};
+    SRLAEncodeParameter par{};
+    bool set_parameter = false;
+    uint32_t offset_lshift = 0;       /* encoder->header.offset_lshift of the reference */
+    uint32_t pack_threads = 0;
+
+    bool dev_ready = false, dev_failed = false;
+    Slot slot[2];
+    DevBuf d_tw, d_geoms, d_thr, d_huff, d_or;
+    std::map<uint32_t, uint32_t> tw_index;   /* nfft -> offset (double2) */
+    std::vector<double> tw_host;
+    bool tw_dirty = false;
+    std::map<uint32_t, uint32_t> geom_index; /* n -> index */
+    std::vector<SrlaGeom> geoms;
+    bool geom_dirty = false;
+    Pool *pool = nullptr;
+    SRLAMI355XStats stats{};
+
+    ~Impl()
+    {
+        delete pool;
+        if (dev_ready) {
+            (void)hipSetDevice(g_device_index);
+            for (auto &s : slot) {
+                if (s.stream) (void)hipStreamSynchronize(s.stream);
+                for (auto &e : s.ev) if (e) (void)hipEventDestroy(e);
+                DevBuf *db[] = { &s.d_input, &s.d_items, &s.d_cands, &s.d_windows, &s.d_results, &s.d_res_ws,
+                                 &s.d_blocks, &s.d_cand_bytes, &s.d_out, &s.d_chan, &s.d_dbg };
+                for (auto *b : db) b->release();
+                PinBuf *pb[] = { &s.h_in, &s.h_out, &s.h_blocks, &s.h_chan };
+                for (auto *b : pb) b->release();
+                if (s.stream) (void)hipStreamDestroy(s.stream);
+            }
+            d_tw.release(); d_geoms.release(); d_thr.release(); d_huff.release(); d_or.release();
+        }
+    }
+
+    uint32_t preset_order() const { return kPresetOrder[par.preset]; }
+    uint32_t num_variants() const { return par.num_channels + (par.num_channels >= 2 ? 2u : 0u); }
+    bool search_enabled() const { return par.min_num_samples_per_block != par.max_num_samples_per_block; }
+
+    bool init_device()
+    {
+        if (dev_ready) return true;
+        if (dev_failed) return false;
+        dev_failed = true;
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+            fprintf(stderr, "[srla-mi355x] no HIP device available: the MI355X encode path cannot run "
+                            "(there is no CPU fallback)\n");
+            return false;
+        }
+        HIP_OK(hipSetDevice(g_device_index));
+        for (auto &s : slot) {
+            HIP_OK(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+            for (auto &e : s.ev) HIP_OK(hipEventCreate(&e));
+        }
+        double thr[32];
+        srla::build_rice_thresholds(thr);
+        if (!d_thr.ensure(sizeof(thr))) return false;
+        HIP_OK(hipMemcpy(d_thr.p, thr, sizeof(thr), hipMemcpyHostToDevice));
+        uint8_t huff[512];
+        memcpy(huff, srla::huffman_plain_lengths(), 256);
+        memcpy(huff + 256, srla::huffman_summed_lengths(), 256);
+        if (!d_huff.ensure(sizeof(huff))) return false;
+        HIP_OK(hipMemcpy(d_huff.p, huff, sizeof(huff), hipMemcpyHostToDevice));
+        if (!d_or.ensure(64)) return false;
+        unsigned hw = std::thread::hardware_concurrency();
+        unsigned nthreads = pack_threads ? pack_threads : std::min(hw ? hw : 1u, 16u);
+        pool = new Pool(nthreads);
+        dev_failed = false;
+        dev_ready = true;
+        return true;
+    }
+
+    uint32_t geom_for(uint32_t n)
+    {
+        auto it = geom_index.find(n);
+        if (it != geom_index.end()) return it->second;
+        SrlaGeom g;
+        srla::fill_geom(n, &g);
+        auto tw = tw_index.find(g.nfft);
+        if (tw == tw_index.end()) {
+            const uint32_t off = (uint32_t)(tw_host.size() / 2);
+            tw_host.resize(tw_host.size() + 2 * (size_t)srla::twiddle_count(g.nfft));
+            srla::build_twiddles(g.nfft, tw_host.data() + 2 * (size_t)off);
+            tw = tw_index.emplace(g.nfft, off).first;
+            tw_dirty = true;
+        }
+        g.tw_off = tw->second;
+        const uint32_t idx = (uint32_t)geoms.size();
+        geoms.push_back(g);
+        geom_index.emplace(n, idx);
+        geom_dirty = true;
+        return idx;
+    }
+
+    /* tables are shared by both slots: wait for everything in flight before re-allocating them */
+    bool sync_tables()
+    {
+        if (!tw_dirty && !geom_dirty) return true;
+        for (auto &s : slot) HIP_OK(hipStreamSynchronize(s.stream));
+        if (tw_dirty) {
+            if (!d_tw.ensure(tw_host.size() * sizeof(double))) return false;
+            HIP_OK(hipMemcpy(d_tw.p, tw_host.data(), tw_host.size() * sizeof(double), hipMemcpyHostToDevice));
+            tw_dirty = false;
+        }
+        if (geom_dirty) {
+            if (!d_geoms.ensure(geoms.size() * sizeof(SrlaGeom))) return false;
+            HIP_OK(hipMemcpy(d_geoms.p, geoms.data(), geoms.size() * sizeof(SrlaGeom), hipMemcpyHostToDevice));
+            geom_dirty = false;
+        }
+        return true;
+    }
+
+    SrlaLdsPlan lds_plan(uint32_t nfft) const
+    {
+        const uint32_t pmax = preset_order();
+        const uint32_t y_bytes = 4 * nfft, fft_bytes = 8 * nfft;
+        const uint32_t lev_bytes = 8 * 5 * (pmax + 3);
+        uint32_t mp = 0;
+        while ((1u << (mp + 1)) <= nfft && mp < SRLA_MAX_PORDER) mp++;
+        const uint32_t means_bytes = 8 * (2u << mp);
+        auto al = [](uint32_t v) { return (v + 15u) & ~15u; };
+        SrlaLdsPlan p;
+        uint32_t off = 0;
+        p.y_off = off; off += al(std::max(y_bytes, 64u));
+        p.fft_off = off; off += al(std::max(fft_bytes, 64u));
+        if (fft_bytes >= lev_bytes) p.lev_off = p.fft_off;
+        else { p.lev_off = off; off += al(lev_bytes); }
+        if (fft_bytes >= y_bytes + means_bytes) p.means_off = p.fft_off + al(y_bytes);
+        else { p.means_off = off; off += al(means_bytes); }
+        p.small_off = off; off += srla_kernel_small_bytes();
+        p.total = off;
+        return p;
+    }
+
+    /* Candidate table of SearchOptimalBlockPartitions (srla_encoder.c:336-389) for the windows
+     * [first sample s0, s0+ns) of a stream; ns ends on a window boundary or at the stream end. */
+    void build_job(Job &job, uint32_t s0, uint32_t ns, bool search)
+    {
+        const uint32_t minb = par.min_num_samples_per_block, maxb = par.max_num_samples_per_block;
+        const uint32_t window_len = search ? par.num_lookahead_samples : maxb;
+        const uint32_t nv = num_variants(), pmax = preset_order();
+        job.s0 = s0; job.ns = ns;
+        job.windows.clear(); job.cands.clear(); job.items.clear(); job.groups.clear();
+        job.num_slots = 0; job.res_elems = 0; job.analyzed_samples = 0;
+
+        struct Pending { uint32_t cand; uint32_t nfft; };
+        std::vector<Pending> analysed;
+        for (uint32_t pos = 0; pos < ns;) {
+            const uint32_t wn = std::min(window_len, ns - pos);
+            SrlaWindowDesc wd{};
+            wd.sample_off = pos; wd.n = wn;
+            wd.cand_base = (uint32_t)job.cands.size();
+            wd.num_nodes = search ? ((wn + minb - 1) / minb + 1) : 2;
+            wd.block_base = job.num_slots;
+            job.num_slots += wd.num_nodes - 1;
+            const uint32_t w = (uint32_t)job.windows.size();
+            auto add_cand = [&](uint32_t i, uint32_t j, uint32_t off, uint32_t n) {
+                SrlaCandDesc cd{};
+                cd.window = w; cd.node_i = i; cd.node_j = j; cd.sample_off = pos + off; cd.n = n;
+                cd.item_base = 0xFFFFFFFFu;
+                if (n > pmax) analysed.push_back({ (uint32_t)job.cands.size(), geoms[geom_for(n)].nfft });
+                job.cands.push_back(cd);
+            };
+            if (!search) add_cand(0, 1, 0, wn);
+            else {
+                for (uint32_t i = 0; i < wd.num_nodes; i++)
+                    for (uint32_t j = i + 1; j < wd.num_nodes; j++) {
+                        uint32_t len = (j - i) * minb;
+                        if (len > maxb) continue;
+                        const uint32_t off = i * minb;
+                        len = std::min(len, wn - off);
+                        add_cand(i, j, off, len);
+                    }
+            }
+            wd.num_cands = (uint32_t)job.cands.size() - wd.cand_base;
+            job.windows.push_back(wd);
+            pos += wn;
+        }
+        /* items grouped by FFT size so that each launch has one LDS plan; big FFTs first */
+        std::stable_sort(analysed.begin(), analysed.end(), [](const Pending &a, const Pending &b) { return a.nfft > b.nfft; });
+        for (size_t k = 0; k < analysed.size();) {
+            Group g{};
+            g.nfft = analysed[k].nfft;
+            g.first = (uint32_t)job.items.size();
+            g.rclass = (int)std::max(1u, g.nfft / 2048u);
+            g.plan = lds_plan(g.nfft);
+            for (; k < analysed.size() && analysed[k].nfft == g.nfft; k++) {
+                SrlaCandDesc &cd = job.cands[analysed[k].cand];
+                cd.item_base = (uint32_t)job.items.size();
+                for (uint32_t v = 0; v < nv; v++) {
+                    SrlaItemDesc it{};
+                    it.sample_off = cd.sample_off; it.n = cd.n; it.variant = v;
+                    it.geom = geom_for(cd.n);
+                    it.res_off = job.res_elems;
+                    it.forced_order = -1;
+                    job.res_elems += (cd.n + 3u) & ~3u;
+                    job.analyzed_samples += cd.n;
+                    job.items.push_back(it);
+                }
+            }
+            g.count = (uint32_t)job.items.size() - g.first;
+            job.groups.push_back(g);
+        }
+    }
+
+    SrlaJobParams job_params(const Job &job, uint32_t channel_stride) const
+    {
+        SrlaJobParams jp{};
+        jp.num_channels = par.num_channels;
+        jp.bits_per_sample = par.bits_per_sample;
+        jp.offset_lshift = offset_lshift;
+        jp.max_order = preset_order();
+        jp.order_fixed = (par.preset == 0) ? 1u : 0u;
+        jp.ltp_order = par.ltp_order;
+        jp.num_samples = job.ns;
+        jp.channel_stride = channel_stride;
+        jp.max_block = par.max_num_samples_per_block;
+        jp.min_block = par.min_num_samples_per_block;
+        jp.num_items = (uint32_t)job.items.size();
+        jp.num_cands = (uint32_t)job.cands.size();
+        jp.num_windows = (uint32_t)job.windows.size();
+        jp.out_stride = job.ns;
+        return jp;
+    }
+
+    /* Enqueue one job on its slot's stream.  d_in: device pointer to channel 0 of the job's first
+     * sample, or nullptr to upload host_in (planar pointers, absolute stream positions). */
+    bool launch_job(Slot &s, const int32_t *d_in, uint32_t d_stride, const int32_t *const *host_in, bool want_dbg)
+    {
+        Job &job = s.job;
+        const uint32_t nch = par.num_channels;
+        if (!sync_tables()) return false;
+        const size_t n_items = job.items.size(), n_cands = job.cands.size(), n_win = job.windows.size();
+        if (!s.d_items.ensure(std::max<size_t>(1, n_items) * sizeof(SrlaItemDesc))) return false;
+        if (!s.d_cands.ensure(n_cands * sizeof(SrlaCandDesc))) return false;
+        if (!s.d_windows.ensure(n_win * sizeof(SrlaWindowDesc))) return false;
+        if (!s.d_results.ensure(std::max<size_t>(1, n_items) * sizeof(SrlaItemResult))) return false;
+        if (!s.d_res_ws.ensure(std::max<uint64_t>(4, job.res_elems) * 4)) return false;
+        if (!s.d_blocks.ensure((size_t)job.num_slots * sizeof(SrlaBlockRecord))) return false;
+        if (!s.d_cand_bytes.ensure(n_cands * 4)) return false;
+        if (!s.d_out.ensure((size_t)nch * job.ns * 4)) return false;
+        if (!s.d_chan.ensure((size_t)job.num_slots * nch * sizeof(SrlaItemResult))) return false;
+        if (!s.h_out.ensure((size_t)nch * job.ns * 4)) return false;
+        if (!s.h_blocks.ensure((size_t)job.num_slots * sizeof(SrlaBlockRecord))) return false;
+        if (!s.h_chan.ensure((size_t)job.num_slots * nch * sizeof(SrlaItemResult))) return false;
+        if (want_dbg && !s.d_dbg.ensure(std::max<size_t>(1, n_items) * SRLA_DBG_STRIDE * sizeof(double))) return false;
+
+        HIP_OK(hipEventRecord(s.ev[0], s.stream));
+        uint32_t stride = d_stride;
+        s.used_h2d = false;
+        if (!d_in) {
+            if (!s.h_in.ensure((size_t)nch * job.ns * 4) || !s.d_input.ensure((size_t)nch * job.ns * 4)) return false;
+            for (uint32_t ch = 0; ch < nch; ch++)
+                memcpy(s.h_in.as<int32_t>() + (size_t)ch * job.ns, host_in[ch] + job.s0, (size_t)job.ns * 4);
+            HIP_OK(hipMemcpyAsync(s.d_input.p, s.h_in.p, (size_t)nch * job.ns * 4, hipMemcpyHostToDevice, s.stream));
+            d_in = s.d_input.as<int32_t>();
+            stride = job.ns;
+            s.used_h2d = true;
+        }
+        if (n_items) HIP_OK(hipMemcpyAsync(s.d_items.p, job.items.data(), n_items * sizeof(SrlaItemDesc), hipMemcpyHostToDevice, s.stream));
+        HIP_OK(hipMemcpyAsync(s.d_cands.p, job.cands.data(), n_cands * sizeof(SrlaCandDesc), hipMemcpyHostToDevice, s.stream));
+        HIP_OK(hipMemcpyAsync(s.d_windows.p, job.windows.data(), n_win * sizeof(SrlaWindowDesc), hipMemcpyHostToDevice, s.stream));
+        HIP_OK(hipEventRecord(s.ev[1], s.stream));
+
+        const SrlaJobParams jp = job_params(job, stride);
+        for (const Group &g : job.groups) {
+            if (srla_launch_analyze(s.stream, g.rclass, g.count, &jp, d_in, s.d_items.as<SrlaItemDesc>(), g.first,
+                                    d_geoms.as<SrlaGeom>(), d_tw.p, &g.plan, d_thr.as<double>(), d_huff.as<uint8_t>(),
+                                    s.d_res_ws.as<int32_t>(), s.d_results.as<SrlaItemResult>(),
+                                    want_dbg ? s.d_dbg.as<double>() : nullptr) != 0) {
+                fprintf(stderr, "[srla-mi355x] item analysis launch failed (nfft %u)\n", g.nfft);
+                return false;
+            }
+            stats.analyze_launches++;
+        }
+        HIP_OK(hipEventRecord(s.ev[2], s.stream));
+        if (srla_launch_price(s.stream, &jp, s.d_windows.as<SrlaWindowDesc>(), s.d_cands.as<SrlaCandDesc>(),
+                              s.d_results.as<SrlaItemResult>(), s.d_blocks.as<SrlaBlockRecord>(),
+                              s.d_cand_bytes.as<uint32_t>()) != 0) return false;
+        HIP_OK(hipEventRecord(s.ev[3], s.stream));
+        if (srla_launch_gather(s.stream, &jp, job.num_slots, d_in, s.d_items.as<SrlaItemDesc>(),
+                               s.d_blocks.as<SrlaBlockRecord>(), s.d_results.as<SrlaItemResult>(),
+                               s.d_res_ws.as<int32_t>(), s.d_out.as<int32_t>(), s.d_chan.as<SrlaItemResult>()) != 0) return false;
+        HIP_OK(hipEventRecord(s.ev[4], s.stream));
+        HIP_OK(hipMemcpyAsync(s.h_out.p, s.d_out.p, (size_t)nch * job.ns * 4, hipMemcpyDeviceToHost, s.stream));
+        HIP_OK(hipMemcpyAsync(s.h_blocks.p, s.d_blocks.p, (size_t)job.num_slots * sizeof(SrlaBlockRecord), hipMemcpyDeviceToHost, s.stream));
+        HIP_OK(hipMemcpyAsync(s.h_chan.p, s.d_chan.p, (size_t)job.num_slots * nch * sizeof(SrlaItemResult), hipMemcpyDeviceToHost, s.stream));
+        HIP_OK(hipEventRecord(s.ev[5], s.stream));
+        s.busy = true;
+        stats.num_windows += n_win; stats.num_candidates += n_cands; stats.num_items += n_items;
+        stats.analyzed_samples += job.analyzed_samples;
+        return true;
+    }
+
+    bool wait_job(Slot &s)
+    {
+        HIP_OK(hipStreamSynchronize(s.stream));
+        float t = 0;
+        if (hipEventElapsedTime(&t, s.ev[0], s.ev[1]) == hipSuccess) stats.h2d_ms += t;
+        if (hipEventElapsedTime(&t, s.ev[1], s.ev[2]) == hipSuccess) stats.analyze_ms += t;
+        if (hipEventElapsedTime(&t, s.ev[2], s.ev[3]) == hipSuccess) stats.price_ms += t;
+        if (hipEventElapsedTime(&t, s.ev[3], s.ev[4]) == hipSuccess) stats.gather_ms += t;
+        if (hipEventElapsedTime(&t, s.ev[4], s.ev[5]) == hipSuccess) stats.d2h_ms += t;
+        s.busy = false;
+        return true;
+    }
+
+    /* Pack every window of a finished job into `data` (stream order); returns false when the
+     * output buffer is too small.  window_bytes[w] receives the size of window w. */
+    SRLAApiResult pack_job(Slot &s, const srla::StreamInfo &si, uint8_t *data, uint32_t data_size,
+                           uint32_t *written, std::vector<uint32_t> &window_bytes)
+    {
+        const auto t0 = Clock::now();
+        const Job &job = s.job;
+        const uint32_t nch = par.num_channels;
+        const SrlaBlockRecord *blocks = s.h_blocks.as<SrlaBlockRecord>();
+        const SrlaItemResult *chan = s.h_chan.as<SrlaItemResult>();
+        const int32_t *out = s.h_out.as<int32_t>();
+        struct Todo { uint32_t slot; uint32_t off; };
+        std::vector<Todo> todo;
+        todo.reserve(job.num_slots);
+        window_bytes.assign(job.windows.size(), 0);
+        uint64_t total = 0;
+        for (size_t w = 0; w < job.windows.size(); w++) {
+            const SrlaWindowDesc &wd = job.windows[w];
+            uint32_t covered = 0;
+            for (uint32_t k = 0; k + 1 < wd.num_nodes; k++) {
+                const SrlaBlockRecord &br = blocks[wd.block_base + k];
+                if (!br.valid) break;
+                todo.push_back({ wd.block_base + k, (uint32_t)total });
+                total += br.bytes;
+                window_bytes[w] += br.bytes;
+                covered += br.n;
+            }
+            if (covered != wd.n) {
+                fprintf(stderr, "[srla-mi355x] internal error: window %zu partition covers %u of %u samples\n", w, covered, wd.n);
+                return SRLA_APIRESULT_NG;
+            }
+        }
+        if (total > data_size) return SRLA_APIRESULT_INSUFFICIENT_BUFFER;
+        std::atomic<int> bad{ 0 };
+        std::atomic<uint64_t> raw{ 0 }, silent{ 0 }, ties{ 0 }, odd{ 0 };
+        pool->parallel_for((uint32_t)todo.size(), [&](uint32_t i) {
+            const SrlaBlockRecord &br = blocks[todo[i].slot];
+            const int32_t *ptr[SRLA_MAX_CH];
+            for (uint32_t ch = 0; ch < nch; ch++) ptr[ch] = out + (size_t)ch * job.ns + br.sample_off;
+            const SrlaItemResult *recs = chan + (size_t)todo[i].slot * nch;
+            const uint32_t sz = srla::pack_block(si, br, recs, ptr, data + todo[i].off);
+            if (sz != br.bytes) bad.fetch_add(1);
+            if (br.block_type == SRLA_BLOCK_RAW) raw.fetch_add(1);
+            else if (br.block_type == SRLA_BLOCK_SILENT) silent.fetch_add(1);
+            else for (uint32_t ch = 0; ch < nch; ch++) {
+                if (recs[ch].flags & SRLA_ITEM_ORDER_TIE) ties.fetch_add(1);
+                if (recs[ch].flags & SRLA_ITEM_ODD_LENGTH) odd.fetch_add(1);
+            }
+        });
+        stats.num_blocks += todo.size(); stats.num_raw_blocks += raw; stats.num_silent_blocks += silent;
+        stats.num_tie_items += ties; stats.num_odd_items += odd;
+        stats.pack_ms += ms_since(t0);
+        if (bad.load() != 0) {
+            fprintf(stderr, "[srla-mi355x] internal error: %d packed block(s) differ from their computed size\n", bad.load());
+            return SRLA_APIRESULT_NG;
+        }
+        *written = (uint32_t)total;
+        return SRLA_APIRESULT_OK;
+    }
+
+    srla::StreamInfo stream_info(uint32_t num_samples) const
+    {
+        srla::StreamInfo si;
+        si.num_channels = par.num_channels; si.bits_per_sample = par.bits_per_sample;
+        si.sampling_rate = par.sampling_rate; si.num_samples = num_samples; si.offset_lshift = offset_lshift;
+        si.max_block = par.max_num_samples_per_block; si.preset = par.preset; si.ltp_order = par.ltp_order;
+        return si;
+    }
+
+    /* windows per job: bounded by scratch memory (~1.5 GB of residual scratch per slot) */
+    uint32_t windows_per_job(bool search) const
+    {
+        const uint32_t window_len = search ? par.num_lookahead_samples : par.max_num_samples_per_block;
+        uint64_t per_window = (uint64_t)window_len * num_variants() * 4;
+        if (search) {
+            const uint32_t ratio = par.max_num_samples_per_block / par.min_num_samples_per_block;
+            per_window *= ratio;
+        }
+        uint64_t w = (1536ull << 20) / std::max<uint64_t>(per_window, 1);
+        const uint64_t cap_samples = 2ull << 20;   /* ~2M samples per job: several jobs per stream so that the
+                                                    * GPU (job k+1) and the host pack (job k) overlap */
+        w = std::min<uint64_t>(w, std::max<uint64_t>(1, cap_samples / window_len));
+        return (uint32_t)std::max<uint64_t>(1, w);
+    }
+
+    /* The body shared by EncodeWhole (host input) and EncodeWholeDevice. */
+    SRLAApiResult encode_stream(const int32_t *const *host_in, const int32_t *d_in, uint32_t d_stride,
+                                uint32_t num_samples, uint8_t *data, uint32_t data_size, uint32_t *output_size,
+                                SRLAEncoder_EncodeBlockCallback cb, bool with_header, bool search)
+    {
+        const auto t0 = Clock::now();
+        const uint32_t nch = par.num_channels;
+        uint32_t write_off = 0;
+        if (with_header) {
+            /* offset left shift: OR of every sample (srla_utility.c:177-203) */
+            uint32_t mask = 0;
+            if (host_in) {
+                for (uint32_t ch = 0; ch < nch; ch++) {
+                    const int32_t *p = host_in[ch];
+                    uint32_t m = 0;
+                    for (uint32_t i = 0; i < num_samples; i++) m |= (uint32_t)p[i];
+                    mask |= m;
+                }
+            } else {
+                Slot &s = slot[0];
+                if (hipMemsetAsync(d_or.p, 0, 4, s.stream) != hipSuccess) return SRLA_APIRESULT_NG;
+                for (uint32_t ch = 0; ch < nch; ch++)
+                    if (srla_launch_or_reduce(s.stream, d_in + (size_t)ch * d_stride, num_samples, d_or.as<uint32_t>()) != 0) return SRLA_APIRESULT_NG;
+                if (hipMemcpyAsync(&mask, d_or.p, 4, hipMemcpyDeviceToHost, s.stream) != hipSuccess) return SRLA_APIRESULT_NG;
+                if (hipStreamSynchronize(s.stream) != hipSuccess) return SRLA_APIRESULT_NG;
+            }
+            uint32_t sh = 0;
+            if (mask != 0) while (((mask >> sh) & 1u) == 0) sh++;
+            offset_lshift = sh;
+            srla::write_stream_header(stream_info(num_samples), data);
+            write_off = SRLA_HEADER_SIZE;
+        }
+        const srla::StreamInfo si = stream_info(num_samples);
+        const uint32_t window_len = search ? par.num_lookahead_samples : par.max_num_samples_per_block;
+        const uint32_t wpj = windows_per_job(search);
+        const uint64_t job_len = (uint64_t)wpj * window_len;
+        const uint32_t njobs = (uint32_t)((num_samples + job_len - 1) / job_len);
+        std::vector<uint32_t> window_bytes;
+        uint32_t progress = 0;
+
+        auto start = [&](uint32_t k) -> bool {
+            Slot &s = slot[k & 1];
+            const uint32_t s0 = (uint32_t)((uint64_t)k * job_len);
+            const uint32_t ns = (uint32_t)std::min<uint64_t>(job_len, num_samples - s0);
+            build_job(s.job, s0, ns, search);
+            return launch_job(s, d_in ? d_in + s0 : nullptr, d_stride, host_in, false);
+        };
+        if (!start(0)) return SRLA_APIRESULT_NG;
+        for (uint32_t k = 0; k < njobs; k++) {
+            if (k + 1 < njobs && !start(k + 1)) return SRLA_APIRESULT_NG;
+            Slot &s = slot[k & 1];
+            if (!wait_job(s)) return SRLA_APIRESULT_NG;
+            uint32_t wrote = 0;
+            const SRLAApiResult rc = pack_job(s, si, data + write_off, data_size - write_off, &wrote, window_bytes);
+            if (rc != SRLA_APIRESULT_OK) {
+                for (auto &sl : slot) if (sl.busy) { (void)hipStreamSynchronize(sl.stream); sl.busy = false; }
+                return rc;
+            }
+            /* callbacks: once per window, in order, pointing into the caller's buffer
+             * (srla_encoder.c:1779-1782) */
+            uint32_t off = write_off;
+            for (size_t w = 0; w < s.job.windows.size(); w++) {
+                progress += s.job.windows[w].n;
+                if (cb) cb(num_samples, progress, data + off, window_bytes[w]);
+                off += window_bytes[w];
+            }
+            write_off += wrote;
+        }
+        *output_size = write_off;
+        stats.total_ms += ms_since(t0);
+        return SRLA_APIRESULT_OK;
+    }
+};
+
+/* ============================================================================================
+ * C ABI
+ * ========================================================================================== */
+namespace {
+
+int32_t work_size_of(const SRLAEncoderConfig *config)
+{
+    /* validity rules of srla_encoder.c:468-496 */
+    if (config == NULL) return -1;
+    if (config->max_num_samples_per_block == 0 || config->min_num_samples_per_block == 0
+        || config->max_num_lookahead_samples == 0 || config->max_num_channels == 0) return -1;
+    if (config->max_num_parameters > config->max_num_samples_per_block) return -1;
+    if (config->min_num_samples_per_block > config->max_num_samples_per_block) return -1;
+    if (config->max_num_lookahead_samples < config->max_num_samples_per_block) return -1;
+    return (int32_t)(sizeof(SRLAEncoder) + 16);
+}
+
+Impl *impl_of(SRLAEncoder *e) { return (e && e->magic == SRLA_HANDLE_MAGIC) ? e->impl : nullptr; }
+
+}  // namespace
+
+extern "C" {
+
+const char *SRLAMI355X_Version(void) { return "srla-mi355x 0.1 (gfx950 HIP; SRLA codec 18 / format 10)"; }
+
+int SRLAMI355X_SetDevice(int device_index)
+{
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device_index < 0 || device_index >= count) return -1;
+    g_device_index = device_index;
+    return (hipSetDevice(device_index) == hipSuccess) ? 0 : -1;
+}
+
+SRLAApiResult SRLAEncoder_EncodeHeader(const struct SRLAHeader *header, uint8_t *data, uint32_t data_size)
+{
+    /* srla_encoder.c:85-165 */
+    if (header == NULL || data == NULL) return SRLA_APIRESULT_INVALID_ARGUMENT;
+    if (data_size < SRLA_HEADER_SIZE) return SRLA_APIRESULT_INSUFFICIENT_BUFFER;
+    if (header->num_channels == 0 || header->num_samples == 0 || header->sampling_rate == 0
+        || header->bits_per_sample == 0 || header->offset_lshift >= 32 || header->max_num_samples_per_block == 0
+        || header->preset >= SRLA_NUM_PARAMETER_PRESETS) return SRLA_APIRESULT_INVALID_FORMAT;
+    srla::StreamInfo si;
+    si.num_channels = header->num_channels; si.bits_per_sample = header->bits_per_sample;
+    si.sampling_rate = header->sampling_rate; si.num_samples = header->num_samples;
+    si.offset_lshift = header->offset_lshift; si.max_block = header->max_num_samples_per_block;
+    si.preset = header->preset; si.ltp_order = 0;
+    srla::write_stream_header(si, data);
+    return SRLA_APIRESULT_OK;
+}
+
+int32_t SRLAEncoder_CalculateWorkSize(const struct SRLAEncoderConfig *config) { return work_size_of(config); }
+
+struct SRLAEncoder *SRLAEncoder_Create(const struct SRLAEncoderConfig *config, void *work, int32_t work_size)
+{
+    /* srla_encoder.c:549-694 */
+    uint8_t own = 0;
+    if (work == NULL && work_size == 0) {
+        if ((work_size = work_size_of(config)) < 0) return NULL;
+        work = malloc((size_t)work_size);
+        own = 1;
+    }
+    if (config == NULL || work == NULL || work_size < work_size_of(config) || work_size_of(config) < 0) {
+        if (own) free(work);
+        return NULL;
+    }
+    SRLAEncoder *e = reinterpret_cast<SRLAEncoder *>(((uintptr_t)work + 15u) & ~(uintptr_t)15u);
+    e->magic = SRLA_HANDLE_MAGIC;
+    e->alloced_by_own = own;
+    e->work = work;
+    e->impl = new Impl();
+    e->impl->cfg = *config;
+    return e;
+}
+
+void SRLAEncoder_Destroy(struct SRLAEncoder *encoder)
+{
+    if (encoder == NULL || encoder->magic != SRLA_HANDLE_MAGIC) return;
+    delete encoder->impl;
+    encoder->impl = nullptr;
+    encoder->magic = 0;
+    if (encoder->alloced_by_own) free(encoder->work);
+}
+
+SRLAApiResult SRLAEncoder_SetEncodeParameter(struct SRLAEncoder *encoder, const struct SRLAEncodeParameter *p)
+{
+    /* srla_encoder.c:710-763 */
+    Impl *im = impl_of(encoder);
+    if (im == nullptr || p == NULL) return SRLA_APIRESULT_INVALID_ARGUMENT;
+    if (p->num_channels == 0 || p->bits_per_sample == 0 || p->sampling_rate == 0
+        || p->preset >= SRLA_NUM_PARAMETER_PRESETS) return SRLA_APIRESULT_INVALID_FORMAT;
+    if (p->min_num_samples_per_block == 0) return SRLA_APIRESULT_INVALID_FORMAT; /* the reference divides by it */
+    if (p->min_num_samples_per_block > p->max_num_samples_per_block
+        || p->num_lookahead_samples < p->max_num_samples_per_block
+        || (p->num_lookahead_samples % p->min_num_samples_per_block) != 0
+        || (p->ltp_order > 0 && (p->ltp_order % 2) == 0) || p->ltp_order > SRLA_MAX_LTP_ORDER)
+        return SRLA_APIRESULT_INVALID_FORMAT;
+    if (im->cfg.max_num_samples_per_block < p->max_num_samples_per_block
+        || im->cfg.min_num_samples_per_block > p->min_num_samples_per_block
+        || im->cfg.max_num_lookahead_samples < p->num_lookahead_samples
+        || im->cfg.max_num_channels < p->num_channels) return SRLA_APIRESULT_INSUFFICIENT_BUFFER;
+    /* limits of this implementation (documented in DESIGN.md) */
+    if (p->num_channels > SRLA_MAX_CH) return SRLA_APIRESULT_INSUFFICIENT_BUFFER;
+    if (p->max_num_samples_per_block > SRLA_MAX_FFT) {
+        fprintf(stderr, "[srla-mi355x] max block size %u exceeds the LDS-resident FFT limit of %u samples\n",
+                p->max_num_samples_per_block, SRLA_MAX_FFT);
+        return SRLA_APIRESULT_INSUFFICIENT_BUFFER;
+    }
+    if (p->num_lookahead_samples / p->min_num_samples_per_block + 1 > SRLA_MAX_NODES) {
+        fprintf(stderr, "[srla-mi355x] look-ahead / min block = %u exceeds %u search nodes\n",
+                p->num_lookahead_samples / p->min_num_samples_per_block, SRLA_MAX_NODES - 1);
+        return SRLA_APIRESULT_INSUFFICIENT_BUFFER;
+    }
+    if (p->bits_per_sample != 8 && p->bits_per_sample != 16 && p->bits_per_sample != 24) return SRLA_APIRESULT_INVALID_FORMAT;
+    if (p->num_svr_filter_learning_iteration != 0) {
+        fprintf(stderr, "[srla-mi355x] SVR coefficient refinement (--svr-filter-learning-iteration) is outside the "
+                        "accelerated path and is not implemented\n");
+        return SRLA_APIRESULT_NG;
+    }
+    im->par = *p;
+    im->offset_lshift = 0;
+    im->set_parameter = true;
+    return SRLA_APIRESULT_OK;
+}
+
+static SRLAApiResult single_window(Impl *im, const int32_t *const *input, uint32_t num_samples, bool search,
+                                   uint8_t *data, uint32_t data_size, uint32_t *output_size, bool size_only)
+{
+    if (!im->init_device()) return SRLA_APIRESULT_NG;
+    if (!size_only)
+        return im->encode_stream(input, nullptr, 0, num_samples, data, data_size, output_size, nullptr, false, search);
+    /* ComputeBlockSize: run the job, read the block record, skip the pack */
+    Slot &s = im->slot[0];
+    im->build_job(s.job, 0, num_samples, false);
+    if (!im->launch_job(s, nullptr, 0, input, false) || !im->wait_job(s)) return SRLA_APIRESULT_NG;
+    const SrlaBlockRecord &br = s.h_blocks.as<SrlaBlockRecord>()[0];
+    if (!br.valid) return SRLA_APIRESULT_NG;
+    *output_size = br.bytes;
+    return SRLA_APIRESULT_OK;
+}
+
+SRLAApiResult SRLAEncoder_ComputeBlockSize(struct SRLAEncoder *encoder, const int32_t *const *input,
+                                           uint32_t num_samples, uint32_t *output_size)
+{
+    /* srla_encoder.c:1477-1546 */
+    Impl *im = impl_of(encoder);
+    if (im == nullptr || input == NULL || num_samples == 0 || output_size == NULL) return SRLA_APIRESULT_INVALID_ARGUMENT;
+    if (!im->set_parameter) return SRLA_APIRESULT_PARAMETER_NOT_SET;
+    if (num_samples > im->par.max_num_samples_per_block) return SRLA_APIRESULT_INSUFFICIENT_BUFFER;
+    return single_window(im, input, num_samples, false, nullptr, 0, output_size, true);
+}
+
+SRLAApiResult SRLAEncoder_EncodeBlock(struct SRLAEncoder *encoder, const int32_t *const *input, uint32_t num_samples,
+                                      uint8_t *data, uint32_t data_size, uint32_t *output_size)
+{
+    /* srla_encoder.c:1549-1643 */
+    Impl *im = impl_of(encoder);
+    if (im == nullptr || input == NULL || num_samples == 0 || data == NULL || data_size == 0 || output_size == NULL)
+        return SRLA_APIRESULT_INVALID_ARGUMENT;
+    if (!im->set_parameter) return SRLA_APIRESULT_PARAMETER_NOT_SET;
+    if (num_samples > im->par.max_num_samples_per_block) return SRLA_APIRESULT_INSUFFICIENT_BUFFER;
+    return single_window(im, input, num_samples, false, data, data_size, output_size, false);
+}
+
+SRLAApiResult SRLAEncoder_EncodeOptimalPartitionedBlock(struct SRLAEncoder *encoder, const int32_t *const *input,
+                                                        uint32_t num_samples, uint8_t *data, uint32_t data_size,
+                                                        uint32_t *output_size)
+{
+    /* srla_encoder.c:1646-1698 */
+    Impl *im = impl_of(encoder);
+    if (im == nullptr || input == NULL || data == NULL || output_size == NULL) return SRLA_APIRESULT_INVALID_ARGUMENT;
+    if (!im->set_parameter) return SRLA_APIRESULT_PARAMETER_NOT_SET;
+    if (num_samples == 0 || num_samples > im->par.num_lookahead_samples) return SRLA_APIRESULT_NG;
+    return single_window(im, input, num_samples, true, data, data_size, output_size, false);
+}
+
+SRLAApiResult SRLAEncoder_EncodeWhole(struct SRLAEncoder *encoder, const int32_t *const *input, uint32_t num_samples,
+                                      uint8_t *data, uint32_t data_size, uint32_t *output_size,
+                                      SRLAEncoder_EncodeBlockCallback encode_callback)
+{
+    /* srla_encoder.c:1701-1788 */
+    Impl *im = impl_of(encoder);
+    if (im == nullptr || input == NULL || data == NULL || output_size == NULL) return SRLA_APIRESULT_INVALID_ARGUMENT;
+    if (!im->set_parameter) return SRLA_APIRESULT_PARAMETER_NOT_SET;
+    if (data_size < SRLA_HEADER_SIZE) return SRLA_APIRESULT_INSUFFICIENT_BUFFER;
+    if (num_samples == 0) return SRLA_APIRESULT_INVALID_FORMAT;
+    if (!im->init_device()) return SRLA_APIRESULT_NG;
+    return im->encode_stream(input, nullptr, 0, num_samples, data, data_size, output_size, encode_callback, true,
+                             im->search_enabled());
+}
+
+SRLAApiResult SRLAMI355X_EncodeWholeDevice(struct SRLAEncoder *encoder, const int32_t *d_input, uint32_t channel_stride,
+                                           uint32_t num_samples, uint8_t *data, uint32_t data_size, uint32_t *output_size,
+                                           SRLAEncoder_EncodeBlockCallback encode_callback)
+{
+    Impl *im = impl_of(encoder);
+    if (im == nullptr || d_input == NULL || data == NULL || output_size == NULL || channel_stride < num_samples)
+        return SRLA_APIRESULT_INVALID_ARGUMENT;
+    if (!im->set_parameter) return SRLA_APIRESULT_PARAMETER_NOT_SET;
+    if (data_size < SRLA_HEADER_SIZE) return SRLA_APIRESULT_INSUFFICIENT_BUFFER;
+    if (num_samples == 0) return SRLA_APIRESULT_INVALID_FORMAT;
+    if (!im->init_device()) return SRLA_APIRESULT_NG;
+    return im->encode_stream(nullptr, d_input, channel_stride, num_samples, data, data_size, output_size,
+                             encode_callback, true, im->search_enabled());
+}
+
+void SRLAMI355X_SetPackThreads(struct SRLAEncoder *encoder, uint32_t num_threads)
+{
+    Impl *im = impl_of(encoder);
+    if (!im) return;
+    im->pack_threads = num_threads;
+    if (im->pool) { delete im->pool; im->pool = new Pool(num_threads ? num_threads : 1); }
+}
+
+void SRLAMI355X_GetStats(struct SRLAEncoder *encoder, struct SRLAMI355XStats *stats, int reset)
+{
+    Impl *im = impl_of(encoder);
+    if (!im) return;
+    if (stats) *stats = im->stats;
+    if (reset) memset(&im->stats, 0, sizeof(im->stats));
+}
+
+SRLAApiResult SRLAMI355X_ProbeBlock(struct SRLAEncoder *encoder, const int32_t *const *input, uint32_t num_samples,
+                                    void *records, int32_t *residuals, double *debug)
+{
+    Impl *im = impl_of(encoder);
+    if (im == nullptr || input == NULL || num_samples == 0) return SRLA_APIRESULT_INVALID_ARGUMENT;
+    if (!im->set_parameter) return SRLA_APIRESULT_PARAMETER_NOT_SET;
+    if (num_samples > im->par.max_num_samples_per_block) return SRLA_APIRESULT_INSUFFICIENT_BUFFER;
+    if (num_samples <= im->preset_order()) return SRLA_APIRESULT_INVALID_ARGUMENT; /* RAW by length: nothing to analyse */
+    if (!im->init_device()) return SRLA_APIRESULT_NG;
+    Slot &s = im->slot[0];
+    im->build_job(s.job, 0, num_samples, false);
+    if (!im->launch_job(s, nullptr, 0, input, true) || !im->wait_job(s)) return SRLA_APIRESULT_NG;
+    const uint32_t nv = im->num_variants();
+    if (records && hipMemcpy(records, s.d_results.p, (size_t)nv * sizeof(SrlaItemResult), hipMemcpyDeviceToHost) != hipSuccess)
+        return SRLA_APIRESULT_NG;
+    if (debug && hipMemcpy(debug, s.d_dbg.p, (size_t)nv * SRLA_DBG_STRIDE * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+        return SRLA_APIRESULT_NG;
+    if (residuals) {
+        for (uint32_t v = 0; v < nv; v++)
+            if (hipMemcpy(residuals + (size_t)v * num_samples, s.d_res_ws.as<int32_t>() + s.job.items[v].res_off,
+                          (size_t)num_samples * 4, hipMemcpyDeviceToHost) != hipSuccess) return SRLA_APIRESULT_NG;
+    }
+    return SRLA_APIRESULT_OK;
+}
+
+}  /* extern "C" */
