@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py -- encode throughput of the MI355X SRLA path on BASELINE.json's metric configuration.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Workload (config.workload): `srla -e -m 4 -B 4096` with the CLI defaults -V 1 -L 4 -P 0 on synthetic
+48 kHz / 16-bit stereo PCM (tools/synth, kind "music"), `--seconds` of audio per GPU per step.
+
+A step is one complete encode of that batch: the planar int32 samples are already resident in HBM when
+the timed region starts (SRLAMI355X_EncodeWholeDevice); the step covers the offset-shift reduction, the
+item-analysis / pricing / gather kernels, the D2H of residuals and parameters and the multi-threaded host
+bit pack, and ends with the complete .srl stream in host memory.  Every rank encodes its own batch
+(frames shard embarrassingly: no collective on the data path), so scaling is weak; value = total sample
+instants (per channel) encoded by all ranks / max-over-ranks time.
+
+Extra objects on the JSON line:
+  roofline      dominant kernel (srla_analyze_items): algorithmic bytes = 16 B per stereo sample instant
+                 x instants per launch, over the launch duration measured with HIP events on
+                the launch stream inside the timed region; peak = 8000 GB/s HBM3E.
+  cpu_baseline  the compiled reference (oracle/_ref, "reference") or the oracle ("port") timed on ONE host
+                core on a bounded sample of the same workload.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+
+
+class Stats(C.Structure):
+    _fields_ = [("num_windows", C.c_uint64), ("num_candidates", C.c_uint64), ("num_items", C.c_uint64),
+                ("num_blocks", C.c_uint64), ("num_raw_blocks", C.c_uint64), ("num_silent_blocks", C.c_uint64),
+                ("num_tie_items", C.c_uint64), ("num_odd_items", C.c_uint64), ("analyze_launches", C.c_uint64),
+                ("analyze_ms", C.c_double), ("price_ms", C.c_double), ("gather_ms", C.c_double),
+                ("h2d_ms", C.c_double), ("d2h_ms", C.c_double), ("pack_ms", C.c_double), ("total_ms", C.c_double),
+                ("analyzed_samples", C.c_uint64)]
+
+
+def cpu_baseline(pcm, cli, seconds, rate):
+    """Single-thread CPU encode of the first `seconds` of the workload (reference if it travelled here)."""
+    import helpers
+    from srla_amd import capi
+    n = min(pcm.shape[1], int(seconds * rate))
+    clip = np.ascontiguousarray(pcm[:, :n])
+    kind = "port"
+    if os.path.exists(helpers.REF_SO):
+        ref = capi.EncoderLib(helpers.REF_SO)
+        run = lambda: ref.encode(clip, sampling_rate=rate, **cli)
+        kind = "reference"
+    else:
+        def run():
+            return helpers.Oracle(clip.shape[0], sampling_rate=rate, **cli).encode_whole(clip)
+    run()  # warm caches / page in
+    best = None
+    for _ in range(2):
+        t0 = time.perf_counter()
+        out = run()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    return {"value": round(n / best / 1e6, 4), "unit": "Msamples/s", "cores": 1, "kind": kind,
+            "sample": "first %.0f s of the same workload (%d samples/ch, stereo), best of 2, %s" %
+                      (n / rate, n, "AVX2 build of the reference, EncodeWhole in memory" if kind == "reference"
+                       else "oracle/srla_oracle.c, scalar C"),
+            "bytes": int(out.size)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--seconds", type=float, default=300.0, help="audio per GPU per step")
+    ap.add_argument("--cpu-seconds", type=float, default=40.0, help="audio for the CPU baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--preset", type=int, default=4)
+    ap.add_argument("--block", type=int, default=4096)
+    ap.add_argument("--divisions", type=int, default=1)
+    ap.add_argument("--ltp", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import helpers
+    from srla_amd import capi
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the MI355X path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl")   # RCCL; used only for the timing barrier / max-reduce
+
+    lib = capi.EncoderLib(helpers.PRODUCT_SO)
+    lib.lib.SRLAMI355X_SetDevice.argtypes = [C.c_int]
+    assert lib.lib.SRLAMI355X_SetDevice(local_rank) == 0
+    lib.lib.SRLAMI355X_EncodeWholeDevice.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p,
+                                                     C.c_uint32, C.POINTER(C.c_uint32), C.c_void_p]
+    lib.lib.SRLAMI355X_GetStats.argtypes = [C.c_void_p, C.POINTER(Stats), C.c_int]
+
+    rate, nch, bps = 48000, 2, 16
+    n = int(args.seconds * rate)
+    n -= n % 2  # even length (odd tails are history dependent in the reference)
+    cli = dict(preset=args.preset, max_block=args.block, divisions=args.divisions, ltp_order=args.ltp)
+    pcm = helpers.synth(helpers.MUSIC, 1000 + rank, rate, nch, n, bps)
+    d_pcm = torch.from_numpy(pcm).cuda()
+    torch.cuda.synchronize()
+
+    cfg, par = capi.cli_setup(nch, bps, rate, **cli)
+    enc = lib.create(cfg)
+    assert enc and lib.set_parameter(enc, par) == capi.OK
+    cap = 2 * pcm.size * 2 + 4096
+    out = np.zeros(cap, dtype=np.uint8)
+    out_size = C.c_uint32(0)
+
+    def step():
+        rc = lib.lib.SRLAMI355X_EncodeWholeDevice(enc, C.c_void_p(d_pcm.data_ptr()), n, n,
+                                                  out.ctypes.data_as(C.c_void_p), cap, C.byref(out_size), None)
+        if rc != capi.OK:
+            raise SystemExit("SRLAMI355X_EncodeWholeDevice -> %d" % rc)
+
+    for _ in range(args.warmup):
+        step()
+    st = Stats()
+    lib.lib.SRLAMI355X_GetStats(enc, C.byref(st), 1)  # reset counters
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    lib.lib.SRLAMI355X_GetStats(enc, C.byref(st), 0)
+    stream = out[:out_size.value].copy()
+
+    if rank == 0:
+        # sanity inside the bench: the stream decodes back to the input (oracle decoder = checker only)
+        back = helpers.oracle_decode(stream)
+        lossless = bool((back == pcm).all())
+        total_instants = float(n) * args.steps * world
+        value = total_instants / elapsed / 1e6
+        launches = max(1, st.analyze_launches)
+        avg_launch_ms = st.analyze_ms / launches
+        instants_per_launch = float(n) * args.steps / launches
+        algo_bytes = 16.0 * instants_per_launch            # 8 B per channel-sample, stereo
+        achieved = algo_bytes / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "encode Msamples/s (-m %d -B %d -V %d -P %d, stereo 48 kHz 16-bit)" % (args.preset, args.block, args.divisions, args.ltp),
+            "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "int32+f64", "data": "synthetic",
+            "config": {"workload": "srla -e -m %d -B %d -V %d -L 4 -P %d; %.0f s synthetic stereo 48 kHz/16-bit (music-like) per GPU per step, "
+                                   "samples resident in HBM, complete .srl stream produced in host memory" %
+                                   (args.preset, args.block, args.divisions, args.ltp, n / rate),
+                       "samples_per_channel_per_step": n, "parallelism": "windows sharded per GPU, no collective"},
+            "compression_ratio": round(out_size.value / float(pcm.size * (bps // 8)), 6),
+            "lossless_roundtrip": lossless,
+            "channel_samples_per_s_M": round(value * nch, 3),
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
+                         "frac": round(achieved / 8000.0, 6), "traffic": traffic,
+                         "kernel": "srla_analyze_items", "avg_launch_ms": round(avg_launch_ms, 4),
+                         "launches": int(st.analyze_launches), "algorithmic_bytes_per_launch": int(algo_bytes),
+                         "items_per_s_M": round(st.num_items / (st.analyze_ms * 1e-3) / 1e6, 3) if st.analyze_ms > 0 else None},
+            "phase_ms_per_step": {"analyze": round(st.analyze_ms / args.steps, 3), "price": round(st.price_ms / args.steps, 3),
+                                  "gather": round(st.gather_ms / args.steps, 3), "d2h": round(st.d2h_ms / args.steps, 3),
+                                  "pack_host": round(st.pack_ms / args.steps, 3), "total_host": round(st.total_ms / args.steps, 3)},
+            "host_cores": os.cpu_count(),
+            "tie_items": int(st.num_tie_items),
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(pcm, cli, args.cpu_seconds, rate)
+            line["speedup_vs_cpu_1core"] = round(value / line["cpu_baseline"]["value"], 2)
+        print(json.dumps(line), flush=True)
+    lib.destroy(enc)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -382,16 +382,18 @@ struct Impl {
             job.windows.push_back(wd);
             pos += wn;
         }
-        /* items grouped by FFT size so that each launch has one LDS plan; big FFTs first */
-        std::stable_sort(analysed.begin(), analysed.end(), [](const Pending &a, const Pending &b) { return a.nfft > b.nfft; });
-        for (size_t k = 0; k < analysed.size();) {
+        /* one launch analyses every item of the job: the LDS plan and the FFT register class are
+         * those of the largest FFT present (smaller items simply leave part of them idle) */
+        uint32_t max_nfft = 0;
+        for (const Pending &p : analysed) max_nfft = std::max(max_nfft, p.nfft);
+        if (!analysed.empty()) {
             Group g{};
-            g.nfft = analysed[k].nfft;
-            g.first = (uint32_t)job.items.size();
+            g.nfft = max_nfft;
+            g.first = 0;
             g.rclass = (int)std::max(1u, g.nfft / 2048u);
             g.plan = lds_plan(g.nfft);
-            for (; k < analysed.size() && analysed[k].nfft == g.nfft; k++) {
-                SrlaCandDesc &cd = job.cands[analysed[k].cand];
+            for (const Pending &p : analysed) {
+                SrlaCandDesc &cd = job.cands[p.cand];
                 cd.item_base = (uint32_t)job.items.size();
                 for (uint32_t v = 0; v < nv; v++) {
                     SrlaItemDesc it{};
@@ -404,7 +406,7 @@ struct Impl {
                     job.items.push_back(it);
                 }
             }
-            g.count = (uint32_t)job.items.size() - g.first;
+            g.count = (uint32_t)job.items.size();
             job.groups.push_back(g);
         }
     }

@@ -14,6 +14,7 @@
 #define SRLA_DBG_ERRVARS  256    /* 256: compensated error variances per order         */
 #define SRLA_DBG_LENS     512    /* 256: estimated code length per order               */
 #define SRLA_DBG_LTPLAGS  768    /* 264: LTP autocorrelation lags                      */
+#define SRLA_DBG_TIMES    1032   /* 8: phase time stamps (100 MHz wall clock ticks)  */
 #define SRLA_DBG_STRIDE   1040
 
 #ifdef __cplusplus

@@ -353,6 +353,8 @@ __global__ __launch_bounds__(NT) void srla_analyze_items(
     const cplx *twbase = twiddles + g.tw_off;
     double *dbg_item = dbg ? dbg + (size_t)item_idx * SRLA_DBG_STRIDE : nullptr;
 
+#define STAMP(k) do { if (dbg_item && tid == 0) dbg_item[SRLA_DBG_TIMES + (k)] = (double)wall_clock64(); } while (0)
+    STAMP(0);
     if (tid == 0) { sm->flags = (n & 1u) ? SRLA_ITEM_ODD_LENGTH : 0u; sm->max_u = 0; sm->seq_path = 0; sm->period = 0; }
 
     /* ---- stage the variant in LDS; exact integer correlations for the pre-emphasis tap ---- */
@@ -414,6 +416,7 @@ __global__ __launch_bounds__(NT) void srla_analyze_items(
     const int32_t preemph_prev = load_variant(in, jp, it.variant, 0);
     __syncthreads();
 
+    STAMP(1);
     /* ---- long-term (pitch) predictor, srla_encoder.c:1010-1057 + lpc.c:1558-1649 ---------- */
     if (jp.ltp_order > 0) {
         windowed_autocorr<R>(y, fftbuf, g, norm_bps, twbase, sm->lags, SRLA_LTP_LAGS + 2);
@@ -509,12 +512,14 @@ __global__ __launch_bounds__(NT) void srla_analyze_items(
         }
     }
 
+    STAMP(2);
     /* ---- LPC analysis ---------------------------------------------------------------------- */
     const uint32_t pmax = jp.max_order;
     uint32_t order = 0;
     if (pmax > 0) {
         windowed_autocorr<R>(y, fftbuf, g, norm_bps, twbase, sm->lags, pmax + 1);
         if (dbg_item) for (uint32_t i = tid; i < pmax + 1; i += NT) dbg_item[SRLA_DBG_LAGS + i] = sm->lags[i];
+        STAMP(3);
         const uint32_t stride = pmax + 3;
         double *err = lev + 3 * stride;
         if (wave == 0) {
@@ -595,6 +600,7 @@ __global__ __launch_bounds__(NT) void srla_analyze_items(
     }
     const uint32_t rshift = sm->rshift;
 
+    STAMP(4);
     /* ---- integer FIR residual (srla_lpc_predict.c:118-265), zig-zag copy kept in LDS -------- */
     uint32_t *u = (uint32_t *)fftbuf;
     int32_t *res_out = res_ws + it.res_off;
@@ -620,6 +626,7 @@ __global__ __launch_bounds__(NT) void srla_analyze_items(
         max_u = wave_max_u32(max_u);
         if (lane == 0) atomicMax(&sm->max_u, max_u);
     }
+    STAMP(5);
     /* finest-level partition sums (exact integers), srla_coder.c:366-381 */
     const uint32_t mp = g.max_porder, nparts = 1u << mp, fl = g.fine_len;
     unsigned long long *sums = (unsigned long long *)(means + (nparts - 1));
@@ -732,6 +739,7 @@ __global__ __launch_bounds__(NT) void srla_analyze_items(
         }
     }
     const uint32_t res_bits = best_bits + 2u;
+    STAMP(6);
 
     /* ---- coefficient cost (srla_encoder.c:1121-1187) and the item record -------------------- */
     SrlaItemResult *out = &results[item_idx];
@@ -861,6 +869,20 @@ __global__ void srla_price_windows(SrlaJobParams jp, const SrlaWindowDesc *__res
         rec.block_type = (packed >> 28) & 3u;
         rec.ch_method = (packed >> 30) & 3u;
         rec.bytes = packed & 0x0FFFFFFFu;
+        if (rec.block_type == SRLA_BLOCK_COMPRESS && nch > 2) {
+            /* ComputeBlockSize prices only the first two channels (srla_encoder.c:1287-1301) and that
+             * price drives the search; EncodeBlock then writes every channel and applies its RAW
+             * fall-back to the size actually written (srla_encoder.c:1605-1611) */
+            uint32_t bits = 2u;
+            for (uint32_t ch = 2; ch < nch; ch++) bits += results[cd.item_base + ch].code_length;
+            const uint32_t l = results[cd.item_base + 0].code_length, r = results[cd.item_base + 1].code_length;
+            const uint32_t m = results[cd.item_base + nch].code_length, s2 = results[cd.item_base + nch + 1].code_length;
+            const uint32_t len[4] = { l + r, m + s2, l + s2, r + s2 };
+            bits += len[rec.ch_method];
+            const uint32_t payload = (bits + 7u) / 8u;
+            if (8u * payload >= bps * cd.n * nch) { rec.block_type = SRLA_BLOCK_RAW; rec.bytes = 11u + (bps * cd.n * nch) / 8u; }
+            else rec.bytes = 11u + payload;
+        }
         for (uint32_t ch = 0; ch < SRLA_MAX_CH; ch++) rec.item[ch] = 0xFFFFFFFFu;
         if (rec.block_type == SRLA_BLOCK_COMPRESS) {
             for (uint32_t ch = 0; ch < nch; ch++) rec.item[ch] = cd.item_base + ch;

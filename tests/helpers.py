@@ -264,3 +264,25 @@ def list_blocks(data):
         raise RuntimeError("oracle_list_blocks -> %d" % rc)
     k = cnt.value
     return list(zip(t[:k].tolist(), ns[:k].tolist(), nb[:k].tolist()))
+
+
+def reference_encode_fresh(pcm, bits_per_sample=16, sampling_rate=48000, **cli):
+    """`srla -e` semantics: the compiled reference in a FRESH process.
+
+    The reference reads never-written words of its malloc'ed work area (the middle sample of an
+    odd-length block, lpc.c:260-264; auto_corr[263..264] in the pitch search, lpc.c:1508-1510), so in
+    a long-lived process its output for such inputs depends on heap history.  A fresh process (what
+    the CLI is) gets zero pages, which is also what the oracle models."""
+    import pickle
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "in.pkl")
+        dst = os.path.join(d, "out.npy")
+        with open(src, "wb") as f:
+            pickle.dump(dict(pcm=pcm, bps=bits_per_sample, rate=sampling_rate, cli=cli), f)
+        code = ("import sys,pickle,numpy as np; sys.path.insert(0,%r); import helpers; "
+                "a=pickle.load(open(%r,'rb')); "
+                "np.save(%r, helpers.reference_encoder().encode(a['pcm'], bits_per_sample=a['bps'], sampling_rate=a['rate'], **a['cli']))"
+                % (os.path.join(ROOT, "tests"), src, dst))
+        subprocess.check_call([sys.executable, "-c", code])
+        return np.load(dst)

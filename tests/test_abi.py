@@ -1,0 +1,164 @@
+"""The C-ABI library: it loads, exports every symbol include/srla_mi355x.h declares, keeps the
+reference's struct layouts, and reproduces the reference API's argument-error behaviour
+(test/srla_encoder/srla_encoder_test.cpp:52-340) -- none of which needs a GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import helpers
+from srla_amd import capi
+
+HEADER = os.path.join(helpers.ROOT, "include", "srla_mi355x.h")
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(SRLA(?:Encoder|MI355X)_[A-Za-z0-9]+)\s*\(", text)) - {"SRLAEncoder_EncodeBlockCallback"})
+
+
+def test_library_exports_every_declared_symbol(product):
+    names = declared_functions()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(product.lib, n), n
+
+
+def test_struct_layouts_match_the_reference():
+    assert C.sizeof(capi.SRLAHeader) == 32
+    assert C.sizeof(capi.SRLAEncodeParameter) == 32
+    assert C.sizeof(capi.SRLAEncoderConfig) == 20
+
+
+def test_encode_header(product):
+    lib = product.lib
+    hdr = capi.SRLAHeader(10, 18, 2, 1234, 48000, 16, 3, 4096, 4)
+    buf = np.zeros(30, np.uint8)
+    assert lib.SRLAEncoder_EncodeHeader(C.byref(hdr), buf.ctypes.data_as(C.c_void_p), 30) == capi.OK
+    assert bytes(buf[:4]) == b"1249"
+    assert list(buf[4:12]) == [0, 0, 0, 10, 0, 0, 0, 18]
+    assert list(buf[12:14]) == [0, 2] and int.from_bytes(bytes(buf[14:18]), "big") == 1234
+    assert int.from_bytes(bytes(buf[18:22]), "big") == 48000 and list(buf[22:25]) == [0, 16, 3]
+    assert int.from_bytes(bytes(buf[25:29]), "big") == 4096 and buf[29] == 4
+    assert lib.SRLAEncoder_EncodeHeader(None, buf.ctypes.data_as(C.c_void_p), 30) == capi.INVALID_ARGUMENT
+    assert lib.SRLAEncoder_EncodeHeader(C.byref(hdr), None, 30) == capi.INVALID_ARGUMENT
+    assert lib.SRLAEncoder_EncodeHeader(C.byref(hdr), buf.ctypes.data_as(C.c_void_p), 29) == capi.INSUFFICIENT_BUFFER
+    for field, bad in (("num_channels", 0), ("num_samples", 0), ("sampling_rate", 0), ("bits_per_sample", 0),
+                       ("offset_lshift", 32), ("max_num_samples_per_block", 0), ("preset", 7)):
+        h = capi.SRLAHeader(10, 18, 2, 1234, 48000, 16, 3, 4096, 4)
+        setattr(h, field, bad)
+        assert lib.SRLAEncoder_EncodeHeader(C.byref(h), buf.ctypes.data_as(C.c_void_p), 30) == capi.INVALID_FORMAT, field
+
+
+def test_work_size_and_create(product):
+    good = capi.SRLAEncoderConfig(8, 2048, 4096, 16384, 255)
+    assert product.lib.SRLAEncoder_CalculateWorkSize(C.byref(good)) > 0
+    assert product.lib.SRLAEncoder_CalculateWorkSize(None) == -1
+    for field, bad in (("max_num_channels", 0), ("min_num_samples_per_block", 0), ("max_num_samples_per_block", 0),
+                       ("max_num_lookahead_samples", 0), ("max_num_parameters", 5000), ("min_num_samples_per_block", 8192),
+                       ("max_num_lookahead_samples", 1024)):
+        c = capi.SRLAEncoderConfig(8, 2048, 4096, 16384, 255)
+        setattr(c, field, bad)
+        assert product.lib.SRLAEncoder_CalculateWorkSize(C.byref(c)) == -1, field
+        assert not product.lib.SRLAEncoder_Create(C.byref(c), None, 0), field
+    enc = product.create(good)
+    assert enc
+    product.destroy(enc)
+    # caller-provided work area
+    size = product.lib.SRLAEncoder_CalculateWorkSize(C.byref(good))
+    work = (C.c_uint8 * size)()
+    assert not product.lib.SRLAEncoder_Create(C.byref(good), work, size - 1)
+    enc = product.lib.SRLAEncoder_Create(C.byref(good), work, size)
+    assert enc
+    product.destroy(enc)
+    product.destroy(None)   # must be harmless, srla_encoder.c:699
+
+
+def test_set_parameter_validation(product):
+    cfg, par = capi.cli_setup(2, 16, 48000, preset=4, max_block=4096, divisions=1)
+    enc = product.create(cfg)
+    assert product.set_parameter(enc, par) == capi.OK
+    assert product.lib.SRLAEncoder_SetEncodeParameter(None, C.byref(par)) == capi.INVALID_ARGUMENT
+    assert product.lib.SRLAEncoder_SetEncodeParameter(enc, None) == capi.INVALID_ARGUMENT
+
+    def variant(**kw):
+        _, p = capi.cli_setup(2, 16, 48000, preset=4, max_block=4096, divisions=1)
+        for k, v in kw.items():
+            setattr(p, k, v)
+        return product.set_parameter(enc, p)
+    # srla_encoder.c:439-450, 727-733
+    assert variant(num_channels=0) == capi.INVALID_FORMAT
+    assert variant(bits_per_sample=0) == capi.INVALID_FORMAT
+    assert variant(sampling_rate=0) == capi.INVALID_FORMAT
+    assert variant(preset=7) == capi.INVALID_FORMAT
+    assert variant(min_num_samples_per_block=8192) == capi.INVALID_FORMAT
+    assert variant(num_lookahead_samples=2048) == capi.INVALID_FORMAT
+    assert variant(num_lookahead_samples=4096 * 4 + 1) == capi.INVALID_FORMAT
+    assert variant(ltp_order=2) == capi.INVALID_FORMAT
+    assert variant(ltp_order=5) == capi.INVALID_FORMAT
+    # capacity, srla_encoder.c:736-741
+    assert variant(max_num_samples_per_block=8192, num_lookahead_samples=16384) == capi.INSUFFICIENT_BUFFER
+    assert variant(min_num_samples_per_block=1024) == capi.INSUFFICIENT_BUFFER
+    assert variant(num_lookahead_samples=4096 * 8) == capi.INSUFFICIENT_BUFFER
+    assert variant(num_channels=9) == capi.INSUFFICIENT_BUFFER
+    product.destroy(enc)
+
+
+def test_argument_errors_of_the_encode_calls(product):
+    cfg, par = capi.cli_setup(2, 16, 48000, preset=4, max_block=4096, divisions=1)
+    enc = product.create(cfg)
+    pcm = np.zeros((2, 4096), np.int32)
+    ptrs = capi.planar_ptrs(pcm)
+    buf = np.zeros(1 << 16, np.uint8)
+    out = C.c_uint32(0)
+    b = buf.ctypes.data_as(C.c_void_p)
+    L = product.lib
+    # before SetEncodeParameter: PARAMETER_NOT_SET (srla_encoder_test.cpp:290-300)
+    assert L.SRLAEncoder_EncodeBlock(enc, ptrs, 4096, b, buf.size, C.byref(out)) == capi.PARAMETER_NOT_SET
+    assert L.SRLAEncoder_ComputeBlockSize(enc, ptrs, 4096, C.byref(out)) == capi.PARAMETER_NOT_SET
+    assert L.SRLAEncoder_EncodeWhole(enc, ptrs, 4096, b, buf.size, C.byref(out), None) == capi.PARAMETER_NOT_SET
+    assert L.SRLAEncoder_EncodeOptimalPartitionedBlock(enc, ptrs, 4096, b, buf.size, C.byref(out)) == capi.PARAMETER_NOT_SET
+    assert product.set_parameter(enc, par) == capi.OK
+    # invalid arguments (srla_encoder_test.cpp:258-288)
+    assert L.SRLAEncoder_EncodeBlock(None, ptrs, 4096, b, buf.size, C.byref(out)) == capi.INVALID_ARGUMENT
+    assert L.SRLAEncoder_EncodeBlock(enc, None, 4096, b, buf.size, C.byref(out)) == capi.INVALID_ARGUMENT
+    assert L.SRLAEncoder_EncodeBlock(enc, ptrs, 0, b, buf.size, C.byref(out)) == capi.INVALID_ARGUMENT
+    assert L.SRLAEncoder_EncodeBlock(enc, ptrs, 4096, None, buf.size, C.byref(out)) == capi.INVALID_ARGUMENT
+    assert L.SRLAEncoder_EncodeBlock(enc, ptrs, 4096, b, 0, C.byref(out)) == capi.INVALID_ARGUMENT
+    assert L.SRLAEncoder_EncodeBlock(enc, ptrs, 4096, b, buf.size, None) == capi.INVALID_ARGUMENT
+    assert L.SRLAEncoder_ComputeBlockSize(enc, ptrs, 0, C.byref(out)) == capi.INVALID_ARGUMENT
+    assert L.SRLAEncoder_ComputeBlockSize(enc, ptrs, 4096, None) == capi.INVALID_ARGUMENT
+    assert L.SRLAEncoder_EncodeWhole(enc, None, 4096, b, buf.size, C.byref(out), None) == capi.INVALID_ARGUMENT
+    assert L.SRLAEncoder_EncodeWhole(enc, ptrs, 4096, None, buf.size, C.byref(out), None) == capi.INVALID_ARGUMENT
+    # more samples than a block holds (srla_encoder.c:1499, 1573)
+    assert L.SRLAEncoder_EncodeBlock(enc, ptrs, 4097, b, buf.size, C.byref(out)) == capi.INSUFFICIENT_BUFFER
+    assert L.SRLAEncoder_ComputeBlockSize(enc, ptrs, 4097, C.byref(out)) == capi.INSUFFICIENT_BUFFER
+    assert L.SRLAEncoder_EncodeWhole(enc, ptrs, 4096, b, 10, C.byref(out), None) == capi.INSUFFICIENT_BUFFER
+    product.destroy(enc)
+
+
+def test_no_silent_cpu_fallback(product):
+    """Without a GPU the compute calls must FAIL (NG), never produce output some other way."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    cfg, par = capi.cli_setup(2, 16, 48000, preset=4, max_block=4096, divisions=1)
+    enc = product.create(cfg)
+    assert product.set_parameter(enc, par) == capi.OK
+    pcm = helpers.synth(helpers.MUSIC, 1, 48000, 2, 4096)
+    rc, data = product.encode_block(enc, pcm)
+    assert rc == capi.NG and data.size == 0
+    rc, size = product.compute_block_size(enc, pcm)
+    assert rc == capi.NG
+    rc, data = product.encode_whole(enc, pcm)
+    assert rc == capi.NG and data.size == 0
+    product.destroy(enc)
+
+
+def test_product_does_not_link_the_oracle():
+    import subprocess
+    out = subprocess.run(["nm", "-D", helpers.PRODUCT_SO], capture_output=True, text=True).stdout
+    assert "oracle_" not in out

@@ -1,0 +1,260 @@
+"""Parity of the HIP path with the oracle and with the reference's golden vectors, through the C ABI.
+Every test here needs the MI355X (`-m gpu`).  Bar: bit-exact -- bytes, residuals, coefficients."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import helpers
+from srla_amd import capi
+from tools_shared import STREAMS, make_input
+
+pytestmark = pytest.mark.gpu
+
+M4 = dict(preset=4, max_block=4096, divisions=1)
+CLIS = {
+    "m4_B4096": M4,
+    "m0_B2048": dict(preset=0, max_block=2048, divisions=1),
+    "m2_B4096_V0": dict(preset=2, max_block=4096, divisions=0),
+    "m4_B4096_V2": dict(preset=4, max_block=4096, divisions=2),
+    "m4_B4096_V2_P3": dict(preset=4, max_block=4096, divisions=2, ltp_order=3),
+    "m4_B8192_V2_P3": dict(preset=4, max_block=8192, divisions=2, ltp_order=3),
+    "m6_B1024_V1_P1": dict(preset=6, max_block=1024, divisions=1, lookahead_factor=2, ltp_order=1),
+    "m5_B2048_V3": dict(preset=5, max_block=2048, divisions=3, lookahead_factor=2),
+    "m1_B512_V0": dict(preset=1, max_block=512, divisions=0),
+}
+
+
+def _probe(product, pcm, bps=16, rate=48000, **cli):
+    nch, n = pcm.shape
+    nv = nch + (2 if nch >= 2 else 0)
+    cfg, par = capi.cli_setup(nch, bps, rate, **cli)
+    enc = product.create(cfg)
+    assert product.set_parameter(enc, par) == capi.OK
+    recs = np.zeros((nv, 1344), np.uint8); res = np.zeros((nv, n), np.int32); dbg = np.zeros((nv, 1040))
+    fn = product.lib.SRLAMI355X_ProbeBlock
+    fn.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_int32)), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    rc = fn(enc, capi.planar_ptrs(pcm), n, recs.ctypes.data_as(C.c_void_p), res.ctypes.data_as(C.c_void_p),
+            dbg.ctypes.data_as(C.c_void_p))
+    product.destroy(enc)
+    assert rc == capi.OK
+    return recs, res, dbg
+
+
+def _fields(r):
+    w = r[:64].view(np.int32)
+    order = int(w[2])
+    return dict(preemph_prev=int(w[0]), preemph_coef=int(w[1]), lpc_order=order, lpc_rshift=int(w[3]), use_sum=int(w[4]),
+                ltp_period=int(w[5]), ltp_coef=[int(w[6]), int(w[7]), int(w[8])], code_length=int(w[9]),
+                res_code_type=int(w[10]), res_porder=int(w[11]), res_bits=int(w[12]), flags=int(w[13]),
+                lpc_coef=r[64:64 + order].view(np.int8).astype(int).tolist())
+
+
+# ------------------------------------------------------------------------------ whole streams ---
+@pytest.mark.parametrize("cli_name", sorted(CLIS))
+@pytest.mark.parametrize("kind,nch", [(helpers.MUSIC, 2), (helpers.VARIED, 2), (helpers.VARIED, 1), (helpers.NOISE, 3)])
+def test_stream_bytes_equal_oracle(product, cli_name, kind, nch):
+    cli = CLIS[cli_name]
+    # lengths chosen so that no block is history dependent in the reference (odd length, or shorter than
+    # the 263 LTP lags with LTP on) -- those are covered by the 'valid and lossless' tests below
+    for n in (49152 + 1000, 9000, 4100, 300):
+        pcm = helpers.synth(kind, 40 + nch, 48000, nch, n)
+        got = product.encode(pcm, **cli)
+        want = helpers.Oracle(nch, **cli).encode_whole(pcm)
+        assert np.array_equal(got, want), (cli_name, kind, nch, n)
+
+
+EVEN = [s for s in STREAMS if not s["odd_length"]]
+ODD = [s for s in STREAMS if s["odd_length"]]
+
+
+@pytest.mark.parametrize("case", EVEN, ids=[c["name"] for c in EVEN])
+def test_golden_streams_from_the_reference(product, case):
+    """The reference's own bytes (SHA-256 + size; full bytes for the small ones), incl. BASELINE.json's
+    configurations at full size (60 s stereo 48 kHz)."""
+    pcm = make_input(case["input"])
+    assert helpers.sha256(pcm) == case["input_sha256"]
+    got = product.encode(pcm, bits_per_sample=case["input"]["bps"], sampling_rate=case["input"].get("rate", 48000), **case["cli"])
+    assert got.size == case["srl_size"]
+    assert helpers.sha256(got) == case["srl_sha256"]
+    if "file" in case:
+        assert np.array_equal(got, np.fromfile(os.path.join(helpers.GOLDEN, case["file"]), dtype=np.uint8))
+
+
+@pytest.mark.parametrize("case", ODD, ids=[c["name"] for c in ODD])
+def test_odd_length_streams_are_valid_and_lossless(product, case):
+    """Odd block lengths: the reference's LPC window leaves the middle sample to whatever its FFT buffer
+    held before (lpc.c:260-264), the device uses 0 there ('known deviations').  The stream must
+    still be a valid SRLA stream that decodes to the input, and all even-length blocks must be identical."""
+    pcm = make_input(case["input"])
+    got = product.encode(pcm, **case["cli"])
+    assert np.array_equal(helpers.oracle_decode(got), pcm)
+    want = helpers.Oracle(pcm.shape[0], **case["cli"]).encode_whole(pcm)
+    gb, wb = helpers.list_blocks(got), helpers.list_blocks(want)
+    assert sum(b[1] for b in gb) == pcm.shape[1]
+    # identical prefix: every block before the tail window
+    tail_start = (pcm.shape[1] // (4 * case["cli"]["max_block"])) * 4 * case["cli"]["max_block"]
+    pos = off = 30
+    done = 0
+    for g, w in zip(gb, wb):
+        if done + g[1] > tail_start:
+            break
+        assert g == w
+        done += g[1]
+        off += g[2]
+    assert np.array_equal(got[:off], want[:off])
+
+
+def test_short_ltp_blocks_are_valid_and_lossless(product):
+    """With LTP on, a block shorter than the 263 autocorrelation lags makes the reference read whatever
+    its FFT buffer held beyond the FFT size (lpc.c:371-373): history dependent, like odd lengths."""
+    cli = CLIS["m4_B4096_V2_P3"]
+    pcm = helpers.synth(helpers.MUSIC, 42, 48000, 2, 49152 + 82)
+    got = product.encode(pcm, **cli)
+    assert np.array_equal(helpers.oracle_decode(got), pcm)
+    want = helpers.Oracle(2, **cli).encode_whole(pcm)
+    gb, wb = helpers.list_blocks(got), helpers.list_blocks(want)
+    assert gb[:-1] == wb[:-1]
+    off = 30 + sum(b[2] for b in gb[:-1])
+    assert np.array_equal(got[:off], want[:off])
+
+
+def test_round_trip_and_idempotence_at_full_size(product):
+    pcm = helpers.synth(helpers.MUSIC, 1, 48000, 2, 2880000)
+    a = product.encode(pcm, **M4)
+    b = product.encode(pcm, **M4)
+    assert np.array_equal(a, b)
+    assert np.array_equal(helpers.oracle_decode(a), pcm)
+
+
+def test_windows_are_stateless(product):
+    """Encoding the second half on its own reproduces the whole stream's bytes for that half
+     -- the property the multi-GPU sharding rests on."""
+    cli = dict(preset=4, max_block=4096, divisions=2, ltp_order=3)
+    n = 16384 * 12
+    pcm = helpers.synth(helpers.MUSIC, 5, 48000, 2, n)
+    whole = product.encode(pcm, **cli)
+    first = product.encode(np.ascontiguousarray(pcm[:, :n // 2]), **cli)
+    second = product.encode(np.ascontiguousarray(pcm[:, n // 2:]), **cli)
+    assert np.array_equal(whole[30:], np.concatenate([first[30:], second[30:]]))
+
+
+# ------------------------------------------------------------------------------ stage level ----
+@pytest.mark.parametrize("n,cli_name,kind", [(4096, "m4_B4096", helpers.MUSIC), (2048, "m4_B4096", helpers.VARIED),
+                                             (3072, "m4_B4096_V2_P3", helpers.MUSIC), (4096, "m4_B4096_V2_P3", helpers.MUSIC),
+                                             (8192, "m4_B8192_V2_P3", helpers.MUSIC), (1000, "m6_B1024_V1_P1", helpers.MUSIC),
+                                             (4096, "m4_B4096", helpers.NOISE), (2050, "m4_B4096_V2_P3", helpers.VARIED),
+                                             (512, "m1_B512_V0", helpers.MUSIC)])
+def test_item_records_residuals_and_lags(product, n, cli_name, kind):
+    cli = CLIS[cli_name]
+    pcm = helpers.synth(kind, 60, 48000, 2, 48000)[:, 20000:20000 + n].copy()
+    recs, res, dbg = _probe(product, pcm, **cli)
+    o = helpers.Oracle(2, **cli)
+    lib = helpers.oracle_lib()
+    left, right = pcm[0].copy(), pcm[1].copy()
+    side = right - left
+    mid = left + (side >> 1)
+    pmax = [0, 8, 16, 32, 64, 128, 255][cli["preset"]]
+    for v, samples in enumerate((left, right, mid, side)):      # device order: plain channels, M, S
+        want, want_res, filtered = o.analyze_channel(samples)
+        got = _fields(recs[v])
+        w = want.as_dict()
+        for key in ("preemph_prev", "preemph_coef", "lpc_order", "lpc_rshift", "use_sum", "ltp_period", "code_length",
+                    "res_code_type", "res_porder", "res_bits", "lpc_coef"):
+            assert got[key] == w[key], (v, key)
+        if w["ltp_period"]:
+            assert got["ltp_coef"][:cli.get("ltp_order", 0)] == w["ltp_coef"][:cli.get("ltp_order", 0)]
+        assert np.array_equal(res[v], want_res), v
+        # fp64 stages: autocorrelation lags and error variances must be the same doubles
+        sig = filtered.astype(np.float64) * 2.0 ** -15
+        lags = np.zeros(pmax + 1)
+        lib.oracle_autocorr(o.h, sig.ctypes.data_as(C.c_void_p), n, lags.ctypes.data_as(C.c_void_p), pmax + 1)
+        assert np.array_equal(dbg[v, 0:pmax + 1], lags), v
+        lags[0] *= (1.0 + 1e-5)
+        rows = np.zeros((pmax, pmax)); ev = np.zeros(pmax + 1)
+        lib.oracle_levinson(lags.ctypes.data_as(C.c_void_p), pmax, n, rows.ctypes.data_as(C.c_void_p), ev.ctypes.data_as(C.c_void_p))
+        assert np.array_equal(dbg[v, 256:256 + pmax + 1], ev), v
+        # estimated code lengths use the device's log(): agree to ~1 ulp-level relative error
+        lens = np.zeros(pmax + 1)
+        lib.oracle_select_order(ev.ctypes.data_as(C.c_void_p), pmax, n, 16, lens.ctypes.data_as(C.c_void_p))
+        assert np.allclose(dbg[v, 513:513 + pmax], lens[1:], rtol=1e-12, atol=1e-9)
+
+
+# ------------------------------------------------------------------------------ block API ------
+def test_block_calls(product):
+    cli = dict(preset=4, max_block=4096, divisions=2)
+    cfg, par = capi.cli_setup(2, 16, 48000, **cli)
+    enc = product.create(cfg)
+    assert product.set_parameter(enc, par) == capi.OK
+    o = helpers.Oracle(2, **cli)
+    sig = helpers.synth(helpers.VARIED, 70, 48000, 2, 48000 * 8)
+    for start, n in ((0, 4096), (48000, 4096), (96000, 1024), (5 * 48000, 4096), (6 * 48000, 2000), (20, 100), (0, 64), (0, 66)):
+        blk = np.ascontiguousarray(sig[:, start:start + n])
+        rc, size = product.compute_block_size(enc, blk)
+        rc2, data = product.encode_block(enc, blk)
+        assert rc == rc2 == capi.OK
+        assert size == data.size == o.compute_block_size(blk)          # srla_encoder_test.cpp:407
+        assert np.array_equal(data, o.encode_block(blk))
+        assert data[0] == 0xFF and data[1] == 0xFF                       # sync code
+    win = np.ascontiguousarray(sig[:, 48000:48000 + 16384])
+    rc, data = product.encode_partitioned(enc, win)
+    assert rc == capi.OK
+    parts = o.search_partitions(win)
+    pos, chunks = 0, []
+    for p in parts:
+        chunks.append(o.encode_block(np.ascontiguousarray(win[:, pos:pos + p])))
+        pos += p
+    assert np.array_equal(data, np.concatenate(chunks))
+    product.destroy(enc)
+
+
+def test_callback_order_and_progress(product):
+    cfg, par = capi.cli_setup(2, 16, 48000, **M4)
+    enc = product.create(cfg)
+    assert product.set_parameter(enc, par) == capi.OK
+    n = 16384 * 5 + 3000
+    pcm = helpers.synth(helpers.MUSIC, 80, 48000, 2, n)
+    seen = []
+
+    def cb(total, progress, ptr, size):
+        seen.append((total, progress, size, bytes(C.string_at(ptr, min(size, 2)))))
+    rc, data = product.encode_whole(enc, pcm, callback=cb)
+    product.destroy(enc)
+    assert rc == capi.OK
+    assert [s[1] for s in seen] == [16384, 32768, 49152, 65536, 81920, n]
+    assert all(s[0] == n and s[3] == b"\xff\xff" for s in seen)
+    assert sum(s[2] for s in seen) == data.size - 30
+
+
+def test_device_resident_input(product):
+    import torch
+    pcm = helpers.synth(helpers.MUSIC, 90, 48000, 2, 480000)
+    want = product.encode(pcm, **M4)
+    cfg, par = capi.cli_setup(2, 16, 48000, **M4)
+    enc = product.create(cfg)
+    assert product.set_parameter(enc, par) == capi.OK
+    stride = pcm.shape[1] + 640
+    d = torch.zeros((2, stride), dtype=torch.int32, device="cuda")
+    d[:, :pcm.shape[1]] = torch.from_numpy(pcm).cuda()
+    torch.cuda.synchronize()
+    fn = product.lib.SRLAMI355X_EncodeWholeDevice
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.c_void_p]
+    buf = np.zeros(pcm.size * 4, np.uint8); out = C.c_uint32(0)
+    rc = fn(enc, C.c_void_p(d.data_ptr()), stride, pcm.shape[1], buf.ctypes.data_as(C.c_void_p), buf.size, C.byref(out), None)
+    product.destroy(enc)
+    assert rc == capi.OK
+    assert np.array_equal(buf[:out.value], want)
+
+
+def test_offset_left_shift_and_small_output_buffer(product):
+    pcm = (helpers.synth(helpers.MUSIC, 91, 48000, 2, 40000) >> 2) << 2
+    got = product.encode(pcm, **M4)
+    assert got[24] == 2
+    assert np.array_equal(got, helpers.Oracle(2, **M4).encode_whole(pcm))
+    cfg, par = capi.cli_setup(2, 16, 48000, **M4)
+    enc = product.create(cfg)
+    assert product.set_parameter(enc, par) == capi.OK
+    rc, _ = product.encode_whole(enc, pcm, cap=2000)
+    assert rc == capi.INSUFFICIENT_BUFFER
+    product.destroy(enc)
