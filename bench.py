@@ -169,7 +169,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("bytes_per_launch")
+                traffic = int(json.load(open(tpath))["bytes_per_instant"] * instants_per_launch)
             except Exception:
                 traffic = None
         line = {
