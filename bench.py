@@ -41,7 +41,8 @@ class Stats(C.Structure):
                 ("num_tie_items", C.c_uint64), ("num_odd_items", C.c_uint64), ("analyze_launches", C.c_uint64),
                 ("analyze_ms", C.c_double), ("price_ms", C.c_double), ("gather_ms", C.c_double),
                 ("h2d_ms", C.c_double), ("d2h_ms", C.c_double), ("pack_ms", C.c_double), ("total_ms", C.c_double),
-                ("analyzed_samples", C.c_uint64)]
+                ("analyzed_samples", C.c_uint64), ("autocorr_ms", C.c_double), ("solve_ms", C.c_double),
+                ("residual_ms", C.c_double)]
 
 
 def cpu_baseline(pcm, cli, seconds, rate):
@@ -189,7 +190,9 @@ def main():
                          "kernel": "srla_analyze_items", "avg_launch_ms": round(avg_launch_ms, 4),
                          "launches": int(st.analyze_launches), "algorithmic_bytes_per_launch": int(algo_bytes),
                          "items_per_s_M": round(st.num_items / (st.analyze_ms * 1e-3) / 1e6, 3) if st.analyze_ms > 0 else None},
-            "phase_ms_per_step": {"analyze": round(st.analyze_ms / args.steps, 3), "price": round(st.price_ms / args.steps, 3),
+            "phase_ms_per_step": {"analyze": round(st.analyze_ms / args.steps, 3),
+                                  "analyze_autocorr": round(st.autocorr_ms / args.steps, 3), "analyze_solve": round(st.solve_ms / args.steps, 3),
+                                  "analyze_residual_cost": round(st.residual_ms / args.steps, 3), "price": round(st.price_ms / args.steps, 3),
                                   "gather": round(st.gather_ms / args.steps, 3), "d2h": round(st.d2h_ms / args.steps, 3),
                                   "pack_host": round(st.pack_ms / args.steps, 3), "total_host": round(st.total_ms / args.steps, 3)},
             "host_cores": os.cpu_count(),

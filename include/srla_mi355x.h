@@ -152,7 +152,7 @@ struct SRLAMI355XStats {
     uint64_t num_tie_items;      /* chosen items whose order choice was within libm tolerance */
     uint64_t num_odd_items;      /* chosen items with an odd block length                */
     uint64_t analyze_launches;
-    double   analyze_ms;         /* HIP-event time of the item-analysis kernel launches  */
+    double   analyze_ms;         /* HIP-event time of the item-analysis kernels of all jobs */
     double   price_ms;
     double   gather_ms;
     double   h2d_ms;
@@ -160,6 +160,9 @@ struct SRLAMI355XStats {
     double   pack_ms;            /* host wall time in the bit-packer                     */
     double   total_ms;           /* host wall time inside Encode*                        */
     uint64_t analyzed_samples;   /* sum of item lengths                                  */
+    double   autocorr_ms;        /* srla_autocorr (+ srla_pitch_solve) share of analyze_ms */
+    double   solve_ms;           /* srla_lpc_solve                                        */
+    double   residual_ms;        /* srla_residual_cost                                    */
 };
 /* cumulative since Create or the last reset */
 void SRLAMI355X_GetStats(struct SRLAEncoder *encoder, struct SRLAMI355XStats *stats, int reset);

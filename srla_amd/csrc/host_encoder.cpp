@@ -191,7 +191,7 @@ struct Job {
 struct Slot {
     hipStream_t stream = nullptr;
     hipEvent_t ev[8] = {};
-    DevBuf d_input, d_items, d_cands, d_windows, d_results, d_res_ws, d_blocks, d_cand_bytes, d_out, d_chan, d_dbg;
+    DevBuf d_input, d_items, d_cands, d_windows, d_results, d_res_ws, d_blocks, d_cand_bytes, d_out, d_chan, d_dbg, d_lags;
     PinBuf h_in, h_out, h_blocks, h_chan;
     Job job;
     bool busy = false;
@@ -228,7 +228,7 @@ struct Impl {
                 if (s.stream) (void)hipStreamSynchronize(s.stream);
                 for (auto &e : s.ev) if (e) (void)hipEventDestroy(e);
                 DevBuf *db[] = { &s.d_input, &s.d_items, &s.d_cands, &s.d_windows, &s.d_results, &s.d_res_ws,
-                                 &s.d_blocks, &s.d_cand_bytes, &s.d_out, &s.d_chan, &s.d_dbg };
+                                 &s.d_blocks, &s.d_cand_bytes, &s.d_out, &s.d_chan, &s.d_dbg, &s.d_lags };
                 for (auto *b : db) b->release();
                 PinBuf *pb[] = { &s.h_in, &s.h_out, &s.h_blocks, &s.h_chan };
                 for (auto *b : pb) b->release();
@@ -316,24 +316,20 @@ struct Impl {
         return true;
     }
 
+    /* LDS carve-up of srla_residual_cost for the largest FFT size of a job */
     SrlaLdsPlan lds_plan(uint32_t nfft) const
     {
-        const uint32_t pmax = preset_order();
-        const uint32_t y_bytes = 4 * nfft, fft_bytes = 8 * nfft;
-        const uint32_t lev_bytes = 8 * 5 * (pmax + 3);
         uint32_t mp = 0;
         while ((1u << (mp + 1)) <= nfft && mp < SRLA_MAX_PORDER) mp++;
-        const uint32_t means_bytes = 8 * (2u << mp);
+        const uint32_t sig_bytes = 4 * (nfft + SRLA_FIR_PAD), means_bytes = 8 * (2u << mp);
         auto al = [](uint32_t v) { return (v + 15u) & ~15u; };
-        SrlaLdsPlan p;
+        SrlaLdsPlan p{};
         uint32_t off = 0;
-        p.y_off = off; off += al(std::max(y_bytes, 64u));
-        p.fft_off = off; off += al(std::max(fft_bytes, 64u));
-        if (fft_bytes >= lev_bytes) p.lev_off = p.fft_off;
-        else { p.lev_off = off; off += al(lev_bytes); }
-        if (fft_bytes >= y_bytes + means_bytes) p.means_off = p.fft_off + al(y_bytes);
-        else { p.means_off = off; off += al(means_bytes); }
-        p.small_off = off; off += srla_kernel_small_bytes();
+        p.y_off = off; off += al(sig_bytes);
+        p.fft_off = off; if (par.ltp_order > 0) off += al(sig_bytes);
+        p.lev_off = 0;
+        p.means_off = off; off += al(means_bytes);
+        p.small_off = off; off += srla_kernel_small_c_bytes();
         p.total = off;
         return p;
     }
@@ -472,15 +468,32 @@ struct Impl {
 
         const SrlaJobParams jp = job_params(job, stride);
         for (const Group &g : job.groups) {
-            if (srla_launch_analyze(s.stream, g.rclass, g.count, &jp, d_in, s.d_items.as<SrlaItemDesc>(), g.first,
-                                    d_geoms.as<SrlaGeom>(), d_tw.p, &g.plan, d_thr.as<double>(), d_huff.as<uint8_t>(),
-                                    s.d_res_ws.as<int32_t>(), s.d_results.as<SrlaItemResult>(),
-                                    want_dbg ? s.d_dbg.as<double>() : nullptr) != 0) {
+            const uint32_t fft_bytes = (8u * g.nfft + 15u) & ~15u;
+            const uint32_t lag_rows = std::max<uint32_t>(par.ltp_order > 0 ? SRLA_LTP_LAGS : 0u, jp.max_order + 1);
+            if (!s.d_lags.ensure((size_t)lag_rows * n_items * sizeof(double))) return false;
+            double *dbg = want_dbg ? s.d_dbg.as<double>() : nullptr;
+            int rc = 0;
+            if (par.ltp_order > 0) {
+                rc |= srla_launch_autocorr(s.stream, g.rclass, &jp, d_in, s.d_items.as<SrlaItemDesc>(), d_geoms.as<SrlaGeom>(), d_tw.p,
+                                           fft_bytes, 1, s.d_results.as<SrlaItemResult>(), s.d_lags.as<double>(), dbg);
+                rc |= srla_launch_pitch_solve(s.stream, &jp, s.d_lags.as<double>(), s.d_results.as<SrlaItemResult>());
+            }
+            rc |= srla_launch_autocorr(s.stream, g.rclass, &jp, d_in, s.d_items.as<SrlaItemDesc>(), d_geoms.as<SrlaGeom>(), d_tw.p,
+                                       fft_bytes, 0, s.d_results.as<SrlaItemResult>(), s.d_lags.as<double>(), dbg);
+            HIP_OK(hipEventRecord(s.ev[6], s.stream));
+            if (jp.max_order > 0)
+                rc |= srla_launch_lpc_solve(s.stream, &jp, s.d_items.as<SrlaItemDesc>(), d_geoms.as<SrlaGeom>(), s.d_lags.as<double>(),
+                                            d_huff.as<uint8_t>(), s.d_results.as<SrlaItemResult>(), dbg);
+            HIP_OK(hipEventRecord(s.ev[7], s.stream));
+            rc |= srla_launch_residual_cost(s.stream, g.rclass, &jp, d_in, s.d_items.as<SrlaItemDesc>(), d_geoms.as<SrlaGeom>(), &g.plan,
+                                            d_thr.as<double>(), s.d_res_ws.as<int32_t>(), s.d_results.as<SrlaItemResult>());
+            if (rc != 0) {
                 fprintf(stderr, "[srla-mi355x] item analysis launch failed (nfft %u)\n", g.nfft);
                 return false;
             }
             stats.analyze_launches++;
         }
+        if (job.groups.empty()) { HIP_OK(hipEventRecord(s.ev[6], s.stream)); HIP_OK(hipEventRecord(s.ev[7], s.stream)); }
         HIP_OK(hipEventRecord(s.ev[2], s.stream));
         if (srla_launch_price(s.stream, &jp, s.d_windows.as<SrlaWindowDesc>(), s.d_cands.as<SrlaCandDesc>(),
                               s.d_results.as<SrlaItemResult>(), s.d_blocks.as<SrlaBlockRecord>(),
@@ -506,6 +519,9 @@ struct Impl {
         float t = 0;
         if (hipEventElapsedTime(&t, s.ev[0], s.ev[1]) == hipSuccess) stats.h2d_ms += t;
         if (hipEventElapsedTime(&t, s.ev[1], s.ev[2]) == hipSuccess) stats.analyze_ms += t;
+        if (hipEventElapsedTime(&t, s.ev[1], s.ev[6]) == hipSuccess) stats.autocorr_ms += t;
+        if (hipEventElapsedTime(&t, s.ev[6], s.ev[7]) == hipSuccess) stats.solve_ms += t;
+        if (hipEventElapsedTime(&t, s.ev[7], s.ev[2]) == hipSuccess) stats.residual_ms += t;
         if (hipEventElapsedTime(&t, s.ev[2], s.ev[3]) == hipSuccess) stats.price_ms += t;
         if (hipEventElapsedTime(&t, s.ev[3], s.ev[4]) == hipSuccess) stats.gather_ms += t;
         if (hipEventElapsedTime(&t, s.ev[4], s.ev[5]) == hipSuccess) stats.d2h_ms += t;

@@ -14,20 +14,27 @@
 #define SRLA_DBG_ERRVARS  256    /* 256: compensated error variances per order         */
 #define SRLA_DBG_LENS     512    /* 256: estimated code length per order               */
 #define SRLA_DBG_LTPLAGS  768    /* 264: LTP autocorrelation lags                      */
-#define SRLA_DBG_TIMES    1032   /* 8: phase time stamps (100 MHz wall clock ticks)  */
 #define SRLA_DBG_STRIDE   1040
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-uint32_t srla_kernel_small_bytes(void);
+uint32_t srla_kernel_small_a_bytes(void);
+uint32_t srla_kernel_small_c_bytes(void);
+#define SRLA_FIR_PAD 256
 
-int srla_launch_analyze(hipStream_t stream, int fft_regs_class, uint32_t num_items_in_group,
-                        const SrlaJobParams *jp, const int32_t *input, const SrlaItemDesc *items,
-                        uint32_t item_first, const SrlaGeom *geoms, const void *twiddles,
-                        const SrlaLdsPlan *plan, const double *rice_thresholds, const uint8_t *huff_len,
-                        int32_t *res_ws, SrlaItemResult *results, double *dbg);
+/* pass 0: LPC lags (initialises the item record unless an LTP pass ran first), pass 1: LTP lags */
+int srla_launch_autocorr(hipStream_t stream, int rclass, const SrlaJobParams *jp, const int32_t *input,
+                         const SrlaItemDesc *items, const SrlaGeom *geoms, const void *twiddles,
+                         uint32_t fft_bytes, uint32_t pass, SrlaItemResult *results, double *lags_ws, double *dbg);
+int srla_launch_pitch_solve(hipStream_t stream, const SrlaJobParams *jp, const double *lags_ws, SrlaItemResult *results);
+int srla_launch_lpc_solve(hipStream_t stream, const SrlaJobParams *jp, const SrlaItemDesc *items,
+                          const SrlaGeom *geoms, const double *lags_ws, const uint8_t *huff_len,
+                          SrlaItemResult *results, double *dbg);
+int srla_launch_residual_cost(hipStream_t stream, int rclass, const SrlaJobParams *jp, const int32_t *input,
+                              const SrlaItemDesc *items, const SrlaGeom *geoms, const SrlaLdsPlan *plan,
+                              const double *rice_thresholds, int32_t *res_ws, SrlaItemResult *results);
 
 int srla_launch_price(hipStream_t stream, const SrlaJobParams *jp, const SrlaWindowDesc *windows,
                       const SrlaCandDesc *cands, const SrlaItemResult *results,

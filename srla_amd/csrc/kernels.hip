@@ -1,23 +1,27 @@
 /*
  * kernels.hip -- hand-written HIP kernels (gfx950 / CDNA4) for the SRLA encode hot path.
  *
- *   srla_analyze_items   one workgroup per item (candidate block x channel variant): samples are
- *                        staged once in LDS and everything up to the item's code length stays
- *                        in LDS / registers: pre-emphasis, optional long-term predictor,
- *                        Welch window + real-FFT autocorrelation (fp64, bit-exact operation
- *                        order of libs/fft), Levinson-Durbin, order choice, 8-bit tap
- *                        quantisation, integer FIR residual, partitioned (recursive) Rice
- *                        code-length search.           (srla_encoder.c:966-1205 and callees)
- *   srla_price_windows   stereo decision + block sizes + the shortest path over block
- *                        divisions, one thread per window.   (srla_encoder.c:1208-1334,
- *                        :1477-1546, :249-424)
- *   srla_gather_blocks   copies the residuals / parameters of the chosen blocks into the
- *                        compact buffers the host bit-packer reads.
- *   srla_or_reduce       whole-stream OR for the offset left shift (srla_utility.c:177-203)
+ * The per-item analysis of ComputeCoefficientsPerChannel (srla_encoder.c:966-1205) is a pipeline of
+ * kernels chosen by the SHAPE of each stage's parallelism, not by the reference's call graph:
  *
- * No MFMA: the path is integer/fp64 reductions and butterflies, not a dense contraction.
- * All fp64 arithmetic must round exactly like the C90 reference: this file is compiled with
- * -ffp-contract=off and additionally pins it with the pragma below.
+ *   srla_autocorr<R>        one workgroup per item.  Samples are loaded once with 16-byte loads and
+ *                           stay in registers: exact integer correlations -> pre-emphasis tap ->
+ *                           pre-emphasis (-> long-term predictor) -> Welch window -> real FFT in LDS
+ *                           (fp64, operation order of libs/fft) -> |X|^2 -> inverse -> lags.
+ *   srla_pitch_solve        (LTP only) ONE LANE per item: the sequential pitch scan of
+ *                           lpc.c:1473-1555 and the 3x3 Cholesky solve, 64 items per wavefront.
+ *   srla_lpc_solve<L>       ONE LANE per item: Levinson-Durbin with the gamma dot product summed in
+ *                           index order (lpc.c:417-438), code-length estimate per order, order choice,
+ *                           8-bit quantiser with error feedback -- all inherently serial per item, so 64
+ *                           recursions run side by side in a wavefront with column-major LDS arrays.
+ *   srla_residual_cost<R>   one workgroup per item: pre-emphasis (+LTP), register-blocked int32 FIR,
+ *                           residual to HBM, partitioned (recursive) Rice code-length search.
+ *   srla_price_windows      stereo decision + block sizes + shortest path, one thread per window.
+ *   srla_gather_blocks      chosen residuals / parameters into the compact D2H buffers.
+ *   srla_or_reduce          whole-stream OR for the offset left shift.
+ *
+ * No MFMA: integer/fp64 butterflies and reductions, not a dense contraction.  All fp64 arithmetic
+ * must round exactly like the C90 reference: compiled with -ffp-contract=off and pinned below.
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -31,33 +35,9 @@
 #define NT 256
 #define WAVE 64
 #define NWAVES (NT / WAVE)
+#define FIR_PAD 256   /* ints of zero padding in front of the signal in LDS (>= max order rounded to 4) */
 
 typedef double2 cplx;
-
-/* fixed-size LDS scratch of kernel A */
-struct Small {
-    double   lags[272];        /* autocorrelation lags (LTP needs 263 + 2 stale reads) */
-    double   dscratch[16];
-    long long lscratch[16];
-    uint32_t uscratch[32];
-    int32_t  coef[256];        /* quantised taps, stream (reversed) order */
-    uint32_t level_bits[16];
-    uint8_t  ktab[2048];       /* heap layout: level p at [2^p - 1, 2^(p+1) - 1) */
-    int32_t  preemph_coef;
-    uint32_t order;
-    uint32_t rshift;
-    uint32_t period;
-    int32_t  ltp_coef[4];
-    uint32_t flags;
-    uint32_t max_u;
-    uint32_t code_type;
-    uint32_t porder;
-    uint32_t res_bits;
-    uint32_t seq_path;
-    uint32_t pad[2];
-};
-
-extern "C" uint32_t srla_kernel_small_bytes(void) { return (uint32_t)((sizeof(Small) + 15) & ~15u); }
 
 /* ---------------------------------------------------------------- small device helpers --- */
 __device__ __forceinline__ uint32_t zigzag32(int32_t s) { return ((uint32_t)s << 1) ^ (uint32_t)(-(int32_t)(s < 0)); }
@@ -105,26 +85,58 @@ __device__ __forceinline__ int32_t load_variant(const int32_t *__restrict__ in, 
     return (int32_t)((uint32_t)l + (uint32_t)(s >> 1));
 }
 
+/* four consecutive variant samples starting at i4 (zeros beyond n); 16-byte loads when possible */
+__device__ __forceinline__ void load_chunk(const int32_t *__restrict__ in, const SrlaJobParams &jp, uint32_t variant,
+                                           uint32_t i4, uint32_t n, bool aligned, int32_t out[4])
+{
+    if (aligned && i4 + 4 <= n) {
+        const uint32_t sh = jp.offset_lshift;
+        if (variant < jp.num_channels) {
+            const int4 a = *reinterpret_cast<const int4 *>(in + (size_t)variant * jp.channel_stride + i4);
+            out[0] = a.x >> sh; out[1] = a.y >> sh; out[2] = a.z >> sh; out[3] = a.w >> sh;
+        } else {
+            const int4 a = *reinterpret_cast<const int4 *>(in + i4);
+            const int4 b = *reinterpret_cast<const int4 *>(in + (size_t)jp.channel_stride + i4);
+            const int32_t l[4] = { a.x >> sh, a.y >> sh, a.z >> sh, a.w >> sh };
+            const int32_t r[4] = { b.x >> sh, b.y >> sh, b.z >> sh, b.w >> sh };
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int32_t s = (int32_t)((uint32_t)r[i] - (uint32_t)l[i]);
+                out[i] = (variant == jp.num_channels + 1) ? s : (int32_t)((uint32_t)l[i] + (uint32_t)(s >> 1));
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++) out[i] = (i4 + i < n) ? load_variant(in, jp, variant, i4 + i) : 0;
+    }
+}
+
+__device__ __forceinline__ bool input_aligned(const int32_t *in, const SrlaJobParams &jp)
+{
+    return ((reinterpret_cast<uintptr_t>(in) & 15u) == 0) && ((jp.channel_stride & 3u) == 0);
+}
+
 /* ------------------------------------------------------------------------------ FFT ------ */
-/* complex FFT of m points held interleaved in LDS, radix-4 decimation in frequency with the
- * reference's (Stockham) butterfly arithmetic; every butterfly output is staged in registers
- * so one LDS buffer suffices (two barriers per stage).  fft.c:71-136.
- * tw: per-stage w1 tables, stage with sub-size n holds n/4 entries. */
+/* complex FFT of m points held interleaved in LDS: radix-4 decimation in frequency with the
+ * reference's (Stockham) butterfly arithmetic (fft.c:71-136).  Butterfly inputs are staged in
+ * registers, so one LDS buffer suffices (two barriers per stage); the stage's twiddle is fetched
+ * together with the inputs so its latency overlaps the LDS reads. */
 template <int R>
 __device__ void fft_complex_lds(cplx *x, uint32_t m, int flag, const cplx *__restrict__ tw)
 {
     const uint32_t tid = threadIdx.x;
     uint32_t n = m, s = 1, log2s = 0;
     const double jim = (double)(-flag);
+    const uint32_t nb = m >> 2;
     while (n > 2) {
         const uint32_t n1 = n >> 2, n2 = n >> 1, n3 = n1 + n2;
-        const uint32_t nb = m >> 2;
-        cplx a[R], b[R], c[R], d[R];
+        cplx a[R], b[R], c[R], d[R], w1[R];
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const uint32_t bf = tid + (uint32_t)r * NT;
             if (bf < nb) {
                 const uint32_t p = bf >> log2s, q = bf & (s - 1);
+                w1[r] = tw[p];
                 a[r] = x[q + s * p];
                 b[r] = x[q + s * (p + n1)];
                 c[r] = x[q + s * (p + n2)];
@@ -137,16 +149,15 @@ __device__ void fft_complex_lds(cplx *x, uint32_t m, int flag, const cplx *__res
             const uint32_t bf = tid + (uint32_t)r * NT;
             if (bf < nb) {
                 const uint32_t p = bf >> log2s, q = bf & (s - 1);
-                const cplx w1 = tw[p];
-                const cplx w2 = c_mul(w1, w1);
-                const cplx w3 = c_mul(w1, w2);
+                const cplx w2 = c_mul(w1[r], w1[r]);
+                const cplx w3 = c_mul(w1[r], w2);
                 const cplx apc = c_add(a[r], c[r]), amc = c_sub(a[r], c[r]), bpd = c_add(b[r], d[r]);
                 const cplx bmd = c_sub(b[r], d[r]);
                 /* (0, -flag) * (b - d), written out as the reference's complex product */
                 const cplx jbmd = make_double2(0.0 * bmd.x - jim * bmd.y, 0.0 * bmd.y + jim * bmd.x);
                 const uint32_t o = q + s * (p << 2);
                 x[o] = c_add(apc, bpd);
-                x[o + s] = c_mul(w1, c_sub(amc, jbmd));
+                x[o + s] = c_mul(w1[r], c_sub(amc, jbmd));
                 x[o + 2 * s] = c_mul(w2, c_sub(apc, bpd));
                 x[o + 3 * s] = c_mul(w3, c_add(amc, jbmd));
             }
@@ -181,79 +192,59 @@ __device__ __forceinline__ uint32_t complex_table_len(uint32_t m)
     return t;
 }
 
-/* spectral symmetry pass of the real FFT (fft.c:164-183); rtw[i-1] = (wr, wi) for pair i */
+/* spectral symmetry pass of the real FFT (fft.c:164-183); rtw[i-1] = (wr, wi) for pair i.
+ * POWER: fuse the forward pass with the power spectrum (lpc.c:357-365) for the pair it just produced. */
+template <bool POWER>
 __device__ void real_fft_pairs(double *x, uint32_t nfft, int flag, const cplx *__restrict__ rtw)
 {
     const double c2 = flag * 0.5;
     const uint32_t quarter = nfft >> 2;
     for (uint32_t i = 1 + threadIdx.x; i <= quarter; i += NT) {
         const uint32_t i1 = i << 1, i2 = i1 + 1, i3 = nfft - i1, i4 = i3 + 1;
+        const cplx w = rtw[i - 1];
         const double x1 = x[i1], x2 = x[i2], x3 = x[i3], x4 = x[i4];
-        const double wr = rtw[i - 1].x, wi = rtw[i - 1].y;
+        const double wr = w.x, wi = w.y;
         const double h1r = 0.5 * (x1 + x3);
         const double h1i = 0.5 * (x2 - x4);
         const double h2r = -c2 * (x2 + x4);
         const double h2i = c2 * (x1 - x3);
-        if (i1 != i3) {
-            x[i1] = h1r + (wr * h2r) - (wi * h2i);
-            x[i2] = h1i + (wr * h2i) + (wi * h2r);
-        }
+        const double y1 = h1r + (wr * h2r) - (wi * h2i);
+        const double y2 = h1i + (wr * h2i) + (wi * h2r);
         /* for the self-paired middle element the reference's second pair of stores wins */
-        x[i3] = h1r - (wr * h2r) + (wi * h2i);
-        x[i4] = -h1i + (wr * h2i) + (wi * h2r);
+        const double y3 = h1r - (wr * h2r) + (wi * h2i);
+        const double y4 = -h1i + (wr * h2i) + (wi * h2r);
+        if (POWER) {
+            if (i1 != i3) { x[i1] = y1 * y1 + y2 * y2; x[i2] = 0.0; }
+            x[i3] = y3 * y3 + y4 * y4; x[i4] = 0.0;
+        } else {
+            if (i1 != i3) { x[i1] = y1; x[i2] = y2; }
+            x[i3] = y3; x[i4] = y4;
+        }
     }
     __syncthreads();
 }
 
-/* Welch window + circular autocorrelation through the FFT (lpc.c:236-266, 330-376).
- * y: pre-emphasised int32 signal in LDS; buf: nfft doubles in LDS; lags_out[0..num_lags). */
+/* circular autocorrelation of the (already windowed, zero padded) doubles in buf (lpc.c:330-376):
+ * on return buf[i] holds the unscaled lag i */
 template <int R>
-__device__ void windowed_autocorr(const int32_t *y, double *buf, const SrlaGeom &g, double norm_bps,
-                                  const cplx *__restrict__ twbase, double *lags_out, uint32_t num_lags)
+__device__ void autocorr_in_place(double *buf, uint32_t nfft, const cplx *__restrict__ twbase)
 {
-    const uint32_t n = g.n, nfft = g.nfft, m = nfft >> 1, half = n >> 1;
+    const uint32_t m = nfft >> 1;
     const uint32_t ct = complex_table_len(m), quarter = nfft >> 2;
     const cplx *tw_fwd = twbase;
     const cplx *tw_inv = twbase + ct;
     const cplx *rtw_fwd = twbase + 2 * ct;
     const cplx *rtw_inv = rtw_fwd + quarter;
-
-    for (uint32_t e = threadIdx.x; e < nfft; e += NT) {
-        double v = 0.0;
-        if (e < n) {
-            const double in = (double)y[e] * norm_bps;
-            uint32_t smpl;
-            bool touched = true;
-            if (e < half) smpl = e;
-            else if (e >= n - half) smpl = n - 1 - e;
-            else { smpl = 0; touched = false; }   /* middle sample of an odd block */
-            if (touched) {
-                const double w = g.welch_divisor * (double)smpl * (double)(n - 1 - smpl);
-                v = in * w;
-            }
-        }
-        buf[e] = v;
-    }
-    __syncthreads();
-
-    /* forward: complex FFT of nfft/2 points, then the symmetry pass, then DC / Nyquist */
     fft_complex_lds<R>((cplx *)buf, m, -1, tw_fwd);
-    real_fft_pairs(buf, nfft, -1, rtw_fwd);
+    /* DC / Nyquist bin: x0 = re + im, x1 = re - im, then squared (fft.c:187-191, lpc.c:358-359) */
     if (threadIdx.x == 0) {
         const double h1r = buf[0], im = buf[1];
-        buf[0] = h1r + im;
-        buf[1] = h1r - im;
+        const double a = h1r + im, b = h1r - im;
+        buf[0] = a * a;
+        buf[1] = b * b;
     }
-    __syncthreads();
-    /* power spectrum, lpc.c:357-365 */
-    for (uint32_t k = threadIdx.x; k < m; k += NT) {
-        const double re = buf[2 * k], im = buf[2 * k + 1];
-        if (k == 0) { buf[0] = re * re; buf[1] = im * im; }
-        else { buf[2 * k] = re * re + im * im; buf[2 * k + 1] = 0.0; }
-    }
-    __syncthreads();
-    /* inverse */
-    real_fft_pairs(buf, nfft, 1, rtw_inv);
+    real_fft_pairs<true>(buf, nfft, -1, rtw_fwd);
+    real_fft_pairs<false>(buf, nfft, 1, rtw_inv);
     if (threadIdx.x == 0) {
         const double h1r = buf[0], im = buf[1];
         buf[0] = 0.5 * (h1r + im);
@@ -261,50 +252,6 @@ __device__ void windowed_autocorr(const int32_t *y, double *buf, const SrlaGeom 
     }
     __syncthreads();
     fft_complex_lds<R>((cplx *)buf, m, 1, tw_inv);
-    for (uint32_t i = threadIdx.x; i < num_lags; i += NT)
-        lags_out[i] = (i < nfft) ? buf[i] * g.acorr_norm : 0.0;
-    __syncthreads();
-}
-
-/* --------------------------------------------------------------------- Levinson-Durbin --- */
-/* Runs on wave 0 only.  lev: a_prev[order+3], a_cur[order+3], prod[order+3], err[order+2].
- * Recursion of lpc.c:379-441 up to `upto` (<= order); the gamma dot product is accumulated in
- * index order.  On return the predictor a_{upto}[0..upto] is in *row_out (points into lev). */
-__device__ void levinson_wave0(const double *r, uint32_t upto, double *lev, uint32_t stride,
-                               double *err, double **row_out)
-{
-    const uint32_t lane = threadIdx.x;
-    double *a_prev = lev, *a_cur = lev + stride, *prod = lev + 2 * stride;
-    if (fabs(r[0]) < (double)FLT_EPSILON) {
-        for (uint32_t i = lane; i < upto + 2; i += WAVE) { a_prev[i] = 0.0; }
-        for (uint32_t i = lane; i < upto + 1; i += WAVE) err[i] = r[0];
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        *row_out = a_prev;
-        return;
-    }
-    if (lane == 0) {
-        const double a1 = -r[1] / r[0];
-        a_prev[0] = 1.0;
-        a_prev[1] = a1;
-        a_prev[2] = 0.0;
-        err[0] = r[0];
-        err[1] = r[0] + r[1] * a1;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    for (uint32_t k = 1; k < upto; k++) {
-        for (uint32_t i = lane; i < k + 1; i += WAVE) prod[i] = a_prev[i] * r[k + 1 - i];
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        double gamma = 0.0;
-        for (uint32_t i = 0; i < k + 1; i++) gamma += prod[i];   /* every lane: same order, same value */
-        const double ek = err[k];
-        gamma /= -ek;
-        if (lane == 0) err[k + 1] = ek * (1.0 - gamma * gamma);
-        for (uint32_t i = lane; i < k + 2; i += WAVE) a_cur[i] = a_prev[i] + gamma * a_prev[k + 1 - i];
-        if (lane == 0) a_cur[k + 2] = 0.0;
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        double *t = a_prev; a_prev = a_cur; a_cur = t;
-    }
-    *row_out = a_prev;
 }
 
 /* ------------------------------------------------------------ order choice (H2: libm) ----- */
@@ -328,318 +275,584 @@ __device__ __forceinline__ double inv_sqrt_cr(double x)
     return r + r * (e - s_lo * r);
 }
 
-/* ------------------------------------------------------------------------- kernel A ------- */
+/* ================================================================================================
+ * K1: srla_autocorr -- pass 0: LPC lags (after the LTP filter when a pitch was found),
+ *                      pass 1: LTP lags.
+ * ============================================================================================== */
+struct SmallA {
+    long long lscratch[2 * NWAVES];
+    uint32_t uscratch[NWAVES];
+    int32_t preemph_coef;
+    uint32_t flags;
+    uint32_t pad[2];
+};
+
+extern "C" uint32_t srla_kernel_small_a_bytes(void) { return (uint32_t)((sizeof(SmallA) + 15) & ~15u); }
+
 template <int R>
-__global__ __launch_bounds__(NT) void srla_analyze_items(
+__global__ __launch_bounds__(NT) void srla_autocorr(
     SrlaJobParams jp, const int32_t *__restrict__ input, const SrlaItemDesc *__restrict__ items,
-    uint32_t item_first, const SrlaGeom *__restrict__ geoms, const cplx *__restrict__ twiddles,
-    SrlaLdsPlan plan, const double *__restrict__ rice_thresholds, const uint8_t *__restrict__ huff_len,
-    int32_t *__restrict__ res_ws, SrlaItemResult *__restrict__ results, double *__restrict__ dbg)
+    const SrlaGeom *__restrict__ geoms, const cplx *__restrict__ twiddles, uint32_t fft_bytes, uint32_t pass,
+    SrlaItemResult *__restrict__ results, double *__restrict__ lags_ws, double *__restrict__ dbg)
 {
+    constexpr int CH = 2 * R;   /* chunks of four samples per thread: covers 2048 * R >= nfft */
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    int32_t *y = (int32_t *)(lds + plan.y_off);
-    double *fftbuf = (double *)(lds + plan.fft_off);
-    double *lev = (double *)(lds + plan.lev_off);
-    double *means = (double *)(lds + plan.means_off);
-    Small *sm = (Small *)(lds + plan.small_off);
+    double *buf = (double *)lds;
+    SmallA *sm = (SmallA *)(lds + fft_bytes);
 
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t item_idx = item_first + blockIdx.x;
+    const uint32_t item_idx = blockIdx.x;
+    const SrlaItemDesc it = items[item_idx];
+    const SrlaGeom g = geoms[it.geom];
+    const uint32_t n = it.n, nfft = g.nfft, bps = jp.bits_per_sample;
+    const int32_t *in = input + it.sample_off;
+    const bool aligned = input_aligned(in, jp);
+    const bool first_pass = (pass == 1) || (jp.ltp_order == 0);   /* the pass that owns the pre-emphasis tap */
+    SrlaItemResult *out = &results[item_idx];
+
+    int32_t v[CH][4];
+    int32_t pv[CH];
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+        const uint32_t i4 = 4u * (tid + (uint32_t)c * NT);
+        load_chunk(in, jp, it.variant, i4, n, aligned, v[c]);
+        pv[c] = (i4 == 0 || i4 >= n) ? v[c][0] : load_variant(in, jp, it.variant, i4 - 1);
+    }
+
+    int32_t coef;
+    if (first_pass) {
+        /* exact integer correlations r0 = sum x^2, r1 = sum x[i] x[i+1] (srla_utility.c:226-240) */
+        long long r0 = 0, r1 = 0;
+        uint32_t absmax = 0;
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+            const uint32_t i4 = 4u * (tid + (uint32_t)c * NT);
+            const int32_t nx = (i4 + 4 < n) ? load_variant(in, jp, it.variant, i4 + 4) : 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const long long x = v[c][i];
+                const long long y = (i < 3) ? (long long)v[c][i + 1] : (long long)nx;
+                r0 += x * x;
+                r1 += x * y;
+                const uint32_t a = (v[c][i] < 0) ? (uint32_t)(-(int64_t)v[c][i]) : (uint32_t)v[c][i];
+                absmax = (a > absmax) ? a : absmax;
+            }
+        }
+        r0 = wave_sum_i64(r0); r1 = wave_sum_i64(r1); absmax = wave_max_u32(absmax);
+        if (lane == 0) { sm->lscratch[wave] = r0; sm->lscratch[NWAVES + wave] = r1; sm->uscratch[wave] = absmax; }
+        __syncthreads();
+        if (tid == 0) {
+            long long s0 = 0, s1 = 0; uint32_t am = 0;
+            for (int w = 0; w < NWAVES; w++) { s0 += sm->lscratch[w]; s1 += sm->lscratch[NWAVES + w]; am = (sm->uscratch[w] > am) ? sm->uscratch[w] : am; }
+            uint32_t flags = (n & 1u) ? SRLA_ITEM_ODD_LENGTH : 0u;
+            if (am == 0) flags |= SRLA_ITEM_INPUT_ZERO;
+            double d0, d1;
+            if (am < (1u << 23) && s0 < (1LL << 53)) {
+                /* every partial sum of the reference's double accumulation is an exactly representable
+                 * integer, so the summation order does not matter */
+                d0 = (double)s0; d1 = (double)s1;
+            } else {
+                /* srla_utility.c:226-240 literally (rounding depends on the order) */
+                double curr = load_variant(in, jp, it.variant, 0), succ = load_variant(in, jp, it.variant, 1);
+                d0 = 0.0; d1 = 0.0;
+                for (uint32_t i = 0; i + 2 < n; i++) {
+                    const double nn = load_variant(in, jp, it.variant, i + 2);
+                    d0 += curr * curr; d1 += curr * succ; curr = succ; succ = nn;
+                }
+                d0 += curr * curr; d1 += curr * succ; curr = succ; d0 += curr * curr;
+            }
+            int32_t c = 0;
+            if (!(d0 < 1e-6)) {
+                c = (int32_t)round_half_away((d1 / d0) * 16.0);
+                c = (c < -16) ? -16 : ((c > 15) ? 15 : c);
+            }
+            sm->preemph_coef = c;
+            /* this pass initialises the item record */
+            out->preemph_prev = load_variant(in, jp, it.variant, 0);
+            out->preemph_coef = c;
+            out->lpc_order = 0; out->lpc_rshift = 0; out->use_sum = 0; out->ltp_period = 0;
+            out->ltp_coef[0] = 0; out->ltp_coef[1] = 0; out->ltp_coef[2] = 0;
+            out->code_length = 0; out->res_code_type = 0; out->res_porder = 0; out->res_bits = 0;
+            out->flags = flags; out->pad[0] = 0; out->pad[1] = 0;
+        }
+        __syncthreads();
+        coef = sm->preemph_coef;
+    } else {
+        coef = out->preemph_coef;
+    }
+    if (pass == 0 && jp.max_order == 0) return;   /* preset 0: fixed order 0, no LPC analysis needed */
+
+    /* pre-emphasis in registers: y[i] = x[i] - ((x[i-1] * coef) >> 4), x[-1] = x[0] (srla_utility.c:342) */
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+        int32_t prev = pv[c];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int32_t cur = v[c][i];
+            v[c][i] = (int32_t)((uint32_t)cur - (uint32_t)((int32_t)((uint32_t)prev * (uint32_t)coef) >> 4));
+            prev = cur;
+        }
+    }
+
+    if (pass == 0 && jp.ltp_order > 0) {
+        const uint32_t period = out->ltp_period;
+        if (period > 0) {
+            /* long-term predictor (srla_lpc_predict.c:267-294): stage y in LDS, filter into registers */
+            int32_t *ylds = (int32_t *)buf;
+            const uint32_t taps = jp.ltp_order, half_order = taps >> 1;
+            const int32_t c0 = out->ltp_coef[0], c1 = out->ltp_coef[1], c2 = out->ltp_coef[2];
+#pragma unroll
+            for (int c = 0; c < CH; c++) {
+                const uint32_t i4 = 4u * (tid + (uint32_t)c * NT);
+                if (i4 < nfft) *reinterpret_cast<int4 *>(ylds + i4) = make_int4(v[c][0], v[c][1], v[c][2], v[c][3]);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < CH; c++) {
+                const uint32_t i4 = 4u * (tid + (uint32_t)c * NT);
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const uint32_t s = i4 + i;
+                    if (s < n && s >= period + half_order + 1) {
+                        const uint32_t base = s - period - half_order;
+                        uint32_t acc = 16u + (uint32_t)c0 * (uint32_t)ylds[base];
+                        if (taps == 3) acc += (uint32_t)c1 * (uint32_t)ylds[base + 1] + (uint32_t)c2 * (uint32_t)ylds[base + 2];
+                        v[c][i] = (int32_t)((uint32_t)v[c][i] - (uint32_t)((int32_t)acc >> 5));
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    /* Welch window (lpc.c:256-266) on the [-1,1) normalised signal, zero padded to nfft */
+    {
+        const double norm_bps = __builtin_ldexp(1.0, -(int)(bps - 1));
+        const uint32_t half = n >> 1;
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+            const uint32_t i4 = 4u * (tid + (uint32_t)c * NT);
+            if (i4 < nfft) {
+                double w[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const uint32_t e = i4 + i;
+                    double val = 0.0;
+                    if (e < n) {
+                        uint32_t smpl; bool touched = true;
+                        if (e < half) smpl = e;
+                        else if (e >= n - half) smpl = n - 1 - e;
+                        else { smpl = 0; touched = false; }   /* middle sample of an odd block */
+                        if (touched) {
+                            const double in_d = (double)v[c][i] * norm_bps;
+                            const double wt = g.welch_divisor * (double)smpl * (double)(n - 1 - smpl);
+                            val = in_d * wt;
+                        }
+                    }
+                    w[i] = val;
+                }
+                *reinterpret_cast<double2 *>(buf + i4) = make_double2(w[0], w[1]);
+                *reinterpret_cast<double2 *>(buf + i4 + 2) = make_double2(w[2], w[3]);
+            }
+        }
+        __syncthreads();
+    }
+
+    autocorr_in_place<R>(buf, nfft, twiddles + g.tw_off);
+
+    const uint32_t num_lags = (pass == 1) ? SRLA_LTP_LAGS : (jp.max_order + 1);
+    const size_t stride = jp.num_items;
+    for (uint32_t i = tid; i < num_lags; i += NT) {
+        const double lag = (i < nfft) ? buf[i] * g.acorr_norm : 0.0;
+        lags_ws[(size_t)i * stride + item_idx] = lag;
+        if (dbg) dbg[(size_t)item_idx * SRLA_DBG_STRIDE + ((pass == 1) ? SRLA_DBG_LTPLAGS : SRLA_DBG_LAGS) + i] = lag;
+    }
+}
+
+/* ================================================================================================
+ * K2p: srla_pitch_solve -- one lane per item (lpc.c:1473-1649, srla_encoder.c:1031-1047)
+ * ============================================================================================== */
+__global__ __launch_bounds__(WAVE) void srla_pitch_solve(SrlaJobParams jp, const double *__restrict__ lags_ws,
+                                                         SrlaItemResult *__restrict__ results)
+{
+    const uint32_t idx = blockIdx.x * WAVE + threadIdx.x;
+    if (idx >= jp.num_items) return;
+    const size_t stride = jp.num_items;
+    /* words 263 and 264 of the reference's lag buffer are never written: zero (fresh pages) */
+    auto R = [&](uint32_t j) -> double { return (j < SRLA_LTP_LAGS) ? lags_ws[(size_t)j * stride + idx] : 0.0; };
+    SrlaItemResult *out = &results[idx];
+    const double r0 = R(0);
+    uint32_t period = 0;
+    if (!(fabs(r0) <= (double)FLT_MIN)) {
+        uint32_t cand[20]; uint32_t ncand = 0, i = SRLA_LTP_MIN_PERIOD; double best = 0.0;
+        const uint32_t maxp = SRLA_LTP_MAX_PERIOD;
+        while (i < maxp && ncand < 20) {
+            uint32_t start, end, peak_at = 0; double peak = 0.0;
+            for (start = i; start < maxp; start++) if (R(start - 1) < 0.0 && R(start) > 0.0) break;
+            for (end = start + 1; end < maxp - 1; end++) if (R(end) > 0.0 && R(end + 1) < 0.0) break;
+            double rm = R(start - 1), rc = R(start);
+            for (uint32_t j = start; j <= end; j++) {
+                const double rn = R(j + 1);
+                if (rc > rm && rc > rn && rc > peak) { peak_at = j; peak = rc; }
+                rm = rc; rc = rn;
+            }
+            if (peak_at != 0) { cand[ncand++] = peak_at; if (peak > best) best = peak; }
+            i = end + 1;
+        }
+        if (ncand > 0 && !(best < 0.1 * r0)) {
+            for (uint32_t k = 0; k < ncand; k++)
+                if (R(cand[k]) >= 0.9 * best) { period = cand[k]; break; }
+        }
+        if (period < (jp.ltp_order / 2) + 1) period = 0;
+    }
+    uint32_t flags = 0;
+    int32_t q[3] = { 0, 0, 0 };
+    if (period > 0) {
+        const int dim = (int)jp.ltp_order;
+        const double rl[3] = { r0 * (1.0 + 1e-5), R(1), R(2) };
+        double am[3][3], inv_diag[3], xs[3];
+        bool ok = true;
+        for (int j = 0; j < dim; j++) for (int k = j; k < dim; k++) am[j][k] = am[k][j] = rl[k - j];
+        for (int i2 = 0; i2 < dim && ok; i2++) {
+            double sum = am[i2][i2];
+            for (int k = i2 - 1; k >= 0; k--) sum -= am[i2][k] * am[i2][k];
+            if (sum <= 0.0) { ok = false; break; }
+            inv_diag[i2] = inv_sqrt_cr(sum);
+            for (int j = i2 + 1; j < dim; j++) {
+                sum = am[i2][j];
+                for (int k = i2 - 1; k >= 0; k--) sum -= am[i2][k] * am[j][k];
+                am[j][i2] = sum * inv_diag[i2];
+            }
+        }
+        if (!ok) { flags |= SRLA_ITEM_LTP_FAIL; period = 0; }
+        else {
+            double b[3] = { 0.0, 0.0, 0.0 };
+            for (int i2 = 0; i2 < dim; i2++) {
+                const uint32_t j = period - jp.ltp_order / 2 + (uint32_t)i2;
+                b[i2] = (j == 0) ? rl[0] : R(j);
+            }
+            for (int i2 = 0; i2 < dim; i2++) {
+                double sum = b[i2];
+                for (int j = i2 - 1; j >= 0; j--) sum -= am[i2][j] * xs[j];
+                xs[i2] = sum * inv_diag[i2];
+            }
+            for (int i2 = dim - 1; i2 >= 0; i2--) {
+                double sum = xs[i2];
+                for (int j = i2 + 1; j < dim; j++) sum -= am[j][i2] * xs[j];
+                xs[i2] = sum * inv_diag[i2];
+            }
+            for (int i2 = 0; i2 < dim; i2++) {
+                const double scaled = xs[i2] * 32.0;
+                const double fr = fabs(scaled) + 0.5;
+                if (fabs(fr - floor(fr + 0.5)) < 1e-9 && fabs(scaled) < 40.0) flags |= SRLA_ITEM_LTP_TIE;
+                int32_t c = (int32_t)round_half_away(scaled);
+                c = (c < -32) ? -32 : ((c > 31) ? 31 : c);
+                q[i2] = c;
+            }
+            for (int i2 = 0; i2 < dim / 2; i2++) { const int32_t t = q[i2]; q[i2] = q[dim - 1 - i2]; q[dim - 1 - i2] = t; }
+        }
+    }
+    out->ltp_period = period;
+    out->ltp_coef[0] = (period > 0) ? q[0] : 0;
+    out->ltp_coef[1] = (period > 0) ? q[1] : 0;
+    out->ltp_coef[2] = (period > 0) ? q[2] : 0;
+    if (flags) out->flags |= flags;
+}
+
+/* ================================================================================================
+ * K2: srla_lpc_solve -- one lane per item; a[] and r[] live in LDS column-major ([i][lane]) so that the
+ * 64 recursions of a wavefront run without bank conflicts.  (lpc.c:379-441, 483-497,
+ * srla_encoder.c:934-957, lpc.c:1341-1405, srla_encoder.c:1104-1108, 1141-1174)
+ * ============================================================================================== */
+template <int L>
+__global__ __launch_bounds__(WAVE) void srla_lpc_solve(
+    SrlaJobParams jp, const SrlaItemDesc *__restrict__ items, const SrlaGeom *__restrict__ geoms,
+    const double *__restrict__ lags_ws, const uint8_t *__restrict__ huff_len,
+    SrlaItemResult *__restrict__ results, double *__restrict__ dbg)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t idx = blockIdx.x * L + lane;
+    if (lane >= L || idx >= jp.num_items) return;   /* no barriers below: lanes are independent */
+    const uint32_t p = jp.max_order;
+    double *a = (double *)lds;                        /* a[i * L + lane], i < p + 2 */
+    double *r = a + (size_t)(p + 2) * L;              /* r[i * L + lane], i < p + 1 */
+#define A_(i) a[(size_t)(i) * L + lane]
+#define R_(i) r[(size_t)(i) * L + lane]
+    const SrlaItemDesc it = items[idx];
+    const SrlaGeom g = geoms[it.geom];
+    const uint32_t n = it.n, bps = jp.bits_per_sample;
+    const size_t stride = jp.num_items;
+    double *dbg_item = dbg ? dbg + (size_t)idx * SRLA_DBG_STRIDE : nullptr;
+    SrlaItemResult *out = &results[idx];
+
+    for (uint32_t i = 0; i <= p; i++) R_(i) = lags_ws[(size_t)i * stride + idx];
+    const double r0 = R_(0) * (1.0 + 1e-5);          /* ridge, lpc.c:483 */
+    R_(0) = r0;
+    const bool silent = fabs(r0) < (double)FLT_EPSILON;
+
+    /* first strict minimum of the estimated code length (srla_encoder.c:940-950) */
+    double best_len = (double)FLT_MAX, second = (double)FLT_MAX;
+    uint32_t best_order = 0;
+    auto consider = [&](uint32_t order, double err_uncompensated) {
+        const double ev = err_uncompensated * g.welch_comp;          /* lpc.c:490-497 */
+        const double mabse = 2.0 * sqrt(ev / 2.0);
+        double len = geometric_entropy(mabse, bps) * (double)n;
+        len += (double)(8u * order);
+        if (dbg_item) { dbg_item[SRLA_DBG_ERRVARS + order] = ev; dbg_item[SRLA_DBG_LENS + order] = len; }
+        if (best_len > len) { second = best_len; best_len = len; best_order = order; }
+        else if (second > len) second = len;
+    };
+    if (dbg_item) dbg_item[SRLA_DBG_ERRVARS] = r0 * g.welch_comp;
+
+    auto recursion = [&](uint32_t upto, bool choose) {
+        /* lpc.c:408-438; on return A_(1..upto) is the predictor of order `upto` */
+        const double a1 = -R_(1) / r0;
+        A_(0) = 1.0; A_(1) = a1; A_(2) = 0.0;
+        double e = r0 + R_(1) * a1;
+        if (choose) consider(1, e);
+        for (uint32_t k = 1; k < upto; k++) {
+            double gamma = 0.0;
+            for (uint32_t i = 0; i < k + 1; i++) gamma += A_(i) * R_(k + 1 - i);   /* index order */
+            gamma /= -e;
+            e = e * (1.0 - gamma * gamma);
+            /* a'[i] = a[i] + gamma * a[k+1-i], i = 0..k+1, done pairwise in place */
+            for (uint32_t i = 0, j = k + 1; i <= j; i++, j--) {
+                const double ai = A_(i), aj = A_(j);
+                A_(i) = ai + gamma * aj;
+                if (i != j) A_(j) = aj + gamma * ai;
+            }
+            A_(k + 2) = 0.0;
+            if (choose) consider(k + 1, e);
+        }
+    };
+
+    uint32_t flags = 0;
+    if (p > 0) {
+        if (silent) { for (uint32_t o = 1; o <= p; o++) consider(o, r0); }
+        else recursion(p, true);
+    }
+    uint32_t order = best_order;
+    if (jp.order_fixed) order = p;
+    else if (best_order != 0 && (second - best_len) <= 1e-9 * fabs(best_len) + 1e-9) flags |= SRLA_ITEM_ORDER_TIE;
+    if (it.forced_order >= 0) order = (uint32_t)it.forced_order;
+
+    uint32_t rshift = 0, use_sum = 0, coef_bits = 0;
+    if (order > 0) {
+        if (!silent && order != p) recursion(order, false);
+        /* 8-bit quantisation with error feedback from the last tap (lpc.c:1341-1405); q[] reuses r[] */
+        int32_t *q = (int32_t *)r;
+#define Q_(i) q[(size_t)(i) * (2 * L) + lane]
+        double maxabs = 0.0;
+        if (!silent) for (uint32_t i = 0; i < order; i++) { const double v = fabs(A_(1 + i)); if (maxabs < v) maxabs = v; }
+        if (maxabs <= 0.0078125) {
+            rshift = 8;
+            for (uint32_t i = 0; i < order; i++) Q_(i) = 0;
+        } else {
+            int ndigit;
+            (void)frexp(maxabs, &ndigit);
+            rshift = (uint32_t)(7 - ndigit);
+            if (rshift >= 16u) rshift = 15u;
+            const double scale = __builtin_ldexp(1.0, (int)rshift);
+            double qerr = 0.0;
+            for (int i = (int)order - 1; i >= 0; i--) {
+                qerr += A_(1 + i) * scale;
+                int32_t qq = (int32_t)round_half_away(qerr);
+                if (qq >= 128) qq = 127; else if (qq < -128) qq = -128;
+                qerr -= (double)qq;
+                Q_(order - 1 - i) = qq;          /* reversed: oldest sample first (srla_encoder.c:1104) */
+            }
+        }
+        /* Huffman cost plain vs pair-summed (srla_encoder.c:1141-1174) */
+        uint32_t plain = 0, summed = 0, overflow = 0;
+        int32_t prevq = 0;
+        for (uint32_t k = 0; k < order; k++) {
+            const int32_t c = Q_(k);
+            out->lpc_coef[k] = (int8_t)c;
+            plain += huff_len[zigzag32(c)];
+            if (k == 0) summed += huff_len[zigzag32(c)];
+            else {
+                const uint32_t z = zigzag32(c + prevq);
+                if (z >= 256u) overflow = 1; else summed += huff_len[256 + z];
+            }
+            prevq = c;
+        }
+        use_sum = (overflow == 0 && (order == 1 || summed < plain)) ? 1u : 0u;
+        coef_bits = use_sum ? summed : plain;
+#undef Q_
+    }
+    out->lpc_order = order;
+    out->lpc_rshift = rshift;
+    out->use_sum = use_sum;
+    out->pad[0] = coef_bits;
+    if (flags) out->flags |= flags;
+#undef A_
+#undef R_
+}
+
+/* ================================================================================================
+ * K3: srla_residual_cost -- FIR residual + Rice code-length search, one workgroup per item
+ * ============================================================================================== */
+struct SmallC {
+    int32_t  coefq[FIR_PAD + 8];   /* taps, front padded with zeros to a multiple of four */
+    uint32_t level_bits[16];
+    uint8_t  ktab[2048];           /* heap layout: level p at [2^p - 1, 2^(p+1) - 1) */
+    uint32_t max_u;
+    uint32_t pad[3];
+};
+
+extern "C" uint32_t srla_kernel_small_c_bytes(void) { return (uint32_t)((sizeof(SmallC) + 15) & ~15u); }
+
+template <int R>
+__global__ __launch_bounds__(NT) void srla_residual_cost(
+    SrlaJobParams jp, const int32_t *__restrict__ input, const SrlaItemDesc *__restrict__ items,
+    const SrlaGeom *__restrict__ geoms, SrlaLdsPlan plan, const double *__restrict__ rice_thresholds,
+    int32_t *__restrict__ res_ws, SrlaItemResult *__restrict__ results)
+{
+    constexpr int CH = 2 * R;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    int32_t *sigA = (int32_t *)(lds + plan.y_off);        /* FIR_PAD zeros, then the signal */
+    int32_t *sigB = (int32_t *)(lds + plan.fft_off);      /* LTP output (only when LTP is on) */
+    double *means = (double *)(lds + plan.means_off);
+    SmallC *sm = (SmallC *)(lds + plan.small_off);
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t item_idx = blockIdx.x;
     const SrlaItemDesc it = items[item_idx];
     const SrlaGeom g = geoms[it.geom];
     const uint32_t n = it.n, bps = jp.bits_per_sample;
     const int32_t *in = input + it.sample_off;
-    const double norm_bps = __builtin_ldexp(1.0, -(int)(bps - 1));
-    const cplx *twbase = twiddles + g.tw_off;
-    double *dbg_item = dbg ? dbg + (size_t)item_idx * SRLA_DBG_STRIDE : nullptr;
+    const bool aligned = input_aligned(in, jp);
+    SrlaItemResult *out = &results[item_idx];
+    const int32_t coef = out->preemph_coef;
+    const uint32_t order = out->lpc_order, rshift = out->lpc_rshift, period = out->ltp_period;
+    const uint32_t o4 = (order + 3u) & ~3u;
 
-#define STAMP(k) do { if (dbg_item && tid == 0) dbg_item[SRLA_DBG_TIMES + (k)] = (double)wall_clock64(); } while (0)
-    STAMP(0);
-    if (tid == 0) { sm->flags = (n & 1u) ? SRLA_ITEM_ODD_LENGTH : 0u; sm->max_u = 0; sm->seq_path = 0; sm->period = 0; }
-
-    /* ---- stage the variant in LDS; exact integer correlations for the pre-emphasis tap ---- */
-    uint32_t absmax = 0;
-    for (uint32_t i = tid; i < n; i += NT) {
-        const int32_t v = load_variant(in, jp, it.variant, i);
-        y[i] = v;
-        const uint32_t a = (v < 0) ? (uint32_t)(-(int64_t)v) : (uint32_t)v;
-        absmax = (a > absmax) ? a : absmax;
-    }
-    __syncthreads();
-    long long r0 = 0, r1 = 0;
-    for (uint32_t i = tid; i < n; i += NT) {
-        const long long c = y[i];
-        r0 += c * c;
-        if (i + 1 < n) r1 += c * (long long)y[i + 1];
-    }
-    r0 = wave_sum_i64(r0); r1 = wave_sum_i64(r1); absmax = wave_max_u32(absmax);
-    if (lane == 0) { sm->lscratch[wave] = r0; sm->lscratch[4 + wave] = r1; sm->uscratch[wave] = absmax; }
-    __syncthreads();
-    if (tid == 0) {
-        long long s0 = 0, s1 = 0; uint32_t am = 0;
-        for (int w = 0; w < NWAVES; w++) { s0 += sm->lscratch[w]; s1 += sm->lscratch[4 + w]; am = (sm->uscratch[w] > am) ? sm->uscratch[w] : am; }
-        if (am == 0) sm->flags |= SRLA_ITEM_INPUT_ZERO;
-        double d0, d1;
-        if (am < (1u << 23) && s0 < (1LL << 53)) {
-            /* every partial sum of the reference's double accumulation is an exactly
-             * representable integer, so the summation order does not matter */
-            d0 = (double)s0; d1 = (double)s1;
-        } else {
-            /* srla_utility.c:226-240 literally (rounding depends on the order) */
-            double curr = y[0], succ = y[1];
-            d0 = 0.0; d1 = 0.0;
-            for (uint32_t i = 0; i + 2 < n; i++) {
-                const double nn = y[i + 2];
-                d0 += curr * curr; d1 += curr * succ; curr = succ; succ = nn;
-            }
-            d0 += curr * curr; d1 += curr * succ; curr = succ; d0 += curr * curr;
-            sm->seq_path = 1;
+    int32_t v[CH][4];
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+        const uint32_t i4 = 4u * (tid + (uint32_t)c * NT);
+        load_chunk(in, jp, it.variant, i4, n, aligned, v[c]);
+        int32_t prev = (i4 == 0 || i4 >= n) ? v[c][0] : load_variant(in, jp, it.variant, i4 - 1);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int32_t cur = v[c][i];
+            v[c][i] = (int32_t)((uint32_t)cur - (uint32_t)((int32_t)((uint32_t)prev * (uint32_t)coef) >> 4));
+            prev = cur;
         }
-        int32_t c = 0;
-        if (!(d0 < 1e-6)) {
-            c = (int32_t)round_half_away((d1 / d0) * 16.0);
-            c = (c < -16) ? -16 : ((c > 15) ? 15 : c);
-        }
-        sm->preemph_coef = c;
+        if (i4 < g.nfft) *reinterpret_cast<int4 *>(sigA + FIR_PAD + i4) = make_int4(v[c][0], v[c][1], v[c][2], v[c][3]);
     }
-    __syncthreads();
-    {
-        /* y[i] -= (x[i-1] * coef) >> 4, x[-1] = x[0]; the neighbour is re-derived from the
-         * input so no thread reads an LDS word another thread rewrites (srla_utility.c:342) */
-        const int32_t c = sm->preemph_coef;
-        for (uint32_t i = tid; i < n; i += NT) {
-            const int32_t cur = y[i];
-            const int32_t prev = (i == 0) ? cur : load_variant(in, jp, it.variant, i - 1);
-            y[i] = (int32_t)((uint32_t)cur - (uint32_t)((int32_t)((uint32_t)prev * (uint32_t)c) >> 4));
-        }
-    }
-    const int32_t preemph_prev = load_variant(in, jp, it.variant, 0);
+    for (uint32_t i = tid; i < FIR_PAD; i += NT) { sigA[i] = 0; if (period > 0) sigB[i] = 0; }
+    /* taps, zero padded in FRONT so that the tap loop runs in aligned groups of four */
+    for (uint32_t k = tid; k < o4; k += NT) sm->coefq[k] = (k < o4 - order) ? 0 : (int32_t)out->lpc_coef[k - (o4 - order)];
+    if (tid < 16) sm->level_bits[tid] = 0;
+    if (tid == 0) sm->max_u = 0;
     __syncthreads();
 
-    STAMP(1);
-    /* ---- long-term (pitch) predictor, srla_encoder.c:1010-1057 + lpc.c:1558-1649 ---------- */
-    if (jp.ltp_order > 0) {
-        windowed_autocorr<R>(y, fftbuf, g, norm_bps, twbase, sm->lags, SRLA_LTP_LAGS + 2);
-        if (tid == 0) {
-            double *r = sm->lags;
-            r[SRLA_LTP_LAGS] = 0.0; r[SRLA_LTP_LAGS + 1] = 0.0;   /* never-written words of the reference's buffer */
-            uint32_t period = 0;
-            if (!(fabs(r[0]) <= (double)FLT_MIN)) {
-                /* lpc.c:1473-1555 */
-                uint32_t cand[20]; uint32_t ncand = 0, i = SRLA_LTP_MIN_PERIOD; double best = 0.0;
-                const uint32_t maxp = SRLA_LTP_MAX_PERIOD;
-                while (i < maxp && ncand < 20) {
-                    uint32_t start, end, peak_at = 0; double peak = 0.0;
-                    for (start = i; start < maxp; start++) if (r[start - 1] < 0.0 && r[start] > 0.0) break;
-                    for (end = start + 1; end < maxp - 1; end++) if (r[end] > 0.0 && r[end + 1] < 0.0) break;
-                    for (uint32_t j = start; j <= end; j++)
-                        if (r[j] > r[j - 1] && r[j] > r[j + 1] && r[j] > peak) { peak_at = j; peak = r[j]; }
-                    if (peak_at != 0) { cand[ncand++] = peak_at; if (peak > best) best = peak; }
-                    i = end + 1;
-                }
-                if (ncand > 0 && !(best < 0.1 * r[0])) {
-                    for (uint32_t k = 0; k < ncand; k++)
-                        if (r[cand[k]] >= 0.9 * best) { period = cand[k]; break; }
-                }
-                if (period < (jp.ltp_order / 2) + 1) period = 0;
-            }
-            if (period > 0) {
-                const int dim = (int)jp.ltp_order;
-                double am[3][3], inv_diag[3], xs[3];
-                bool ok = true;
-                r[0] *= (1.0 + 1e-5);
-                for (int j = 0; j < dim; j++) for (int k = j; k < dim; k++) am[j][k] = am[k][j] = r[k - j];
-                for (int i2 = 0; i2 < dim && ok; i2++) {
-                    double sum = am[i2][i2];
-                    for (int k = i2 - 1; k >= 0; k--) sum -= am[i2][k] * am[i2][k];
-                    if (sum <= 0.0) { ok = false; break; }
-                    inv_diag[i2] = inv_sqrt_cr(sum);
-                    for (int j = i2 + 1; j < dim; j++) {
-                        sum = am[i2][j];
-                        for (int k = i2 - 1; k >= 0; k--) sum -= am[i2][k] * am[j][k];
-                        am[j][i2] = sum * inv_diag[i2];
-                    }
-                }
-                if (!ok) { sm->flags |= SRLA_ITEM_LTP_FAIL; period = 0; }
-                else {
-                    const double *b = &r[period - jp.ltp_order / 2];
-                    for (int i2 = 0; i2 < dim; i2++) {
-                        double sum = b[i2];
-                        for (int j = i2 - 1; j >= 0; j--) sum -= am[i2][j] * xs[j];
-                        xs[i2] = sum * inv_diag[i2];
-                    }
-                    for (int i2 = dim - 1; i2 >= 0; i2--) {
-                        double sum = xs[i2];
-                        for (int j = i2 + 1; j < dim; j++) sum -= am[j][i2] * xs[j];
-                        xs[i2] = sum * inv_diag[i2];
-                    }
-                    int32_t q[3] = { 0, 0, 0 };
-                    for (int i2 = 0; i2 < dim; i2++) {
-                        const double scaled = xs[i2] * 32.0;
-                        const double fr = fabs(scaled) + 0.5;
-                        if (fabs(fr - floor(fr + 0.5)) < 1e-9 && fabs(scaled) < 40.0) sm->flags |= SRLA_ITEM_LTP_TIE;
-                        int32_t c = (int32_t)round_half_away(scaled);
-                        c = (c < -32) ? -32 : ((c > 31) ? 31 : c);
-                        q[i2] = c;
-                    }
-                    for (int i2 = 0; i2 < dim / 2; i2++) { const int32_t t = q[i2]; q[i2] = q[dim - 1 - i2]; q[dim - 1 - i2] = t; }
-                    sm->ltp_coef[0] = q[0]; sm->ltp_coef[1] = q[1]; sm->ltp_coef[2] = q[2];
+    const int32_t *src = sigA + FIR_PAD;
+    if (period > 0) {
+        /* long-term predictor, srla_lpc_predict.c:267-294 */
+        const uint32_t taps = jp.ltp_order, half_order = taps >> 1;
+        const int32_t c0 = out->ltp_coef[0], c1 = out->ltp_coef[1], c2 = out->ltp_coef[2];
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+            const uint32_t i4 = 4u * (tid + (uint32_t)c * NT);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t s = i4 + i;
+                if (s < n && s >= period + half_order + 1) {
+                    const uint32_t base = s - period - half_order;
+                    uint32_t acc = 16u + (uint32_t)c0 * (uint32_t)src[base];
+                    if (taps == 3) acc += (uint32_t)c1 * (uint32_t)src[base + 1] + (uint32_t)c2 * (uint32_t)src[base + 2];
+                    v[c][i] = (int32_t)((uint32_t)v[c][i] - (uint32_t)((int32_t)acc >> 5));
                 }
             }
-            sm->period = period;
+            if (i4 < g.nfft) *reinterpret_cast<int4 *>(sigB + FIR_PAD + i4) = make_int4(v[c][0], v[c][1], v[c][2], v[c][3]);
         }
         __syncthreads();
-        if (dbg_item) for (uint32_t i = tid; i < SRLA_LTP_LAGS; i += NT) dbg_item[SRLA_DBG_LTPLAGS + i] = sm->lags[i];
-        const uint32_t period = sm->period;
-        if (period > 0) {
-            /* srla_lpc_predict.c:267-294, out of place through the (idle) FFT buffer */
-            int32_t *tmp = (int32_t *)fftbuf;
-            const uint32_t taps = jp.ltp_order, half_order = taps >> 1;
-            const int32_t c0 = sm->ltp_coef[0], c1 = sm->ltp_coef[1], c2 = sm->ltp_coef[2];
-            for (uint32_t i = tid; i < n; i += NT) {
-                int32_t v = y[i];
-                if (i >= period + half_order + 1) {
-                    const uint32_t base = i - period - half_order;
-                    uint32_t acc = 16u + (uint32_t)c0 * (uint32_t)y[base];
-                    if (taps == 3) acc += (uint32_t)c1 * (uint32_t)y[base + 1] + (uint32_t)c2 * (uint32_t)y[base + 2];
-                    v = (int32_t)((uint32_t)v - (uint32_t)((int32_t)acc >> 5));
-                }
-                tmp[i] = v;
-            }
-            __syncthreads();
-            for (uint32_t i = tid; i < n; i += NT) y[i] = tmp[i];
-            __syncthreads();
-        }
+        src = sigB + FIR_PAD;
     }
 
-    STAMP(2);
-    /* ---- LPC analysis ---------------------------------------------------------------------- */
-    const uint32_t pmax = jp.max_order;
-    uint32_t order = 0;
-    if (pmax > 0) {
-        windowed_autocorr<R>(y, fftbuf, g, norm_bps, twbase, sm->lags, pmax + 1);
-        if (dbg_item) for (uint32_t i = tid; i < pmax + 1; i += NT) dbg_item[SRLA_DBG_LAGS + i] = sm->lags[i];
-        STAMP(3);
-        const uint32_t stride = pmax + 3;
-        double *err = lev + 3 * stride;
-        if (wave == 0) {
-            if (lane == 0) sm->lags[0] *= (1.0 + 1e-5);     /* ridge, lpc.c:483 */
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            double *row;
-            levinson_wave0(sm->lags, pmax, lev, stride, err, &row);
-            /* window power compensation (lpc.c:490-497) and the code-length estimate per order
-             * (srla_encoder.c:934-957), one order per lane */
-            double best_len = (double)FLT_MAX, second = (double)FLT_MAX; uint32_t best_order = 0;
-            for (uint32_t base = 0; base <= pmax; base += WAVE) {
-                const uint32_t o = base + lane;
-                double len = __builtin_nan("");
-                if (o <= pmax) {
-                    const double ev = err[o] * g.welch_comp;
-                    err[o] = ev;
-                    if (o >= 1) {
-                        const double mabse = 2.0 * sqrt(ev / 2.0);
-                        len = geometric_entropy(mabse, bps) * (double)n;
-                        len += (double)(8u * o);
-                    }
-                }
-                if (dbg_item && o <= pmax) { dbg_item[SRLA_DBG_ERRVARS + o] = err[o]; dbg_item[SRLA_DBG_LENS + o] = len; }
-                /* first strict minimum == lowest order among the smallest lengths */
-                for (uint32_t l = 0; l < WAVE; l++) {
-                    const double cl = __shfl(len, (int)l, WAVE);
-                    if (base + l >= 1 && base + l <= pmax) {
-                        if (best_len > cl) { second = best_len; best_len = cl; best_order = base + l; }
-                        else if (second > cl) second = cl;
-                    }
-                }
-            }
-            if (jp.order_fixed) best_order = pmax;
-            else if (best_order != 0 && (second - best_len) <= 1e-9 * fabs(best_len) + 1e-9) {
-                if (lane == 0) sm->flags |= SRLA_ITEM_ORDER_TIE;
-            }
-            if (it.forced_order >= 0) best_order = (uint32_t)it.forced_order;
-            order = best_order;
-            /* recompute the recursion up to the chosen order to get that order's predictor */
-            if (order > 0) {
-                levinson_wave0(sm->lags, order, lev, stride, lev + 4 * stride, &row);
-                if (lane == 0) {
-                    /* 8-bit quantisation with error feedback from the last tap (lpc.c:1341-1405) */
-                    const double *cf = row + 1;
-                    double maxabs = 0.0;
-                    for (uint32_t i = 0; i < order; i++) { const double a = fabs(cf[i]); if (maxabs < a) maxabs = a; }
-                    uint32_t rshift;
-                    if (maxabs <= 0.0078125) {
-                        rshift = 8;
-                        for (uint32_t i = 0; i < order; i++) sm->coef[i] = 0;
-                    } else {
-                        int ndigit;
-                        (void)frexp(maxabs, &ndigit);
-                        rshift = (uint32_t)(7 - ndigit);
-                        if (rshift >= 16u) rshift = 15u;
-                        const double scale = __builtin_ldexp(1.0, (int)rshift);
-                        double qerr = 0.0;
-                        for (int i = (int)order - 1; i >= 0; i--) {
-                            qerr += cf[i] * scale;
-                            int32_t q = (int32_t)round_half_away(qerr);
-                            if (q >= 128) q = 127; else if (q < -128) q = -128;
-                            qerr -= (double)q;
-                            sm->coef[order - 1 - i] = q;       /* reversed: oldest sample first */
-                        }
-                    }
-                    sm->rshift = rshift;
-                }
-            } else if (lane == 0) {
-                sm->rshift = 0;
-            }
-            if (lane == 0) sm->order = order;
-        }
-        __syncthreads();
-        order = sm->order;
-    } else {
-        if (tid == 0) { sm->order = 0; sm->rshift = 0; }
-        __syncthreads();
-    }
-    const uint32_t rshift = sm->rshift;
-
-    STAMP(4);
-    /* ---- integer FIR residual (srla_lpc_predict.c:118-265), zig-zag copy kept in LDS -------- */
-    uint32_t *u = (uint32_t *)fftbuf;
-    int32_t *res_out = res_ws + it.res_off;
+    /* ---- int32 wrap-around FIR (srla_lpc_predict.c:118-265), four outputs per group, taps in fours ---- */
+    uint32_t uz[CH][4];
     {
         const int32_t half = (int32_t)(1u << ((rshift - 1u) & 31u));
-        uint32_t max_u = 0;
-        for (uint32_t s = tid; s < n; s += NT) {
-            int32_t r;
-            if (order == 0) r = y[s];
-            else if (s == 0) r = y[0];
-            else if (s < order) r = (int32_t)((uint32_t)y[s] - (uint32_t)y[s - 1]);
-            else {
-                uint32_t acc = (uint32_t)half;
-                const int32_t *win = y + (s - order);
-                for (uint32_t k = 0; k < order; k++) acc += (uint32_t)sm->coef[k] * (uint32_t)win[k];
-                r = (int32_t)((uint32_t)y[s] + (uint32_t)((int32_t)acc >> rshift));
+        uint32_t acc[CH][4];
+        int4 cur[CH];
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+            const uint32_t i4 = 4u * (tid + (uint32_t)c * NT);
+#pragma unroll
+            for (int i = 0; i < 4; i++) acc[c][i] = (uint32_t)half;
+            cur[c] = (i4 < n) ? *reinterpret_cast<const int4 *>(src + (int)i4 - (int)o4) : make_int4(0, 0, 0, 0);
+        }
+        for (uint32_t kb = 0; kb < o4; kb += 4) {
+            const int4 cf = *reinterpret_cast<const int4 *>(&sm->coefq[kb]);
+#pragma unroll
+            for (int c = 0; c < CH; c++) {
+                const uint32_t i4 = 4u * (tid + (uint32_t)c * NT);
+                if (i4 < n) {
+                    const int4 nxt = *reinterpret_cast<const int4 *>(src + (int)i4 - (int)o4 + (int)kb + 4);
+                    const uint32_t w0 = (uint32_t)cur[c].x, w1 = (uint32_t)cur[c].y, w2 = (uint32_t)cur[c].z, w3 = (uint32_t)cur[c].w;
+                    const uint32_t w4 = (uint32_t)nxt.x, w5 = (uint32_t)nxt.y, w6 = (uint32_t)nxt.z;
+                    const uint32_t f0 = (uint32_t)cf.x, f1 = (uint32_t)cf.y, f2 = (uint32_t)cf.z, f3 = (uint32_t)cf.w;
+                    acc[c][0] += f0 * w0 + f1 * w1 + f2 * w2 + f3 * w3;
+                    acc[c][1] += f0 * w1 + f1 * w2 + f2 * w3 + f3 * w4;
+                    acc[c][2] += f0 * w2 + f1 * w3 + f2 * w4 + f3 * w5;
+                    acc[c][3] += f0 * w3 + f1 * w4 + f2 * w5 + f3 * w6;
+                    cur[c] = nxt;
+                }
             }
-            res_out[s] = r;
-            const uint32_t z = zigzag32(r);
-            u[s] = z;
-            max_u = (z > max_u) ? z : max_u;
+        }
+        uint32_t max_u = 0;
+        int32_t *res_out = res_ws + it.res_off;
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+            const uint32_t i4 = 4u * (tid + (uint32_t)c * NT);
+            if (i4 < n) {
+                int32_t rr[4];
+                /* after the tap loop cur[c] holds src[i4 .. i4+3] */
+                const int32_t y4[4] = { cur[c].x, cur[c].y, cur[c].z, cur[c].w };
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const uint32_t s = i4 + i;
+                    int32_t rv;
+                    if (order == 0 || s == 0) rv = y4[i];
+                    else if (s < order) rv = (int32_t)((uint32_t)y4[i] - (uint32_t)src[s - 1]);
+                    else rv = (int32_t)((uint32_t)y4[i] + (uint32_t)((int32_t)acc[c][i] >> rshift));
+                    if (s >= n) rv = 0;
+                    rr[i] = rv;
+                    const uint32_t z = zigzag32(rv);
+                    uz[c][i] = z;
+                    max_u = (z > max_u) ? z : max_u;
+                }
+                if (i4 + 4 <= n) *reinterpret_cast<int4 *>(res_out + i4) = make_int4(rr[0], rr[1], rr[2], rr[3]);
+                else { for (int i = 0; i < 4; i++) if (i4 + i < n) res_out[i4 + i] = rr[i]; }
+            }
         }
         max_u = wave_max_u32(max_u);
         if (lane == 0) atomicMax(&sm->max_u, max_u);
     }
-    STAMP(5);
-    /* finest-level partition sums (exact integers), srla_coder.c:366-381 */
+    __syncthreads();   /* every FIR read of the signal is done: the zig-zag residual may overwrite it */
+    uint32_t *u = (uint32_t *)(sigA + FIR_PAD);
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+        const uint32_t i4 = 4u * (tid + (uint32_t)c * NT);
+        if (i4 < n) *reinterpret_cast<uint4 *>(u + i4) = make_uint4(uz[c][0], uz[c][1], uz[c][2], uz[c][3]);
+    }
+
+    /* ---- partitioned (recursive) Rice search, srla_coder.c:349-484 -------------------------------- */
     const uint32_t mp = g.max_porder, nparts = 1u << mp, fl = g.fine_len;
     unsigned long long *sums = (unsigned long long *)(means + (nparts - 1));
-    for (uint32_t p = tid; p < nparts; p += NT) sums[p] = 0ull;
-    if (tid < 16) sm->level_bits[tid] = 0;
-    __syncthreads();
     const uint32_t tpp = (nparts >= NT) ? 1u : (NT / nparts);     /* threads per finest partition */
+    if (tpp > 1) { for (uint32_t p = tid; p < nparts; p += NT) sums[p] = 0ull; }
+    __syncthreads();
     if (tpp == 1) {
         for (uint32_t p = tid; p < nparts; p += NT) {
             unsigned long long s = 0;
             const uint32_t *up = u + p * fl;
             for (uint32_t i = 0; i < fl; i++) s += up[i];
-            sums[p] = s;
+            means[(nparts - 1) + p] = (double)s / (double)fl;     /* exact integer sum, srla_coder.c:373-381 */
         }
     } else {
         const uint32_t p = tid / tpp, j = tid % tpp;
@@ -647,21 +860,29 @@ __global__ __launch_bounds__(NT) void srla_analyze_items(
         const uint32_t *up = u + p * fl;
         for (uint32_t i = j; i < fl; i += tpp) s += up[i];
         atomicAdd(&sums[p], s);
+        __syncthreads();
+        for (uint32_t q = tid; q < nparts; q += NT) { const unsigned long long t = sums[q]; means[(nparts - 1) + q] = (double)t / (double)fl; }
     }
     __syncthreads();
-    for (uint32_t p = tid; p < nparts; p += NT) {
-        const unsigned long long s = sums[p];
-        means[(nparts - 1) + p] = (double)s / (double)fl;
-    }
-    __syncthreads();
-    for (int lvl = (int)mp - 1; lvl >= 0; lvl--) {
+    const uint32_t max_u_all = sm->max_u;
+    uint32_t code_type;
+    /* pairwise mean tree (srla_coder.c:385-389): wide levels by the whole workgroup, the narrow top by one wave */
+    int lvl = (int)mp - 1;
+    for (; lvl >= 0 && (1u << lvl) >= WAVE; lvl--) {
         const uint32_t cnt = 1u << lvl;
         for (uint32_t p = tid; p < cnt; p += NT)
             means[(cnt - 1) + p] = (means[(2 * cnt - 1) + 2 * p] + means[(2 * cnt - 1) + 2 * p + 1]) / 2.0;
         __syncthreads();
     }
-    uint32_t code_type;
-    if (sm->max_u == 0) code_type = SRLA_CODE_ALLZERO;
+    if (tid < WAVE) {
+        for (; lvl >= 0; lvl--) {
+            const uint32_t cnt = 1u << lvl;
+            if (tid < cnt) means[(cnt - 1) + tid] = (means[(2 * cnt - 1) + 2 * tid] + means[(2 * cnt - 1) + 2 * tid + 1]) / 2.0;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        }
+    }
+    __syncthreads();
+    if (max_u_all == 0) code_type = SRLA_CODE_ALLZERO;
     else if (means[0] < 2) code_type = SRLA_CODE_RICE;
     else code_type = SRLA_CODE_RECURSIVE_RICE;
 
@@ -682,7 +903,9 @@ __global__ __launch_bounds__(NT) void srla_analyze_items(
             sm->ktab[e] = (uint8_t)k;
         }
         __syncthreads();
-        /* cost of every partition order in one pass over the residual */
+        /* cost of every partition order in one pass over the residual; side information per level:
+         * 10 bits of partition order, 5 bits for the first parameter, zig-zag(delta) + 1 per further
+         * partition (srla_coder.c:415-427) */
         uint32_t acc[SRLA_MAX_PORDER + 1];
 #pragma unroll
         for (int l = 0; l <= SRLA_MAX_PORDER; l++) acc[l] = 0;
@@ -694,18 +917,26 @@ __global__ __launch_bounds__(NT) void srla_analyze_items(
                 const uint32_t *up = u + p * fl;
                 uint32_t kk[SRLA_MAX_PORDER + 1];
 #pragma unroll
-                for (int l = 0; l <= SRLA_MAX_PORDER; l++)
-                    kk[l] = ((uint32_t)l <= mp) ? sm->ktab[((1u << l) - 1) + (p >> (mp - l))] : 0u;
+                for (int l = 0; l <= SRLA_MAX_PORDER; l++) {
+                    kk[l] = 0;
+                    if ((uint32_t)l <= mp) {
+                        const uint32_t pl = p >> (mp - l), e = ((1u << l) - 1) + pl;
+                        kk[l] = sm->ktab[e];
+                        /* the first thread of the first fine partition of a level-l partition books its side info */
+                        if (j_first == 0 && (p & ((1u << (mp - l)) - 1)) == 0)
+                            acc[l] += (pl == 0) ? 15u : (zigzag32((int32_t)kk[l] - (int32_t)sm->ktab[e - 1]) + 1u);
+                    }
+                }
                 for (uint32_t i = j_first; i < fl; i += j_step) {
-                    const uint32_t v = up[i];
+                    const uint32_t val = up[i];
 #pragma unroll
                     for (int l = 0; l <= SRLA_MAX_PORDER; l++) {
                         if ((uint32_t)l <= mp) {
                             const uint32_t k = kk[l];
                             if (code_type == SRLA_CODE_RICE) {
-                                acc[l] += 1u + k + (v >> k);                      /* srla_coder.c:327-330 */
+                                acc[l] += 1u + k + (val >> k);                      /* srla_coder.c:327-330 */
                             } else {
-                                int32_t over = (int32_t)v - (int32_t)(2u << k);  /* srla_coder.c:333-347 */
+                                int32_t over = (int32_t)val - (int32_t)(2u << k);  /* srla_coder.c:333-347 */
                                 over = (over > 0) ? over : 0;
                                 acc[l] += (k + 2u) + ((uint32_t)over >> k);
                             }
@@ -721,77 +952,31 @@ __global__ __launch_bounds__(NT) void srla_analyze_items(
                 if (lane == 0) atomicAdd(&sm->level_bits[l], s);
             }
         }
-        /* side information: 10 bits of partition order, 5 bits for the first parameter, then
-         * zig-zag(delta) + 1 per further partition (srla_coder.c:415-427) */
-        for (uint32_t e = tid; e < 2 * nparts - 1; e += NT) {
-            const uint32_t lvl = 31u - (uint32_t)__clz((int)(e + 1));
-            const uint32_t p = e + 1 - (1u << lvl);
-            uint32_t side;
-            if (p == 0) side = 10u + 5u;
-            else side = zigzag32((int32_t)sm->ktab[e] - (int32_t)sm->ktab[e - 1]) + 1u;
-            atomicAdd(&sm->level_bits[lvl], side);
-        }
         __syncthreads();
         best_bits = 0xFFFFFFFFu;
         for (uint32_t l = 0; l <= mp; l++) {
             const uint32_t b = sm->level_bits[l];
             if (b < best_bits) { best_bits = b; best_porder = l; }
         }
-    }
-    const uint32_t res_bits = best_bits + 2u;
-    STAMP(6);
-
-    /* ---- coefficient cost (srla_encoder.c:1121-1187) and the item record -------------------- */
-    SrlaItemResult *out = &results[item_idx];
-    if (code_type != SRLA_CODE_ALLZERO)
         for (uint32_t p = tid; p < (1u << best_porder); p += NT) out->kparam[p] = sm->ktab[((1u << best_porder) - 1) + p];
-    for (uint32_t k = tid; k < order; k += NT) out->lpc_coef[k] = (int8_t)sm->coef[k];
-    if (wave == 0) {
-        uint32_t plain = 0, summed = 0, overflow = 0;
-        for (uint32_t k = lane; k < order; k += WAVE) {
-            const int32_t c = sm->coef[k];
-            plain += huff_len[zigzag32(c)];
-            if (k == 0) summed += huff_len[zigzag32(c)];
-            else {
-                const uint32_t z = zigzag32(c + sm->coef[k - 1]);
-                if (z >= 256u) overflow = 1; else summed += huff_len[256 + z];
-            }
-        }
-        plain = wave_sum_u32(plain); summed = wave_sum_u32(summed); overflow = wave_sum_u32(overflow);
-        if (lane == 0) {
-            uint32_t use_sum = 0, coef_bits = 0;
-            if (order > 0) {
-                use_sum = (overflow == 0 && (order == 1 || summed < plain)) ? 1u : 0u;
-                coef_bits = use_sum ? summed : plain;
-            }
-            uint32_t bits = res_bits;
-            bits += bps + 1u;              /* pre-emphasis state */
-            bits += 5u;                    /* pre-emphasis tap   */
-            bits += 8u + 4u + 1u;          /* order, shift, sum flag */
-            bits += coef_bits;
-            bits += 1u;                    /* LTP flag */
-            const uint32_t period = sm->period;
-            if (period > 0) bits += 1u + 8u + jp.ltp_order * 6u;
-            out->preemph_prev = preemph_prev;
-            out->preemph_coef = sm->preemph_coef;
-            out->lpc_order = order;
-            out->lpc_rshift = rshift;
-            out->use_sum = use_sum;
-            out->ltp_period = period;
-            out->ltp_coef[0] = (period > 0) ? sm->ltp_coef[0] : 0;
-            out->ltp_coef[1] = (period > 0) ? sm->ltp_coef[1] : 0;
-            out->ltp_coef[2] = (period > 0) ? sm->ltp_coef[2] : 0;
-            out->code_length = bits;
-            out->res_code_type = code_type;
-            out->res_porder = best_porder;
-            out->res_bits = res_bits;
-            out->flags = sm->flags;
-            out->pad[0] = 0; out->pad[1] = 0;
-        }
+    }
+    if (tid == 0) {
+        const uint32_t res_bits = best_bits + 2u;
+        uint32_t bits = res_bits;                 /* srla_encoder.c:1121-1187 */
+        bits += bps + 1u;                         /* pre-emphasis state */
+        bits += 5u;                               /* pre-emphasis tap   */
+        bits += 8u + 4u + 1u;                     /* order, shift, sum flag */
+        bits += out->pad[0];                      /* tap codes (srla_lpc_solve) */
+        bits += 1u;                               /* LTP flag */
+        if (period > 0) bits += 1u + 8u + jp.ltp_order * 6u;
+        out->code_length = bits;
+        out->res_code_type = code_type;
+        out->res_porder = best_porder;
+        out->res_bits = res_bits;
     }
 }
 
-/* ------------------------------------------------------------------------- kernel B ------- */
+/* ------------------------------------------------------------------------- pricing -------- */
 /* One thread per window.  Block cost: ComputeBlockSize (srla_encoder.c:1477-1546) on top of the
  * stereo decision of ComputeCoefficients (:1275-1327); path: ApplyDijkstraMethod (:249-307)
  * with its exact tie behaviour; partition read-back (:397-421). */
@@ -805,7 +990,6 @@ __global__ void srla_price_windows(SrlaJobParams jp, const SrlaWindowDesc *__res
     const SrlaWindowDesc wd = windows[w];
     const uint32_t nch = jp.num_channels, bps = jp.bits_per_sample, nodes = wd.num_nodes;
 
-    /* candidate costs */
     for (uint32_t c = 0; c < wd.num_cands; c++) {
         const SrlaCandDesc cd = cands[wd.cand_base + c];
         const uint32_t raw_bytes = 11u + (bps * cd.n * nch) / 8u;
@@ -900,10 +1084,9 @@ __global__ void srla_price_windows(SrlaJobParams jp, const SrlaWindowDesc *__res
     for (uint32_t k = count; k < nodes - 1; k++) blocks[wd.block_base + k].valid = 0;
 }
 
-/* ------------------------------------------------------------------------- kernel C ------- */
-/* grid = (block slots, channels).  Residuals of compress blocks (raw shifted-back samples for
- * RAW blocks) land at the block's own sample positions of out[ch][...]; the chosen item records
- * are copied next to them. */
+/* ------------------------------------------------------------------------- gather --------- */
+/* grid = (block slots, channels).  Residuals of compress blocks (original samples for RAW blocks) land
+ * at the block's own sample positions of out[ch][...]; the chosen item records are copied next to them. */
 __global__ __launch_bounds__(NT) void srla_gather_blocks(
     SrlaJobParams jp, const int32_t *__restrict__ input, const SrlaItemDesc *__restrict__ items,
     const SrlaBlockRecord *__restrict__ blocks, const SrlaItemResult *__restrict__ results,
@@ -931,37 +1114,94 @@ __global__ __launch_bounds__(NT) void srla_gather_blocks(
 __global__ __launch_bounds__(NT) void srla_or_reduce(const int32_t *__restrict__ in, size_t count, uint32_t *__restrict__ out)
 {
     uint32_t m = 0;
-    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < count; i += (size_t)gridDim.x * NT) m |= (uint32_t)in[i];
+    const size_t start = ((size_t)blockIdx.x * NT + threadIdx.x) * 4, step = (size_t)gridDim.x * NT * 4;
+    const bool aligned = (reinterpret_cast<uintptr_t>(in) & 15u) == 0;
+    for (size_t i = start; i < count; i += step) {
+        if (aligned && i + 4 <= count) {
+            const int4 a = *reinterpret_cast<const int4 *>(in + i);
+            m |= (uint32_t)a.x | (uint32_t)a.y | (uint32_t)a.z | (uint32_t)a.w;
+        } else {
+            for (size_t k = i; k < count && k < i + 4; k++) m |= (uint32_t)in[k];
+        }
+    }
     for (int off = 32; off > 0; off >>= 1) m |= __shfl_down(m, off, WAVE);
     if ((threadIdx.x & 63) == 0 && m) atomicOr(out, m);
 }
 
 /* --------------------------------------------------------------------------- launchers ---- */
-extern "C" int srla_launch_analyze(hipStream_t stream, int regs_per_thread_class, uint32_t num_items_in_group,
-                                   const SrlaJobParams *jp, const int32_t *input, const SrlaItemDesc *items,
-                                   uint32_t item_first, const SrlaGeom *geoms, const void *twiddles,
-                                   const SrlaLdsPlan *plan, const double *rice_thresholds, const uint8_t *huff_len,
-                                   int32_t *res_ws, SrlaItemResult *results, double *dbg)
-{
-    if (num_items_in_group == 0) return 0;
-    dim3 grid(num_items_in_group), block(NT);
-#define LAUNCH(RR)                                                                                          \
-    do {                                                                                                    \
-        static bool attr_set_##RR = false;                                                                  \
-        if (!attr_set_##RR) {                                                                               \
-            (void)hipFuncSetAttribute((const void *)srla_analyze_items<RR>,                                 \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);              \
-            attr_set_##RR = true;                                                                           \
-        }                                                                                                   \
-        hipLaunchKernelGGL(srla_analyze_items<RR>, grid, block, plan->total, stream, *jp, input, items,     \
-                           item_first, geoms, (const cplx *)twiddles, *plan, rice_thresholds, huff_len,     \
-                           res_ws, results, dbg);                                                           \
+#define SET_LDS_ATTR(fn)                                                                                     \
+    do {                                                                                                     \
+        static bool done_ = false;                                                                           \
+        if (!done_) { (void)hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done_ = true; } \
     } while (0)
-    switch (regs_per_thread_class) {
+
+extern "C" int srla_launch_autocorr(hipStream_t stream, int rclass, const SrlaJobParams *jp, const int32_t *input,
+                                    const SrlaItemDesc *items, const SrlaGeom *geoms, const void *twiddles,
+                                    uint32_t fft_bytes, uint32_t pass, SrlaItemResult *results, double *lags_ws, double *dbg)
+{
+    if (jp->num_items == 0) return 0;
+    const uint32_t lds = fft_bytes + srla_kernel_small_a_bytes();
+    dim3 grid(jp->num_items), block(NT);
+#define LAUNCH(RR)                                                                                           \
+    do {                                                                                                     \
+        SET_LDS_ATTR(srla_autocorr<RR>);                                                                     \
+        hipLaunchKernelGGL(srla_autocorr<RR>, grid, block, lds, stream, *jp, input, items, geoms,            \
+                           (const cplx *)twiddles, fft_bytes, pass, results, lags_ws, dbg);                  \
+    } while (0)
+    switch (rclass) {
     case 1: LAUNCH(1); break;
     case 2: LAUNCH(2); break;
     case 4: LAUNCH(4); break;
-    case 8: LAUNCH(8); break;
+    default: return -1;
+    }
+#undef LAUNCH
+    return (hipGetLastError() == hipSuccess) ? 0 : -2;
+}
+
+extern "C" int srla_launch_pitch_solve(hipStream_t stream, const SrlaJobParams *jp, const double *lags_ws,
+                                       SrlaItemResult *results)
+{
+    if (jp->num_items == 0) return 0;
+    hipLaunchKernelGGL(srla_pitch_solve, dim3((jp->num_items + WAVE - 1) / WAVE), dim3(WAVE), 0, stream, *jp, lags_ws, results);
+    return (hipGetLastError() == hipSuccess) ? 0 : -2;
+}
+
+extern "C" int srla_launch_lpc_solve(hipStream_t stream, const SrlaJobParams *jp, const SrlaItemDesc *items,
+                                     const SrlaGeom *geoms, const double *lags_ws, const uint8_t *huff_len,
+                                     SrlaItemResult *results, double *dbg)
+{
+    if (jp->num_items == 0) return 0;
+    const uint32_t p = jp->max_order;
+    if (p <= 128) {
+        const uint32_t lds = (2 * p + 3) * 8 * 64;
+        SET_LDS_ATTR(srla_lpc_solve<64>);
+        hipLaunchKernelGGL(srla_lpc_solve<64>, dim3((jp->num_items + 63) / 64), dim3(WAVE), lds, stream,
+                           *jp, items, geoms, lags_ws, huff_len, results, dbg);
+    } else {
+        const uint32_t lds = (2 * p + 3) * 8 * 32;
+        SET_LDS_ATTR(srla_lpc_solve<32>);
+        hipLaunchKernelGGL(srla_lpc_solve<32>, dim3((jp->num_items + 31) / 32), dim3(WAVE), lds, stream,
+                           *jp, items, geoms, lags_ws, huff_len, results, dbg);
+    }
+    return (hipGetLastError() == hipSuccess) ? 0 : -2;
+}
+
+extern "C" int srla_launch_residual_cost(hipStream_t stream, int rclass, const SrlaJobParams *jp, const int32_t *input,
+                                         const SrlaItemDesc *items, const SrlaGeom *geoms, const SrlaLdsPlan *plan,
+                                         const double *rice_thresholds, int32_t *res_ws, SrlaItemResult *results)
+{
+    if (jp->num_items == 0) return 0;
+    dim3 grid(jp->num_items), block(NT);
+#define LAUNCH(RR)                                                                                           \
+    do {                                                                                                     \
+        SET_LDS_ATTR(srla_residual_cost<RR>);                                                                \
+        hipLaunchKernelGGL(srla_residual_cost<RR>, grid, block, plan->total, stream, *jp, input, items, geoms, \
+                           *plan, rice_thresholds, res_ws, results);                                         \
+    } while (0)
+    switch (rclass) {
+    case 1: LAUNCH(1); break;
+    case 2: LAUNCH(2); break;
+    case 4: LAUNCH(4); break;
     default: return -1;
     }
 #undef LAUNCH
@@ -993,7 +1233,7 @@ extern "C" int srla_launch_gather(hipStream_t stream, const SrlaJobParams *jp, u
 extern "C" int srla_launch_or_reduce(hipStream_t stream, const int32_t *in, size_t count, uint32_t *out)
 {
     size_t blocks = (count + NT * 16 - 1) / (NT * 16);
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > 4096) blocks = 4096;
     if (blocks == 0) blocks = 1;
     hipLaunchKernelGGL(srla_or_reduce, dim3((uint32_t)blocks), dim3(NT), 0, stream, in, count, out);
     return (hipGetLastError() == hipSuccess) ? 0 : -2;

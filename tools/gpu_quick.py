@@ -81,15 +81,3 @@ for kind in (MUSIC, VARIED):
                 print("ok", kind, nch, cli, g.size, "%.3fs" % tg, flush=True)
 print("mismatches:", nbad, "elapsed %.1f" % (time.time() - t0))
 
-# ---- per-phase latency of one isolated item (100 MHz ticks -> us) -------------------------------
-if os.environ.get("SRLA_PHASES"):
-    names = ["load+preemph", "ltp", "lpc autocorr", "levinson+order+quant", "fir", "code search"]
-    for label, n, cli in (("n4096 -m4", 4096, dict(preset=4, max_block=4096, divisions=1)),
-                          ("n2048 -m4", 2048, dict(preset=4, max_block=4096, divisions=1)),
-                          ("n4096 -m4 P3", 4096, dict(preset=4, max_block=4096, divisions=1, ltp_order=3)),
-                          ("n4096 -m2", 4096, dict(preset=2, max_block=4096, divisions=1))):
-        pcm = synth(MUSIC, 1, 48000, 2, 48000)
-        recs, res, dbg = probe(pcm, n, **cli)
-        recs, res, dbg = probe(pcm, n, **cli)
-        t = dbg[0, 1032:1039]
-        print(label, "order", rec_fields(recs[0])["order"], " ".join("%s=%.1fus" % (nm, (t[i + 1] - t[i]) / 100.0) for i, nm in enumerate(names)), "total=%.1fus" % ((t[6] - t[0]) / 100.0))
