@@ -132,7 +132,9 @@ SRLAApiResult SRLAEncoder_EncodeWhole(
  * (one process per GPU is the intended deployment; default device 0). Returns 0 on success. */
 int SRLAMI355X_SetDevice(int device_index);
 
-/* Number of host threads the bit-packer may use (default: min(hardware threads, 16)). */
+/* Number of host threads the bit-packer may use (default: min(hardware threads, 16), or the
+ * SRLA_MI355X_PACK_THREADS environment variable).  With several processes per node (one per GPU) give
+ * each process hardware_threads / processes. */
 void SRLAMI355X_SetPackThreads(struct SRLAEncoder *encoder, uint32_t num_threads);
 
 /* EncodeWhole for samples already resident in HBM: d_input is a device pointer to planar
@@ -154,7 +156,7 @@ struct SRLAMI355XStats {
     uint64_t analyze_launches;
     double   analyze_ms;         /* HIP-event time of the item-analysis kernels of all jobs */
     double   price_ms;
-    double   gather_ms;
+    double   gather_ms;          /* srla_pack_blocks: device-side residual coding of the chosen blocks */
     double   h2d_ms;
     double   d2h_ms;
     double   pack_ms;            /* host wall time in the bit-packer                     */

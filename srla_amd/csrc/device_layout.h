@@ -77,6 +77,27 @@ typedef struct SrlaItemResult {
     uint8_t  kparam[1024];       /* Rice k / recursive-Rice k2 per partition of porder */
 } SrlaItemResult;               /* 64 + 256 + 1024 = 1344 bytes */
 
+/* The part of an item record the host bit-packer still needs once the device has coded the residual
+ * (a prefix of SrlaItemResult: scalar fields + taps). */
+typedef struct SrlaChanRecord {
+    int32_t  preemph_prev;
+    int32_t  preemph_coef;
+    uint32_t lpc_order;
+    uint32_t lpc_rshift;
+    uint32_t use_sum;
+    uint32_t ltp_period;
+    int32_t  ltp_coef[3];
+    uint32_t code_length;
+    uint32_t res_code_type;
+    uint32_t res_porder;
+    uint32_t res_bits;      /* exact length in bits of the channel's residual bitstring */
+    uint32_t flags;
+    uint32_t pad[2];
+    int8_t   lpc_coef[256];
+} SrlaChanRecord;               /* 320 bytes */
+
+#define SRLA_PACK_SLACK 128u    /* bytes of slack per block slot in the packed-bits buffer */
+
 typedef struct SrlaCandDesc {
     uint32_t window;
     uint32_t node_i, node_j;

@@ -7,8 +7,8 @@
  *           host-libm constant tables, H2D/D2H staging, the multi-threaded bit pack.
  *   device  everything between samples and (residuals, parameters, block partition): kernels.hip.
  *
- * A stream is processed as a sequence of jobs (ranges of whole windows).  Two job slots are
- * kept in flight: while the GPU analyses job k+1 the host packs job k.  Windows carry no state
+ * A stream is processed as a sequence of jobs (ranges of whole windows).  Three job slots are
+ * kept in flight: while the host packs job k the GPU runs job k+1 and already has job k+2 queued.  Windows carry no state
  * from one to the next, so jobs are independent; only the offset left shift is a
  * whole-stream quantity and is computed first.
  *
@@ -24,6 +24,7 @@
 #include <functional>
 #include <map>
 #include <mutex>
+#include <stddef.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -40,6 +41,7 @@
 #define SRLA_MAX_FFT      8192u       /* largest block the LDS-resident FFT handles */
 
 static_assert(sizeof(SrlaItemResult) == SRLAMI355X_ITEM_RECORD_BYTES, "record size");
+static_assert(sizeof(SrlaChanRecord) == 320 && offsetof(SrlaItemResult, lpc_coef) == offsetof(SrlaChanRecord, lpc_coef), "chan record is a prefix of the item record");
 static_assert(SRLA_DBG_STRIDE == SRLAMI355X_DEBUG_DOUBLES, "debug stride");
 
 struct SRLAEncoder {
@@ -124,6 +126,7 @@ public:
         {
             std::lock_guard<std::mutex> l(m_);
             fn_ = &fn; next_.store(0); count_ = count; pending_ = (unsigned)workers_.size(); gen_++;
+            gen_atomic_.store(gen_, std::memory_order_release);
         }
         cv_.notify_all();
         run_chunk();
@@ -147,6 +150,12 @@ private:
         uint64_t seen = 0;
         for (;;) {
             {
+                /* spin briefly before sleeping: pack rounds arrive every few hundred microseconds */
+                for (int spin = 0; spin < 2000 && gen_atomic_.load(std::memory_order_acquire) == seen && !stop_; spin++) {
+#if defined(__x86_64__)
+                    __builtin_ia32_pause();
+#endif
+                }
                 std::unique_lock<std::mutex> l(m_);
                 cv_.wait(l, [&] { return stop_ || gen_ != seen; });
                 if (stop_) return;
@@ -168,6 +177,7 @@ private:
     uint32_t count_ = 0;
     unsigned pending_;
     uint64_t gen_ = 0;
+    std::atomic<uint64_t> gen_atomic_{ 0 };
 };
 
 /* ---- one job: a range of whole windows -------------------------------------------------- */
@@ -186,13 +196,15 @@ struct Job {
     uint32_t num_slots = 0;
     uint64_t res_elems = 0;
     uint64_t analyzed_samples = 0;
+    uint64_t key = 0;                 /* geometry signature: equal keys => identical descriptor tables */
+    bool uploaded = false;            /* the slot's device copies match the tables above */
 };
 
 struct Slot {
     hipStream_t stream = nullptr;
     hipEvent_t ev[8] = {};
-    DevBuf d_input, d_items, d_cands, d_windows, d_results, d_res_ws, d_blocks, d_cand_bytes, d_out, d_chan, d_dbg, d_lags;
-    PinBuf h_in, h_out, h_blocks, h_chan;
+    DevBuf d_input, d_items, d_cands, d_windows, d_results, d_res_ws, d_blocks, d_cand_bytes, d_packed, d_chan, d_dbg, d_lags;
+    PinBuf h_in, h_packed, h_blocks, h_chan;
     Job job;
     bool busy = false;
     bool used_h2d = false;
@@ -204,11 +216,13 @@ struct Impl {
     SRLAEncoderConfig cfg{};
     SRLAEncodeParameter par{};
     bool set_parameter = false;
+    uint32_t param_generation = 0;    /* bumped by SetEncodeParameter: invalidates cached job tables */
     uint32_t offset_lshift = 0;       /* encoder->header.offset_lshift of the reference */
     uint32_t pack_threads = 0;
 
     bool dev_ready = false, dev_failed = false;
-    Slot slot[2];
+    static constexpr uint32_t kSlots = 3;   /* jobs in flight: the GPU always has one queued behind the running one */
+    Slot slot[kSlots];
     DevBuf d_tw, d_geoms, d_thr, d_huff, d_or;
     std::map<uint32_t, uint32_t> tw_index;   /* nfft -> offset (double2) */
     std::vector<double> tw_host;
@@ -228,9 +242,9 @@ struct Impl {
                 if (s.stream) (void)hipStreamSynchronize(s.stream);
                 for (auto &e : s.ev) if (e) (void)hipEventDestroy(e);
                 DevBuf *db[] = { &s.d_input, &s.d_items, &s.d_cands, &s.d_windows, &s.d_results, &s.d_res_ws,
-                                 &s.d_blocks, &s.d_cand_bytes, &s.d_out, &s.d_chan, &s.d_dbg, &s.d_lags };
+                                 &s.d_blocks, &s.d_cand_bytes, &s.d_packed, &s.d_chan, &s.d_dbg, &s.d_lags };
                 for (auto *b : db) b->release();
-                PinBuf *pb[] = { &s.h_in, &s.h_out, &s.h_blocks, &s.h_chan };
+                PinBuf *pb[] = { &s.h_in, &s.h_packed, &s.h_blocks, &s.h_chan };
                 for (auto *b : pb) b->release();
                 if (s.stream) (void)hipStreamDestroy(s.stream);
             }
@@ -269,7 +283,17 @@ struct Impl {
         HIP_OK(hipMemcpy(d_huff.p, huff, sizeof(huff), hipMemcpyHostToDevice));
         if (!d_or.ensure(64)) return false;
         unsigned hw = std::thread::hardware_concurrency();
+        /* a container's CPU quota (cgroup v2 cpu.max = "<quota> <period>") bounds the useful thread count */
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            long long quota = 0, period = 0;
+            if (fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0) {
+                const unsigned q = (unsigned)((quota + period - 1) / period);
+                if (q > 0 && (hw == 0 || q < hw)) hw = q;
+            }
+            fclose(f);
+        }
         unsigned nthreads = pack_threads ? pack_threads : std::min(hw ? hw : 1u, 16u);
+        if (const char *e = getenv("SRLA_MI355X_PACK_THREADS")) { const int v = atoi(e); if (v > 0) nthreads = (unsigned)v; }
         pool = new Pool(nthreads);
         dev_failed = false;
         dev_ready = true;
@@ -341,7 +365,12 @@ struct Impl {
         const uint32_t minb = par.min_num_samples_per_block, maxb = par.max_num_samples_per_block;
         const uint32_t window_len = search ? par.num_lookahead_samples : maxb;
         const uint32_t nv = num_variants(), pmax = preset_order();
-        job.s0 = s0; job.ns = ns;
+        /* all tables are relative to the job's first sample, so jobs of equal length share them */
+        const uint64_t key = ((uint64_t)ns << 24) ^ ((uint64_t)param_generation << 1) ^ (search ? 1u : 0u) ^ 0x8000000000000000ull;
+        job.s0 = s0;
+        if (job.key == key && job.ns == ns) return;
+        job.key = key; job.uploaded = false;
+        job.ns = ns;
         job.windows.clear(); job.cands.clear(); job.items.clear(); job.groups.clear();
         job.num_slots = 0; job.res_elems = 0; job.analyzed_samples = 0;
 
@@ -435,18 +464,23 @@ struct Impl {
         const uint32_t nch = par.num_channels;
         if (!sync_tables()) return false;
         const size_t n_items = job.items.size(), n_cands = job.cands.size(), n_win = job.windows.size();
-        if (!s.d_items.ensure(std::max<size_t>(1, n_items) * sizeof(SrlaItemDesc))) return false;
-        if (!s.d_cands.ensure(n_cands * sizeof(SrlaCandDesc))) return false;
-        if (!s.d_windows.ensure(n_win * sizeof(SrlaWindowDesc))) return false;
+        {
+            const void *pi = s.d_items.p, *pc = s.d_cands.p, *pw = s.d_windows.p;
+            if (!s.d_items.ensure(std::max<size_t>(1, n_items) * sizeof(SrlaItemDesc))) return false;
+            if (!s.d_cands.ensure(n_cands * sizeof(SrlaCandDesc))) return false;
+            if (!s.d_windows.ensure(n_win * sizeof(SrlaWindowDesc))) return false;
+            if (pi != s.d_items.p || pc != s.d_cands.p || pw != s.d_windows.p) job.uploaded = false;
+        }
         if (!s.d_results.ensure(std::max<size_t>(1, n_items) * sizeof(SrlaItemResult))) return false;
         if (!s.d_res_ws.ensure(std::max<uint64_t>(4, job.res_elems) * 4)) return false;
         if (!s.d_blocks.ensure((size_t)job.num_slots * sizeof(SrlaBlockRecord))) return false;
         if (!s.d_cand_bytes.ensure(n_cands * 4)) return false;
-        if (!s.d_out.ensure((size_t)nch * job.ns * 4)) return false;
-        if (!s.d_chan.ensure((size_t)job.num_slots * nch * sizeof(SrlaItemResult))) return false;
-        if (!s.h_out.ensure((size_t)nch * job.ns * 4)) return false;
+        const size_t packed_bytes = (size_t)job.ns * nch * (par.bits_per_sample / 8) + (size_t)job.num_slots * SRLA_PACK_SLACK + 64;
+        if (!s.d_packed.ensure(packed_bytes)) return false;
+        if (!s.d_chan.ensure((size_t)job.num_slots * nch * sizeof(SrlaChanRecord))) return false;
+        if (!s.h_packed.ensure(packed_bytes)) return false;
         if (!s.h_blocks.ensure((size_t)job.num_slots * sizeof(SrlaBlockRecord))) return false;
-        if (!s.h_chan.ensure((size_t)job.num_slots * nch * sizeof(SrlaItemResult))) return false;
+        if (!s.h_chan.ensure((size_t)job.num_slots * nch * sizeof(SrlaChanRecord))) return false;
         if (want_dbg && !s.d_dbg.ensure(std::max<size_t>(1, n_items) * SRLA_DBG_STRIDE * sizeof(double))) return false;
 
         HIP_OK(hipEventRecord(s.ev[0], s.stream));
@@ -461,9 +495,12 @@ struct Impl {
             stride = job.ns;
             s.used_h2d = true;
         }
-        if (n_items) HIP_OK(hipMemcpyAsync(s.d_items.p, job.items.data(), n_items * sizeof(SrlaItemDesc), hipMemcpyHostToDevice, s.stream));
-        HIP_OK(hipMemcpyAsync(s.d_cands.p, job.cands.data(), n_cands * sizeof(SrlaCandDesc), hipMemcpyHostToDevice, s.stream));
-        HIP_OK(hipMemcpyAsync(s.d_windows.p, job.windows.data(), n_win * sizeof(SrlaWindowDesc), hipMemcpyHostToDevice, s.stream));
+        if (!job.uploaded) {
+            if (n_items) HIP_OK(hipMemcpyAsync(s.d_items.p, job.items.data(), n_items * sizeof(SrlaItemDesc), hipMemcpyHostToDevice, s.stream));
+            HIP_OK(hipMemcpyAsync(s.d_cands.p, job.cands.data(), n_cands * sizeof(SrlaCandDesc), hipMemcpyHostToDevice, s.stream));
+            HIP_OK(hipMemcpyAsync(s.d_windows.p, job.windows.data(), n_win * sizeof(SrlaWindowDesc), hipMemcpyHostToDevice, s.stream));
+            job.uploaded = true;
+        }
         HIP_OK(hipEventRecord(s.ev[1], s.stream));
 
         const SrlaJobParams jp = job_params(job, stride);
@@ -499,13 +536,13 @@ struct Impl {
                               s.d_results.as<SrlaItemResult>(), s.d_blocks.as<SrlaBlockRecord>(),
                               s.d_cand_bytes.as<uint32_t>()) != 0) return false;
         HIP_OK(hipEventRecord(s.ev[3], s.stream));
-        if (srla_launch_gather(s.stream, &jp, job.num_slots, d_in, s.d_items.as<SrlaItemDesc>(),
-                               s.d_blocks.as<SrlaBlockRecord>(), s.d_results.as<SrlaItemResult>(),
-                               s.d_res_ws.as<int32_t>(), s.d_out.as<int32_t>(), s.d_chan.as<SrlaItemResult>()) != 0) return false;
+        if (srla_launch_pack(s.stream, &jp, job.num_slots, d_in, s.d_items.as<SrlaItemDesc>(),
+                             s.d_blocks.as<SrlaBlockRecord>(), s.d_results.as<SrlaItemResult>(),
+                             s.d_res_ws.as<int32_t>(), s.d_packed.as<uint8_t>(), s.d_chan.as<SrlaChanRecord>()) != 0) return false;
         HIP_OK(hipEventRecord(s.ev[4], s.stream));
-        HIP_OK(hipMemcpyAsync(s.h_out.p, s.d_out.p, (size_t)nch * job.ns * 4, hipMemcpyDeviceToHost, s.stream));
+        HIP_OK(hipMemcpyAsync(s.h_packed.p, s.d_packed.p, packed_bytes, hipMemcpyDeviceToHost, s.stream));
         HIP_OK(hipMemcpyAsync(s.h_blocks.p, s.d_blocks.p, (size_t)job.num_slots * sizeof(SrlaBlockRecord), hipMemcpyDeviceToHost, s.stream));
-        HIP_OK(hipMemcpyAsync(s.h_chan.p, s.d_chan.p, (size_t)job.num_slots * nch * sizeof(SrlaItemResult), hipMemcpyDeviceToHost, s.stream));
+        HIP_OK(hipMemcpyAsync(s.h_chan.p, s.d_chan.p, (size_t)job.num_slots * nch * sizeof(SrlaChanRecord), hipMemcpyDeviceToHost, s.stream));
         HIP_OK(hipEventRecord(s.ev[5], s.stream));
         s.busy = true;
         stats.num_windows += n_win; stats.num_candidates += n_cands; stats.num_items += n_items;
@@ -538,8 +575,9 @@ struct Impl {
         const Job &job = s.job;
         const uint32_t nch = par.num_channels;
         const SrlaBlockRecord *blocks = s.h_blocks.as<SrlaBlockRecord>();
-        const SrlaItemResult *chan = s.h_chan.as<SrlaItemResult>();
-        const int32_t *out = s.h_out.as<int32_t>();
+        const SrlaChanRecord *chan = s.h_chan.as<SrlaChanRecord>();
+        const uint8_t *packed = s.h_packed.as<uint8_t>();
+        const uint32_t bytes_ps = par.bits_per_sample / 8;
         struct Todo { uint32_t slot; uint32_t off; };
         std::vector<Todo> todo;
         todo.reserve(job.num_slots);
@@ -564,12 +602,12 @@ struct Impl {
         if (total > data_size) return SRLA_APIRESULT_INSUFFICIENT_BUFFER;
         std::atomic<int> bad{ 0 };
         std::atomic<uint64_t> raw{ 0 }, silent{ 0 }, ties{ 0 }, odd{ 0 };
-        pool->parallel_for((uint32_t)todo.size(), [&](uint32_t i) {
+        static const bool skip_pack = getenv("SRLA_MI355X_DIAG_SKIP_PACK") != nullptr;   /* diagnostics only: output is garbage */
+        pool->parallel_for(skip_pack ? 0u : (uint32_t)todo.size(), [&](uint32_t i) {
             const SrlaBlockRecord &br = blocks[todo[i].slot];
-            const int32_t *ptr[SRLA_MAX_CH];
-            for (uint32_t ch = 0; ch < nch; ch++) ptr[ch] = out + (size_t)ch * job.ns + br.sample_off;
-            const SrlaItemResult *recs = chan + (size_t)todo[i].slot * nch;
-            const uint32_t sz = srla::pack_block(si, br, recs, ptr, data + todo[i].off);
+            const uint8_t *region = packed + (size_t)br.sample_off * nch * bytes_ps + (size_t)todo[i].slot * SRLA_PACK_SLACK;
+            const SrlaChanRecord *recs = chan + (size_t)todo[i].slot * nch;
+            const uint32_t sz = srla::pack_block(si, br, recs, region, data + todo[i].off);
             if (sz != br.bytes) bad.fetch_add(1);
             if (br.block_type == SRLA_BLOCK_RAW) raw.fetch_add(1);
             else if (br.block_type == SRLA_BLOCK_SILENT) silent.fetch_add(1);
@@ -655,16 +693,17 @@ struct Impl {
         uint32_t progress = 0;
 
         auto start = [&](uint32_t k) -> bool {
-            Slot &s = slot[k & 1];
+            Slot &s = slot[k % kSlots];
             const uint32_t s0 = (uint32_t)((uint64_t)k * job_len);
             const uint32_t ns = (uint32_t)std::min<uint64_t>(job_len, num_samples - s0);
             build_job(s.job, s0, ns, search);
             return launch_job(s, d_in ? d_in + s0 : nullptr, d_stride, host_in, false);
         };
-        if (!start(0)) return SRLA_APIRESULT_NG;
+        for (uint32_t k = 0; k + 1 < kSlots && k < njobs; k++)
+            if (!start(k)) return SRLA_APIRESULT_NG;
         for (uint32_t k = 0; k < njobs; k++) {
-            if (k + 1 < njobs && !start(k + 1)) return SRLA_APIRESULT_NG;
-            Slot &s = slot[k & 1];
+            if (k + kSlots - 1 < njobs && !start(k + kSlots - 1)) return SRLA_APIRESULT_NG;
+            Slot &s = slot[k % kSlots];
             if (!wait_job(s)) return SRLA_APIRESULT_NG;
             uint32_t wrote = 0;
             const SRLAApiResult rc = pack_job(s, si, data + write_off, data_size - write_off, &wrote, window_bytes);
@@ -807,6 +846,7 @@ SRLAApiResult SRLAEncoder_SetEncodeParameter(struct SRLAEncoder *encoder, const 
         return SRLA_APIRESULT_NG;
     }
     im->par = *p;
+    im->param_generation++;
     im->offset_lshift = 0;
     im->set_parameter = true;
     return SRLA_APIRESULT_OK;

@@ -1,8 +1,9 @@
 /*
  * host_pack.cpp -- the host side of the bitstream: stream header, block framing, Fletcher-16 and
  * the bit-serial Rice / recursive-Rice / static-Huffman pack (this part of the codec stays on
- * the host by design; the GPU supplies residuals and every parameter, so nothing is searched
- * again here).
+ * the host by design: header fields, Huffman-coded taps, concatenation, framing, checksum.  The GPU
+ * supplies every parameter and the already Rice-coded residual bitstring of each channel,
+ * so the host ORs words together instead of coding sample by sample).
  *
  * Bitstream facts restated from the reference (paths relative to the reference tree):
  *   stream header   libs/srla_encoder/src/srla_encoder.c:134-161
@@ -64,45 +65,15 @@ inline void put_u32be(uint8_t *p, uint32_t v)
     p[0] = (uint8_t)(v >> 24); p[1] = (uint8_t)(v >> 16); p[2] = (uint8_t)(v >> 8); p[3] = (uint8_t)v;
 }
 
-void pack_residual(BitSink &w, const SrlaItemResult &rec, const int32_t *res, uint32_t n)
+/* append `nbits` bits of a byte-aligned MSB-first bitstring */
+inline void append_bits(BitSink &w, const uint8_t *src, uint32_t nbits)
 {
-    w.put(rec.res_code_type, 2);
-    if (rec.res_code_type == SRLA_CODE_ALLZERO) return;
-    const uint32_t porder = rec.res_porder, len = n >> porder;
-    w.put(porder, 10);
-    uint32_t prev = 0;
-    for (uint32_t part = 0; part < (1u << porder); part++) {
-        const uint32_t k = rec.kparam[part];
-        if (part == 0) w.put(k, 5);
-        else w.zeros_then_one(zigzag((int32_t)k - (int32_t)prev));
-        prev = k;
-        const int32_t *r = res + (size_t)part * len;
-        if (rec.res_code_type == SRLA_CODE_RICE) {
-            for (uint32_t i = 0; i < len; i++) {
-                const uint32_t u = zigzag(r[i]);
-                w.zeros_then_one(u >> k);
-                w.put(u, k);
-            }
-        } else {
-            const uint32_t k1 = k + 1, k1pow = 1u << k1;
-            for (uint32_t i = 0; i < len; i++) {
-                const uint32_t u = zigzag(r[i]);
-                if (u < k1pow) {
-                    w.put(k1pow | u, k1 + 1);
-                } else {
-                    const uint32_t v = u - k1pow;
-                    const uint32_t q = 1 + (v >> k);
-                    if (q + 1 + k <= 32) {
-                        /* q zeros, the terminating one and the k low bits in one store */
-                        w.put((1u << k) | (v & ((1u << k) - 1u)), q + 1 + k);
-                    } else {
-                        w.zeros_then_one(q);
-                        w.put(v, k);
-                    }
-                }
-            }
-        }
-    }
+    uint32_t i = 0;
+    for (; i + 32 <= nbits; i += 32, src += 4)
+        w.put(((uint32_t)src[0] << 24) | ((uint32_t)src[1] << 16) | ((uint32_t)src[2] << 8) | (uint32_t)src[3], 32);
+    uint32_t rem = nbits - i;
+    while (rem >= 8) { w.put(*src++, 8); rem -= 8; }
+    if (rem) w.put((uint32_t)(*src) >> (8 - rem), rem);
 }
 
 }  // namespace
@@ -134,8 +105,8 @@ void write_stream_header(const StreamInfo &s, uint8_t *p)
     p[29] = (uint8_t)s.preset;
 }
 
-uint32_t pack_block(const StreamInfo &s, const SrlaBlockRecord &br, const SrlaItemResult *chan,
-                    const int32_t *const *data, uint8_t *out)
+uint32_t pack_block(const StreamInfo &s, const SrlaBlockRecord &br, const SrlaChanRecord *chan,
+                    const uint8_t *region, uint8_t *out)
 {
     const uint32_t nch = s.num_channels, bps = s.bits_per_sample, n = br.n;
     uint8_t *payload = out + 11;
@@ -148,7 +119,7 @@ uint32_t pack_block(const StreamInfo &s, const SrlaBlockRecord &br, const SrlaIt
             w.put(zigzag(chan[ch].preemph_coef), 5);
         }
         for (uint32_t ch = 0; ch < nch; ch++) {
-            const SrlaItemResult &c = chan[ch];
+            const SrlaChanRecord &c = chan[ch];
             w.put(c.lpc_order, 8);
             w.put(c.lpc_rshift, 4);
             w.put(c.use_sum, 1);
@@ -167,7 +138,7 @@ uint32_t pack_block(const StreamInfo &s, const SrlaBlockRecord &br, const SrlaIt
             }
         }
         for (uint32_t ch = 0; ch < nch; ch++) {
-            const SrlaItemResult &c = chan[ch];
+            const SrlaChanRecord &c = chan[ch];
             w.put(c.ltp_period != 0, 1);
             if (c.ltp_period > 0) {
                 w.put((s.ltp_order - 1) / 2, 1);
@@ -175,17 +146,16 @@ uint32_t pack_block(const StreamInfo &s, const SrlaBlockRecord &br, const SrlaIt
                 for (uint32_t i = 0; i < s.ltp_order; i++) w.put(zigzag(c.ltp_coef[i]), 6);
             }
         }
-        for (uint32_t ch = 0; ch < nch; ch++) pack_residual(w, chan[ch], data[ch], n);
+        /* residuals: the device coded them (srla_coder.c:532-595); OR the words in behind the header */
+        const uint8_t *src = region;
+        for (uint32_t ch = 0; ch < nch; ch++) {
+            append_bits(w, src, chan[ch].res_bits);
+            src += ((chan[ch].res_bits + 63u) >> 6) << 3;
+        }
         payload_bytes = (uint32_t)(w.finish() - payload);
     } else if (br.block_type == SRLA_BLOCK_RAW) {
-        const uint32_t bytes = bps / 8;
-        uint8_t *q = payload;
-        for (uint32_t i = 0; i < n; i++)
-            for (uint32_t ch = 0; ch < nch; ch++) {
-                const uint32_t u = zigzag(data[ch][i]);
-                for (uint32_t b = 0; b < bytes; b++) *q++ = (uint8_t)(u >> (8 * (bytes - 1 - b)));
-            }
-        payload_bytes = (uint32_t)(q - payload);
+        payload_bytes = (bps / 8) * n * nch;
+        memcpy(payload, region, payload_bytes);
     }
     put_u16be(out, 0xFFFF);
     put_u32be(out + 2, payload_bytes + 5);

@@ -40,10 +40,10 @@ int srla_launch_price(hipStream_t stream, const SrlaJobParams *jp, const SrlaWin
                       const SrlaCandDesc *cands, const SrlaItemResult *results,
                       SrlaBlockRecord *blocks, uint32_t *cand_bytes);
 
-int srla_launch_gather(hipStream_t stream, const SrlaJobParams *jp, uint32_t num_slots,
-                       const int32_t *input, const SrlaItemDesc *items, const SrlaBlockRecord *blocks,
-                       const SrlaItemResult *results, const int32_t *res_ws, int32_t *out,
-                       SrlaItemResult *chan_out);
+int srla_launch_pack(hipStream_t stream, const SrlaJobParams *jp, uint32_t num_slots,
+                     const int32_t *input, const SrlaItemDesc *items, const SrlaBlockRecord *blocks,
+                     const SrlaItemResult *results, const int32_t *res_ws, uint8_t *packed,
+                     SrlaChanRecord *chan_out);
 
 int srla_launch_or_reduce(hipStream_t stream, const int32_t *in, size_t count, uint32_t *out);
 

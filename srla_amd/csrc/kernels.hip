@@ -17,7 +17,8 @@
  *   srla_residual_cost<R>   one workgroup per item: pre-emphasis (+LTP), register-blocked int32 FIR,
  *                           residual to HBM, partitioned (recursive) Rice code-length search.
  *   srla_price_windows      stereo decision + block sizes + shortest path, one thread per window.
- *   srla_gather_blocks      chosen residuals / parameters into the compact D2H buffers.
+ *   srla_pack_blocks        codes the chosen blocks' residuals into per-channel bitstrings (prefix-summed
+ *                           bit offsets) for the host bit-packer; RAW payloads; compact records.
  *   srla_or_reduce          whole-stream OR for the offset left shift.
  *
  * No MFMA: integer/fp64 butterflies and reductions, not a dense contraction.  All fp64 arithmetic
@@ -26,6 +27,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <float.h>
+#include <algorithm>
 
 #include "device_layout.h"
 #include "kernels.h"
@@ -1084,29 +1086,153 @@ __global__ void srla_price_windows(SrlaJobParams jp, const SrlaWindowDesc *__res
     for (uint32_t k = count; k < nodes - 1; k++) blocks[wd.block_base + k].valid = 0;
 }
 
-/* ------------------------------------------------------------------------- gather --------- */
-/* grid = (block slots, channels).  Residuals of compress blocks (original samples for RAW blocks) land
- * at the block's own sample positions of out[ch][...]; the chosen item records are copied next to them. */
-__global__ __launch_bounds__(NT) void srla_gather_blocks(
+/* ------------------------------------------------------------------------- pack ----------- */
+/* grid = (block slots, channels).  For every chosen block the device emits, per channel, the complete
+ * residual bitstring of SRLACoder_Encode (srla_coder.c:532-595: 2-bit code type, 10-bit partition order,
+ * per partition the parameter -- 5 bits, then unary zig-zag deltas -- followed by the (recursive) Rice
+ * codes), MSB first, starting on an 8-byte boundary inside the block's region of the packed buffer.
+ * Bit offsets come from a workgroup prefix sum over the code lengths; bits are assembled in LDS with
+ * atomic ORs and stored with 16-byte coalesced writes.  The host only writes the header fields, ORs the
+ * channel bitstrings behind them, and frames / checksums the block.  RAW blocks get their final payload
+ * bytes (srla_encoder.c:823-852).  Block region = [sample_off * nch * bps/8 + slot * SLACK, ...). */
+__device__ __forceinline__ void lds_put_bits(uint32_t *w, uint32_t bitpos, uint32_t value, uint32_t nbits)
+{
+    /* nbits in [1,32]; word k holds stream bits 32k..32k+31, most significant first */
+    if (nbits < 32) value &= (1u << nbits) - 1u;
+    const uint32_t wi = bitpos >> 5, o = bitpos & 31u;
+    if (o + nbits <= 32u) atomicOr(&w[wi], value << (32u - o - nbits));
+    else {
+        const uint32_t spill = o + nbits - 32u;
+        atomicOr(&w[wi], value >> spill);
+        atomicOr(&w[wi + 1], value << (32u - spill));
+    }
+}
+
+__global__ __launch_bounds__(NT) void srla_pack_blocks(
     SrlaJobParams jp, const int32_t *__restrict__ input, const SrlaItemDesc *__restrict__ items,
     const SrlaBlockRecord *__restrict__ blocks, const SrlaItemResult *__restrict__ results,
-    const int32_t *__restrict__ res_ws, int32_t *__restrict__ out, SrlaItemResult *__restrict__ chan_out)
+    const int32_t *__restrict__ res_ws, uint8_t *__restrict__ packed, SrlaChanRecord *__restrict__ chan_out,
+    uint32_t lds_words)
 {
-    const uint32_t slot = blockIdx.x, ch = blockIdx.y;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    uint32_t *words = (uint32_t *)lds;                       /* lds_words entries */
+    uint32_t *scan = words + lds_words;                      /* NWAVES + 1 entries */
+    const uint32_t slot = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const SrlaBlockRecord rec = blocks[slot];
     if (!rec.valid) return;
-    int32_t *dst = out + (size_t)ch * jp.out_stride + rec.sample_off;
-    if (rec.block_type == SRLA_BLOCK_COMPRESS) {
-        const uint32_t item = rec.item[ch];
-        const int32_t *src = res_ws + items[item].res_off;
-        for (uint32_t i = threadIdx.x; i < rec.n; i += NT) dst[i] = src[i];
-        /* item record: 1344 bytes = 336 words */
-        const uint32_t *rs = (const uint32_t *)&results[item];
-        uint32_t *rd = (uint32_t *)&chan_out[(size_t)slot * jp.num_channels + ch];
-        for (uint32_t i = threadIdx.x; i < sizeof(SrlaItemResult) / 4; i += NT) rd[i] = rs[i];
-    } else if (rec.block_type == SRLA_BLOCK_RAW) {
+    const uint32_t nch = jp.num_channels, bytes_ps = jp.bits_per_sample >> 3, n = rec.n;
+    uint8_t *region = packed + (size_t)rec.sample_off * nch * bytes_ps + (size_t)slot * SRLA_PACK_SLACK;
+
+    if (rec.block_type == SRLA_BLOCK_RAW) {
+        /* interleaved, zig-zag mapped, big endian (srla_encoder.c:823-852); one channel per grid row */
         const int32_t *src = input + (size_t)ch * jp.channel_stride + rec.sample_off;
-        for (uint32_t i = threadIdx.x; i < rec.n; i += NT) dst[i] = src[i];
+        for (uint32_t i = tid; i < n; i += NT) {
+            const uint32_t u = zigzag32(src[i]);
+            uint8_t *q = region + ((size_t)i * nch + ch) * bytes_ps;
+            for (uint32_t b = 0; b < bytes_ps; b++) q[b] = (uint8_t)(u >> (8 * (bytes_ps - 1 - b)));
+        }
+        return;
+    }
+    if (rec.block_type != SRLA_BLOCK_COMPRESS) return;
+
+    const uint32_t item = rec.item[ch];
+    const SrlaItemResult *ir = &results[item];
+    /* scalar fields + taps for the host */
+    {
+        const uint32_t *rs = (const uint32_t *)ir;
+        uint32_t *rd = (uint32_t *)&chan_out[(size_t)slot * nch + ch];
+        for (uint32_t i = tid; i < sizeof(SrlaChanRecord) / 4; i += NT) rd[i] = rs[i];
+    }
+    /* this channel's bitstring starts behind the previous channels', 8-byte aligned */
+    uint32_t byte_off = 0;
+    for (uint32_t c = 0; c < ch; c++) byte_off += ((results[rec.item[c]].res_bits + 63u) >> 6) << 3;
+    const uint32_t total_bits = ir->res_bits, code_type = ir->res_code_type, porder = ir->res_porder;
+    const uint32_t out_words = ((total_bits + 63u) >> 6) << 1;       /* 32-bit words, padded to 8 bytes */
+    uint32_t *dst = (uint32_t *)(region + byte_off);
+    const bool in_lds = out_words <= lds_words;
+    uint32_t *w = in_lds ? words : dst;
+    for (uint32_t i = tid; i < out_words; i += NT) w[i] = 0;
+    __syncthreads();
+    if (!in_lds) __threadfence_block();
+
+    if (code_type == SRLA_CODE_ALLZERO) {
+        if (tid == 0) lds_put_bits(w, 0, SRLA_CODE_ALLZERO, 2);
+    } else {
+        const int32_t *res = res_ws + items[item].res_off;
+        const uint32_t plen = n >> porder;
+        const uint32_t per = (n + NT - 1) / NT;                  /* contiguous samples per thread */
+        const uint32_t s0 = tid * per, s1 = (s0 + per < n) ? (s0 + per) : n;
+        /* pass 1: bits this thread will emit */
+        uint32_t mybits = 0;
+        for (uint32_t s = s0; s < s1; s++) {
+            const uint32_t part = s / plen;
+            const uint32_t k = ir->kparam[part];
+            if (s == part * plen) {
+                if (part == 0) mybits += 2u + 10u + 5u;
+                else mybits += zigzag32((int32_t)k - (int32_t)ir->kparam[part - 1]) + 1u;
+            }
+            const uint32_t u = zigzag32(res[s]);
+            if (code_type == SRLA_CODE_RICE) mybits += 1u + k + (u >> k);
+            else {
+                const uint32_t k1pow = 2u << k;
+                mybits += (u < k1pow) ? (k + 2u) : (k + 2u + ((u - k1pow) >> k));
+            }
+        }
+        /* exclusive prefix sum over the workgroup */
+        uint32_t incl = mybits;
+        for (int off = 1; off < WAVE; off <<= 1) { const uint32_t t = __shfl_up(incl, off, WAVE); if (lane >= (uint32_t)off) incl += t; }
+        if (lane == WAVE - 1) scan[wave] = incl;
+        __syncthreads();
+        uint32_t base = incl - mybits;
+        for (uint32_t k = 0; k < wave; k++) base += scan[k];
+        /* pass 2: emit */
+        uint32_t pos = base;
+        for (uint32_t s = s0; s < s1; s++) {
+            const uint32_t part = s / plen;
+            const uint32_t k = ir->kparam[part];
+            if (s == part * plen) {
+                if (part == 0) {
+                    lds_put_bits(w, pos, code_type, 2); pos += 2;
+                    lds_put_bits(w, pos, porder, 10); pos += 10;
+                    lds_put_bits(w, pos, k, 5); pos += 5;
+                } else {
+                    const uint32_t z = zigzag32((int32_t)k - (int32_t)ir->kparam[part - 1]);
+                    pos += z;                                 /* z zeros */
+                    lds_put_bits(w, pos, 1u, 1); pos += 1;
+                }
+            }
+            const uint32_t u = zigzag32(res[s]);
+            if (code_type == SRLA_CODE_RICE) {
+                pos += u >> k;                                /* quotient in unary: zeros */
+                lds_put_bits(w, pos, 1u, 1); pos += 1;
+                if (k) { lds_put_bits(w, pos, u, k); pos += k; }
+            } else {
+                const uint32_t k1 = k + 1u, k1pow = 1u << k1;
+                if (u < k1pow) {
+                    lds_put_bits(w, pos, 1u, 1); pos += 1;    /* (2^k1 | u) in k1 + 1 bits */
+                    lds_put_bits(w, pos, u, k1); pos += k1;
+                } else {
+                    const uint32_t v = u - k1pow;
+                    pos += 1u + (v >> k);
+                    lds_put_bits(w, pos, 1u, 1); pos += 1;
+                    if (k) { lds_put_bits(w, pos, v, k); pos += k; }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    /* to stream byte order (big endian words) */
+    if (in_lds) {
+        for (uint32_t i = tid * 4; i < out_words; i += NT * 4) {
+            uint4 v = make_uint4(words[i], (i + 1 < out_words) ? words[i + 1] : 0, (i + 2 < out_words) ? words[i + 2] : 0,
+                                 (i + 3 < out_words) ? words[i + 3] : 0);
+            v.x = __builtin_bswap32(v.x); v.y = __builtin_bswap32(v.y); v.z = __builtin_bswap32(v.z); v.w = __builtin_bswap32(v.w);
+            if (i + 4 <= out_words && ((reinterpret_cast<uintptr_t>(dst + i) & 15u) == 0)) *reinterpret_cast<uint4 *>(dst + i) = v;
+            else { dst[i] = v.x; if (i + 1 < out_words) dst[i + 1] = v.y; if (i + 2 < out_words) dst[i + 2] = v.z; if (i + 3 < out_words) dst[i + 3] = v.w; }
+        }
+    } else {
+        __threadfence_block();
+        for (uint32_t i = tid; i < out_words; i += NT) dst[i] = __builtin_bswap32(dst[i]);
     }
 }
 
@@ -1219,14 +1345,19 @@ extern "C" int srla_launch_price(hipStream_t stream, const SrlaJobParams *jp, co
     return (hipGetLastError() == hipSuccess) ? 0 : -2;
 }
 
-extern "C" int srla_launch_gather(hipStream_t stream, const SrlaJobParams *jp, uint32_t num_slots,
-                                  const int32_t *input, const SrlaItemDesc *items, const SrlaBlockRecord *blocks,
-                                  const SrlaItemResult *results, const int32_t *res_ws, int32_t *out,
-                                  SrlaItemResult *chan_out)
+extern "C" int srla_launch_pack(hipStream_t stream, const SrlaJobParams *jp, uint32_t num_slots,
+                                const int32_t *input, const SrlaItemDesc *items, const SrlaBlockRecord *blocks,
+                                const SrlaItemResult *results, const int32_t *res_ws, uint8_t *packed,
+                                SrlaChanRecord *chan_out)
 {
     if (num_slots == 0) return 0;
-    hipLaunchKernelGGL(srla_gather_blocks, dim3(num_slots, jp->num_channels), dim3(NT), 0, stream,
-                       *jp, input, items, blocks, results, res_ws, out, chan_out);
+    /* LDS staging for one channel's bitstring: a compress block is always smaller than its raw size */
+    uint64_t bits = (uint64_t)jp->bits_per_sample * jp->max_block * jp->num_channels;
+    uint32_t lds_words = (uint32_t)std::min<uint64_t>((bits + 63) / 64 * 2 + 4, 24 * 1024);   /* <= 96 KB */
+    const uint32_t lds = lds_words * 4 + 64;
+    SET_LDS_ATTR(srla_pack_blocks);
+    hipLaunchKernelGGL(srla_pack_blocks, dim3(num_slots, jp->num_channels), dim3(NT), lds, stream,
+                       *jp, input, items, blocks, results, res_ws, packed, chan_out, lds_words);
     return (hipGetLastError() == hipSuccess) ? 0 : -2;
 }
 
