@@ -22,6 +22,7 @@ extern "C" {
 
 uint32_t srla_kernel_small_a_bytes(void);
 uint32_t srla_kernel_small_c_bytes(void);
+uint32_t srla_kernel_fast_lds_bytes(uint32_t fl);   /* LDS of the 1024*fl-sample fast path of srla_residual_cost */
 #define SRLA_FIR_PAD 256
 
 /* pass 0: LPC lags (initialises the item record unless an LTP pass ran first), pass 1: LTP lags */

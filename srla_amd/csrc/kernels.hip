@@ -705,6 +705,271 @@ struct SmallC {
 
 extern "C" uint32_t srla_kernel_small_c_bytes(void) { return (uint32_t)((sizeof(SmallC) + 15) & ~15u); }
 
+/* ---- fast path of K3 for blocks of 1024 * FL samples (FL = 1..4): every thread owns S = 4 * FL
+ * CONTIGUOUS samples = four finest partitions of the 1024-way split, so the whole partition-mean tree
+ * (srla_coder.c:366-389) lives in registers: levels 10..8 inside a thread, 7..2 by wave shuffles, 1..0
+ * through four LDS words.  The residual never goes back to LDS; only the signal (for the FIR windows of
+ * neighbouring threads) and the 2047-byte parameter table do.  LDS layout of the signal: four words of
+ * padding after every S samples so that the 16-byte window loads of a wavefront are conflict free. */
+struct SmallF {
+    int32_t  coefq[FIR_PAD + 8];
+    uint32_t level_bits[16];
+    uint8_t  ktab[2048];
+    double   wave_mean[NWAVES];
+    uint32_t wave_max[NWAVES];
+    uint32_t pad[4];
+};
+
+template <int FL>
+__device__ __forceinline__ uint32_t sig_index(int s_plus_pad)
+{
+    constexpr int S = 4 * FL;
+    return (uint32_t)(s_plus_pad + (s_plus_pad / S) * 4);
+}
+
+__device__ __forceinline__ uint32_t rice_param(double mean, uint32_t code_type, const double *__restrict__ thr)
+{
+    if (code_type == SRLA_CODE_RICE) {
+        uint32_t k = 0;   /* srla_coder.c:262-276 through the host-derived monotone thresholds */
+        for (int t = 0; t < 32; t++) k += (mean >= thr[t]) ? 1u : 0u;
+        return k;
+    }
+    const double gp = 0.66794162356 * (1.0 + mean);   /* srla_coder.c:298-311 */
+    const uint32_t golomb = (uint32_t)((1.0 > gp) ? 1.0 : gp);
+    return 31u - (uint32_t)__clz((int)golomb);
+}
+
+__device__ __forceinline__ uint32_t code_cost(uint32_t val, uint32_t k, uint32_t code_type)
+{
+    if (code_type == SRLA_CODE_RICE) return 1u + k + (val >> k);                 /* srla_coder.c:327-330 */
+    int32_t over = (int32_t)val - (int32_t)(2u << k);                             /* srla_coder.c:333-347 */
+    over = (over > 0) ? over : 0;
+    return (k + 2u) + ((uint32_t)over >> k);
+}
+
+template <int FL>
+__device__ void residual_cost_fast(const SrlaJobParams &jp, const int32_t *__restrict__ in, const SrlaItemDesc &it,
+                                   unsigned char *lds, const double *__restrict__ rice_thresholds,
+                                   int32_t *__restrict__ res_ws, SrlaItemResult *__restrict__ out)
+{
+    constexpr int S = 4 * FL;                                   /* samples per thread */
+    constexpr int PADS = ((FIR_PAD + S - 1) / S) * S;           /* front padding, a multiple of S */
+    constexpr uint32_t SIG_WORDS = (uint32_t)((PADS + 1024 * FL) / S) * (S + 4) + 8;
+    int32_t *sig = (int32_t *)lds;
+    SmallF *sm = (SmallF *)(lds + ((SIG_WORDS * 4 + 15) & ~15u));
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t n = 1024u * FL, bps = jp.bits_per_sample;
+    const bool aligned = input_aligned(in, jp);
+    const int32_t coef = out->preemph_coef;
+    const uint32_t order = out->lpc_order, rshift = out->lpc_rshift, period = out->ltp_period;
+    const uint32_t o4 = (order + 3u) & ~3u;
+    const uint32_t s_base = (uint32_t)S * tid;
+
+    /* load + pre-emphasis (srla_utility.c:342) */
+    int32_t y[S];
+#pragma unroll
+    for (int c = 0; c < FL; c++) {
+        int32_t t4[4];
+        load_chunk(in, jp, it.variant, s_base + 4 * c, n, aligned, t4);
+        y[4 * c] = t4[0]; y[4 * c + 1] = t4[1]; y[4 * c + 2] = t4[2]; y[4 * c + 3] = t4[3];
+    }
+    {
+        int32_t prev = (tid == 0) ? y[0] : load_variant(in, jp, it.variant, s_base - 1);
+#pragma unroll
+        for (int i = 0; i < S; i++) {
+            const int32_t cur = y[i];
+            y[i] = (int32_t)((uint32_t)cur - (uint32_t)((int32_t)((uint32_t)prev * (uint32_t)coef) >> 4));
+            prev = cur;
+        }
+    }
+#define PUBLISH_Y()                                                                                              \
+    _Pragma("unroll") for (int c = 0; c < FL; c++)                                                               \
+        *reinterpret_cast<int4 *>(sig + sig_index<FL>(PADS + (int)s_base + 4 * c)) = make_int4(y[4 * c], y[4 * c + 1], y[4 * c + 2], y[4 * c + 3]);
+    PUBLISH_Y();
+    for (uint32_t i = tid; i < (uint32_t)(PADS / S) * (S + 4); i += NT) sig[i] = 0;    /* front padding */
+    for (uint32_t k = tid; k < o4; k += NT) sm->coefq[k] = (k < o4 - order) ? 0 : (int32_t)out->lpc_coef[k - (o4 - order)];
+    if (tid < 16) sm->level_bits[tid] = 0;
+    __syncthreads();
+
+    if (period > 0) {
+        /* long-term predictor, srla_lpc_predict.c:267-294 (in place: read everything, barrier, rewrite) */
+        const uint32_t taps = jp.ltp_order, half_order = taps >> 1;
+        const int32_t c0 = out->ltp_coef[0], c1 = out->ltp_coef[1], c2 = out->ltp_coef[2];
+#pragma unroll
+        for (int i = 0; i < S; i++) {
+            const uint32_t s = s_base + i;
+            if (s >= period + half_order + 1) {
+                const int base = PADS + (int)(s - period - half_order);
+                uint32_t acc = 16u + (uint32_t)c0 * (uint32_t)sig[sig_index<FL>(base)];
+                if (taps == 3) acc += (uint32_t)c1 * (uint32_t)sig[sig_index<FL>(base + 1)] + (uint32_t)c2 * (uint32_t)sig[sig_index<FL>(base + 2)];
+                y[i] = (int32_t)((uint32_t)y[i] - (uint32_t)((int32_t)acc >> 5));
+            }
+        }
+        __syncthreads();
+        PUBLISH_Y();
+        __syncthreads();
+    }
+#undef PUBLISH_Y
+
+    /* int32 wrap-around FIR (srla_lpc_predict.c:118-265) */
+    uint32_t u[S];
+    uint32_t max_u = 0;
+    {
+        const int32_t half = (int32_t)(1u << ((rshift - 1u) & 31u));
+        uint32_t acc[S];
+        int4 cur[FL];
+#pragma unroll
+        for (int i = 0; i < S; i++) acc[i] = (uint32_t)half;
+#pragma unroll
+        for (int c = 0; c < FL; c++) cur[c] = *reinterpret_cast<const int4 *>(sig + sig_index<FL>(PADS + (int)s_base + 4 * c - (int)o4));
+        for (uint32_t kb = 0; kb < o4; kb += 4) {
+            const int4 cf = *reinterpret_cast<const int4 *>(&sm->coefq[kb]);
+            const uint32_t f0 = (uint32_t)cf.x, f1 = (uint32_t)cf.y, f2 = (uint32_t)cf.z, f3 = (uint32_t)cf.w;
+#pragma unroll
+            for (int c = 0; c < FL; c++) {
+                const int4 nxt = *reinterpret_cast<const int4 *>(sig + sig_index<FL>(PADS + (int)s_base + 4 * c - (int)o4 + (int)kb + 4));
+                const uint32_t w0 = (uint32_t)cur[c].x, w1 = (uint32_t)cur[c].y, w2 = (uint32_t)cur[c].z, w3 = (uint32_t)cur[c].w;
+                const uint32_t w4 = (uint32_t)nxt.x, w5 = (uint32_t)nxt.y, w6 = (uint32_t)nxt.z;
+                acc[4 * c + 0] += f0 * w0 + f1 * w1 + f2 * w2 + f3 * w3;
+                acc[4 * c + 1] += f0 * w1 + f1 * w2 + f2 * w3 + f3 * w4;
+                acc[4 * c + 2] += f0 * w2 + f1 * w3 + f2 * w4 + f3 * w5;
+                acc[4 * c + 3] += f0 * w3 + f1 * w4 + f2 * w5 + f3 * w6;
+                cur[c] = nxt;
+            }
+        }
+        const int32_t yprev = (tid == 0) ? 0 : sig[sig_index<FL>(PADS + (int)s_base - 1)];
+        int32_t *res_out = res_ws + it.res_off + s_base;
+        int32_t rr[S];
+#pragma unroll
+        for (int i = 0; i < S; i++) {
+            const uint32_t s = s_base + i;
+            int32_t rv;
+            if (order == 0 || s == 0) rv = y[i];
+            else if (s < order) rv = (int32_t)((uint32_t)y[i] - (uint32_t)((i == 0) ? yprev : y[i - 1]));
+            else rv = (int32_t)((uint32_t)y[i] + (uint32_t)((int32_t)acc[i] >> rshift));
+            rr[i] = rv;
+            u[i] = zigzag32(rv);
+            max_u = (u[i] > max_u) ? u[i] : max_u;
+        }
+#pragma unroll
+        for (int c = 0; c < FL; c++) *reinterpret_cast<int4 *>(res_out + 4 * c) = make_int4(rr[4 * c], rr[4 * c + 1], rr[4 * c + 2], rr[4 * c + 3]);
+    }
+
+    /* partition means: exact integer sums at the finest level, pairwise averages above */
+    double m10[4];
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        unsigned long long sum = 0;
+#pragma unroll
+        for (int i = 0; i < FL; i++) sum += u[p * FL + i];
+        m10[p] = (double)sum / (double)FL;
+    }
+    double m[11];                                   /* m[l]: mean of the level-l partition this thread lies in */
+    const double m9a = (m10[0] + m10[1]) / 2.0, m9b = (m10[2] + m10[3]) / 2.0;
+    m[8] = (m9a + m9b) / 2.0;
+#pragma unroll
+    for (int l = 7; l >= 2; l--) {
+        const double other = __shfl_xor(m[l + 1], 1 << (7 - l), WAVE);
+        /* (mean[2p] + mean[2p+1]) / 2: the lane holding the even child adds in that order */
+        const bool even = ((lane >> (7 - l)) & 1u) == 0;
+        m[l] = even ? (m[l + 1] + other) / 2.0 : (other + m[l + 1]) / 2.0;
+    }
+    max_u = wave_max_u32(max_u);
+    if (lane == 0) { sm->wave_mean[wave] = m[2]; sm->wave_max[wave] = max_u; }
+    __syncthreads();
+    {
+        const double a = sm->wave_mean[0], b = sm->wave_mean[1], c = sm->wave_mean[2], d = sm->wave_mean[3];
+        const double m1a = (a + b) / 2.0, m1b = (c + d) / 2.0;
+        m[1] = (wave < 2) ? m1a : m1b;
+        m[0] = (m1a + m1b) / 2.0;
+        max_u = sm->wave_max[0];
+        for (int w = 1; w < NWAVES; w++) max_u = (sm->wave_max[w] > max_u) ? sm->wave_max[w] : max_u;
+    }
+    uint32_t code_type;
+    if (max_u == 0) code_type = SRLA_CODE_ALLZERO;
+    else if (m[0] < 2) code_type = SRLA_CODE_RICE;
+    else code_type = SRLA_CODE_RECURSIVE_RICE;
+
+    uint32_t best_porder = 0, best_bits = 0;
+    if (code_type != SRLA_CODE_ALLZERO) {
+        uint32_t k10[4], k9[2], kl[9];
+#pragma unroll
+        for (int p = 0; p < 4; p++) k10[p] = rice_param(m10[p], code_type, rice_thresholds);
+        k9[0] = rice_param(m9a, code_type, rice_thresholds);
+        k9[1] = rice_param(m9b, code_type, rice_thresholds);
+#pragma unroll
+        for (int l = 0; l <= 8; l++) kl[l] = rice_param(m[l], code_type, rice_thresholds);
+        /* publish the table (leaders only), heap layout */
+#pragma unroll
+        for (int p = 0; p < 4; p++) sm->ktab[1023 + 4 * tid + p] = (uint8_t)k10[p];
+        sm->ktab[511 + 2 * tid] = (uint8_t)k9[0];
+        sm->ktab[511 + 2 * tid + 1] = (uint8_t)k9[1];
+#pragma unroll
+        for (int l = 0; l <= 8; l++)
+            if ((tid & ((1u << (8 - l)) - 1u)) == 0) sm->ktab[((1u << l) - 1) + (tid >> (8 - l))] = (uint8_t)kl[l];
+        __syncthreads();
+        uint32_t acc[11];
+        /* side information (srla_coder.c:415-427) booked by the first thread of each partition */
+        {
+            uint32_t side10 = 0;
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                const uint32_t part = 4 * tid + p;
+                const uint32_t prevk = (p == 0) ? ((part == 0) ? 0u : sm->ktab[1023 + part - 1]) : k10[p - 1];
+                side10 += (part == 0) ? 15u : (zigzag32((int32_t)k10[p] - (int32_t)prevk) + 1u);
+            }
+            acc[10] = side10;
+            const uint32_t prev9 = (tid == 0) ? 0u : sm->ktab[511 + 2 * tid - 1];
+            acc[9] = ((tid == 0) ? 15u : (zigzag32((int32_t)k9[0] - (int32_t)prev9) + 1u)) + (zigzag32((int32_t)k9[1] - (int32_t)k9[0]) + 1u);
+#pragma unroll
+            for (int l = 0; l <= 8; l++) {
+                uint32_t side = 0;
+                if ((tid & ((1u << (8 - l)) - 1u)) == 0) {
+                    const uint32_t part = tid >> (8 - l);
+                    side = (part == 0) ? 15u : (zigzag32((int32_t)kl[l] - (int32_t)sm->ktab[((1u << l) - 1) + part - 1]) + 1u);
+                }
+                acc[l] = side;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < S; i++) {
+            const uint32_t val = u[i];
+            acc[10] += code_cost(val, k10[i / FL], code_type);
+            acc[9] += code_cost(val, k9[i / (2 * FL)], code_type);
+#pragma unroll
+            for (int l = 0; l <= 8; l++) acc[l] += code_cost(val, kl[l], code_type);
+        }
+#pragma unroll
+        for (int l = 0; l <= 10; l++) {
+            const uint32_t sum = wave_sum_u32(acc[l]);
+            if (lane == 0) atomicAdd(&sm->level_bits[l], sum);
+        }
+        __syncthreads();
+        best_bits = 0xFFFFFFFFu;
+        for (uint32_t l = 0; l <= 10; l++) {
+            const uint32_t b = sm->level_bits[l];
+            if (b < best_bits) { best_bits = b; best_porder = l; }
+        }
+        for (uint32_t p = tid; p < (1u << best_porder); p += NT) out->kparam[p] = sm->ktab[((1u << best_porder) - 1) + p];
+    }
+    if (tid == 0) {
+        const uint32_t res_bits = best_bits + 2u;
+        uint32_t bits = res_bits + (bps + 1u) + 5u + (8u + 4u + 1u) + out->pad[0] + 1u;   /* srla_encoder.c:1121-1187 */
+        if (period > 0) bits += 1u + 8u + jp.ltp_order * 6u;
+        out->code_length = bits;
+        out->res_code_type = code_type;
+        out->res_porder = best_porder;
+        out->res_bits = res_bits;
+    }
+}
+
+extern "C" uint32_t srla_kernel_fast_lds_bytes(uint32_t fl)
+{
+    const uint32_t S = 4 * fl, pads = ((FIR_PAD + S - 1) / S) * S;
+    const uint32_t sig_words = ((pads + 1024 * fl) / S) * (S + 4) + 8;
+    return ((sig_words * 4 + 15) & ~15u) + (uint32_t)((sizeof(SmallF) + 15) & ~15u);
+}
+
 template <int R>
 __global__ __launch_bounds__(NT) void srla_residual_cost(
     SrlaJobParams jp, const int32_t *__restrict__ input, const SrlaItemDesc *__restrict__ items,
@@ -713,6 +978,21 @@ __global__ __launch_bounds__(NT) void srla_residual_cost(
 {
     constexpr int CH = 2 * R;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    {
+        /* blocks of 1024 * FL samples take the register / shuffle fast path */
+        const SrlaItemDesc itf = items[blockIdx.x];
+        const uint32_t fl = itf.n >> 10;
+        if ((itf.n & 1023u) == 0 && fl >= 1 && fl <= 4 && fl <= (uint32_t)(2 * R)) {
+            const int32_t *inf = input + itf.sample_off;
+            SrlaItemResult *outf = &results[blockIdx.x];
+            switch (fl) {
+            case 1: residual_cost_fast<1>(jp, inf, itf, lds, rice_thresholds, res_ws, outf); return;
+            case 2: residual_cost_fast<2>(jp, inf, itf, lds, rice_thresholds, res_ws, outf); return;
+            case 3: residual_cost_fast<3>(jp, inf, itf, lds, rice_thresholds, res_ws, outf); return;
+            default: residual_cost_fast<4>(jp, inf, itf, lds, rice_thresholds, res_ws, outf); return;
+            }
+        }
+    }
     int32_t *sigA = (int32_t *)(lds + plan.y_off);        /* FIR_PAD zeros, then the signal */
     int32_t *sigB = (int32_t *)(lds + plan.fft_off);      /* LTP output (only when LTP is on) */
     double *means = (double *)(lds + plan.means_off);
