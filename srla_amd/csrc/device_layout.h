@@ -143,7 +143,9 @@ typedef struct SrlaJobParams {
     uint32_t num_items;
     uint32_t num_cands;
     uint32_t num_windows;
-    uint32_t out_stride;      /* elements between channel planes of the gathered output */
+    uint32_t out_stride;      /* unused */
+    const uint32_t *lshift_dev; /* when non-null the offset left shift is read from here (device memory): lets
+                               * a whole stream be enqueued before its OR-reduction has finished */
 } SrlaJobParams;
 
 /* LDS carve-up of kernel A for one FFT-size group (bytes, 16-byte aligned); host decides overlays */

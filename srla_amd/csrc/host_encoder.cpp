@@ -203,7 +203,8 @@ struct Job {
 struct Slot {
     hipStream_t stream = nullptr;
     hipEvent_t ev[8] = {};
-    DevBuf d_input, d_items, d_cands, d_windows, d_results, d_res_ws, d_blocks, d_cand_bytes, d_packed, d_chan, d_dbg, d_lags;
+    hipEvent_t chain[3] = {};        /* autocorr done, residual_cost done, pack done: stage chaining across jobs */
+    DevBuf d_input, d_items, d_cands, d_windows, d_results, d_res_ws, d_blocks, d_cand_bytes, d_packed, d_chan, d_dbg, d_lags, d_err;
     PinBuf h_in, h_packed, h_blocks, h_chan;
     Job job;
     bool busy = false;
@@ -221,8 +222,15 @@ struct Impl {
     uint32_t pack_threads = 0;
 
     bool dev_ready = false, dev_failed = false;
-    static constexpr uint32_t kSlots = 3;   /* jobs in flight: the GPU always has one queued behind the running one */
-    Slot slot[kSlots];
+    static constexpr uint32_t kMaxSlots = 8;
+    static constexpr uint32_t kStreams = 3;   /* more streams than HW queues serialise badly (measured) */
+    hipStream_t streams[kStreams] = {};
+    hipEvent_t ev_or = nullptr;       /* offset-shift reduction done */
+    bool lshift_on_device = false;
+    PinBuf h_or;
+    uint32_t kSlots = 3;              /* job buffer sets (SRLA_MI355X_SLOTS); slot i runs on stream i % kStreams */
+    uint64_t job_samples = 2ull << 20; /* samples per job (SRLA_MI355X_JOB_SAMPLES) */
+    Slot slot[kMaxSlots];
     DevBuf d_tw, d_geoms, d_thr, d_huff, d_or;
     std::map<uint32_t, uint32_t> tw_index;   /* nfft -> offset (double2) */
     std::vector<double> tw_host;
@@ -231,6 +239,7 @@ struct Impl {
     std::vector<SrlaGeom> geoms;
     bool geom_dirty = false;
     Pool *pool = nullptr;
+    Slot *last_launched = nullptr;    /* the job enqueued before this one (stage chaining) */
     SRLAMI355XStats stats{};
 
     ~Impl()
@@ -241,13 +250,16 @@ struct Impl {
             for (auto &s : slot) {
                 if (s.stream) (void)hipStreamSynchronize(s.stream);
                 for (auto &e : s.ev) if (e) (void)hipEventDestroy(e);
+                for (auto &e : s.chain) if (e) (void)hipEventDestroy(e);
                 DevBuf *db[] = { &s.d_input, &s.d_items, &s.d_cands, &s.d_windows, &s.d_results, &s.d_res_ws,
-                                 &s.d_blocks, &s.d_cand_bytes, &s.d_packed, &s.d_chan, &s.d_dbg, &s.d_lags };
+                                 &s.d_blocks, &s.d_cand_bytes, &s.d_packed, &s.d_chan, &s.d_dbg, &s.d_lags, &s.d_err };
                 for (auto *b : db) b->release();
                 PinBuf *pb[] = { &s.h_in, &s.h_packed, &s.h_blocks, &s.h_chan };
                 for (auto *b : pb) b->release();
-                if (s.stream) (void)hipStreamDestroy(s.stream);
             }
+            for (auto &st : streams) if (st) (void)hipStreamDestroy(st);
+            if (ev_or) (void)hipEventDestroy(ev_or);
+            h_or.release();
             d_tw.release(); d_geoms.release(); d_thr.release(); d_huff.release(); d_or.release();
         }
     }
@@ -261,6 +273,8 @@ struct Impl {
         if (dev_ready) return true;
         if (dev_failed) return false;
         dev_failed = true;
+        if (const char *e = getenv("SRLA_MI355X_SLOTS")) { const int v = atoi(e); if (v >= 2 && v <= (int)kMaxSlots) kSlots = (uint32_t)v; }
+        if (const char *e = getenv("SRLA_MI355X_JOB_SAMPLES")) { const long long v = atoll(e); if (v >= 65536) job_samples = (uint64_t)v; }
         int count = 0;
         if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
             fprintf(stderr, "[srla-mi355x] no HIP device available: the MI355X encode path cannot run "
@@ -268,9 +282,14 @@ struct Impl {
             return false;
         }
         HIP_OK(hipSetDevice(g_device_index));
-        for (auto &s : slot) {
-            HIP_OK(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+        for (auto &st : streams) HIP_OK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        HIP_OK(hipEventCreateWithFlags(&ev_or, hipEventDisableTiming));
+        if (!h_or.ensure(64)) return false;
+        for (uint32_t si = 0; si < kSlots; si++) {
+            Slot &s = slot[si];
+            s.stream = streams[si % kStreams];
             for (auto &e : s.ev) HIP_OK(hipEventCreate(&e));
+            for (auto &e : s.chain) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         }
         double thr[32];
         srla::build_rice_thresholds(thr);
@@ -326,7 +345,7 @@ struct Impl {
     bool sync_tables()
     {
         if (!tw_dirty && !geom_dirty) return true;
-        for (auto &s : slot) HIP_OK(hipStreamSynchronize(s.stream));
+        for (auto &s : slot) if (s.stream) HIP_OK(hipStreamSynchronize(s.stream));
         if (tw_dirty) {
             if (!d_tw.ensure(tw_host.size() * sizeof(double))) return false;
             HIP_OK(hipMemcpy(d_tw.p, tw_host.data(), tw_host.size() * sizeof(double), hipMemcpyHostToDevice));
@@ -455,6 +474,7 @@ struct Impl {
         jp.num_cands = (uint32_t)job.cands.size();
         jp.num_windows = (uint32_t)job.windows.size();
         jp.out_stride = job.ns;
+        jp.lshift_dev = lshift_on_device ? (d_or.as<uint32_t>() + 1) : nullptr;
         return jp;
     }
 
@@ -504,14 +524,22 @@ struct Impl {
             job.uploaded = true;
         }
         HIP_OK(hipEventRecord(s.ev[1], s.stream));
+        if (lshift_on_device) HIP_OK(hipStreamWaitEvent(s.stream, ev_or, 0));
 
         const SrlaJobParams jp = job_params(job, stride);
         for (const Group &g : job.groups) {
             const uint32_t fft_bytes = (8u * g.nfft + 15u) & ~15u;
             const uint32_t lag_rows = std::max<uint32_t>(par.ltp_order > 0 ? SRLA_LTP_LAGS : 0u, jp.max_order + 1);
             if (!s.d_lags.ensure((size_t)lag_rows * n_items * sizeof(double))) return false;
+            if (!s.d_err.ensure((size_t)(jp.max_order + 1) * n_items * sizeof(double))) return false;
             double *dbg = want_dbg ? s.d_dbg.as<double>() : nullptr;
             int rc = 0;
+            /* The wide kernels (autocorr, residual_cost, pack) each fill the GPU; the solve / pricing
+             * kernels are a few wavefronts of serial work.  Chaining each wide stage behind the SAME stage
+             * of the previous job staggers the jobs, so that the latency-bound kernels of job k overlap the
+             * wide kernels of job k+1 instead of all jobs idling through them together. */
+            Slot *prev = (last_launched && last_launched != &s) ? last_launched : nullptr;
+            if (prev) HIP_OK(hipStreamWaitEvent(s.stream, prev->chain[0], 0));
             if (par.ltp_order > 0) {
                 rc |= srla_launch_autocorr(s.stream, g.rclass, &jp, d_in, s.d_items.as<SrlaItemDesc>(), d_geoms.as<SrlaGeom>(), d_tw.p,
                                            fft_bytes, 1, s.d_results.as<SrlaItemResult>(), s.d_lags.as<double>(), dbg);
@@ -519,34 +547,43 @@ struct Impl {
             }
             rc |= srla_launch_autocorr(s.stream, g.rclass, &jp, d_in, s.d_items.as<SrlaItemDesc>(), d_geoms.as<SrlaGeom>(), d_tw.p,
                                        fft_bytes, 0, s.d_results.as<SrlaItemResult>(), s.d_lags.as<double>(), dbg);
+            HIP_OK(hipEventRecord(s.chain[0], s.stream));
             HIP_OK(hipEventRecord(s.ev[6], s.stream));
             if (jp.max_order > 0)
                 rc |= srla_launch_lpc_solve(s.stream, &jp, s.d_items.as<SrlaItemDesc>(), d_geoms.as<SrlaGeom>(), s.d_lags.as<double>(),
-                                            d_huff.as<uint8_t>(), s.d_results.as<SrlaItemResult>(), dbg);
+                                            s.d_err.as<double>(), d_huff.as<uint8_t>(), s.d_results.as<SrlaItemResult>(), dbg);
             HIP_OK(hipEventRecord(s.ev[7], s.stream));
+            if (prev) HIP_OK(hipStreamWaitEvent(s.stream, prev->chain[1], 0));
             rc |= srla_launch_residual_cost(s.stream, g.rclass, &jp, d_in, s.d_items.as<SrlaItemDesc>(), d_geoms.as<SrlaGeom>(), &g.plan,
                                             d_thr.as<double>(), s.d_res_ws.as<int32_t>(), s.d_results.as<SrlaItemResult>());
+            HIP_OK(hipEventRecord(s.chain[1], s.stream));
             if (rc != 0) {
                 fprintf(stderr, "[srla-mi355x] item analysis launch failed (nfft %u)\n", g.nfft);
                 return false;
             }
             stats.analyze_launches++;
         }
-        if (job.groups.empty()) { HIP_OK(hipEventRecord(s.ev[6], s.stream)); HIP_OK(hipEventRecord(s.ev[7], s.stream)); }
+        if (job.groups.empty()) {
+            HIP_OK(hipEventRecord(s.ev[6], s.stream)); HIP_OK(hipEventRecord(s.ev[7], s.stream));
+            HIP_OK(hipEventRecord(s.chain[0], s.stream)); HIP_OK(hipEventRecord(s.chain[1], s.stream));
+        }
         HIP_OK(hipEventRecord(s.ev[2], s.stream));
         if (srla_launch_price(s.stream, &jp, s.d_windows.as<SrlaWindowDesc>(), s.d_cands.as<SrlaCandDesc>(),
                               s.d_results.as<SrlaItemResult>(), s.d_blocks.as<SrlaBlockRecord>(),
                               s.d_cand_bytes.as<uint32_t>()) != 0) return false;
         HIP_OK(hipEventRecord(s.ev[3], s.stream));
+        if (last_launched && last_launched != &s) HIP_OK(hipStreamWaitEvent(s.stream, last_launched->chain[2], 0));
         if (srla_launch_pack(s.stream, &jp, job.num_slots, d_in, s.d_items.as<SrlaItemDesc>(),
                              s.d_blocks.as<SrlaBlockRecord>(), s.d_results.as<SrlaItemResult>(),
                              s.d_res_ws.as<int32_t>(), s.d_packed.as<uint8_t>(), s.d_chan.as<SrlaChanRecord>()) != 0) return false;
+        HIP_OK(hipEventRecord(s.chain[2], s.stream));
         HIP_OK(hipEventRecord(s.ev[4], s.stream));
         HIP_OK(hipMemcpyAsync(s.h_packed.p, s.d_packed.p, packed_bytes, hipMemcpyDeviceToHost, s.stream));
         HIP_OK(hipMemcpyAsync(s.h_blocks.p, s.d_blocks.p, (size_t)job.num_slots * sizeof(SrlaBlockRecord), hipMemcpyDeviceToHost, s.stream));
         HIP_OK(hipMemcpyAsync(s.h_chan.p, s.d_chan.p, (size_t)job.num_slots * nch * sizeof(SrlaChanRecord), hipMemcpyDeviceToHost, s.stream));
         HIP_OK(hipEventRecord(s.ev[5], s.stream));
         s.busy = true;
+        last_launched = &s;
         stats.num_windows += n_win; stats.num_candidates += n_cands; stats.num_items += n_items;
         stats.analyzed_samples += job.analyzed_samples;
         return true;
@@ -554,7 +591,7 @@ struct Impl {
 
     bool wait_job(Slot &s)
     {
-        HIP_OK(hipStreamSynchronize(s.stream));
+        HIP_OK(hipEventSynchronize(s.ev[5]));     /* this job only: its stream may already carry a later job */
         float t = 0;
         if (hipEventElapsedTime(&t, s.ev[0], s.ev[1]) == hipSuccess) stats.h2d_ms += t;
         if (hipEventElapsedTime(&t, s.ev[1], s.ev[2]) == hipSuccess) stats.analyze_ms += t;
@@ -648,8 +685,7 @@ struct Impl {
             per_window *= ratio;
         }
         uint64_t w = (1536ull << 20) / std::max<uint64_t>(per_window, 1);
-        const uint64_t cap_samples = 2ull << 20;   /* ~2M samples per job: several jobs per stream so that the
-                                                    * GPU (job k+1) and the host pack (job k) overlap */
+        const uint64_t cap_samples = job_samples;  /* several jobs per stream so that the GPU and the host pack overlap */
         w = std::min<uint64_t>(w, std::max<uint64_t>(1, cap_samples / window_len));
         return (uint32_t)std::max<uint64_t>(1, w);
     }
@@ -673,18 +709,20 @@ struct Impl {
                     mask |= m;
                 }
             } else {
-                Slot &s = slot[0];
-                if (hipMemsetAsync(d_or.p, 0, 4, s.stream) != hipSuccess) return SRLA_APIRESULT_NG;
-                for (uint32_t ch = 0; ch < nch; ch++)
-                    if (srla_launch_or_reduce(s.stream, d_in + (size_t)ch * d_stride, num_samples, d_or.as<uint32_t>()) != 0) return SRLA_APIRESULT_NG;
-                if (hipMemcpyAsync(&mask, d_or.p, 4, hipMemcpyDeviceToHost, s.stream) != hipSuccess) return SRLA_APIRESULT_NG;
-                if (hipStreamSynchronize(s.stream) != hipSuccess) return SRLA_APIRESULT_NG;
+                /* on the device, without a host round trip: the jobs read the shift from device memory */
+                hipStream_t st = streams[0];
+                if (hipMemsetAsync(d_or.p, 0, 8, st) != hipSuccess) return SRLA_APIRESULT_NG;
+                if (srla_launch_or_reduce(st, d_in, d_stride, num_samples, nch, d_or.as<uint32_t>()) != 0) return SRLA_APIRESULT_NG;
+                if (hipMemcpyAsync(h_or.p, d_or.p, 8, hipMemcpyDeviceToHost, st) != hipSuccess) return SRLA_APIRESULT_NG;
+                if (hipEventRecord(ev_or, st) != hipSuccess) return SRLA_APIRESULT_NG;
+                lshift_on_device = true;
             }
-            uint32_t sh = 0;
-            if (mask != 0) while (((mask >> sh) & 1u) == 0) sh++;
-            offset_lshift = sh;
-            srla::write_stream_header(stream_info(num_samples), data);
-            write_off = SRLA_HEADER_SIZE;
+            if (!lshift_on_device) {
+                uint32_t sh = 0;
+                if (mask != 0) while (((mask >> sh) & 1u) == 0) sh++;
+                offset_lshift = sh;
+            }
+            write_off = SRLA_HEADER_SIZE;   /* the header itself is written once the shift is known (below) */
         }
         const srla::StreamInfo si = stream_info(num_samples);
         const uint32_t window_len = search ? par.num_lookahead_samples : par.max_num_samples_per_block;
@@ -701,18 +739,32 @@ struct Impl {
             build_job(s.job, s0, ns, search);
             return launch_job(s, d_in ? d_in + s0 : nullptr, d_stride, host_in, false);
         };
-        for (uint32_t k = 0; k + 1 < kSlots && k < njobs; k++)
-            if (!start(k)) return SRLA_APIRESULT_NG;
+        /* kSlots - 1 jobs are kept queued on the GPU; job k + kSlots - 1 is enqueued as soon as job k has
+         * completed and BEFORE the host packs job k, so the GPU never waits for the packer */
+        auto fail = [&](SRLAApiResult rc) {
+            for (auto &st : streams) if (st) (void)hipStreamSynchronize(st);
+            for (auto &sl : slot) sl.busy = false;
+            lshift_on_device = false;
+            return rc;
+        };
+        const uint32_t ahead = kSlots - 1;
+        for (uint32_t k = 0; k < ahead && k < njobs; k++)
+            if (!start(k)) return fail(SRLA_APIRESULT_NG);
         for (uint32_t k = 0; k < njobs; k++) {
-            if (k + kSlots - 1 < njobs && !start(k + kSlots - 1)) return SRLA_APIRESULT_NG;
             Slot &s = slot[k % kSlots];
-            if (!wait_job(s)) return SRLA_APIRESULT_NG;
+            if (!wait_job(s)) return fail(SRLA_APIRESULT_NG);
+            if (k + ahead < njobs && !start(k + ahead)) return fail(SRLA_APIRESULT_NG);
+            if (k == 0 && with_header) {
+                if (lshift_on_device) {
+                    /* stream 0 has been synchronised by wait_job(job 0): the reduction result is on the host */
+                    if (hipEventSynchronize(ev_or) != hipSuccess) return fail(SRLA_APIRESULT_NG);
+                    offset_lshift = h_or.as<uint32_t>()[1];
+                }
+                srla::write_stream_header(stream_info(num_samples), data);
+            }
             uint32_t wrote = 0;
             const SRLAApiResult rc = pack_job(s, si, data + write_off, data_size - write_off, &wrote, window_bytes);
-            if (rc != SRLA_APIRESULT_OK) {
-                for (auto &sl : slot) if (sl.busy) { (void)hipStreamSynchronize(sl.stream); sl.busy = false; }
-                return rc;
-            }
+            if (rc != SRLA_APIRESULT_OK) return fail(rc);
             /* callbacks: once per window, in order, pointing into the caller's buffer
              * (srla_encoder.c:1779-1782) */
             uint32_t off = write_off;
@@ -723,6 +775,7 @@ struct Impl {
             }
             write_off += wrote;
         }
+        lshift_on_device = false;
         *output_size = write_off;
         stats.total_ms += ms_since(t0);
         return SRLA_APIRESULT_OK;

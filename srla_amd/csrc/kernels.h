@@ -31,7 +31,7 @@ int srla_launch_autocorr(hipStream_t stream, int rclass, const SrlaJobParams *jp
                          uint32_t fft_bytes, uint32_t pass, SrlaItemResult *results, double *lags_ws, double *dbg);
 int srla_launch_pitch_solve(hipStream_t stream, const SrlaJobParams *jp, const double *lags_ws, SrlaItemResult *results);
 int srla_launch_lpc_solve(hipStream_t stream, const SrlaJobParams *jp, const SrlaItemDesc *items,
-                          const SrlaGeom *geoms, const double *lags_ws, const uint8_t *huff_len,
+                          const SrlaGeom *geoms, const double *lags_ws, double *err_ws, const uint8_t *huff_len,
                           SrlaItemResult *results, double *dbg);
 int srla_launch_residual_cost(hipStream_t stream, int rclass, const SrlaJobParams *jp, const int32_t *input,
                               const SrlaItemDesc *items, const SrlaGeom *geoms, const SrlaLdsPlan *plan,
@@ -46,7 +46,8 @@ int srla_launch_pack(hipStream_t stream, const SrlaJobParams *jp, uint32_t num_s
                      const SrlaItemResult *results, const int32_t *res_ws, uint8_t *packed,
                      SrlaChanRecord *chan_out);
 
-int srla_launch_or_reduce(hipStream_t stream, const int32_t *in, size_t count, uint32_t *out);
+int srla_launch_or_reduce(hipStream_t stream, const int32_t *in, size_t channel_stride, size_t count,
+                          uint32_t num_channels, uint32_t *out);
 
 #ifdef __cplusplus
 }

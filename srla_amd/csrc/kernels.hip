@@ -10,10 +10,11 @@
  *                           (fp64, operation order of libs/fft) -> |X|^2 -> inverse -> lags.
  *   srla_pitch_solve        (LTP only) ONE LANE per item: the sequential pitch scan of
  *                           lpc.c:1473-1555 and the 3x3 Cholesky solve, 64 items per wavefront.
- *   srla_lpc_solve<L>       ONE LANE per item: Levinson-Durbin with the gamma dot product summed in
- *                           index order (lpc.c:417-438), code-length estimate per order, order choice,
- *                           8-bit quantiser with error feedback -- all inherently serial per item, so 64
- *                           recursions run side by side in a wavefront with column-major LDS arrays.
+ *   srla_lpc_recursion<L>   ONE LANE per item: Levinson-Durbin with the gamma dot product summed in index
+ *                           order (lpc.c:417-438) -- inherently serial per item, so 64 recursions run side by
+ *                           side in a wavefront on column-major LDS arrays.
+ *   srla_order_select       one wave per item, lane = order: code-length estimate and its first strict minimum.
+ *   srla_lpc_quantize<L>    one lane per item: predictor of the chosen order, 8-bit quantiser, tap cost.
  *   srla_residual_cost<R>   one workgroup per item: pre-emphasis (+LTP), register-blocked int32 FIR,
  *                           residual to HBM, partitioned (recursive) Rice code-length search.
  *   srla_price_windows      stereo decision + block sizes + shortest path, one thread per window.
@@ -299,6 +300,7 @@ __global__ __launch_bounds__(NT) void srla_autocorr(
 {
     constexpr int CH = 2 * R;   /* chunks of four samples per thread: covers 2048 * R >= nfft */
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    if (jp.lshift_dev) jp.offset_lshift = *jp.lshift_dev;
     double *buf = (double *)lds;
     SmallA *sm = (SmallA *)(lds + fft_bytes);
 
@@ -562,15 +564,124 @@ __global__ __launch_bounds__(WAVE) void srla_pitch_solve(SrlaJobParams jp, const
 }
 
 /* ================================================================================================
- * K2: srla_lpc_solve -- one lane per item; a[] and r[] live in LDS column-major ([i][lane]) so that the
- * 64 recursions of a wavefront run without bank conflicts.  (lpc.c:379-441, 483-497,
- * srla_encoder.c:934-957, lpc.c:1341-1405, srla_encoder.c:1104-1108, 1141-1174)
+ * K2: Levinson-Durbin / order choice / quantiser.  Three kernels:
+ *   srla_lpc_recursion<L>  one LANE per item: the full recursion (lpc.c:379-441) with the gamma dot product
+ *                          summed in index order; a[] and r[] live in LDS column-major ([i][lane]) so the 64
+ *                          recursions of a wavefront run without bank conflicts; loops are unrolled so that
+ *                          several LDS loads are in flight per dependent add.  Writes the (uncompensated)
+ *                          error variance of every order.
+ *   srla_order_select      one WAVE per item, lane = order: window compensation (lpc.c:490-497), code-length
+ *                          estimate (srla_encoder.c:934-957) and its first strict minimum -- fully parallel.
+ *   srla_lpc_quantize<L>   one LANE per item: recursion up to the chosen order, 8-bit quantiser with error
+ *                          feedback (lpc.c:1341-1405), tap order reversal (srla_encoder.c:1104-1108), Huffman
+ *                          cost plain vs pair-summed (srla_encoder.c:1141-1174).
  * ============================================================================================== */
+#define A_(i) a[(size_t)(i) * L + lane]
+#define R_(i) r[(size_t)(i) * L + lane]
+
+/* recursion up to `upto` (>= 1); err_out (may be null) receives the error variance of orders 1..upto at
+ * err_out[order * stride]; on return A_(1..upto) is the predictor of order `upto` */
 template <int L>
-__global__ __launch_bounds__(WAVE) void srla_lpc_solve(
-    SrlaJobParams jp, const SrlaItemDesc *__restrict__ items, const SrlaGeom *__restrict__ geoms,
-    const double *__restrict__ lags_ws, const uint8_t *__restrict__ huff_len,
-    SrlaItemResult *__restrict__ results, double *__restrict__ dbg)
+__device__ __forceinline__ void levinson_lane(double *a, double *r, uint32_t lane, double r0, uint32_t upto,
+                                              double *err_out, size_t stride)
+{
+    const double a1 = -R_(1) / r0;
+    A_(0) = 1.0; A_(1) = a1; A_(2) = 0.0;
+    double e = r0 + R_(1) * a1;
+    if (err_out) err_out[stride] = e;
+    for (uint32_t k = 1; k < upto; k++) {
+        /* gamma = sum_{i=0..k} a[i] * r[k+1-i], accumulated in index order (lpc.c:420-423) */
+        double gamma = 0.0;
+        uint32_t i = 0;
+        for (; i + 4 <= k + 1; i += 4) {
+            const double x0 = A_(i), x1 = A_(i + 1), x2 = A_(i + 2), x3 = A_(i + 3);
+            const double y0 = R_(k + 1 - i), y1 = R_(k - i), y2 = R_(k - 1 - i), y3 = R_(k - 2 - i);
+            const double p0 = x0 * y0, p1 = x1 * y1, p2 = x2 * y2, p3 = x3 * y3;
+            gamma += p0; gamma += p1; gamma += p2; gamma += p3;
+        }
+        for (; i < k + 1; i++) gamma += A_(i) * R_(k + 1 - i);
+        gamma /= -e;
+        e = e * (1.0 - gamma * gamma);
+        /* a'[i] = a[i] + gamma * a[k+1-i] for i = 0..k+1, pairwise in place (lpc.c:430-433) */
+        uint32_t lo = 0, hi = k + 1;
+        for (; lo + 1 < hi - 1; lo += 2, hi -= 2) {
+            const double al0 = A_(lo), ah0 = A_(hi), al1 = A_(lo + 1), ah1 = A_(hi - 1);
+            A_(lo) = al0 + gamma * ah0; A_(hi) = ah0 + gamma * al0;
+            A_(lo + 1) = al1 + gamma * ah1; A_(hi - 1) = ah1 + gamma * al1;
+        }
+        for (; lo <= hi; lo++, hi--) {
+            const double al = A_(lo), ah = A_(hi);
+            A_(lo) = al + gamma * ah;
+            if (lo != hi) A_(hi) = ah + gamma * al;
+            if (hi == 0) break;
+        }
+        A_(k + 2) = 0.0;
+        if (err_out) err_out[(size_t)(k + 1) * stride] = e;
+    }
+}
+
+/* Register-resident variant for max order P <= 64: the predictor a[] lives in VGPRs (fully unrolled
+ * recursion, static indices), the lags r[] stay in LDS column-major -- their loads do not depend on the
+ * running sum, so the only serial chain left is the index-ordered accumulation itself.  `upto` may differ
+ * per lane (exec-masked steps); orders above the wave's maximum are skipped. */
+template <int P>
+__device__ __forceinline__ void levinson_regs(double (&a)[P + 2], const double *r, uint32_t lane, double r0, uint32_t upto,
+                                              double *err_out, size_t stride)
+{
+    constexpr int L = WAVE;
+    const double r1 = R_(1);
+    const double a1 = -r1 / r0;
+    a[0] = 1.0; a[1] = a1; a[2] = 0.0;
+    double e = r0 + r1 * a1;
+    if (err_out) err_out[stride] = e;
+#pragma unroll
+    for (int k = 1; k < P; k++) {
+        if ((uint32_t)k < upto) {
+            double gamma = 0.0;
+#pragma unroll
+            for (int i = 0; i <= k; i++) gamma += a[i] * R_(k + 1 - i);          /* index order, lpc.c:420-423 */
+            gamma /= -e;
+            e = e * (1.0 - gamma * gamma);
+#pragma unroll
+            for (int i = 0; i <= (k + 1) / 2; i++) {
+                const int j = k + 1 - i;
+                const double ai = a[i], aj = a[j];
+                a[i] = ai + gamma * aj;
+                if (i != j) a[j] = aj + gamma * ai;
+            }
+            a[k + 2 <= P + 1 ? k + 2 : P + 1] = (k + 2 <= P + 1) ? 0.0 : a[P + 1];
+            if (err_out) err_out[(size_t)(k + 1) * stride] = e;
+        }
+    }
+}
+
+template <int P>
+__global__ __launch_bounds__(WAVE) void srla_lpc_recursion_regs(SrlaJobParams jp, const double *__restrict__ lags_ws,
+                                                                double *__restrict__ err_ws)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr int L = WAVE;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t idx = blockIdx.x * WAVE + lane;
+    if (idx >= jp.num_items) return;
+    double *r = (double *)lds;
+    const size_t stride = jp.num_items;
+#pragma unroll 8
+    for (uint32_t i = 0; i <= (uint32_t)P; i++) R_(i) = lags_ws[(size_t)i * stride + idx];
+    const double r0 = R_(0) * (1.0 + 1e-5);          /* ridge, lpc.c:483 */
+    double *err = err_ws + idx;
+    err[0] = r0;
+    if (fabs(r0) < (double)FLT_EPSILON) {
+        for (uint32_t o = 1; o <= (uint32_t)P; o++) err[(size_t)o * stride] = r0;   /* lpc.c:395-405 */
+        return;
+    }
+    double a[P + 2];
+    levinson_regs<P>(a, r, lane, r0, (uint32_t)P, err, stride);
+}
+
+template <int L>
+__global__ __launch_bounds__(WAVE) void srla_lpc_recursion(SrlaJobParams jp, const double *__restrict__ lags_ws,
+                                                           double *__restrict__ err_ws)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const uint32_t lane = threadIdx.x;
@@ -579,69 +690,177 @@ __global__ __launch_bounds__(WAVE) void srla_lpc_solve(
     const uint32_t p = jp.max_order;
     double *a = (double *)lds;                        /* a[i * L + lane], i < p + 2 */
     double *r = a + (size_t)(p + 2) * L;              /* r[i * L + lane], i < p + 1 */
-#define A_(i) a[(size_t)(i) * L + lane]
-#define R_(i) r[(size_t)(i) * L + lane]
-    const SrlaItemDesc it = items[idx];
-    const SrlaGeom g = geoms[it.geom];
-    const uint32_t n = it.n, bps = jp.bits_per_sample;
     const size_t stride = jp.num_items;
-    double *dbg_item = dbg ? dbg + (size_t)idx * SRLA_DBG_STRIDE : nullptr;
-    SrlaItemResult *out = &results[idx];
-
     for (uint32_t i = 0; i <= p; i++) R_(i) = lags_ws[(size_t)i * stride + idx];
     const double r0 = R_(0) * (1.0 + 1e-5);          /* ridge, lpc.c:483 */
-    R_(0) = r0;
-    const bool silent = fabs(r0) < (double)FLT_EPSILON;
-
-    /* first strict minimum of the estimated code length (srla_encoder.c:940-950) */
-    double best_len = (double)FLT_MAX, second = (double)FLT_MAX;
-    uint32_t best_order = 0;
-    auto consider = [&](uint32_t order, double err_uncompensated) {
-        const double ev = err_uncompensated * g.welch_comp;          /* lpc.c:490-497 */
-        const double mabse = 2.0 * sqrt(ev / 2.0);
-        double len = geometric_entropy(mabse, bps) * (double)n;
-        len += (double)(8u * order);
-        if (dbg_item) { dbg_item[SRLA_DBG_ERRVARS + order] = ev; dbg_item[SRLA_DBG_LENS + order] = len; }
-        if (best_len > len) { second = best_len; best_len = len; best_order = order; }
-        else if (second > len) second = len;
-    };
-    if (dbg_item) dbg_item[SRLA_DBG_ERRVARS] = r0 * g.welch_comp;
-
-    auto recursion = [&](uint32_t upto, bool choose) {
-        /* lpc.c:408-438; on return A_(1..upto) is the predictor of order `upto` */
-        const double a1 = -R_(1) / r0;
-        A_(0) = 1.0; A_(1) = a1; A_(2) = 0.0;
-        double e = r0 + R_(1) * a1;
-        if (choose) consider(1, e);
-        for (uint32_t k = 1; k < upto; k++) {
-            double gamma = 0.0;
-            for (uint32_t i = 0; i < k + 1; i++) gamma += A_(i) * R_(k + 1 - i);   /* index order */
-            gamma /= -e;
-            e = e * (1.0 - gamma * gamma);
-            /* a'[i] = a[i] + gamma * a[k+1-i], i = 0..k+1, done pairwise in place */
-            for (uint32_t i = 0, j = k + 1; i <= j; i++, j--) {
-                const double ai = A_(i), aj = A_(j);
-                A_(i) = ai + gamma * aj;
-                if (i != j) A_(j) = aj + gamma * ai;
-            }
-            A_(k + 2) = 0.0;
-            if (choose) consider(k + 1, e);
-        }
-    };
-
-    uint32_t flags = 0;
-    if (p > 0) {
-        if (silent) { for (uint32_t o = 1; o <= p; o++) consider(o, r0); }
-        else recursion(p, true);
+    double *err = err_ws + idx;
+    err[0] = r0;
+    if (fabs(r0) < (double)FLT_EPSILON) {
+        for (uint32_t o = 1; o <= p; o++) err[(size_t)o * stride] = r0;   /* lpc.c:395-405 */
+        return;
     }
-    uint32_t order = best_order;
-    if (jp.order_fixed) order = p;
-    else if (best_order != 0 && (second - best_len) <= 1e-9 * fabs(best_len) + 1e-9) flags |= SRLA_ITEM_ORDER_TIE;
-    if (it.forced_order >= 0) order = (uint32_t)it.forced_order;
+    levinson_lane<L>(a, r, lane, r0, p, err, stride);
+}
 
+__global__ __launch_bounds__(WAVE) void srla_order_select(
+    SrlaJobParams jp, const SrlaItemDesc *__restrict__ items, const SrlaGeom *__restrict__ geoms,
+    const double *__restrict__ err_ws, SrlaItemResult *__restrict__ results, double *__restrict__ dbg)
+{
+    const uint32_t idx = blockIdx.x, lane = threadIdx.x;
+    const SrlaItemDesc it = items[idx];
+    const double comp = geoms[it.geom].welch_comp;
+    const uint32_t p = jp.max_order, n = it.n, bps = jp.bits_per_sample;
+    const size_t stride = jp.num_items;
+    double *dbg_item = dbg ? dbg + (size_t)idx * SRLA_DBG_STRIDE : nullptr;
+    if (dbg_item && lane == 0) dbg_item[SRLA_DBG_ERRVARS] = err_ws[idx] * comp;
+    /* first strict minimum == the lowest order among the smallest lengths; lengths that are NaN or not
+     * below FLT_MAX are never chosen (srla_encoder.c:938-950) */
+    const double kInf = __builtin_inf();
+    double best = kInf, second = kInf;
+    uint32_t best_order = 0;
+    for (uint32_t base = 1; base <= p; base += WAVE) {
+        const uint32_t o = base + lane;
+        double len = kInf;
+        if (o <= p) {
+            const double ev = err_ws[(size_t)o * stride + idx] * comp;          /* lpc.c:490-497 */
+            const double mabse = 2.0 * sqrt(ev / 2.0);
+            double l = geometric_entropy(mabse, bps) * (double)n;
+            l += (double)(8u * o);
+            if (dbg_item) { dbg_item[SRLA_DBG_ERRVARS + o] = ev; dbg_item[SRLA_DBG_LENS + o] = l; }
+            if (l < (double)FLT_MAX) len = l;
+        }
+        /* wave reduction of (len, order) in lexicographic order, plus the runner-up length */
+        double v = len, v2 = kInf; uint32_t vo = o;
+        for (int off = 32; off > 0; off >>= 1) {
+            const double ov = __shfl_xor(v, off, WAVE), ov2 = __shfl_xor(v2, off, WAVE);
+            const uint32_t oo = __shfl_xor(vo, off, WAVE);
+            const bool other_wins = (ov < v) || (ov == v && oo < vo);
+            const double loser = other_wins ? v : ov;
+            double s2 = (ov2 < v2) ? ov2 : v2;
+            s2 = (loser < s2) ? loser : s2;
+            if (other_wins) { v = ov; vo = oo; }
+            v2 = s2;
+        }
+        if (v < best) { second = (best < v2) ? best : v2; best = v; best_order = vo; }
+        else { const double c = (v < v2) ? v : v2; second = (c < second) ? c : second; }
+    }
+    if (lane == 0) {
+        uint32_t order = (best < kInf) ? best_order : 0u;
+        uint32_t flags = 0;
+        if (jp.order_fixed) order = p;
+        else if (order != 0 && (second - best) <= 1e-9 * fabs(best) + 1e-9) flags |= SRLA_ITEM_ORDER_TIE;
+        if (it.forced_order >= 0) order = (uint32_t)it.forced_order;
+        results[idx].lpc_order = order;
+        if (flags) results[idx].flags |= flags;
+    }
+}
+
+/* shared tail of the quantiser kernels: cf(i) = tap i of the chosen predictor */
+template <typename CF, typename QS, typename QL>
+__device__ __forceinline__ void quantize_and_price(uint32_t order, bool silent, CF cf, QS qstore, QL qload,
+                                                   const uint8_t *__restrict__ huff_len, SrlaItemResult *out)
+{
     uint32_t rshift = 0, use_sum = 0, coef_bits = 0;
     if (order > 0) {
-        if (!silent && order != p) recursion(order, false);
+        /* 8-bit quantisation with error feedback from the last tap (lpc.c:1341-1405) */
+        double maxabs = 0.0;
+        if (!silent) for (uint32_t i = 0; i < order; i++) { const double v = fabs(cf(i)); if (maxabs < v) maxabs = v; }
+        if (maxabs <= 0.0078125) {
+            rshift = 8;
+            for (uint32_t i = 0; i < order; i++) qstore(i, 0);
+        } else {
+            int ndigit;
+            (void)frexp(maxabs, &ndigit);
+            rshift = (uint32_t)(7 - ndigit);
+            if (rshift >= 16u) rshift = 15u;
+            const double scale = __builtin_ldexp(1.0, (int)rshift);
+            double qerr = 0.0;
+            for (int i = (int)order - 1; i >= 0; i--) {
+                qerr += cf((uint32_t)i) * scale;
+                int32_t qq = (int32_t)round_half_away(qerr);
+                if (qq >= 128) qq = 127; else if (qq < -128) qq = -128;
+                qerr -= (double)qq;
+                qstore(order - 1 - (uint32_t)i, qq);        /* reversed: oldest sample first (srla_encoder.c:1104) */
+            }
+        }
+        /* Huffman cost plain vs pair-summed (srla_encoder.c:1141-1174) */
+        uint32_t plain = 0, summed = 0, overflow = 0;
+        int32_t prevq = 0;
+        for (uint32_t k = 0; k < order; k++) {
+            const int32_t c = qload(k);
+            out->lpc_coef[k] = (int8_t)c;
+            plain += huff_len[zigzag32(c)];
+            if (k == 0) summed += huff_len[zigzag32(c)];
+            else {
+                const uint32_t z = zigzag32(c + prevq);
+                if (z >= 256u) overflow = 1; else summed += huff_len[256 + z];
+            }
+            prevq = c;
+        }
+        use_sum = (overflow == 0 && (order == 1 || summed < plain)) ? 1u : 0u;
+        coef_bits = use_sum ? summed : plain;
+    }
+    out->lpc_rshift = rshift;
+    out->use_sum = use_sum;
+    out->pad[0] = coef_bits;
+}
+
+template <int P>
+__global__ __launch_bounds__(WAVE) void srla_lpc_quantize_regs(
+    SrlaJobParams jp, const double *__restrict__ lags_ws, const uint8_t *__restrict__ huff_len,
+    SrlaItemResult *__restrict__ results)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr int L = WAVE;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t idx = blockIdx.x * WAVE + lane;
+    if (idx >= jp.num_items) return;
+    double *r = (double *)lds;                       /* r[i * 64 + lane], i <= P; later: a copy of the taps */
+    const size_t stride = jp.num_items;
+    SrlaItemResult *out = &results[idx];
+    const uint32_t order = out->lpc_order;
+    bool silent = true;
+    if (order > 0) {
+        for (uint32_t i = 0; i <= order; i++) R_(i) = lags_ws[(size_t)i * stride + idx];
+        const double r0 = R_(0) * (1.0 + 1e-5);
+        silent = fabs(r0) < (double)FLT_EPSILON;
+        double a[P + 2];
+        if (!silent) {
+            levinson_regs<P>(a, r, lane, r0, order, nullptr, 0);
+            /* taps to LDS (dynamic indexing from here on); r[] is no longer needed */
+#pragma unroll
+            for (int i = 0; i < P; i++) if ((uint32_t)i < order) R_(i) = a[1 + i];
+        }
+    }
+    double *taps = r;
+    int32_t *q = (int32_t *)(r + (size_t)(P + 1) * L);
+    quantize_and_price(order, silent,
+                       [&](uint32_t i) -> double { return taps[(size_t)i * L + lane]; },
+                       [&](uint32_t i, int32_t v) { q[(size_t)i * L + lane] = v; },
+                       [&](uint32_t i) -> int32_t { return q[(size_t)i * L + lane]; }, huff_len, out);
+}
+
+template <int L>
+__global__ __launch_bounds__(WAVE) void srla_lpc_quantize(
+    SrlaJobParams jp, const double *__restrict__ lags_ws, const uint8_t *__restrict__ huff_len,
+    SrlaItemResult *__restrict__ results)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t idx = blockIdx.x * L + lane;
+    if (lane >= L || idx >= jp.num_items) return;
+    const uint32_t p = jp.max_order;
+    double *a = (double *)lds;
+    double *r = a + (size_t)(p + 2) * L;
+    const size_t stride = jp.num_items;
+    SrlaItemResult *out = &results[idx];
+    const uint32_t order = out->lpc_order;
+    uint32_t rshift = 0, use_sum = 0, coef_bits = 0;
+    if (order > 0) {
+        for (uint32_t i = 0; i <= order; i++) R_(i) = lags_ws[(size_t)i * stride + idx];
+        const double r0 = R_(0) * (1.0 + 1e-5);
+        const bool silent = fabs(r0) < (double)FLT_EPSILON;
+        if (!silent) levinson_lane<L>(a, r, lane, r0, order, nullptr, 0);
         /* 8-bit quantisation with error feedback from the last tap (lpc.c:1341-1405); q[] reuses r[] */
         int32_t *q = (int32_t *)r;
 #define Q_(i) q[(size_t)(i) * (2 * L) + lane]
@@ -683,14 +902,12 @@ __global__ __launch_bounds__(WAVE) void srla_lpc_solve(
         coef_bits = use_sum ? summed : plain;
 #undef Q_
     }
-    out->lpc_order = order;
     out->lpc_rshift = rshift;
     out->use_sum = use_sum;
     out->pad[0] = coef_bits;
-    if (flags) out->flags |= flags;
+}
 #undef A_
 #undef R_
-}
 
 /* ================================================================================================
  * K3: srla_residual_cost -- FIR residual + Rice code-length search, one workgroup per item
@@ -978,6 +1195,7 @@ __global__ __launch_bounds__(NT) void srla_residual_cost(
 {
     constexpr int CH = 2 * R;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    if (jp.lshift_dev) jp.offset_lshift = *jp.lshift_dev;
     {
         /* blocks of 1024 * FL samples take the register / shuffle fast path */
         const SrlaItemDesc itf = items[blockIdx.x];
@@ -1517,21 +1735,36 @@ __global__ __launch_bounds__(NT) void srla_pack_blocks(
 }
 
 /* ------------------------------------------------------------------- offset left shift ---- */
-__global__ __launch_bounds__(NT) void srla_or_reduce(const int32_t *__restrict__ in, size_t count, uint32_t *__restrict__ out)
+/* OR of every sample of every channel (srla_utility.c:177-203); grid.y = channel */
+__global__ __launch_bounds__(NT) void srla_or_reduce(const int32_t *__restrict__ in, size_t channel_stride, size_t count,
+                                                     uint32_t *__restrict__ out)
 {
+    const int32_t *p = in + (size_t)blockIdx.y * channel_stride;
     uint32_t m = 0;
-    const size_t start = ((size_t)blockIdx.x * NT + threadIdx.x) * 4, step = (size_t)gridDim.x * NT * 4;
-    const bool aligned = (reinterpret_cast<uintptr_t>(in) & 15u) == 0;
-    for (size_t i = start; i < count; i += step) {
-        if (aligned && i + 4 <= count) {
-            const int4 a = *reinterpret_cast<const int4 *>(in + i);
-            m |= (uint32_t)a.x | (uint32_t)a.y | (uint32_t)a.z | (uint32_t)a.w;
-        } else {
-            for (size_t k = i; k < count && k < i + 4; k++) m |= (uint32_t)in[k];
+    const bool aligned = (reinterpret_cast<uintptr_t>(p) & 15u) == 0;
+    const size_t step = (size_t)gridDim.x * NT * 4;
+    size_t i = ((size_t)blockIdx.x * NT + threadIdx.x) * 4;
+    if (aligned) {
+        /* four independent 16-byte loads in flight per thread */
+        for (; i + 3 * step + 4 <= count; i += 4 * step) {
+            const int4 a = *reinterpret_cast<const int4 *>(p + i);
+            const int4 b = *reinterpret_cast<const int4 *>(p + i + step);
+            const int4 c = *reinterpret_cast<const int4 *>(p + i + 2 * step);
+            const int4 d = *reinterpret_cast<const int4 *>(p + i + 3 * step);
+            m |= (uint32_t)(a.x | a.y | a.z | a.w) | (uint32_t)(b.x | b.y | b.z | b.w) | (uint32_t)(c.x | c.y | c.z | c.w) | (uint32_t)(d.x | d.y | d.z | d.w);
         }
     }
+    for (; i < count; i += step)
+        for (size_t k = i; k < count && k < i + 4; k++) m |= (uint32_t)p[k];
     for (int off = 32; off > 0; off >>= 1) m |= __shfl_down(m, off, WAVE);
     if ((threadIdx.x & 63) == 0 && m) atomicOr(out, m);
+}
+
+/* out[1] = trailing zero count of out[0] (0 when the stream is all zero) */
+__global__ void srla_mask_to_shift(uint32_t *__restrict__ out)
+{
+    const uint32_t mask = out[0];
+    out[1] = mask ? (uint32_t)(__ffs((int)mask) - 1) : 0u;
 }
 
 /* --------------------------------------------------------------------------- launchers ---- */
@@ -1573,22 +1806,41 @@ extern "C" int srla_launch_pitch_solve(hipStream_t stream, const SrlaJobParams *
 }
 
 extern "C" int srla_launch_lpc_solve(hipStream_t stream, const SrlaJobParams *jp, const SrlaItemDesc *items,
-                                     const SrlaGeom *geoms, const double *lags_ws, const uint8_t *huff_len,
+                                     const SrlaGeom *geoms, const double *lags_ws, double *err_ws, const uint8_t *huff_len,
                                      SrlaItemResult *results, double *dbg)
 {
     if (jp->num_items == 0) return 0;
     const uint32_t p = jp->max_order;
-    if (p <= 128) {
+    const dim3 g64((jp->num_items + 63) / 64), blk(WAVE);
+#define REGS_PATH(PP)                                                                                                    \
+    do {                                                                                                                 \
+        const uint32_t lds_a = (PP + 1) * 8 * 64, lds_c = (PP + 1) * 8 * 64 + PP * 4 * 64;                               \
+        SET_LDS_ATTR(srla_lpc_recursion_regs<PP>);                                                                       \
+        SET_LDS_ATTR(srla_lpc_quantize_regs<PP>);                                                                        \
+        hipLaunchKernelGGL(srla_lpc_recursion_regs<PP>, g64, blk, lds_a, stream, *jp, lags_ws, err_ws);                  \
+        hipLaunchKernelGGL(srla_order_select, dim3(jp->num_items), blk, 0, stream, *jp, items, geoms, err_ws, results, dbg); \
+        hipLaunchKernelGGL(srla_lpc_quantize_regs<PP>, g64, blk, lds_c, stream, *jp, lags_ws, huff_len, results);        \
+    } while (0)
+    if (p == 8) REGS_PATH(8);
+    else if (p == 16) REGS_PATH(16);
+    else if (p == 32) REGS_PATH(32);
+    else if (p == 64) REGS_PATH(64);
+    else if (p <= 128) {
         const uint32_t lds = (2 * p + 3) * 8 * 64;
-        SET_LDS_ATTR(srla_lpc_solve<64>);
-        hipLaunchKernelGGL(srla_lpc_solve<64>, dim3((jp->num_items + 63) / 64), dim3(WAVE), lds, stream,
-                           *jp, items, geoms, lags_ws, huff_len, results, dbg);
+        SET_LDS_ATTR(srla_lpc_recursion<64>);
+        SET_LDS_ATTR(srla_lpc_quantize<64>);
+        hipLaunchKernelGGL(srla_lpc_recursion<64>, g64, blk, lds, stream, *jp, lags_ws, err_ws);
+        hipLaunchKernelGGL(srla_order_select, dim3(jp->num_items), blk, 0, stream, *jp, items, geoms, err_ws, results, dbg);
+        hipLaunchKernelGGL(srla_lpc_quantize<64>, g64, blk, lds, stream, *jp, lags_ws, huff_len, results);
     } else {
         const uint32_t lds = (2 * p + 3) * 8 * 32;
-        SET_LDS_ATTR(srla_lpc_solve<32>);
-        hipLaunchKernelGGL(srla_lpc_solve<32>, dim3((jp->num_items + 31) / 32), dim3(WAVE), lds, stream,
-                           *jp, items, geoms, lags_ws, huff_len, results, dbg);
+        SET_LDS_ATTR(srla_lpc_recursion<32>);
+        SET_LDS_ATTR(srla_lpc_quantize<32>);
+        hipLaunchKernelGGL(srla_lpc_recursion<32>, dim3((jp->num_items + 31) / 32), blk, lds, stream, *jp, lags_ws, err_ws);
+        hipLaunchKernelGGL(srla_order_select, dim3(jp->num_items), blk, 0, stream, *jp, items, geoms, err_ws, results, dbg);
+        hipLaunchKernelGGL(srla_lpc_quantize<32>, dim3((jp->num_items + 31) / 32), blk, lds, stream, *jp, lags_ws, huff_len, results);
     }
+#undef REGS_PATH
     return (hipGetLastError() == hipSuccess) ? 0 : -2;
 }
 
@@ -1641,11 +1893,14 @@ extern "C" int srla_launch_pack(hipStream_t stream, const SrlaJobParams *jp, uin
     return (hipGetLastError() == hipSuccess) ? 0 : -2;
 }
 
-extern "C" int srla_launch_or_reduce(hipStream_t stream, const int32_t *in, size_t count, uint32_t *out)
+extern "C" int srla_launch_or_reduce(hipStream_t stream, const int32_t *in, size_t channel_stride, size_t count,
+                                     uint32_t num_channels, uint32_t *out)
 {
-    size_t blocks = (count + NT * 16 - 1) / (NT * 16);
-    if (blocks > 4096) blocks = 4096;
+    /* out[0] must be zero on entry; on completion out[0] = OR mask, out[1] = offset left shift */
+    size_t blocks = (count + NT * 64 - 1) / (NT * 64);
+    if (blocks > 2048) blocks = 2048;
     if (blocks == 0) blocks = 1;
-    hipLaunchKernelGGL(srla_or_reduce, dim3((uint32_t)blocks), dim3(NT), 0, stream, in, count, out);
+    hipLaunchKernelGGL(srla_or_reduce, dim3((uint32_t)blocks, num_channels), dim3(NT), 0, stream, in, channel_stride, count, out);
+    hipLaunchKernelGGL(srla_mask_to_shift, dim3(1), dim3(1), 0, stream, out);
     return (hipGetLastError() == hipSuccess) ? 0 : -2;
 }
