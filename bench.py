@@ -90,14 +90,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--seconds", type=float, default=300.0, help="audio per GPU per step")
+    ap.add_argument("--seconds", type=float, default=600.0, help="audio per GPU per step")
     ap.add_argument("--cpu-seconds", type=float, default=40.0, help="audio for the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--preset", type=int, default=4)
     ap.add_argument("--block", type=int, default=4096)
     ap.add_argument("--divisions", type=int, default=1)
     ap.add_argument("--ltp", type=int, default=0)
-    ap.add_argument("--pack-threads", type=int, default=0, help="host threads for the bit pack (default: min(16, usable CPUs / ranks))")
+    ap.add_argument("--no-numa-pin", action="store_true", help="do not restrict the process to the GPU-local NUMA node")
+    ap.add_argument("--pack-threads", type=int, default=0, help="host threads for the bit pack (default: min(8, usable CPUs / (2 * ranks)))")
     args = ap.parse_args()
 
     import torch
@@ -116,6 +117,22 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl")   # RCCL; used only for the timing barrier / max-reduce
 
+    # one process per GPU, kept on the CPUs of the GPU's own NUMA node (doorbells, pinned buffers, pack threads)
+    numa_cpus = None
+    if not args.no_numa_pin:
+        try:
+            pr = torch.cuda.get_device_properties(local_rank)
+            bdf = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+            cpus = set()
+            for part in open("/sys/bus/pci/devices/%s/local_cpulist" % bdf).read().strip().split(","):
+                lo, _, hi = part.partition("-")
+                cpus.update(range(int(lo), int(hi or lo) + 1))
+            cpus &= os.sched_getaffinity(0)
+            if cpus:
+                os.sched_setaffinity(0, cpus)
+                numa_cpus = len(cpus)
+        except Exception:
+            numa_cpus = None
     lib = capi.EncoderLib(helpers.PRODUCT_SO)
     lib.lib.SRLAMI355X_SetDevice.argtypes = [C.c_int]
     assert lib.lib.SRLAMI355X_SetDevice(local_rank) == 0
@@ -134,7 +151,7 @@ def main():
     cfg, par = capi.cli_setup(nch, bps, rate, **cli)
     enc = lib.create(cfg)
     assert enc and lib.set_parameter(enc, par) == capi.OK
-    pack_threads = args.pack_threads or max(2, min(16, usable_cpus() // max(1, world)))
+    pack_threads = args.pack_threads or max(1, min(8, usable_cpus() // (2 * max(1, world))))
     lib.lib.SRLAMI355X_SetPackThreads.argtypes = [C.c_void_p, C.c_uint32]
     lib.lib.SRLAMI355X_SetPackThreads(enc, pack_threads)
     cap = 2 * pcm.size * 2 + 4096
@@ -180,8 +197,13 @@ def main():
             lossless = bool((back == pcm).all())
         total_instants = float(n) * args.steps * world
         value = total_instants / elapsed / 1e6
-        launches = max(1, st.analyze_launches)
-        avg_launch_ms = st.analyze_ms / launches
+        launches = max(1, st.analyze_launches)          # one launch of each analysis kernel per job
+        # dominant kernel = the analysis kernel with the largest total time (HIP events around each launch,
+        # recorded on the stream the kernel runs on, inside the timed region)
+        kernels = {"srla_autocorr": st.autocorr_ms, "srla_lpc_recursion+order_select+quantize": st.solve_ms,
+                   "srla_residual_cost": st.residual_ms}
+        dominant = max(kernels, key=kernels.get)
+        avg_launch_ms = kernels[dominant] / launches
         instants_per_launch = float(n) * args.steps / launches
         algo_bytes = 16.0 * instants_per_launch            # 8 B per channel-sample, stereo
         achieved = algo_bytes / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
@@ -206,15 +228,16 @@ def main():
             "channel_samples_per_s_M": round(value * nch, 3),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(achieved / 8000.0, 6), "traffic": traffic,
-                         "kernel": "srla_analyze_items", "avg_launch_ms": round(avg_launch_ms, 4),
+                         "kernel": dominant, "avg_launch_ms": round(avg_launch_ms, 4),
+                         "per_kernel_avg_launch_ms": {k: round(v / launches, 4) for k, v in kernels.items()},
                          "launches": int(st.analyze_launches), "algorithmic_bytes_per_launch": int(algo_bytes),
                          "items_per_s_M": round(st.num_items / (st.analyze_ms * 1e-3) / 1e6, 3) if st.analyze_ms > 0 else None},
             "phase_ms_per_step": {"analyze": round(st.analyze_ms / args.steps, 3),
                                   "analyze_autocorr": round(st.autocorr_ms / args.steps, 3), "analyze_solve": round(st.solve_ms / args.steps, 3),
                                   "analyze_residual_cost": round(st.residual_ms / args.steps, 3), "price": round(st.price_ms / args.steps, 3),
                                   "gather": round(st.gather_ms / args.steps, 3), "d2h": round(st.d2h_ms / args.steps, 3),
-                                  "pack_host": round(st.pack_ms / args.steps, 3), "total_host": round(st.total_ms / args.steps, 3)},
-            "host_cores": os.cpu_count(), "host_cpu_quota": usable_cpus(), "host_pack_threads": pack_threads,
+                                  "enqueue_host": round(st.h2d_ms / args.steps, 3), "pack_host": round(st.pack_ms / args.steps, 3), "total_host": round(st.total_ms / args.steps, 3)},
+            "host_cores": os.cpu_count(), "host_cpu_quota": usable_cpus(), "host_pack_threads": pack_threads, "numa_local_cpus": numa_cpus,
             "tie_items": int(st.num_tie_items),
         }
         if not args.no_cpu_baseline:

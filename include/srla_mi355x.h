@@ -132,7 +132,7 @@ SRLAApiResult SRLAEncoder_EncodeWhole(
  * (one process per GPU is the intended deployment; default device 0). Returns 0 on success. */
 int SRLAMI355X_SetDevice(int device_index);
 
-/* Number of host threads the bit-packer may use (default: min(hardware threads, 16), or the
+/* Number of host threads the bit-packer may use (default: min(8, usable CPUs / 2), or the
  * SRLA_MI355X_PACK_THREADS environment variable).  With several processes per node (one per GPU) give
  * each process hardware_threads / processes. */
 void SRLAMI355X_SetPackThreads(struct SRLAEncoder *encoder, uint32_t num_threads);

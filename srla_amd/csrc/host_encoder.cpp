@@ -151,7 +151,7 @@ private:
         for (;;) {
             {
                 /* spin briefly before sleeping: pack rounds arrive every few hundred microseconds */
-                for (int spin = 0; spin < 2000 && gen_atomic_.load(std::memory_order_acquire) == seen && !stop_; spin++) {
+                for (int spin = 0; spin < 200 && gen_atomic_.load(std::memory_order_acquire) == seen && !stop_; spin++) {
 #if defined(__x86_64__)
                     __builtin_ia32_pause();
 #endif
@@ -202,8 +202,12 @@ struct Job {
 
 struct Slot {
     hipStream_t stream = nullptr;
-    hipEvent_t ev[8] = {};
-    hipEvent_t chain[3] = {};        /* autocorr done, residual_cost done, pack done: stage chaining across jobs */
+    hipEvent_t t0[6] = {}, t1[6] = {};   /* start / end of the six stages of the job (see Impl::run_stage) */
+    const int32_t *in_cur = nullptr;     /* device input of the current job */
+    uint32_t stride_cur = 0;
+    SrlaJobParams jp{};
+    size_t packed_bytes = 0;
+    bool want_dbg = false;
     DevBuf d_input, d_items, d_cands, d_windows, d_results, d_res_ws, d_blocks, d_cand_bytes, d_packed, d_chan, d_dbg, d_lags, d_err;
     PinBuf h_in, h_packed, h_blocks, h_chan;
     Job job;
@@ -228,7 +232,7 @@ struct Impl {
     hipEvent_t ev_or = nullptr;       /* offset-shift reduction done */
     bool lshift_on_device = false;
     PinBuf h_or;
-    uint32_t kSlots = 3;              /* job buffer sets (SRLA_MI355X_SLOTS); slot i runs on stream i % kStreams */
+    uint32_t kSlots = 4;              /* job buffer sets (SRLA_MI355X_SLOTS); slot i runs on stream i % kStreams */
     uint64_t job_samples = 2ull << 20; /* samples per job (SRLA_MI355X_JOB_SAMPLES) */
     Slot slot[kMaxSlots];
     DevBuf d_tw, d_geoms, d_thr, d_huff, d_or;
@@ -239,7 +243,6 @@ struct Impl {
     std::vector<SrlaGeom> geoms;
     bool geom_dirty = false;
     Pool *pool = nullptr;
-    Slot *last_launched = nullptr;    /* the job enqueued before this one (stage chaining) */
     SRLAMI355XStats stats{};
 
     ~Impl()
@@ -248,9 +251,9 @@ struct Impl {
         if (dev_ready) {
             (void)hipSetDevice(g_device_index);
             for (auto &s : slot) {
-                if (s.stream) (void)hipStreamSynchronize(s.stream);
-                for (auto &e : s.ev) if (e) (void)hipEventDestroy(e);
-                for (auto &e : s.chain) if (e) (void)hipEventDestroy(e);
+                for (auto &st : streams) if (st) (void)hipStreamSynchronize(st);
+                for (auto &e : s.t0) if (e) (void)hipEventDestroy(e);
+                for (auto &e : s.t1) if (e) (void)hipEventDestroy(e);
                 DevBuf *db[] = { &s.d_input, &s.d_items, &s.d_cands, &s.d_windows, &s.d_results, &s.d_res_ws,
                                  &s.d_blocks, &s.d_cand_bytes, &s.d_packed, &s.d_chan, &s.d_dbg, &s.d_lags, &s.d_err };
                 for (auto *b : db) b->release();
@@ -287,9 +290,9 @@ struct Impl {
         if (!h_or.ensure(64)) return false;
         for (uint32_t si = 0; si < kSlots; si++) {
             Slot &s = slot[si];
-            s.stream = streams[si % kStreams];
-            for (auto &e : s.ev) HIP_OK(hipEventCreate(&e));
-            for (auto &e : s.chain) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            s.stream = streams[0];
+            for (auto &e : s.t0) HIP_OK(hipEventCreate(&e));
+            for (auto &e : s.t1) HIP_OK(hipEventCreate(&e));
         }
         double thr[32];
         srla::build_rice_thresholds(thr);
@@ -311,7 +314,9 @@ struct Impl {
             }
             fclose(f);
         }
-        unsigned nthreads = pack_threads ? pack_threads : std::min(hw ? hw : 1u, 16u);
+        /* half of the usable CPUs, at most 8: the enqueueing thread and the HIP runtime's own helper threads
+         * need the rest (measured: more pack threads than that makes launches and D2H completion slower) */
+        unsigned nthreads = pack_threads ? pack_threads : std::max(1u, std::min((hw ? hw : 2u) / 2u, 8u));
         if (const char *e = getenv("SRLA_MI355X_PACK_THREADS")) { const int v = atoi(e); if (v > 0) nthreads = (unsigned)v; }
         pool = new Pool(nthreads);
         dev_failed = false;
@@ -345,7 +350,7 @@ struct Impl {
     bool sync_tables()
     {
         if (!tw_dirty && !geom_dirty) return true;
-        for (auto &s : slot) if (s.stream) HIP_OK(hipStreamSynchronize(s.stream));
+        for (auto &st : streams) if (st) HIP_OK(hipStreamSynchronize(st));
         if (tw_dirty) {
             if (!d_tw.ensure(tw_host.size() * sizeof(double))) return false;
             HIP_OK(hipMemcpy(d_tw.p, tw_host.data(), tw_host.size() * sizeof(double), hipMemcpyHostToDevice));
@@ -480,10 +485,18 @@ struct Impl {
 
     /* Enqueue one job on its slot's stream.  d_in: device pointer to channel 0 of the job's first
      * sample, or nullptr to upload host_in (planar pointers, absolute stream positions). */
-    bool launch_job(Slot &s, const int32_t *d_in, uint32_t d_stride, const int32_t *const *host_in, bool want_dbg)
+    /* ---- staged execution of one job --------------------------------------------------------------------
+     * Three streams: W carries the wide kernels (autocorr, residual_cost, pack_blocks), N the narrow ones
+     * (Levinson / order / quantiser, pricing), C the D2H copies.  A job's stages are chained with events;
+     * encode_stream enqueues the stages of consecutive jobs skewed (software pipeline), so that W always has
+     * a wide kernel to run while N works through the serial stages of the neighbouring job. */
+    enum { ST_A = 0, ST_B, ST_C, ST_D, ST_E, ST_F, NUM_ST };
+
+    bool prepare_job(Slot &s, const int32_t *d_in, uint32_t d_stride, const int32_t *const *host_in, bool want_dbg)
     {
         Job &job = s.job;
         const uint32_t nch = par.num_channels;
+        hipStream_t W = streams[0];
         if (!sync_tables()) return false;
         const size_t n_items = job.items.size(), n_cands = job.cands.size(), n_win = job.windows.size();
         {
@@ -497,110 +510,131 @@ struct Impl {
         if (!s.d_res_ws.ensure(std::max<uint64_t>(4, job.res_elems) * 4)) return false;
         if (!s.d_blocks.ensure((size_t)job.num_slots * sizeof(SrlaBlockRecord))) return false;
         if (!s.d_cand_bytes.ensure(n_cands * 4)) return false;
-        const size_t packed_bytes = (size_t)job.ns * nch * (par.bits_per_sample / 8) + (size_t)job.num_slots * SRLA_PACK_SLACK + 64;
-        if (!s.d_packed.ensure(packed_bytes)) return false;
+        s.packed_bytes = (size_t)job.ns * nch * (par.bits_per_sample / 8) + (size_t)job.num_slots * SRLA_PACK_SLACK + 64;
+        if (!s.d_packed.ensure(s.packed_bytes)) return false;
         if (!s.d_chan.ensure((size_t)job.num_slots * nch * sizeof(SrlaChanRecord))) return false;
-        if (!s.h_packed.ensure(packed_bytes)) return false;
+        if (!s.h_packed.ensure(s.packed_bytes)) return false;
         if (!s.h_blocks.ensure((size_t)job.num_slots * sizeof(SrlaBlockRecord))) return false;
         if (!s.h_chan.ensure((size_t)job.num_slots * nch * sizeof(SrlaChanRecord))) return false;
         if (want_dbg && !s.d_dbg.ensure(std::max<size_t>(1, n_items) * SRLA_DBG_STRIDE * sizeof(double))) return false;
-
-        HIP_OK(hipEventRecord(s.ev[0], s.stream));
-        uint32_t stride = d_stride;
+        const uint32_t lag_rows = std::max<uint32_t>(par.ltp_order > 0 ? SRLA_LTP_LAGS : 0u, preset_order() + 1);
+        if (!s.d_lags.ensure((size_t)lag_rows * std::max<size_t>(1, n_items) * sizeof(double))) return false;
+        if (!s.d_err.ensure((size_t)(preset_order() + 1) * std::max<size_t>(1, n_items) * sizeof(double))) return false;
+        s.want_dbg = want_dbg;
+        s.in_cur = d_in;
+        s.stride_cur = d_stride;
         s.used_h2d = false;
         if (!d_in) {
             if (!s.h_in.ensure((size_t)nch * job.ns * 4) || !s.d_input.ensure((size_t)nch * job.ns * 4)) return false;
             for (uint32_t ch = 0; ch < nch; ch++)
                 memcpy(s.h_in.as<int32_t>() + (size_t)ch * job.ns, host_in[ch] + job.s0, (size_t)job.ns * 4);
-            HIP_OK(hipMemcpyAsync(s.d_input.p, s.h_in.p, (size_t)nch * job.ns * 4, hipMemcpyHostToDevice, s.stream));
-            d_in = s.d_input.as<int32_t>();
-            stride = job.ns;
+            HIP_OK(hipMemcpyAsync(s.d_input.p, s.h_in.p, (size_t)nch * job.ns * 4, hipMemcpyHostToDevice, W));
+            s.in_cur = s.d_input.as<int32_t>();
+            s.stride_cur = job.ns;
             s.used_h2d = true;
         }
         if (!job.uploaded) {
-            if (n_items) HIP_OK(hipMemcpyAsync(s.d_items.p, job.items.data(), n_items * sizeof(SrlaItemDesc), hipMemcpyHostToDevice, s.stream));
-            HIP_OK(hipMemcpyAsync(s.d_cands.p, job.cands.data(), n_cands * sizeof(SrlaCandDesc), hipMemcpyHostToDevice, s.stream));
-            HIP_OK(hipMemcpyAsync(s.d_windows.p, job.windows.data(), n_win * sizeof(SrlaWindowDesc), hipMemcpyHostToDevice, s.stream));
+            if (n_items) HIP_OK(hipMemcpyAsync(s.d_items.p, job.items.data(), n_items * sizeof(SrlaItemDesc), hipMemcpyHostToDevice, W));
+            HIP_OK(hipMemcpyAsync(s.d_cands.p, job.cands.data(), n_cands * sizeof(SrlaCandDesc), hipMemcpyHostToDevice, W));
+            HIP_OK(hipMemcpyAsync(s.d_windows.p, job.windows.data(), n_win * sizeof(SrlaWindowDesc), hipMemcpyHostToDevice, W));
             job.uploaded = true;
         }
-        HIP_OK(hipEventRecord(s.ev[1], s.stream));
-        if (lshift_on_device) HIP_OK(hipStreamWaitEvent(s.stream, ev_or, 0));
-
-        const SrlaJobParams jp = job_params(job, stride);
-        for (const Group &g : job.groups) {
-            const uint32_t fft_bytes = (8u * g.nfft + 15u) & ~15u;
-            const uint32_t lag_rows = std::max<uint32_t>(par.ltp_order > 0 ? SRLA_LTP_LAGS : 0u, jp.max_order + 1);
-            if (!s.d_lags.ensure((size_t)lag_rows * n_items * sizeof(double))) return false;
-            if (!s.d_err.ensure((size_t)(jp.max_order + 1) * n_items * sizeof(double))) return false;
-            double *dbg = want_dbg ? s.d_dbg.as<double>() : nullptr;
-            int rc = 0;
-            /* The wide kernels (autocorr, residual_cost, pack) each fill the GPU; the solve / pricing
-             * kernels are a few wavefronts of serial work.  Chaining each wide stage behind the SAME stage
-             * of the previous job staggers the jobs, so that the latency-bound kernels of job k overlap the
-             * wide kernels of job k+1 instead of all jobs idling through them together. */
-            Slot *prev = (last_launched && last_launched != &s) ? last_launched : nullptr;
-            if (prev) HIP_OK(hipStreamWaitEvent(s.stream, prev->chain[0], 0));
-            if (par.ltp_order > 0) {
-                rc |= srla_launch_autocorr(s.stream, g.rclass, &jp, d_in, s.d_items.as<SrlaItemDesc>(), d_geoms.as<SrlaGeom>(), d_tw.p,
-                                           fft_bytes, 1, s.d_results.as<SrlaItemResult>(), s.d_lags.as<double>(), dbg);
-                rc |= srla_launch_pitch_solve(s.stream, &jp, s.d_lags.as<double>(), s.d_results.as<SrlaItemResult>());
-            }
-            rc |= srla_launch_autocorr(s.stream, g.rclass, &jp, d_in, s.d_items.as<SrlaItemDesc>(), d_geoms.as<SrlaGeom>(), d_tw.p,
-                                       fft_bytes, 0, s.d_results.as<SrlaItemResult>(), s.d_lags.as<double>(), dbg);
-            HIP_OK(hipEventRecord(s.chain[0], s.stream));
-            HIP_OK(hipEventRecord(s.ev[6], s.stream));
-            if (jp.max_order > 0)
-                rc |= srla_launch_lpc_solve(s.stream, &jp, s.d_items.as<SrlaItemDesc>(), d_geoms.as<SrlaGeom>(), s.d_lags.as<double>(),
-                                            s.d_err.as<double>(), d_huff.as<uint8_t>(), s.d_results.as<SrlaItemResult>(), dbg);
-            HIP_OK(hipEventRecord(s.ev[7], s.stream));
-            if (prev) HIP_OK(hipStreamWaitEvent(s.stream, prev->chain[1], 0));
-            rc |= srla_launch_residual_cost(s.stream, g.rclass, &jp, d_in, s.d_items.as<SrlaItemDesc>(), d_geoms.as<SrlaGeom>(), &g.plan,
-                                            d_thr.as<double>(), s.d_res_ws.as<int32_t>(), s.d_results.as<SrlaItemResult>());
-            HIP_OK(hipEventRecord(s.chain[1], s.stream));
-            if (rc != 0) {
-                fprintf(stderr, "[srla-mi355x] item analysis launch failed (nfft %u)\n", g.nfft);
-                return false;
-            }
-            stats.analyze_launches++;
-        }
-        if (job.groups.empty()) {
-            HIP_OK(hipEventRecord(s.ev[6], s.stream)); HIP_OK(hipEventRecord(s.ev[7], s.stream));
-            HIP_OK(hipEventRecord(s.chain[0], s.stream)); HIP_OK(hipEventRecord(s.chain[1], s.stream));
-        }
-        HIP_OK(hipEventRecord(s.ev[2], s.stream));
-        if (srla_launch_price(s.stream, &jp, s.d_windows.as<SrlaWindowDesc>(), s.d_cands.as<SrlaCandDesc>(),
-                              s.d_results.as<SrlaItemResult>(), s.d_blocks.as<SrlaBlockRecord>(),
-                              s.d_cand_bytes.as<uint32_t>()) != 0) return false;
-        HIP_OK(hipEventRecord(s.ev[3], s.stream));
-        if (last_launched && last_launched != &s) HIP_OK(hipStreamWaitEvent(s.stream, last_launched->chain[2], 0));
-        if (srla_launch_pack(s.stream, &jp, job.num_slots, d_in, s.d_items.as<SrlaItemDesc>(),
-                             s.d_blocks.as<SrlaBlockRecord>(), s.d_results.as<SrlaItemResult>(),
-                             s.d_res_ws.as<int32_t>(), s.d_packed.as<uint8_t>(), s.d_chan.as<SrlaChanRecord>()) != 0) return false;
-        HIP_OK(hipEventRecord(s.chain[2], s.stream));
-        HIP_OK(hipEventRecord(s.ev[4], s.stream));
-        HIP_OK(hipMemcpyAsync(s.h_packed.p, s.d_packed.p, packed_bytes, hipMemcpyDeviceToHost, s.stream));
-        HIP_OK(hipMemcpyAsync(s.h_blocks.p, s.d_blocks.p, (size_t)job.num_slots * sizeof(SrlaBlockRecord), hipMemcpyDeviceToHost, s.stream));
-        HIP_OK(hipMemcpyAsync(s.h_chan.p, s.d_chan.p, (size_t)job.num_slots * nch * sizeof(SrlaChanRecord), hipMemcpyDeviceToHost, s.stream));
-        HIP_OK(hipEventRecord(s.ev[5], s.stream));
+        s.jp = job_params(job, s.stride_cur);
         s.busy = true;
-        last_launched = &s;
         stats.num_windows += n_win; stats.num_candidates += n_cands; stats.num_items += n_items;
         stats.analyzed_samples += job.analyzed_samples;
+        stats.analyze_launches++;
+        return true;
+    }
+
+    bool run_stage(Slot &s, int st)
+    {
+        Job &job = s.job;
+        hipStream_t W = streams[0], N = streams[1], C = streams[2];
+        const SrlaJobParams &jp = s.jp;
+        double *dbg = s.want_dbg ? s.d_dbg.as<double>() : nullptr;
+        const bool have_items = !job.groups.empty();
+        int rc = 0;
+        switch (st) {
+        case ST_A: {
+            if (lshift_on_device) HIP_OK(hipStreamWaitEvent(W, ev_or, 0));
+            HIP_OK(hipEventRecord(s.t0[ST_A], W));
+            if (have_items) {
+                const Group &g = job.groups[0];
+                const uint32_t fft_bytes = (8u * g.nfft + 15u) & ~15u;
+                if (par.ltp_order > 0) {
+                    rc |= srla_launch_autocorr(W, g.rclass, &jp, s.in_cur, s.d_items.as<SrlaItemDesc>(), d_geoms.as<SrlaGeom>(), d_tw.p,
+                                               fft_bytes, 1, s.d_results.as<SrlaItemResult>(), s.d_lags.as<double>(), dbg);
+                    rc |= srla_launch_pitch_solve(W, &jp, s.d_lags.as<double>(), s.d_results.as<SrlaItemResult>());
+                }
+                rc |= srla_launch_autocorr(W, g.rclass, &jp, s.in_cur, s.d_items.as<SrlaItemDesc>(), d_geoms.as<SrlaGeom>(), d_tw.p,
+                                           fft_bytes, 0, s.d_results.as<SrlaItemResult>(), s.d_lags.as<double>(), dbg);
+            }
+            HIP_OK(hipEventRecord(s.t1[ST_A], W));
+            break; }
+        case ST_B:
+            HIP_OK(hipStreamWaitEvent(N, s.t1[ST_A], 0));
+            HIP_OK(hipEventRecord(s.t0[ST_B], N));
+            if (have_items && jp.max_order > 0)
+                rc |= srla_launch_lpc_solve(N, &jp, s.d_items.as<SrlaItemDesc>(), d_geoms.as<SrlaGeom>(), s.d_lags.as<double>(),
+                                            s.d_err.as<double>(), d_huff.as<uint8_t>(), s.d_results.as<SrlaItemResult>(), dbg);
+            HIP_OK(hipEventRecord(s.t1[ST_B], N));
+            break;
+        case ST_C:
+            HIP_OK(hipStreamWaitEvent(W, s.t1[ST_B], 0));
+            HIP_OK(hipEventRecord(s.t0[ST_C], W));
+            if (have_items) {
+                const Group &g = job.groups[0];
+                rc |= srla_launch_residual_cost(W, g.rclass, &jp, s.in_cur, s.d_items.as<SrlaItemDesc>(), d_geoms.as<SrlaGeom>(), &g.plan,
+                                                d_thr.as<double>(), s.d_res_ws.as<int32_t>(), s.d_results.as<SrlaItemResult>());
+            }
+            HIP_OK(hipEventRecord(s.t1[ST_C], W));
+            break;
+        case ST_D:
+            HIP_OK(hipStreamWaitEvent(N, s.t1[ST_C], 0));
+            HIP_OK(hipEventRecord(s.t0[ST_D], N));
+            rc |= srla_launch_price(N, &jp, s.d_windows.as<SrlaWindowDesc>(), s.d_cands.as<SrlaCandDesc>(),
+                                    s.d_results.as<SrlaItemResult>(), s.d_blocks.as<SrlaBlockRecord>(), s.d_cand_bytes.as<uint32_t>());
+            HIP_OK(hipEventRecord(s.t1[ST_D], N));
+            break;
+        case ST_E:
+            HIP_OK(hipStreamWaitEvent(W, s.t1[ST_D], 0));
+            HIP_OK(hipEventRecord(s.t0[ST_E], W));
+            rc |= srla_launch_pack(W, &jp, job.num_slots, s.in_cur, s.d_items.as<SrlaItemDesc>(), s.d_blocks.as<SrlaBlockRecord>(),
+                                   s.d_results.as<SrlaItemResult>(), s.d_res_ws.as<int32_t>(), s.d_packed.as<uint8_t>(),
+                                   s.d_chan.as<SrlaChanRecord>());
+            HIP_OK(hipEventRecord(s.t1[ST_E], W));
+            break;
+        case ST_F:
+            HIP_OK(hipStreamWaitEvent(C, s.t1[ST_E], 0));
+            HIP_OK(hipEventRecord(s.t0[ST_F], C));
+            HIP_OK(hipMemcpyAsync(s.h_packed.p, s.d_packed.p, s.packed_bytes, hipMemcpyDeviceToHost, C));
+            HIP_OK(hipMemcpyAsync(s.h_blocks.p, s.d_blocks.p, (size_t)job.num_slots * sizeof(SrlaBlockRecord), hipMemcpyDeviceToHost, C));
+            HIP_OK(hipMemcpyAsync(s.h_chan.p, s.d_chan.p, (size_t)job.num_slots * par.num_channels * sizeof(SrlaChanRecord), hipMemcpyDeviceToHost, C));
+            HIP_OK(hipEventRecord(s.t1[ST_F], C));
+            break;
+        default: return false;
+        }
+        if (rc != 0) { fprintf(stderr, "[srla-mi355x] kernel launch failed in stage %d\n", st); return false; }
+        return true;
+    }
+
+    /* all stages of one job back to back (single-block calls, probes) */
+    bool launch_job(Slot &s, const int32_t *d_in, uint32_t d_stride, const int32_t *const *host_in, bool want_dbg)
+    {
+        if (!prepare_job(s, d_in, d_stride, host_in, want_dbg)) return false;
+        for (int st = 0; st < NUM_ST; st++) if (!run_stage(s, st)) return false;
         return true;
     }
 
     bool wait_job(Slot &s)
     {
-        HIP_OK(hipEventSynchronize(s.ev[5]));     /* this job only: its stream may already carry a later job */
+        HIP_OK(hipEventSynchronize(s.t1[ST_F]));
         float t = 0;
-        if (hipEventElapsedTime(&t, s.ev[0], s.ev[1]) == hipSuccess) stats.h2d_ms += t;
-        if (hipEventElapsedTime(&t, s.ev[1], s.ev[2]) == hipSuccess) stats.analyze_ms += t;
-        if (hipEventElapsedTime(&t, s.ev[1], s.ev[6]) == hipSuccess) stats.autocorr_ms += t;
-        if (hipEventElapsedTime(&t, s.ev[6], s.ev[7]) == hipSuccess) stats.solve_ms += t;
-        if (hipEventElapsedTime(&t, s.ev[7], s.ev[2]) == hipSuccess) stats.residual_ms += t;
-        if (hipEventElapsedTime(&t, s.ev[2], s.ev[3]) == hipSuccess) stats.price_ms += t;
-        if (hipEventElapsedTime(&t, s.ev[3], s.ev[4]) == hipSuccess) stats.gather_ms += t;
-        if (hipEventElapsedTime(&t, s.ev[4], s.ev[5]) == hipSuccess) stats.d2h_ms += t;
+        double *acc[NUM_ST] = { &stats.autocorr_ms, &stats.solve_ms, &stats.residual_ms, &stats.price_ms, &stats.gather_ms, &stats.d2h_ms };
+        for (int st = 0; st < NUM_ST; st++)
+            if (hipEventElapsedTime(&t, s.t0[st], s.t1[st]) == hipSuccess) *acc[st] += t;
+        stats.analyze_ms = stats.autocorr_ms + stats.solve_ms + stats.residual_ms;
         s.busy = false;
         return true;
     }
@@ -732,35 +766,49 @@ struct Impl {
         std::vector<uint32_t> window_bytes;
         uint32_t progress = 0;
 
-        auto start = [&](uint32_t k) -> bool {
-            Slot &s = slot[k % kSlots];
-            const uint32_t s0 = (uint32_t)((uint64_t)k * job_len);
-            const uint32_t ns = (uint32_t)std::min<uint64_t>(job_len, num_samples - s0);
-            build_job(s.job, s0, ns, search);
-            return launch_job(s, d_in ? d_in + s0 : nullptr, d_stride, host_in, false);
-        };
-        /* kSlots - 1 jobs are kept queued on the GPU; job k + kSlots - 1 is enqueued as soon as job k has
-         * completed and BEFORE the host packs job k, so the GPU never waits for the packer */
         auto fail = [&](SRLAApiResult rc) {
             for (auto &st : streams) if (st) (void)hipStreamSynchronize(st);
             for (auto &sl : slot) sl.busy = false;
             lshift_on_device = false;
             return rc;
         };
-        const uint32_t ahead = kSlots - 1;
-        for (uint32_t k = 0; k < ahead && k < njobs; k++)
-            if (!start(k)) return fail(SRLA_APIRESULT_NG);
-        for (uint32_t k = 0; k < njobs; k++) {
-            Slot &s = slot[k % kSlots];
+        auto job_slot = [&](uint32_t k) -> Slot & { return slot[k % kSlots]; };
+        auto begin = [&](uint32_t k) -> bool {
+            Slot &s = job_slot(k);
+            const uint32_t s0 = (uint32_t)((uint64_t)k * job_len);
+            const uint32_t ns = (uint32_t)std::min<uint64_t>(job_len, num_samples - s0);
+            build_job(s.job, s0, ns, search);
+            return prepare_job(s, d_in ? d_in + s0 : nullptr, d_stride, host_in, false);
+        };
+        /* Software pipeline over jobs: iteration t enqueues  autocorr + solve of job t,  residual_cost +
+         * pricing of job t-1,  pack + D2H of job t-2,  then packs job t-3 on the host.  Needs 4 buffer sets. */
+        const uint32_t depth = 3;
+        uint32_t header_done = with_header ? 0 : 1;
+        for (uint32_t t = 0; t < njobs + depth; t++) {
+            const auto t_enq = Clock::now();
+            if (t < njobs) {
+                if (!begin(t) || !run_stage(job_slot(t), ST_A) || !run_stage(job_slot(t), ST_B)) return fail(SRLA_APIRESULT_NG);
+            }
+            if (t >= 1 && t - 1 < njobs) {
+                Slot &s = job_slot(t - 1);
+                if (!run_stage(s, ST_C) || !run_stage(s, ST_D)) return fail(SRLA_APIRESULT_NG);
+            }
+            if (t >= 2 && t - 2 < njobs) {
+                Slot &s = job_slot(t - 2);
+                if (!run_stage(s, ST_E) || !run_stage(s, ST_F)) return fail(SRLA_APIRESULT_NG);
+            }
+            stats.h2d_ms += ms_since(t_enq);       /* host time spent enqueueing (no H2D of samples on this path) */
+            if (t < depth) continue;
+            const uint32_t k = t - depth;
+            Slot &s = job_slot(k);
             if (!wait_job(s)) return fail(SRLA_APIRESULT_NG);
-            if (k + ahead < njobs && !start(k + ahead)) return fail(SRLA_APIRESULT_NG);
-            if (k == 0 && with_header) {
+            if (!header_done) {
                 if (lshift_on_device) {
-                    /* stream 0 has been synchronised by wait_job(job 0): the reduction result is on the host */
                     if (hipEventSynchronize(ev_or) != hipSuccess) return fail(SRLA_APIRESULT_NG);
                     offset_lshift = h_or.as<uint32_t>()[1];
                 }
                 srla::write_stream_header(stream_info(num_samples), data);
+                header_done = 1;
             }
             uint32_t wrote = 0;
             const SRLAApiResult rc = pack_job(s, si, data + write_off, data_size - write_off, &wrote, window_bytes);
