@@ -285,7 +285,15 @@ struct Impl {
             return false;
         }
         HIP_OK(hipSetDevice(g_device_index));
-        for (auto &st : streams) HIP_OK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        {
+            /* the narrow stream gets the highest priority: its few wavefronts should grab CU resources as soon
+             * as a wide kernel's workgroup retires, because the next wide kernel of that job waits for them */
+            int lo = 0, hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+            HIP_OK(hipStreamCreateWithPriority(&streams[0], hipStreamNonBlocking, lo));
+            HIP_OK(hipStreamCreateWithPriority(&streams[1], hipStreamNonBlocking, hi));
+            HIP_OK(hipStreamCreateWithPriority(&streams[2], hipStreamNonBlocking, lo));
+        }
         HIP_OK(hipEventCreateWithFlags(&ev_or, hipEventDisableTiming));
         if (!h_or.ensure(64)) return false;
         for (uint32_t si = 0; si < kSlots; si++) {

@@ -29,7 +29,7 @@ const double kPi = 3.14159265358979323846; /* fft.c:17 */
 uint32_t complex_table_len(uint32_t m)
 {
     uint32_t t = 0;
-    for (uint32_t n = m; n > 2; n >>= 2) t += n >> 2;
+    for (uint32_t n = m; n > 2; n >>= 2) t += 3 * (n >> 2);   /* w^p, w^2p, w^3p per stage */
     return t;
 }
 
@@ -48,10 +48,14 @@ void build_twiddles(uint32_t nfft, double *out /* 2 doubles per entry */)
             const double theta0 = 2.0 * kPi / (int)n;
             C2 wdelta{ cos(theta0), flag * sin(theta0) };
             C2 w1{ 1.0, 0.0 };
-            for (uint32_t p = 0; p < (n >> 2); p++) {
-                *o++ = w1;
-                w1 = mul(w1, wdelta);
+            const uint32_t n1 = n >> 2;
+            for (uint32_t p = 0; p < n1; p++) {
+                const C2 w2 = mul(w1, w1);       /* fft.c:95 */
+                const C2 w3 = mul(w1, w2);       /* fft.c:96 */
+                o[p] = w1; o[n1 + p] = w2; o[2 * n1 + p] = w3;
+                w1 = mul(w1, wdelta);            /* fft.c:107 */
             }
+            o += 3 * n1;
         }
     }
     for (int pass = 0; pass < 2; pass++) {

@@ -75,37 +75,51 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
     return v;
 }
 
+/* what the sample loaders need from the job parameters (kept in registers; the by-value kernel argument
+ * is never modified) */
+struct InputView {
+    uint32_t nch, stride, sh;
+};
+__device__ __forceinline__ InputView input_view(const SrlaJobParams &jp)
+{
+    InputView v;
+    v.nch = jp.num_channels;
+    v.stride = jp.channel_stride;
+    v.sh = jp.lshift_dev ? *jp.lshift_dev : jp.offset_lshift;
+    return v;
+}
+
 /* variant sample i of the job input (srla_encoder.c:1229-1253, srla_utility.c:91-103) */
-__device__ __forceinline__ int32_t load_variant(const int32_t *__restrict__ in, const SrlaJobParams &jp,
+__device__ __forceinline__ int32_t load_variant(const int32_t *__restrict__ in, const InputView &jp,
                                                 uint32_t variant, uint32_t idx)
 {
-    const uint32_t sh = jp.offset_lshift;
-    if (variant < jp.num_channels) return in[(size_t)variant * jp.channel_stride + idx] >> sh;
+    const uint32_t sh = jp.sh;
+    if (variant < jp.nch) return in[(size_t)variant * jp.stride + idx] >> sh;
     const int32_t l = in[idx] >> sh;
-    const int32_t r = in[(size_t)jp.channel_stride + idx] >> sh;
+    const int32_t r = in[(size_t)jp.stride + idx] >> sh;
     const int32_t s = (int32_t)((uint32_t)r - (uint32_t)l);
-    if (variant == jp.num_channels + 1) return s;
+    if (variant == jp.nch + 1) return s;
     return (int32_t)((uint32_t)l + (uint32_t)(s >> 1));
 }
 
 /* four consecutive variant samples starting at i4 (zeros beyond n); 16-byte loads when possible */
-__device__ __forceinline__ void load_chunk(const int32_t *__restrict__ in, const SrlaJobParams &jp, uint32_t variant,
+__device__ __forceinline__ void load_chunk(const int32_t *__restrict__ in, const InputView &jp, uint32_t variant,
                                            uint32_t i4, uint32_t n, bool aligned, int32_t out[4])
 {
     if (aligned && i4 + 4 <= n) {
-        const uint32_t sh = jp.offset_lshift;
-        if (variant < jp.num_channels) {
-            const int4 a = *reinterpret_cast<const int4 *>(in + (size_t)variant * jp.channel_stride + i4);
+        const uint32_t sh = jp.sh;
+        if (variant < jp.nch) {
+            const int4 a = *reinterpret_cast<const int4 *>(in + (size_t)variant * jp.stride + i4);
             out[0] = a.x >> sh; out[1] = a.y >> sh; out[2] = a.z >> sh; out[3] = a.w >> sh;
         } else {
             const int4 a = *reinterpret_cast<const int4 *>(in + i4);
-            const int4 b = *reinterpret_cast<const int4 *>(in + (size_t)jp.channel_stride + i4);
+            const int4 b = *reinterpret_cast<const int4 *>(in + (size_t)jp.stride + i4);
             const int32_t l[4] = { a.x >> sh, a.y >> sh, a.z >> sh, a.w >> sh };
             const int32_t r[4] = { b.x >> sh, b.y >> sh, b.z >> sh, b.w >> sh };
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const int32_t s = (int32_t)((uint32_t)r[i] - (uint32_t)l[i]);
-                out[i] = (variant == jp.num_channels + 1) ? s : (int32_t)((uint32_t)l[i] + (uint32_t)(s >> 1));
+                out[i] = (variant == jp.nch + 1) ? s : (int32_t)((uint32_t)l[i] + (uint32_t)(s >> 1));
             }
         }
     } else {
@@ -114,9 +128,9 @@ __device__ __forceinline__ void load_chunk(const int32_t *__restrict__ in, const
     }
 }
 
-__device__ __forceinline__ bool input_aligned(const int32_t *in, const SrlaJobParams &jp)
+__device__ __forceinline__ bool input_aligned(const int32_t *in, const InputView &jp)
 {
-    return ((reinterpret_cast<uintptr_t>(in) & 15u) == 0) && ((jp.channel_stride & 3u) == 0);
+    return ((reinterpret_cast<uintptr_t>(in) & 15u) == 0) && ((jp.stride & 3u) == 0);
 }
 
 /* ------------------------------------------------------------------------------ FFT ------ */
@@ -127,19 +141,20 @@ __device__ __forceinline__ bool input_aligned(const int32_t *in, const SrlaJobPa
 template <int R>
 __device__ void fft_complex_lds(cplx *x, uint32_t m, int flag, const cplx *__restrict__ tw)
 {
+    /* tw: per stage (sub-size n) three tables of n/4 entries each: w^p, w^2p, w^3p -- the host builds them with
+     * the reference's own products (w2 = w1*w1, w3 = w1*w2, fft.c:95-96), so the values are identical */
     const uint32_t tid = threadIdx.x;
     uint32_t n = m, s = 1, log2s = 0;
-    const double jim = (double)(-flag);
     const uint32_t nb = m >> 2;
     while (n > 2) {
         const uint32_t n1 = n >> 2, n2 = n >> 1, n3 = n1 + n2;
-        cplx a[R], b[R], c[R], d[R], w1[R];
+        cplx a[R], b[R], c[R], d[R], w1[R], w2[R], w3[R];
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const uint32_t bf = tid + (uint32_t)r * NT;
             if (bf < nb) {
                 const uint32_t p = bf >> log2s, q = bf & (s - 1);
-                w1[r] = tw[p];
+                w1[r] = tw[p]; w2[r] = tw[n1 + p]; w3[r] = tw[2 * n1 + p];
                 a[r] = x[q + s * p];
                 b[r] = x[q + s * (p + n1)];
                 c[r] = x[q + s * (p + n2)];
@@ -152,21 +167,20 @@ __device__ void fft_complex_lds(cplx *x, uint32_t m, int flag, const cplx *__res
             const uint32_t bf = tid + (uint32_t)r * NT;
             if (bf < nb) {
                 const uint32_t p = bf >> log2s, q = bf & (s - 1);
-                const cplx w2 = c_mul(w1[r], w1[r]);
-                const cplx w3 = c_mul(w1[r], w2);
                 const cplx apc = c_add(a[r], c[r]), amc = c_sub(a[r], c[r]), bpd = c_add(b[r], d[r]);
                 const cplx bmd = c_sub(b[r], d[r]);
-                /* (0, -flag) * (b - d), written out as the reference's complex product */
-                const cplx jbmd = make_double2(0.0 * bmd.x - jim * bmd.y, 0.0 * bmd.y + jim * bmd.x);
+                /* (0, -flag) * (b - d): the reference evaluates 0*re - (-flag)*im and 0*im + (-flag)*re
+                 * (fft.c:57-63, 104); for finite data that is exactly (flag*im, -flag*re) up to the sign of a zero */
+                const cplx jbmd = (flag < 0) ? make_double2(-bmd.y, bmd.x) : make_double2(bmd.y, -bmd.x);
                 const uint32_t o = q + s * (p << 2);
                 x[o] = c_add(apc, bpd);
                 x[o + s] = c_mul(w1[r], c_sub(amc, jbmd));
-                x[o + 2 * s] = c_mul(w2, c_sub(apc, bpd));
-                x[o + 3 * s] = c_mul(w3, c_add(amc, jbmd));
+                x[o + 2 * s] = c_mul(w2[r], c_sub(apc, bpd));
+                x[o + 3 * s] = c_mul(w3[r], c_add(amc, jbmd));
             }
         }
         __syncthreads();
-        tw += n1;
+        tw += 3 * n1;
         n >>= 2;
         s <<= 2;
         log2s += 2;
@@ -191,7 +205,7 @@ __device__ void fft_complex_lds(cplx *x, uint32_t m, int flag, const cplx *__res
 __device__ __forceinline__ uint32_t complex_table_len(uint32_t m)
 {
     uint32_t t = 0;
-    for (uint32_t n = m; n > 2; n >>= 2) t += n >> 2;
+    for (uint32_t n = m; n > 2; n >>= 2) t += 3 * (n >> 2);
     return t;
 }
 
@@ -300,7 +314,7 @@ __global__ __launch_bounds__(NT) void srla_autocorr(
 {
     constexpr int CH = 2 * R;   /* chunks of four samples per thread: covers 2048 * R >= nfft */
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    if (jp.lshift_dev) jp.offset_lshift = *jp.lshift_dev;
+    const InputView iv = input_view(jp);
     double *buf = (double *)lds;
     SmallA *sm = (SmallA *)(lds + fft_bytes);
 
@@ -310,7 +324,7 @@ __global__ __launch_bounds__(NT) void srla_autocorr(
     const SrlaGeom g = geoms[it.geom];
     const uint32_t n = it.n, nfft = g.nfft, bps = jp.bits_per_sample;
     const int32_t *in = input + it.sample_off;
-    const bool aligned = input_aligned(in, jp);
+    const bool aligned = input_aligned(in, iv);
     const bool first_pass = (pass == 1) || (jp.ltp_order == 0);   /* the pass that owns the pre-emphasis tap */
     SrlaItemResult *out = &results[item_idx];
 
@@ -319,8 +333,8 @@ __global__ __launch_bounds__(NT) void srla_autocorr(
 #pragma unroll
     for (int c = 0; c < CH; c++) {
         const uint32_t i4 = 4u * (tid + (uint32_t)c * NT);
-        load_chunk(in, jp, it.variant, i4, n, aligned, v[c]);
-        pv[c] = (i4 == 0 || i4 >= n) ? v[c][0] : load_variant(in, jp, it.variant, i4 - 1);
+        load_chunk(in, iv, it.variant, i4, n, aligned, v[c]);
+        pv[c] = (i4 == 0 || i4 >= n) ? v[c][0] : load_variant(in, iv, it.variant, i4 - 1);
     }
 
     int32_t coef;
@@ -331,7 +345,7 @@ __global__ __launch_bounds__(NT) void srla_autocorr(
 #pragma unroll
         for (int c = 0; c < CH; c++) {
             const uint32_t i4 = 4u * (tid + (uint32_t)c * NT);
-            const int32_t nx = (i4 + 4 < n) ? load_variant(in, jp, it.variant, i4 + 4) : 0;
+            const int32_t nx = (i4 + 4 < n) ? load_variant(in, iv, it.variant, i4 + 4) : 0;
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const long long x = v[c][i];
@@ -357,10 +371,10 @@ __global__ __launch_bounds__(NT) void srla_autocorr(
                 d0 = (double)s0; d1 = (double)s1;
             } else {
                 /* srla_utility.c:226-240 literally (rounding depends on the order) */
-                double curr = load_variant(in, jp, it.variant, 0), succ = load_variant(in, jp, it.variant, 1);
+                double curr = load_variant(in, iv, it.variant, 0), succ = load_variant(in, iv, it.variant, 1);
                 d0 = 0.0; d1 = 0.0;
                 for (uint32_t i = 0; i + 2 < n; i++) {
-                    const double nn = load_variant(in, jp, it.variant, i + 2);
+                    const double nn = load_variant(in, iv, it.variant, i + 2);
                     d0 += curr * curr; d1 += curr * succ; curr = succ; succ = nn;
                 }
                 d0 += curr * curr; d1 += curr * succ; curr = succ; d0 += curr * curr;
@@ -372,7 +386,7 @@ __global__ __launch_bounds__(NT) void srla_autocorr(
             }
             sm->preemph_coef = c;
             /* this pass initialises the item record */
-            out->preemph_prev = load_variant(in, jp, it.variant, 0);
+            out->preemph_prev = load_variant(in, iv, it.variant, 0);
             out->preemph_coef = c;
             out->lpc_order = 0; out->lpc_rshift = 0; out->use_sum = 0; out->ltp_period = 0;
             out->ltp_coef[0] = 0; out->ltp_coef[1] = 0; out->ltp_coef[2] = 0;
@@ -965,7 +979,7 @@ __device__ __forceinline__ uint32_t code_cost(uint32_t val, uint32_t k, uint32_t
 }
 
 template <int FL>
-__device__ void residual_cost_fast(const SrlaJobParams &jp, const int32_t *__restrict__ in, const SrlaItemDesc &it,
+__device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, const InputView &iv, const int32_t *__restrict__ in, const SrlaItemDesc &it,
                                    unsigned char *lds, const double *__restrict__ rice_thresholds,
                                    int32_t *__restrict__ res_ws, SrlaItemResult *__restrict__ out)
 {
@@ -976,7 +990,7 @@ __device__ void residual_cost_fast(const SrlaJobParams &jp, const int32_t *__res
     SmallF *sm = (SmallF *)(lds + ((SIG_WORDS * 4 + 15) & ~15u));
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t n = 1024u * FL, bps = jp.bits_per_sample;
-    const bool aligned = input_aligned(in, jp);
+    const bool aligned = input_aligned(in, iv);
     const int32_t coef = out->preemph_coef;
     const uint32_t order = out->lpc_order, rshift = out->lpc_rshift, period = out->ltp_period;
     const uint32_t o4 = (order + 3u) & ~3u;
@@ -987,11 +1001,11 @@ __device__ void residual_cost_fast(const SrlaJobParams &jp, const int32_t *__res
 #pragma unroll
     for (int c = 0; c < FL; c++) {
         int32_t t4[4];
-        load_chunk(in, jp, it.variant, s_base + 4 * c, n, aligned, t4);
+        load_chunk(in, iv, it.variant, s_base + 4 * c, n, aligned, t4);
         y[4 * c] = t4[0]; y[4 * c + 1] = t4[1]; y[4 * c + 2] = t4[2]; y[4 * c + 3] = t4[3];
     }
     {
-        int32_t prev = (tid == 0) ? y[0] : load_variant(in, jp, it.variant, s_base - 1);
+        int32_t prev = (tid == 0) ? y[0] : load_variant(in, iv, it.variant, s_base - 1);
 #pragma unroll
         for (int i = 0; i < S; i++) {
             const int32_t cur = y[i];
@@ -1039,18 +1053,19 @@ __device__ void residual_cost_fast(const SrlaJobParams &jp, const int32_t *__res
         for (int i = 0; i < S; i++) acc[i] = (uint32_t)half;
 #pragma unroll
         for (int c = 0; c < FL; c++) cur[c] = *reinterpret_cast<const int4 *>(sig + sig_index<FL>(PADS + (int)s_base + 4 * c - (int)o4));
+        /* every sample fits in 24 bits (the fast path is only taken for bps <= 18: |x| < 2^(bps-1) per channel,
+         * S = R - L doubles it, pre-emphasis doubles again, the LTP at most quadruples) and the taps are 8-bit, so
+         * the full-rate 24-bit multiply gives the same low 32 bits as the wrap-around 32-bit product */
         for (uint32_t kb = 0; kb < o4; kb += 4) {
             const int4 cf = *reinterpret_cast<const int4 *>(&sm->coefq[kb]);
-            const uint32_t f0 = (uint32_t)cf.x, f1 = (uint32_t)cf.y, f2 = (uint32_t)cf.z, f3 = (uint32_t)cf.w;
 #pragma unroll
             for (int c = 0; c < FL; c++) {
                 const int4 nxt = *reinterpret_cast<const int4 *>(sig + sig_index<FL>(PADS + (int)s_base + 4 * c - (int)o4 + (int)kb + 4));
-                const uint32_t w0 = (uint32_t)cur[c].x, w1 = (uint32_t)cur[c].y, w2 = (uint32_t)cur[c].z, w3 = (uint32_t)cur[c].w;
-                const uint32_t w4 = (uint32_t)nxt.x, w5 = (uint32_t)nxt.y, w6 = (uint32_t)nxt.z;
-                acc[4 * c + 0] += f0 * w0 + f1 * w1 + f2 * w2 + f3 * w3;
-                acc[4 * c + 1] += f0 * w1 + f1 * w2 + f2 * w3 + f3 * w4;
-                acc[4 * c + 2] += f0 * w2 + f1 * w3 + f2 * w4 + f3 * w5;
-                acc[4 * c + 3] += f0 * w3 + f1 * w4 + f2 * w5 + f3 * w6;
+                const int w0 = cur[c].x, w1 = cur[c].y, w2 = cur[c].z, w3 = cur[c].w, w4 = nxt.x, w5 = nxt.y, w6 = nxt.z;
+                acc[4 * c + 0] += (uint32_t)(__mul24(cf.x, w0) + __mul24(cf.y, w1) + __mul24(cf.z, w2) + __mul24(cf.w, w3));
+                acc[4 * c + 1] += (uint32_t)(__mul24(cf.x, w1) + __mul24(cf.y, w2) + __mul24(cf.z, w3) + __mul24(cf.w, w4));
+                acc[4 * c + 2] += (uint32_t)(__mul24(cf.x, w2) + __mul24(cf.y, w3) + __mul24(cf.z, w4) + __mul24(cf.w, w5));
+                acc[4 * c + 3] += (uint32_t)(__mul24(cf.x, w3) + __mul24(cf.y, w4) + __mul24(cf.z, w5) + __mul24(cf.w, w6));
                 cur[c] = nxt;
             }
         }
@@ -1148,13 +1163,54 @@ __device__ void residual_cost_fast(const SrlaJobParams &jp, const int32_t *__res
                 acc[l] = side;
             }
         }
+        /* All of a thread's parameters usually span <= 4 consecutive values: then the cost of each of its four
+         * fine partitions is tabulated once per candidate k and every level just selects (4x fewer operations
+         * than pricing every sample under every level). */
+        uint32_t kmin = kl[0], kmax = kl[0];
 #pragma unroll
-        for (int i = 0; i < S; i++) {
-            const uint32_t val = u[i];
-            acc[10] += code_cost(val, k10[i / FL], code_type);
-            acc[9] += code_cost(val, k9[i / (2 * FL)], code_type);
+        for (int l = 1; l <= 8; l++) { kmin = (kl[l] < kmin) ? kl[l] : kmin; kmax = (kl[l] > kmax) ? kl[l] : kmax; }
 #pragma unroll
-            for (int l = 0; l <= 8; l++) acc[l] += code_cost(val, kl[l], code_type);
+        for (int p = 0; p < 2; p++) { kmin = (k9[p] < kmin) ? k9[p] : kmin; kmax = (k9[p] > kmax) ? k9[p] : kmax; }
+#pragma unroll
+        for (int p = 0; p < 4; p++) { kmin = (k10[p] < kmin) ? k10[p] : kmin; kmax = (k10[p] > kmax) ? k10[p] : kmax; }
+        if (kmax - kmin <= 3u) {
+            uint32_t T[4][4];
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    uint32_t t = 0;
+#pragma unroll
+                    for (int i = 0; i < FL; i++) t += code_cost(u[p * FL + i], kmin + j, code_type);
+                    T[p][j] = t;
+                }
+            }
+#define PICK(p, k) (((k) - kmin) == 0u ? T[p][0] : (((k) - kmin) == 1u ? T[p][1] : (((k) - kmin) == 2u ? T[p][2] : T[p][3])))
+            acc[10] += PICK(0, k10[0]) + PICK(1, k10[1]) + PICK(2, k10[2]) + PICK(3, k10[3]);
+            acc[9] += PICK(0, k9[0]) + PICK(1, k9[0]) + PICK(2, k9[1]) + PICK(3, k9[1]);
+            uint32_t Cj[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) Cj[j] = T[0][j] + T[1][j] + T[2][j] + T[3][j];
+#pragma unroll
+            for (int l = 0; l <= 8; l++) {
+                const uint32_t d = kl[l] - kmin;
+                acc[l] += (d == 0u) ? Cj[0] : ((d == 1u) ? Cj[1] : ((d == 2u) ? Cj[2] : Cj[3]));
+            }
+#undef PICK
+        } else {
+            /* rare (a thread's parameters span more than four values): price every sample under every level,
+             * rolled loops over the residual just written and the published parameter table */
+            const int32_t *mine = res_ws + it.res_off + s_base;
+#pragma unroll
+            for (int l = 0; l <= 10; l++) {
+                uint32_t a = 0;
+#pragma unroll 1
+                for (int i = 0; i < S; i++) {
+                    const uint32_t part = (4u * tid + (uint32_t)(i / FL)) >> (10 - l);
+                    a += code_cost(zigzag32(mine[i]), sm->ktab[((1u << l) - 1) + part], code_type);
+                }
+                acc[l] += a;
+            }
         }
 #pragma unroll
         for (int l = 0; l <= 10; l++) {
@@ -1195,19 +1251,19 @@ __global__ __launch_bounds__(NT) void srla_residual_cost(
 {
     constexpr int CH = 2 * R;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    if (jp.lshift_dev) jp.offset_lshift = *jp.lshift_dev;
+    const InputView iv = input_view(jp);
     {
         /* blocks of 1024 * FL samples take the register / shuffle fast path */
         const SrlaItemDesc itf = items[blockIdx.x];
         const uint32_t fl = itf.n >> 10;
-        if ((itf.n & 1023u) == 0 && fl >= 1 && fl <= 4 && fl <= (uint32_t)(2 * R)) {
+        if ((itf.n & 1023u) == 0 && fl >= 1 && fl <= 4 && fl <= (uint32_t)(2 * R) && jp.bits_per_sample <= 18) {
             const int32_t *inf = input + itf.sample_off;
             SrlaItemResult *outf = &results[blockIdx.x];
             switch (fl) {
-            case 1: residual_cost_fast<1>(jp, inf, itf, lds, rice_thresholds, res_ws, outf); return;
-            case 2: residual_cost_fast<2>(jp, inf, itf, lds, rice_thresholds, res_ws, outf); return;
-            case 3: residual_cost_fast<3>(jp, inf, itf, lds, rice_thresholds, res_ws, outf); return;
-            default: residual_cost_fast<4>(jp, inf, itf, lds, rice_thresholds, res_ws, outf); return;
+            case 1: residual_cost_fast<1>(jp, iv, inf, itf, lds, rice_thresholds, res_ws, outf); return;
+            case 2: residual_cost_fast<2>(jp, iv, inf, itf, lds, rice_thresholds, res_ws, outf); return;
+            case 3: residual_cost_fast<3>(jp, iv, inf, itf, lds, rice_thresholds, res_ws, outf); return;
+            default: residual_cost_fast<4>(jp, iv, inf, itf, lds, rice_thresholds, res_ws, outf); return;
             }
         }
     }
@@ -1222,7 +1278,7 @@ __global__ __launch_bounds__(NT) void srla_residual_cost(
     const SrlaGeom g = geoms[it.geom];
     const uint32_t n = it.n, bps = jp.bits_per_sample;
     const int32_t *in = input + it.sample_off;
-    const bool aligned = input_aligned(in, jp);
+    const bool aligned = input_aligned(in, iv);
     SrlaItemResult *out = &results[item_idx];
     const int32_t coef = out->preemph_coef;
     const uint32_t order = out->lpc_order, rshift = out->lpc_rshift, period = out->ltp_period;
@@ -1232,8 +1288,8 @@ __global__ __launch_bounds__(NT) void srla_residual_cost(
 #pragma unroll
     for (int c = 0; c < CH; c++) {
         const uint32_t i4 = 4u * (tid + (uint32_t)c * NT);
-        load_chunk(in, jp, it.variant, i4, n, aligned, v[c]);
-        int32_t prev = (i4 == 0 || i4 >= n) ? v[c][0] : load_variant(in, jp, it.variant, i4 - 1);
+        load_chunk(in, iv, it.variant, i4, n, aligned, v[c]);
+        int32_t prev = (i4 == 0 || i4 >= n) ? v[c][0] : load_variant(in, iv, it.variant, i4 - 1);
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int32_t cur = v[c][i];
