@@ -65,13 +65,42 @@ inline void put_u32be(uint8_t *p, uint32_t v)
     p[0] = (uint8_t)(v >> 24); p[1] = (uint8_t)(v >> 16); p[2] = (uint8_t)(v >> 8); p[3] = (uint8_t)v;
 }
 
-/* append `nbits` bits of a byte-aligned MSB-first bitstring */
+inline uint64_t load_be64(const uint8_t *p) { uint64_t v; memcpy(&v, p, 8); return __builtin_bswap64(v); }
+inline void store_be64(uint8_t *p, uint64_t v) { v = __builtin_bswap64(v); memcpy(p, &v, 8); }
+
+/* Append `nbits` bits of a byte-aligned MSB-first bitstring (the device pads every bitstring to a multiple
+ * of 8 bytes, so whole 64-bit words can be read).  The sink's pending bits are merged once, then the body
+ * is a shifted 64-bit copy; the tail goes back through put(). */
 inline void append_bits(BitSink &w, const uint8_t *src, uint32_t nbits)
 {
-    uint32_t i = 0;
-    for (; i + 32 <= nbits; i += 32, src += 4)
+    uint32_t done = 0;
+    if (nbits >= 128) {
+        const uint32_t c = w.cnt;                       /* pending bits (< 32) in the low end of acc */
+        const uint64_t pend = c ? (w.acc & ((1ull << c) - 1ull)) : 0ull;
+        uint64_t carry = c ? (pend << (64 - c)) : 0ull; /* pending bits, left aligned */
+        uint8_t *p = w.p;
+        const uint32_t words = nbits >> 6;
+        if (c == 0) {
+            memcpy(p, src, (size_t)words * 8);
+            p += (size_t)words * 8;
+        } else {
+            for (uint32_t i = 0; i < words; i++) {
+                const uint64_t v = load_be64(src + (size_t)i * 8);
+                store_be64(p, carry | (v >> c));
+                carry = v << (64 - c);
+                p += 8;
+            }
+        }
+        w.p = p;
+        w.acc = c ? (carry >> (64 - c)) : 0ull;          /* the last c bits read are pending again */
+        done = words << 6;
+        src += (size_t)words * 8;
+    }
+    uint32_t rem = nbits - done;
+    while (rem >= 32) {
         w.put(((uint32_t)src[0] << 24) | ((uint32_t)src[1] << 16) | ((uint32_t)src[2] << 8) | (uint32_t)src[3], 32);
-    uint32_t rem = nbits - i;
+        src += 4; rem -= 32;
+    }
     while (rem >= 8) { w.put(*src++, 8); rem -= 8; }
     if (rem) w.put((uint32_t)(*src) >> (8 - rem), rem);
 }
@@ -80,14 +109,23 @@ inline void append_bits(BitSink &w, const uint8_t *src, uint32_t nbits)
 
 uint16_t fletcher16(const uint8_t *data, size_t size)
 {
-    uint32_t c0 = 0, c1 = 0;
-    while (size > 0) {
-        size_t chunk = (size < 5802) ? size : 5802;
-        size -= chunk;
-        while (chunk--) { c0 += *data++; c1 += c0; }
-        c0 = (c0 + c0 / 255u) & 0xFFu;
-        c1 = (c1 + c1 / 255u) & 0xFFu;
+    /* The reference (srla_utility.c:36-60) runs c0 += b, c1 += c0 and folds both mod 255 every 5802 bytes with
+     * (x + x/255) & 0xFF, which IS x mod 255 (255q + r + q = 256q + r).  Hence c0 = sum(b_i) mod 255 and
+     * c1 = sum((size - i) * b_i) mod 255, which needs no running dependency: two plain sums the compiler can
+     * vectorise, accumulated per 256-byte chunk in 32 bits and widened to 64. */
+    uint64_t a = 0, wsum = 0;            /* a = sum b_i ; wsum = sum i * b_i (i = global index) */
+    size_t base = 0;
+    while (base < size) {
+        const size_t len = (size - base < 256) ? (size - base) : 256;
+        uint32_t ca = 0, cw = 0;
+        const uint8_t *p = data + base;
+        for (size_t i = 0; i < len; i++) { ca += p[i]; cw += (uint32_t)i * p[i]; }
+        a += ca;
+        wsum += cw + (uint64_t)base * ca;
+        base += len;
     }
+    const uint64_t c0 = a % 255u;
+    const uint64_t c1 = ((uint64_t)(size % 255u) * c0 + 255u * 255u - (wsum % 255u)) % 255u;
     return (uint16_t)((c1 << 8) | c0);
 }
 

@@ -17,7 +17,7 @@
  *   srla_lpc_quantize<L>    one lane per item: predictor of the chosen order, 8-bit quantiser, tap cost.
  *   srla_residual_cost<R>   one workgroup per item: pre-emphasis (+LTP), register-blocked int32 FIR,
  *                           residual to HBM, partitioned (recursive) Rice code-length search.
- *   srla_price_windows      stereo decision + block sizes + shortest path, one thread per window.
+ *   srla_price_windows      stereo decision + block sizes + shortest path, one wave per window.
  *   srla_pack_blocks        codes the chosen blocks' residuals into per-channel bitstrings (prefix-summed
  *                           bit offsets) for the host bit-packer; RAW payloads; compact records.
  *   srla_or_reduce          whole-stream OR for the offset left shift.
@@ -1533,20 +1533,38 @@ __global__ __launch_bounds__(NT) void srla_residual_cost(
 }
 
 /* ------------------------------------------------------------------------- pricing -------- */
-/* One thread per window.  Block cost: ComputeBlockSize (srla_encoder.c:1477-1546) on top of the
- * stereo decision of ComputeCoefficients (:1275-1327); path: ApplyDijkstraMethod (:249-307)
- * with its exact tie behaviour; partition read-back (:397-421). */
-__global__ void srla_price_windows(SrlaJobParams jp, const SrlaWindowDesc *__restrict__ windows,
-                                   const SrlaCandDesc *__restrict__ cands,
-                                   const SrlaItemResult *__restrict__ results,
-                                   SrlaBlockRecord *__restrict__ blocks, uint32_t *__restrict__ cand_bytes)
+/* One wave per window.  Block cost: ComputeBlockSize (srla_encoder.c:1477-1546) on top of the
+ * stereo decision of ComputeCoefficients (:1275-1327), one candidate per lane; path:
+ * ApplyDijkstraMethod (:249-307) with its exact tie behaviour (lowest-index minimum, strict
+ * improvement), the node scan and the edge relaxation spread over the lanes; partition read-back
+ * (:397-421), one block record per lane. */
+#define SRLA_MAX_WINDOW_CANDS (SRLA_MAX_NODES * (SRLA_MAX_NODES - 1) / 2)
+
+__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v)
 {
-    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= jp.num_windows) return;
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t lo = __shfl_xor((uint32_t)v, off, WAVE), hi = __shfl_xor((uint32_t)(v >> 32), off, WAVE);
+        const uint64_t o = ((uint64_t)hi << 32) | lo;
+        v = (o < v) ? o : v;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(WAVE) void srla_price_windows(SrlaJobParams jp, const SrlaWindowDesc *__restrict__ windows,
+                                                           const SrlaCandDesc *__restrict__ cands,
+                                                           const SrlaItemResult *__restrict__ results,
+                                                           SrlaBlockRecord *__restrict__ blocks, uint32_t *__restrict__ cand_bytes)
+{
+    __shared__ uint32_t s_packed[SRLA_MAX_WINDOW_CANDS];
+    __shared__ uint8_t s_ni[SRLA_MAX_WINDOW_CANDS], s_nj[SRLA_MAX_WINDOW_CANDS];
+    __shared__ uint32_t s_cost[SRLA_MAX_NODES], s_path[SRLA_MAX_NODES], s_via[SRLA_MAX_NODES], s_used[SRLA_MAX_NODES];
+    __shared__ uint32_t s_order[SRLA_MAX_NODES];
+    const uint32_t w = blockIdx.x, lane = threadIdx.x;
     const SrlaWindowDesc wd = windows[w];
     const uint32_t nch = jp.num_channels, bps = jp.bits_per_sample, nodes = wd.num_nodes;
+    (void)cand_bytes;
 
-    for (uint32_t c = 0; c < wd.num_cands; c++) {
+    for (uint32_t c = lane; c < wd.num_cands; c += WAVE) {
         const SrlaCandDesc cd = cands[wd.cand_base + c];
         const uint32_t raw_bytes = 11u + (bps * cd.n * nch) / 8u;
         uint32_t bytes = raw_bytes, type = SRLA_BLOCK_RAW, method = 0;
@@ -1571,37 +1589,47 @@ __global__ void srla_price_windows(SrlaJobParams jp, const SrlaWindowDesc *__res
                 else { type = SRLA_BLOCK_COMPRESS; bytes = 11u + bits / 8u; }
             }
         }
-        cand_bytes[wd.cand_base + c] = bytes | (type << 28) | (method << 30);
+        s_packed[c] = bytes | (type << 28) | (method << 30);
+        s_ni[c] = (uint8_t)cd.node_i; s_nj[c] = (uint8_t)cd.node_j;
     }
+    for (uint32_t i = lane; i < nodes; i += WAVE) {
+        s_cost[i] = (i == 0) ? 0u : SRLA_BIG_WEIGHT; s_path[i] = 0xFFFFFFFFu; s_via[i] = 0xFFFFFFFFu; s_used[i] = 0;
+    }
+    __syncthreads();
     /* shortest path 0 -> nodes-1 over candidate edges */
-    long long cost[SRLA_MAX_NODES];
-    uint32_t path[SRLA_MAX_NODES];
-    uint32_t via_cand[SRLA_MAX_NODES];
-    uint8_t used[SRLA_MAX_NODES];
-    for (uint32_t i = 0; i < nodes; i++) { cost[i] = SRLA_BIG_WEIGHT; path[i] = 0xFFFFFFFFu; used[i] = 0; via_cand[i] = 0xFFFFFFFFu; }
-    cost[0] = 0;
     uint32_t target = 0;
     for (uint32_t guard = 0; guard <= nodes; guard++) {
-        long long mn = SRLA_BIG_WEIGHT;
-        for (uint32_t i = 0; i < nodes; i++) if (!used[i] && mn > cost[i]) { mn = cost[i]; target = i; }
+        /* first unused node whose cost is below BIG and minimal (`mn > cost[i]`, ascending i) */
+        uint64_t key = ~0ull;
+        for (uint32_t i = lane; i < nodes; i += WAVE)
+            if (!s_used[i] && s_cost[i] < SRLA_BIG_WEIGHT) { const uint64_t k = ((uint64_t)s_cost[i] << 8) | i; key = (k < key) ? k : key; }
+        key = wave_min_u64(key);
+        if (key != ~0ull) target = (uint32_t)(key & 0xFFu);
         if (target == nodes - 1) break;
-        /* relax every edge leaving `target` (edges are the candidates with node_i == target) */
-        for (uint32_t c = 0; c < wd.num_cands; c++) {
-            const SrlaCandDesc cd = cands[wd.cand_base + c];
-            if (cd.node_i != target) continue;
-            const long long via = (long long)(cand_bytes[wd.cand_base + c] & 0x0FFFFFFFu) + cost[target];
-            if (cost[cd.node_j] > via) { cost[cd.node_j] = via; path[cd.node_j] = target; via_cand[cd.node_j] = c; }
+        const uint32_t base_cost = s_cost[target];
+        /* relax every edge leaving `target`; its edges end on distinct nodes, so the lanes never collide */
+        for (uint32_t c = lane; c < wd.num_cands; c += WAVE) {
+            if (s_ni[c] != target) continue;
+            const uint32_t j = s_nj[c];
+            const uint32_t via = (s_packed[c] & 0x0FFFFFFFu) + base_cost;
+            if (s_cost[j] > via) { s_cost[j] = via; s_path[j] = target; s_via[j] = c; }
         }
-        used[target] = 1;
+        if (lane == 0) s_used[target] = 1;
+        __syncthreads();
     }
     /* read the partition back and emit block records in stream order */
     uint32_t count = 0;
-    for (uint32_t node = nodes - 1; node != 0 && path[node] != 0xFFFFFFFFu; node = path[node]) count++;
-    uint32_t node = nodes - 1;
-    for (uint32_t k = 0; k < count; k++) {
-        const uint32_t c = via_cand[node];
+    if (lane == 0) {
+        for (uint32_t node = nodes - 1; node != 0 && s_path[node] != 0xFFFFFFFFu; node = s_path[node]) s_order[count++] = node;
+    }
+    count = __shfl(count, 0, WAVE);
+    __syncthreads();
+    for (uint32_t k = lane; k < nodes - 1; k += WAVE) {
+        if (k >= count) { blocks[wd.block_base + k].valid = 0; continue; }
+        const uint32_t node = s_order[k];
+        const uint32_t c = s_via[node];
         const SrlaCandDesc cd = cands[wd.cand_base + c];
-        const uint32_t packed = cand_bytes[wd.cand_base + c];
+        const uint32_t packed = s_packed[c];
         SrlaBlockRecord rec;
         rec.valid = 1;
         rec.sample_off = cd.sample_off;
@@ -1635,9 +1663,7 @@ __global__ void srla_price_windows(SrlaJobParams jp, const SrlaWindowDesc *__res
         }
         rec.pad[0] = 0; rec.pad[1] = 0;
         blocks[wd.block_base + (count - 1 - k)] = rec;
-        node = path[node];
     }
-    for (uint32_t k = count; k < nodes - 1; k++) blocks[wd.block_base + k].valid = 0;
 }
 
 /* ------------------------------------------------------------------------- pack ----------- */
@@ -1927,8 +1953,7 @@ extern "C" int srla_launch_price(hipStream_t stream, const SrlaJobParams *jp, co
                                  SrlaBlockRecord *blocks, uint32_t *cand_bytes)
 {
     if (jp->num_windows == 0) return 0;
-    const uint32_t bs = 64;
-    hipLaunchKernelGGL(srla_price_windows, dim3((jp->num_windows + bs - 1) / bs), dim3(bs), 0, stream,
+    hipLaunchKernelGGL(srla_price_windows, dim3(jp->num_windows), dim3(WAVE), 0, stream,
                        *jp, windows, cands, results, blocks, cand_bytes);
     return (hipGetLastError() == hipSuccess) ? 0 : -2;
 }
