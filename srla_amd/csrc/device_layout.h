@@ -77,26 +77,19 @@ typedef struct SrlaItemResult {
     uint8_t  kparam[1024];       /* Rice k / recursive-Rice k2 per partition of porder */
 } SrlaItemResult;               /* 64 + 256 + 1024 = 1344 bytes */
 
-/* The part of an item record the host bit-packer still needs once the device has coded the residual
- * (a prefix of SrlaItemResult: scalar fields + taps). */
-typedef struct SrlaChanRecord {
-    int32_t  preemph_prev;
-    int32_t  preemph_coef;
-    uint32_t lpc_order;
-    uint32_t lpc_rshift;
-    uint32_t use_sum;
-    uint32_t ltp_period;
-    int32_t  ltp_coef[3];
-    uint32_t code_length;
-    uint32_t res_code_type;
-    uint32_t res_porder;
-    uint32_t res_bits;      /* exact length in bits of the channel's residual bitstring */
-    uint32_t flags;
-    uint32_t pad[2];
-    int8_t   lpc_coef[256];
-} SrlaChanRecord;               /* 320 bytes */
+#define SRLA_PACK_SLACK 128u    /* bytes of slack per block slot in the global pack scratch */
 
-#define SRLA_PACK_SLACK 128u    /* bytes of slack per block slot in the packed-bits buffer */
+/* Job summary the device writes into pinned host memory (srla_block_offsets / srla_pack_blocks). */
+typedef struct SrlaJobInfo {
+    uint32_t total_bytes;    /* bytes of all blocks of the job                          */
+    uint32_t base;           /* stream offset of the job's first block                  */
+    uint32_t num_blocks, num_raw, num_silent;
+    uint32_t num_tie_items, num_odd_items;   /* flagged items among the chosen blocks   */
+    uint32_t error;          /* SRLA_JOBERR_* bits                                      */
+} SrlaJobInfo;
+#define SRLA_JOBERR_OVERFLOW 1u  /* the stream would not fit the caller's buffer: nothing written from here on */
+#define SRLA_JOBERR_SIZE     2u  /* a packed block differs from its computed size (internal error)           */
+#define SRLA_JOBERR_COVER    4u  /* a window's chosen blocks do not tile it (internal error)                 */
 
 typedef struct SrlaCandDesc {
     uint32_t window;
@@ -117,7 +110,7 @@ typedef struct SrlaWindowDesc {
     uint32_t pad0, pad1;
 } SrlaWindowDesc;
 
-/* One encoded block as the host pack consumes it (kernel B output, stream order inside a window). */
+/* One chosen block (srla_price_windows output, stream order inside a window). */
 typedef struct SrlaBlockRecord {
     uint32_t valid;         /* 0 = unused slot */
     uint32_t sample_off;

@@ -41,7 +41,6 @@
 #define SRLA_MAX_FFT      8192u       /* largest block the LDS-resident FFT handles */
 
 static_assert(sizeof(SrlaItemResult) == SRLAMI355X_ITEM_RECORD_BYTES, "record size");
-static_assert(sizeof(SrlaChanRecord) == 320 && offsetof(SrlaItemResult, lpc_coef) == offsetof(SrlaChanRecord, lpc_coef), "chan record is a prefix of the item record");
 static_assert(SRLA_DBG_STRIDE == SRLAMI355X_DEBUG_DOUBLES, "debug stride");
 
 struct SRLAEncoder {
@@ -206,10 +205,12 @@ struct Slot {
     const int32_t *in_cur = nullptr;     /* device input of the current job */
     uint32_t stride_cur = 0;
     SrlaJobParams jp{};
-    size_t packed_bytes = 0;
     bool want_dbg = false;
-    DevBuf d_input, d_items, d_cands, d_windows, d_results, d_res_ws, d_blocks, d_cand_bytes, d_packed, d_chan, d_dbg, d_lags, d_err;
-    PinBuf h_in, h_packed, h_blocks, h_chan;
+    /* where this job's blocks go (set when the job is begun, used by the pack stage) */
+    uint8_t *out_direct = nullptr;       /* device-visible caller buffer, or nullptr: stage through h_stream */
+    uint32_t out_first = 1, out_init_pos = 0, out_limit = 0xFFFFFFFFu;
+    DevBuf d_input, d_items, d_cands, d_windows, d_results, d_res_ws, d_blocks, d_block_off, d_ctl, d_scratch, d_dbg, d_lags, d_err;
+    PinBuf h_in, h_stream, h_info;       /* h_info: SrlaJobInfo followed by the per-window byte counts */
     Job job;
     bool busy = false;
     bool used_h2d = false;
@@ -235,7 +236,8 @@ struct Impl {
     uint32_t kSlots = 4;              /* job buffer sets (SRLA_MI355X_SLOTS); slot i runs on stream i % kStreams */
     uint64_t job_samples = 2ull << 20; /* samples per job (SRLA_MI355X_JOB_SAMPLES) */
     Slot slot[kMaxSlots];
-    DevBuf d_tw, d_geoms, d_thr, d_huff, d_or;
+    DevBuf d_tw, d_geoms, d_thr, d_huff, d_huffcode, d_pos, d_or;
+    bool force_staging = false;       /* SRLA_MI355X_STAGING: never write the caller's buffer from the device */
     std::map<uint32_t, uint32_t> tw_index;   /* nfft -> offset (double2) */
     std::vector<double> tw_host;
     bool tw_dirty = false;
@@ -255,15 +257,15 @@ struct Impl {
                 for (auto &e : s.t0) if (e) (void)hipEventDestroy(e);
                 for (auto &e : s.t1) if (e) (void)hipEventDestroy(e);
                 DevBuf *db[] = { &s.d_input, &s.d_items, &s.d_cands, &s.d_windows, &s.d_results, &s.d_res_ws,
-                                 &s.d_blocks, &s.d_cand_bytes, &s.d_packed, &s.d_chan, &s.d_dbg, &s.d_lags, &s.d_err };
+                                 &s.d_blocks, &s.d_block_off, &s.d_ctl, &s.d_scratch, &s.d_dbg, &s.d_lags, &s.d_err };
                 for (auto *b : db) b->release();
-                PinBuf *pb[] = { &s.h_in, &s.h_packed, &s.h_blocks, &s.h_chan };
+                PinBuf *pb[] = { &s.h_in, &s.h_stream, &s.h_info };
                 for (auto *b : pb) b->release();
             }
             for (auto &st : streams) if (st) (void)hipStreamDestroy(st);
             if (ev_or) (void)hipEventDestroy(ev_or);
             h_or.release();
-            d_tw.release(); d_geoms.release(); d_thr.release(); d_huff.release(); d_or.release();
+            d_tw.release(); d_geoms.release(); d_thr.release(); d_huff.release(); d_huffcode.release(); d_pos.release(); d_or.release();
         }
     }
 
@@ -311,6 +313,15 @@ struct Impl {
         memcpy(huff + 256, srla::huffman_summed_lengths(), 256);
         if (!d_huff.ensure(sizeof(huff))) return false;
         HIP_OK(hipMemcpy(d_huff.p, huff, sizeof(huff), hipMemcpyHostToDevice));
+        {
+            uint32_t codes[512];
+            for (int i = 0; i < 256; i++) { codes[i] = srla::huffman_plain_codes()[i]; codes[256 + i] = srla::huffman_summed_codes()[i]; }
+            if (!d_huffcode.ensure(sizeof(codes))) return false;
+            HIP_OK(hipMemcpy(d_huffcode.p, codes, sizeof(codes), hipMemcpyHostToDevice));
+        }
+        if (!d_pos.ensure(64)) return false;
+        HIP_OK(hipMemset(d_pos.p, 0, 64));
+        force_staging = getenv("SRLA_MI355X_STAGING") != nullptr;
         if (!d_or.ensure(64)) return false;
         unsigned hw = std::thread::hardware_concurrency();
         /* a container's CPU quota (cgroup v2 cpu.max = "<quota> <period>") bounds the useful thread count */
@@ -498,7 +509,7 @@ struct Impl {
      * (Levinson / order / quantiser, pricing), C the D2H copies.  A job's stages are chained with events;
      * encode_stream enqueues the stages of consecutive jobs skewed (software pipeline), so that W always has
      * a wide kernel to run while N works through the serial stages of the neighbouring job. */
-    enum { ST_A = 0, ST_B, ST_C, ST_D, ST_E, ST_F, NUM_ST };
+    enum { ST_A = 0, ST_B, ST_C, ST_D, ST_E, NUM_ST };
 
     bool prepare_job(Slot &s, const int32_t *d_in, uint32_t d_stride, const int32_t *const *host_in, bool want_dbg)
     {
@@ -517,13 +528,16 @@ struct Impl {
         if (!s.d_results.ensure(std::max<size_t>(1, n_items) * sizeof(SrlaItemResult))) return false;
         if (!s.d_res_ws.ensure(std::max<uint64_t>(4, job.res_elems) * 4)) return false;
         if (!s.d_blocks.ensure((size_t)job.num_slots * sizeof(SrlaBlockRecord))) return false;
-        if (!s.d_cand_bytes.ensure(n_cands * 4)) return false;
-        s.packed_bytes = (size_t)job.ns * nch * (par.bits_per_sample / 8) + (size_t)job.num_slots * SRLA_PACK_SLACK + 64;
-        if (!s.d_packed.ensure(s.packed_bytes)) return false;
-        if (!s.d_chan.ensure((size_t)job.num_slots * nch * sizeof(SrlaChanRecord))) return false;
-        if (!s.h_packed.ensure(s.packed_bytes)) return false;
-        if (!s.h_blocks.ensure((size_t)job.num_slots * sizeof(SrlaBlockRecord))) return false;
-        if (!s.h_chan.ensure((size_t)job.num_slots * nch * sizeof(SrlaChanRecord))) return false;
+        if (!s.d_block_off.ensure((size_t)job.num_slots * 4 + 16)) return false;
+        if (!s.d_ctl.ensure(64)) return false;
+        if (!s.h_info.ensure(sizeof(SrlaJobInfo) + n_win * 4)) return false;
+        {
+            /* a block is never larger than its raw form (11 + n * nch * bytes): bound of the job's stream bytes */
+            const size_t bound = (size_t)job.ns * nch * (par.bits_per_sample / 8) + (size_t)job.num_slots * SRLA_PACK_SLACK + 64;
+            if (!s.out_direct && !s.h_stream.ensure(bound)) return false;
+            const SrlaJobParams probe = job_params(job, d_stride);
+            if (srla_pack_needs_scratch(&probe) && !s.d_scratch.ensure(bound)) return false;
+        }
         if (want_dbg && !s.d_dbg.ensure(std::max<size_t>(1, n_items) * SRLA_DBG_STRIDE * sizeof(double))) return false;
         const uint32_t lag_rows = std::max<uint32_t>(par.ltp_order > 0 ? SRLA_LTP_LAGS : 0u, preset_order() + 1);
         if (!s.d_lags.ensure((size_t)lag_rows * std::max<size_t>(1, n_items) * sizeof(double))) return false;
@@ -602,24 +616,22 @@ struct Impl {
             HIP_OK(hipStreamWaitEvent(N, s.t1[ST_C], 0));
             HIP_OK(hipEventRecord(s.t0[ST_D], N));
             rc |= srla_launch_price(N, &jp, s.d_windows.as<SrlaWindowDesc>(), s.d_cands.as<SrlaCandDesc>(),
-                                    s.d_results.as<SrlaItemResult>(), s.d_blocks.as<SrlaBlockRecord>(), s.d_cand_bytes.as<uint32_t>());
+                                    s.d_results.as<SrlaItemResult>(), s.d_blocks.as<SrlaBlockRecord>());
             HIP_OK(hipEventRecord(s.t1[ST_D], N));
             break;
         case ST_E:
-            HIP_OK(hipStreamWaitEvent(W, s.t1[ST_D], 0));
-            HIP_OK(hipEventRecord(s.t0[ST_E], W));
-            rc |= srla_launch_pack(W, &jp, job.num_slots, s.in_cur, s.d_items.as<SrlaItemDesc>(), s.d_blocks.as<SrlaBlockRecord>(),
-                                   s.d_results.as<SrlaItemResult>(), s.d_res_ws.as<int32_t>(), s.d_packed.as<uint8_t>(),
-                                   s.d_chan.as<SrlaChanRecord>());
-            HIP_OK(hipEventRecord(s.t1[ST_E], W));
-            break;
-        case ST_F:
-            HIP_OK(hipStreamWaitEvent(C, s.t1[ST_E], 0));
-            HIP_OK(hipEventRecord(s.t0[ST_F], C));
-            HIP_OK(hipMemcpyAsync(s.h_packed.p, s.d_packed.p, s.packed_bytes, hipMemcpyDeviceToHost, C));
-            HIP_OK(hipMemcpyAsync(s.h_blocks.p, s.d_blocks.p, (size_t)job.num_slots * sizeof(SrlaBlockRecord), hipMemcpyDeviceToHost, C));
-            HIP_OK(hipMemcpyAsync(s.h_chan.p, s.d_chan.p, (size_t)job.num_slots * par.num_channels * sizeof(SrlaChanRecord), hipMemcpyDeviceToHost, C));
-            HIP_OK(hipEventRecord(s.t1[ST_F], C));
+            /* block offsets + complete blocks, written where the stream wants them (the caller's pinned buffer,
+             * or this slot's pinned staging buffer); runs on its own stream and leaves W to autocorr / residual_cost */
+            HIP_OK(hipStreamWaitEvent(C, s.t1[ST_D], 0));
+            HIP_OK(hipEventRecord(s.t0[ST_E], C));
+            rc |= srla_launch_pack(C, &jp, job.num_slots, s.in_cur, s.d_items.as<SrlaItemDesc>(), s.d_windows.as<SrlaWindowDesc>(),
+                                   s.d_blocks.as<SrlaBlockRecord>(), s.d_results.as<SrlaItemResult>(), s.d_res_ws.as<int32_t>(),
+                                   d_huffcode.as<uint32_t>(), d_huff.as<uint8_t>(), s.d_block_off.as<uint32_t>(),
+                                   d_pos.as<uint32_t>(), s.d_ctl.as<uint32_t>(), s.out_first, s.out_init_pos,
+                                   s.out_direct ? 1u : 0u, s.out_limit, s.out_direct ? s.out_direct : s.h_stream.as<uint8_t>(),
+                                   s.d_scratch.as<uint8_t>(), s.h_info.as<SrlaJobInfo>(),
+                                   reinterpret_cast<uint32_t *>(s.h_info.as<SrlaJobInfo>() + 1));
+            HIP_OK(hipEventRecord(s.t1[ST_E], C));
             break;
         default: return false;
         }
@@ -637,9 +649,9 @@ struct Impl {
 
     bool wait_job(Slot &s)
     {
-        HIP_OK(hipEventSynchronize(s.t1[ST_F]));
+        HIP_OK(hipEventSynchronize(s.t1[ST_E]));
         float t = 0;
-        double *acc[NUM_ST] = { &stats.autocorr_ms, &stats.solve_ms, &stats.residual_ms, &stats.price_ms, &stats.gather_ms, &stats.d2h_ms };
+        double *acc[NUM_ST] = { &stats.autocorr_ms, &stats.solve_ms, &stats.residual_ms, &stats.price_ms, &stats.gather_ms };
         for (int st = 0; st < NUM_ST; st++)
             if (hipEventElapsedTime(&t, s.t0[st], s.t1[st]) == hipSuccess) *acc[st] += t;
         stats.analyze_ms = stats.autocorr_ms + stats.solve_ms + stats.residual_ms;
@@ -647,64 +659,32 @@ struct Impl {
         return true;
     }
 
-    /* Pack every window of a finished job into `data` (stream order); returns false when the
-     * output buffer is too small.  window_bytes[w] receives the size of window w. */
-    SRLAApiResult pack_job(Slot &s, const srla::StreamInfo &si, uint8_t *data, uint32_t data_size,
-                           uint32_t *written, std::vector<uint32_t> &window_bytes)
+    /* A finished job: check the device's verdict, move the bytes to `data + write_off` unless the device wrote
+     * them there itself, and report the per-window sizes. */
+    SRLAApiResult finish_job(Slot &s, uint8_t *data, uint32_t write_off, uint32_t *written, const uint32_t **window_bytes)
     {
         const auto t0 = Clock::now();
-        const Job &job = s.job;
-        const uint32_t nch = par.num_channels;
-        const SrlaBlockRecord *blocks = s.h_blocks.as<SrlaBlockRecord>();
-        const SrlaChanRecord *chan = s.h_chan.as<SrlaChanRecord>();
-        const uint8_t *packed = s.h_packed.as<uint8_t>();
-        const uint32_t bytes_ps = par.bits_per_sample / 8;
-        struct Todo { uint32_t slot; uint32_t off; };
-        std::vector<Todo> todo;
-        todo.reserve(job.num_slots);
-        window_bytes.assign(job.windows.size(), 0);
-        uint64_t total = 0;
-        for (size_t w = 0; w < job.windows.size(); w++) {
-            const SrlaWindowDesc &wd = job.windows[w];
-            uint32_t covered = 0;
-            for (uint32_t k = 0; k + 1 < wd.num_nodes; k++) {
-                const SrlaBlockRecord &br = blocks[wd.block_base + k];
-                if (!br.valid) break;
-                todo.push_back({ wd.block_base + k, (uint32_t)total });
-                total += br.bytes;
-                window_bytes[w] += br.bytes;
-                covered += br.n;
-            }
-            if (covered != wd.n) {
-                fprintf(stderr, "[srla-mi355x] internal error: window %zu partition covers %u of %u samples\n", w, covered, wd.n);
-                return SRLA_APIRESULT_NG;
-            }
-        }
-        if (total > data_size) return SRLA_APIRESULT_INSUFFICIENT_BUFFER;
-        std::atomic<int> bad{ 0 };
-        std::atomic<uint64_t> raw{ 0 }, silent{ 0 }, ties{ 0 }, odd{ 0 };
-        static const bool skip_pack = getenv("SRLA_MI355X_DIAG_SKIP_PACK") != nullptr;   /* diagnostics only: output is garbage */
-        pool->parallel_for(skip_pack ? 0u : (uint32_t)todo.size(), [&](uint32_t i) {
-            const SrlaBlockRecord &br = blocks[todo[i].slot];
-            const uint8_t *region = packed + (size_t)br.sample_off * nch * bytes_ps + (size_t)todo[i].slot * SRLA_PACK_SLACK;
-            const SrlaChanRecord *recs = chan + (size_t)todo[i].slot * nch;
-            const uint32_t sz = srla::pack_block(si, br, recs, region, data + todo[i].off);
-            if (sz != br.bytes) bad.fetch_add(1);
-            if (br.block_type == SRLA_BLOCK_RAW) raw.fetch_add(1);
-            else if (br.block_type == SRLA_BLOCK_SILENT) silent.fetch_add(1);
-            else for (uint32_t ch = 0; ch < nch; ch++) {
-                if (recs[ch].flags & SRLA_ITEM_ORDER_TIE) ties.fetch_add(1);
-                if (recs[ch].flags & SRLA_ITEM_ODD_LENGTH) odd.fetch_add(1);
-            }
-        });
-        stats.num_blocks += todo.size(); stats.num_raw_blocks += raw; stats.num_silent_blocks += silent;
-        stats.num_tie_items += ties; stats.num_odd_items += odd;
-        stats.pack_ms += ms_since(t0);
-        if (bad.load() != 0) {
-            fprintf(stderr, "[srla-mi355x] internal error: %d packed block(s) differ from their computed size\n", bad.load());
+        const SrlaJobInfo info = *s.h_info.as<SrlaJobInfo>();
+        if (info.error & SRLA_JOBERR_OVERFLOW) return SRLA_APIRESULT_INSUFFICIENT_BUFFER;
+        if (info.error != 0 || info.base != write_off) {
+            fprintf(stderr, "[srla-mi355x] internal error: device pack reported 0x%x (%s%s), stream offset %u vs %u\n", info.error,
+                    (info.error & SRLA_JOBERR_SIZE) ? "a packed block differs from its computed size " : "",
+                    (info.error & SRLA_JOBERR_COVER) ? "a window's blocks do not cover it" : "", info.base, write_off);
             return SRLA_APIRESULT_NG;
         }
-        *written = (uint32_t)total;
+        if (!s.out_direct && data != nullptr) {
+            const uint8_t *src = s.h_stream.as<uint8_t>();
+            const uint32_t chunk = 256u << 10, total = info.total_bytes;
+            pool->parallel_for((total + chunk - 1) / chunk, [&](uint32_t i) {
+                const uint32_t o = i * chunk;
+                memcpy(data + write_off + o, src + o, std::min(chunk, total - o));
+            });
+        }
+        stats.num_blocks += info.num_blocks; stats.num_raw_blocks += info.num_raw; stats.num_silent_blocks += info.num_silent;
+        stats.num_tie_items += info.num_tie_items; stats.num_odd_items += info.num_odd_items;
+        stats.pack_ms += ms_since(t0);
+        *written = info.total_bytes;
+        *window_bytes = reinterpret_cast<const uint32_t *>(s.h_info.as<SrlaJobInfo>() + 1);
         return SRLA_APIRESULT_OK;
     }
 
@@ -766,12 +746,20 @@ struct Impl {
             }
             write_off = SRLA_HEADER_SIZE;   /* the header itself is written once the shift is known (below) */
         }
-        const srla::StreamInfo si = stream_info(num_samples);
+        /* can the device store into the caller's buffer (pinned / registered host memory)? */
+        uint8_t *out_direct = nullptr;
+        if (!force_staging) {
+            hipPointerAttribute_t at;
+            memset(&at, 0, sizeof(at));
+            if (hipPointerGetAttributes(&at, data) == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer != nullptr)
+                out_direct = static_cast<uint8_t *>(at.devicePointer);
+            else (void)hipGetLastError();
+        }
+        const uint32_t init_pos = write_off;
         const uint32_t window_len = search ? par.num_lookahead_samples : par.max_num_samples_per_block;
         const uint32_t wpj = windows_per_job(search);
         const uint64_t job_len = (uint64_t)wpj * window_len;
         const uint32_t njobs = (uint32_t)((num_samples + job_len - 1) / job_len);
-        std::vector<uint32_t> window_bytes;
         uint32_t progress = 0;
 
         auto fail = [&](SRLAApiResult rc) {
@@ -786,10 +774,11 @@ struct Impl {
             const uint32_t s0 = (uint32_t)((uint64_t)k * job_len);
             const uint32_t ns = (uint32_t)std::min<uint64_t>(job_len, num_samples - s0);
             build_job(s.job, s0, ns, search);
+            s.out_direct = out_direct; s.out_first = (k == 0); s.out_init_pos = init_pos; s.out_limit = data_size;
             return prepare_job(s, d_in ? d_in + s0 : nullptr, d_stride, host_in, false);
         };
         /* Software pipeline over jobs: iteration t enqueues  autocorr + solve of job t,  residual_cost +
-         * pricing of job t-1,  pack + D2H of job t-2,  then packs job t-3 on the host.  Needs 4 buffer sets. */
+         * pricing of job t-1,  block assembly of job t-2,  then collects job t-3.  Needs 4 buffer sets. */
         const uint32_t depth = 3;
         uint32_t header_done = with_header ? 0 : 1;
         for (uint32_t t = 0; t < njobs + depth; t++) {
@@ -803,7 +792,7 @@ struct Impl {
             }
             if (t >= 2 && t - 2 < njobs) {
                 Slot &s = job_slot(t - 2);
-                if (!run_stage(s, ST_E) || !run_stage(s, ST_F)) return fail(SRLA_APIRESULT_NG);
+                if (!run_stage(s, ST_E)) return fail(SRLA_APIRESULT_NG);
             }
             stats.h2d_ms += ms_since(t_enq);       /* host time spent enqueueing (no H2D of samples on this path) */
             if (t < depth) continue;
@@ -819,7 +808,8 @@ struct Impl {
                 header_done = 1;
             }
             uint32_t wrote = 0;
-            const SRLAApiResult rc = pack_job(s, si, data + write_off, data_size - write_off, &wrote, window_bytes);
+            const uint32_t *window_bytes = nullptr;
+            const SRLAApiResult rc = finish_job(s, data, write_off, &wrote, &window_bytes);
             if (rc != SRLA_APIRESULT_OK) return fail(rc);
             /* callbacks: once per window, in order, pointing into the caller's buffer
              * (srla_encoder.c:1779-1782) */
@@ -972,10 +962,11 @@ static SRLAApiResult single_window(Impl *im, const int32_t *const *input, uint32
     /* ComputeBlockSize: run the job, read the block record, skip the pack */
     Slot &s = im->slot[0];
     im->build_job(s.job, 0, num_samples, false);
+    s.out_direct = nullptr; s.out_first = 1; s.out_init_pos = 0; s.out_limit = 0xFFFFFFFFu;
     if (!im->launch_job(s, nullptr, 0, input, false) || !im->wait_job(s)) return SRLA_APIRESULT_NG;
-    const SrlaBlockRecord &br = s.h_blocks.as<SrlaBlockRecord>()[0];
-    if (!br.valid) return SRLA_APIRESULT_NG;
-    *output_size = br.bytes;
+    const SrlaJobInfo *info = s.h_info.as<SrlaJobInfo>();
+    if (info->error != 0 || info->num_blocks != 1) return SRLA_APIRESULT_NG;
+    *output_size = info->total_bytes;
     return SRLA_APIRESULT_OK;
 }
 
@@ -1071,6 +1062,7 @@ SRLAApiResult SRLAMI355X_ProbeBlock(struct SRLAEncoder *encoder, const int32_t *
     if (!im->init_device()) return SRLA_APIRESULT_NG;
     Slot &s = im->slot[0];
     im->build_job(s.job, 0, num_samples, false);
+    s.out_direct = nullptr; s.out_first = 1; s.out_init_pos = 0; s.out_limit = 0xFFFFFFFFu;
     if (!im->launch_job(s, nullptr, 0, input, true) || !im->wait_job(s)) return SRLA_APIRESULT_NG;
     const uint32_t nv = im->num_variants();
     if (records && hipMemcpy(records, s.d_results.p, (size_t)nv * sizeof(SrlaItemResult), hipMemcpyDeviceToHost) != hipSuccess)

@@ -1,11 +1,9 @@
-/* host_pack.h -- host-side bitstream writer (see host_pack.cpp). */
+/* host_pack.h -- what is left of the bitstream on the host (see host_pack.cpp). */
 #ifndef SRLA_HOST_PACK_H
 #define SRLA_HOST_PACK_H
 
 #include <stddef.h>
 #include <stdint.h>
-
-#include "device_layout.h"
 
 namespace srla {
 
@@ -20,16 +18,12 @@ struct StreamInfo {
     uint32_t ltp_order;
 };
 
-uint16_t fletcher16(const uint8_t *data, size_t size);
 void write_stream_header(const StreamInfo &s, uint8_t *p /* 30 bytes */);
-/* Writes one complete block (11-byte header + payload) and returns its size, which equals
- * br.bytes by construction.  chan: one record per channel (compress blocks); region: the block's
- * region of the device-packed buffer -- per channel the residual bitstring (MSB first, each starting on
- * an 8-byte boundary, chan[ch].res_bits long) for compress blocks, the final payload bytes for raw. */
-uint32_t pack_block(const StreamInfo &s, const SrlaBlockRecord &br, const SrlaChanRecord *chan,
-                    const uint8_t *region, uint8_t *out);
+/* static Huffman tables of the tap codes (format constants), uploaded to the device */
 const unsigned char *huffman_plain_lengths();
 const unsigned char *huffman_summed_lengths();
+const unsigned int *huffman_plain_codes();
+const unsigned int *huffman_summed_codes();
 
 }  // namespace srla
 #endif

@@ -1553,7 +1553,7 @@ __device__ __forceinline__ uint64_t wave_min_u64(uint64_t v)
 __global__ __launch_bounds__(WAVE) void srla_price_windows(SrlaJobParams jp, const SrlaWindowDesc *__restrict__ windows,
                                                            const SrlaCandDesc *__restrict__ cands,
                                                            const SrlaItemResult *__restrict__ results,
-                                                           SrlaBlockRecord *__restrict__ blocks, uint32_t *__restrict__ cand_bytes)
+                                                           SrlaBlockRecord *__restrict__ blocks)
 {
     __shared__ uint32_t s_packed[SRLA_MAX_WINDOW_CANDS];
     __shared__ uint8_t s_ni[SRLA_MAX_WINDOW_CANDS], s_nj[SRLA_MAX_WINDOW_CANDS];
@@ -1562,7 +1562,6 @@ __global__ __launch_bounds__(WAVE) void srla_price_windows(SrlaJobParams jp, con
     const uint32_t w = blockIdx.x, lane = threadIdx.x;
     const SrlaWindowDesc wd = windows[w];
     const uint32_t nch = jp.num_channels, bps = jp.bits_per_sample, nodes = wd.num_nodes;
-    (void)cand_bytes;
 
     for (uint32_t c = lane; c < wd.num_cands; c += WAVE) {
         const SrlaCandDesc cd = cands[wd.cand_base + c];
@@ -1630,14 +1629,9 @@ __global__ __launch_bounds__(WAVE) void srla_price_windows(SrlaJobParams jp, con
         const uint32_t c = s_via[node];
         const SrlaCandDesc cd = cands[wd.cand_base + c];
         const uint32_t packed = s_packed[c];
-        SrlaBlockRecord rec;
-        rec.valid = 1;
-        rec.sample_off = cd.sample_off;
-        rec.n = cd.n;
-        rec.block_type = (packed >> 28) & 3u;
-        rec.ch_method = (packed >> 30) & 3u;
-        rec.bytes = packed & 0x0FFFFFFFu;
-        if (rec.block_type == SRLA_BLOCK_COMPRESS && nch > 2) {
+        uint32_t block_type = (packed >> 28) & 3u, bytes = packed & 0x0FFFFFFFu;
+        const uint32_t ch_method = (packed >> 30) & 3u;
+        if (block_type == SRLA_BLOCK_COMPRESS && nch > 2) {
             /* ComputeBlockSize prices only the first two channels (srla_encoder.c:1287-1301) and that
              * price drives the search; EncodeBlock then writes every channel and applies its RAW
              * fall-back to the size actually written (srla_encoder.c:1605-1611) */
@@ -1645,37 +1639,132 @@ __global__ __launch_bounds__(WAVE) void srla_price_windows(SrlaJobParams jp, con
             for (uint32_t ch = 2; ch < nch; ch++) bits += results[cd.item_base + ch].code_length;
             const uint32_t l = results[cd.item_base + 0].code_length, r = results[cd.item_base + 1].code_length;
             const uint32_t m = results[cd.item_base + nch].code_length, s2 = results[cd.item_base + nch + 1].code_length;
-            const uint32_t len[4] = { l + r, m + s2, l + s2, r + s2 };
-            bits += len[rec.ch_method];
+            bits += (ch_method == 0) ? l + r : (ch_method == 1) ? m + s2 : (ch_method == 2) ? l + s2 : r + s2;
             const uint32_t payload = (bits + 7u) / 8u;
-            if (8u * payload >= bps * cd.n * nch) { rec.block_type = SRLA_BLOCK_RAW; rec.bytes = 11u + (bps * cd.n * nch) / 8u; }
-            else rec.bytes = 11u + payload;
+            if (8u * payload >= bps * cd.n * nch) { block_type = SRLA_BLOCK_RAW; bytes = 11u + (bps * cd.n * nch) / 8u; }
+            else bytes = 11u + payload;
         }
-        for (uint32_t ch = 0; ch < SRLA_MAX_CH; ch++) rec.item[ch] = 0xFFFFFFFFu;
-        if (rec.block_type == SRLA_BLOCK_COMPRESS) {
-            for (uint32_t ch = 0; ch < nch; ch++) rec.item[ch] = cd.item_base + ch;
-            if (nch >= 2) {
-                const uint32_t mi = cd.item_base + nch, si = cd.item_base + nch + 1;
-                if (rec.ch_method == 1) { rec.item[0] = mi; rec.item[1] = si; }
-                else if (rec.ch_method == 2) { rec.item[1] = si; }
-                else if (rec.ch_method == 3) { rec.item[0] = si; }
+        SrlaBlockRecord *rec = &blocks[wd.block_base + (count - 1 - k)];
+        rec->valid = 1;
+        rec->sample_off = cd.sample_off;
+        rec->n = cd.n;
+        rec->block_type = block_type;
+        rec->ch_method = ch_method;
+        rec->bytes = bytes;
+        for (uint32_t ch = 0; ch < SRLA_MAX_CH; ch++) {
+            uint32_t it = 0xFFFFFFFFu;
+            if (block_type == SRLA_BLOCK_COMPRESS && ch < nch) {
+                it = cd.item_base + ch;
+                if (nch >= 2) {
+                    const uint32_t mi = cd.item_base + nch, si = cd.item_base + nch + 1;
+                    if (ch == 0 && ch_method == 1) it = mi;
+                    if (ch == 0 && ch_method == 3) it = si;
+                    if (ch == 1 && (ch_method == 1 || ch_method == 2)) it = si;
+                }
             }
+            rec->item[ch] = it;
         }
-        rec.pad[0] = 0; rec.pad[1] = 0;
-        blocks[wd.block_base + (count - 1 - k)] = rec;
+        rec->pad[0] = 0; rec->pad[1] = 0;
     }
 }
 
 /* ------------------------------------------------------------------------- pack ----------- */
-/* grid = (block slots, channels).  For every chosen block the device emits, per channel, the complete
- * residual bitstring of SRLACoder_Encode (srla_coder.c:532-595: 2-bit code type, 10-bit partition order,
- * per partition the parameter -- 5 bits, then unary zig-zag deltas -- followed by the (recursive) Rice
- * codes), MSB first, starting on an 8-byte boundary inside the block's region of the packed buffer.
- * Bit offsets come from a workgroup prefix sum over the code lengths; bits are assembled in LDS with
- * atomic ORs and stored with 16-byte coalesced writes.  The host only writes the header fields, ORs the
- * channel bitstrings behind them, and frames / checksums the block.  RAW blocks get their final payload
- * bytes (srla_encoder.c:823-852).  Block region = [sample_off * nch * bps/8 + slot * SLACK, ...). */
-__device__ __forceinline__ void lds_put_bits(uint32_t *w, uint32_t bitpos, uint32_t value, uint32_t nbits)
+/* srla_block_offsets (one workgroup per job): exclusive prefix sum of the chosen blocks' byte sizes in
+ * stream order, the job's position in the output stream (a device-resident running offset, so jobs can be
+ * enqueued back to back without a host round trip), per-window byte counts for the encode callback, block
+ * statistics and the overflow / coverage checks of SRLAEncoder_EncodeWhole (srla_encoder.c:1756-1783). */
+__global__ __launch_bounds__(NT) void srla_block_offsets(
+    SrlaJobParams jp, const SrlaWindowDesc *__restrict__ windows, const SrlaBlockRecord *__restrict__ blocks,
+    const SrlaItemResult *__restrict__ results, uint32_t num_slots, uint32_t *__restrict__ block_off,
+    uint32_t *__restrict__ stream_pos /* [0] running offset, [1] sticky overflow flag */,
+    uint32_t *__restrict__ ctl /* [0] base added to block_off by the pack kernel, [1] skip */,
+    uint32_t first, uint32_t init_pos, uint32_t absolute, uint32_t limit, SrlaJobInfo *__restrict__ info,
+    uint32_t *__restrict__ window_bytes)
+{
+    __shared__ uint32_t s_wave[NWAVES];
+    __shared__ uint32_t s_cnt[5];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nch = jp.num_channels;
+    if (tid < 5) s_cnt[tid] = 0;
+    __syncthreads();
+    uint32_t carry = 0;
+    uint32_t nblk = 0, nraw = 0, nsil = 0, ntie = 0, nodd = 0;
+    for (uint32_t base = 0; base < num_slots; base += NT) {
+        const uint32_t i = base + tid;
+        uint32_t b = 0;
+        if (i < num_slots && blocks[i].valid) {
+            const SrlaBlockRecord *rec = &blocks[i];
+            b = rec->bytes;
+            nblk++;
+            if (rec->block_type == SRLA_BLOCK_RAW) nraw++;
+            else if (rec->block_type == SRLA_BLOCK_SILENT) nsil++;
+            else for (uint32_t ch = 0; ch < nch; ch++) {
+                const uint32_t f = results[rec->item[ch]].flags;
+                if (f & SRLA_ITEM_ORDER_TIE) ntie++;
+                if (f & SRLA_ITEM_ODD_LENGTH) nodd++;
+            }
+        }
+        uint32_t incl = b;
+        for (int off = 1; off < WAVE; off <<= 1) { const uint32_t t = __shfl_up(incl, off, WAVE); if (lane >= (uint32_t)off) incl += t; }
+        if (lane == WAVE - 1) s_wave[wave] = incl;
+        __syncthreads();
+        uint32_t pre = carry, tot = 0;
+        for (uint32_t k = 0; k < NWAVES; k++) { if (k < wave) pre += s_wave[k]; tot += s_wave[k]; }
+        if (i < num_slots) block_off[i] = pre + incl - b;
+        carry += tot;
+        __syncthreads();
+    }
+    const uint32_t total = carry;
+    {
+        const uint32_t v[5] = { nblk, nraw, nsil, ntie, nodd };
+        for (int k = 0; k < 5; k++) { const uint32_t s = wave_sum_u32(v[k]); if (lane == 0 && s) atomicAdd(&s_cnt[k], s); }
+    }
+    __syncthreads();
+    /* per-window sizes + coverage: the chosen blocks of a window must tile it exactly */
+    uint32_t bad = 0;
+    for (uint32_t w = tid; w < jp.num_windows; w += NT) {
+        const SrlaWindowDesc wd = windows[w];
+        const uint32_t b0 = wd.block_base, b1 = wd.block_base + wd.num_nodes - 1;
+        const uint32_t start = block_off[b0], end = (b1 < num_slots) ? block_off[b1] : total;
+        window_bytes[w] = end - start;
+        uint32_t covered = 0;
+        for (uint32_t k = b0; k < b1; k++) { if (!blocks[k].valid) break; covered += blocks[k].n; }
+        if (covered != wd.n) bad = 1;
+    }
+    bad = wave_max_u32(bad);
+    if (lane == 0 && bad) atomicOr(&s_cnt[0], 0x80000000u);
+    __syncthreads();
+    if (tid == 0) {
+        const uint32_t pos = first ? init_pos : stream_pos[0];
+        uint32_t err = (s_cnt[0] & 0x80000000u) ? SRLA_JOBERR_COVER : 0u;
+        uint32_t skip = first ? 0u : stream_pos[1];
+        if ((uint64_t)pos + total > (uint64_t)limit) { err |= SRLA_JOBERR_OVERFLOW; skip = 1; }
+        if (err & SRLA_JOBERR_COVER) skip = 1;
+        stream_pos[0] = skip ? pos : pos + total;
+        stream_pos[1] = skip;
+        ctl[0] = absolute ? pos : 0u;
+        ctl[1] = skip;
+        info->total_bytes = total;
+        info->base = pos;
+        info->num_blocks = s_cnt[0] & 0x7FFFFFFFu;
+        info->num_raw = s_cnt[1];
+        info->num_silent = s_cnt[2];
+        info->num_tie_items = s_cnt[3];
+        info->num_odd_items = s_cnt[4];
+        info->error = err;
+    }
+}
+
+/* srla_pack_blocks, one workgroup per chosen block: assembles the COMPLETE block of the stream -- the
+ * 11-byte block header (srla_encoder.c:1583-1595, 1629-1636), the compress payload (:1368-1452: channel
+ * method, pre-emphasis state, LPC order / shift / static-Huffman coded taps, LTP fields, then per channel the
+ * residual code of SRLACoder_Encode, srla_coder.c:532-595: 2-bit code type, 10-bit partition order, per
+ * partition the parameter -- 5 bits, then unary zig-zag deltas -- followed by the (recursive) Rice codes) or
+ * the raw payload (:823-852), and the Fletcher-16 checksum (srla_utility.c:36-60) -- MSB first in LDS (bit
+ * offsets from a workgroup prefix sum over the code lengths, bits merged with LDS atomic ORs), and stores it
+ * at its final byte offset of the output stream with 16-byte stores.  Blocks too large for LDS are assembled in
+ * a global scratch region instead (template parameter G). */
+template <bool G>
+__device__ __forceinline__ void put_bits(uint32_t *w, uint32_t bitpos, uint32_t value, uint32_t nbits)
 {
     /* nbits in [1,32]; word k holds stream bits 32k..32k+31, most significant first */
     if (nbits < 32) value &= (1u << nbits) - 1u;
@@ -1688,131 +1777,257 @@ __device__ __forceinline__ void lds_put_bits(uint32_t *w, uint32_t bitpos, uint3
     }
 }
 
+template <bool G>
+__device__ __forceinline__ uint32_t get_word(const uint32_t *w, uint32_t i)
+{
+    /* the global scratch is filled by L2 atomics: read it past the (non-coherent) vector L1 */
+    if (G) return __hip_atomic_load(&w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return w[i];
+}
+
+template <bool G>
+__device__ __forceinline__ void pack_block_body(
+    const SrlaJobParams &jp, const SrlaBlockRecord *__restrict__ recp, const int32_t *__restrict__ input,
+    const SrlaItemDesc *__restrict__ items, const SrlaItemResult *__restrict__ results, const int32_t *__restrict__ res_ws,
+    const uint32_t *__restrict__ huff_code, const uint8_t *__restrict__ huff_len, uint32_t *w, uint32_t *aux,
+    uint8_t *__restrict__ dst, SrlaJobInfo *__restrict__ info)
+{
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    /* scalars of the record; item[] stays in memory (dynamic indexing of a by-value copy would spill) */
+    const uint32_t nch = jp.num_channels, bps = jp.bits_per_sample, n = recp->n, T = recp->bytes;
+    const uint32_t block_type = recp->block_type, sample_off = recp->sample_off;
+    const uint32_t nwords = ((T + 3u) >> 2) + 1u;
+    for (uint32_t i = tid; i < nwords; i += NT) w[i] = 0;
+    __syncthreads();
+    if (tid == 0) {
+        put_bits<G>(w, 0, 0xFFFFu, 16);                 /* sync code */
+        put_bits<G>(w, 16, T - 11u + 5u, 32);           /* size of what follows the size field */
+        put_bits<G>(w, 64, block_type, 8);
+        put_bits<G>(w, 72, n, 16);
+    }
+    uint32_t end_bits = 88;                             /* uniform: first bit behind the payload */
+    if (block_type == SRLA_BLOCK_RAW) {
+        /* interleaved, zig-zag mapped, big endian */
+        const uint32_t count = n * nch;
+        for (uint32_t i = tid; i < count; i += NT) {
+            const uint32_t s = i / nch, ch = i - s * nch;
+            const int32_t v = input[(size_t)ch * jp.channel_stride + sample_off + s];
+            put_bits<G>(w, 88u + i * bps, zigzag32(v), bps);
+        }
+        end_bits = 88u + count * bps;
+    } else if (block_type == SRLA_BLOCK_COMPRESS) {
+        /* header bits of the payload: every thread needs their count, wave 0 writes them */
+        uint32_t hdr_bits = 2u + nch * (bps + 1u + 5u);
+        for (uint32_t ch = 0; ch < nch; ch++) {
+            const SrlaItemResult *ir = &results[recp->item[ch]];
+            hdr_bits += 8u + 4u + 1u + ir->pad[0] + 1u;
+            if (ir->ltp_period > 0) hdr_bits += 1u + 8u + jp.ltp_order * 6u;
+        }
+        if (wave == 0) {
+            uint32_t p = 88;
+            if (lane == 0) put_bits<G>(w, p, recp->ch_method, 2);
+            p += 2;
+            if (lane < nch) {
+                const SrlaItemResult *ir = &results[recp->item[lane]];
+                put_bits<G>(w, p + lane * (bps + 6u), zigzag32(ir->preemph_prev), bps + 1u);
+                put_bits<G>(w, p + lane * (bps + 6u) + bps + 1u, zigzag32(ir->preemph_coef), 5);
+            }
+            p += nch * (bps + 6u);
+            for (uint32_t ch = 0; ch < nch; ch++) {
+                const SrlaItemResult *ir = &results[recp->item[ch]];
+                const uint32_t order = ir->lpc_order, use_sum = ir->use_sum;
+                if (lane == 0) {
+                    put_bits<G>(w, p, order, 8);
+                    put_bits<G>(w, p + 8, ir->lpc_rshift, 4);
+                    put_bits<G>(w, p + 12, use_sum, 1);
+                }
+                p += 13;
+                for (uint32_t b0 = 0; b0 < order; b0 += WAVE) {
+                    const uint32_t i = b0 + lane;
+                    uint32_t code = 0, len = 0;
+                    if (i < order) {
+                        const int32_t c = ir->lpc_coef[i];
+                        if (!use_sum || i == 0) { const uint32_t u = zigzag32(c); code = huff_code[u]; len = huff_len[u]; }
+                        else { const uint32_t u = zigzag32(c + (int32_t)ir->lpc_coef[i - 1]); code = huff_code[256 + u]; len = huff_len[256 + u]; }
+                    }
+                    uint32_t incl = len;
+                    for (int off = 1; off < WAVE; off <<= 1) { const uint32_t t = __shfl_up(incl, off, WAVE); if (lane >= (uint32_t)off) incl += t; }
+                    if (len) put_bits<G>(w, p + incl - len, code, len);
+                    p += __shfl(incl, WAVE - 1, WAVE);
+                }
+            }
+            for (uint32_t ch = 0; ch < nch; ch++) {
+                const SrlaItemResult *ir = &results[recp->item[ch]];
+                const uint32_t period = ir->ltp_period;
+                if (lane == 0) {
+                    put_bits<G>(w, p, period != 0, 1);
+                    if (period > 0) {
+                        put_bits<G>(w, p + 1, (jp.ltp_order - 1u) / 2u, 1);
+                        put_bits<G>(w, p + 2, period - SRLA_LTP_MIN_PERIOD, 8);
+                        for (uint32_t i = 0; i < jp.ltp_order; i++) put_bits<G>(w, p + 10 + 6 * i, zigzag32(ir->ltp_coef[i]), 6);
+                    }
+                }
+                p += 1u + (period > 0 ? 9u + 6u * jp.ltp_order : 0u);
+            }
+            if (lane == 0 && p != 88u + hdr_bits) info->error = SRLA_JOBERR_SIZE;
+        }
+        /* residual codes, channel after channel */
+        uint32_t chan_base = 88u + hdr_bits;
+        for (uint32_t ch = 0; ch < nch; ch++) {
+            const uint32_t item = recp->item[ch];
+            const SrlaItemResult *ir = &results[item];
+            const uint32_t total_bits = ir->res_bits, code_type = ir->res_code_type, porder = ir->res_porder;
+            if (code_type == SRLA_CODE_ALLZERO) {
+                if (tid == 0) put_bits<G>(w, chan_base, SRLA_CODE_ALLZERO, 2);
+            } else {
+                const int32_t *res = res_ws + items[item].res_off;
+                const uint32_t plen = n >> porder;
+                const uint32_t per = (n + NT - 1) / NT;                  /* contiguous samples per thread */
+                const uint32_t s0 = (tid * per < n) ? tid * per : n, s1 = (s0 + per < n) ? (s0 + per) : n;
+                const uint32_t part0 = (s0 < n) ? s0 / plen : 0;
+                /* pass 1: bits this thread will emit */
+                uint32_t mybits = 0;
+                {
+                    uint32_t part = part0, next = (part0 + 1) * plen;
+                    uint32_t k = ir->kparam[part];
+                    for (uint32_t s = s0; s < s1; s++) {
+                        if (s == next) { part++; next += plen; k = ir->kparam[part]; }
+                        if (s == part * plen) {
+                            if (part == 0) mybits += 2u + 10u + 5u;
+                            else mybits += zigzag32((int32_t)k - (int32_t)ir->kparam[part - 1]) + 1u;
+                        }
+                        const uint32_t u = zigzag32(res[s]);
+                        if (code_type == SRLA_CODE_RICE) mybits += 1u + k + (u >> k);
+                        else {
+                            const uint32_t k1pow = 2u << k;
+                            mybits += (u < k1pow) ? (k + 2u) : (k + 2u + ((u - k1pow) >> k));
+                        }
+                    }
+                }
+                /* exclusive prefix sum over the workgroup */
+                uint32_t incl = mybits;
+                for (int off = 1; off < WAVE; off <<= 1) { const uint32_t t = __shfl_up(incl, off, WAVE); if (lane >= (uint32_t)off) incl += t; }
+                __syncthreads();                                         /* aux is reused channel after channel */
+                if (lane == WAVE - 1) aux[wave] = incl;
+                __syncthreads();
+                uint32_t pos = chan_base + incl - mybits;
+                for (uint32_t k = 0; k < wave; k++) pos += aux[k];
+                /* pass 2: emit */
+                {
+                    uint32_t part = part0, next = (part0 + 1) * plen;
+                    uint32_t k = ir->kparam[part];
+                    for (uint32_t s = s0; s < s1; s++) {
+                        if (s == next) { part++; next += plen; k = ir->kparam[part]; }
+                        if (s == part * plen) {
+                            if (part == 0) {
+                                put_bits<G>(w, pos, code_type, 2); pos += 2;
+                                put_bits<G>(w, pos, porder, 10); pos += 10;
+                                put_bits<G>(w, pos, k, 5); pos += 5;
+                            } else {
+                                pos += zigzag32((int32_t)k - (int32_t)ir->kparam[part - 1]);   /* zeros */
+                                put_bits<G>(w, pos, 1u, 1); pos += 1;
+                            }
+                        }
+                        const uint32_t u = zigzag32(res[s]);
+                        if (code_type == SRLA_CODE_RICE) {
+                            pos += u >> k;                                /* quotient in unary: zeros */
+                            put_bits<G>(w, pos, (1u << k) | (u & ((1u << k) - 1u)), k + 1u); pos += k + 1u;
+                        } else {
+                            const uint32_t k1 = k + 1u, k1pow = 1u << k1;
+                            if (u < k1pow) {
+                                put_bits<G>(w, pos, 1u, 1); pos += 1;                       /* (2^k1 | u) in k1 + 1 bits */
+                                put_bits<G>(w, pos, u, k1); pos += k1;
+                            } else {
+                                const uint32_t v = u - k1pow;
+                                pos += 1u + (v >> k);
+                                put_bits<G>(w, pos, (1u << k) | (v & ((1u << k) - 1u)), k + 1u); pos += k + 1u;
+                            }
+                        }
+                    }
+                }
+            }
+            chan_base += total_bits;
+        }
+        end_bits = chan_base;
+    }
+    if (tid == 0 && 11u + ((end_bits - 88u + 7u) >> 3) != T) info->error = SRLA_JOBERR_SIZE;
+    __syncthreads();
+
+    /* Fletcher-16 over bytes [8, T): the reference folds c0 += b, c1 += c0 modulo 255, i.e.
+     * c0 = sum b_i, c1 = sum (L - i) b_i  (mod 255) with i counted from byte 8 and L = T - 8 */
+    {
+        const uint32_t L = T - 8u;
+        uint64_t a = 0, ws = 0;
+        for (uint32_t wi = 2u + tid; wi < nwords; wi += NT) {
+            const uint32_t v = get_word<G>(w, wi);
+            const uint32_t i0 = 4u * wi - 8u;
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) {
+                const uint32_t b = (v >> (24u - 8u * k)) & 0xFFu;       /* zero beyond T */
+                a += b;
+                ws += (uint64_t)b * (uint64_t)(uint32_t)((L > i0 + k) ? (L - i0 - k) : 0u);
+            }
+        }
+        uint32_t c0 = (uint32_t)(a % 255u), c1 = (uint32_t)(ws % 255u);
+        c0 = wave_sum_u32(c0); c1 = wave_sum_u32(c1);
+        if (lane == 0) { aux[8 + wave] = c0; aux[16 + wave] = c1; }
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t s0 = 0, s1 = 0;
+            for (uint32_t k = 0; k < NWAVES; k++) { s0 += aux[8 + k]; s1 += aux[16 + k]; }
+            put_bits<G>(w, 48, ((s1 % 255u) << 8) | (s0 % 255u), 16);
+        }
+        __syncthreads();
+    }
+
+    /* store at the block's byte offset of the stream: bytes up to the first 16-byte boundary, 16-byte body, tail */
+    {
+        const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 15u);
+        uint32_t head = (16u - mis) & 15u;
+        if (head > T) head = T;
+        const uint32_t nvec = (T - head) >> 4;
+        const uint32_t tail0 = head + (nvec << 4);
+        auto byte_at = [&](uint32_t b) -> uint8_t { return (uint8_t)(get_word<G>(w, b >> 2) >> (24u - 8u * (b & 3u))); };
+        if (tid < head) dst[tid] = byte_at(tid);
+        if (tid >= 32 && tid - 32 < T - tail0) dst[tail0 + tid - 32] = byte_at(tail0 + tid - 32);
+        const uint32_t r8 = 8u * (head & 3u);
+        for (uint32_t v = tid; v < nvec; v += NT) {
+            const uint32_t q = (head + (v << 4)) >> 2;
+            uint32_t x[5];
+#pragma unroll
+            for (int k = 0; k < 5; k++) x[k] = get_word<G>(w, q + k);   /* q + 4 <= nwords - 1 */
+            uint4 o;
+            if (r8 == 0) { o.x = x[0]; o.y = x[1]; o.z = x[2]; o.w = x[3]; }
+            else {
+                o.x = (x[0] << r8) | (x[1] >> (32u - r8)); o.y = (x[1] << r8) | (x[2] >> (32u - r8));
+                o.z = (x[2] << r8) | (x[3] >> (32u - r8)); o.w = (x[3] << r8) | (x[4] >> (32u - r8));
+            }
+            o.x = __builtin_bswap32(o.x); o.y = __builtin_bswap32(o.y); o.z = __builtin_bswap32(o.z); o.w = __builtin_bswap32(o.w);
+            *reinterpret_cast<uint4 *>(dst + head + (v << 4)) = o;
+        }
+    }
+}
+
 __global__ __launch_bounds__(NT) void srla_pack_blocks(
     SrlaJobParams jp, const int32_t *__restrict__ input, const SrlaItemDesc *__restrict__ items,
     const SrlaBlockRecord *__restrict__ blocks, const SrlaItemResult *__restrict__ results,
-    const int32_t *__restrict__ res_ws, uint8_t *__restrict__ packed, SrlaChanRecord *__restrict__ chan_out,
-    uint32_t lds_words)
+    const int32_t *__restrict__ res_ws, const uint32_t *__restrict__ huff_code, const uint8_t *__restrict__ huff_len,
+    const uint32_t *__restrict__ block_off, const uint32_t *__restrict__ ctl, uint8_t *__restrict__ out,
+    uint8_t *__restrict__ scratch, SrlaJobInfo *__restrict__ info, uint32_t lds_words)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    uint32_t *words = (uint32_t *)lds;                       /* lds_words entries */
-    uint32_t *scan = words + lds_words;                      /* NWAVES + 1 entries */
-    const uint32_t slot = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const SrlaBlockRecord rec = blocks[slot];
-    if (!rec.valid) return;
-    const uint32_t nch = jp.num_channels, bytes_ps = jp.bits_per_sample >> 3, n = rec.n;
-    uint8_t *region = packed + (size_t)rec.sample_off * nch * bytes_ps + (size_t)slot * SRLA_PACK_SLACK;
-
-    if (rec.block_type == SRLA_BLOCK_RAW) {
-        /* interleaved, zig-zag mapped, big endian (srla_encoder.c:823-852); one channel per grid row */
-        const int32_t *src = input + (size_t)ch * jp.channel_stride + rec.sample_off;
-        for (uint32_t i = tid; i < n; i += NT) {
-            const uint32_t u = zigzag32(src[i]);
-            uint8_t *q = region + ((size_t)i * nch + ch) * bytes_ps;
-            for (uint32_t b = 0; b < bytes_ps; b++) q[b] = (uint8_t)(u >> (8 * (bytes_ps - 1 - b)));
-        }
-        return;
-    }
-    if (rec.block_type != SRLA_BLOCK_COMPRESS) return;
-
-    const uint32_t item = rec.item[ch];
-    const SrlaItemResult *ir = &results[item];
-    /* scalar fields + taps for the host */
-    {
-        const uint32_t *rs = (const uint32_t *)ir;
-        uint32_t *rd = (uint32_t *)&chan_out[(size_t)slot * nch + ch];
-        for (uint32_t i = tid; i < sizeof(SrlaChanRecord) / 4; i += NT) rd[i] = rs[i];
-    }
-    /* this channel's bitstring starts behind the previous channels', 8-byte aligned */
-    uint32_t byte_off = 0;
-    for (uint32_t c = 0; c < ch; c++) byte_off += ((results[rec.item[c]].res_bits + 63u) >> 6) << 3;
-    const uint32_t total_bits = ir->res_bits, code_type = ir->res_code_type, porder = ir->res_porder;
-    const uint32_t out_words = ((total_bits + 63u) >> 6) << 1;       /* 32-bit words, padded to 8 bytes */
-    uint32_t *dst = (uint32_t *)(region + byte_off);
-    const bool in_lds = out_words <= lds_words;
-    uint32_t *w = in_lds ? words : dst;
-    for (uint32_t i = tid; i < out_words; i += NT) w[i] = 0;
-    __syncthreads();
-    if (!in_lds) __threadfence_block();
-
-    if (code_type == SRLA_CODE_ALLZERO) {
-        if (tid == 0) lds_put_bits(w, 0, SRLA_CODE_ALLZERO, 2);
+    uint32_t *aux = (uint32_t *)lds;                         /* 32 words: wave sums */
+    uint32_t *words = aux + 32;                              /* lds_words entries */
+    const uint32_t slot = blockIdx.x;
+    const SrlaBlockRecord *recp = &blocks[slot];
+    if (!recp->valid || ctl[1]) return;
+    uint8_t *dst = out + (size_t)ctl[0] + block_off[slot];
+    const uint32_t nwords = ((recp->bytes + 3u) >> 2) + 1u;
+    if (nwords <= lds_words) {
+        pack_block_body<false>(jp, recp, input, items, results, res_ws, huff_code, huff_len, words, aux, dst, info);
     } else {
-        const int32_t *res = res_ws + items[item].res_off;
-        const uint32_t plen = n >> porder;
-        const uint32_t per = (n + NT - 1) / NT;                  /* contiguous samples per thread */
-        const uint32_t s0 = tid * per, s1 = (s0 + per < n) ? (s0 + per) : n;
-        /* pass 1: bits this thread will emit */
-        uint32_t mybits = 0;
-        for (uint32_t s = s0; s < s1; s++) {
-            const uint32_t part = s / plen;
-            const uint32_t k = ir->kparam[part];
-            if (s == part * plen) {
-                if (part == 0) mybits += 2u + 10u + 5u;
-                else mybits += zigzag32((int32_t)k - (int32_t)ir->kparam[part - 1]) + 1u;
-            }
-            const uint32_t u = zigzag32(res[s]);
-            if (code_type == SRLA_CODE_RICE) mybits += 1u + k + (u >> k);
-            else {
-                const uint32_t k1pow = 2u << k;
-                mybits += (u < k1pow) ? (k + 2u) : (k + 2u + ((u - k1pow) >> k));
-            }
-        }
-        /* exclusive prefix sum over the workgroup */
-        uint32_t incl = mybits;
-        for (int off = 1; off < WAVE; off <<= 1) { const uint32_t t = __shfl_up(incl, off, WAVE); if (lane >= (uint32_t)off) incl += t; }
-        if (lane == WAVE - 1) scan[wave] = incl;
-        __syncthreads();
-        uint32_t base = incl - mybits;
-        for (uint32_t k = 0; k < wave; k++) base += scan[k];
-        /* pass 2: emit */
-        uint32_t pos = base;
-        for (uint32_t s = s0; s < s1; s++) {
-            const uint32_t part = s / plen;
-            const uint32_t k = ir->kparam[part];
-            if (s == part * plen) {
-                if (part == 0) {
-                    lds_put_bits(w, pos, code_type, 2); pos += 2;
-                    lds_put_bits(w, pos, porder, 10); pos += 10;
-                    lds_put_bits(w, pos, k, 5); pos += 5;
-                } else {
-                    const uint32_t z = zigzag32((int32_t)k - (int32_t)ir->kparam[part - 1]);
-                    pos += z;                                 /* z zeros */
-                    lds_put_bits(w, pos, 1u, 1); pos += 1;
-                }
-            }
-            const uint32_t u = zigzag32(res[s]);
-            if (code_type == SRLA_CODE_RICE) {
-                pos += u >> k;                                /* quotient in unary: zeros */
-                lds_put_bits(w, pos, 1u, 1); pos += 1;
-                if (k) { lds_put_bits(w, pos, u, k); pos += k; }
-            } else {
-                const uint32_t k1 = k + 1u, k1pow = 1u << k1;
-                if (u < k1pow) {
-                    lds_put_bits(w, pos, 1u, 1); pos += 1;    /* (2^k1 | u) in k1 + 1 bits */
-                    lds_put_bits(w, pos, u, k1); pos += k1;
-                } else {
-                    const uint32_t v = u - k1pow;
-                    pos += 1u + (v >> k);
-                    lds_put_bits(w, pos, 1u, 1); pos += 1;
-                    if (k) { lds_put_bits(w, pos, v, k); pos += k; }
-                }
-            }
-        }
-    }
-    __syncthreads();
-    /* to stream byte order (big endian words) */
-    if (in_lds) {
-        for (uint32_t i = tid * 4; i < out_words; i += NT * 4) {
-            uint4 v = make_uint4(words[i], (i + 1 < out_words) ? words[i + 1] : 0, (i + 2 < out_words) ? words[i + 2] : 0,
-                                 (i + 3 < out_words) ? words[i + 3] : 0);
-            v.x = __builtin_bswap32(v.x); v.y = __builtin_bswap32(v.y); v.z = __builtin_bswap32(v.z); v.w = __builtin_bswap32(v.w);
-            if (i + 4 <= out_words && ((reinterpret_cast<uintptr_t>(dst + i) & 15u) == 0)) *reinterpret_cast<uint4 *>(dst + i) = v;
-            else { dst[i] = v.x; if (i + 1 < out_words) dst[i + 1] = v.y; if (i + 2 < out_words) dst[i + 2] = v.z; if (i + 3 < out_words) dst[i + 3] = v.w; }
-        }
-    } else {
-        __threadfence_block();
-        for (uint32_t i = tid; i < out_words; i += NT) dst[i] = __builtin_bswap32(dst[i]);
+        const size_t off = ((size_t)recp->sample_off * jp.num_channels * (jp.bits_per_sample >> 3) + (size_t)slot * SRLA_PACK_SLACK + 3u) & ~(size_t)3u;
+        pack_block_body<true>(jp, recp, input, items, results, res_ws, huff_code, huff_len, (uint32_t *)(scratch + off), aux, dst, info);
     }
 }
 
@@ -1950,27 +2165,43 @@ extern "C" int srla_launch_residual_cost(hipStream_t stream, int rclass, const S
 
 extern "C" int srla_launch_price(hipStream_t stream, const SrlaJobParams *jp, const SrlaWindowDesc *windows,
                                  const SrlaCandDesc *cands, const SrlaItemResult *results,
-                                 SrlaBlockRecord *blocks, uint32_t *cand_bytes)
+                                 SrlaBlockRecord *blocks)
 {
     if (jp->num_windows == 0) return 0;
     hipLaunchKernelGGL(srla_price_windows, dim3(jp->num_windows), dim3(WAVE), 0, stream,
-                       *jp, windows, cands, results, blocks, cand_bytes);
+                       *jp, windows, cands, results, blocks);
     return (hipGetLastError() == hipSuccess) ? 0 : -2;
 }
 
+/* LDS words the pack kernel gets for one block; larger blocks (see srla_pack_needs_scratch) go through global scratch */
+extern "C" uint32_t srla_pack_lds_words(const SrlaJobParams *jp)
+{
+    const uint64_t bytes = 11ull + ((uint64_t)jp->bits_per_sample * jp->max_block * jp->num_channels) / 8;
+    return (uint32_t)std::min<uint64_t>((bytes + 3) / 4 + 1, 24 * 1024);   /* <= 96 KB */
+}
+
+extern "C" int srla_pack_needs_scratch(const SrlaJobParams *jp)
+{
+    const uint64_t bytes = 11ull + ((uint64_t)jp->bits_per_sample * jp->max_block * jp->num_channels) / 8;
+    return ((bytes + 3) / 4 + 1) > 24 * 1024;
+}
+
 extern "C" int srla_launch_pack(hipStream_t stream, const SrlaJobParams *jp, uint32_t num_slots,
-                                const int32_t *input, const SrlaItemDesc *items, const SrlaBlockRecord *blocks,
-                                const SrlaItemResult *results, const int32_t *res_ws, uint8_t *packed,
-                                SrlaChanRecord *chan_out)
+                                const int32_t *input, const SrlaItemDesc *items, const SrlaWindowDesc *windows,
+                                const SrlaBlockRecord *blocks, const SrlaItemResult *results, const int32_t *res_ws,
+                                const uint32_t *huff_code, const uint8_t *huff_len, uint32_t *block_off,
+                                uint32_t *stream_pos, uint32_t *ctl, uint32_t first, uint32_t init_pos, uint32_t absolute,
+                                uint32_t limit, uint8_t *out, uint8_t *scratch, SrlaJobInfo *info, uint32_t *window_bytes)
 {
     if (num_slots == 0) return 0;
-    /* LDS staging for one channel's bitstring: a compress block is always smaller than its raw size */
-    uint64_t bits = (uint64_t)jp->bits_per_sample * jp->max_block * jp->num_channels;
-    uint32_t lds_words = (uint32_t)std::min<uint64_t>((bits + 63) / 64 * 2 + 4, 24 * 1024);   /* <= 96 KB */
-    const uint32_t lds = lds_words * 4 + 64;
+    hipLaunchKernelGGL(srla_block_offsets, dim3(1), dim3(NT), 0, stream, *jp, windows, blocks, results, num_slots, block_off,
+                       stream_pos, ctl, first, init_pos, absolute, limit, info, window_bytes);
+    const uint32_t lds_words = srla_pack_lds_words(jp);
+    const uint32_t lds = (lds_words + 32) * 4;
     SET_LDS_ATTR(srla_pack_blocks);
-    hipLaunchKernelGGL(srla_pack_blocks, dim3(num_slots, jp->num_channels), dim3(NT), lds, stream,
-                       *jp, input, items, blocks, results, res_ws, packed, chan_out, lds_words);
+    hipLaunchKernelGGL(srla_pack_blocks, dim3(num_slots), dim3(NT), lds, stream,
+                       *jp, input, items, blocks, results, res_ws, huff_code, huff_len, block_off, ctl, out, scratch, info,
+                       lds_words);
     return (hipGetLastError() == hipSuccess) ? 0 : -2;
 }
 
