@@ -26,6 +26,7 @@
  * must round exactly like the C90 reference: compiled with -ffp-contract=off and pinned below.
  */
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdint.h>
 #include <float.h>
 #include <algorithm>
@@ -2173,17 +2174,25 @@ extern "C" int srla_launch_price(hipStream_t stream, const SrlaJobParams *jp, co
     return (hipGetLastError() == hipSuccess) ? 0 : -2;
 }
 
-/* LDS words the pack kernel gets for one block; larger blocks (see srla_pack_needs_scratch) go through global scratch */
+/* LDS words the pack kernel gets for one block; larger blocks (see srla_pack_needs_scratch) are assembled in a
+ * global scratch region.  SRLA_MI355X_PACK_LDS_WORDS lowers the cap (tests use it to reach the global path). */
+static uint32_t pack_lds_cap()
+{
+    uint32_t cap = 24 * 1024;                               /* <= 96 KB */
+    if (const char *e = getenv("SRLA_MI355X_PACK_LDS_WORDS")) { const int v = atoi(e); if (v >= 8 && v < (int)cap) cap = (uint32_t)v; }
+    return cap;
+}
+
 extern "C" uint32_t srla_pack_lds_words(const SrlaJobParams *jp)
 {
     const uint64_t bytes = 11ull + ((uint64_t)jp->bits_per_sample * jp->max_block * jp->num_channels) / 8;
-    return (uint32_t)std::min<uint64_t>((bytes + 3) / 4 + 1, 24 * 1024);   /* <= 96 KB */
+    return (uint32_t)std::min<uint64_t>((bytes + 3) / 4 + 1, pack_lds_cap());
 }
 
 extern "C" int srla_pack_needs_scratch(const SrlaJobParams *jp)
 {
     const uint64_t bytes = 11ull + ((uint64_t)jp->bits_per_sample * jp->max_block * jp->num_channels) / 8;
-    return ((bytes + 3) / 4 + 1) > 24 * 1024;
+    return ((bytes + 3) / 4 + 1) > pack_lds_cap();
 }
 
 extern "C" int srla_launch_pack(hipStream_t stream, const SrlaJobParams *jp, uint32_t num_slots,

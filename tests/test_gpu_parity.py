@@ -258,3 +258,58 @@ def test_offset_left_shift_and_small_output_buffer(product):
     rc, _ = product.encode_whole(enc, pcm, cap=2000)
     assert rc == capi.INSUFFICIENT_BUFFER
     product.destroy(enc)
+
+
+# ------------------------------------------------------------- where the device puts the stream ---
+def _encode_into(product, enc, pcm, buf_ptr, cap, callback=None):
+    out = C.c_uint32(0)
+    cb = capi.CALLBACK(callback) if callback is not None else None
+    rc = product.lib.SRLAEncoder_EncodeWhole(enc, capi.planar_ptrs(pcm), pcm.shape[1], C.c_void_p(buf_ptr), cap, C.byref(out),
+                                             C.cast(cb, C.c_void_p) if cb is not None else None)
+    return rc, out.value
+
+
+@pytest.mark.parametrize("misalign", [0, 3, 13])
+def test_pinned_output_is_written_by_the_device(product, misalign):
+    """A pinned (device-visible) output buffer receives every block straight from the pack kernel, at any
+    byte alignment; the result equals the staged path's and the oracle's."""
+    import torch
+    pcm = helpers.synth(helpers.VARIED, 95, 48000, 2, 300000)
+    cli = dict(preset=4, max_block=4096, divisions=2)
+    want = helpers.Oracle(2, **cli).encode_whole(pcm)
+    cfg, par = capi.cli_setup(2, 16, 48000, **cli)
+    enc = product.create(cfg)
+    assert product.set_parameter(enc, par) == capi.OK
+    pinned = torch.full((pcm.size * 4 + 64,), 0xAA, dtype=torch.uint8).pin_memory()
+    view = pinned.numpy()
+    seen = []
+    rc, size = _encode_into(product, enc, pcm, pinned.data_ptr() + misalign, want.size,     # exactly large enough
+                            callback=lambda total, progress, ptr, sz: seen.append((progress, sz)))
+    assert rc == capi.OK and size == want.size
+    assert np.array_equal(view[misalign:misalign + size], want)
+    assert (view[:misalign] == 0xAA).all() and (view[misalign + size:] == 0xAA).all()       # nothing outside the stream
+    assert sum(s[1] for s in seen) == size - 30 and seen[-1][0] == pcm.shape[1]
+    # one byte short: INSUFFICIENT_BUFFER, and the device never stores past the buffer it was given
+    view[:] = 0x55
+    rc, _ = _encode_into(product, enc, pcm, pinned.data_ptr() + misalign, want.size - 1)
+    assert rc == capi.INSUFFICIENT_BUFFER
+    assert (view[misalign + want.size - 1:] == 0x55).all() and (view[:misalign] == 0x55).all()
+    # and the encoder still works afterwards
+    rc, size = _encode_into(product, enc, pcm, pinned.data_ptr(), view.size)
+    assert rc == capi.OK and np.array_equal(view[:size], want)
+    product.destroy(enc)
+
+
+@pytest.mark.parametrize("nch,bps,cli_name,kind", [(8, 24, "m4_B8192_V2_P3", helpers.NOISE), (8, 24, "m4_B8192_V2_P3", helpers.MUSIC),
+                                                    (2, 16, "m4_B4096_V2", helpers.VARIED)])
+def test_blocks_assembled_in_global_scratch(product, nch, bps, cli_name, kind, monkeypatch):
+    """Blocks that do not fit the pack kernel's LDS staging are assembled in a global scratch region: 8-channel
+    24-bit blocks of 8192 samples exceed it on their own; a lowered cap sends ordinary blocks the same way."""
+    cli = CLIS[cli_name]
+    if nch == 2:
+        monkeypatch.setenv("SRLA_MI355X_PACK_LDS_WORDS", "64")
+    n = 8192 * 5 + 4096
+    pcm = helpers.synth(kind, 96, 48000, nch, n, bps)
+    got = product.encode(pcm, bits_per_sample=bps, **cli)
+    want = helpers.Oracle(nch, bits_per_sample=bps, **cli).encode_whole(pcm)
+    assert np.array_equal(got, want)
