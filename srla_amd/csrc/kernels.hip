@@ -60,20 +60,40 @@ __device__ __forceinline__ double round_half_away(double d)
     return (d >= 0.0) ? floor(d + 0.5) : -floor(-d + 0.5);
 }
 
-__device__ __forceinline__ long long wave_sum_i64(long long v)
-{
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, WAVE);
-    return v;
-}
+/* Wave-wide reductions on the DPP path (no LDS traffic): inclusive scan inside each row of 16 lanes
+ * (row_shr 1,2,4,8), then row 0 -> 1 and 2 -> 3 (row_bcast15), then lane 31 -> rows 2,3 (row_bcast31);
+ * lane 63 ends up with the total, which is returned in every lane.  All 64 lanes must be active. */
+#define SRLA_DPP_STEP(T, v, OP, IDENT, CTRL, ROWMASK) \
+    v = OP(v, (T)__builtin_amdgcn_update_dpp((int)(IDENT), (int)(v), CTRL, ROWMASK, 0xf, false))
+__device__ __forceinline__ uint32_t u32_add(uint32_t a, uint32_t b) { return a + b; }
+__device__ __forceinline__ uint32_t u32_max(uint32_t a, uint32_t b) { return (a > b) ? a : b; }
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
 {
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, WAVE);
-    return v;
+    SRLA_DPP_STEP(uint32_t, v, u32_add, 0, 0x111, 0xf); SRLA_DPP_STEP(uint32_t, v, u32_add, 0, 0x112, 0xf);
+    SRLA_DPP_STEP(uint32_t, v, u32_add, 0, 0x114, 0xf); SRLA_DPP_STEP(uint32_t, v, u32_add, 0, 0x118, 0xf);
+    SRLA_DPP_STEP(uint32_t, v, u32_add, 0, 0x142, 0xa); SRLA_DPP_STEP(uint32_t, v, u32_add, 0, 0x143, 0xc);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 {
-    for (int off = 32; off > 0; off >>= 1) { uint32_t o = __shfl_down(v, off, WAVE); v = (o > v) ? o : v; }
-    return v;
+    SRLA_DPP_STEP(uint32_t, v, u32_max, 0, 0x111, 0xf); SRLA_DPP_STEP(uint32_t, v, u32_max, 0, 0x112, 0xf);
+    SRLA_DPP_STEP(uint32_t, v, u32_max, 0, 0x114, 0xf); SRLA_DPP_STEP(uint32_t, v, u32_max, 0, 0x118, 0xf);
+    SRLA_DPP_STEP(uint32_t, v, u32_max, 0, 0x142, 0xa); SRLA_DPP_STEP(uint32_t, v, u32_max, 0, 0x143, 0xc);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ long long wave_sum_i64(long long v)
+{
+#define SRLA_DPP64(CTRL, ROWMASK)                                                                                  \
+    {                                                                                                              \
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, ROWMASK, 0xf, false);  \
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)((unsigned long long)v >> 32), CTRL, ROWMASK, 0xf, false); \
+        v += (long long)(((unsigned long long)hi << 32) | lo);                                                     \
+    }
+    SRLA_DPP64(0x111, 0xf) SRLA_DPP64(0x112, 0xf) SRLA_DPP64(0x114, 0xf) SRLA_DPP64(0x118, 0xf) SRLA_DPP64(0x142, 0xa) SRLA_DPP64(0x143, 0xc)
+#undef SRLA_DPP64
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, 63);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((unsigned long long)v >> 32), 63);
+    return (long long)(((unsigned long long)hi << 32) | lo);
 }
 
 /* what the sample loaders need from the job parameters (kept in registers; the by-value kernel argument
@@ -948,6 +968,7 @@ struct SmallF {
     uint32_t level_bits[16];
     uint8_t  ktab[2048];
     double   wave_mean[NWAVES];
+    double   thr[32];                 /* Rice parameter thresholds (copy of the host table) */
     uint32_t wave_max[NWAVES];
     uint32_t pad[4];
 };
@@ -959,11 +980,15 @@ __device__ __forceinline__ uint32_t sig_index(int s_plus_pad)
     return (uint32_t)(s_plus_pad + (s_plus_pad / S) * 4);
 }
 
-__device__ __forceinline__ uint32_t rice_param(double mean, uint32_t code_type, const double *__restrict__ thr)
+__device__ __forceinline__ uint32_t rice_param(double mean, uint32_t code_type, const double *thr)
 {
     if (code_type == SRLA_CODE_RICE) {
-        uint32_t k = 0;   /* srla_coder.c:262-276 through the host-derived monotone thresholds */
-        for (int t = 0; t < 32; t++) k += (mean >= thr[t]) ? 1u : 0u;
+        /* srla_coder.c:262-276 through the host-derived thresholds: k = #{t : mean >= thr[t]}; thr ascends
+         * (unreachable entries are +inf), so a 5-step bisection plus one compare counts them */
+        uint32_t k = 0;
+#pragma unroll
+        for (uint32_t step = 16; step > 0; step >>= 1) k += (mean >= thr[k + step - 1]) ? step : 0u;
+        k += (k == 31u && mean >= thr[31]) ? 1u : 0u;
         return k;
     }
     const double gp = 0.66794162356 * (1.0 + mean);   /* srla_coder.c:298-311 */
@@ -974,9 +999,26 @@ __device__ __forceinline__ uint32_t rice_param(double mean, uint32_t code_type, 
 __device__ __forceinline__ uint32_t code_cost(uint32_t val, uint32_t k, uint32_t code_type)
 {
     if (code_type == SRLA_CODE_RICE) return 1u + k + (val >> k);                 /* srla_coder.c:327-330 */
-    int32_t over = (int32_t)val - (int32_t)(2u << k);                             /* srla_coder.c:333-347 */
-    over = (over > 0) ? over : 0;
-    return (k + 2u) + ((uint32_t)over >> k);
+    /* srla_coder.c:333-347: k + 2 bits up to 2^(k+1), then one more bit per 2^k */
+    return (k + 2u) + (__builtin_elementwise_sub_sat(val, 2u << k) >> k);
+}
+
+/* the part of code_cost that depends on the sample: sum it, add count * fixed(k) once */
+__device__ __forceinline__ uint32_t code_cost_var(uint32_t val, uint32_t k, uint32_t code_type)
+{
+    return (code_type == SRLA_CODE_RICE) ? (val >> k) : (__builtin_elementwise_sub_sat(val, 2u << k) >> k);
+}
+__device__ __forceinline__ uint32_t code_cost_fixed(uint32_t k, uint32_t code_type)
+{
+    return (code_type == SRLA_CODE_RICE) ? (1u + k) : (k + 2u);
+}
+
+/* acc + a * b on the full-rate 24-bit multiplier (a, b within 24 bits signed) */
+__device__ __forceinline__ uint32_t mad24(int32_t a, int32_t b, uint32_t acc)
+{
+    uint32_t r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(acc));
+    return r;
 }
 
 template <int FL>
@@ -1021,6 +1063,7 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
     for (uint32_t i = tid; i < (uint32_t)(PADS / S) * (S + 4); i += NT) sig[i] = 0;    /* front padding */
     for (uint32_t k = tid; k < o4; k += NT) sm->coefq[k] = (k < o4 - order) ? 0 : (int32_t)out->lpc_coef[k - (o4 - order)];
     if (tid < 16) sm->level_bits[tid] = 0;
+    if (tid >= 32 && tid < 64) sm->thr[tid - 32] = rice_thresholds[tid - 32];
     __syncthreads();
 
     if (period > 0) {
@@ -1063,10 +1106,10 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
             for (int c = 0; c < FL; c++) {
                 const int4 nxt = *reinterpret_cast<const int4 *>(sig + sig_index<FL>(PADS + (int)s_base + 4 * c - (int)o4 + (int)kb + 4));
                 const int w0 = cur[c].x, w1 = cur[c].y, w2 = cur[c].z, w3 = cur[c].w, w4 = nxt.x, w5 = nxt.y, w6 = nxt.z;
-                acc[4 * c + 0] += (uint32_t)(__mul24(cf.x, w0) + __mul24(cf.y, w1) + __mul24(cf.z, w2) + __mul24(cf.w, w3));
-                acc[4 * c + 1] += (uint32_t)(__mul24(cf.x, w1) + __mul24(cf.y, w2) + __mul24(cf.z, w3) + __mul24(cf.w, w4));
-                acc[4 * c + 2] += (uint32_t)(__mul24(cf.x, w2) + __mul24(cf.y, w3) + __mul24(cf.z, w4) + __mul24(cf.w, w5));
-                acc[4 * c + 3] += (uint32_t)(__mul24(cf.x, w3) + __mul24(cf.y, w4) + __mul24(cf.z, w5) + __mul24(cf.w, w6));
+                acc[4 * c + 0] = mad24(cf.w, w3, mad24(cf.z, w2, mad24(cf.y, w1, mad24(cf.x, w0, acc[4 * c + 0]))));
+                acc[4 * c + 1] = mad24(cf.w, w4, mad24(cf.z, w3, mad24(cf.y, w2, mad24(cf.x, w1, acc[4 * c + 1]))));
+                acc[4 * c + 2] = mad24(cf.w, w5, mad24(cf.z, w4, mad24(cf.y, w3, mad24(cf.x, w2, acc[4 * c + 2]))));
+                acc[4 * c + 3] = mad24(cf.w, w6, mad24(cf.z, w5, mad24(cf.y, w4, mad24(cf.x, w3, acc[4 * c + 3]))));
                 cur[c] = nxt;
             }
         }
@@ -1127,11 +1170,11 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
     if (code_type != SRLA_CODE_ALLZERO) {
         uint32_t k10[4], k9[2], kl[9];
 #pragma unroll
-        for (int p = 0; p < 4; p++) k10[p] = rice_param(m10[p], code_type, rice_thresholds);
-        k9[0] = rice_param(m9a, code_type, rice_thresholds);
-        k9[1] = rice_param(m9b, code_type, rice_thresholds);
+        for (int p = 0; p < 4; p++) k10[p] = rice_param(m10[p], code_type, sm->thr);
+        k9[0] = rice_param(m9a, code_type, sm->thr);
+        k9[1] = rice_param(m9b, code_type, sm->thr);
 #pragma unroll
-        for (int l = 0; l <= 8; l++) kl[l] = rice_param(m[l], code_type, rice_thresholds);
+        for (int l = 0; l <= 8; l++) kl[l] = rice_param(m[l], code_type, sm->thr);
         /* publish the table (leaders only), heap layout */
 #pragma unroll
         for (int p = 0; p < 4; p++) sm->ktab[1023 + 4 * tid + p] = (uint8_t)k10[p];
@@ -1180,9 +1223,9 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
             for (int p = 0; p < 4; p++) {
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    uint32_t t = 0;
+                    uint32_t t = (uint32_t)FL * code_cost_fixed(kmin + j, code_type);
 #pragma unroll
-                    for (int i = 0; i < FL; i++) t += code_cost(u[p * FL + i], kmin + j, code_type);
+                    for (int i = 0; i < FL; i++) t += code_cost_var(u[p * FL + i], kmin + j, code_type);
                     T[p][j] = t;
                 }
             }
