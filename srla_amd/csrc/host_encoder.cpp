@@ -195,6 +195,8 @@ struct Job {
     uint32_t num_slots = 0;
     uint64_t res_elems = 0;
     uint64_t analyzed_samples = 0;
+    std::vector<uint32_t> class_index; /* item indices grouped by FFT-size class (srla_autocorr launches per class) */
+    uint32_t class_first[3] = {}, class_count[3] = {};   /* N' <= 2048, 4096, 8192 */
     uint64_t key = 0;                 /* geometry signature: equal keys => identical descriptor tables */
     bool uploaded = false;            /* the slot's device copies match the tables above */
 };
@@ -209,7 +211,7 @@ struct Slot {
     /* where this job's blocks go (set when the job is begun, used by the pack stage) */
     uint8_t *out_direct = nullptr;       /* device-visible caller buffer, or nullptr: stage through h_stream */
     uint32_t out_first = 1, out_init_pos = 0, out_limit = 0xFFFFFFFFu;
-    DevBuf d_input, d_items, d_cands, d_windows, d_results, d_res_ws, d_blocks, d_block_off, d_ctl, d_scratch, d_dbg, d_lags, d_err;
+    DevBuf d_input, d_items, d_cands, d_windows, d_results, d_res_ws, d_blocks, d_block_off, d_ctl, d_scratch, d_dbg, d_lags, d_err, d_class_index;
     PinBuf h_in, h_stream, h_info;       /* h_info: SrlaJobInfo followed by the per-window byte counts */
     Job job;
     bool busy = false;
@@ -257,7 +259,7 @@ struct Impl {
                 for (auto &e : s.t0) if (e) (void)hipEventDestroy(e);
                 for (auto &e : s.t1) if (e) (void)hipEventDestroy(e);
                 DevBuf *db[] = { &s.d_input, &s.d_items, &s.d_cands, &s.d_windows, &s.d_results, &s.d_res_ws,
-                                 &s.d_blocks, &s.d_block_off, &s.d_ctl, &s.d_scratch, &s.d_dbg, &s.d_lags, &s.d_err };
+                                 &s.d_blocks, &s.d_block_off, &s.d_ctl, &s.d_scratch, &s.d_dbg, &s.d_lags, &s.d_err, &s.d_class_index };
                 for (auto *b : db) b->release();
                 PinBuf *pb[] = { &s.h_in, &s.h_stream, &s.h_info };
                 for (auto *b : pb) b->release();
@@ -416,7 +418,7 @@ struct Impl {
         if (job.key == key && job.ns == ns) return;
         job.key = key; job.uploaded = false;
         job.ns = ns;
-        job.windows.clear(); job.cands.clear(); job.items.clear(); job.groups.clear();
+        job.windows.clear(); job.cands.clear(); job.items.clear(); job.groups.clear(); job.class_index.clear();
         job.num_slots = 0; job.res_elems = 0; job.analyzed_samples = 0;
 
         struct Pending { uint32_t cand; uint32_t nfft; };
@@ -479,6 +481,16 @@ struct Impl {
             g.count = (uint32_t)job.items.size();
             job.groups.push_back(g);
         }
+        job.class_index.clear();
+        for (int c = 0; c < 3; c++) {
+            job.class_first[c] = (uint32_t)job.class_index.size();
+            for (uint32_t i = 0; i < job.items.size(); i++) {
+                const uint32_t nfft = geoms[job.items[i].geom].nfft;
+                const int cls = (nfft <= 2048u) ? 0 : ((nfft <= 4096u) ? 1 : 2);
+                if (cls == c) job.class_index.push_back(i);
+            }
+            job.class_count[c] = (uint32_t)job.class_index.size() - job.class_first[c];
+        }
     }
 
     SrlaJobParams job_params(const Job &job, uint32_t channel_stride) const
@@ -523,7 +535,9 @@ struct Impl {
             if (!s.d_items.ensure(std::max<size_t>(1, n_items) * sizeof(SrlaItemDesc))) return false;
             if (!s.d_cands.ensure(n_cands * sizeof(SrlaCandDesc))) return false;
             if (!s.d_windows.ensure(n_win * sizeof(SrlaWindowDesc))) return false;
-            if (pi != s.d_items.p || pc != s.d_cands.p || pw != s.d_windows.p) job.uploaded = false;
+            const void *px = s.d_class_index.p;
+            if (!s.d_class_index.ensure(std::max<size_t>(1, n_items) * 4)) return false;
+            if (pi != s.d_items.p || pc != s.d_cands.p || pw != s.d_windows.p || px != s.d_class_index.p) job.uploaded = false;
         }
         if (!s.d_results.ensure(std::max<size_t>(1, n_items) * sizeof(SrlaItemResult))) return false;
         if (!s.d_res_ws.ensure(std::max<uint64_t>(4, job.res_elems) * 4)) return false;
@@ -557,6 +571,7 @@ struct Impl {
         }
         if (!job.uploaded) {
             if (n_items) HIP_OK(hipMemcpyAsync(s.d_items.p, job.items.data(), n_items * sizeof(SrlaItemDesc), hipMemcpyHostToDevice, W));
+            if (n_items) HIP_OK(hipMemcpyAsync(s.d_class_index.p, job.class_index.data(), n_items * 4, hipMemcpyHostToDevice, W));
             HIP_OK(hipMemcpyAsync(s.d_cands.p, job.cands.data(), n_cands * sizeof(SrlaCandDesc), hipMemcpyHostToDevice, W));
             HIP_OK(hipMemcpyAsync(s.d_windows.p, job.windows.data(), n_win * sizeof(SrlaWindowDesc), hipMemcpyHostToDevice, W));
             job.uploaded = true;
@@ -582,15 +597,14 @@ struct Impl {
             if (lshift_on_device) HIP_OK(hipStreamWaitEvent(W, ev_or, 0));
             HIP_OK(hipEventRecord(s.t0[ST_A], W));
             if (have_items) {
-                const Group &g = job.groups[0];
-                const uint32_t fft_bytes = (8u * g.nfft + 15u) & ~15u;
-                if (par.ltp_order > 0) {
-                    rc |= srla_launch_autocorr(W, g.rclass, &jp, s.in_cur, s.d_items.as<SrlaItemDesc>(), d_geoms.as<SrlaGeom>(), d_tw.p,
-                                               fft_bytes, 1, s.d_results.as<SrlaItemResult>(), s.d_lags.as<double>(), dbg);
-                    rc |= srla_launch_pitch_solve(W, &jp, s.d_lags.as<double>(), s.d_results.as<SrlaItemResult>());
+                static const int kClass[3] = { 1, 2, 4 };
+                for (int pass = (par.ltp_order > 0) ? 1 : 0; pass >= 0; pass--) {
+                    for (int c = 0; c < 3; c++)
+                        rc |= srla_launch_autocorr(W, kClass[c], &jp, s.in_cur, s.d_items.as<SrlaItemDesc>(), d_geoms.as<SrlaGeom>(), d_tw.p,
+                                                   (uint32_t)pass, s.d_results.as<SrlaItemResult>(), s.d_lags.as<double>(), dbg,
+                                                   s.d_class_index.as<uint32_t>() + job.class_first[c], job.class_count[c]);
+                    if (pass == 1) rc |= srla_launch_pitch_solve(W, &jp, s.d_lags.as<double>(), s.d_results.as<SrlaItemResult>());
                 }
-                rc |= srla_launch_autocorr(W, g.rclass, &jp, s.in_cur, s.d_items.as<SrlaItemDesc>(), d_geoms.as<SrlaGeom>(), d_tw.p,
-                                           fft_bytes, 0, s.d_results.as<SrlaItemResult>(), s.d_lags.as<double>(), dbg);
             }
             HIP_OK(hipEventRecord(s.t1[ST_A], W));
             break; }

@@ -96,6 +96,12 @@ __device__ __forceinline__ long long wave_sum_i64(long long v)
     return (long long)(((unsigned long long)hi << 32) | lo);
 }
 
+__device__ __forceinline__ uint32_t xcd_position(uint32_t b, uint32_t count)
+{
+    const uint32_t chunk = (count + 7u) >> 3;
+    return (b & 7u) * chunk + (b >> 3);
+}
+
 /* what the sample loaders need from the job parameters (kept in registers; the by-value kernel argument
  * is never modified) */
 struct InputView {
@@ -158,9 +164,17 @@ __device__ __forceinline__ bool input_aligned(const int32_t *in, const InputView
 /* complex FFT of m points held interleaved in LDS: radix-4 decimation in frequency with the
  * reference's (Stockham) butterfly arithmetic (fft.c:71-136).  Butterfly inputs are staged in
  * registers, so one LDS buffer suffices (two barriers per stage); the stage's twiddle is fetched
- * together with the inputs so its latency overlaps the LDS reads. */
-template <int R>
-__device__ void fft_complex_lds(cplx *x, uint32_t m, int flag, const cplx *__restrict__ tw)
+ * together with the inputs so its latency overlaps the LDS reads.
+ * LDS index padding (cidx): one complex slot after every sixteen, so that the stride-4 and stride-16 stores of the
+ * first two stages spread over the banks.
+ * PRUNE: only the first `need` complex outputs of the transform will be read (the inverse transform feeds a few
+ * dozen lags).  Output k of butterfly (p, q) of the stage with stride s is read by a needed butterfly of a later
+ * stage iff q + s k < need, so butterflies with q >= need are skipped and outputs with s k >= need are neither
+ * multiplied by their twiddle nor stored. */
+__device__ __forceinline__ uint32_t cidx(uint32_t c) { return c + (c >> 4); }
+
+template <int R, bool PRUNE>
+__device__ void fft_complex_lds(cplx *x, uint32_t m, int flag, const cplx *__restrict__ tw, uint32_t need)
 {
     /* tw: per stage (sub-size n) three tables of n/4 entries each: w^p, w^2p, w^3p -- the host builds them with
      * the reference's own products (w2 = w1*w1, w3 = w1*w2, fft.c:95-96), so the values are identical */
@@ -169,35 +183,39 @@ __device__ void fft_complex_lds(cplx *x, uint32_t m, int flag, const cplx *__res
     const uint32_t nb = m >> 2;
     while (n > 2) {
         const uint32_t n1 = n >> 2, n2 = n >> 1, n3 = n1 + n2;
+        /* uniform: which outputs can matter at all */
+        const bool k1 = !PRUNE || s < need, k2 = !PRUNE || 2 * s < need, k3 = !PRUNE || 3 * s < need;
         cplx a[R], b[R], c[R], d[R], w1[R], w2[R], w3[R];
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const uint32_t bf = tid + (uint32_t)r * NT;
-            if (bf < nb) {
-                const uint32_t p = bf >> log2s, q = bf & (s - 1);
-                w1[r] = tw[p]; w2[r] = tw[n1 + p]; w3[r] = tw[2 * n1 + p];
-                a[r] = x[q + s * p];
-                b[r] = x[q + s * (p + n1)];
-                c[r] = x[q + s * (p + n2)];
-                d[r] = x[q + s * (p + n3)];
+            const uint32_t p = bf >> log2s, q = bf & (s - 1);
+            if (bf < nb && (!PRUNE || q < need)) {
+                if (k1) w1[r] = tw[p];
+                if (k2) w2[r] = tw[n1 + p];
+                if (k3) w3[r] = tw[2 * n1 + p];
+                a[r] = x[cidx(q + s * p)];
+                b[r] = x[cidx(q + s * (p + n1))];
+                c[r] = x[cidx(q + s * (p + n2))];
+                d[r] = x[cidx(q + s * (p + n3))];
             }
         }
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const uint32_t bf = tid + (uint32_t)r * NT;
-            if (bf < nb) {
-                const uint32_t p = bf >> log2s, q = bf & (s - 1);
+            const uint32_t p = bf >> log2s, q = bf & (s - 1);
+            if (bf < nb && (!PRUNE || q < need)) {
                 const cplx apc = c_add(a[r], c[r]), amc = c_sub(a[r], c[r]), bpd = c_add(b[r], d[r]);
                 const cplx bmd = c_sub(b[r], d[r]);
                 /* (0, -flag) * (b - d): the reference evaluates 0*re - (-flag)*im and 0*im + (-flag)*re
                  * (fft.c:57-63, 104); for finite data that is exactly (flag*im, -flag*re) up to the sign of a zero */
                 const cplx jbmd = (flag < 0) ? make_double2(-bmd.y, bmd.x) : make_double2(bmd.y, -bmd.x);
                 const uint32_t o = q + s * (p << 2);
-                x[o] = c_add(apc, bpd);
-                x[o + s] = c_mul(w1[r], c_sub(amc, jbmd));
-                x[o + 2 * s] = c_mul(w2[r], c_sub(apc, bpd));
-                x[o + 3 * s] = c_mul(w3[r], c_add(amc, jbmd));
+                x[cidx(o)] = c_add(apc, bpd);
+                if (k1) x[cidx(o + s)] = c_mul(w1[r], c_sub(amc, jbmd));
+                if (k2) x[cidx(o + 2 * s)] = c_mul(w2[r], c_sub(apc, bpd));
+                if (k3) x[cidx(o + 3 * s)] = c_mul(w3[r], c_add(amc, jbmd));
             }
         }
         __syncthreads();
@@ -211,13 +229,16 @@ __device__ void fft_complex_lds(cplx *x, uint32_t m, int flag, const cplx *__res
 #pragma unroll
         for (int r = 0; r < 2 * R; r++) {
             const uint32_t q = tid + (uint32_t)r * NT;
-            if (q < s) { a[r] = x[q]; b[r] = x[q + s]; }
+            if (q < s && (!PRUNE || q < need)) { a[r] = x[cidx(q)]; b[r] = x[cidx(q + s)]; }
         }
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < 2 * R; r++) {
             const uint32_t q = tid + (uint32_t)r * NT;
-            if (q < s) { x[q] = c_add(a[r], b[r]); x[q + s] = c_sub(a[r], b[r]); }
+            if (q < s && (!PRUNE || q < need)) {
+                x[cidx(q)] = c_add(a[r], b[r]);
+                if (!PRUNE || q + s < need) x[cidx(q + s)] = c_sub(a[r], b[r]);
+            }
         }
         __syncthreads();
     }
@@ -230,42 +251,68 @@ __device__ __forceinline__ uint32_t complex_table_len(uint32_t m)
     return t;
 }
 
-/* spectral symmetry pass of the real FFT (fft.c:164-183); rtw[i-1] = (wr, wi) for pair i.
- * POWER: fuse the forward pass with the power spectrum (lpc.c:357-365) for the pair it just produced. */
-template <bool POWER>
-__device__ void real_fft_pairs(double *x, uint32_t nfft, int flag, const cplx *__restrict__ rtw)
+/* Between the two transforms, one pass over the spectrum: the symmetry pass of the forward real FFT
+ * (fft.c:164-183) for the pair (i, N/2 - i), the power spectrum of both bins (lpc.c:357-365), and the
+ * symmetry pass of the inverse real FFT on the result -- the same thread owns the same pair in all three,
+ * so nothing goes back to LDS in between.  rtw_fwd / rtw_inv [i-1] = (wr, wi) for pair i. */
+__device__ void spectrum_power_pass(cplx *x, uint32_t nfft, const cplx *__restrict__ rtw_fwd, const cplx *__restrict__ rtw_inv)
 {
-    const double c2 = flag * 0.5;
-    const uint32_t quarter = nfft >> 2;
+    const uint32_t quarter = nfft >> 2, m = nfft >> 1;
+    if (threadIdx.x == 0) {
+        /* DC / Nyquist bin: x0 = re + im, x1 = re - im, squared (fft.c:187-191, lpc.c:358-359); then the inverse's
+         * 0.5 (x0 + x1), 0.5 (x0 - x1) */
+        const cplx z = x[0];
+        const double a = z.x + z.y, b = z.x - z.y;
+        const double pa = a * a, pb = b * b;
+        x[0] = make_double2(0.5 * (pa + pb), 0.5 * (pa - pb));
+    }
     for (uint32_t i = 1 + threadIdx.x; i <= quarter; i += NT) {
-        const uint32_t i1 = i << 1, i2 = i1 + 1, i3 = nfft - i1, i4 = i3 + 1;
-        const cplx w = rtw[i - 1];
-        const double x1 = x[i1], x2 = x[i2], x3 = x[i3], x4 = x[i4];
-        const double wr = w.x, wi = w.y;
-        const double h1r = 0.5 * (x1 + x3);
-        const double h1i = 0.5 * (x2 - x4);
-        const double h2r = -c2 * (x2 + x4);
-        const double h2i = c2 * (x1 - x3);
-        const double y1 = h1r + (wr * h2r) - (wi * h2i);
-        const double y2 = h1i + (wr * h2i) + (wi * h2r);
-        /* for the self-paired middle element the reference's second pair of stores wins */
-        const double y3 = h1r - (wr * h2r) + (wi * h2i);
-        const double y4 = -h1i + (wr * h2i) + (wi * h2r);
-        if (POWER) {
-            if (i1 != i3) { x[i1] = y1 * y1 + y2 * y2; x[i2] = 0.0; }
-            x[i3] = y3 * y3 + y4 * y4; x[i4] = 0.0;
-        } else {
-            if (i1 != i3) { x[i1] = y1; x[i2] = y2; }
-            x[i3] = y3; x[i4] = y4;
+        const bool self = (i == m - i);                       /* the middle bin pairs with itself */
+        const uint32_t ia = cidx(i), ib = cidx(m - i);
+        double p1, p3;
+        {
+            const double c2 = -0.5;                           /* flag = -1 */
+            const cplx w = rtw_fwd[i - 1];
+            const cplx za = x[ia], zb = x[ib];
+            const double x1 = za.x, x2 = za.y, x3 = zb.x, x4 = zb.y;
+            const double wr = w.x, wi = w.y;
+            const double h1r = 0.5 * (x1 + x3);
+            const double h1i = 0.5 * (x2 - x4);
+            const double h2r = -c2 * (x2 + x4);
+            const double h2i = c2 * (x1 - x3);
+            const double y1 = h1r + (wr * h2r) - (wi * h2i);
+            const double y2 = h1i + (wr * h2i) + (wi * h2r);
+            /* for the self-paired middle element the reference's second pair of stores wins */
+            const double y3 = h1r - (wr * h2r) + (wi * h2i);
+            const double y4 = -h1i + (wr * h2i) + (wi * h2r);
+            p1 = y1 * y1 + y2 * y2;
+            p3 = y3 * y3 + y4 * y4;
+            if (self) p1 = p3;
+        }
+        {
+            const double c2 = 0.5;                            /* flag = +1 */
+            const cplx w = rtw_inv[i - 1];
+            const double x1 = p1, x2 = 0.0, x3 = p3, x4 = 0.0;
+            const double wr = w.x, wi = w.y;
+            const double h1r = 0.5 * (x1 + x3);
+            const double h1i = 0.5 * (x2 - x4);
+            const double h2r = -c2 * (x2 + x4);
+            const double h2i = c2 * (x1 - x3);
+            const double y1 = h1r + (wr * h2r) - (wi * h2i);
+            const double y2 = h1i + (wr * h2i) + (wi * h2r);
+            const double y3 = h1r - (wr * h2r) + (wi * h2i);
+            const double y4 = -h1i + (wr * h2i) + (wi * h2r);
+            if (!self) x[ia] = make_double2(y1, y2);
+            x[ib] = make_double2(y3, y4);
         }
     }
     __syncthreads();
 }
 
-/* circular autocorrelation of the (already windowed, zero padded) doubles in buf (lpc.c:330-376):
- * on return buf[i] holds the unscaled lag i */
+/* circular autocorrelation of the (already windowed, zero padded) signal in buf (lpc.c:330-376): on return
+ * complex slot cidx(i/2) component i&1 holds the unscaled lag i, for i < num_lags */
 template <int R>
-__device__ void autocorr_in_place(double *buf, uint32_t nfft, const cplx *__restrict__ twbase)
+__device__ void autocorr_in_place(cplx *buf, uint32_t nfft, const cplx *__restrict__ twbase, uint32_t num_lags)
 {
     const uint32_t m = nfft >> 1;
     const uint32_t ct = complex_table_len(m), quarter = nfft >> 2;
@@ -273,23 +320,9 @@ __device__ void autocorr_in_place(double *buf, uint32_t nfft, const cplx *__rest
     const cplx *tw_inv = twbase + ct;
     const cplx *rtw_fwd = twbase + 2 * ct;
     const cplx *rtw_inv = rtw_fwd + quarter;
-    fft_complex_lds<R>((cplx *)buf, m, -1, tw_fwd);
-    /* DC / Nyquist bin: x0 = re + im, x1 = re - im, then squared (fft.c:187-191, lpc.c:358-359) */
-    if (threadIdx.x == 0) {
-        const double h1r = buf[0], im = buf[1];
-        const double a = h1r + im, b = h1r - im;
-        buf[0] = a * a;
-        buf[1] = b * b;
-    }
-    real_fft_pairs<true>(buf, nfft, -1, rtw_fwd);
-    real_fft_pairs<false>(buf, nfft, 1, rtw_inv);
-    if (threadIdx.x == 0) {
-        const double h1r = buf[0], im = buf[1];
-        buf[0] = 0.5 * (h1r + im);
-        buf[1] = 0.5 * (h1r - im);
-    }
-    __syncthreads();
-    fft_complex_lds<R>((cplx *)buf, m, 1, tw_inv);
+    fft_complex_lds<R, false>(buf, m, -1, tw_fwd, m);
+    spectrum_power_pass(buf, nfft, rtw_fwd, rtw_inv);
+    fft_complex_lds<R, true>(buf, m, 1, tw_inv, (num_lags + 1) >> 1);
 }
 
 /* ------------------------------------------------------------ order choice (H2: libm) ----- */
@@ -331,16 +364,19 @@ template <int R>
 __global__ __launch_bounds__(NT) void srla_autocorr(
     SrlaJobParams jp, const int32_t *__restrict__ input, const SrlaItemDesc *__restrict__ items,
     const SrlaGeom *__restrict__ geoms, const cplx *__restrict__ twiddles, uint32_t fft_bytes, uint32_t pass,
-    SrlaItemResult *__restrict__ results, double *__restrict__ lags_ws, double *__restrict__ dbg)
+    SrlaItemResult *__restrict__ results, double *__restrict__ lags_ws, double *__restrict__ dbg,
+    const uint32_t *__restrict__ item_index, uint32_t count)
 {
     constexpr int CH = 2 * R;   /* chunks of four samples per thread: covers 2048 * R >= nfft */
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const InputView iv = input_view(jp);
-    double *buf = (double *)lds;
+    cplx *buf = (cplx *)lds;
     SmallA *sm = (SmallA *)(lds + fft_bytes);
 
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t item_idx = blockIdx.x;
+    const uint32_t pos = xcd_position(blockIdx.x, count);
+    if (pos >= count) return;
+    const uint32_t item_idx = item_index ? item_index[pos] : pos;   /* items of one FFT-size class */
     const SrlaItemDesc it = items[item_idx];
     const SrlaGeom g = geoms[it.geom];
     const uint32_t n = it.n, nfft = g.nfft, bps = jp.bits_per_sample;
@@ -490,19 +526,21 @@ __global__ __launch_bounds__(NT) void srla_autocorr(
                     }
                     w[i] = val;
                 }
-                *reinterpret_cast<double2 *>(buf + i4) = make_double2(w[0], w[1]);
-                *reinterpret_cast<double2 *>(buf + i4 + 2) = make_double2(w[2], w[3]);
+                const uint32_t cb = cidx(i4 >> 1);          /* i4 / 2 is even: both slots lie in the same group of 16 */
+                buf[cb] = make_double2(w[0], w[1]);
+                buf[cb + 1] = make_double2(w[2], w[3]);
             }
         }
         __syncthreads();
     }
 
-    autocorr_in_place<R>(buf, nfft, twiddles + g.tw_off);
-
     const uint32_t num_lags = (pass == 1) ? SRLA_LTP_LAGS : (jp.max_order + 1);
+    autocorr_in_place<R>(buf, nfft, twiddles + g.tw_off, (num_lags < nfft) ? num_lags : nfft);
+
     const size_t stride = jp.num_items;
     for (uint32_t i = tid; i < num_lags; i += NT) {
-        const double lag = (i < nfft) ? buf[i] * g.acorr_norm : 0.0;
+        double lag = 0.0;
+        if (i < nfft) { const cplx z = buf[cidx(i >> 1)]; lag = ((i & 1u) ? z.y : z.x) * g.acorr_norm; }
         lags_ws[(size_t)i * stride + item_idx] = lag;
         if (dbg) dbg[(size_t)item_idx * SRLA_DBG_STRIDE + ((pass == 1) ? SRLA_DBG_LTPLAGS : SRLA_DBG_LAGS) + i] = lag;
     }
@@ -2117,16 +2155,20 @@ __global__ void srla_mask_to_shift(uint32_t *__restrict__ out)
 
 extern "C" int srla_launch_autocorr(hipStream_t stream, int rclass, const SrlaJobParams *jp, const int32_t *input,
                                     const SrlaItemDesc *items, const SrlaGeom *geoms, const void *twiddles,
-                                    uint32_t fft_bytes, uint32_t pass, SrlaItemResult *results, double *lags_ws, double *dbg)
+                                    uint32_t pass, SrlaItemResult *results, double *lags_ws, double *dbg,
+                                    const uint32_t *item_index, uint32_t count)
 {
-    if (jp->num_items == 0) return 0;
+    if (count == 0) return 0;
+    /* rclass = largest FFT size of the launch / 2048.  LDS: nfft / 2 complex slots plus one pad slot per sixteen */
+    const uint32_t nfft = 2048u * (uint32_t)rclass, m = nfft >> 1;
+    const uint32_t fft_bytes = ((m + (m >> 4) + 2) * 16u + 15u) & ~15u;
     const uint32_t lds = fft_bytes + srla_kernel_small_a_bytes();
-    dim3 grid(jp->num_items), block(NT);
+    dim3 grid(8u * ((count + 7u) >> 3)), block(NT);
 #define LAUNCH(RR)                                                                                           \
     do {                                                                                                     \
         SET_LDS_ATTR(srla_autocorr<RR>);                                                                     \
         hipLaunchKernelGGL(srla_autocorr<RR>, grid, block, lds, stream, *jp, input, items, geoms,            \
-                           (const cplx *)twiddles, fft_bytes, pass, results, lags_ws, dbg);                  \
+                           (const cplx *)twiddles, fft_bytes, pass, results, lags_ws, dbg, item_index, count); \
     } while (0)
     switch (rclass) {
     case 1: LAUNCH(1); break;
