@@ -42,7 +42,7 @@ class Stats(C.Structure):
                 ("analyze_ms", C.c_double), ("price_ms", C.c_double), ("gather_ms", C.c_double),
                 ("h2d_ms", C.c_double), ("d2h_ms", C.c_double), ("pack_ms", C.c_double), ("total_ms", C.c_double),
                 ("analyzed_samples", C.c_uint64), ("autocorr_ms", C.c_double), ("solve_ms", C.c_double),
-                ("residual_ms", C.c_double)]
+                ("residual_ms", C.c_double), ("timed_jobs", C.c_uint64)]
 
 
 def usable_cpus():
@@ -202,14 +202,15 @@ def main():
         total_instants = float(n) * args.steps * world
         value = total_instants / elapsed / 1e6
         launches = max(1, st.analyze_launches)          # one launch of each analysis kernel per job
-        # dominant kernel = the analysis kernel with the largest total time (HIP events around each launch,
-        # recorded on the stream the kernel runs on, inside the timed region)
-        kernels = {"srla_autocorr": st.autocorr_ms, "srla_lpc_recursion+order_select+quantize": st.solve_ms,
-                   "srla_residual_cost": st.residual_ms}
-        # the solve entry is a chain of three kernels (each shorter than the other two entries): the roofline line
-        # is about ONE kernel, so the choice is between the two wide ones
-        dominant = max(("srla_autocorr", "srla_residual_cost"), key=kernels.get)
-        avg_launch_ms = kernels[dominant] / launches
+        # HIP events recorded by the library on the stream each kernel runs on, inside the timed region
+        # the roofline line is about ONE kernel: srla_residual_cost, the longest single launch of a job
+        # srla_residual_cost is timed on every job, the other stages on one job in four (each start event costs
+        # stream time); srla_autocorr is two launches per job (one per FFT-size class)
+        timed = max(1, st.timed_jobs)
+        per_job = {"srla_autocorr": st.autocorr_ms / timed, "srla_lpc_recursion+order_select+quantize": st.solve_ms / timed,
+                   "srla_residual_cost": st.residual_ms / launches}
+        dominant = "srla_residual_cost"
+        avg_launch_ms = per_job[dominant]
         instants_per_launch = float(n) * args.steps / launches
         algo_bytes = 16.0 * instants_per_launch            # 8 B per channel-sample, stereo
         achieved = algo_bytes / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
@@ -235,13 +236,13 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(achieved / 8000.0, 6), "traffic": traffic,
                          "kernel": dominant, "avg_launch_ms": round(avg_launch_ms, 4),
-                         "per_kernel_avg_launch_ms": {k: round(v / launches, 4) for k, v in kernels.items()},
+                         "per_job_stage_ms": {k: round(v, 4) for k, v in per_job.items()},
                          "launches": int(st.analyze_launches), "algorithmic_bytes_per_launch": int(algo_bytes),
-                         "items_per_s_M": round(st.num_items / (st.analyze_ms * 1e-3) / 1e6, 3) if st.analyze_ms > 0 else None},
-            "phase_ms_per_step": {"analyze": round(st.analyze_ms / args.steps, 3),
-                                  "analyze_autocorr": round(st.autocorr_ms / args.steps, 3), "analyze_solve": round(st.solve_ms / args.steps, 3),
-                                  "analyze_residual_cost": round(st.residual_ms / args.steps, 3), "price": round(st.price_ms / args.steps, 3),
-                                  "pack_blocks": round(st.gather_ms / args.steps, 3),
+                         "items_per_launch": int(st.num_items / launches)},
+            "phase_ms_per_step": {"autocorr": round(st.autocorr_ms / timed * launches / args.steps, 3),
+                                  "solve": round(st.solve_ms / timed * launches / args.steps, 3),
+                                  "residual_cost": round(st.residual_ms / args.steps, 3), "price": round(st.price_ms / timed * launches / args.steps, 3),
+                                  "pack_blocks": round(st.gather_ms / timed * launches / args.steps, 3),
                                   "enqueue_host": round(st.h2d_ms / args.steps, 3), "collect_host": round(st.pack_ms / args.steps, 3), "total_host": round(st.total_ms / args.steps, 3)},
             "host_cores": os.cpu_count(), "host_cpu_quota": usable_cpus(), "host_pack_threads": pack_threads, "numa_local_cpus": numa_cpus,
             "tie_items": int(st.num_tie_items),

@@ -153,18 +153,19 @@ struct SRLAMI355XStats {
     uint64_t num_silent_blocks;
     uint64_t num_tie_items;      /* chosen items whose order choice was within libm tolerance */
     uint64_t num_odd_items;      /* chosen items with an odd block length                */
-    uint64_t analyze_launches;
-    double   analyze_ms;         /* HIP-event time of the item-analysis kernels of all jobs */
-    double   price_ms;
-    double   gather_ms;          /* srla_pack_blocks: device-side residual coding of the chosen blocks */
-    double   h2d_ms;
-    double   d2h_ms;
-    double   pack_ms;            /* host wall time in the bit-packer                     */
+    uint64_t analyze_launches;   /* jobs enqueued (one launch of srla_residual_cost each)  */
+    double   analyze_ms;         /* autocorr_ms + solve_ms + residual_ms                   */
+    double   price_ms;           /* srla_price_windows (timed jobs only)                   */
+    double   gather_ms;          /* srla_block_offsets + srla_pack_blocks (timed jobs only) */
+    double   h2d_ms;             /* host wall time spent enqueueing                        */
+    double   d2h_ms;             /* unused (no copies on the data path)                    */
+    double   pack_ms;            /* host wall time collecting finished jobs                */
     double   total_ms;           /* host wall time inside Encode*                        */
     uint64_t analyzed_samples;   /* sum of item lengths                                  */
-    double   autocorr_ms;        /* srla_autocorr (+ srla_pitch_solve) share of analyze_ms */
-    double   solve_ms;           /* srla_lpc_solve                                        */
-    double   residual_ms;        /* srla_residual_cost                                    */
+    double   autocorr_ms;        /* srla_autocorr launches (+ srla_pitch_solve), timed jobs only */
+    double   solve_ms;           /* recursion + order selection + quantiser, timed jobs only  */
+    double   residual_ms;        /* srla_residual_cost, HIP events around the launch, every job */
+    uint64_t timed_jobs;         /* jobs on which every stage was timed (one in four); residual_ms covers all jobs */
 };
 /* cumulative since Create or the last reset */
 void SRLAMI355X_GetStats(struct SRLAEncoder *encoder, struct SRLAMI355XStats *stats, int reset);

@@ -208,6 +208,7 @@ struct Slot {
     uint32_t stride_cur = 0;
     SrlaJobParams jp{};
     bool want_dbg = false;
+    bool timed = false;                  /* this job records start events for every stage (one job in four) */
     /* where this job's blocks go (set when the job is begun, used by the pack stage) */
     uint8_t *out_direct = nullptr;       /* device-visible caller buffer, or nullptr: stage through h_stream */
     uint32_t out_first = 1, out_init_pos = 0, out_limit = 0xFFFFFFFFu;
@@ -239,6 +240,7 @@ struct Impl {
     uint64_t job_samples = 2ull << 20; /* samples per job (SRLA_MI355X_JOB_SAMPLES) */
     Slot slot[kMaxSlots];
     DevBuf d_tw, d_geoms, d_thr, d_huff, d_huffcode, d_pos, d_or;
+    bool timing = true;               /* stage timing events (SRLA_MI355X_NO_TIMING drops them) */
     bool force_staging = false;       /* SRLA_MI355X_STAGING: never write the caller's buffer from the device */
     std::map<uint32_t, uint32_t> tw_index;   /* nfft -> offset (double2) */
     std::vector<double> tw_host;
@@ -324,6 +326,7 @@ struct Impl {
         if (!d_pos.ensure(64)) return false;
         HIP_OK(hipMemset(d_pos.p, 0, 64));
         force_staging = getenv("SRLA_MI355X_STAGING") != nullptr;
+        timing = getenv("SRLA_MI355X_NO_TIMING") == nullptr;
         if (!d_or.ensure(64)) return false;
         unsigned hw = std::thread::hardware_concurrency();
         /* a container's CPU quota (cgroup v2 cpu.max = "<quota> <period>") bounds the useful thread count */
@@ -595,7 +598,7 @@ struct Impl {
         switch (st) {
         case ST_A: {
             if (lshift_on_device) HIP_OK(hipStreamWaitEvent(W, ev_or, 0));
-            HIP_OK(hipEventRecord(s.t0[ST_A], W));
+            if (s.timed) HIP_OK(hipEventRecord(s.t0[ST_A], W));
             if (have_items) {
                 static const int kClass[3] = { 1, 2, 4 };
                 for (int pass = (par.ltp_order > 0) ? 1 : 0; pass >= 0; pass--) {
@@ -610,7 +613,7 @@ struct Impl {
             break; }
         case ST_B:
             HIP_OK(hipStreamWaitEvent(N, s.t1[ST_A], 0));
-            HIP_OK(hipEventRecord(s.t0[ST_B], N));
+            if (s.timed) HIP_OK(hipEventRecord(s.t0[ST_B], N));
             if (have_items && jp.max_order > 0)
                 rc |= srla_launch_lpc_solve(N, &jp, s.d_items.as<SrlaItemDesc>(), d_geoms.as<SrlaGeom>(), s.d_lags.as<double>(),
                                             s.d_err.as<double>(), d_huff.as<uint8_t>(), s.d_results.as<SrlaItemResult>(), dbg);
@@ -618,7 +621,7 @@ struct Impl {
             break;
         case ST_C:
             HIP_OK(hipStreamWaitEvent(W, s.t1[ST_B], 0));
-            HIP_OK(hipEventRecord(s.t0[ST_C], W));
+            if (timing) HIP_OK(hipEventRecord(s.t0[ST_C], W));   /* the roofline kernel: timed on every job */
             if (have_items) {
                 const Group &g = job.groups[0];
                 rc |= srla_launch_residual_cost(W, g.rclass, &jp, s.in_cur, s.d_items.as<SrlaItemDesc>(), d_geoms.as<SrlaGeom>(), &g.plan,
@@ -628,7 +631,7 @@ struct Impl {
             break;
         case ST_D:
             HIP_OK(hipStreamWaitEvent(N, s.t1[ST_C], 0));
-            HIP_OK(hipEventRecord(s.t0[ST_D], N));
+            if (s.timed) HIP_OK(hipEventRecord(s.t0[ST_D], N));
             rc |= srla_launch_price(N, &jp, s.d_windows.as<SrlaWindowDesc>(), s.d_cands.as<SrlaCandDesc>(),
                                     s.d_results.as<SrlaItemResult>(), s.d_blocks.as<SrlaBlockRecord>());
             HIP_OK(hipEventRecord(s.t1[ST_D], N));
@@ -637,7 +640,7 @@ struct Impl {
             /* block offsets + complete blocks, written where the stream wants them (the caller's pinned buffer,
              * or this slot's pinned staging buffer); runs on its own stream and leaves W to autocorr / residual_cost */
             HIP_OK(hipStreamWaitEvent(C, s.t1[ST_D], 0));
-            HIP_OK(hipEventRecord(s.t0[ST_E], C));
+            if (s.timed) HIP_OK(hipEventRecord(s.t0[ST_E], C));
             rc |= srla_launch_pack(C, &jp, job.num_slots, s.in_cur, s.d_items.as<SrlaItemDesc>(), s.d_windows.as<SrlaWindowDesc>(),
                                    s.d_blocks.as<SrlaBlockRecord>(), s.d_results.as<SrlaItemResult>(), s.d_res_ws.as<int32_t>(),
                                    d_huffcode.as<uint32_t>(), d_huff.as<uint8_t>(), s.d_block_off.as<uint32_t>(),
@@ -667,7 +670,8 @@ struct Impl {
         float t = 0;
         double *acc[NUM_ST] = { &stats.autocorr_ms, &stats.solve_ms, &stats.residual_ms, &stats.price_ms, &stats.gather_ms };
         for (int st = 0; st < NUM_ST; st++)
-            if (hipEventElapsedTime(&t, s.t0[st], s.t1[st]) == hipSuccess) *acc[st] += t;
+            if ((s.timed || (timing && st == ST_C)) && hipEventElapsedTime(&t, s.t0[st], s.t1[st]) == hipSuccess) *acc[st] += t;
+        if (s.timed) stats.timed_jobs++;
         stats.analyze_ms = stats.autocorr_ms + stats.solve_ms + stats.residual_ms;
         s.busy = false;
         return true;
@@ -789,6 +793,7 @@ struct Impl {
             const uint32_t ns = (uint32_t)std::min<uint64_t>(job_len, num_samples - s0);
             build_job(s.job, s0, ns, search);
             s.out_direct = out_direct; s.out_first = (k == 0); s.out_init_pos = init_pos; s.out_limit = data_size;
+            s.timed = timing && (k % 4 == 0);
             return prepare_job(s, d_in ? d_in + s0 : nullptr, d_stride, host_in, false);
         };
         /* Software pipeline over jobs: iteration t enqueues  autocorr + solve of job t,  residual_cost +
@@ -976,7 +981,7 @@ static SRLAApiResult single_window(Impl *im, const int32_t *const *input, uint32
     /* ComputeBlockSize: run the job, read the block record, skip the pack */
     Slot &s = im->slot[0];
     im->build_job(s.job, 0, num_samples, false);
-    s.out_direct = nullptr; s.out_first = 1; s.out_init_pos = 0; s.out_limit = 0xFFFFFFFFu;
+    s.out_direct = nullptr; s.out_first = 1; s.out_init_pos = 0; s.out_limit = 0xFFFFFFFFu; s.timed = im->timing;
     if (!im->launch_job(s, nullptr, 0, input, false) || !im->wait_job(s)) return SRLA_APIRESULT_NG;
     const SrlaJobInfo *info = s.h_info.as<SrlaJobInfo>();
     if (info->error != 0 || info->num_blocks != 1) return SRLA_APIRESULT_NG;
@@ -1076,7 +1081,7 @@ SRLAApiResult SRLAMI355X_ProbeBlock(struct SRLAEncoder *encoder, const int32_t *
     if (!im->init_device()) return SRLA_APIRESULT_NG;
     Slot &s = im->slot[0];
     im->build_job(s.job, 0, num_samples, false);
-    s.out_direct = nullptr; s.out_first = 1; s.out_init_pos = 0; s.out_limit = 0xFFFFFFFFu;
+    s.out_direct = nullptr; s.out_first = 1; s.out_init_pos = 0; s.out_limit = 0xFFFFFFFFu; s.timed = im->timing;
     if (!im->launch_job(s, nullptr, 0, input, true) || !im->wait_job(s)) return SRLA_APIRESULT_NG;
     const uint32_t nv = im->num_variants();
     if (records && hipMemcpy(records, s.d_results.p, (size_t)nv * sizeof(SrlaItemResult), hipMemcpyDeviceToHost) != hipSuccess)
