@@ -247,6 +247,18 @@ def main():
             "host_cores": os.cpu_count(), "host_cpu_quota": usable_cpus(), "host_pack_threads": pack_threads, "numa_local_cpus": numa_cpus,
             "tie_items": int(st.num_tie_items),
         }
+        # PCIe-inclusive rate of the reference's own entry point (pageable host planes in, same output buffer), best of 3
+        # calls outside the timed region; reported beside `value`, never as `value`
+        host_t = []
+        for _ in range(3):
+            t1 = time.perf_counter()
+            rc = lib.lib.SRLAEncoder_EncodeWhole(enc, capi.planar_ptrs(pcm), n, out.ctypes.data_as(C.c_void_p), cap, C.byref(out_size), None)
+            host_t.append(time.perf_counter() - t1)
+            if rc != capi.OK:
+                raise SystemExit("SRLAEncoder_EncodeWhole -> %d" % rc)
+        line["host_input"] = {"value": round(n / min(host_t) / 1e6, 3), "unit": "Msamples/s", "ms_per_call": round(1e3 * min(host_t), 3),
+                              "same_bytes": bool(np.array_equal(out[:out_size.value], stream)),
+                              "note": "SRLAEncoder_EncodeWhole, pageable int32 planes in host memory: host OR pass + staged H2D + the same device pipeline"}
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(pcm, cli, args.cpu_seconds, rate)
             line["speedup_vs_cpu_1core"] = round(value / line["cpu_baseline"]["value"], 2)

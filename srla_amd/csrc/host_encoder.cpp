@@ -203,7 +203,8 @@ struct Job {
 
 struct Slot {
     hipStream_t stream = nullptr;
-    hipEvent_t t0[6] = {}, t1[6] = {};   /* start / end of the six stages of the job (see Impl::run_stage) */
+    hipEvent_t t0[6] = {}, t1[6] = {};   /* start / end of the stages of the job (see Impl::run_stage) */
+    hipEvent_t ev_in = nullptr;          /* the job's samples have arrived in d_input (host-input calls) */
     const int32_t *in_cur = nullptr;     /* device input of the current job */
     uint32_t stride_cur = 0;
     SrlaJobParams jp{};
@@ -233,6 +234,7 @@ struct Impl {
     static constexpr uint32_t kMaxSlots = 8;
     static constexpr uint32_t kStreams = 3;   /* more streams than HW queues serialise badly (measured) */
     hipStream_t streams[kStreams] = {};
+    hipStream_t upload = nullptr;      /* H2D of host-input jobs: a DMA queue of its own, so uploads never wait behind kernels */
     hipEvent_t ev_or = nullptr;       /* offset-shift reduction done */
     bool lshift_on_device = false;
     PinBuf h_or;
@@ -241,6 +243,7 @@ struct Impl {
     Slot slot[kMaxSlots];
     DevBuf d_tw, d_geoms, d_thr, d_huff, d_huffcode, d_pos, d_or;
     bool timing = true;               /* stage timing events (SRLA_MI355X_NO_TIMING drops them) */
+    bool in_pinned = false;           /* this call's input planes are pinned host memory */
     bool force_staging = false;       /* SRLA_MI355X_STAGING: never write the caller's buffer from the device */
     std::map<uint32_t, uint32_t> tw_index;   /* nfft -> offset (double2) */
     std::vector<double> tw_host;
@@ -260,6 +263,7 @@ struct Impl {
                 for (auto &st : streams) if (st) (void)hipStreamSynchronize(st);
                 for (auto &e : s.t0) if (e) (void)hipEventDestroy(e);
                 for (auto &e : s.t1) if (e) (void)hipEventDestroy(e);
+                if (s.ev_in) (void)hipEventDestroy(s.ev_in);
                 DevBuf *db[] = { &s.d_input, &s.d_items, &s.d_cands, &s.d_windows, &s.d_results, &s.d_res_ws,
                                  &s.d_blocks, &s.d_block_off, &s.d_ctl, &s.d_scratch, &s.d_dbg, &s.d_lags, &s.d_err, &s.d_class_index };
                 for (auto *b : db) b->release();
@@ -267,6 +271,7 @@ struct Impl {
                 for (auto *b : pb) b->release();
             }
             for (auto &st : streams) if (st) (void)hipStreamDestroy(st);
+            if (upload) (void)hipStreamDestroy(upload);
             if (ev_or) (void)hipEventDestroy(ev_or);
             h_or.release();
             d_tw.release(); d_geoms.release(); d_thr.release(); d_huff.release(); d_huffcode.release(); d_pos.release(); d_or.release();
@@ -301,12 +306,14 @@ struct Impl {
             HIP_OK(hipStreamCreateWithPriority(&streams[2], hipStreamNonBlocking, lo));
         }
         HIP_OK(hipEventCreateWithFlags(&ev_or, hipEventDisableTiming));
+        HIP_OK(hipStreamCreateWithFlags(&upload, hipStreamNonBlocking));
         if (!h_or.ensure(64)) return false;
         for (uint32_t si = 0; si < kSlots; si++) {
             Slot &s = slot[si];
             s.stream = streams[0];
             for (auto &e : s.t0) HIP_OK(hipEventCreate(&e));
             for (auto &e : s.t1) HIP_OK(hipEventCreate(&e));
+            HIP_OK(hipEventCreateWithFlags(&s.ev_in, hipEventDisableTiming));
         }
         double thr[32];
         srla::build_rice_thresholds(thr);
@@ -564,10 +571,24 @@ struct Impl {
         s.stride_cur = d_stride;
         s.used_h2d = false;
         if (!d_in) {
-            if (!s.h_in.ensure((size_t)nch * job.ns * 4) || !s.d_input.ensure((size_t)nch * job.ns * 4)) return false;
-            for (uint32_t ch = 0; ch < nch; ch++)
-                memcpy(s.h_in.as<int32_t>() + (size_t)ch * job.ns, host_in[ch] + job.s0, (size_t)job.ns * 4);
-            HIP_OK(hipMemcpyAsync(s.d_input.p, s.h_in.p, (size_t)nch * job.ns * 4, hipMemcpyHostToDevice, W));
+            if ((!in_pinned && !s.h_in.ensure((size_t)nch * job.ns * 4)) || !s.d_input.ensure((size_t)nch * job.ns * 4)) return false;
+            if (in_pinned) {
+                /* the caller's planes are pinned: DMA straight out of them */
+                for (uint32_t ch = 0; ch < nch; ch++)
+                    HIP_OK(hipMemcpyAsync(s.d_input.as<int32_t>() + (size_t)ch * job.ns, host_in[ch] + job.s0, (size_t)job.ns * 4,
+                                          hipMemcpyHostToDevice, upload));
+            } else {
+                /* pageable -> pinned staging on the pool threads, then one DMA on the upload stream */
+                const uint32_t chunk = 256u << 10, per_ch = (job.ns + chunk - 1) / chunk;
+                int32_t *dst = s.h_in.as<int32_t>();
+                const Job *jb = &job;
+                pool->parallel_for(per_ch * nch, [&](uint32_t i) {
+                    const uint32_t ch = i / per_ch, o = (i % per_ch) * chunk;
+                    memcpy(dst + (size_t)ch * jb->ns + o, host_in[ch] + jb->s0 + o, (size_t)std::min(chunk, jb->ns - o) * 4);
+                });
+                HIP_OK(hipMemcpyAsync(s.d_input.p, s.h_in.p, (size_t)nch * job.ns * 4, hipMemcpyHostToDevice, upload));
+            }
+            HIP_OK(hipEventRecord(s.ev_in, upload));
             s.in_cur = s.d_input.as<int32_t>();
             s.stride_cur = job.ns;
             s.used_h2d = true;
@@ -598,6 +619,7 @@ struct Impl {
         switch (st) {
         case ST_A: {
             if (lshift_on_device) HIP_OK(hipStreamWaitEvent(W, ev_or, 0));
+            if (s.used_h2d) HIP_OK(hipStreamWaitEvent(W, s.ev_in, 0));
             if (s.timed) HIP_OK(hipEventRecord(s.t0[ST_A], W));
             if (have_items) {
                 static const int kClass[3] = { 1, 2, 4 };
@@ -659,6 +681,7 @@ struct Impl {
     /* all stages of one job back to back (single-block calls, probes) */
     bool launch_job(Slot &s, const int32_t *d_in, uint32_t d_stride, const int32_t *const *host_in, bool want_dbg)
     {
+        in_pinned = false;
         if (!prepare_job(s, d_in, d_stride, host_in, want_dbg)) return false;
         for (int st = 0; st < NUM_ST; st++) if (!run_stage(s, st)) return false;
         return true;
@@ -738,16 +761,29 @@ struct Impl {
         const auto t0 = Clock::now();
         const uint32_t nch = par.num_channels;
         uint32_t write_off = 0;
+        in_pinned = false;
+        if (host_in && !force_staging) {
+            in_pinned = true;
+            for (uint32_t ch = 0; ch < nch && in_pinned; ch++) {
+                hipPointerAttribute_t at;
+                memset(&at, 0, sizeof(at));
+                if (hipPointerGetAttributes(&at, host_in[ch]) != hipSuccess || at.type != hipMemoryTypeHost) { in_pinned = false; (void)hipGetLastError(); }
+            }
+        }
         if (with_header) {
             /* offset left shift: OR of every sample (srla_utility.c:177-203) */
             uint32_t mask = 0;
             if (host_in) {
-                for (uint32_t ch = 0; ch < nch; ch++) {
-                    const int32_t *p = host_in[ch];
+                const uint32_t chunk = 1u << 20, per_ch = (num_samples + chunk - 1) / chunk;
+                std::atomic<uint32_t> acc{ 0 };
+                pool->parallel_for(per_ch * nch, [&](uint32_t i) {
+                    const uint32_t ch = i / per_ch, o = (i % per_ch) * chunk, len = std::min(chunk, num_samples - o);
+                    const int32_t *p = host_in[ch] + o;
                     uint32_t m = 0;
-                    for (uint32_t i = 0; i < num_samples; i++) m |= (uint32_t)p[i];
-                    mask |= m;
-                }
+                    for (uint32_t k = 0; k < len; k++) m |= (uint32_t)p[k];
+                    acc.fetch_or(m, std::memory_order_relaxed);
+                });
+                mask = acc.load();
             } else {
                 /* on the device, without a host round trip: the jobs read the shift from device memory */
                 hipStream_t st = streams[0];
@@ -782,6 +818,7 @@ struct Impl {
 
         auto fail = [&](SRLAApiResult rc) {
             for (auto &st : streams) if (st) (void)hipStreamSynchronize(st);
+            if (upload) (void)hipStreamSynchronize(upload);
             for (auto &sl : slot) sl.busy = false;
             lshift_on_device = false;
             return rc;

@@ -313,3 +313,14 @@ def test_blocks_assembled_in_global_scratch(product, nch, bps, cli_name, kind, m
     got = product.encode(pcm, bits_per_sample=bps, **cli)
     want = helpers.Oracle(nch, bits_per_sample=bps, **cli).encode_whole(pcm)
     assert np.array_equal(got, want)
+
+
+def test_pinned_input_planes_are_read_by_dma(product):
+    """Host input in pinned memory is uploaded straight from the caller's planes (no staging copy); same bytes."""
+    import torch
+    pcm = helpers.synth(helpers.VARIED, 97, 48000, 2, 2_500_000)       # more than one job
+    want = product.encode(pcm, **M4)
+    pinned = torch.from_numpy(pcm).pin_memory()
+    got = product.encode(pinned.numpy(), **M4)
+    assert np.array_equal(got, want)
+    assert np.array_equal(helpers.oracle_decode(got), pcm)
