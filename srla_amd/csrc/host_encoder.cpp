@@ -411,7 +411,7 @@ struct Impl {
         p.small_off = off; off += srla_kernel_small_c_bytes();
         p.total = off;
         /* the fast path of the same kernel carves the block differently: make sure it fits too */
-        for (uint32_t fl = 1; fl <= 4 && 1024u * fl <= nfft; fl++) p.total = std::max(p.total, srla_kernel_fast_lds_bytes(fl));
+        for (uint32_t fl = 1; fl <= 8 && 1024u * fl <= nfft; fl++) p.total = std::max(p.total, srla_kernel_fast_lds_bytes(fl));
         return p;
     }
 

@@ -1338,14 +1338,25 @@ __global__ __launch_bounds__(NT) void srla_residual_cost(
         /* blocks of 1024 * FL samples take the register / shuffle fast path */
         const SrlaItemDesc itf = items[blockIdx.x];
         const uint32_t fl = itf.n >> 10;
-        if ((itf.n & 1023u) == 0 && fl >= 1 && fl <= 4 && fl <= (uint32_t)(2 * R) && jp.bits_per_sample <= 18) {
+        if ((itf.n & 1023u) == 0 && fl >= 1 && fl <= 8 && fl <= (uint32_t)(2 * R) && jp.bits_per_sample <= 18) {
             const int32_t *inf = input + itf.sample_off;
             SrlaItemResult *outf = &results[blockIdx.x];
             switch (fl) {
             case 1: residual_cost_fast<1>(jp, iv, inf, itf, lds, rice_thresholds, res_ws, outf); return;
             case 2: residual_cost_fast<2>(jp, iv, inf, itf, lds, rice_thresholds, res_ws, outf); return;
             case 3: residual_cost_fast<3>(jp, iv, inf, itf, lds, rice_thresholds, res_ws, outf); return;
-            default: residual_cost_fast<4>(jp, iv, inf, itf, lds, rice_thresholds, res_ws, outf); return;
+            case 4: residual_cost_fast<4>(jp, iv, inf, itf, lds, rice_thresholds, res_ws, outf); return;
+            default:
+                /* only the 8192-sample class (R = 4) holds these instantiations */
+                if constexpr (R >= 4) {
+                    switch (fl) {
+                    case 5: residual_cost_fast<5>(jp, iv, inf, itf, lds, rice_thresholds, res_ws, outf); return;
+                    case 6: residual_cost_fast<6>(jp, iv, inf, itf, lds, rice_thresholds, res_ws, outf); return;
+                    case 7: residual_cost_fast<7>(jp, iv, inf, itf, lds, rice_thresholds, res_ws, outf); return;
+                    default: residual_cost_fast<8>(jp, iv, inf, itf, lds, rice_thresholds, res_ws, outf); return;
+                    }
+                }
+                return;
             }
         }
     }
