@@ -197,8 +197,8 @@ def main():
 
     if rank == 0:
         # sanity inside the bench: the stream decodes back to the input (oracle decoder = checker only)
-        back = helpers.oracle_decode(stream)
-        lossless = bool((back == pcm).all())
+        diag = bool(os.environ.get("SRLA_MI355X_K3_STOP"))          # kernel timing experiments: no stream is produced
+        lossless = None if diag else bool((helpers.oracle_decode(stream) == pcm).all())
         total_instants = float(n) * args.steps * world
         value = total_instants / elapsed / 1e6
         launches = max(1, st.analyze_launches)          # one launch of each analysis kernel per job
@@ -250,13 +250,14 @@ def main():
         # PCIe-inclusive rate of the reference's own entry point (pageable host planes in, same output buffer), best of 3
         # calls outside the timed region; reported beside `value`, never as `value`
         host_t = []
-        for _ in range(3):
+        for _ in range(0 if diag else 3):
             t1 = time.perf_counter()
             rc = lib.lib.SRLAEncoder_EncodeWhole(enc, capi.planar_ptrs(pcm), n, out.ctypes.data_as(C.c_void_p), cap, C.byref(out_size), None)
             host_t.append(time.perf_counter() - t1)
             if rc != capi.OK:
                 raise SystemExit("SRLAEncoder_EncodeWhole -> %d" % rc)
-        line["host_input"] = {"value": round(n / min(host_t) / 1e6, 3), "unit": "Msamples/s", "ms_per_call": round(1e3 * min(host_t), 3),
+        if host_t:
+            line["host_input"] = {"value": round(n / min(host_t) / 1e6, 3), "unit": "Msamples/s", "ms_per_call": round(1e3 * min(host_t), 3),
                               "same_bytes": bool(np.array_equal(out[:out_size.value], stream)),
                               "note": "SRLAEncoder_EncodeWhole, pageable int32 planes in host memory: host OR pass + staged H2D + the same device pipeline"}
         if not args.no_cpu_baseline:

@@ -519,7 +519,7 @@ struct Impl {
         jp.num_items = (uint32_t)job.items.size();
         jp.num_cands = (uint32_t)job.cands.size();
         jp.num_windows = (uint32_t)job.windows.size();
-        jp.out_stride = job.ns;
+        { static const char *e = getenv("SRLA_MI355X_K3_STOP"); jp.out_stride = e ? (uint32_t)atoi(e) : 0u; }   /* diagnostics */
         jp.lshift_dev = lshift_on_device ? (d_or.as<uint32_t>() + 1) : nullptr;
         return jp;
     }
@@ -706,6 +706,8 @@ struct Impl {
     {
         const auto t0 = Clock::now();
         const SrlaJobInfo info = *s.h_info.as<SrlaJobInfo>();
+        static const bool diag = getenv("SRLA_MI355X_K3_STOP") != nullptr;   /* timing experiments: the stream is garbage */
+        if (diag) { *written = 0; *window_bytes = reinterpret_cast<const uint32_t *>(s.h_info.as<SrlaJobInfo>() + 1); return SRLA_APIRESULT_OK; }
         if (info.error & SRLA_JOBERR_OVERFLOW) return SRLA_APIRESULT_INSUFFICIENT_BUFFER;
         if (info.error != 0 || info.base != write_off) {
             fprintf(stderr, "[srla-mi355x] internal error: device pack reported 0x%x (%s%s), stream offset %u vs %u\n", info.error,

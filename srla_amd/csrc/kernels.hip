@@ -1103,6 +1103,7 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
     if (tid < 16) sm->level_bits[tid] = 0;
     if (tid >= 32 && tid < 64) sm->thr[tid - 32] = rice_thresholds[tid - 32];
     __syncthreads();
+    if (jp.out_stride == 1) { if (y[0] == 0x7fffffff) out->pad[1] = 1; return; }
 
     if (period > 0) {
         /* long-term predictor, srla_lpc_predict.c:267-294 (in place: read everything, barrier, rewrite) */
@@ -1168,6 +1169,7 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
 #pragma unroll
         for (int c = 0; c < FL; c++) *reinterpret_cast<int4 *>(res_out + 4 * c) = make_int4(rr[4 * c], rr[4 * c + 1], rr[4 * c + 2], rr[4 * c + 3]);
     }
+    if (jp.out_stride == 2) { if (max_u == 0x7fffffff) out->pad[1] = 1; return; }
 
     /* partition means: exact integer sums at the finest level, pairwise averages above */
     double m10[4];
@@ -1203,6 +1205,7 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
     if (max_u == 0) code_type = SRLA_CODE_ALLZERO;
     else if (m[0] < 2) code_type = SRLA_CODE_RICE;
     else code_type = SRLA_CODE_RECURSIVE_RICE;
+    if (jp.out_stride == 3) { if (m[0] == 1.2345) out->pad[1] = 1; return; }
 
     uint32_t best_porder = 0, best_bits = 0;
     if (code_type != SRLA_CODE_ALLZERO) {
@@ -1222,6 +1225,7 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
         for (int l = 0; l <= 8; l++)
             if ((tid & ((1u << (8 - l)) - 1u)) == 0) sm->ktab[((1u << l) - 1) + (tid >> (8 - l))] = (uint8_t)kl[l];
         __syncthreads();
+        if (jp.out_stride == 4) { if (kl[0] + k10[3] == 0x7fffffff) out->pad[1] = 1; return; }
         uint32_t acc[11];
         /* side information (srla_coder.c:415-427) booked by the first thread of each partition */
         {
@@ -1245,55 +1249,34 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
                 acc[l] = side;
             }
         }
-        /* All of a thread's parameters usually span <= 4 consecutive values: then the cost of each of its four
-         * fine partitions is tabulated once per candidate k and every level just selects (4x fewer operations
-         * than pricing every sample under every level). */
-        uint32_t kmin = kl[0], kmax = kl[0];
-#pragma unroll
-        for (int l = 1; l <= 8; l++) { kmin = (kl[l] < kmin) ? kl[l] : kmin; kmax = (kl[l] > kmax) ? kl[l] : kmax; }
-#pragma unroll
-        for (int p = 0; p < 2; p++) { kmin = (k9[p] < kmin) ? k9[p] : kmin; kmax = (k9[p] > kmax) ? k9[p] : kmax; }
-#pragma unroll
-        for (int p = 0; p < 4; p++) { kmin = (k10[p] < kmin) ? k10[p] : kmin; kmax = (k10[p] > kmax) ? k10[p] : kmax; }
-        if (kmax - kmin <= 3u) {
-            uint32_t T[4][4];
-#pragma unroll
-            for (int p = 0; p < 4; p++) {
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    uint32_t t = (uint32_t)FL * code_cost_fixed(kmin + j, code_type);
-#pragma unroll
-                    for (int i = 0; i < FL; i++) t += code_cost_var(u[p * FL + i], kmin + j, code_type);
-                    T[p][j] = t;
-                }
-            }
-#define PICK(p, k) (((k) - kmin) == 0u ? T[p][0] : (((k) - kmin) == 1u ? T[p][1] : (((k) - kmin) == 2u ? T[p][2] : T[p][3])))
-            acc[10] += PICK(0, k10[0]) + PICK(1, k10[1]) + PICK(2, k10[2]) + PICK(3, k10[3]);
-            acc[9] += PICK(0, k9[0]) + PICK(1, k9[0]) + PICK(2, k9[1]) + PICK(3, k9[1]);
-            uint32_t Cj[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) Cj[j] = T[0][j] + T[1][j] + T[2][j] + T[3][j];
+        /* Code bits of this thread's samples under every level's parameters.  Levels 0..8 price all of the thread's
+         * samples with one parameter, level 9 each half, level 10 each quarter: 11 evaluations per sample, no tables,
+         * no lane divergence (the variable part is a saturating subtract + shift, srla_coder.c:327-347). */
+        {
+            uint32_t fixed8 = 0;                                  /* sum over levels is not needed: per level below */
+            (void)fixed8;
 #pragma unroll
             for (int l = 0; l <= 8; l++) {
-                const uint32_t d = kl[l] - kmin;
-                acc[l] += (d == 0u) ? Cj[0] : ((d == 1u) ? Cj[1] : ((d == 2u) ? Cj[2] : Cj[3]));
-            }
-#undef PICK
-        } else {
-            /* rare (a thread's parameters span more than four values): price every sample under every level,
-             * rolled loops over the residual just written and the published parameter table */
-            const int32_t *mine = res_ws + it.res_off + s_base;
+                uint32_t t = (uint32_t)S * code_cost_fixed(kl[l], code_type);
 #pragma unroll
-            for (int l = 0; l <= 10; l++) {
-                uint32_t a = 0;
-#pragma unroll 1
-                for (int i = 0; i < S; i++) {
-                    const uint32_t part = (4u * tid + (uint32_t)(i / FL)) >> (10 - l);
-                    a += code_cost(zigzag32(mine[i]), sm->ktab[((1u << l) - 1) + part], code_type);
-                }
-                acc[l] += a;
+                for (int i = 0; i < S; i++) t += code_cost_var(u[i], kl[l], code_type);
+                acc[l] += t;
+            }
+            {
+                uint32_t t = (uint32_t)(2 * FL) * (code_cost_fixed(k9[0], code_type) + code_cost_fixed(k9[1], code_type));
+#pragma unroll
+                for (int i = 0; i < S; i++) t += code_cost_var(u[i], k9[i / (2 * FL)], code_type);
+                acc[9] += t;
+            }
+            {
+                uint32_t t = (uint32_t)FL * (code_cost_fixed(k10[0], code_type) + code_cost_fixed(k10[1], code_type)
+                                             + code_cost_fixed(k10[2], code_type) + code_cost_fixed(k10[3], code_type));
+#pragma unroll
+                for (int i = 0; i < S; i++) t += code_cost_var(u[i], k10[i / FL], code_type);
+                acc[10] += t;
             }
         }
+        if (jp.out_stride == 5) { uint32_t t = 0; for (int l = 0; l <= 10; l++) t += acc[l]; if (t == 0x7fffffff) out->pad[1] = 1; return; }
 #pragma unroll
         for (int l = 0; l <= 10; l++) {
             const uint32_t sum = wave_sum_u32(acc[l]);
