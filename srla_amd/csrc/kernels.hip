@@ -2112,25 +2112,41 @@ __global__ __launch_bounds__(NT) void srla_pack_blocks(
 __global__ __launch_bounds__(NT) void srla_or_reduce(const int32_t *__restrict__ in, size_t channel_stride, size_t count,
                                                      uint32_t *__restrict__ out)
 {
+    /* every workgroup streams ONE contiguous slice of the channel (16 KB per step, four 16-byte loads in flight
+     * per thread): contiguous slices keep DRAM pages and the TLB busy with useful data */
     const int32_t *p = in + (size_t)blockIdx.y * channel_stride;
+    const size_t per = (((count + gridDim.x - 1) / gridDim.x) + (NT * 16 - 1)) / (NT * 16) * (NT * 16);
+    const size_t lo = (size_t)blockIdx.x * per;
+    size_t hi = lo + per;
+    if (hi > count) hi = count;
     uint32_t m = 0;
-    const bool aligned = (reinterpret_cast<uintptr_t>(p) & 15u) == 0;
-    const size_t step = (size_t)gridDim.x * NT * 4;
-    size_t i = ((size_t)blockIdx.x * NT + threadIdx.x) * 4;
-    if (aligned) {
-        /* four independent 16-byte loads in flight per thread */
-        for (; i + 3 * step + 4 <= count; i += 4 * step) {
-            const int4 a = *reinterpret_cast<const int4 *>(p + i);
-            const int4 b = *reinterpret_cast<const int4 *>(p + i + step);
-            const int4 c = *reinterpret_cast<const int4 *>(p + i + 2 * step);
-            const int4 d = *reinterpret_cast<const int4 *>(p + i + 3 * step);
-            m |= (uint32_t)(a.x | a.y | a.z | a.w) | (uint32_t)(b.x | b.y | b.z | b.w) | (uint32_t)(c.x | c.y | c.z | c.w) | (uint32_t)(d.x | d.y | d.z | d.w);
+    if (lo < hi) {
+        const bool aligned = (reinterpret_cast<uintptr_t>(p) & 15u) == 0;
+        size_t i = lo + (size_t)threadIdx.x * 4;
+        if (aligned) {
+            for (; i + 3 * NT * 4 + 4 <= hi; i += 4 * NT * 4) {
+                const int4 a = *reinterpret_cast<const int4 *>(p + i);
+                const int4 b = *reinterpret_cast<const int4 *>(p + i + NT * 4);
+                const int4 c = *reinterpret_cast<const int4 *>(p + i + 2 * NT * 4);
+                const int4 d = *reinterpret_cast<const int4 *>(p + i + 3 * NT * 4);
+                m |= (uint32_t)(a.x | a.y | a.z | a.w) | (uint32_t)(b.x | b.y | b.z | b.w) | (uint32_t)(c.x | c.y | c.z | c.w) | (uint32_t)(d.x | d.y | d.z | d.w);
+            }
         }
+        for (; i < hi; i += NT * 4)
+            for (size_t k = i; k < hi && k < i + 4; k++) m |= (uint32_t)p[k];
     }
-    for (; i < count; i += step)
-        for (size_t k = i; k < count && k < i + 4; k++) m |= (uint32_t)p[k];
+    /* one atomic per workgroup, and only if it would add bits: same-address atomics serialise in L2 (32 K of them
+     * cost more than streaming the 230 MB) */
+    __shared__ uint32_t s_m[NWAVES];
     for (int off = 32; off > 0; off >>= 1) m |= __shfl_down(m, off, WAVE);
-    if ((threadIdx.x & 63) == 0 && m) atomicOr(out, m);
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t all = 0;
+        for (int w = 0; w < NWAVES; w++) all |= s_m[w];
+        const uint32_t seen = __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (all & ~seen) atomicOr(out, all);
+    }
 }
 
 /* out[1] = trailing zero count of out[0] (0 when the stream is all zero) */
