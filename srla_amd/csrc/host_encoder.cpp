@@ -213,7 +213,7 @@ struct Slot {
     /* where this job's blocks go (set when the job is begun, used by the pack stage) */
     uint8_t *out_direct = nullptr;       /* device-visible caller buffer, or nullptr: stage through h_stream */
     uint32_t out_first = 1, out_init_pos = 0, out_limit = 0xFFFFFFFFu;
-    DevBuf d_input, d_items, d_cands, d_windows, d_results, d_res_ws, d_blocks, d_block_off, d_ctl, d_scratch, d_dbg, d_lags, d_err, d_class_index;
+    DevBuf d_input, d_items, d_cands, d_windows, d_results, d_res_ws, d_blocks, d_block_off, d_ctl, d_scratch, d_dbg, d_lags, d_err, d_class_index, d_stream;
     PinBuf h_in, h_stream, h_info;       /* h_info: SrlaJobInfo followed by the per-window byte counts */
     Job job;
     bool busy = false;
@@ -265,7 +265,7 @@ struct Impl {
                 for (auto &e : s.t1) if (e) (void)hipEventDestroy(e);
                 if (s.ev_in) (void)hipEventDestroy(s.ev_in);
                 DevBuf *db[] = { &s.d_input, &s.d_items, &s.d_cands, &s.d_windows, &s.d_results, &s.d_res_ws,
-                                 &s.d_blocks, &s.d_block_off, &s.d_ctl, &s.d_scratch, &s.d_dbg, &s.d_lags, &s.d_err, &s.d_class_index };
+                                 &s.d_blocks, &s.d_block_off, &s.d_ctl, &s.d_scratch, &s.d_dbg, &s.d_lags, &s.d_err, &s.d_class_index, &s.d_stream };
                 for (auto *b : db) b->release();
                 PinBuf *pb[] = { &s.h_in, &s.h_stream, &s.h_info };
                 for (auto *b : pb) b->release();
@@ -563,6 +563,7 @@ struct Impl {
             /* a block is never larger than its raw form (11 + n * nch * bytes): bound of the job's stream bytes */
             const size_t bound = (size_t)job.ns * nch * (par.bits_per_sample / 8) + (size_t)job.num_slots * SRLA_PACK_SLACK + 64;
             if (!s.out_direct && !s.h_stream.ensure(bound)) return false;
+            if (!s.d_stream.ensure(bound + 32)) return false;
             const SrlaJobParams probe = job_params(job, d_stride);
             if (srla_pack_needs_scratch(&probe) && !s.d_scratch.ensure(bound)) return false;
         }
@@ -671,7 +672,7 @@ struct Impl {
                                    s.d_blocks.as<SrlaBlockRecord>(), s.d_results.as<SrlaItemResult>(), s.d_res_ws.as<int32_t>(),
                                    d_huffcode.as<uint32_t>(), d_huff.as<uint8_t>(), s.d_block_off.as<uint32_t>(),
                                    d_pos.as<uint32_t>(), s.d_ctl.as<uint32_t>(), s.out_first, s.out_init_pos,
-                                   s.out_direct ? 1u : 0u, s.out_limit, s.out_direct ? s.out_direct : s.h_stream.as<uint8_t>(),
+                                   s.out_direct ? 1u : 0u, s.out_limit, s.d_stream.as<uint8_t>(), s.out_direct ? s.out_direct : s.h_stream.as<uint8_t>(),
                                    s.d_scratch.as<uint8_t>(), s.h_info.as<SrlaJobInfo>(),
                                    reinterpret_cast<uint32_t *>(s.h_info.as<SrlaJobInfo>() + 1));
             HIP_OK(hipEventRecord(s.t1[ST_E], C));

@@ -43,11 +43,12 @@ int srla_launch_residual_cost(hipStream_t stream, int rclass, const SrlaJobParam
 int srla_launch_price(hipStream_t stream, const SrlaJobParams *jp, const SrlaWindowDesc *windows,
                       const SrlaCandDesc *cands, const SrlaItemResult *results, SrlaBlockRecord *blocks);
 
-/* srla_block_offsets + srla_pack_blocks: the job's blocks, complete, at their byte offsets of the stream.
+/* srla_block_offsets + srla_pack_blocks + srla_stream_out: the job's blocks, complete, assembled in the device
+ * buffer `stage` and then moved to their byte offsets of the stream in host memory `dst`.
  *   stream_pos  device u32[2], running output offset + sticky overflow flag, carried from job to job
  *   first/init_pos  the first job of a stream starts the running offset at init_pos
- *   absolute    1: `out` is the caller's (device-visible) stream buffer and blocks land at running offset + prefix;
- *               0: `out` is a per-job staging buffer and blocks land at their prefix inside the job
+ *   absolute    1: `dst` is the caller's (device-visible) stream buffer and blocks land at running offset + prefix;
+ *               0: `dst` is a per-job pinned staging buffer and blocks land at their prefix inside the job
  *   limit       size of the caller's buffer: a job that would exceed it writes nothing and reports OVERFLOW
  *   info / window_bytes  job summary and per-window sizes (device-visible pinned host memory)            */
 int srla_launch_pack(hipStream_t stream, const SrlaJobParams *jp, uint32_t num_slots,
@@ -55,7 +56,7 @@ int srla_launch_pack(hipStream_t stream, const SrlaJobParams *jp, uint32_t num_s
                      const SrlaBlockRecord *blocks, const SrlaItemResult *results, const int32_t *res_ws,
                      const uint32_t *huff_code, const uint8_t *huff_len, uint32_t *block_off,
                      uint32_t *stream_pos, uint32_t *ctl, uint32_t first, uint32_t init_pos, uint32_t absolute,
-                     uint32_t limit, uint8_t *out, uint8_t *scratch, SrlaJobInfo *info, uint32_t *window_bytes);
+                     uint32_t limit, uint8_t *stage, uint8_t *dst, uint8_t *scratch, SrlaJobInfo *info, uint32_t *window_bytes);
 uint32_t srla_pack_lds_words(const SrlaJobParams *jp);
 int srla_pack_needs_scratch(const SrlaJobParams *jp);   /* blocks may exceed the LDS staging: allocate the scratch */
 

@@ -1766,8 +1766,8 @@ __global__ __launch_bounds__(NT) void srla_block_offsets(
     SrlaJobParams jp, const SrlaWindowDesc *__restrict__ windows, const SrlaBlockRecord *__restrict__ blocks,
     const SrlaItemResult *__restrict__ results, uint32_t num_slots, uint32_t *__restrict__ block_off,
     uint32_t *__restrict__ stream_pos /* [0] running offset, [1] sticky overflow flag */,
-    uint32_t *__restrict__ ctl /* [0] base added to block_off by the pack kernel, [1] skip */,
-    uint32_t first, uint32_t init_pos, uint32_t absolute, uint32_t limit, SrlaJobInfo *__restrict__ info,
+    uint32_t *__restrict__ ctl /* [0] phase added to block_off by the pack kernel, [1] skip, [2] job bytes, [3] offset in dst */,
+    uint32_t first, uint32_t init_pos, uint32_t absolute, uint32_t limit, uint64_t dst_addr, SrlaJobInfo *__restrict__ info,
     uint32_t *__restrict__ window_bytes)
 {
     __shared__ uint32_t s_wave[NWAVES];
@@ -1830,8 +1830,13 @@ __global__ __launch_bounds__(NT) void srla_block_offsets(
         if (err & SRLA_JOBERR_COVER) skip = 1;
         stream_pos[0] = skip ? pos : pos + total;
         stream_pos[1] = skip;
-        ctl[0] = absolute ? pos : 0u;
+        /* the pack kernel assembles the job's bytes in a device buffer with the same 16-byte phase as their final
+         * address, so that srla_stream_out moves them with aligned 16-byte accesses */
+        const uint32_t dst_off = absolute ? pos : 0u;
+        ctl[0] = (uint32_t)((dst_addr + dst_off) & 15u);
         ctl[1] = skip;
+        ctl[2] = total;
+        ctl[3] = dst_off;
         info->total_bytes = total;
         info->base = pos;
         info->num_blocks = s_cnt[0] & 0x7FFFFFFFu;
@@ -1878,7 +1883,7 @@ template <bool G>
 __device__ __forceinline__ void pack_block_body(
     const SrlaJobParams &jp, const SrlaBlockRecord *__restrict__ recp, const int32_t *__restrict__ input,
     const SrlaItemDesc *__restrict__ items, const SrlaItemResult *__restrict__ results, const int32_t *__restrict__ res_ws,
-    const uint32_t *__restrict__ huff_code, const uint8_t *__restrict__ huff_len, uint32_t *w, uint32_t *aux,
+    const uint32_t *__restrict__ huff_code, const uint8_t *__restrict__ huff_len, uint32_t *w, uint32_t *aux, uint32_t *kpar,
     uint8_t *__restrict__ dst, SrlaJobInfo *__restrict__ info)
 {
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1960,7 +1965,10 @@ __device__ __forceinline__ void pack_block_body(
             }
             if (lane == 0 && p != 88u + hdr_bits) info->error = SRLA_JOBERR_SIZE;
         }
-        /* residual codes, channel after channel */
+        /* residual codes, channel after channel.  The partition parameters go to LDS first (a parameter fetched from
+         * global memory at every partition boundary stalled the loops), the thread's residuals are fetched once with
+         * 16-byte loads and kept in registers for both passes. */
+        constexpr uint32_t CACHE = 16;                                   /* residuals a thread can keep */
         uint32_t chan_base = 88u + hdr_bits;
         for (uint32_t ch = 0; ch < nch; ch++) {
             const uint32_t item = recp->item[ch];
@@ -1969,28 +1977,48 @@ __device__ __forceinline__ void pack_block_body(
             if (code_type == SRLA_CODE_ALLZERO) {
                 if (tid == 0) put_bits<G>(w, chan_base, SRLA_CODE_ALLZERO, 2);
             } else {
+                uint8_t *kp = reinterpret_cast<uint8_t *>(kpar) + (ch & 1u) * 1024u;
+                {
+                    const uint32_t *src = reinterpret_cast<const uint32_t *>(ir->kparam);
+                    uint32_t *d32 = reinterpret_cast<uint32_t *>(kp);
+                    for (uint32_t i = tid; i < (((1u << porder) + 3u) >> 2); i += NT) d32[i] = src[i];
+                }
                 const int32_t *res = res_ws + items[item].res_off;
                 const uint32_t plen = n >> porder;
                 const uint32_t per = (n + NT - 1) / NT;                  /* contiguous samples per thread */
                 const uint32_t s0 = (tid * per < n) ? tid * per : n, s1 = (s0 + per < n) ? (s0 + per) : n;
                 const uint32_t part0 = (s0 < n) ? s0 / plen : 0;
+                const bool cached = per <= CACHE && (per & 3u) == 0 && s0 + per <= n;   /* s0 is a multiple of 4: aligned */
+                uint32_t uc[CACHE];
+                if (cached) {
+#pragma unroll
+                    for (uint32_t c = 0; c < CACHE / 4; c++) {
+                        if (4 * c < per) {
+                            const int4 q = *reinterpret_cast<const int4 *>(res + s0 + 4 * c);
+                            uc[4 * c] = zigzag32(q.x); uc[4 * c + 1] = zigzag32(q.y); uc[4 * c + 2] = zigzag32(q.z); uc[4 * c + 3] = zigzag32(q.w);
+                        }
+                    }
+                }
+                __syncthreads();                                         /* kp is complete */
                 /* pass 1: bits this thread will emit */
                 uint32_t mybits = 0;
                 {
                     uint32_t part = part0, next = (part0 + 1) * plen;
-                    uint32_t k = ir->kparam[part];
-                    for (uint32_t s = s0; s < s1; s++) {
-                        if (s == next) { part++; next += plen; k = ir->kparam[part]; }
+                    uint32_t k = kp[part];
+                    auto count = [&](uint32_t s, uint32_t u) {
+                        if (s == next) { part++; next += plen; k = kp[part]; }
                         if (s == part * plen) {
                             if (part == 0) mybits += 2u + 10u + 5u;
-                            else mybits += zigzag32((int32_t)k - (int32_t)ir->kparam[part - 1]) + 1u;
+                            else mybits += zigzag32((int32_t)k - (int32_t)kp[part - 1]) + 1u;
                         }
-                        const uint32_t u = zigzag32(res[s]);
                         if (code_type == SRLA_CODE_RICE) mybits += 1u + k + (u >> k);
-                        else {
-                            const uint32_t k1pow = 2u << k;
-                            mybits += (u < k1pow) ? (k + 2u) : (k + 2u + ((u - k1pow) >> k));
-                        }
+                        else mybits += (k + 2u) + (__builtin_elementwise_sub_sat(u, 2u << k) >> k);
+                    };
+                    if (cached) {
+#pragma unroll
+                        for (uint32_t i = 0; i < CACHE; i++) if (i < per) count(s0 + i, uc[i]);
+                    } else {
+                        for (uint32_t s = s0; s < s1; s++) count(s, zigzag32(res[s]));
                     }
                 }
                 /* exclusive prefix sum over the workgroup */
@@ -2004,20 +2032,17 @@ __device__ __forceinline__ void pack_block_body(
                 /* pass 2: emit */
                 {
                     uint32_t part = part0, next = (part0 + 1) * plen;
-                    uint32_t k = ir->kparam[part];
-                    for (uint32_t s = s0; s < s1; s++) {
-                        if (s == next) { part++; next += plen; k = ir->kparam[part]; }
+                    uint32_t k = kp[part];
+                    auto emit = [&](uint32_t s, uint32_t u) {
+                        if (s == next) { part++; next += plen; k = kp[part]; }
                         if (s == part * plen) {
                             if (part == 0) {
-                                put_bits<G>(w, pos, code_type, 2); pos += 2;
-                                put_bits<G>(w, pos, porder, 10); pos += 10;
-                                put_bits<G>(w, pos, k, 5); pos += 5;
+                                put_bits<G>(w, pos, (code_type << 15) | (porder << 5) | k, 17); pos += 17;   /* 2 + 10 + 5 bits */
                             } else {
-                                pos += zigzag32((int32_t)k - (int32_t)ir->kparam[part - 1]);   /* zeros */
+                                pos += zigzag32((int32_t)k - (int32_t)kp[part - 1]);   /* zeros */
                                 put_bits<G>(w, pos, 1u, 1); pos += 1;
                             }
                         }
-                        const uint32_t u = zigzag32(res[s]);
                         if (code_type == SRLA_CODE_RICE) {
                             pos += u >> k;                                /* quotient in unary: zeros */
                             put_bits<G>(w, pos, (1u << k) | (u & ((1u << k) - 1u)), k + 1u); pos += k + 1u;
@@ -2032,6 +2057,12 @@ __device__ __forceinline__ void pack_block_body(
                                 put_bits<G>(w, pos, (1u << k) | (v & ((1u << k) - 1u)), k + 1u); pos += k + 1u;
                             }
                         }
+                    };
+                    if (cached) {
+#pragma unroll
+                        for (uint32_t i = 0; i < CACHE; i++) if (i < per) emit(s0 + i, uc[i]);
+                    } else {
+                        for (uint32_t s = s0; s < s1; s++) emit(s, zigzag32(res[s]));
                     }
                 }
             }
@@ -2106,18 +2137,47 @@ __global__ __launch_bounds__(NT) void srla_pack_blocks(
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     uint32_t *aux = (uint32_t *)lds;                         /* 32 words: wave sums */
-    uint32_t *words = aux + 32;                              /* lds_words entries */
+    uint32_t *kpar = aux + 32;                               /* 2 x 1024 bytes: partition parameters of the channel in work */
+    uint32_t *words = kpar + 512;                            /* lds_words entries */
     const uint32_t slot = blockIdx.x;
     const SrlaBlockRecord *recp = &blocks[slot];
     if (!recp->valid || ctl[1]) return;
     uint8_t *dst = out + (size_t)ctl[0] + block_off[slot];
     const uint32_t nwords = ((recp->bytes + 3u) >> 2) + 1u;
     if (nwords <= lds_words) {
-        pack_block_body<false>(jp, recp, input, items, results, res_ws, huff_code, huff_len, words, aux, dst, info);
+        pack_block_body<false>(jp, recp, input, items, results, res_ws, huff_code, huff_len, words, aux, kpar, dst, info);
     } else {
         const size_t off = ((size_t)recp->sample_off * jp.num_channels * (jp.bits_per_sample >> 3) + (size_t)slot * SRLA_PACK_SLACK + 3u) & ~(size_t)3u;
-        pack_block_body<true>(jp, recp, input, items, results, res_ws, huff_code, huff_len, (uint32_t *)(scratch + off), aux, dst, info);
+        pack_block_body<true>(jp, recp, input, items, results, res_ws, huff_code, huff_len, (uint32_t *)(scratch + off), aux, kpar, dst, info);
     }
+}
+
+/* srla_stream_out: the job's finished bytes, device buffer -> their place in host memory (the caller's pinned
+ * buffer or the pinned staging buffer).  A handful of workgroups keep the PCIe link busy; letting the 1000+ pack
+ * workgroups store to host memory themselves kept them (and their LDS) resident for the duration of the link
+ * transfer and slowed the concurrently running srla_autocorr by 30 %. */
+__global__ __launch_bounds__(NT) void srla_stream_out(const uint8_t *__restrict__ stage, const uint32_t *__restrict__ ctl,
+                                                      uint8_t *__restrict__ dst, uint32_t pause)
+{
+    if (ctl[1]) return;
+    const uint8_t *src = stage + ctl[0];
+    uint8_t *d = dst + ctl[3];
+    const uint32_t total = ctl[2];
+    uint32_t head = (16u - (uint32_t)(reinterpret_cast<uintptr_t>(d) & 15u)) & 15u;    /* src has the same phase */
+    if (head > total) head = total;
+    const uint32_t nvec = (total - head) >> 4, tail0 = head + (nvec << 4);
+    const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x, gsize = gridDim.x * blockDim.x;
+    if (gtid < head) d[gtid] = src[gtid];
+    if (gtid >= 32 && gtid - 32 < total - tail0) d[tail0 + gtid - 32] = src[tail0 + gtid - 32];
+    const uint4 *s4 = reinterpret_cast<const uint4 *>(src + head);
+    uint4 *d4 = reinterpret_cast<uint4 *>(d + head);
+    uint32_t v = gtid;
+    for (; v + 3 * gsize < nvec; v += 4 * gsize) {
+        const uint4 a = s4[v], b = s4[v + gsize], c = s4[v + 2 * gsize], e = s4[v + 3 * gsize];
+        d4[v] = a; d4[v + gsize] = b; d4[v + 2 * gsize] = c; d4[v + 3 * gsize] = e;
+        for (uint32_t z = 0; z < pause; z++) __builtin_amdgcn_s_sleep(8);
+    }
+    for (; v < nvec; v += gsize) d4[v] = s4[v];
 }
 
 /* ------------------------------------------------------------------- offset left shift ---- */
@@ -2310,17 +2370,25 @@ extern "C" int srla_launch_pack(hipStream_t stream, const SrlaJobParams *jp, uin
                                 const SrlaBlockRecord *blocks, const SrlaItemResult *results, const int32_t *res_ws,
                                 const uint32_t *huff_code, const uint8_t *huff_len, uint32_t *block_off,
                                 uint32_t *stream_pos, uint32_t *ctl, uint32_t first, uint32_t init_pos, uint32_t absolute,
-                                uint32_t limit, uint8_t *out, uint8_t *scratch, SrlaJobInfo *info, uint32_t *window_bytes)
+                                uint32_t limit, uint8_t *stage, uint8_t *dst, uint8_t *scratch, SrlaJobInfo *info,
+                                uint32_t *window_bytes)
 {
     if (num_slots == 0) return 0;
     hipLaunchKernelGGL(srla_block_offsets, dim3(1), dim3(NT), 0, stream, *jp, windows, blocks, results, num_slots, block_off,
-                       stream_pos, ctl, first, init_pos, absolute, limit, info, window_bytes);
+                       stream_pos, ctl, first, init_pos, absolute, limit, (uint64_t)reinterpret_cast<uintptr_t>(dst), info, window_bytes);
     const uint32_t lds_words = srla_pack_lds_words(jp);
-    const uint32_t lds = (lds_words + 32) * 4;
+    const uint32_t lds = (lds_words + 32 + 512) * 4;
     SET_LDS_ATTR(srla_pack_blocks);
     hipLaunchKernelGGL(srla_pack_blocks, dim3(num_slots), dim3(NT), lds, stream,
-                       *jp, input, items, blocks, results, res_ws, huff_code, huff_len, block_off, ctl, out, scratch, info,
+                       *jp, input, items, blocks, results, res_ws, huff_code, huff_len, block_off, ctl, stage, scratch, info,
                        lds_words);
+    static int out_wgs = 0, out_thr = 0, out_sleep = 0;
+    if (out_wgs == 0) {
+        const char *e = getenv("SRLA_MI355X_OUT_WGS"); out_wgs = e ? atoi(e) : 1; if (out_wgs < 1) out_wgs = 1;
+        e = getenv("SRLA_MI355X_OUT_THREADS"); out_thr = e ? atoi(e) : NT; if (out_thr < 64 || out_thr > NT) out_thr = NT;
+        e = getenv("SRLA_MI355X_OUT_SLEEP"); out_sleep = e ? atoi(e) : 0;
+    }
+    hipLaunchKernelGGL(srla_stream_out, dim3((uint32_t)out_wgs), dim3((uint32_t)out_thr), 0, stream, stage, ctl, dst, (uint32_t)out_sleep);
     return (hipGetLastError() == hipSuccess) ? 0 : -2;
 }
 
