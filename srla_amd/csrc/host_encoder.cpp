@@ -243,6 +243,7 @@ struct Impl {
     Slot slot[kMaxSlots];
     DevBuf d_tw, d_geoms, d_thr, d_huff, d_huffcode, d_pos, d_or;
     bool timing = true;               /* stage timing events (SRLA_MI355X_NO_TIMING drops them) */
+    uint32_t timing_stride = 4;       /* every n-th job carries start events on all stages (SRLA_MI355X_TIMING_STRIDE) */
     bool in_pinned = false;           /* this call's input planes are pinned host memory */
     bool force_staging = false;       /* SRLA_MI355X_STAGING: never write the caller's buffer from the device */
     std::map<uint32_t, uint32_t> tw_index;   /* nfft -> offset (double2) */
@@ -338,6 +339,7 @@ struct Impl {
         HIP_OK(hipMemset(d_pos.p, 0, 64));
         force_staging = getenv("SRLA_MI355X_STAGING") != nullptr;
         timing = getenv("SRLA_MI355X_NO_TIMING") == nullptr;
+        if (const char *e = getenv("SRLA_MI355X_TIMING_STRIDE")) { const int v = atoi(e); if (v >= 1) timing_stride = (uint32_t)v; }
         if (!d_or.ensure(64)) return false;
         unsigned hw = std::thread::hardware_concurrency();
         /* a container's CPU quota (cgroup v2 cpu.max = "<quota> <period>") bounds the useful thread count */
@@ -621,61 +623,73 @@ struct Impl {
         double *dbg = s.want_dbg ? s.d_dbg.as<double>() : nullptr;
         const bool have_items = !job.groups.empty();
         int rc = 0;
+        /* Stage events ride on the kernel dispatches themselves (hipExtLaunchKernel): the end event on the stage's last
+         * launch, the start event (timed jobs only) on its first -- no separate marker packets between the kernels
+         * of the critical stream.  A stage without launches records its end event the ordinary way. */
+        hipEvent_t ev0 = s.timed ? s.t0[st] : nullptr;
         switch (st) {
         case ST_A: {
             if (lshift_on_device) HIP_OK(hipStreamWaitEvent(W, ev_or, 0));
             if (s.used_h2d) HIP_OK(hipStreamWaitEvent(W, s.ev_in, 0));
-            if (s.timed) HIP_OK(hipEventRecord(s.t0[ST_A], W));
+            struct L { int kind, cls, pass; };                       /* kind 0: autocorr class launch, 1: pitch solve */
+            L seq[8]; int nl = 0;
             if (have_items) {
-                static const int kClass[3] = { 1, 2, 4 };
                 for (int pass = (par.ltp_order > 0) ? 1 : 0; pass >= 0; pass--) {
-                    for (int c = 0; c < 3; c++)
-                        rc |= srla_launch_autocorr(W, kClass[c], &jp, s.in_cur, s.d_items.as<SrlaItemDesc>(), d_geoms.as<SrlaGeom>(), d_tw.p,
-                                                   (uint32_t)pass, s.d_results.as<SrlaItemResult>(), s.d_lags.as<double>(), dbg,
-                                                   s.d_class_index.as<uint32_t>() + job.class_first[c], job.class_count[c]);
-                    if (pass == 1) rc |= srla_launch_pitch_solve(W, &jp, s.d_lags.as<double>(), s.d_results.as<SrlaItemResult>());
+                    for (int c = 0; c < 3; c++) if (job.class_count[c]) seq[nl++] = { 0, c, pass };
+                    if (pass == 1) seq[nl++] = { 1, 0, 1 };
                 }
             }
-            HIP_OK(hipEventRecord(s.t1[ST_A], W));
+            static const int kClass[3] = { 1, 2, 4 };
+            for (int i = 0; i < nl; i++) {
+                hipEvent_t e0 = (i == 0) ? ev0 : nullptr, e1 = (i == nl - 1) ? s.t1[ST_A] : nullptr;
+                if (seq[i].kind == 0) {
+                    const int c = seq[i].cls;
+                    rc |= srla_launch_autocorr(W, kClass[c], &jp, s.in_cur, s.d_items.as<SrlaItemDesc>(), d_geoms.as<SrlaGeom>(), d_tw.p,
+                                               (uint32_t)seq[i].pass, s.d_results.as<SrlaItemResult>(), s.d_lags.as<double>(), dbg,
+                                               s.d_class_index.as<uint32_t>() + job.class_first[c], job.class_count[c], e0, e1);
+                } else {
+                    rc |= srla_launch_pitch_solve(W, &jp, s.d_lags.as<double>(), s.d_results.as<SrlaItemResult>(), e0, e1);
+                }
+            }
+            if (nl == 0) { if (ev0) HIP_OK(hipEventRecord(ev0, W)); HIP_OK(hipEventRecord(s.t1[ST_A], W)); }
             break; }
         case ST_B:
             HIP_OK(hipStreamWaitEvent(N, s.t1[ST_A], 0));
-            if (s.timed) HIP_OK(hipEventRecord(s.t0[ST_B], N));
-            if (have_items && jp.max_order > 0)
+            if (have_items && jp.max_order > 0) {
                 rc |= srla_launch_lpc_solve(N, &jp, s.d_items.as<SrlaItemDesc>(), d_geoms.as<SrlaGeom>(), s.d_lags.as<double>(),
-                                            s.d_err.as<double>(), d_huff.as<uint8_t>(), s.d_results.as<SrlaItemResult>(), dbg);
-            HIP_OK(hipEventRecord(s.t1[ST_B], N));
+                                            s.d_err.as<double>(), d_huff.as<uint8_t>(), s.d_results.as<SrlaItemResult>(), dbg, ev0, s.t1[ST_B]);
+            } else { if (ev0) HIP_OK(hipEventRecord(ev0, N)); HIP_OK(hipEventRecord(s.t1[ST_B], N)); }
             break;
         case ST_C:
             HIP_OK(hipStreamWaitEvent(W, s.t1[ST_B], 0));
-            if (timing) HIP_OK(hipEventRecord(s.t0[ST_C], W));   /* the roofline kernel: timed on every job */
             if (have_items) {
                 const Group &g = job.groups[0];
+                /* the roofline kernel: start event on every job */
                 rc |= srla_launch_residual_cost(W, g.rclass, &jp, s.in_cur, s.d_items.as<SrlaItemDesc>(), d_geoms.as<SrlaGeom>(), &g.plan,
-                                                d_thr.as<double>(), s.d_res_ws.as<int32_t>(), s.d_results.as<SrlaItemResult>());
-            }
-            HIP_OK(hipEventRecord(s.t1[ST_C], W));
+                                                d_thr.as<double>(), s.d_res_ws.as<int32_t>(), s.d_results.as<SrlaItemResult>(),
+                                                timing ? s.t0[ST_C] : nullptr, s.t1[ST_C]);
+            } else { if (timing) HIP_OK(hipEventRecord(s.t0[ST_C], W)); HIP_OK(hipEventRecord(s.t1[ST_C], W)); }
             break;
         case ST_D:
             HIP_OK(hipStreamWaitEvent(N, s.t1[ST_C], 0));
-            if (s.timed) HIP_OK(hipEventRecord(s.t0[ST_D], N));
-            rc |= srla_launch_price(N, &jp, s.d_windows.as<SrlaWindowDesc>(), s.d_cands.as<SrlaCandDesc>(),
-                                    s.d_results.as<SrlaItemResult>(), s.d_blocks.as<SrlaBlockRecord>());
-            HIP_OK(hipEventRecord(s.t1[ST_D], N));
+            if (jp.num_windows) {
+                rc |= srla_launch_price(N, &jp, s.d_windows.as<SrlaWindowDesc>(), s.d_cands.as<SrlaCandDesc>(),
+                                        s.d_results.as<SrlaItemResult>(), s.d_blocks.as<SrlaBlockRecord>(), ev0, s.t1[ST_D]);
+            } else { if (ev0) HIP_OK(hipEventRecord(ev0, N)); HIP_OK(hipEventRecord(s.t1[ST_D], N)); }
             break;
         case ST_E:
-            /* block offsets + complete blocks, written where the stream wants them (the caller's pinned buffer,
+            /* block offsets + complete blocks + stream-out to where the stream wants them (the caller's pinned buffer,
              * or this slot's pinned staging buffer); runs on its own stream and leaves W to autocorr / residual_cost */
             HIP_OK(hipStreamWaitEvent(C, s.t1[ST_D], 0));
-            if (s.timed) HIP_OK(hipEventRecord(s.t0[ST_E], C));
-            rc |= srla_launch_pack(C, &jp, job.num_slots, s.in_cur, s.d_items.as<SrlaItemDesc>(), s.d_windows.as<SrlaWindowDesc>(),
-                                   s.d_blocks.as<SrlaBlockRecord>(), s.d_results.as<SrlaItemResult>(), s.d_res_ws.as<int32_t>(),
-                                   d_huffcode.as<uint32_t>(), d_huff.as<uint8_t>(), s.d_block_off.as<uint32_t>(),
-                                   d_pos.as<uint32_t>(), s.d_ctl.as<uint32_t>(), s.out_first, s.out_init_pos,
-                                   s.out_direct ? 1u : 0u, s.out_limit, s.d_stream.as<uint8_t>(), s.out_direct ? s.out_direct : s.h_stream.as<uint8_t>(),
-                                   s.d_scratch.as<uint8_t>(), s.h_info.as<SrlaJobInfo>(),
-                                   reinterpret_cast<uint32_t *>(s.h_info.as<SrlaJobInfo>() + 1));
-            HIP_OK(hipEventRecord(s.t1[ST_E], C));
+            if (job.num_slots) {
+                rc |= srla_launch_pack(C, &jp, job.num_slots, s.in_cur, s.d_items.as<SrlaItemDesc>(), s.d_windows.as<SrlaWindowDesc>(),
+                                       s.d_blocks.as<SrlaBlockRecord>(), s.d_results.as<SrlaItemResult>(), s.d_res_ws.as<int32_t>(),
+                                       d_huffcode.as<uint32_t>(), d_huff.as<uint8_t>(), s.d_block_off.as<uint32_t>(),
+                                       d_pos.as<uint32_t>(), s.d_ctl.as<uint32_t>(), s.out_first, s.out_init_pos,
+                                       s.out_direct ? 1u : 0u, s.out_limit, s.d_stream.as<uint8_t>(), s.out_direct ? s.out_direct : s.h_stream.as<uint8_t>(),
+                                       s.d_scratch.as<uint8_t>(), s.h_info.as<SrlaJobInfo>(),
+                                       reinterpret_cast<uint32_t *>(s.h_info.as<SrlaJobInfo>() + 1), ev0, s.t1[ST_E]);
+            } else { if (ev0) HIP_OK(hipEventRecord(ev0, C)); HIP_OK(hipEventRecord(s.t1[ST_E], C)); }
             break;
         default: return false;
         }
@@ -857,7 +871,7 @@ struct Impl {
             const uint32_t s0 = plan[k].s0, ns = plan[k].ns;
             build_job(s.job, s0, ns, search);
             s.out_direct = out_direct; s.out_first = (k == 0); s.out_init_pos = init_pos; s.out_limit = data_size;
-            s.timed = timing && (k % 4 == 0);
+            s.timed = timing && (k % timing_stride == 0);
             return prepare_job(s, d_in ? d_in + s0 : nullptr, d_stride, host_in, false);
         };
         /* Software pipeline over jobs: iteration t enqueues  autocorr + solve of job t,  residual_cost +

@@ -16,6 +16,8 @@
 #define SRLA_DBG_LTPLAGS  768    /* 264: LTP autocorrelation lags                      */
 #define SRLA_DBG_STRIDE   1040
 
+/* ev_start / ev_stop (either may be null): events attached to the first / last kernel dispatch of the call itself
+ * (hipExtLaunchKernel), i.e. start and completion of the kernels with no extra barrier packet in the stream. */
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -31,17 +33,20 @@ uint32_t srla_kernel_fast_lds_bytes(uint32_t fl);   /* LDS of the 1024*fl-sample
 int srla_launch_autocorr(hipStream_t stream, int rclass, const SrlaJobParams *jp, const int32_t *input,
                          const SrlaItemDesc *items, const SrlaGeom *geoms, const void *twiddles,
                          uint32_t pass, SrlaItemResult *results, double *lags_ws, double *dbg,
-                         const uint32_t *item_index, uint32_t count);
-int srla_launch_pitch_solve(hipStream_t stream, const SrlaJobParams *jp, const double *lags_ws, SrlaItemResult *results);
+                         const uint32_t *item_index, uint32_t count, hipEvent_t ev_start, hipEvent_t ev_stop);
+int srla_launch_pitch_solve(hipStream_t stream, const SrlaJobParams *jp, const double *lags_ws, SrlaItemResult *results,
+                            hipEvent_t ev_start, hipEvent_t ev_stop);
 int srla_launch_lpc_solve(hipStream_t stream, const SrlaJobParams *jp, const SrlaItemDesc *items,
                           const SrlaGeom *geoms, const double *lags_ws, double *err_ws, const uint8_t *huff_len,
-                          SrlaItemResult *results, double *dbg);
+                          SrlaItemResult *results, double *dbg, hipEvent_t ev_start, hipEvent_t ev_stop);
 int srla_launch_residual_cost(hipStream_t stream, int rclass, const SrlaJobParams *jp, const int32_t *input,
                               const SrlaItemDesc *items, const SrlaGeom *geoms, const SrlaLdsPlan *plan,
-                              const double *rice_thresholds, int32_t *res_ws, SrlaItemResult *results);
+                              const double *rice_thresholds, int32_t *res_ws, SrlaItemResult *results,
+                              hipEvent_t ev_start, hipEvent_t ev_stop);
 
 int srla_launch_price(hipStream_t stream, const SrlaJobParams *jp, const SrlaWindowDesc *windows,
-                      const SrlaCandDesc *cands, const SrlaItemResult *results, SrlaBlockRecord *blocks);
+                      const SrlaCandDesc *cands, const SrlaItemResult *results, SrlaBlockRecord *blocks,
+                      hipEvent_t ev_start, hipEvent_t ev_stop);
 
 /* srla_block_offsets + srla_pack_blocks + srla_stream_out: the job's blocks, complete, assembled in the device
  * buffer `stage` and then moved to their byte offsets of the stream in host memory `dst`.
@@ -56,7 +61,8 @@ int srla_launch_pack(hipStream_t stream, const SrlaJobParams *jp, uint32_t num_s
                      const SrlaBlockRecord *blocks, const SrlaItemResult *results, const int32_t *res_ws,
                      const uint32_t *huff_code, const uint8_t *huff_len, uint32_t *block_off,
                      uint32_t *stream_pos, uint32_t *ctl, uint32_t first, uint32_t init_pos, uint32_t absolute,
-                     uint32_t limit, uint8_t *stage, uint8_t *dst, uint8_t *scratch, SrlaJobInfo *info, uint32_t *window_bytes);
+                     uint32_t limit, uint8_t *stage, uint8_t *dst, uint8_t *scratch, SrlaJobInfo *info, uint32_t *window_bytes,
+                     hipEvent_t ev_start, hipEvent_t ev_stop);
 uint32_t srla_pack_lds_words(const SrlaJobParams *jp);
 int srla_pack_needs_scratch(const SrlaJobParams *jp);   /* blocks may exceed the LDS staging: allocate the scratch */
 

@@ -26,6 +26,7 @@
  * must round exactly like the C90 reference: compiled with -ffp-contract=off and pinned below.
  */
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdlib.h>
 #include <stdint.h>
 #include <float.h>
@@ -2239,7 +2240,7 @@ __global__ void srla_mask_to_shift(uint32_t *__restrict__ out)
 extern "C" int srla_launch_autocorr(hipStream_t stream, int rclass, const SrlaJobParams *jp, const int32_t *input,
                                     const SrlaItemDesc *items, const SrlaGeom *geoms, const void *twiddles,
                                     uint32_t pass, SrlaItemResult *results, double *lags_ws, double *dbg,
-                                    const uint32_t *item_index, uint32_t count)
+                                    const uint32_t *item_index, uint32_t count, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     if (count == 0) return 0;
     /* rclass = largest FFT size of the launch / 2048.  LDS: nfft / 2 complex slots plus one pad slot per sixteen */
@@ -2250,7 +2251,7 @@ extern "C" int srla_launch_autocorr(hipStream_t stream, int rclass, const SrlaJo
 #define LAUNCH(RR)                                                                                           \
     do {                                                                                                     \
         SET_LDS_ATTR(srla_autocorr<RR>);                                                                     \
-        hipLaunchKernelGGL(srla_autocorr<RR>, grid, block, lds, stream, *jp, input, items, geoms,            \
+        hipExtLaunchKernelGGL(srla_autocorr<RR>, grid, block, lds, stream, ev_start, ev_stop, 0, *jp, input, items, geoms,            \
                            (const cplx *)twiddles, fft_bytes, pass, results, lags_ws, dbg, item_index, count); \
     } while (0)
     switch (rclass) {
@@ -2264,18 +2265,18 @@ extern "C" int srla_launch_autocorr(hipStream_t stream, int rclass, const SrlaJo
 }
 
 extern "C" int srla_launch_pitch_solve(hipStream_t stream, const SrlaJobParams *jp, const double *lags_ws,
-                                       SrlaItemResult *results)
+                                       SrlaItemResult *results, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     if (jp->num_items == 0) return 0;
     const uint32_t lds = SRLA_LTP_LAGS * PITCH_ITEMS * 8u;
     SET_LDS_ATTR(srla_pitch_solve);
-    hipLaunchKernelGGL(srla_pitch_solve, dim3((jp->num_items + PITCH_ITEMS - 1) / PITCH_ITEMS), dim3(WAVE), lds, stream, *jp, lags_ws, results);
+    hipExtLaunchKernelGGL(srla_pitch_solve, dim3((jp->num_items + PITCH_ITEMS - 1) / PITCH_ITEMS), dim3(WAVE), lds, stream, ev_start, ev_stop, 0, *jp, lags_ws, results);
     return (hipGetLastError() == hipSuccess) ? 0 : -2;
 }
 
 extern "C" int srla_launch_lpc_solve(hipStream_t stream, const SrlaJobParams *jp, const SrlaItemDesc *items,
                                      const SrlaGeom *geoms, const double *lags_ws, double *err_ws, const uint8_t *huff_len,
-                                     SrlaItemResult *results, double *dbg)
+                                     SrlaItemResult *results, double *dbg, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     if (jp->num_items == 0) return 0;
     const uint32_t p = jp->max_order;
@@ -2285,9 +2286,9 @@ extern "C" int srla_launch_lpc_solve(hipStream_t stream, const SrlaJobParams *jp
         const uint32_t lds_a = (PP + 1) * 8 * 64, lds_c = (PP + 1) * 8 * 64 + PP * 4 * 64;                               \
         SET_LDS_ATTR(srla_lpc_recursion_regs<PP>);                                                                       \
         SET_LDS_ATTR(srla_lpc_quantize_regs<PP>);                                                                        \
-        hipLaunchKernelGGL(srla_lpc_recursion_regs<PP>, g64, blk, lds_a, stream, *jp, lags_ws, err_ws);                  \
+        hipExtLaunchKernelGGL(srla_lpc_recursion_regs<PP>, g64, blk, lds_a, stream, ev_start, nullptr, 0, *jp, lags_ws, err_ws);                  \
         hipLaunchKernelGGL(srla_order_select, dim3(jp->num_items), blk, 0, stream, *jp, items, geoms, err_ws, results, dbg); \
-        hipLaunchKernelGGL(srla_lpc_quantize_regs<PP>, g64, blk, lds_c, stream, *jp, lags_ws, huff_len, results);        \
+        hipExtLaunchKernelGGL(srla_lpc_quantize_regs<PP>, g64, blk, lds_c, stream, nullptr, ev_stop, 0, *jp, lags_ws, huff_len, results);        \
     } while (0)
     if (p == 8) REGS_PATH(8);
     else if (p == 16) REGS_PATH(16);
@@ -2297,16 +2298,16 @@ extern "C" int srla_launch_lpc_solve(hipStream_t stream, const SrlaJobParams *jp
         const uint32_t lds = (2 * p + 3) * 8 * 64;
         SET_LDS_ATTR(srla_lpc_recursion<64>);
         SET_LDS_ATTR(srla_lpc_quantize<64>);
-        hipLaunchKernelGGL(srla_lpc_recursion<64>, g64, blk, lds, stream, *jp, lags_ws, err_ws);
+        hipExtLaunchKernelGGL(srla_lpc_recursion<64>, g64, blk, lds, stream, ev_start, nullptr, 0, *jp, lags_ws, err_ws);
         hipLaunchKernelGGL(srla_order_select, dim3(jp->num_items), blk, 0, stream, *jp, items, geoms, err_ws, results, dbg);
-        hipLaunchKernelGGL(srla_lpc_quantize<64>, g64, blk, lds, stream, *jp, lags_ws, huff_len, results);
+        hipExtLaunchKernelGGL(srla_lpc_quantize<64>, g64, blk, lds, stream, nullptr, ev_stop, 0, *jp, lags_ws, huff_len, results);
     } else {
         const uint32_t lds = (2 * p + 3) * 8 * 32;
         SET_LDS_ATTR(srla_lpc_recursion<32>);
         SET_LDS_ATTR(srla_lpc_quantize<32>);
-        hipLaunchKernelGGL(srla_lpc_recursion<32>, dim3((jp->num_items + 31) / 32), blk, lds, stream, *jp, lags_ws, err_ws);
+        hipExtLaunchKernelGGL(srla_lpc_recursion<32>, dim3((jp->num_items + 31) / 32), blk, lds, stream, ev_start, nullptr, 0, *jp, lags_ws, err_ws);
         hipLaunchKernelGGL(srla_order_select, dim3(jp->num_items), blk, 0, stream, *jp, items, geoms, err_ws, results, dbg);
-        hipLaunchKernelGGL(srla_lpc_quantize<32>, dim3((jp->num_items + 31) / 32), blk, lds, stream, *jp, lags_ws, huff_len, results);
+        hipExtLaunchKernelGGL(srla_lpc_quantize<32>, dim3((jp->num_items + 31) / 32), blk, lds, stream, nullptr, ev_stop, 0, *jp, lags_ws, huff_len, results);
     }
 #undef REGS_PATH
     return (hipGetLastError() == hipSuccess) ? 0 : -2;
@@ -2314,14 +2315,15 @@ extern "C" int srla_launch_lpc_solve(hipStream_t stream, const SrlaJobParams *jp
 
 extern "C" int srla_launch_residual_cost(hipStream_t stream, int rclass, const SrlaJobParams *jp, const int32_t *input,
                                          const SrlaItemDesc *items, const SrlaGeom *geoms, const SrlaLdsPlan *plan,
-                                         const double *rice_thresholds, int32_t *res_ws, SrlaItemResult *results)
+                                         const double *rice_thresholds, int32_t *res_ws, SrlaItemResult *results,
+                                         hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     if (jp->num_items == 0) return 0;
     dim3 grid(jp->num_items), block(NT);
 #define LAUNCH(RR)                                                                                           \
     do {                                                                                                     \
         SET_LDS_ATTR(srla_residual_cost<RR>);                                                                \
-        hipLaunchKernelGGL(srla_residual_cost<RR>, grid, block, plan->total, stream, *jp, input, items, geoms, \
+        hipExtLaunchKernelGGL(srla_residual_cost<RR>, grid, block, plan->total, stream, ev_start, ev_stop, 0, *jp, input, items, geoms, \
                            *plan, rice_thresholds, res_ws, results);                                         \
     } while (0)
     switch (rclass) {
@@ -2336,10 +2338,10 @@ extern "C" int srla_launch_residual_cost(hipStream_t stream, int rclass, const S
 
 extern "C" int srla_launch_price(hipStream_t stream, const SrlaJobParams *jp, const SrlaWindowDesc *windows,
                                  const SrlaCandDesc *cands, const SrlaItemResult *results,
-                                 SrlaBlockRecord *blocks)
+                                 SrlaBlockRecord *blocks, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     if (jp->num_windows == 0) return 0;
-    hipLaunchKernelGGL(srla_price_windows, dim3(jp->num_windows), dim3(WAVE), 0, stream,
+    hipExtLaunchKernelGGL(srla_price_windows, dim3(jp->num_windows), dim3(WAVE), 0, stream, ev_start, ev_stop, 0,
                        *jp, windows, cands, results, blocks);
     return (hipGetLastError() == hipSuccess) ? 0 : -2;
 }
@@ -2371,10 +2373,10 @@ extern "C" int srla_launch_pack(hipStream_t stream, const SrlaJobParams *jp, uin
                                 const uint32_t *huff_code, const uint8_t *huff_len, uint32_t *block_off,
                                 uint32_t *stream_pos, uint32_t *ctl, uint32_t first, uint32_t init_pos, uint32_t absolute,
                                 uint32_t limit, uint8_t *stage, uint8_t *dst, uint8_t *scratch, SrlaJobInfo *info,
-                                uint32_t *window_bytes)
+                                uint32_t *window_bytes, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     if (num_slots == 0) return 0;
-    hipLaunchKernelGGL(srla_block_offsets, dim3(1), dim3(NT), 0, stream, *jp, windows, blocks, results, num_slots, block_off,
+    hipExtLaunchKernelGGL(srla_block_offsets, dim3(1), dim3(NT), 0, stream, ev_start, nullptr, 0, *jp, windows, blocks, results, num_slots, block_off,
                        stream_pos, ctl, first, init_pos, absolute, limit, (uint64_t)reinterpret_cast<uintptr_t>(dst), info, window_bytes);
     const uint32_t lds_words = srla_pack_lds_words(jp);
     const uint32_t lds = (lds_words + 32 + 512) * 4;
@@ -2388,7 +2390,7 @@ extern "C" int srla_launch_pack(hipStream_t stream, const SrlaJobParams *jp, uin
         e = getenv("SRLA_MI355X_OUT_THREADS"); out_thr = e ? atoi(e) : NT; if (out_thr < 64 || out_thr > NT) out_thr = NT;
         e = getenv("SRLA_MI355X_OUT_SLEEP"); out_sleep = e ? atoi(e) : 0;
     }
-    hipLaunchKernelGGL(srla_stream_out, dim3((uint32_t)out_wgs), dim3((uint32_t)out_thr), 0, stream, stage, ctl, dst, (uint32_t)out_sleep);
+    hipExtLaunchKernelGGL(srla_stream_out, dim3((uint32_t)out_wgs), dim3((uint32_t)out_thr), 0, stream, nullptr, ev_stop, 0, stage, ctl, dst, (uint32_t)out_sleep);
     return (hipGetLastError() == hipSuccess) ? 0 : -2;
 }
 
