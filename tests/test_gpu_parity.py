@@ -324,3 +324,13 @@ def test_pinned_input_planes_are_read_by_dma(product):
     got = product.encode(pinned.numpy(), **M4)
     assert np.array_equal(got, want)
     assert np.array_equal(helpers.oracle_decode(got), pcm)
+
+
+def test_random_configurations_match_the_oracle(product):
+    """A slice of tools/gpu_sweep.py: random channel counts, bit depths, presets, block sizes, division depths,
+    look-ahead factors, LTP orders, lengths and signal kinds; bytes must equal the oracle's."""
+    import sys
+    sys.path.insert(0, os.path.join(helpers.ROOT, "tools"))
+    import gpu_sweep
+    done, bad = gpu_sweep.sweep(60, 3, max_samples=1_500_000)
+    assert done >= 40 and bad == 0

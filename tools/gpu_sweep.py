@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep on an MI355X: library bytes vs oracle bytes over random configurations and lengths.
+
+    python tools/gpu_sweep.py [cases] [seed]
+
+Lengths are chosen so that every block is even and (with LTP) at least 263 samples long, i.e. inside the set of
+inputs for which the reference itself is history independent.  Prints one line per mismatch and a
+summary; exit status 1 on any mismatch."""
+import os
+import random
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT)
+import helpers  # noqa: E402
+from srla_amd import capi  # noqa: E402
+
+
+def sweep(cases, seed, max_samples=6_000_000):
+    rnd = random.Random(seed)
+    lib = capi.EncoderLib(helpers.PRODUCT_SO)
+    bad = 0
+    done = 0
+    for case in range(cases):
+        nch = rnd.choice([1, 2, 2, 2, 3, 5, 8])
+        bps = rnd.choice([16, 16, 16, 8, 24])
+        preset = rnd.choice([0, 1, 2, 3, 4, 4, 4, 5, 6])
+        log2b = rnd.choice([8, 9, 10, 11, 12, 12, 13])
+        divisions = rnd.choice([0, 1, 1, 2, 3])
+        ltp = rnd.choice([0, 0, 0, 1, 3])
+        max_block = 1 << log2b
+        min_block = max_block >> divisions
+        if min_block < 64:
+            continue
+        if ltp and min_block < 264:
+            ltp = 0                                      # shorter blocks + LTP: the reference reads stale lags
+        order = [0, 8, 16, 32, 64, 128, 255][preset]
+        if order > min_block:
+            continue
+        lookahead_factor = rnd.choice([1, 2, 4]) if divisions else 4
+        if (max_block * lookahead_factor) // min_block + 1 > 65:
+            continue
+        # length: whole min blocks plus an even tail that is long enough for the LTP lags
+        nblocks = rnd.randint(1, max(2, min(600000 // min_block, 3 * (2 << 20) // min_block // 4)))
+        tail = rnd.choice([0, 0, 2 * rnd.randint(132 if ltp else 1, max(133, min_block // 2 - 1))])
+        if tail >= min_block:
+            tail = 0
+        n = nblocks * min_block + tail
+        if n * nch > max_samples:
+            n = (max_samples // nch // min_block) * min_block
+        if n == 0:
+            continue
+        kind = rnd.choice([helpers.MUSIC, helpers.VARIED, helpers.VARIED, helpers.NOISE, helpers.SINE])
+        cli = dict(preset=preset, max_block=max_block, divisions=divisions, ltp_order=ltp, lookahead_factor=lookahead_factor)
+        pcm = helpers.synth(kind, 5000 + case, 48000, nch, n, bps)
+        if rnd.random() < 0.15:
+            pcm = (pcm >> 3) << 3                       # exercises the offset left shift
+        try:
+            got = lib.encode(pcm, bits_per_sample=bps, **cli)
+        except RuntimeError as e:                        # limits of the implementation are refused loudly
+            print("refused", cli, nch, bps, n, e)
+            continue
+        want = helpers.Oracle(nch, bits_per_sample=bps, **cli).encode_whole(pcm)
+        done += 1
+        if not np.array_equal(got, want):
+            bad += 1
+            print("MISMATCH case %d: nch=%d bps=%d n=%d kind=%d %s sizes %d vs %d" % (case, nch, bps, n, kind, cli, got.size, want.size), flush=True)
+    return done, bad
+
+
+def main():
+    done, bad = sweep(int(sys.argv[1]) if len(sys.argv) > 1 else 150, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    print("sweep: %d compared, %d mismatches" % (done, bad))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
