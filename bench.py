@@ -97,6 +97,7 @@ def main():
     ap.add_argument("--block", type=int, default=4096)
     ap.add_argument("--divisions", type=int, default=1)
     ap.add_argument("--ltp", type=int, default=0)
+    ap.add_argument("--bps", type=int, default=16, choices=[8, 16, 24], help="bits per sample of the synthetic input (the metric is quoted at 16)")
     ap.add_argument("--no-numa-pin", action="store_true", help="do not restrict the process to the GPU-local NUMA node")
     ap.add_argument("--pack-threads", type=int, default=0, help="host threads copying staged blocks when the output is pageable (default: min(8, usable CPUs / (2 * ranks)))")
     ap.add_argument("--pageable-output", action="store_true", help="give the encoder an ordinary (pageable) output buffer: the device then "
@@ -142,7 +143,7 @@ def main():
                                                      C.c_uint32, C.POINTER(C.c_uint32), C.c_void_p]
     lib.lib.SRLAMI355X_GetStats.argtypes = [C.c_void_p, C.POINTER(Stats), C.c_int]
 
-    rate, nch, bps = 48000, 2, 16
+    rate, nch, bps = 48000, 2, args.bps
     n = int(args.seconds * rate)
     n -= n % 2  # even length (odd tails are history dependent in the reference)
     cli = dict(preset=args.preset, max_block=args.block, divisions=args.divisions, ltp_order=args.ltp)
@@ -222,13 +223,13 @@ def main():
             except Exception:
                 traffic = None
         line = {
-            "metric": "encode Msamples/s (-m %d -B %d -V %d -P %d, stereo 48 kHz 16-bit)" % (args.preset, args.block, args.divisions, args.ltp),
+            "metric": "encode Msamples/s (-m %d -B %d -V %d -P %d, stereo 48 kHz %d-bit)" % (args.preset, args.block, args.divisions, args.ltp, bps),
             "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int32+f64", "data": "synthetic",
-            "config": {"workload": "srla -e -m %d -B %d -V %d -L 4 -P %d; %.0f s synthetic stereo 48 kHz/16-bit (music-like) per GPU per step, "
+            "config": {"workload": "srla -e -m %d -B %d -V %d -L 4 -P %d; %.0f s synthetic stereo 48 kHz/%d-bit (music-like) per GPU per step, "
                                    "samples resident in HBM, complete .srl stream produced in %s host memory" %
-                                   (args.preset, args.block, args.divisions, args.ltp, n / rate, "pageable" if args.pageable_output else "pinned"),
+                                   (args.preset, args.block, args.divisions, args.ltp, n / rate, bps, "pageable" if args.pageable_output else "pinned"),
                        "samples_per_channel_per_step": n, "parallelism": "windows sharded per GPU, no collective"},
             "compression_ratio": round(out_size.value / float(pcm.size * (bps // 8)), 6),
             "lossless_roundtrip": lossless,

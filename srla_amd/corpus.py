@@ -52,3 +52,70 @@ def encode_corpus(encode_fn, files, rank=0, world=1, group=None):
         merged = mine
     merged.sort(key=lambda e: e["index"])
     return merged, streams
+
+
+def main_cli(lib, in_dir, out_dir, cli):
+    """`python -m srla_amd.cli -e --corpus IN --out OUT` (optionally under torchrun, one rank per GPU): every .wav
+    below IN is encoded to OUT/<relative name>.srl by the rank that owns it; rank 0 prints the manifest summary."""
+    import ctypes as C
+    import os
+    import time
+
+    from . import wavio
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    lib.lib.SRLAMI355X_SetDevice.argtypes = [C.c_int]
+    if lib.lib.SRLAMI355X_SetDevice(local_rank) != 0:
+        raise SystemExit("srla_amd.cli: no MI355X for local rank %d (there is no CPU fallback)" % local_rank)
+    group = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")       # only a manifest travels; the data path has no collective
+    paths = []
+    for base, _dirs, names in sorted(os.walk(in_dir)):
+        for nm in sorted(names):
+            if nm.lower().endswith(".wav"):
+                paths.append(os.path.join(base, nm))
+    # sample counts from the file sizes (44-byte canonical header): only the balance depends on it
+    class Src:
+        def __init__(self, path):
+            self.path = path
+            self.num_samples = max(1, os.path.getsize(path))
+        def __call__(self):
+            return self.path
+
+    def encode_path(path):
+        pcm, rate, bps = wavio.read_wav(path)
+        from . import capi
+        cfg, par = capi.cli_setup(pcm.shape[0], bps, rate, **cli)
+        enc = lib.create(cfg)
+        try:
+            if lib.set_parameter(enc, par) != capi.OK:
+                raise RuntimeError("SetEncodeParameter failed for %s" % path)
+            rc, data = lib.encode_whole(enc, pcm, cap=2 * os.path.getsize(path))
+            if rc != capi.OK:
+                raise RuntimeError("EncodeWhole -> %d for %s" % (rc, path))
+        finally:
+            lib.destroy(enc)
+        rel = os.path.relpath(path, in_dir)
+        out_path = os.path.join(out_dir, os.path.splitext(rel)[0] + ".srl")
+        os.makedirs(os.path.dirname(out_path) or ".", exist_ok=True)
+        with open(out_path, "wb") as f:
+            f.write(data.tobytes())
+        return data
+
+    t0 = time.perf_counter()
+    manifest, _ = encode_corpus(encode_path, [(p, Src(p)) for p in paths], rank=rank, world=world, group=group)
+    dt = time.perf_counter() - t0
+    if rank == 0:
+        total_out = sum(e["bytes"] for e in manifest)
+        total_in = sum(os.path.getsize(e["name"]) for e in manifest)
+        print("finished: %d files, %d -> %d (%6.2f %%) in %.2f s on %d GPU(s)"
+              % (len(manifest), total_in, total_out, 100.0 * total_out / max(1, total_in), dt, world))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+    return 0
