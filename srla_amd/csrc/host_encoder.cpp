@@ -239,7 +239,7 @@ struct Impl {
     bool lshift_on_device = false;
     PinBuf h_or;
     uint32_t kSlots = 4;              /* job buffer sets (SRLA_MI355X_SLOTS); slot i runs on stream i % kStreams */
-    uint64_t job_samples = 2ull << 20; /* samples per job (SRLA_MI355X_JOB_SAMPLES) */
+    uint64_t job_samples = 4ull << 20; /* samples per job (SRLA_MI355X_JOB_SAMPLES): fixed per-job latencies (serial solve chain, launch gaps) favour large jobs; measured best for long streams, and never worse than smaller ones for short streams */
     Slot slot[kMaxSlots];
     DevBuf d_tw, d_geoms, d_thr, d_huff, d_huffcode, d_pos, d_or;
     bool timing = true;               /* stage timing events (SRLA_MI355X_NO_TIMING drops them) */
