@@ -104,6 +104,47 @@ struct PinBuf {
     template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
+/* ---- staging copy: pageable planes -> pinned buffer, with the OR of the samples as a by-product ---------
+ * The pinned buffer is only read by the DMA engine afterwards, so the stores bypass the cache (no read-for-ownership
+ * traffic): about 1.5x the throughput of memcpy for this pattern. */
+#if defined(__x86_64__)
+#include <immintrin.h>
+__attribute__((target("avx2"))) static uint32_t copy_or_avx2(int32_t *dst, const int32_t *src, size_t n)
+{
+    uint32_t m = 0;
+    size_t k = 0;
+    while (k < n && (reinterpret_cast<uintptr_t>(dst + k) & 31u)) { const int32_t x = src[k]; dst[k] = x; m |= (uint32_t)x; k++; }
+    __m256i acc = _mm256_setzero_si256();
+    for (; k + 32 <= n; k += 32) {
+        const __m256i a = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(src + k));
+        const __m256i b = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(src + k + 8));
+        const __m256i c = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(src + k + 16));
+        const __m256i d = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(src + k + 24));
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(dst + k), a);
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(dst + k + 8), b);
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(dst + k + 16), c);
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(dst + k + 24), d);
+        acc = _mm256_or_si256(acc, _mm256_or_si256(_mm256_or_si256(a, b), _mm256_or_si256(c, d)));
+    }
+    alignas(32) uint32_t lanes[8];
+    _mm256_store_si256(reinterpret_cast<__m256i *>(lanes), acc);
+    for (int i = 0; i < 8; i++) m |= lanes[i];
+    for (; k < n; k++) { const int32_t x = src[k]; dst[k] = x; m |= (uint32_t)x; }
+    _mm_sfence();
+    return m;
+}
+#endif
+static uint32_t copy_or(int32_t *dst, const int32_t *src, size_t n)
+{
+#if defined(__x86_64__)
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    if (avx2) return copy_or_avx2(dst, src, n);
+#endif
+    uint32_t m = 0;
+    for (size_t k = 0; k < n; k++) { const int32_t x = src[k]; dst[k] = x; m |= (uint32_t)x; }
+    return m;
+}
+
 /* ---- a tiny persistent thread pool for the bit pack ------------------------------------- */
 class Pool {
 public:
@@ -245,6 +286,13 @@ struct Impl {
     bool timing = true;               /* stage timing events (SRLA_MI355X_NO_TIMING drops them) */
     uint32_t timing_stride = 4;       /* every n-th job carries start events on all stages (SRLA_MI355X_TIMING_STRIDE) */
     bool in_pinned = false;           /* this call's input planes are pinned host memory */
+    /* Host input without a callback: the stream is encoded assuming offset shift 0 while the staging copies gather the
+     * OR of all samples; only if that OR has trailing zeros (rare for audio) the stream is encoded again with the
+     * right shift.  Saves a separate pass over the input before the first kernel can start. */
+    bool spec_or_active = false;
+    std::atomic<uint32_t> spec_or{ 0 };
+    int forced_lshift = -1;           /* >= 0: the shift is known (second attempt) */
+    bool no_speculation = false;      /* SRLA_MI355X_NO_SPECULATION */
     bool force_staging = false;       /* SRLA_MI355X_STAGING: never write the caller's buffer from the device */
     std::map<uint32_t, uint32_t> tw_index;   /* nfft -> offset (double2) */
     std::vector<double> tw_host;
@@ -338,6 +386,7 @@ struct Impl {
         if (!d_pos.ensure(64)) return false;
         HIP_OK(hipMemset(d_pos.p, 0, 64));
         force_staging = getenv("SRLA_MI355X_STAGING") != nullptr;
+        no_speculation = getenv("SRLA_MI355X_NO_SPECULATION") != nullptr;
         timing = getenv("SRLA_MI355X_NO_TIMING") == nullptr;
         if (const char *e = getenv("SRLA_MI355X_TIMING_STRIDE")) { const int v = atoi(e); if (v >= 1) timing_stride = (uint32_t)v; }
         if (!d_or.ensure(64)) return false;
@@ -580,18 +629,34 @@ struct Impl {
         if (!d_in) {
             if ((!in_pinned && !s.h_in.ensure((size_t)nch * job.ns * 4)) || !s.d_input.ensure((size_t)nch * job.ns * 4)) return false;
             if (in_pinned) {
-                /* the caller's planes are pinned: DMA straight out of them */
+                /* the caller's planes are pinned: DMA straight out of them (the OR of the job's samples, when it is
+                 * still being gathered, is computed by the pool threads meanwhile) */
                 for (uint32_t ch = 0; ch < nch; ch++)
                     HIP_OK(hipMemcpyAsync(s.d_input.as<int32_t>() + (size_t)ch * job.ns, host_in[ch] + job.s0, (size_t)job.ns * 4,
                                           hipMemcpyHostToDevice, upload));
+                if (spec_or_active) {
+                    const uint32_t chunk = 256u << 10, per_ch = (job.ns + chunk - 1) / chunk;
+                    const Job *jb = &job;
+                    pool->parallel_for(per_ch * nch, [&](uint32_t i) {
+                        const uint32_t ch = i / per_ch, o = (i % per_ch) * chunk, len = std::min(chunk, jb->ns - o);
+                        const int32_t *src = host_in[ch] + jb->s0 + o;
+                        uint32_t m = 0;
+                        for (uint32_t k = 0; k < len; k++) m |= (uint32_t)src[k];
+                        spec_or.fetch_or(m, std::memory_order_relaxed);
+                    });
+                }
             } else {
                 /* pageable -> pinned staging on the pool threads, then one DMA on the upload stream */
                 const uint32_t chunk = 256u << 10, per_ch = (job.ns + chunk - 1) / chunk;
                 int32_t *dst = s.h_in.as<int32_t>();
                 const Job *jb = &job;
+                const bool track = spec_or_active;
                 pool->parallel_for(per_ch * nch, [&](uint32_t i) {
-                    const uint32_t ch = i / per_ch, o = (i % per_ch) * chunk;
-                    memcpy(dst + (size_t)ch * jb->ns + o, host_in[ch] + jb->s0 + o, (size_t)std::min(chunk, jb->ns - o) * 4);
+                    const uint32_t ch = i / per_ch, o = (i % per_ch) * chunk, len = std::min(chunk, jb->ns - o);
+                    const int32_t *src = host_in[ch] + jb->s0 + o;
+                    int32_t *d = dst + (size_t)ch * jb->ns + o;
+                    const uint32_t m = copy_or(d, src, len);   /* the copy also gathers the OR of the samples it moves */
+                    if (track) spec_or.fetch_or(m, std::memory_order_relaxed);
                 });
                 HIP_OK(hipMemcpyAsync(s.d_input.p, s.h_in.p, (size_t)nch * job.ns * 4, hipMemcpyHostToDevice, upload));
             }
@@ -782,6 +847,7 @@ struct Impl {
         const auto t0 = Clock::now();
         const uint32_t nch = par.num_channels;
         uint32_t write_off = 0;
+        spec_or_active = false;
         in_pinned = false;
         if (host_in && !force_staging) {
             in_pinned = true;
@@ -794,7 +860,15 @@ struct Impl {
         if (with_header) {
             /* offset left shift: OR of every sample (srla_utility.c:177-203) */
             uint32_t mask = 0;
-            if (host_in) {
+            spec_or_active = false;
+            if (host_in && forced_lshift >= 0) {
+                offset_lshift = (uint32_t)forced_lshift;
+                mask = offset_lshift ? (1u << offset_lshift) : 1u;       /* reproduces the shift below */
+            } else if (host_in && cb == nullptr && !no_speculation) {
+                spec_or_active = true;
+                spec_or.store(0);
+                mask = 1u;                                               /* assume shift 0 */
+            } else if (host_in) {
                 const uint32_t chunk = 1u << 20, per_ch = (num_samples + chunk - 1) / chunk;
                 std::atomic<uint32_t> acc{ 0 };
                 pool->parallel_for(per_ch * nch, [&](uint32_t i) {
@@ -863,6 +937,7 @@ struct Impl {
             if (upload) (void)hipStreamSynchronize(upload);
             for (auto &sl : slot) sl.busy = false;
             lshift_on_device = false;
+            spec_or_active = false;
             return rc;
         };
         auto job_slot = [&](uint32_t k) -> Slot & { return slot[plan[k].slot]; };
@@ -919,6 +994,19 @@ struct Impl {
             write_off += wrote;
         }
         lshift_on_device = false;
+        if (spec_or_active) {
+            spec_or_active = false;
+            const uint32_t m = spec_or.load();
+            uint32_t sh = 0;
+            if (m != 0) while (((m >> sh) & 1u) == 0) sh++;
+            if (sh != 0) {
+                /* the assumption was wrong: encode again with the shift that the whole stream has */
+                forced_lshift = (int)sh;
+                const SRLAApiResult rc = encode_stream(host_in, d_in, d_stride, num_samples, data, data_size, output_size, cb, with_header, search);
+                forced_lshift = -1;
+                return rc;
+            }
+        }
         *output_size = write_off;
         stats.total_ms += ms_since(t0);
         return SRLA_APIRESULT_OK;
