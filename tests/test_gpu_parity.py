@@ -334,3 +334,24 @@ def test_random_configurations_match_the_oracle(product):
     import gpu_sweep
     done, bad = gpu_sweep.sweep(60, 3, max_samples=1_500_000)
     assert done >= 40 and bad == 0
+
+
+@pytest.mark.parametrize("pinned", [False, True])
+@pytest.mark.parametrize("with_callback", [False, True])
+def test_offset_shift_found_after_the_fact(product, pinned, with_callback):
+    """Host input is encoded assuming shift 0 while the staging copies gather the OR (no callback), or after an OR pass
+    (callback); a stream whose samples share trailing zeros must come out with the right shift either way."""
+    import torch
+    pcm = (helpers.synth(helpers.MUSIC, 98, 48000, 2, 600000) >> 3) << 3
+    want = helpers.Oracle(2, **M4).encode_whole(pcm)
+    assert want[24] == 3
+    src = torch.from_numpy(pcm).pin_memory().numpy() if pinned else pcm
+    cfg, par = capi.cli_setup(2, 16, 48000, **M4)
+    enc = product.create(cfg)
+    assert product.set_parameter(enc, par) == capi.OK
+    seen = []
+    rc, got = product.encode_whole(enc, src, callback=(lambda t, p, d, s: seen.append(s)) if with_callback else None)
+    product.destroy(enc)
+    assert rc == capi.OK and np.array_equal(got, want)
+    if with_callback:
+        assert sum(seen) == want.size - 30
