@@ -444,7 +444,7 @@ __global__ __launch_bounds__(NT) void srla_autocorr(
             }
             sm->preemph_coef = c;
             /* this pass initialises the item record */
-            out->preemph_prev = load_variant(in, iv, it.variant, 0);
+            out->preemph_prev = v[0][0];      /* thread 0 holds sample 0 (not yet pre-emphasised) */
             out->preemph_coef = c;
             out->lpc_order = 0; out->lpc_rshift = 0; out->use_sum = 0; out->ltp_period = 0;
             out->ltp_coef[0] = 0; out->ltp_coef[1] = 0; out->ltp_coef[2] = 0;
@@ -505,27 +505,44 @@ __global__ __launch_bounds__(NT) void srla_autocorr(
     {
         const double norm_bps = __builtin_ldexp(1.0, -(int)(bps - 1));
         const uint32_t half = n >> 1;
+        /* weight(e) = (divisor * smpl) * (n - 1 - smpl), smpl = e in the first half and n - 1 - e in the second:
+         * both factors are small integers, so they are formed as doubles by exact additions from one conversion per
+         * thread instead of two int -> double conversions per sample (quarter-rate instructions) */
+        const double d_tid4 = (double)(4u * tid), d_nm1 = (double)(n - 1u);
 #pragma unroll
         for (int c = 0; c < CH; c++) {
             const uint32_t i4 = 4u * (tid + (uint32_t)c * NT);
             if (i4 < nfft) {
                 double w[4];
+                const double de0 = d_tid4 + (double)(4 * c * NT);          /* (double)i4, exact */
+                const bool first = i4 + 4u <= half, second = i4 >= n - half && i4 + 4u <= n;
+                if (first || second) {
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const uint32_t e = i4 + i;
-                    double val = 0.0;
-                    if (e < n) {
-                        uint32_t smpl; bool touched = true;
-                        if (e < half) smpl = e;
-                        else if (e >= n - half) smpl = n - 1 - e;
-                        else { smpl = 0; touched = false; }   /* middle sample of an odd block */
-                        if (touched) {
-                            const double in_d = (double)v[c][i] * norm_bps;
-                            const double wt = g.welch_divisor * (double)smpl * (double)(n - 1 - smpl);
-                            val = in_d * wt;
-                        }
+                    for (int i = 0; i < 4; i++) {
+                        const double de = de0 + (double)i, dr = d_nm1 - de;   /* (double)e and (double)(n - 1 - e), exact */
+                        const double a = first ? de : dr, b = first ? dr : de;
+                        const double in_d = (double)v[c][i] * norm_bps;
+                        const double wt = g.welch_divisor * a * b;
+                        w[i] = in_d * wt;
                     }
-                    w[i] = val;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const uint32_t e = i4 + i;
+                        double val = 0.0;
+                        if (e < n) {
+                            uint32_t smpl; bool touched = true;
+                            if (e < half) smpl = e;
+                            else if (e >= n - half) smpl = n - 1 - e;
+                            else { smpl = 0; touched = false; }   /* middle sample of an odd block */
+                            if (touched) {
+                                const double in_d = (double)v[c][i] * norm_bps;
+                                const double wt = g.welch_divisor * (double)smpl * (double)(n - 1 - smpl);
+                                val = in_d * wt;
+                            }
+                        }
+                        w[i] = val;
+                    }
                 }
                 const uint32_t cb = cidx(i4 >> 1);          /* i4 / 2 is even: both slots lie in the same group of 16 */
                 buf[cb] = make_double2(w[0], w[1]);
