@@ -387,12 +387,15 @@ __global__ __launch_bounds__(NT) void srla_autocorr(
     SrlaItemResult *out = &results[item_idx];
 
     int32_t v[CH][4];
-    int32_t pv[CH];
+    int32_t pv[CH], nxv[CH];
 #pragma unroll
     for (int c = 0; c < CH; c++) {
         const uint32_t i4 = 4u * (tid + (uint32_t)c * NT);
         load_chunk(in, iv, it.variant, i4, n, aligned, v[c]);
         pv[c] = (i4 == 0 || i4 >= n) ? v[c][0] : load_variant(in, iv, it.variant, i4 - 1);
+        /* the sample after the chunk (for r1), fetched together with the chunk so that no memory round trip is left
+         * for the reduction phase */
+        nxv[c] = (first_pass && i4 + 4 < n) ? load_variant(in, iv, it.variant, i4 + 4) : 0;
     }
 
     int32_t coef;
@@ -402,8 +405,7 @@ __global__ __launch_bounds__(NT) void srla_autocorr(
         uint32_t absmax = 0;
 #pragma unroll
         for (int c = 0; c < CH; c++) {
-            const uint32_t i4 = 4u * (tid + (uint32_t)c * NT);
-            const int32_t nx = (i4 + 4 < n) ? load_variant(in, iv, it.variant, i4 + 4) : 0;
+            const int32_t nx = nxv[c];
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const long long x = v[c][i];
@@ -417,42 +419,51 @@ __global__ __launch_bounds__(NT) void srla_autocorr(
         r0 = wave_sum_i64(r0); r1 = wave_sum_i64(r1); absmax = wave_max_u32(absmax);
         if (lane == 0) { sm->lscratch[wave] = r0; sm->lscratch[NWAVES + wave] = r1; sm->uscratch[wave] = absmax; }
         __syncthreads();
-        if (tid == 0) {
-            long long s0 = 0, s1 = 0; uint32_t am = 0;
-            for (int w = 0; w < NWAVES; w++) { s0 += sm->lscratch[w]; s1 += sm->lscratch[NWAVES + w]; am = (sm->uscratch[w] > am) ? sm->uscratch[w] : am; }
-            uint32_t flags = (n & 1u) ? SRLA_ITEM_ODD_LENGTH : 0u;
-            if (am == 0) flags |= SRLA_ITEM_INPUT_ZERO;
-            double d0, d1;
-            if (am < (1u << 23) && s0 < (1LL << 53)) {
-                /* every partial sum of the reference's double accumulation is an exactly representable
-                 * integer, so the summation order does not matter */
-                d0 = (double)s0; d1 = (double)s1;
-            } else {
-                /* srla_utility.c:226-240 literally (rounding depends on the order) */
-                double curr = load_variant(in, iv, it.variant, 0), succ = load_variant(in, iv, it.variant, 1);
-                d0 = 0.0; d1 = 0.0;
-                for (uint32_t i = 0; i + 2 < n; i++) {
-                    const double nn = load_variant(in, iv, it.variant, i + 2);
-                    d0 += curr * curr; d1 += curr * succ; curr = succ; succ = nn;
-                }
-                d0 += curr * curr; d1 += curr * succ; curr = succ; d0 += curr * curr;
-            }
+        /* every thread finishes the reduction and derives the tap itself (uniform values): no second barrier, no
+         * single-lane section the other 255 threads wait for */
+        long long s0 = 0, s1 = 0; uint32_t am = 0;
+        for (int w = 0; w < NWAVES; w++) { s0 += sm->lscratch[w]; s1 += sm->lscratch[NWAVES + w]; am = (sm->uscratch[w] > am) ? sm->uscratch[w] : am; }
+        uint32_t flags = (n & 1u) ? SRLA_ITEM_ODD_LENGTH : 0u;
+        if (am == 0) flags |= SRLA_ITEM_INPUT_ZERO;
+        if (am < (1u << 23) && s0 < (1LL << 53)) {
+            /* every partial sum of the reference's double accumulation is an exactly representable
+             * integer, so the summation order does not matter */
+            const double d0 = (double)s0, d1 = (double)s1;
             int32_t c = 0;
             if (!(d0 < 1e-6)) {
                 c = (int32_t)round_half_away((d1 / d0) * 16.0);
                 c = (c < -16) ? -16 : ((c > 15) ? 15 : c);
             }
-            sm->preemph_coef = c;
+            coef = c;
+        } else {
+            /* srla_utility.c:226-240 literally (rounding depends on the order): one lane, rare */
+            if (tid == 0) {
+                double curr = load_variant(in, iv, it.variant, 0), succ = load_variant(in, iv, it.variant, 1);
+                double d0 = 0.0, d1 = 0.0;
+                for (uint32_t i = 0; i + 2 < n; i++) {
+                    const double nn = load_variant(in, iv, it.variant, i + 2);
+                    d0 += curr * curr; d1 += curr * succ; curr = succ; succ = nn;
+                }
+                d0 += curr * curr; d1 += curr * succ; curr = succ; d0 += curr * curr;
+                int32_t c = 0;
+                if (!(d0 < 1e-6)) {
+                    c = (int32_t)round_half_away((d1 / d0) * 16.0);
+                    c = (c < -16) ? -16 : ((c > 15) ? 15 : c);
+                }
+                sm->preemph_coef = c;
+            }
+            __syncthreads();
+            coef = sm->preemph_coef;
+        }
+        if (tid == 0) {
             /* this pass initialises the item record */
             out->preemph_prev = v[0][0];      /* thread 0 holds sample 0 (not yet pre-emphasised) */
-            out->preemph_coef = c;
+            out->preemph_coef = coef;
             out->lpc_order = 0; out->lpc_rshift = 0; out->use_sum = 0; out->ltp_period = 0;
             out->ltp_coef[0] = 0; out->ltp_coef[1] = 0; out->ltp_coef[2] = 0;
             out->code_length = 0; out->res_code_type = 0; out->res_porder = 0; out->res_bits = 0;
             out->flags = flags; out->pad[0] = 0; out->pad[1] = 0;
         }
-        __syncthreads();
-        coef = sm->preemph_coef;
     } else {
         coef = out->preemph_coef;
     }
