@@ -58,6 +58,21 @@ typedef struct SrlaItemDesc {
     uint32_t pad;
 } SrlaItemDesc;
 
+/* What srla_autocorr needs to know about an item, in one record (item descriptor + the constants of its block
+ * length): one load at the head of the workgroup instead of a chain of three dependent ones.  The host keeps one
+ * array of these per FFT-size class. */
+typedef struct SrlaAutocorrItem {
+    uint32_t item;          /* index into the item / result tables */
+    uint32_t sample_off;
+    uint32_t n;
+    uint32_t variant;
+    uint32_t nfft;
+    uint32_t tw_off;
+    uint32_t pad0, pad1;
+    double   welch_divisor;
+    double   acorr_norm;
+} SrlaAutocorrItem;        /* 48 bytes */
+
 /* What kernel A leaves per item (everything SRLAEncoderCoefficient carries + costs). */
 typedef struct SrlaItemResult {
     int32_t  preemph_prev;

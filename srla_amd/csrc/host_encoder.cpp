@@ -236,7 +236,7 @@ struct Job {
     uint32_t num_slots = 0;
     uint64_t res_elems = 0;
     uint64_t analyzed_samples = 0;
-    std::vector<uint32_t> class_index; /* item indices grouped by FFT-size class (srla_autocorr launches per class) */
+    std::vector<SrlaAutocorrItem> class_index; /* the items grouped by FFT-size class (srla_autocorr launches per class) */
     uint32_t class_first[3] = {}, class_count[3] = {};   /* N' <= 2048, 4096, 8192 */
     uint64_t key = 0;                 /* geometry signature: equal keys => identical descriptor tables */
     bool uploaded = false;            /* the slot's device copies match the tables above */
@@ -552,7 +552,14 @@ struct Impl {
             for (uint32_t i = 0; i < job.items.size(); i++) {
                 const uint32_t nfft = geoms[job.items[i].geom].nfft;
                 const int cls = (nfft <= 2048u) ? 0 : ((nfft <= 4096u) ? 1 : 2);
-                if (cls == c) job.class_index.push_back(i);
+                if (cls == c) {
+                    const SrlaItemDesc &it = job.items[i];
+                    const SrlaGeom &gm = geoms[it.geom];
+                    SrlaAutocorrItem ai{};
+                    ai.item = i; ai.sample_off = it.sample_off; ai.n = it.n; ai.variant = it.variant;
+                    ai.nfft = gm.nfft; ai.tw_off = gm.tw_off; ai.welch_divisor = gm.welch_divisor; ai.acorr_norm = gm.acorr_norm;
+                    job.class_index.push_back(ai);
+                }
             }
             job.class_count[c] = (uint32_t)job.class_index.size() - job.class_first[c];
         }
@@ -601,7 +608,7 @@ struct Impl {
             if (!s.d_cands.ensure(n_cands * sizeof(SrlaCandDesc))) return false;
             if (!s.d_windows.ensure(n_win * sizeof(SrlaWindowDesc))) return false;
             const void *px = s.d_class_index.p;
-            if (!s.d_class_index.ensure(std::max<size_t>(1, n_items) * 4)) return false;
+            if (!s.d_class_index.ensure(std::max<size_t>(1, n_items) * sizeof(SrlaAutocorrItem))) return false;
             if (pi != s.d_items.p || pc != s.d_cands.p || pw != s.d_windows.p || px != s.d_class_index.p) job.uploaded = false;
         }
         if (!s.d_results.ensure(std::max<size_t>(1, n_items) * sizeof(SrlaItemResult))) return false;
@@ -667,7 +674,7 @@ struct Impl {
         }
         if (!job.uploaded) {
             if (n_items) HIP_OK(hipMemcpyAsync(s.d_items.p, job.items.data(), n_items * sizeof(SrlaItemDesc), hipMemcpyHostToDevice, W));
-            if (n_items) HIP_OK(hipMemcpyAsync(s.d_class_index.p, job.class_index.data(), n_items * 4, hipMemcpyHostToDevice, W));
+            if (n_items) HIP_OK(hipMemcpyAsync(s.d_class_index.p, job.class_index.data(), n_items * sizeof(SrlaAutocorrItem), hipMemcpyHostToDevice, W));
             HIP_OK(hipMemcpyAsync(s.d_cands.p, job.cands.data(), n_cands * sizeof(SrlaCandDesc), hipMemcpyHostToDevice, W));
             HIP_OK(hipMemcpyAsync(s.d_windows.p, job.windows.data(), n_win * sizeof(SrlaWindowDesc), hipMemcpyHostToDevice, W));
             job.uploaded = true;
@@ -711,7 +718,7 @@ struct Impl {
                     const int c = seq[i].cls;
                     rc |= srla_launch_autocorr(W, kClass[c], &jp, s.in_cur, s.d_items.as<SrlaItemDesc>(), d_geoms.as<SrlaGeom>(), d_tw.p,
                                                (uint32_t)seq[i].pass, s.d_results.as<SrlaItemResult>(), s.d_lags.as<double>(), dbg,
-                                               s.d_class_index.as<uint32_t>() + job.class_first[c], job.class_count[c], e0, e1);
+                                               s.d_class_index.as<SrlaAutocorrItem>() + job.class_first[c], job.class_count[c], e0, e1);
                 } else {
                     rc |= srla_launch_pitch_solve(W, &jp, s.d_lags.as<double>(), s.d_results.as<SrlaItemResult>(), e0, e1);
                 }

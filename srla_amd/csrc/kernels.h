@@ -28,12 +28,12 @@ uint32_t srla_kernel_fast_lds_bytes(uint32_t fl);   /* LDS of the 1024*fl-sample
 #define SRLA_FIR_PAD 256
 
 /* pass 0: LPC lags (initialises the item record unless an LTP pass ran first), pass 1: LTP lags.
- * One launch per FFT-size class (rclass = 1, 2, 4 for N' <= 2048, 4096, 8192): item_index lists the `count`
- * items of the class (nullptr: items 0..count-1). */
+ * One launch per FFT-size class (rclass = 1, 2, 4 for N' <= 2048, 4096, 8192): class_items holds the `count`
+ * items of the class. */
 int srla_launch_autocorr(hipStream_t stream, int rclass, const SrlaJobParams *jp, const int32_t *input,
                          const SrlaItemDesc *items, const SrlaGeom *geoms, const void *twiddles,
                          uint32_t pass, SrlaItemResult *results, double *lags_ws, double *dbg,
-                         const uint32_t *item_index, uint32_t count, hipEvent_t ev_start, hipEvent_t ev_stop);
+                         const SrlaAutocorrItem *class_items, uint32_t count, hipEvent_t ev_start, hipEvent_t ev_stop);
 int srla_launch_pitch_solve(hipStream_t stream, const SrlaJobParams *jp, const double *lags_ws, SrlaItemResult *results,
                             hipEvent_t ev_start, hipEvent_t ev_stop);
 int srla_launch_lpc_solve(hipStream_t stream, const SrlaJobParams *jp, const SrlaItemDesc *items,

@@ -366,7 +366,7 @@ __global__ __launch_bounds__(NT) void srla_autocorr(
     SrlaJobParams jp, const int32_t *__restrict__ input, const SrlaItemDesc *__restrict__ items,
     const SrlaGeom *__restrict__ geoms, const cplx *__restrict__ twiddles, uint32_t fft_bytes, uint32_t pass,
     SrlaItemResult *__restrict__ results, double *__restrict__ lags_ws, double *__restrict__ dbg,
-    const uint32_t *__restrict__ item_index, uint32_t count)
+    const SrlaAutocorrItem *__restrict__ class_items, uint32_t count)
 {
     constexpr int CH = 2 * R;   /* chunks of four samples per thread: covers 2048 * R >= nfft */
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -377,9 +377,9 @@ __global__ __launch_bounds__(NT) void srla_autocorr(
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t pos = xcd_position(blockIdx.x, count);
     if (pos >= count) return;
-    const uint32_t item_idx = item_index ? item_index[pos] : pos;   /* items of one FFT-size class */
-    const SrlaItemDesc it = items[item_idx];
-    const SrlaGeom g = geoms[it.geom];
+    const SrlaAutocorrItem it = class_items[pos];                    /* items of one FFT-size class */
+    const uint32_t item_idx = it.item;
+    const struct { uint32_t nfft, tw_off; double welch_divisor, acorr_norm; } g = { it.nfft, it.tw_off, it.welch_divisor, it.acorr_norm };
     const uint32_t n = it.n, nfft = g.nfft, bps = jp.bits_per_sample;
     const int32_t *in = input + it.sample_off;
     const bool aligned = input_aligned(in, iv);
@@ -2268,7 +2268,7 @@ __global__ void srla_mask_to_shift(uint32_t *__restrict__ out)
 extern "C" int srla_launch_autocorr(hipStream_t stream, int rclass, const SrlaJobParams *jp, const int32_t *input,
                                     const SrlaItemDesc *items, const SrlaGeom *geoms, const void *twiddles,
                                     uint32_t pass, SrlaItemResult *results, double *lags_ws, double *dbg,
-                                    const uint32_t *item_index, uint32_t count, hipEvent_t ev_start, hipEvent_t ev_stop)
+                                    const SrlaAutocorrItem *class_items, uint32_t count, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     if (count == 0) return 0;
     /* rclass = largest FFT size of the launch / 2048.  LDS: nfft / 2 complex slots plus one pad slot per sixteen */
@@ -2280,7 +2280,7 @@ extern "C" int srla_launch_autocorr(hipStream_t stream, int rclass, const SrlaJo
     do {                                                                                                     \
         SET_LDS_ATTR(srla_autocorr<RR>);                                                                     \
         hipExtLaunchKernelGGL(srla_autocorr<RR>, grid, block, lds, stream, ev_start, ev_stop, 0, *jp, input, items, geoms,            \
-                           (const cplx *)twiddles, fft_bytes, pass, results, lags_ws, dbg, item_index, count); \
+                           (const cplx *)twiddles, fft_bytes, pass, results, lags_ws, dbg, class_items, count); \
     } while (0)
     switch (rclass) {
     case 1: LAUNCH(1); break;
