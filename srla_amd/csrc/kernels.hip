@@ -182,41 +182,54 @@ __device__ void fft_complex_lds(cplx *x, uint32_t m, int flag, const cplx *__res
     const uint32_t tid = threadIdx.x;
     uint32_t n = m, s = 1, log2s = 0;
     const uint32_t nb = m >> 2;
+    /* Index arithmetic of a stage, with q + s p = bf (p = bf >> log2 s, q = bf & (s - 1)):
+     *   inputs   q + s (p + k n/4)  = bf + k m/4          (s n = m)
+     *   outputs  q + s (4 p + k)    = (4 bf - 3 q) + k s
+     * and with the pad slot per sixteen: cidx(base + k step) = cidx(base) + k (step + step / 16) whenever step is a
+     * multiple of 16 or (for the outputs of the first two stages) base % 16 + 3 step < 16.  So each butterfly needs
+     * two padded bases and two uniform strides instead of eight padded addresses. */
+    const uint32_t m4 = m >> 2;
+    const bool affine = (m4 & 15u) == 0;                     /* m >= 64 */
+    const uint32_t rstep = m4 + (m4 >> 4);
     while (n > 2) {
-        const uint32_t n1 = n >> 2, n2 = n >> 1, n3 = n1 + n2;
+        const uint32_t n1 = n >> 2;
+        const uint32_t wstep = s + (s >> 4);
         /* uniform: which outputs can matter at all */
         const bool k1 = !PRUNE || s < need, k2 = !PRUNE || 2 * s < need, k3 = !PRUNE || 3 * s < need;
         cplx a[R], b[R], c[R], d[R], w1[R], w2[R], w3[R];
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const uint32_t bf = tid + (uint32_t)r * NT;
-            const uint32_t p = bf >> log2s, q = bf & (s - 1);
+            const uint32_t q = bf & (s - 1);
             if (bf < nb && (!PRUNE || q < need)) {
+                const uint32_t p = bf >> log2s;
                 if (k1) w1[r] = tw[p];
                 if (k2) w2[r] = tw[n1 + p];
                 if (k3) w3[r] = tw[2 * n1 + p];
-                a[r] = x[cidx(q + s * p)];
-                b[r] = x[cidx(q + s * (p + n1))];
-                c[r] = x[cidx(q + s * (p + n2))];
-                d[r] = x[cidx(q + s * (p + n3))];
+                if (affine) {
+                    const uint32_t rb = cidx(bf);
+                    a[r] = x[rb]; b[r] = x[rb + rstep]; c[r] = x[rb + 2 * rstep]; d[r] = x[rb + 3 * rstep];
+                } else {
+                    a[r] = x[cidx(bf)]; b[r] = x[cidx(bf + m4)]; c[r] = x[cidx(bf + 2 * m4)]; d[r] = x[cidx(bf + 3 * m4)];
+                }
             }
         }
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const uint32_t bf = tid + (uint32_t)r * NT;
-            const uint32_t p = bf >> log2s, q = bf & (s - 1);
+            const uint32_t q = bf & (s - 1);
             if (bf < nb && (!PRUNE || q < need)) {
                 const cplx apc = c_add(a[r], c[r]), amc = c_sub(a[r], c[r]), bpd = c_add(b[r], d[r]);
                 const cplx bmd = c_sub(b[r], d[r]);
                 /* (0, -flag) * (b - d): the reference evaluates 0*re - (-flag)*im and 0*im + (-flag)*re
                  * (fft.c:57-63, 104); for finite data that is exactly (flag*im, -flag*re) up to the sign of a zero */
                 const cplx jbmd = (flag < 0) ? make_double2(-bmd.y, bmd.x) : make_double2(bmd.y, -bmd.x);
-                const uint32_t o = q + s * (p << 2);
-                x[cidx(o)] = c_add(apc, bpd);
-                if (k1) x[cidx(o + s)] = c_mul(w1[r], c_sub(amc, jbmd));
-                if (k2) x[cidx(o + 2 * s)] = c_mul(w2[r], c_sub(apc, bpd));
-                if (k3) x[cidx(o + 3 * s)] = c_mul(w3[r], c_add(amc, jbmd));
+                const uint32_t wb = cidx(4u * bf - 3u * q);
+                x[wb] = c_add(apc, bpd);
+                if (k1) x[wb + wstep] = c_mul(w1[r], c_sub(amc, jbmd));
+                if (k2) x[wb + 2 * wstep] = c_mul(w2[r], c_sub(apc, bpd));
+                if (k3) x[wb + 3 * wstep] = c_mul(w3[r], c_add(amc, jbmd));
             }
         }
         __syncthreads();
