@@ -1364,7 +1364,7 @@ extern "C" uint32_t srla_kernel_fast_lds_bytes(uint32_t fl)
 }
 
 template <int R>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(5, 8))) void srla_residual_cost(
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(R >= 4 ? 2 : 5, 8))) void srla_residual_cost(
     SrlaJobParams jp, const int32_t *__restrict__ input, const SrlaItemDesc *__restrict__ items,
     const SrlaGeom *__restrict__ geoms, SrlaLdsPlan plan, const double *__restrict__ rice_thresholds,
     int32_t *__restrict__ res_ws, SrlaItemResult *__restrict__ results)
