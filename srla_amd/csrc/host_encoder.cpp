@@ -254,6 +254,7 @@ struct Slot {
     /* where this job's blocks go (set when the job is begun, used by the pack stage) */
     uint8_t *out_direct = nullptr;       /* device-visible caller buffer, or nullptr: stage through h_stream */
     uint32_t out_first = 1, out_init_pos = 0, out_limit = 0xFFFFFFFFu;
+    uint32_t out_boost = 1;              /* stream-out workgroup multiplier (the last jobs of a stream drain faster) */
     DevBuf d_input, d_items, d_cands, d_windows, d_results, d_res_ws, d_blocks, d_block_off, d_ctl, d_scratch, d_dbg, d_lags, d_err, d_class_index, d_stream;
     PinBuf h_in, h_stream, h_info;       /* h_info: SrlaJobInfo followed by the per-window byte counts */
     Job job;
@@ -284,6 +285,7 @@ struct Impl {
     Slot slot[kMaxSlots];
     DevBuf d_tw, d_geoms, d_thr, d_huff, d_huffcode, d_pos, d_or;
     bool timing = true;               /* stage timing events (SRLA_MI355X_NO_TIMING drops them) */
+    uint32_t tail_boost = 4, tail_boost_jobs = 3;   /* SRLA_MI355X_TAIL_BOOST="wgs,jobs" */
     uint32_t timing_stride = 4;       /* every n-th job carries start events on all stages (SRLA_MI355X_TIMING_STRIDE) */
     bool in_pinned = false;           /* this call's input planes are pinned host memory */
     /* Host input without a callback: the stream is encoded assuming offset shift 0 while the staging copies gather the
@@ -388,6 +390,7 @@ struct Impl {
         force_staging = getenv("SRLA_MI355X_STAGING") != nullptr;
         no_speculation = getenv("SRLA_MI355X_NO_SPECULATION") != nullptr;
         timing = getenv("SRLA_MI355X_NO_TIMING") == nullptr;
+        if (const char *e = getenv("SRLA_MI355X_TAIL_BOOST")) { unsigned a = 0, b = 0; if (sscanf(e, "%u,%u", &a, &b) == 2 && a >= 1) { tail_boost = a; tail_boost_jobs = b; } }
         if (const char *e = getenv("SRLA_MI355X_TIMING_STRIDE")) { const int v = atoi(e); if (v >= 1) timing_stride = (uint32_t)v; }
         if (!d_or.ensure(64)) return false;
         unsigned hw = std::thread::hardware_concurrency();
@@ -760,7 +763,7 @@ struct Impl {
                                        d_pos.as<uint32_t>(), s.d_ctl.as<uint32_t>(), s.out_first, s.out_init_pos,
                                        s.out_direct ? 1u : 0u, s.out_limit, s.d_stream.as<uint8_t>(), s.out_direct ? s.out_direct : s.h_stream.as<uint8_t>(),
                                        s.d_scratch.as<uint8_t>(), s.h_info.as<SrlaJobInfo>(),
-                                       reinterpret_cast<uint32_t *>(s.h_info.as<SrlaJobInfo>() + 1), ev0, s.t1[ST_E]);
+                                       reinterpret_cast<uint32_t *>(s.h_info.as<SrlaJobInfo>() + 1), ev0, s.t1[ST_E], s.out_boost);
             } else { if (ev0) HIP_OK(hipEventRecord(ev0, C)); HIP_OK(hipEventRecord(s.t1[ST_E], C)); }
             break;
         default: return false;
@@ -954,6 +957,7 @@ struct Impl {
             build_job(s.job, s0, ns, search);
             s.out_direct = out_direct; s.out_first = (k == 0); s.out_init_pos = init_pos; s.out_limit = data_size;
             s.timed = timing && (k % timing_stride == 0);
+            s.out_boost = (k + tail_boost_jobs >= njobs) ? tail_boost : 1u;
             return prepare_job(s, d_in ? d_in + s0 : nullptr, d_stride, host_in, false);
         };
         /* Software pipeline over jobs: iteration t enqueues  autocorr + solve of job t,  residual_cost +
@@ -1154,7 +1158,7 @@ static SRLAApiResult single_window(Impl *im, const int32_t *const *input, uint32
     /* ComputeBlockSize: run the job, read the block record, skip the pack */
     Slot &s = im->slot[0];
     im->build_job(s.job, 0, num_samples, false);
-    s.out_direct = nullptr; s.out_first = 1; s.out_init_pos = 0; s.out_limit = 0xFFFFFFFFu; s.timed = im->timing;
+    s.out_direct = nullptr; s.out_first = 1; s.out_init_pos = 0; s.out_limit = 0xFFFFFFFFu; s.timed = im->timing; s.out_boost = 1;
     if (!im->launch_job(s, nullptr, 0, input, false) || !im->wait_job(s)) return SRLA_APIRESULT_NG;
     const SrlaJobInfo *info = s.h_info.as<SrlaJobInfo>();
     if (info->error != 0 || info->num_blocks != 1) return SRLA_APIRESULT_NG;
@@ -1254,7 +1258,7 @@ SRLAApiResult SRLAMI355X_ProbeBlock(struct SRLAEncoder *encoder, const int32_t *
     if (!im->init_device()) return SRLA_APIRESULT_NG;
     Slot &s = im->slot[0];
     im->build_job(s.job, 0, num_samples, false);
-    s.out_direct = nullptr; s.out_first = 1; s.out_init_pos = 0; s.out_limit = 0xFFFFFFFFu; s.timed = im->timing;
+    s.out_direct = nullptr; s.out_first = 1; s.out_init_pos = 0; s.out_limit = 0xFFFFFFFFu; s.timed = im->timing; s.out_boost = 1;
     if (!im->launch_job(s, nullptr, 0, input, true) || !im->wait_job(s)) return SRLA_APIRESULT_NG;
     const uint32_t nv = im->num_variants();
     if (records && hipMemcpy(records, s.d_results.p, (size_t)nv * sizeof(SrlaItemResult), hipMemcpyDeviceToHost) != hipSuccess)

@@ -55,14 +55,16 @@ int srla_launch_price(hipStream_t stream, const SrlaJobParams *jp, const SrlaWin
  *   absolute    1: `dst` is the caller's (device-visible) stream buffer and blocks land at running offset + prefix;
  *               0: `dst` is a per-job pinned staging buffer and blocks land at their prefix inside the job
  *   limit       size of the caller's buffer: a job that would exceed it writes nothing and reports OVERFLOW
- *   info / window_bytes  job summary and per-window sizes (device-visible pinned host memory)            */
+ *   info / window_bytes  job summary and per-window sizes (device-visible pinned host memory)
+ *   out_boost   > 1: that many times the usual number of stream-out workgroups (the last jobs of a stream, when the
+ *               wide kernels are about to run dry and PCIe back-pressure no longer slows anything down)      */
 int srla_launch_pack(hipStream_t stream, const SrlaJobParams *jp, uint32_t num_slots,
                      const int32_t *input, const SrlaItemDesc *items, const SrlaWindowDesc *windows,
                      const SrlaBlockRecord *blocks, const SrlaItemResult *results, const int32_t *res_ws,
                      const uint32_t *huff_code, const uint8_t *huff_len, uint32_t *block_off,
                      uint32_t *stream_pos, uint32_t *ctl, uint32_t first, uint32_t init_pos, uint32_t absolute,
                      uint32_t limit, uint8_t *stage, uint8_t *dst, uint8_t *scratch, SrlaJobInfo *info, uint32_t *window_bytes,
-                     hipEvent_t ev_start, hipEvent_t ev_stop);
+                     hipEvent_t ev_start, hipEvent_t ev_stop, uint32_t out_boost);
 uint32_t srla_pack_lds_words(const SrlaJobParams *jp);
 int srla_pack_needs_scratch(const SrlaJobParams *jp);   /* blocks may exceed the LDS staging: allocate the scratch */
 

@@ -2414,7 +2414,7 @@ extern "C" int srla_launch_pack(hipStream_t stream, const SrlaJobParams *jp, uin
                                 const uint32_t *huff_code, const uint8_t *huff_len, uint32_t *block_off,
                                 uint32_t *stream_pos, uint32_t *ctl, uint32_t first, uint32_t init_pos, uint32_t absolute,
                                 uint32_t limit, uint8_t *stage, uint8_t *dst, uint8_t *scratch, SrlaJobInfo *info,
-                                uint32_t *window_bytes, hipEvent_t ev_start, hipEvent_t ev_stop)
+                                uint32_t *window_bytes, hipEvent_t ev_start, hipEvent_t ev_stop, uint32_t out_boost)
 {
     if (num_slots == 0) return 0;
     hipExtLaunchKernelGGL(srla_block_offsets, dim3(1), dim3(NT), 0, stream, ev_start, nullptr, 0, *jp, windows, blocks, results, num_slots, block_off,
@@ -2431,7 +2431,7 @@ extern "C" int srla_launch_pack(hipStream_t stream, const SrlaJobParams *jp, uin
         e = getenv("SRLA_MI355X_OUT_THREADS"); out_thr = e ? atoi(e) : NT; if (out_thr < 64 || out_thr > NT) out_thr = NT;
         e = getenv("SRLA_MI355X_OUT_SLEEP"); out_sleep = e ? atoi(e) : 0;
     }
-    hipExtLaunchKernelGGL(srla_stream_out, dim3((uint32_t)out_wgs), dim3((uint32_t)out_thr), 0, stream, nullptr, ev_stop, 0, stage, ctl, dst, (uint32_t)out_sleep);
+    hipExtLaunchKernelGGL(srla_stream_out, dim3((uint32_t)out_wgs * (out_boost ? out_boost : 1u)), dim3((uint32_t)out_thr), 0, stream, nullptr, ev_stop, 0, stage, ctl, dst, (uint32_t)out_sleep);
     return (hipGetLastError() == hipSuccess) ? 0 : -2;
 }
 
