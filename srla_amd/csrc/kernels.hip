@@ -174,7 +174,7 @@ __device__ __forceinline__ bool input_aligned(const int32_t *in, const InputView
  * multiplied by their twiddle nor stored. */
 __device__ __forceinline__ uint32_t cidx(uint32_t c) { return c + (c >> 4); }
 
-template <int R, bool PRUNE>
+template <int R, int NTK, bool PRUNE>
 __device__ void fft_complex_lds(cplx *x, uint32_t m, int flag, const cplx *__restrict__ tw, uint32_t need)
 {
     /* tw: per stage (sub-size n) three tables of n/4 entries each: w^p, w^2p, w^3p -- the host builds them with
@@ -199,7 +199,7 @@ __device__ void fft_complex_lds(cplx *x, uint32_t m, int flag, const cplx *__res
         cplx a[R], b[R], c[R], d[R], w1[R], w2[R], w3[R];
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            const uint32_t bf = tid + (uint32_t)r * NT;
+            const uint32_t bf = tid + (uint32_t)r * NTK;
             const uint32_t q = bf & (s - 1);
             if (bf < nb && (!PRUNE || q < need)) {
                 const uint32_t p = bf >> log2s;
@@ -217,7 +217,7 @@ __device__ void fft_complex_lds(cplx *x, uint32_t m, int flag, const cplx *__res
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            const uint32_t bf = tid + (uint32_t)r * NT;
+            const uint32_t bf = tid + (uint32_t)r * NTK;
             const uint32_t q = bf & (s - 1);
             if (bf < nb && (!PRUNE || q < need)) {
                 const cplx apc = c_add(a[r], c[r]), amc = c_sub(a[r], c[r]), bpd = c_add(b[r], d[r]);
@@ -242,13 +242,13 @@ __device__ void fft_complex_lds(cplx *x, uint32_t m, int flag, const cplx *__res
         cplx a[2 * R], b[2 * R];
 #pragma unroll
         for (int r = 0; r < 2 * R; r++) {
-            const uint32_t q = tid + (uint32_t)r * NT;
+            const uint32_t q = tid + (uint32_t)r * NTK;
             if (q < s && (!PRUNE || q < need)) { a[r] = x[cidx(q)]; b[r] = x[cidx(q + s)]; }
         }
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < 2 * R; r++) {
-            const uint32_t q = tid + (uint32_t)r * NT;
+            const uint32_t q = tid + (uint32_t)r * NTK;
             if (q < s && (!PRUNE || q < need)) {
                 x[cidx(q)] = c_add(a[r], b[r]);
                 if (!PRUNE || q + s < need) x[cidx(q + s)] = c_sub(a[r], b[r]);
@@ -269,6 +269,7 @@ __device__ __forceinline__ uint32_t complex_table_len(uint32_t m)
  * (fft.c:164-183) for the pair (i, N/2 - i), the power spectrum of both bins (lpc.c:357-365), and the
  * symmetry pass of the inverse real FFT on the result -- the same thread owns the same pair in all three,
  * so nothing goes back to LDS in between.  rtw_fwd / rtw_inv [i-1] = (wr, wi) for pair i. */
+template <int NTK>
 __device__ void spectrum_power_pass(cplx *x, uint32_t nfft, const cplx *__restrict__ rtw_fwd, const cplx *__restrict__ rtw_inv)
 {
     const uint32_t quarter = nfft >> 2, m = nfft >> 1;
@@ -280,7 +281,7 @@ __device__ void spectrum_power_pass(cplx *x, uint32_t nfft, const cplx *__restri
         const double pa = a * a, pb = b * b;
         x[0] = make_double2(0.5 * (pa + pb), 0.5 * (pa - pb));
     }
-    for (uint32_t i = 1 + threadIdx.x; i <= quarter; i += NT) {
+    for (uint32_t i = 1 + threadIdx.x; i <= quarter; i += NTK) {
         const bool self = (i == m - i);                       /* the middle bin pairs with itself */
         const uint32_t ia = cidx(i), ib = cidx(m - i);
         double p1, p3;
@@ -325,7 +326,7 @@ __device__ void spectrum_power_pass(cplx *x, uint32_t nfft, const cplx *__restri
 
 /* circular autocorrelation of the (already windowed, zero padded) signal in buf (lpc.c:330-376): on return
  * complex slot cidx(i/2) component i&1 holds the unscaled lag i, for i < num_lags */
-template <int R>
+template <int R, int NTK>
 __device__ void autocorr_in_place(cplx *buf, uint32_t nfft, const cplx *__restrict__ twbase, uint32_t num_lags)
 {
     const uint32_t m = nfft >> 1;
@@ -334,9 +335,9 @@ __device__ void autocorr_in_place(cplx *buf, uint32_t nfft, const cplx *__restri
     const cplx *tw_inv = twbase + ct;
     const cplx *rtw_fwd = twbase + 2 * ct;
     const cplx *rtw_inv = rtw_fwd + quarter;
-    fft_complex_lds<R, false>(buf, m, -1, tw_fwd, m);
-    spectrum_power_pass(buf, nfft, rtw_fwd, rtw_inv);
-    fft_complex_lds<R, true>(buf, m, 1, tw_inv, (num_lags + 1) >> 1);
+    fft_complex_lds<R, NTK, false>(buf, m, -1, tw_fwd, m);
+    spectrum_power_pass<NTK>(buf, nfft, rtw_fwd, rtw_inv);
+    fft_complex_lds<R, NTK, true>(buf, m, 1, tw_inv, (num_lags + 1) >> 1);
 }
 
 /* ------------------------------------------------------------ order choice (H2: libm) ----- */
@@ -365,8 +366,8 @@ __device__ __forceinline__ double inv_sqrt_cr(double x)
  *                      pass 1: LTP lags.
  * ============================================================================================== */
 struct SmallA {
-    long long lscratch[2 * NWAVES];
-    uint32_t uscratch[NWAVES];
+    long long lscratch[2 * 8];
+    uint32_t uscratch[8];
     int32_t preemph_coef;
     uint32_t flags;
     uint32_t pad[2];
@@ -374,14 +375,14 @@ struct SmallA {
 
 extern "C" uint32_t srla_kernel_small_a_bytes(void) { return (uint32_t)((sizeof(SmallA) + 15) & ~15u); }
 
-template <int R>
-__global__ __launch_bounds__(NT) void srla_autocorr(
+template <int R, int NTK>
+__global__ __launch_bounds__(NTK) void srla_autocorr(
     SrlaJobParams jp, const int32_t *__restrict__ input, const SrlaItemDesc *__restrict__ items,
     const SrlaGeom *__restrict__ geoms, const cplx *__restrict__ twiddles, uint32_t fft_bytes, uint32_t pass,
     SrlaItemResult *__restrict__ results, double *__restrict__ lags_ws, double *__restrict__ dbg,
     const SrlaAutocorrItem *__restrict__ class_items, uint32_t count)
 {
-    constexpr int CH = 2 * R;   /* chunks of four samples per thread: covers 2048 * R >= nfft */
+    constexpr int CH = 2 * R;   /* chunks of four samples per thread: covers 8 * R * NTK >= nfft */
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const InputView iv = input_view(jp);
     cplx *buf = (cplx *)lds;
@@ -403,7 +404,7 @@ __global__ __launch_bounds__(NT) void srla_autocorr(
     int32_t pv[CH], nxv[CH];
 #pragma unroll
     for (int c = 0; c < CH; c++) {
-        const uint32_t i4 = 4u * (tid + (uint32_t)c * NT);
+        const uint32_t i4 = 4u * (tid + (uint32_t)c * NTK);
         load_chunk(in, iv, it.variant, i4, n, aligned, v[c]);
         pv[c] = (i4 == 0 || i4 >= n) ? v[c][0] : load_variant(in, iv, it.variant, i4 - 1);
         /* the sample after the chunk (for r1), fetched together with the chunk so that no memory round trip is left
@@ -430,12 +431,12 @@ __global__ __launch_bounds__(NT) void srla_autocorr(
             }
         }
         r0 = wave_sum_i64(r0); r1 = wave_sum_i64(r1); absmax = wave_max_u32(absmax);
-        if (lane == 0) { sm->lscratch[wave] = r0; sm->lscratch[NWAVES + wave] = r1; sm->uscratch[wave] = absmax; }
+        if (lane == 0) { sm->lscratch[wave] = r0; sm->lscratch[8 + wave] = r1; sm->uscratch[wave] = absmax; }
         __syncthreads();
         /* every thread finishes the reduction and derives the tap itself (uniform values): no second barrier, no
          * single-lane section the other 255 threads wait for */
         long long s0 = 0, s1 = 0; uint32_t am = 0;
-        for (int w = 0; w < NWAVES; w++) { s0 += sm->lscratch[w]; s1 += sm->lscratch[NWAVES + w]; am = (sm->uscratch[w] > am) ? sm->uscratch[w] : am; }
+        for (int w = 0; w < NTK / WAVE; w++) { s0 += sm->lscratch[w]; s1 += sm->lscratch[8 + w]; am = (sm->uscratch[w] > am) ? sm->uscratch[w] : am; }
         uint32_t flags = (n & 1u) ? SRLA_ITEM_ODD_LENGTH : 0u;
         if (am == 0) flags |= SRLA_ITEM_INPUT_ZERO;
         if (am < (1u << 23) && s0 < (1LL << 53)) {
@@ -503,13 +504,13 @@ __global__ __launch_bounds__(NT) void srla_autocorr(
             const int32_t c0 = out->ltp_coef[0], c1 = out->ltp_coef[1], c2 = out->ltp_coef[2];
 #pragma unroll
             for (int c = 0; c < CH; c++) {
-                const uint32_t i4 = 4u * (tid + (uint32_t)c * NT);
+                const uint32_t i4 = 4u * (tid + (uint32_t)c * NTK);
                 if (i4 < nfft) *reinterpret_cast<int4 *>(ylds + i4) = make_int4(v[c][0], v[c][1], v[c][2], v[c][3]);
             }
             __syncthreads();
 #pragma unroll
             for (int c = 0; c < CH; c++) {
-                const uint32_t i4 = 4u * (tid + (uint32_t)c * NT);
+                const uint32_t i4 = 4u * (tid + (uint32_t)c * NTK);
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     const uint32_t s = i4 + i;
@@ -535,10 +536,10 @@ __global__ __launch_bounds__(NT) void srla_autocorr(
         const double d_tid4 = (double)(4u * tid), d_nm1 = (double)(n - 1u);
 #pragma unroll
         for (int c = 0; c < CH; c++) {
-            const uint32_t i4 = 4u * (tid + (uint32_t)c * NT);
+            const uint32_t i4 = 4u * (tid + (uint32_t)c * NTK);
             if (i4 < nfft) {
                 double w[4];
-                const double de0 = d_tid4 + (double)(4 * c * NT);          /* (double)i4, exact */
+                const double de0 = d_tid4 + (double)(4 * c * NTK);          /* (double)i4, exact */
                 const bool first = i4 + 4u <= half, second = i4 >= n - half && i4 + 4u <= n;
                 if (first || second) {
 #pragma unroll
@@ -577,10 +578,10 @@ __global__ __launch_bounds__(NT) void srla_autocorr(
     }
 
     const uint32_t num_lags = (pass == 1) ? SRLA_LTP_LAGS : (jp.max_order + 1);
-    autocorr_in_place<R>(buf, nfft, twiddles + g.tw_off, (num_lags < nfft) ? num_lags : nfft);
+    autocorr_in_place<R, NTK>(buf, nfft, twiddles + g.tw_off, (num_lags < nfft) ? num_lags : nfft);
 
     const size_t stride = jp.num_items;
-    for (uint32_t i = tid; i < num_lags; i += NT) {
+    for (uint32_t i = tid; i < num_lags; i += NTK) {
         double lag = 0.0;
         if (i < nfft) { const cplx z = buf[cidx(i >> 1)]; lag = ((i & 1u) ? z.y : z.x) * g.acorr_norm; }
         lags_ws[(size_t)i * stride + item_idx] = lag;
@@ -2288,17 +2289,19 @@ extern "C" int srla_launch_autocorr(hipStream_t stream, int rclass, const SrlaJo
     const uint32_t nfft = 2048u * (uint32_t)rclass, m = nfft >> 1;
     const uint32_t fft_bytes = ((m + (m >> 4) + 2) * 16u + 15u) & ~15u;
     const uint32_t lds = fft_bytes + srla_kernel_small_a_bytes();
-    dim3 grid(8u * ((count + 7u) >> 3)), block(NT);
-#define LAUNCH(RR)                                                                                           \
+    dim3 grid(8u * ((count + 7u) >> 3));
+    /* 8192-point items run on 512 threads (two butterflies per thread and stage): their 70 KB of LDS allow two
+     * workgroups per CU, which with 256 threads would be two wavefronts per SIMD */
+#define LAUNCH(RR, TT)                                                                                       \
     do {                                                                                                     \
-        SET_LDS_ATTR(srla_autocorr<RR>);                                                                     \
-        hipExtLaunchKernelGGL(srla_autocorr<RR>, grid, block, lds, stream, ev_start, ev_stop, 0, *jp, input, items, geoms,            \
+        SET_LDS_ATTR((srla_autocorr<RR, TT>));                                                               \
+        hipExtLaunchKernelGGL((srla_autocorr<RR, TT>), grid, dim3(TT), lds, stream, ev_start, ev_stop, 0, *jp, input, items, geoms, \
                            (const cplx *)twiddles, fft_bytes, pass, results, lags_ws, dbg, class_items, count); \
     } while (0)
     switch (rclass) {
-    case 1: LAUNCH(1); break;
-    case 2: LAUNCH(2); break;
-    case 4: LAUNCH(4); break;
+    case 1: LAUNCH(1, 256); break;
+    case 2: LAUNCH(2, 256); break;
+    case 4: LAUNCH(2, 512); break;
     default: return -1;
     }
 #undef LAUNCH
