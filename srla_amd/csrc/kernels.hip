@@ -1311,11 +1311,17 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
         {
             uint32_t fixed8 = 0;                                  /* sum over levels is not needed: per level below */
             (void)fixed8;
+            /* neighbouring coarse levels very often have the same parameter in every lane of the wavefront: then the
+             * thread's sum is the one just computed (wave-uniform test, so no lane diverges) */
+            uint32_t t = 0;
 #pragma unroll
             for (int l = 0; l <= 8; l++) {
-                uint32_t t = (uint32_t)S * code_cost_fixed(kl[l], code_type);
+                const bool same = (l > 0) && __all((int)(kl[l] == kl[l > 0 ? l - 1 : 0]));
+                if (!same) {
+                    t = (uint32_t)S * code_cost_fixed(kl[l], code_type);
 #pragma unroll
-                for (int i = 0; i < S; i++) t += code_cost_var(u[i], kl[l], code_type);
+                    for (int i = 0; i < S; i++) t += code_cost_var(u[i], kl[l], code_type);
+                }
                 acc[l] += t;
             }
             {
