@@ -57,7 +57,7 @@ def usable_cpus():
     return n
 
 
-def cpu_baseline(pcm, cli, seconds, rate):
+def cpu_baseline(pcm, cli, seconds, rate, bps=16):
     """Single-thread CPU encode of the first `seconds` of the workload (reference if it travelled here)."""
     import helpers
     from srla_amd import capi
@@ -66,11 +66,11 @@ def cpu_baseline(pcm, cli, seconds, rate):
     kind = "port"
     if os.path.exists(helpers.REF_SO):
         ref = capi.EncoderLib(helpers.REF_SO)
-        run = lambda: ref.encode(clip, sampling_rate=rate, **cli)
+        run = lambda: ref.encode(clip, bits_per_sample=bps, sampling_rate=rate, **cli)
         kind = "reference"
     else:
         def run():
-            return helpers.Oracle(clip.shape[0], sampling_rate=rate, **cli).encode_whole(clip)
+            return helpers.Oracle(clip.shape[0], bits_per_sample=bps, sampling_rate=rate, **cli).encode_whole(clip)
     run()  # warm caches / page in
     best = None
     for _ in range(2):
@@ -251,7 +251,7 @@ def main():
         # PCIe-inclusive rate of the reference's own entry point (pageable host planes in, same output buffer), best of 3
         # calls outside the timed region; reported beside `value`, never as `value`
         host_t = []
-        for _ in range(0 if diag else 3):
+        for _ in range(0 if (diag or world > 1) else 3):     # single-GPU runs only
             t1 = time.perf_counter()
             rc = lib.lib.SRLAEncoder_EncodeWhole(enc, capi.planar_ptrs(pcm), n, out.ctypes.data_as(C.c_void_p), cap, C.byref(out_size), None)
             host_t.append(time.perf_counter() - t1)
@@ -261,8 +261,8 @@ def main():
             line["host_input"] = {"value": round(n / min(host_t) / 1e6, 3), "unit": "Msamples/s", "ms_per_call": round(1e3 * min(host_t), 3),
                               "same_bytes": bool(np.array_equal(out[:out_size.value], stream)),
                               "note": "SRLAEncoder_EncodeWhole, pageable int32 planes in host memory: staging copies (which also gather the offset-shift OR) + H2D + the same device pipeline"}
-        if not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(pcm, cli, args.cpu_seconds, rate)
+        if not args.no_cpu_baseline and world == 1:        # rank 0 at N = 1 only
+            line["cpu_baseline"] = cpu_baseline(pcm, cli, args.cpu_seconds, rate, bps)
             line["speedup_vs_cpu_1core"] = round(value / line["cpu_baseline"]["value"], 2)
         print(json.dumps(line), flush=True)
     lib.destroy(enc)
