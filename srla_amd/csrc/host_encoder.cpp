@@ -4,13 +4,14 @@
  * What runs where:
  *   host    argument checking exactly as the reference API, stream header, splitting the stream
  *           into look-ahead windows, the candidate/item tables of the block-division search,
- *           host-libm constant tables, H2D/D2H staging, the multi-threaded bit pack.
- *   device  everything between samples and (residuals, parameters, block partition): kernels.hip.
+ *           host-libm constant tables, staging of host input, enqueueing, collecting finished jobs.
+ *   device  everything between samples and finished stream bytes: kernels.hip.
  *
- * A stream is processed as a sequence of jobs (ranges of whole windows).  Three job slots are
- * kept in flight: while the host packs job k the GPU runs job k+1 and already has job k+2 queued.  Windows carry no state
+ * A stream is processed as a sequence of jobs (ranges of whole windows, ~4 M samples).  The stages of consecutive
+ * jobs are enqueued skewed on three streams (software pipeline, see run_stage / encode_stream) with up to four jobs
+ * in flight; the host thread only enqueues and waits for one event per job.  Windows carry no state
  * from one to the next, so jobs are independent; only the offset left shift is a
- * whole-stream quantity and is computed first.
+ * whole-stream quantity (device-resident for device input, speculated for host input).
  *
  * There is no CPU fallback: if no HIP device can be initialised every Encode* / ComputeBlockSize
  * call fails with SRLA_APIRESULT_NG and a message on stderr.

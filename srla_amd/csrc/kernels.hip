@@ -4,22 +4,25 @@
  * The per-item analysis of ComputeCoefficientsPerChannel (srla_encoder.c:966-1205) is a pipeline of
  * kernels chosen by the SHAPE of each stage's parallelism, not by the reference's call graph:
  *
- *   srla_autocorr<R>        one workgroup per item.  Samples are loaded once with 16-byte loads and
- *                           stay in registers: exact integer correlations -> pre-emphasis tap ->
- *                           pre-emphasis (-> long-term predictor) -> Welch window -> real FFT in LDS
- *                           (fp64, operation order of libs/fft) -> |X|^2 -> inverse -> lags.
- *   srla_pitch_solve        (LTP only) ONE LANE per item: the sequential pitch scan of
- *                           lpc.c:1473-1555 and the 3x3 Cholesky solve, 64 items per wavefront.
- *   srla_lpc_recursion<L>   ONE LANE per item: Levinson-Durbin with the gamma dot product summed in index
+ *   srla_autocorr<R, T>     one workgroup per item, one launch per FFT-size class.  Samples are loaded once with
+ *                           16-byte loads and stay in registers: exact integer correlations -> pre-emphasis tap ->
+ *                           pre-emphasis (-> long-term predictor) -> Welch window -> real FFT in one padded LDS
+ *                           buffer (fp64, operation order of libs/fft) -> forward symmetry pass, |X|^2 and inverse
+ *                           symmetry pass fused -> inverse FFT pruned to the lags that are read -> lags.
+ *   srla_pitch_solve        (LTP only) ONE LANE per item: the sequential pitch scan of lpc.c:1473-1555 (lags staged
+ *                           in LDS) and the 3x3 Cholesky solve.
+ *   srla_lpc_recursion(_regs)  ONE LANE per item: Levinson-Durbin with the gamma dot product summed in index
  *                           order (lpc.c:417-438) -- inherently serial per item, so 64 recursions run side by
- *                           side in a wavefront on column-major LDS arrays.
+ *                           side in a wavefront (coefficients in registers for the preset orders, LDS otherwise).
  *   srla_order_select       one wave per item, lane = order: code-length estimate and its first strict minimum.
- *   srla_lpc_quantize<L>    one lane per item: predictor of the chosen order, 8-bit quantiser, tap cost.
- *   srla_residual_cost<R>   one workgroup per item: pre-emphasis (+LTP), register-blocked int32 FIR,
- *                           residual to HBM, partitioned (recursive) Rice code-length search.
+ *   srla_lpc_quantize(_regs)   one lane per item: predictor of the chosen order, 8-bit quantiser, tap cost.
+ *   srla_residual_cost<R>   one workgroup per item: pre-emphasis (+LTP), register-blocked int32 FIR on the 24-bit
+ *                           multiplier, residual to HBM, partitioned (recursive) Rice code-length search.
  *   srla_price_windows      stereo decision + block sizes + shortest path, one wave per window.
- *   srla_pack_blocks        codes the chosen blocks' residuals into per-channel bitstrings (prefix-summed
- *                           bit offsets) for the host bit-packer; RAW payloads; compact records.
+ *   srla_block_offsets      byte offset of every chosen block, the job's place in the stream, per-window sizes.
+ *   srla_pack_blocks        one workgroup per chosen block: the COMPLETE block (header, payload fields, Huffman
+ *                           coded taps, Rice coded residuals, Fletcher-16) assembled in LDS.
+ *   srla_stream_out         the job's finished bytes, device buffer -> host memory (one workgroup, PCIe paced).
  *   srla_or_reduce          whole-stream OR for the offset left shift.
  *
  * No MFMA: integer/fp64 butterflies and reductions, not a dense contraction.  All fp64 arithmetic
