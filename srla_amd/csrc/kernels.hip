@@ -169,13 +169,13 @@ __device__ __forceinline__ bool input_aligned(const int32_t *in, const InputView
  * reference's (Stockham) butterfly arithmetic (fft.c:71-136).  Butterfly inputs are staged in
  * registers, so one LDS buffer suffices (two barriers per stage); the stage's twiddle is fetched
  * together with the inputs so its latency overlaps the LDS reads.
- * LDS index padding (cidx): one complex slot after every sixteen, so that the stride-4 and stride-16 stores of the
- * first two stages spread over the banks.
+ * LDS slots are not padded: one pad slot per 16 (which takes the first two stages' strided stores off the same
+ * banks) was measured 2 % SLOWER than plain indexing -- the extra address arithmetic costs more than the conflicts.
  * PRUNE: only the first `need` complex outputs of the transform will be read (the inverse transform feeds a few
  * dozen lags).  Output k of butterfly (p, q) of the stage with stride s is read by a needed butterfly of a later
  * stage iff q + s k < need, so butterflies with q >= need are skipped and outputs with s k >= need are neither
  * multiplied by their twiddle nor stored. */
-__device__ __forceinline__ uint32_t cidx(uint32_t c) { return c + (c >> 4); }
+__device__ __forceinline__ uint32_t cidx(uint32_t c) { return c; }   /* slot of complex element c (identity, see above) */
 
 template <int R, int NTK, bool PRUNE>
 __device__ void fft_complex_lds(cplx *x, uint32_t m, int flag, const cplx *__restrict__ tw, uint32_t need)
@@ -188,15 +188,10 @@ __device__ void fft_complex_lds(cplx *x, uint32_t m, int flag, const cplx *__res
     /* Index arithmetic of a stage, with q + s p = bf (p = bf >> log2 s, q = bf & (s - 1)):
      *   inputs   q + s (p + k n/4)  = bf + k m/4          (s n = m)
      *   outputs  q + s (4 p + k)    = (4 bf - 3 q) + k s
-     * and with the pad slot per sixteen: cidx(base + k step) = cidx(base) + k (step + step / 16) whenever step is a
-     * multiple of 16 or (for the outputs of the first two stages) base % 16 + 3 step < 16.  So each butterfly needs
-     * two padded bases and two uniform strides instead of eight padded addresses. */
+     * i.e. each butterfly needs two bases and two uniform strides instead of eight computed addresses. */
     const uint32_t m4 = m >> 2;
-    const bool affine = (m4 & 15u) == 0;                     /* m >= 64 */
-    const uint32_t rstep = m4 + (m4 >> 4);
     while (n > 2) {
         const uint32_t n1 = n >> 2;
-        const uint32_t wstep = s + (s >> 4);
         /* uniform: which outputs can matter at all */
         const bool k1 = !PRUNE || s < need, k2 = !PRUNE || 2 * s < need, k3 = !PRUNE || 3 * s < need;
         cplx a[R], b[R], c[R], d[R], w1[R], w2[R], w3[R];
@@ -209,12 +204,7 @@ __device__ void fft_complex_lds(cplx *x, uint32_t m, int flag, const cplx *__res
                 if (k1) w1[r] = tw[p];
                 if (k2) w2[r] = tw[n1 + p];
                 if (k3) w3[r] = tw[2 * n1 + p];
-                if (affine) {
-                    const uint32_t rb = cidx(bf);
-                    a[r] = x[rb]; b[r] = x[rb + rstep]; c[r] = x[rb + 2 * rstep]; d[r] = x[rb + 3 * rstep];
-                } else {
-                    a[r] = x[cidx(bf)]; b[r] = x[cidx(bf + m4)]; c[r] = x[cidx(bf + 2 * m4)]; d[r] = x[cidx(bf + 3 * m4)];
-                }
+                a[r] = x[bf]; b[r] = x[bf + m4]; c[r] = x[bf + 2 * m4]; d[r] = x[bf + 3 * m4];
             }
         }
         __syncthreads();
@@ -228,11 +218,11 @@ __device__ void fft_complex_lds(cplx *x, uint32_t m, int flag, const cplx *__res
                 /* (0, -flag) * (b - d): the reference evaluates 0*re - (-flag)*im and 0*im + (-flag)*re
                  * (fft.c:57-63, 104); for finite data that is exactly (flag*im, -flag*re) up to the sign of a zero */
                 const cplx jbmd = (flag < 0) ? make_double2(-bmd.y, bmd.x) : make_double2(bmd.y, -bmd.x);
-                const uint32_t wb = cidx(4u * bf - 3u * q);
+                const uint32_t wb = 4u * bf - 3u * q;
                 x[wb] = c_add(apc, bpd);
-                if (k1) x[wb + wstep] = c_mul(w1[r], c_sub(amc, jbmd));
-                if (k2) x[wb + 2 * wstep] = c_mul(w2[r], c_sub(apc, bpd));
-                if (k3) x[wb + 3 * wstep] = c_mul(w3[r], c_add(amc, jbmd));
+                if (k1) x[wb + s] = c_mul(w1[r], c_sub(amc, jbmd));
+                if (k2) x[wb + 2 * s] = c_mul(w2[r], c_sub(apc, bpd));
+                if (k3) x[wb + 3 * s] = c_mul(w3[r], c_add(amc, jbmd));
             }
         }
         __syncthreads();
@@ -2294,9 +2284,9 @@ extern "C" int srla_launch_autocorr(hipStream_t stream, int rclass, const SrlaJo
                                     const SrlaAutocorrItem *class_items, uint32_t count, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     if (count == 0) return 0;
-    /* rclass = largest FFT size of the launch / 2048.  LDS: nfft / 2 complex slots plus one pad slot per sixteen */
+    /* rclass = largest FFT size of the launch / 2048.  LDS: nfft / 2 complex slots */
     const uint32_t nfft = 2048u * (uint32_t)rclass, m = nfft >> 1;
-    const uint32_t fft_bytes = ((m + (m >> 4) + 2) * 16u + 15u) & ~15u;
+    const uint32_t fft_bytes = (m * 16u + 15u) & ~15u;
     const uint32_t lds = fft_bytes + srla_kernel_small_a_bytes();
     dim3 grid(8u * ((count + 7u) >> 3));
     /* 8192-point items run on 512 threads (two butterflies per thread and stage): their 70 KB of LDS allow two
