@@ -908,11 +908,23 @@ struct Impl {
         }
         /* can the device store into the caller's buffer (pinned / registered host memory)? */
         uint8_t *out_direct = nullptr;
+        bool out_in_hbm = false;
         if (!force_staging) {
             hipPointerAttribute_t at;
             memset(&at, 0, sizeof(at));
-            if (hipPointerGetAttributes(&at, data) == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer != nullptr)
+            const hipError_t pe = hipPointerGetAttributes(&at, data);
+            if (pe == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer != nullptr)
                 out_direct = static_cast<uint8_t *>(at.devicePointer);
+            else if (pe == hipSuccess && at.type == hipMemoryTypeDevice) {
+                /* the caller wants the stream in device memory: same path, only the header needs a copy */
+                out_direct = data;
+                out_in_hbm = true;
+            } else (void)hipGetLastError();
+        }
+        if (force_staging && data != nullptr) {
+            hipPointerAttribute_t at;
+            memset(&at, 0, sizeof(at));
+            if (hipPointerGetAttributes(&at, data) == hipSuccess && at.type == hipMemoryTypeDevice) { out_direct = data; out_in_hbm = true; }
             else (void)hipGetLastError();
         }
         const uint32_t init_pos = write_off;
@@ -988,7 +1000,13 @@ struct Impl {
                     if (hipEventSynchronize(ev_or) != hipSuccess) return fail(SRLA_APIRESULT_NG);
                     offset_lshift = h_or.as<uint32_t>()[1];
                 }
-                srla::write_stream_header(stream_info(num_samples), data);
+                if (out_in_hbm) {
+                    uint8_t hdr[SRLA_HEADER_SIZE];
+                    srla::write_stream_header(stream_info(num_samples), hdr);
+                    if (hipMemcpy(data, hdr, SRLA_HEADER_SIZE, hipMemcpyHostToDevice) != hipSuccess) return fail(SRLA_APIRESULT_NG);
+                } else {
+                    srla::write_stream_header(stream_info(num_samples), data);
+                }
                 header_done = 1;
             }
             uint32_t wrote = 0;

@@ -355,3 +355,21 @@ def test_offset_shift_found_after_the_fact(product, pinned, with_callback):
     assert rc == capi.OK and np.array_equal(got, want)
     if with_callback:
         assert sum(seen) == want.size - 30
+
+
+def test_output_buffer_in_device_memory(product):
+    """`data` may be device memory: the stream (header included) is left in HBM."""
+    import torch
+    pcm = helpers.synth(helpers.MUSIC, 99, 48000, 2, 200000)
+    want = product.encode(pcm, **M4)
+    cfg, par = capi.cli_setup(2, 16, 48000, **M4)
+    enc = product.create(cfg)
+    assert product.set_parameter(enc, par) == capi.OK
+    d_out = torch.full((want.size + 1000,), 0xEE, dtype=torch.uint8, device="cuda")
+    size = C.c_uint32(0)
+    rc = product.lib.SRLAEncoder_EncodeWhole(enc, capi.planar_ptrs(pcm), pcm.shape[1], C.c_void_p(d_out.data_ptr()), d_out.numel(),
+                                             C.byref(size), None)
+    product.destroy(enc)
+    assert rc == capi.OK and size.value == want.size
+    got = d_out.cpu().numpy()
+    assert np.array_equal(got[:size.value], want) and (got[size.value:] == 0xEE).all()
