@@ -238,7 +238,7 @@ struct Job {
     uint64_t res_elems = 0;
     uint64_t analyzed_samples = 0;
     std::vector<SrlaAutocorrItem> class_index; /* the items grouped by FFT-size class (srla_autocorr launches per class) */
-    uint32_t class_first[3] = {}, class_count[3] = {};   /* N' <= 2048, 4096, 8192 */
+    uint32_t class_first[4] = {}, class_count[4] = {};   /* N' <= 1024, 2048, 4096, 8192 */
     uint64_t key = 0;                 /* geometry signature: equal keys => identical descriptor tables */
     bool uploaded = false;            /* the slot's device copies match the tables above */
 };
@@ -551,11 +551,11 @@ struct Impl {
             job.groups.push_back(g);
         }
         job.class_index.clear();
-        for (int c = 0; c < 3; c++) {
+        for (int c = 0; c < 4; c++) {
             job.class_first[c] = (uint32_t)job.class_index.size();
             for (uint32_t i = 0; i < job.items.size(); i++) {
                 const uint32_t nfft = geoms[job.items[i].geom].nfft;
-                const int cls = (nfft <= 2048u) ? 0 : ((nfft <= 4096u) ? 1 : 2);
+                const int cls = (nfft <= 1024u) ? 0 : ((nfft <= 2048u) ? 1 : ((nfft <= 4096u) ? 2 : 3));
                 if (cls == c) {
                     const SrlaItemDesc &it = job.items[i];
                     const SrlaGeom &gm = geoms[it.geom];
@@ -708,14 +708,14 @@ struct Impl {
             if (lshift_on_device) HIP_OK(hipStreamWaitEvent(W, ev_or, 0));
             if (s.used_h2d) HIP_OK(hipStreamWaitEvent(W, s.ev_in, 0));
             struct L { int kind, cls, pass; };                       /* kind 0: autocorr class launch, 1: pitch solve */
-            L seq[8]; int nl = 0;
+            L seq[12]; int nl = 0;
             if (have_items) {
                 for (int pass = (par.ltp_order > 0) ? 1 : 0; pass >= 0; pass--) {
-                    for (int c = 0; c < 3; c++) if (job.class_count[c]) seq[nl++] = { 0, c, pass };
+                    for (int c = 0; c < 4; c++) if (job.class_count[c]) seq[nl++] = { 0, c, pass };
                     if (pass == 1) seq[nl++] = { 1, 0, 1 };
                 }
             }
-            static const int kClass[3] = { 1, 2, 4 };
+            static const int kClass[4] = { 0, 1, 2, 4 };     /* FFT size / 2048 (0: at most 1024 points) */
             for (int i = 0; i < nl; i++) {
                 hipEvent_t e0 = (i == 0) ? ev0 : nullptr, e1 = (i == nl - 1) ? s.t1[ST_A] : nullptr;
                 if (seq[i].kind == 0) {

@@ -28,7 +28,7 @@ uint32_t srla_kernel_fast_lds_bytes(uint32_t fl);   /* LDS of the 1024*fl-sample
 #define SRLA_FIR_PAD 256
 
 /* pass 0: LPC lags (initialises the item record unless an LTP pass ran first), pass 1: LTP lags.
- * One launch per FFT-size class (rclass = 1, 2, 4 for N' <= 2048, 4096, 8192): class_items holds the `count`
+ * One launch per FFT-size class (rclass = 0, 1, 2, 4 for N' <= 1024, 2048, 4096, 8192): class_items holds the `count`
  * items of the class. */
 int srla_launch_autocorr(hipStream_t stream, int rclass, const SrlaJobParams *jp, const int32_t *input,
                          const SrlaItemDesc *items, const SrlaGeom *geoms, const void *twiddles,

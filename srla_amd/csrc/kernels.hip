@@ -2284,8 +2284,8 @@ extern "C" int srla_launch_autocorr(hipStream_t stream, int rclass, const SrlaJo
                                     const SrlaAutocorrItem *class_items, uint32_t count, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     if (count == 0) return 0;
-    /* rclass = largest FFT size of the launch / 2048.  LDS: nfft / 2 complex slots */
-    const uint32_t nfft = 2048u * (uint32_t)rclass, m = nfft >> 1;
+    /* rclass = largest FFT size of the launch / 2048 (0: <= 1024 points).  LDS: nfft / 2 complex slots */
+    const uint32_t nfft = rclass ? 2048u * (uint32_t)rclass : 1024u, m = nfft >> 1;
     const uint32_t fft_bytes = (m * 16u + 15u) & ~15u;
     const uint32_t lds = fft_bytes + srla_kernel_small_a_bytes();
     dim3 grid(8u * ((count + 7u) >> 3));
@@ -2298,6 +2298,7 @@ extern "C" int srla_launch_autocorr(hipStream_t stream, int rclass, const SrlaJo
                            (const cplx *)twiddles, fft_bytes, pass, results, lags_ws, dbg, class_items, count); \
     } while (0)
     switch (rclass) {
+    case 0: LAUNCH(1, 128); break;     /* <= 1024 points: 128 threads (one butterfly each), 8 KB of LDS */
     case 1: LAUNCH(1, 256); break;
     case 2: LAUNCH(2, 256); break;
     case 4: LAUNCH(2, 512); break;
