@@ -1093,7 +1093,10 @@ __device__ __forceinline__ uint32_t code_cost(uint32_t val, uint32_t k, uint32_t
 /* the part of code_cost that depends on the sample: sum it, add count * fixed(k) once */
 __device__ __forceinline__ uint32_t code_cost_var(uint32_t val, uint32_t k, uint32_t code_type)
 {
-    return (code_type == SRLA_CODE_RICE) ? (val >> k) : (__builtin_elementwise_sub_sat(val, 2u << k) >> k);
+    /* one formula for both codes: Rice is the recursive code with threshold 0 (the threshold depends on k only, so it
+     * leaves the sample loops; a select between the two forms would not) */
+    const uint32_t thr = (code_type == SRLA_CODE_RICE) ? 0u : (2u << k);
+    return __builtin_elementwise_sub_sat(val, thr) >> k;
 }
 __device__ __forceinline__ uint32_t code_cost_fixed(uint32_t k, uint32_t code_type)
 {
