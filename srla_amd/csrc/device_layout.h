@@ -68,10 +68,14 @@ typedef struct SrlaAutocorrItem {
     uint32_t variant;
     uint32_t nfft;
     uint32_t tw_off;
-    uint32_t pad0, pad1;
+    uint32_t chain_src;     /* chain mode: 1 + pool offset of the word the odd block's middle sample inherits, 0: zero */
+    uint32_t chain_dump;    /* chain mode: 1 + pool offset where the call leaves its whole FFT buffer, 0: not kept  */
+    uint32_t chain_lags;    /* chain mode, LTP lags of an FFT shorter than the 263 lags: 1 + index into the gather table
+                             * (one entry per lag from nfft on: 1 + pool offset of the word the reference reads, lpc.c:371-373) */
+    uint32_t pad0;
     double   welch_divisor;
     double   acorr_norm;
-} SrlaAutocorrItem;        /* 48 bytes */
+} SrlaAutocorrItem;        /* 56 bytes */
 
 /* What kernel A leaves per item (everything SRLAEncoderCoefficient carries + costs). */
 typedef struct SrlaItemResult {

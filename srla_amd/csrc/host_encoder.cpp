@@ -327,6 +327,9 @@ struct Impl {
             if (ev_or) (void)hipEventDestroy(ev_or);
             h_or.release();
             d_tw.release(); d_geoms.release(); d_thr.release(); d_huff.release(); d_huffcode.release(); d_pos.release(); d_or.release();
+            d_chain_pool.release(); d_chain_tab.release();
+            for (auto &b : d_chain_list) b.release();
+            for (auto &b : d_chain_select) b.release();
         }
     }
 
@@ -476,15 +479,17 @@ struct Impl {
 
     /* Candidate table of SearchOptimalBlockPartitions (srla_encoder.c:336-389) for the windows
      * [first sample s0, s0+ns) of a stream; ns ends on a window boundary or at the stream end. */
-    void build_job(Job &job, uint32_t s0, uint32_t ns, bool search)
+    /* `lens` (chain mode): the job's windows are these blocks, one candidate each, instead of the regular tiling */
+    void build_job(Job &job, uint32_t s0, uint32_t ns, bool search, const std::vector<uint32_t> *lens = nullptr)
     {
         const uint32_t minb = par.min_num_samples_per_block, maxb = par.max_num_samples_per_block;
         const uint32_t window_len = search ? par.num_lookahead_samples : maxb;
         const uint32_t nv = num_variants(), pmax = preset_order();
         /* all tables are relative to the job's first sample, so jobs of equal length share them */
-        const uint64_t key = ((uint64_t)ns << 24) ^ ((uint64_t)param_generation << 1) ^ (search ? 1u : 0u) ^ 0x8000000000000000ull;
+        const uint64_t key = lens ? 1ull : (((uint64_t)ns << 24) ^ ((uint64_t)param_generation << 1) ^ (search ? 1u : 0u) ^ 0x8000000000000000ull);
         job.s0 = s0;
-        if (job.key == key && job.ns == ns) return;
+        if (!lens && job.key == key && job.ns == ns) return;
+        if (lens) search = false;
         job.key = key; job.uploaded = false;
         job.ns = ns;
         job.windows.clear(); job.cands.clear(); job.items.clear(); job.groups.clear(); job.class_index.clear();
@@ -492,8 +497,8 @@ struct Impl {
 
         struct Pending { uint32_t cand; uint32_t nfft; };
         std::vector<Pending> analysed;
-        for (uint32_t pos = 0; pos < ns;) {
-            const uint32_t wn = std::min(window_len, ns - pos);
+        for (uint32_t pos = 0, wi = 0; pos < ns; wi++) {
+            const uint32_t wn = lens ? (*lens)[wi] : std::min(window_len, ns - pos);
             SrlaWindowDesc wd{};
             wd.sample_off = pos; wd.n = wn;
             wd.cand_base = (uint32_t)job.cands.size();
@@ -722,9 +727,9 @@ struct Impl {
                     const int c = seq[i].cls;
                     rc |= srla_launch_autocorr(W, kClass[c], &jp, s.in_cur, s.d_items.as<SrlaItemDesc>(), d_geoms.as<SrlaGeom>(), d_tw.p,
                                                (uint32_t)seq[i].pass, s.d_results.as<SrlaItemResult>(), s.d_lags.as<double>(), dbg,
-                                               s.d_class_index.as<SrlaAutocorrItem>() + job.class_first[c], job.class_count[c], e0, e1);
+                                               s.d_class_index.as<SrlaAutocorrItem>() + job.class_first[c], job.class_count[c], e0, e1, nullptr, nullptr);
                 } else {
-                    rc |= srla_launch_pitch_solve(W, &jp, s.d_lags.as<double>(), s.d_results.as<SrlaItemResult>(), e0, e1);
+                    rc |= srla_launch_pitch_solve(W, &jp, s.d_lags.as<double>(), s.d_results.as<SrlaItemResult>(), e0, e1, nullptr, 0);
                 }
             }
             if (nl == 0) { if (ev0) HIP_OK(hipEventRecord(ev0, W)); HIP_OK(hipEventRecord(s.t1[ST_A], W)); }
@@ -793,6 +798,268 @@ struct Impl {
         stats.analyze_ms = stats.autocorr_ms + stats.solve_ms + stats.residual_ms;
         s.busy = false;
         return true;
+    }
+
+    /* ---- chain mode: the odd-length tail window ------------------------------------------------------------
+     * The reference's Welch window never writes the middle word of an odd-length block (lpc.c:260-264), so that
+     * word of its persistent FFT buffer (lpc.c:58,211) still holds what the previous autocorrelation call left
+     * there: the analysis of an odd block depends on the calls before it.  With an even minimum block size only
+     * the blocks that end at the end of the stream can be odd, so only the last window of an odd-length stream is
+     * affected.  That window is encoded in "chain mode": the host lists the reference's autocorrelation calls in
+     * its order (search: every candidate block, for each M, S, then the channels, LTP lags before LPC lags,
+     * srla_encoder.c:310-424,1208-1334; then the chosen partitions once more, :1646-1698), gives every call a place
+     * in a device pool where it leaves its complete FFT buffer, and points every odd call at the word it inherits:
+     * index n/2 of the latest earlier call whose FFT was longer than n/2.  Calls are launched in rounds so that a
+     * call runs after its source; even calls need no source and all run in round 0.  The calls before the window
+     * matter only through the last block encoded before it (the "seed" job).  A fresh handle starts from zeros,
+     * as the `srla` tool's freshly mapped buffer does. */
+    struct ChainCall { uint32_t job, item, pass, n, nfft, round; int32_t src; uint32_t dump, lags; };
+    struct ChainLaunch { uint32_t round, pass, cls, first, count; };
+    struct ChainJob {
+        std::vector<SrlaAutocorrItem> list;
+        std::vector<ChainLaunch> launches;
+        std::vector<uint32_t> select;     /* per item: the round of its LTP-lag call */
+        uint32_t rounds = 0;
+    };
+    std::vector<ChainCall> chain_calls;
+    uint64_t chain_pool_used = 0;
+    std::vector<uint32_t> chain_tab;      /* gather table for the LTP lags beyond a short FFT (SrlaAutocorrItem::chain_lags) */
+    size_t chain_tab_uploaded = 0;
+    DevBuf d_chain_pool, d_chain_tab, d_chain_list[3], d_chain_select[3];
+
+    /* the reference's calls for the candidates of `job`, appended in its order; silent(off, n): the block is all zero */
+    void chain_append(uint32_t jobidx, const Job &job, const std::function<bool(uint32_t, uint32_t)> &silent)
+    {
+        const uint32_t nch = par.num_channels, nv = num_variants();
+        std::vector<uint32_t> pass1_round(job.items.size(), 0);
+        for (const SrlaCandDesc &cd : job.cands) {
+            if (cd.item_base == 0xFFFFFFFFu || silent(cd.sample_off, cd.n)) continue;   /* RAW by length / SILENT: no analysis (srla_encoder.c:766-796) */
+            for (uint32_t k = 0; k < nv; k++) {
+                const uint32_t v = (nch >= 2) ? ((k < 2) ? nch + k : k - 2) : k;        /* M, S, then the channels (srla_encoder.c:1229-1275) */
+                const uint32_t item = cd.item_base + v;
+                for (int pass = (par.ltp_order > 0) ? 1 : 0; pass >= 0; pass--) {
+                    ChainCall c{};
+                    c.job = jobidx; c.item = item; c.pass = (uint32_t)pass; c.n = cd.n; c.nfft = geoms[job.items[item].geom].nfft;
+                    c.src = -1; c.dump = (uint32_t)chain_pool_used; chain_pool_used += c.nfft;
+                    uint32_t round = (pass == 0 && par.ltp_order > 0) ? pass1_round[item] : 0;
+                    if (c.n & 1u) {
+                        const uint32_t mid = c.n >> 1;
+                        for (int64_t j = (int64_t)chain_calls.size() - 1; j >= 0; j--)
+                            if (chain_calls[(size_t)j].nfft > mid) { c.src = (int32_t)j; break; }
+                        if (c.src >= 0 && chain_calls[(size_t)c.src].job == jobidx) {
+                            /* inside a round the LTP-lag launches come first, then the pitch solve, then the LPC-lag launches */
+                            const ChainCall &sc = chain_calls[(size_t)c.src];
+                            const uint32_t need = (pass == 0 && sc.pass == 1) ? sc.round : sc.round + 1;
+                            round = std::max(round, need);
+                        }
+                    }
+                    if (pass == 1 && c.nfft < SRLA_LTP_LAGS) {
+                        /* lpc.c:371-373 copies 263 lags out of a shorter FFT buffer: the words from nfft on are those
+                         * of the latest earlier calls that reached them (zero when none did) */
+                        c.lags = (uint32_t)chain_tab.size() + 1u;
+                        const size_t base = chain_tab.size();
+                        chain_tab.resize(base + (SRLA_LTP_LAGS - c.nfft), 0u);
+                        uint32_t lo = c.nfft;
+                        for (int64_t j = (int64_t)chain_calls.size() - 1; j >= 0 && lo < SRLA_LTP_LAGS; j--) {
+                            const ChainCall &sc = chain_calls[(size_t)j];
+                            if (sc.nfft <= lo) continue;
+                            const uint32_t hi = std::min<uint32_t>(sc.nfft, SRLA_LTP_LAGS);
+                            for (uint32_t i = lo; i < hi; i++) chain_tab[base + (i - c.nfft)] = sc.dump + i + 1u;
+                            lo = hi;
+                            if (sc.job == jobidx) round = std::max(round, sc.round + 1);
+                        }
+                    }
+                    c.round = round;
+                    if (pass == 1) pass1_round[item] = round;
+                    chain_calls.push_back(c);
+                }
+            }
+        }
+    }
+
+    void chain_build(uint32_t jobidx, const Job &job, ChainJob &cj)
+    {
+        struct Entry { uint32_t round, pass, cls; SrlaAutocorrItem ai; };
+        std::vector<Entry> entries;
+        const bool ltp = par.ltp_order > 0;
+        std::vector<uint8_t> seen(job.items.size(), 0);
+        auto make = [&](uint32_t item) {
+            const SrlaItemDesc &it = job.items[item];
+            const SrlaGeom &gm = geoms[it.geom];
+            SrlaAutocorrItem ai{};
+            ai.item = item; ai.sample_off = it.sample_off; ai.n = it.n; ai.variant = it.variant;
+            ai.nfft = gm.nfft; ai.tw_off = gm.tw_off; ai.welch_divisor = gm.welch_divisor; ai.acorr_norm = gm.acorr_norm;
+            return ai;
+        };
+        auto cls_of = [](uint32_t nfft) { return (nfft <= 1024u) ? 0u : ((nfft <= 2048u) ? 1u : ((nfft <= 4096u) ? 2u : 3u)); };
+        cj.select.assign(std::max<size_t>(1, job.items.size()), 0xFFFFFFFFu);
+        cj.rounds = 1;
+        for (const ChainCall &c : chain_calls) {
+            if (c.job != jobidx) continue;
+            SrlaAutocorrItem ai = make(c.item);
+            ai.chain_dump = c.dump + 1u;
+            ai.chain_lags = c.lags;
+            if (c.src >= 0) ai.chain_src = chain_calls[(size_t)c.src].dump + (c.n >> 1) + 1u;
+            entries.push_back({ c.round, c.pass, cls_of(ai.nfft), ai });
+            if (c.pass == 1 || !ltp) cj.select[c.item] = c.round;
+            seen[c.item] = 1;
+            cj.rounds = std::max(cj.rounds, c.round + 1);
+        }
+        /* items of silent blocks: no call of the reference, but their records are still initialised by the kernel */
+        for (uint32_t i = 0; i < job.items.size(); i++)
+            if (!seen[i]) {
+                const SrlaAutocorrItem ai = make(i);
+                for (int pass = ltp ? 1 : 0; pass >= 0; pass--) entries.push_back({ 0u, (uint32_t)pass, cls_of(ai.nfft), ai });
+                cj.select[i] = 0;
+            }
+        std::stable_sort(entries.begin(), entries.end(), [](const Entry &a, const Entry &b) {
+            if (a.round != b.round) return a.round < b.round;
+            if (a.pass != b.pass) return a.pass > b.pass;
+            return a.cls < b.cls;
+        });
+        cj.list.clear(); cj.launches.clear();
+        for (const Entry &e : entries) {
+            if (cj.launches.empty() || cj.launches.back().round != e.round || cj.launches.back().pass != e.pass || cj.launches.back().cls != e.cls)
+                cj.launches.push_back({ e.round, e.pass, e.cls, (uint32_t)cj.list.size(), 0u });
+            cj.launches.back().count++;
+            cj.list.push_back(e.ai);
+        }
+    }
+
+    /* stage A of a chain job: the autocorrelation launches round by round */
+    bool chain_stage_a(Slot &s, uint32_t jobidx, const ChainJob &cj)
+    {
+        hipStream_t W = streams[0];
+        const SrlaJobParams &jp = s.jp;
+        if (!d_chain_list[jobidx].ensure(std::max<size_t>(1, cj.list.size()) * sizeof(SrlaAutocorrItem))) return false;
+        if (!d_chain_select[jobidx].ensure(cj.select.size() * 4)) return false;
+        if (!cj.list.empty()) HIP_OK(hipMemcpy(d_chain_list[jobidx].p, cj.list.data(), cj.list.size() * sizeof(SrlaAutocorrItem), hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(d_chain_select[jobidx].p, cj.select.data(), cj.select.size() * 4, hipMemcpyHostToDevice));
+        if (chain_tab.size() > chain_tab_uploaded) {
+            /* only the new entries: kernels of the jobs before may still be reading theirs */
+            if (chain_tab.size() * 4 > d_chain_tab.cap) return false;
+            HIP_OK(hipMemcpy(d_chain_tab.as<uint32_t>() + chain_tab_uploaded, chain_tab.data() + chain_tab_uploaded,
+                             (chain_tab.size() - chain_tab_uploaded) * 4, hipMemcpyHostToDevice));
+            chain_tab_uploaded = chain_tab.size();
+        }
+        if (lshift_on_device) HIP_OK(hipStreamWaitEvent(W, ev_or, 0));
+        if (s.used_h2d) HIP_OK(hipStreamWaitEvent(W, s.ev_in, 0));
+        static const int kClass[4] = { 0, 1, 2, 4 };
+        int rc = 0;
+        size_t li = 0;
+        for (uint32_t r = 0; r < cj.rounds; r++)
+            for (int pass = (par.ltp_order > 0) ? 1 : 0; pass >= 0; pass--) {
+                bool any = false;
+                for (; li < cj.launches.size() && cj.launches[li].round == r && cj.launches[li].pass == (uint32_t)pass; li++) {
+                    const ChainLaunch &l = cj.launches[li];
+                    rc |= srla_launch_autocorr(W, kClass[l.cls], &jp, s.in_cur, s.d_items.as<SrlaItemDesc>(), d_geoms.as<SrlaGeom>(), d_tw.p,
+                                               (uint32_t)pass, s.d_results.as<SrlaItemResult>(), s.d_lags.as<double>(), nullptr,
+                                               d_chain_list[jobidx].as<SrlaAutocorrItem>() + l.first, l.count, nullptr, nullptr,
+                                               d_chain_pool.as<double>(), d_chain_tab.as<uint32_t>());
+                    any = true;
+                }
+                if (pass == 1 && any)
+                    rc |= srla_launch_pitch_solve(W, &jp, s.d_lags.as<double>(), s.d_results.as<SrlaItemResult>(), nullptr, nullptr,
+                                                  d_chain_select[jobidx].as<uint32_t>(), r);
+            }
+        HIP_OK(hipEventRecord(s.t1[ST_A], W));
+        if (rc != 0) { fprintf(stderr, "[srla-mi355x] kernel launch failed in a chain stage\n"); return false; }
+        return true;
+    }
+
+    /* The last window [tail_start, tail_start + tail_n) of a stream in chain mode.  seed_n > 0: the block
+     * [seed_off, seed_off + seed_n) was the last one encoded before it. */
+    SRLAApiResult chain_tail(const int32_t *const *host_in, const int32_t *d_in, uint32_t d_stride, uint32_t tail_start, uint32_t tail_n,
+                             bool search, uint32_t seed_off, uint32_t seed_n, uint8_t *data, uint32_t data_size, uint8_t *out_direct,
+                             uint32_t init_pos, bool first_job, uint32_t write_off, uint32_t *wrote)
+    {
+        const uint32_t nch = par.num_channels, nv = num_variants(), passes = par.ltp_order > 0 ? 2u : 1u;
+        /* which blocks are all zero decides which calls exist: look at the samples */
+        auto fetch = [&](uint32_t off, uint32_t n, std::vector<int32_t> &dst) -> bool {
+            dst.resize((size_t)nch * n);
+            for (uint32_t ch = 0; ch < nch; ch++) {
+                if (host_in) memcpy(dst.data() + (size_t)ch * n, host_in[ch] + off, (size_t)n * 4);
+                else if (hipMemcpy(dst.data() + (size_t)ch * n, d_in + (size_t)ch * d_stride + off, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) return false;
+            }
+            return true;
+        };
+        std::vector<int32_t> tail_smp, seed_smp;
+        if (!fetch(tail_start, tail_n, tail_smp) || (seed_n && !fetch(seed_off, seed_n, seed_smp))) return SRLA_APIRESULT_NG;
+        auto silent_in = [nch](const std::vector<int32_t> &v, uint32_t total, uint32_t off, uint32_t n) {
+            for (uint32_t ch = 0; ch < nch; ch++) {
+                const int32_t *p = v.data() + (size_t)ch * total + off;
+                for (uint32_t i = 0; i < n; i++) if (p[i] != 0) return false;
+            }
+            return true;
+        };
+        const std::function<bool(uint32_t, uint32_t)> silent_tail = [&](uint32_t off, uint32_t n) { return silent_in(tail_smp, tail_n, off, n); };
+        const std::function<bool(uint32_t, uint32_t)> silent_seed = [&](uint32_t off, uint32_t n) { return silent_in(seed_smp, seed_n, off, n); };
+
+        chain_calls.clear();
+        chain_pool_used = 0;
+        chain_tab.clear();
+        chain_tab_uploaded = 0;
+        Slot &q = slot[0], &sj = slot[1], &e = slot[2];
+        ChainJob cq, cs, ce;
+        auto setup = [&](Slot &s) {
+            s.out_direct = nullptr; s.out_first = 1; s.out_init_pos = 0; s.out_limit = 0xFFFFFFFFu; s.timed = false; s.out_boost = 1;
+        };
+        if (seed_n) {
+            const std::vector<uint32_t> lens{ seed_n };
+            build_job(q.job, seed_off, seed_n, false, &lens);
+            chain_append(0, q.job, silent_seed);
+        }
+        if (search) {
+            sj.job.key = 0;
+            build_job(sj.job, tail_start, tail_n, true);
+            chain_append(1, sj.job, silent_tail);
+        } else {
+            const std::vector<uint32_t> lens{ tail_n };
+            build_job(e.job, tail_start, tail_n, false, &lens);
+            chain_append(2, e.job, silent_tail);
+        }
+        {
+            /* the encode job's calls are not known yet when searching: its blocks tile the window, an FFT is shorter
+             * than twice its block (or the smallest FFT size) */
+            const uint32_t max_parts = search ? (tail_n + par.min_num_samples_per_block - 1) / par.min_num_samples_per_block : 0u;
+            const uint64_t bound = chain_pool_used + (uint64_t)nv * passes * (2ull * tail_n + 64ull * max_parts);
+            if (!d_chain_pool.ensure(bound * sizeof(double))) return SRLA_APIRESULT_NG;
+            const size_t tab_bound = chain_tab.size() + (size_t)std::max(1u, max_parts) * nv * SRLA_LTP_LAGS;
+            if (!d_chain_tab.ensure(tab_bound * 4)) return SRLA_APIRESULT_NG;
+        }
+        if (seed_n) {
+            chain_build(0, q.job, cq);
+            setup(q);
+            if (!prepare_job(q, d_in ? d_in + seed_off : nullptr, d_stride, host_in, false) || !chain_stage_a(q, 0, cq)) return SRLA_APIRESULT_NG;
+        }
+        if (search) {
+            chain_build(1, sj.job, cs);
+            setup(sj);
+            if (!prepare_job(sj, d_in ? d_in + tail_start : nullptr, d_stride, host_in, false) || !chain_stage_a(sj, 1, cs)) return SRLA_APIRESULT_NG;
+            for (int st = ST_B; st <= ST_D; st++) if (!run_stage(sj, st)) return SRLA_APIRESULT_NG;
+            if (hipEventSynchronize(sj.t1[ST_D]) != hipSuccess) return SRLA_APIRESULT_NG;
+            const SrlaWindowDesc &wd = sj.job.windows[0];
+            std::vector<SrlaBlockRecord> recs(wd.num_nodes - 1);
+            if (hipMemcpy(recs.data(), sj.d_blocks.as<SrlaBlockRecord>() + wd.block_base, recs.size() * sizeof(SrlaBlockRecord), hipMemcpyDeviceToHost) != hipSuccess)
+                return SRLA_APIRESULT_NG;
+            std::vector<uint32_t> lens;
+            uint32_t covered = 0;
+            for (const SrlaBlockRecord &r : recs) if (r.valid) { lens.push_back(r.n); covered += r.n; }
+            if (covered != tail_n) { fprintf(stderr, "[srla-mi355x] internal error: the tail window's partitions cover %u of %u samples\n", covered, tail_n); return SRLA_APIRESULT_NG; }
+            sj.busy = false;
+            build_job(e.job, tail_start, tail_n, false, &lens);
+            chain_append(2, e.job, silent_tail);
+            if (chain_pool_used * sizeof(double) > d_chain_pool.cap) return SRLA_APIRESULT_NG;
+        }
+        chain_build(2, e.job, ce);
+        setup(e);
+        e.out_direct = out_direct; e.out_first = first_job ? 1u : 0u; e.out_init_pos = init_pos; e.out_limit = data_size; e.out_boost = tail_boost;
+        if (!prepare_job(e, d_in ? d_in + tail_start : nullptr, d_stride, host_in, false) || !chain_stage_a(e, 2, ce)) return SRLA_APIRESULT_NG;
+        for (int st = ST_B; st <= ST_E; st++) if (!run_stage(e, st)) return SRLA_APIRESULT_NG;
+        if (!wait_job(e)) return SRLA_APIRESULT_NG;
+        q.busy = false;
+        const uint32_t *window_bytes = nullptr;
+        return finish_job(e, data, write_off, wrote, &window_bytes);
     }
 
     /* A finished job: check the device's verdict, move the bytes to `data + write_off` unless the device wrote
@@ -936,10 +1203,22 @@ struct Impl {
          * block assembly and stream-out are pure latency (0.27 ms for a full job, 8 % of a 600 s stream's time).
          * The two tail jobs have buffer sets of their own, so that repeated calls of equal length keep finding
          * their descriptor tables cached. */
+        /* an odd-length last window goes through chain mode (see chain_tail) once everything before it is out */
+        uint32_t chain_n = 0;
+        {
+            static const bool no_chain = getenv("SRLA_MI355X_NO_CHAIN") != nullptr;
+            const uint32_t tn = num_samples % window_len;
+            const uint32_t grid = search ? par.min_num_samples_per_block : par.max_num_samples_per_block;
+            if ((tn & 1u) && (grid & 1u) == 0 && (window_len % grid) == 0 && !no_chain) chain_n = tn;
+            /* likewise an LTP analysis of a block shorter than the 263 lags reads what earlier calls left beyond its FFT
+             * (lpc.c:371-373); with a minimum block above 256 samples only the window's last block can be that short */
+            if (tn > 0 && par.ltp_order > 0 && grid > 256u && (window_len % grid) == 0 && ((tn - 1u) % grid) + 1u <= 256u && !no_chain) chain_n = tn;
+        }
+        const uint32_t body = num_samples - chain_n;
         struct JobPlan { uint32_t s0, ns, slot; };
         std::vector<JobPlan> plan;
         {
-            uint64_t nfull = num_samples / job_len, rest = num_samples - nfull * job_len;
+            uint64_t nfull = body / job_len, rest = body - nfull * job_len;
             if (rest == 0 && nfull > 0) { nfull--; rest = job_len; }
             for (uint64_t k = 0; k < nfull; k++) plan.push_back({ (uint32_t)(k * job_len), (uint32_t)job_len, (uint32_t)(k % kSlots) });
             const uint64_t small = (uint64_t)std::max<uint32_t>(1u, 262144u / window_len) * window_len;
@@ -977,6 +1256,22 @@ struct Impl {
          * pricing of job t-1,  block assembly of job t-2,  then collects job t-3.  Needs 4 buffer sets. */
         const uint32_t depth = 3;
         uint32_t header_done = with_header ? 0 : 1;
+        auto write_header = [&]() -> bool {
+            if (header_done) return true;
+            if (lshift_on_device) {
+                if (hipEventSynchronize(ev_or) != hipSuccess) return false;
+                offset_lshift = h_or.as<uint32_t>()[1];
+            }
+            if (out_in_hbm) {
+                uint8_t hdr[SRLA_HEADER_SIZE];
+                srla::write_stream_header(stream_info(num_samples), hdr);
+                if (hipMemcpy(data, hdr, SRLA_HEADER_SIZE, hipMemcpyHostToDevice) != hipSuccess) return false;
+            } else {
+                srla::write_stream_header(stream_info(num_samples), data);
+            }
+            header_done = 1;
+            return true;
+        };
         for (uint32_t t = 0; t < njobs + depth; t++) {
             const auto t_enq = Clock::now();
             if (t < njobs) {
@@ -995,20 +1290,7 @@ struct Impl {
             const uint32_t k = t - depth;
             Slot &s = job_slot(k);
             if (!wait_job(s)) return fail(SRLA_APIRESULT_NG);
-            if (!header_done) {
-                if (lshift_on_device) {
-                    if (hipEventSynchronize(ev_or) != hipSuccess) return fail(SRLA_APIRESULT_NG);
-                    offset_lshift = h_or.as<uint32_t>()[1];
-                }
-                if (out_in_hbm) {
-                    uint8_t hdr[SRLA_HEADER_SIZE];
-                    srla::write_stream_header(stream_info(num_samples), hdr);
-                    if (hipMemcpy(data, hdr, SRLA_HEADER_SIZE, hipMemcpyHostToDevice) != hipSuccess) return fail(SRLA_APIRESULT_NG);
-                } else {
-                    srla::write_stream_header(stream_info(num_samples), data);
-                }
-                header_done = 1;
-            }
+            if (!write_header()) return fail(SRLA_APIRESULT_NG);
             uint32_t wrote = 0;
             const uint32_t *window_bytes = nullptr;
             const SRLAApiResult rc = finish_job(s, data, write_off, &wrote, &window_bytes);
@@ -1021,6 +1303,27 @@ struct Impl {
                 if (cb) cb(num_samples, progress, data + off, window_bytes[w]);
                 off += window_bytes[w];
             }
+            write_off += wrote;
+        }
+        if (chain_n) {
+            if (!write_header()) return fail(SRLA_APIRESULT_NG);
+            /* the last block encoded before the window: its final call is what the window's first odd call can inherit from */
+            uint32_t seed_off = 0, seed_n = 0;
+            if (body > 0 && !search) { seed_n = par.max_num_samples_per_block; seed_off = body - seed_n; }
+            else if (body > 0) {
+                Slot &ls = job_slot(njobs - 1);
+                const SrlaWindowDesc &wd = ls.job.windows.back();
+                std::vector<SrlaBlockRecord> recs(wd.num_nodes - 1);
+                if (hipMemcpy(recs.data(), ls.d_blocks.as<SrlaBlockRecord>() + wd.block_base, recs.size() * sizeof(SrlaBlockRecord), hipMemcpyDeviceToHost) != hipSuccess)
+                    return fail(SRLA_APIRESULT_NG);
+                for (const SrlaBlockRecord &r : recs) if (r.valid) { seed_off = ls.job.s0 + r.sample_off; seed_n = r.n; }
+            }
+            uint32_t wrote = 0;
+            const SRLAApiResult rc = chain_tail(host_in, d_in, d_stride, body, chain_n, search, seed_off, seed_n, data, data_size, out_direct,
+                                                init_pos, njobs == 0, write_off, &wrote);
+            if (rc != SRLA_APIRESULT_OK) return fail(rc);
+            progress += chain_n;
+            if (cb) cb(num_samples, progress, data + write_off, wrote);
             write_off += wrote;
         }
         lshift_on_device = false;
@@ -1175,6 +1478,11 @@ static SRLAApiResult single_window(Impl *im, const int32_t *const *input, uint32
     if (!size_only)
         return im->encode_stream(input, nullptr, 0, num_samples, data, data_size, output_size, nullptr, false, search);
     /* ComputeBlockSize: run the job, read the block record, skip the pack */
+    if ((num_samples & 1u) || (im->par.ltp_order > 0 && num_samples <= 256u)) {
+        /* a history-dependent block (chain mode): its size is that of the block EncodeBlock would write */
+        std::vector<uint8_t> tmp((size_t)num_samples * im->par.num_channels * (im->par.bits_per_sample / 8) + 64);
+        return im->encode_stream(input, nullptr, 0, num_samples, tmp.data(), (uint32_t)tmp.size(), output_size, nullptr, false, search);
+    }
     Slot &s = im->slot[0];
     im->build_job(s.job, 0, num_samples, false);
     s.out_direct = nullptr; s.out_first = 1; s.out_init_pos = 0; s.out_limit = 0xFFFFFFFFu; s.timed = im->timing; s.out_boost = 1;

@@ -33,9 +33,12 @@ uint32_t srla_kernel_fast_lds_bytes(uint32_t fl);   /* LDS of the 1024*fl-sample
 int srla_launch_autocorr(hipStream_t stream, int rclass, const SrlaJobParams *jp, const int32_t *input,
                          const SrlaItemDesc *items, const SrlaGeom *geoms, const void *twiddles,
                          uint32_t pass, SrlaItemResult *results, double *lags_ws, double *dbg,
-                         const SrlaAutocorrItem *class_items, uint32_t count, hipEvent_t ev_start, hipEvent_t ev_stop);
+                         const SrlaAutocorrItem *class_items, uint32_t count, hipEvent_t ev_start, hipEvent_t ev_stop,
+                         double *chain_pool /* null outside chain mode (device_layout.h: chain_src / chain_dump) */,
+                         const uint32_t *chain_tab /* gather table of chain_lags */);
 int srla_launch_pitch_solve(hipStream_t stream, const SrlaJobParams *jp, const double *lags_ws, SrlaItemResult *results,
-                            hipEvent_t ev_start, hipEvent_t ev_stop);
+                            hipEvent_t ev_start, hipEvent_t ev_stop,
+                            const uint32_t *select /* null: every item; else only items with select[item] == round */, uint32_t round);
 int srla_launch_lpc_solve(hipStream_t stream, const SrlaJobParams *jp, const SrlaItemDesc *items,
                           const SrlaGeom *geoms, const double *lags_ws, double *err_ws, const uint8_t *huff_len,
                           SrlaItemResult *results, double *dbg, hipEvent_t ev_start, hipEvent_t ev_stop);

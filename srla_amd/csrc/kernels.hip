@@ -373,7 +373,8 @@ __global__ __launch_bounds__(NTK) void srla_autocorr(
     SrlaJobParams jp, const int32_t *__restrict__ input, const SrlaItemDesc *__restrict__ items,
     const SrlaGeom *__restrict__ geoms, const cplx *__restrict__ twiddles, uint32_t fft_bytes, uint32_t pass,
     SrlaItemResult *__restrict__ results, double *__restrict__ lags_ws, double *__restrict__ dbg,
-    const SrlaAutocorrItem *__restrict__ class_items, uint32_t count)
+    const SrlaAutocorrItem *__restrict__ class_items, uint32_t count, double *__restrict__ chain_pool,
+    const uint32_t *__restrict__ chain_tab)
 {
     constexpr int CH = 2 * R;   /* chunks of four samples per thread: covers 8 * R * NTK >= nfft */
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -474,7 +475,12 @@ __global__ __launch_bounds__(NTK) void srla_autocorr(
     } else {
         coef = out->preemph_coef;
     }
-    if (pass == 0 && jp.max_order == 0) return;   /* preset 0: fixed order 0, no LPC analysis needed */
+    /* Chain mode (the odd-length tail window of a stream, host_encoder.cpp): the launch reproduces one call of
+     * the reference on its persistent FFT buffer (lpc.c:58,211).  chain_src - 1 is where the buffer's middle word
+     * stands in chain_pool (the Welch window leaves it untouched for odd n, lpc.c:260-264); at chain_dump - 1 the
+     * call leaves the complete buffer (all nfft words of the inverse transform) for the calls after it. */
+    const bool chain = chain_pool != nullptr;
+    if (pass == 0 && jp.max_order == 0 && !chain) return;   /* preset 0: fixed order 0, no LPC analysis needed */
 
     /* pre-emphasis in registers: y[i] = x[i] - ((x[i-1] * coef) >> 4), x[-1] = x[0] (srla_utility.c:342) */
 #pragma unroll
@@ -557,6 +563,8 @@ __global__ __launch_bounds__(NTK) void srla_autocorr(
                                 const double in_d = (double)v[c][i] * norm_bps;
                                 const double wt = g.welch_divisor * (double)smpl * (double)(n - 1 - smpl);
                                 val = in_d * wt;
+                            } else if (chain && it.chain_src) {
+                                val = chain_pool[it.chain_src - 1u];
                             }
                         }
                         w[i] = val;
@@ -571,12 +579,22 @@ __global__ __launch_bounds__(NTK) void srla_autocorr(
     }
 
     const uint32_t num_lags = (pass == 1) ? SRLA_LTP_LAGS : (jp.max_order + 1);
-    autocorr_in_place<R, NTK>(buf, nfft, twiddles + g.tw_off, (num_lags < nfft) ? num_lags : nfft);
+    const bool dump = chain && it.chain_dump;
+    autocorr_in_place<R, NTK>(buf, nfft, twiddles + g.tw_off, (num_lags < nfft && !dump) ? num_lags : nfft);
+    if (dump) {
+        double *dst = chain_pool + (it.chain_dump - 1u);
+        for (uint32_t i = tid; i < nfft; i += NTK) { const cplx z = buf[cidx(i >> 1)]; dst[i] = (i & 1u) ? z.y : z.x; }
+    }
 
     const size_t stride = jp.num_items;
     for (uint32_t i = tid; i < num_lags; i += NTK) {
         double lag = 0.0;
         if (i < nfft) { const cplx z = buf[cidx(i >> 1)]; lag = ((i & 1u) ? z.y : z.x) * g.acorr_norm; }
+        else if (chain && it.chain_lags) {
+            /* the reference copies 263 lags out of a shorter FFT buffer: what earlier calls left there */
+            const uint32_t o = chain_tab[it.chain_lags - 1u + (i - nfft)];
+            if (o) lag = chain_pool[o - 1u] * g.acorr_norm;
+        }
         lags_ws[(size_t)i * stride + item_idx] = lag;
         if (dbg) dbg[(size_t)item_idx * SRLA_DBG_STRIDE + ((pass == 1) ? SRLA_DBG_LTPLAGS : SRLA_DBG_LAGS) + i] = lag;
     }
@@ -587,7 +605,8 @@ __global__ __launch_bounds__(NTK) void srla_autocorr(
  * ============================================================================================== */
 #define PITCH_ITEMS 32u
 __global__ __launch_bounds__(WAVE) void srla_pitch_solve(SrlaJobParams jp, const double *__restrict__ lags_ws,
-                                                         SrlaItemResult *__restrict__ results)
+                                                         SrlaItemResult *__restrict__ results,
+                                                         const uint32_t *__restrict__ select, uint32_t round)
 {
     /* The scan below is a chain of data-dependent loads; out of global memory each one costs a full round trip
      * (measured 0.4 ms per job).  The wavefront first copies the lags of its PITCH_ITEMS items into LDS
@@ -603,6 +622,7 @@ __global__ __launch_bounds__(WAVE) void srla_pitch_solve(SrlaJobParams jp, const
     __syncthreads();
     const uint32_t idx = first + threadIdx.x;
     if (threadIdx.x >= PITCH_ITEMS || idx >= jp.num_items) return;
+    if (select != nullptr && select[idx] != round) return;   /* chain mode: only the items whose LTP lags this round produced */
     const uint32_t lane = threadIdx.x;
     /* words 263 and 264 of the reference's lag buffer are never written: zero (fresh pages) */
     auto R = [&](uint32_t j) -> double { return (j < SRLA_LTP_LAGS) ? s_r[j * PITCH_ITEMS + lane] : 0.0; };
@@ -2284,7 +2304,8 @@ __global__ void srla_mask_to_shift(uint32_t *__restrict__ out)
 extern "C" int srla_launch_autocorr(hipStream_t stream, int rclass, const SrlaJobParams *jp, const int32_t *input,
                                     const SrlaItemDesc *items, const SrlaGeom *geoms, const void *twiddles,
                                     uint32_t pass, SrlaItemResult *results, double *lags_ws, double *dbg,
-                                    const SrlaAutocorrItem *class_items, uint32_t count, hipEvent_t ev_start, hipEvent_t ev_stop)
+                                    const SrlaAutocorrItem *class_items, uint32_t count, hipEvent_t ev_start, hipEvent_t ev_stop,
+                                    double *chain_pool, const uint32_t *chain_tab)
 {
     if (count == 0) return 0;
     /* rclass = largest FFT size of the launch / 2048 (0: <= 1024 points).  LDS: nfft / 2 complex slots */
@@ -2298,7 +2319,7 @@ extern "C" int srla_launch_autocorr(hipStream_t stream, int rclass, const SrlaJo
     do {                                                                                                     \
         SET_LDS_ATTR((srla_autocorr<RR, TT>));                                                               \
         hipExtLaunchKernelGGL((srla_autocorr<RR, TT>), grid, dim3(TT), lds, stream, ev_start, ev_stop, 0, *jp, input, items, geoms, \
-                           (const cplx *)twiddles, fft_bytes, pass, results, lags_ws, dbg, class_items, count); \
+                           (const cplx *)twiddles, fft_bytes, pass, results, lags_ws, dbg, class_items, count, chain_pool, chain_tab); \
     } while (0)
     switch (rclass) {
     case 0: LAUNCH(1, 128); break;     /* <= 1024 points: 128 threads (one butterfly each), 8 KB of LDS */
@@ -2312,12 +2333,13 @@ extern "C" int srla_launch_autocorr(hipStream_t stream, int rclass, const SrlaJo
 }
 
 extern "C" int srla_launch_pitch_solve(hipStream_t stream, const SrlaJobParams *jp, const double *lags_ws,
-                                       SrlaItemResult *results, hipEvent_t ev_start, hipEvent_t ev_stop)
+                                       SrlaItemResult *results, hipEvent_t ev_start, hipEvent_t ev_stop,
+                                       const uint32_t *select, uint32_t round)
 {
     if (jp->num_items == 0) return 0;
     const uint32_t lds = SRLA_LTP_LAGS * PITCH_ITEMS * 8u;
     SET_LDS_ATTR(srla_pitch_solve);
-    hipExtLaunchKernelGGL(srla_pitch_solve, dim3((jp->num_items + PITCH_ITEMS - 1) / PITCH_ITEMS), dim3(WAVE), lds, stream, ev_start, ev_stop, 0, *jp, lags_ws, results);
+    hipExtLaunchKernelGGL(srla_pitch_solve, dim3((jp->num_items + PITCH_ITEMS - 1) / PITCH_ITEMS), dim3(WAVE), lds, stream, ev_start, ev_stop, 0, *jp, lags_ws, results, select, round);
     return (hipGetLastError() == hipSuccess) ? 0 : -2;
 }
 

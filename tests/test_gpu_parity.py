@@ -56,8 +56,8 @@ def _fields(r):
 @pytest.mark.parametrize("kind,nch", [(helpers.MUSIC, 2), (helpers.VARIED, 2), (helpers.VARIED, 1), (helpers.NOISE, 3)])
 def test_stream_bytes_equal_oracle(product, cli_name, kind, nch):
     cli = CLIS[cli_name]
-    # lengths chosen so that no block is history dependent in the reference (odd length, or shorter than
-    # the 263 LTP lags with LTP on) -- those are covered by the 'valid and lossless' tests below
+    # lengths without history-dependent blocks (odd length, or shorter than the 263 LTP lags with LTP on): those go
+    # through chain mode and have tests of their own below
     for n in (49152 + 1000, 9000, 4100, 300):
         pcm = helpers.synth(kind, 40 + nch, 48000, nch, n)
         got = product.encode(pcm, **cli)
@@ -83,41 +83,105 @@ def test_golden_streams_from_the_reference(product, case):
 
 
 @pytest.mark.parametrize("case", ODD, ids=[c["name"] for c in ODD])
-def test_odd_length_streams_are_valid_and_lossless(product, case):
-    """Odd block lengths: the reference's LPC window leaves the middle sample to whatever its FFT buffer
-    held before (lpc.c:260-264), the device uses 0 there ('known deviations').  The stream must
-    still be a valid SRLA stream that decodes to the input, and all even-length blocks must be identical."""
+def test_odd_length_golden_streams_from_the_reference(product, case):
+    """Odd block lengths: the reference's LPC window leaves the middle sample to whatever its FFT buffer held
+    before (lpc.c:260-264), so the last window of an odd-length stream depends on the calls before it.  The library
+    encodes that window in chain mode and must reproduce the bytes `srla -e` wrote."""
     pcm = make_input(case["input"])
     got = product.encode(pcm, **case["cli"])
+    assert got.size == case["srl_size"]
+    assert helpers.sha256(got) == case["srl_sha256"]
+    if "file" in case:
+        assert np.array_equal(got, np.fromfile(os.path.join(helpers.GOLDEN, case["file"]), dtype=np.uint8))
     assert np.array_equal(helpers.oracle_decode(got), pcm)
-    want = helpers.Oracle(pcm.shape[0], **case["cli"]).encode_whole(pcm)
-    gb, wb = helpers.list_blocks(got), helpers.list_blocks(want)
-    assert sum(b[1] for b in gb) == pcm.shape[1]
-    # identical prefix: every block before the tail window
-    tail_start = (pcm.shape[1] // (4 * case["cli"]["max_block"])) * 4 * case["cli"]["max_block"]
-    pos = off = 30
-    done = 0
-    for g, w in zip(gb, wb):
-        if done + g[1] > tail_start:
-            break
-        assert g == w
-        done += g[1]
-        off += g[2]
-    assert np.array_equal(got[:off], want[:off])
 
 
-def test_short_ltp_blocks_are_valid_and_lossless(product):
-    """With LTP on, a block shorter than the 263 autocorrelation lags makes the reference read whatever
-    its FFT buffer held beyond the FFT size (lpc.c:371-373): history dependent, like odd lengths."""
+# tails of every flavour: odd (longer / shorter than a minimum block, shorter than the LTP lags), even but shorter than
+# the 263 LTP lags, streams shorter than one window or one minimum block
+TAILS = (49152 + 1001, 49152 + 4097 + 512, 32768 + 77, 32768 + 2049, 3001, 301, 4095, 9001, 49152 + 82, 32768 + 4096 + 200,
+         131, 32768 + 8192 + 255)
+
+
+@pytest.mark.parametrize("cli_name", sorted(CLIS))
+@pytest.mark.parametrize("kind,nch", [(helpers.MUSIC, 2), (helpers.VARIED, 1), (helpers.NOISE, 3)])
+def test_history_dependent_tails_equal_oracle(product, cli_name, kind, nch):
+    cli = CLIS[cli_name]
+    for n in TAILS:
+        pcm = helpers.synth(kind, 70 + nch, 48000, nch, n)
+        got = product.encode(pcm, **cli)
+        want = helpers.Oracle(nch, **cli).encode_whole(pcm)
+        assert np.array_equal(got, want), (cli_name, kind, nch, n)
+
+
+def test_short_ltp_tail_block(product):
+    """With LTP on, a block shorter than the 263 autocorrelation lags makes the reference read whatever its FFT
+    buffer held beyond the FFT size (lpc.c:371-373): history dependent, like odd lengths, and handled the same way."""
     cli = CLIS["m4_B4096_V2_P3"]
     pcm = helpers.synth(helpers.MUSIC, 42, 48000, 2, 49152 + 82)
     got = product.encode(pcm, **cli)
-    assert np.array_equal(helpers.oracle_decode(got), pcm)
+    assert np.array_equal(got, helpers.Oracle(2, **cli).encode_whole(pcm))
+
+
+def test_chain_tail_with_silence_raw_blocks_callback_and_device_input(product):
+    import torch
+    cli = dict(preset=4, max_block=4096, divisions=2)
+    n = 16384 * 3 + 4096 + 1025
+    pcm = helpers.synth(helpers.MUSIC, 77, 48000, 2, n)
+    pcm[:, 16384 * 3 + 1024:16384 * 3 + 3072] = 0            # silent candidates inside the tail window: no analysis calls
     want = helpers.Oracle(2, **cli).encode_whole(pcm)
-    gb, wb = helpers.list_blocks(got), helpers.list_blocks(want)
-    assert gb[:-1] == wb[:-1]
-    off = 30 + sum(b[2] for b in gb[:-1])
-    assert np.array_equal(got[:off], want[:off])
+    cfg, par = capi.cli_setup(2, 16, 48000, **cli)
+    enc = product.create(cfg)
+    assert product.set_parameter(enc, par) == capi.OK
+    seen = []
+    rc, data = product.encode_whole(enc, pcm, callback=lambda total, progress, ptr, size: seen.append((progress, size)))
+    assert rc == capi.OK and np.array_equal(data, want)
+    assert [s[0] for s in seen] == [16384, 32768, 49152, n]
+    assert sum(s[1] for s in seen) == data.size - 30
+    # the same stream from device memory, and into a buffer that is too small for the tail window
+    d = torch.from_numpy(pcm).cuda()
+    torch.cuda.synchronize()
+    fn = product.lib.SRLAMI355X_EncodeWholeDevice
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.c_void_p]
+    buf = np.zeros(pcm.size * 4, np.uint8); out = C.c_uint32(0)
+    rc = fn(enc, C.c_void_p(d.data_ptr()), n, n, buf.ctypes.data_as(C.c_void_p), buf.size, C.byref(out), None)
+    assert rc == capi.OK and np.array_equal(buf[:out.value], want)
+    rc, _ = product.encode_whole(enc, pcm, cap=want.size - 40)
+    assert rc == capi.INSUFFICIENT_BUFFER
+    product.destroy(enc)
+    # a stream that ends in silence, one whose tail is RAW by length (not longer than the order), a silent stream
+    for m, zero_from in ((16384 + 2049, 16384 + 1024), (16384 + 33, None), (4097, 0)):
+        x = helpers.synth(helpers.MUSIC, 78, 48000, 2, m)
+        if zero_from is not None:
+            x[:, zero_from:] = 0
+        assert np.array_equal(product.encode(x, **cli), helpers.Oracle(2, **cli).encode_whole(x)), m
+
+
+def test_odd_block_calls_on_a_fresh_handle(product):
+    """EncodeBlock / ComputeBlockSize / EncodeOptimalPartitionedBlock of odd-length input: a fresh handle starts from
+    a zeroed FFT buffer, as a fresh oracle does (calls on a used handle of the reference depend on all earlier calls)."""
+    cli = dict(preset=4, max_block=4096, divisions=2, ltp_order=3)
+    sig = helpers.synth(helpers.VARIED, 71, 48000, 2, 48000 * 2)
+    cfg, par = capi.cli_setup(2, 16, 48000, **cli)
+    enc = product.create(cfg)
+    assert product.set_parameter(enc, par) == capi.OK
+    for start, n in ((0, 4095), (48000, 1001), (30000, 301), (100, 99)):
+        blk = np.ascontiguousarray(sig[:, start:start + n])
+        rc, size = product.compute_block_size(enc, blk)
+        rc2, data = product.encode_block(enc, blk)
+        assert rc == rc2 == capi.OK
+        assert size == data.size
+        assert np.array_equal(data, helpers.Oracle(2, **cli).encode_block(blk)), (start, n)
+    win = np.ascontiguousarray(sig[:, 20000:20000 + 16384 - 1027])
+    rc, data = product.encode_partitioned(enc, win)
+    assert rc == capi.OK
+    o = helpers.Oracle(2, **cli)
+    parts = o.search_partitions(win)
+    pos, chunks = 0, []
+    for p in parts:
+        chunks.append(o.encode_block(np.ascontiguousarray(win[:, pos:pos + p])))
+        pos += p
+    assert np.array_equal(data, np.concatenate(chunks))
+    product.destroy(enc)
 
 
 def test_round_trip_and_idempotence_at_full_size(product):

@@ -3,9 +3,10 @@
 
     python tools/gpu_sweep.py [cases] [seed]
 
-Lengths are chosen so that every block is even and (with LTP) at least 263 samples long, i.e. inside the set of
-inputs for which the reference itself is history independent.  Prints one line per mismatch and a
-summary; exit status 1 on any mismatch."""
+Any length, odd ones included (the last window of such a stream is history dependent in the reference and goes
+through the library's chain mode); LTP only with minimum blocks of at least 264 samples (shorter blocks
+anywhere in the stream read stale lags in the reference, DESIGN.md 5.2).  Prints one line per mismatch and a summary;
+exit status 1 on any mismatch."""
 import os
 import random
 import sys
@@ -43,11 +44,9 @@ def sweep(cases, seed, max_samples=6_000_000):
         lookahead_factor = rnd.choice([1, 2, 4]) if divisions else 4
         if (max_block * lookahead_factor) // min_block + 1 > 65:
             continue
-        # length: whole min blocks plus an even tail that is long enough for the LTP lags
-        nblocks = rnd.randint(1, max(2, min(600000 // min_block, 3 * (2 << 20) // min_block // 4)))
-        tail = rnd.choice([0, 0, 2 * rnd.randint(132 if ltp else 1, max(133, min_block // 2 - 1))])
-        if tail >= min_block:
-            tail = 0
+        # length: whole min blocks plus any tail
+        nblocks = rnd.randint(0, max(2, min(600000 // min_block, 3 * (2 << 20) // min_block // 4)))
+        tail = rnd.choice([0, rnd.randint(1, min_block - 1), rnd.randint(1, min_block - 1)])
         n = nblocks * min_block + tail
         if n * nch > max_samples:
             n = (max_samples // nch // min_block) * min_block
