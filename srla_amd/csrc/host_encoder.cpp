@@ -245,6 +245,7 @@ struct Job {
 
 struct Slot {
     hipStream_t stream = nullptr;
+    hipStream_t own_stream = nullptr;    /* chain-mode jobs: every stage but the block assembly runs here */
     hipEvent_t t0[6] = {}, t1[6] = {};   /* start / end of the stages of the job (see Impl::run_stage) */
     hipEvent_t ev_in = nullptr;          /* the job's samples have arrived in d_input (host-input calls) */
     const int32_t *in_cur = nullptr;     /* device input of the current job */
@@ -274,9 +275,10 @@ struct Impl {
     uint32_t pack_threads = 0;
 
     bool dev_ready = false, dev_failed = false;
-    static constexpr uint32_t kMaxSlots = 8;
+    static constexpr uint32_t kMaxSlots = 11;         /* rotating + 2 tail + 3 chain-mode job buffer sets */
     static constexpr uint32_t kStreams = 3;   /* more streams than HW queues serialise badly (measured) */
     hipStream_t streams[kStreams] = {};
+    hipStream_t chain_stream = nullptr; /* autocorrelation rounds of chain mode */
     hipStream_t upload = nullptr;      /* H2D of host-input jobs: a DMA queue of its own, so uploads never wait behind kernels */
     hipEvent_t ev_or = nullptr;       /* offset-shift reduction done */
     bool lshift_on_device = false;
@@ -324,6 +326,7 @@ struct Impl {
             }
             for (auto &st : streams) if (st) (void)hipStreamDestroy(st);
             if (upload) (void)hipStreamDestroy(upload);
+            if (chain_stream) { (void)hipStreamSynchronize(chain_stream); (void)hipStreamDestroy(chain_stream); }
             if (ev_or) (void)hipEventDestroy(ev_or);
             h_or.release();
             d_tw.release(); d_geoms.release(); d_thr.release(); d_huff.release(); d_huffcode.release(); d_pos.release(); d_or.release();
@@ -342,7 +345,7 @@ struct Impl {
         if (dev_ready) return true;
         if (dev_failed) return false;
         dev_failed = true;
-        if (const char *e = getenv("SRLA_MI355X_SLOTS")) { const int v = atoi(e); if (v >= 2 && v + 2 <= (int)kMaxSlots) kSlots = (uint32_t)v; }   /* + 2 slots for the tail jobs */
+        if (const char *e = getenv("SRLA_MI355X_SLOTS")) { const int v = atoi(e); if (v >= 2 && v + 5 <= (int)kMaxSlots) kSlots = (uint32_t)v; }   /* + 2 slots for the tail jobs, + 3 for chain mode */
         if (const char *e = getenv("SRLA_MI355X_JOB_SAMPLES")) { const long long v = atoll(e); if (v >= 65536) job_samples = (uint64_t)v; }
         int count = 0;
         if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
@@ -366,6 +369,11 @@ struct Impl {
         }
         HIP_OK(hipEventCreateWithFlags(&ev_or, hipEventDisableTiming));
         HIP_OK(hipStreamCreateWithFlags(&upload, hipStreamNonBlocking));
+        {
+            int lo = 0, hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+            HIP_OK(hipStreamCreateWithPriority(&chain_stream, hipStreamNonBlocking, hi));   /* a few workgroups per launch, latency bound */
+        }
         if (!h_or.ensure(64)) return false;
         for (uint32_t si = 0; si < kMaxSlots; si++) {
             Slot &s = slot[si];
@@ -699,7 +707,9 @@ struct Impl {
     bool run_stage(Slot &s, int st)
     {
         Job &job = s.job;
-        hipStream_t W = streams[0], N = streams[1], C = streams[2];
+        /* chain-mode jobs keep to their own stream up to the pricing, so that the regular jobs never queue behind their
+         * many small dependent launches; the block assembly stays on C, where the order of the stream's blocks is made */
+        hipStream_t W = s.own_stream ? s.own_stream : streams[0], N = s.own_stream ? s.own_stream : streams[1], C = streams[2];
         const SrlaJobParams &jp = s.jp;
         double *dbg = s.want_dbg ? s.d_dbg.as<double>() : nullptr;
         const bool have_items = !job.groups.empty();
@@ -912,16 +922,18 @@ struct Impl {
                 for (int pass = ltp ? 1 : 0; pass >= 0; pass--) entries.push_back({ 0u, (uint32_t)pass, cls_of(ai.nfft), ai });
                 cj.select[i] = 0;
             }
+        /* one launch per round and pass, instantiated for the longest FFT among its items (shorter ones leave part of
+         * the workgroup idle): the launches are few and dependent, their number is what costs */
         std::stable_sort(entries.begin(), entries.end(), [](const Entry &a, const Entry &b) {
             if (a.round != b.round) return a.round < b.round;
-            if (a.pass != b.pass) return a.pass > b.pass;
-            return a.cls < b.cls;
+            return a.pass > b.pass;
         });
         cj.list.clear(); cj.launches.clear();
         for (const Entry &e : entries) {
-            if (cj.launches.empty() || cj.launches.back().round != e.round || cj.launches.back().pass != e.pass || cj.launches.back().cls != e.cls)
+            if (cj.launches.empty() || cj.launches.back().round != e.round || cj.launches.back().pass != e.pass)
                 cj.launches.push_back({ e.round, e.pass, e.cls, (uint32_t)cj.list.size(), 0u });
             cj.launches.back().count++;
+            cj.launches.back().cls = std::max(cj.launches.back().cls, e.cls);
             cj.list.push_back(e.ai);
         }
     }
@@ -929,7 +941,9 @@ struct Impl {
     /* stage A of a chain job: the autocorrelation launches round by round */
     bool chain_stage_a(Slot &s, uint32_t jobidx, const ChainJob &cj)
     {
-        hipStream_t W = streams[0];
+        /* many small dependent launches: on a stream of their own, so that the regular jobs' wide kernels do not queue
+         * behind them */
+        hipStream_t W = s.own_stream;
         const SrlaJobParams &jp = s.jp;
         if (!d_chain_list[jobidx].ensure(std::max<size_t>(1, cj.list.size()) * sizeof(SrlaAutocorrItem))) return false;
         if (!d_chain_select[jobidx].ensure(cj.select.size() * 4)) return false;
@@ -942,6 +956,9 @@ struct Impl {
                              (chain_tab.size() - chain_tab_uploaded) * 4, hipMemcpyHostToDevice));
             chain_tab_uploaded = chain_tab.size();
         }
+        /* prepare_job put the descriptor uploads on the wide stream: everything after this stage must see them */
+        HIP_OK(hipEventRecord(s.t0[ST_A], streams[0]));
+        HIP_OK(hipStreamWaitEvent(W, s.t0[ST_A], 0));
         if (lshift_on_device) HIP_OK(hipStreamWaitEvent(W, ev_or, 0));
         if (s.used_h2d) HIP_OK(hipStreamWaitEvent(W, s.ev_in, 0));
         static const int kClass[4] = { 0, 1, 2, 4 };
@@ -967,99 +984,142 @@ struct Impl {
         return true;
     }
 
-    /* The last window [tail_start, tail_start + tail_n) of a stream in chain mode.  seed_n > 0: the block
-     * [seed_off, seed_off + seed_n) was the last one encoded before it. */
-    SRLAApiResult chain_tail(const int32_t *const *host_in, const int32_t *d_in, uint32_t d_stride, uint32_t tail_start, uint32_t tail_n,
-                             bool search, uint32_t seed_off, uint32_t seed_n, uint8_t *data, uint32_t data_size, uint8_t *out_direct,
-                             uint32_t init_pos, bool first_job, uint32_t write_off, uint32_t *wrote)
+    /* The last window [tail_start, tail_start + tail_n) of a stream in chain mode, in three steps so that it overlaps
+     * the regular jobs: chain_begin (seed + search job; needs nothing from the jobs before unless the seed does),
+     * chain_encode_ad (reads the search result, enqueues the encode job up to its pricing), chain_encode_e (block
+     * assembly, after the last regular job's).  seed_n > 0: the block [seed_off, seed_off + seed_n) is the last one
+     * encoded before the window. */
+    struct ChainRun {
+        bool active = false, begun = false, early = false, ad_done = false;
+        uint32_t tail_start = 0, tail_n = 0;
+        bool search = false;
+        const int32_t *const *host_in = nullptr;
+        const int32_t *d_in = nullptr;
+        uint32_t d_stride = 0;
+        std::vector<int32_t> tail_smp, seed_smp;
+        uint32_t seed_n = 0;
+        ChainJob cq, cs, ce;
+    } chain;
+    static constexpr uint32_t kChainSlot = kMaxSlots - 3;   /* seed, search, encode */
+
+    bool chain_silent(const std::vector<int32_t> &v, uint32_t total, uint32_t off, uint32_t n) const
     {
+        for (uint32_t ch = 0; ch < par.num_channels; ch++) {
+            const int32_t *p = v.data() + (size_t)ch * total + off;
+            for (uint32_t i = 0; i < n; i++) if (p[i] != 0) return false;
+        }
+        return true;
+    }
+
+    void chain_slot_defaults(Slot &s)
+    {
+        s.own_stream = streams[1];   /* the narrow stream: a stream of their own ended up sharing a hardware queue with the wide one and waited for the whole stream (measured) */
+        s.out_direct = nullptr; s.out_first = 1; s.out_init_pos = 0; s.out_limit = 0xFFFFFFFFu; s.timed = false; s.out_boost = 1;
+    }
+
+    bool chain_begin(uint32_t seed_off, uint32_t seed_n)
+    {
+        ChainRun &c = chain;
         const uint32_t nch = par.num_channels, nv = num_variants(), passes = par.ltp_order > 0 ? 2u : 1u;
         /* which blocks are all zero decides which calls exist: look at the samples */
         auto fetch = [&](uint32_t off, uint32_t n, std::vector<int32_t> &dst) -> bool {
             dst.resize((size_t)nch * n);
             for (uint32_t ch = 0; ch < nch; ch++) {
-                if (host_in) memcpy(dst.data() + (size_t)ch * n, host_in[ch] + off, (size_t)n * 4);
-                else if (hipMemcpy(dst.data() + (size_t)ch * n, d_in + (size_t)ch * d_stride + off, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) return false;
+                if (c.host_in) memcpy(dst.data() + (size_t)ch * n, c.host_in[ch] + off, (size_t)n * 4);
+                else if (hipMemcpy(dst.data() + (size_t)ch * n, c.d_in + (size_t)ch * c.d_stride + off, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) return false;
             }
             return true;
         };
-        std::vector<int32_t> tail_smp, seed_smp;
-        if (!fetch(tail_start, tail_n, tail_smp) || (seed_n && !fetch(seed_off, seed_n, seed_smp))) return SRLA_APIRESULT_NG;
-        auto silent_in = [nch](const std::vector<int32_t> &v, uint32_t total, uint32_t off, uint32_t n) {
-            for (uint32_t ch = 0; ch < nch; ch++) {
-                const int32_t *p = v.data() + (size_t)ch * total + off;
-                for (uint32_t i = 0; i < n; i++) if (p[i] != 0) return false;
-            }
-            return true;
-        };
-        const std::function<bool(uint32_t, uint32_t)> silent_tail = [&](uint32_t off, uint32_t n) { return silent_in(tail_smp, tail_n, off, n); };
-        const std::function<bool(uint32_t, uint32_t)> silent_seed = [&](uint32_t off, uint32_t n) { return silent_in(seed_smp, seed_n, off, n); };
-
+        c.seed_n = seed_n;
+        if (!fetch(c.tail_start, c.tail_n, c.tail_smp) || (seed_n && !fetch(seed_off, seed_n, c.seed_smp))) return false;
+        const std::function<bool(uint32_t, uint32_t)> silent_tail = [&](uint32_t off, uint32_t n) { return chain_silent(c.tail_smp, c.tail_n, off, n); };
+        const std::function<bool(uint32_t, uint32_t)> silent_seed = [&](uint32_t off, uint32_t n) { return chain_silent(c.seed_smp, c.seed_n, off, n); };
         chain_calls.clear();
         chain_pool_used = 0;
         chain_tab.clear();
         chain_tab_uploaded = 0;
-        Slot &q = slot[0], &sj = slot[1], &e = slot[2];
-        ChainJob cq, cs, ce;
-        auto setup = [&](Slot &s) {
-            s.out_direct = nullptr; s.out_first = 1; s.out_init_pos = 0; s.out_limit = 0xFFFFFFFFu; s.timed = false; s.out_boost = 1;
-        };
+        Slot &q = slot[kChainSlot], &sj = slot[kChainSlot + 1], &e = slot[kChainSlot + 2];
         if (seed_n) {
             const std::vector<uint32_t> lens{ seed_n };
             build_job(q.job, seed_off, seed_n, false, &lens);
             chain_append(0, q.job, silent_seed);
         }
-        if (search) {
-            sj.job.key = 0;
-            build_job(sj.job, tail_start, tail_n, true);
+        if (c.search) {
+            build_job(sj.job, c.tail_start, c.tail_n, true);
             chain_append(1, sj.job, silent_tail);
         } else {
-            const std::vector<uint32_t> lens{ tail_n };
-            build_job(e.job, tail_start, tail_n, false, &lens);
+            const std::vector<uint32_t> lens{ c.tail_n };
+            build_job(e.job, c.tail_start, c.tail_n, false, &lens);
             chain_append(2, e.job, silent_tail);
         }
         {
             /* the encode job's calls are not known yet when searching: its blocks tile the window, an FFT is shorter
              * than twice its block (or the smallest FFT size) */
-            const uint32_t max_parts = search ? (tail_n + par.min_num_samples_per_block - 1) / par.min_num_samples_per_block : 0u;
-            const uint64_t bound = chain_pool_used + (uint64_t)nv * passes * (2ull * tail_n + 64ull * max_parts);
-            if (!d_chain_pool.ensure(bound * sizeof(double))) return SRLA_APIRESULT_NG;
+            const uint32_t max_parts = c.search ? (c.tail_n + par.min_num_samples_per_block - 1) / par.min_num_samples_per_block : 0u;
+            const uint64_t bound = chain_pool_used + (uint64_t)nv * passes * (2ull * c.tail_n + 64ull * max_parts);
+            if (!d_chain_pool.ensure(bound * sizeof(double))) return false;
             const size_t tab_bound = chain_tab.size() + (size_t)std::max(1u, max_parts) * nv * SRLA_LTP_LAGS;
-            if (!d_chain_tab.ensure(tab_bound * 4)) return SRLA_APIRESULT_NG;
+            if (!d_chain_tab.ensure(tab_bound * 4)) return false;
         }
         if (seed_n) {
-            chain_build(0, q.job, cq);
-            setup(q);
-            if (!prepare_job(q, d_in ? d_in + seed_off : nullptr, d_stride, host_in, false) || !chain_stage_a(q, 0, cq)) return SRLA_APIRESULT_NG;
+            chain_build(0, q.job, c.cq);
+            chain_slot_defaults(q);
+            if (!prepare_job(q, c.d_in ? c.d_in + seed_off : nullptr, c.d_stride, c.host_in, false) || !chain_stage_a(q, 0, c.cq)) return false;
         }
-        if (search) {
-            chain_build(1, sj.job, cs);
-            setup(sj);
-            if (!prepare_job(sj, d_in ? d_in + tail_start : nullptr, d_stride, host_in, false) || !chain_stage_a(sj, 1, cs)) return SRLA_APIRESULT_NG;
-            for (int st = ST_B; st <= ST_D; st++) if (!run_stage(sj, st)) return SRLA_APIRESULT_NG;
-            if (hipEventSynchronize(sj.t1[ST_D]) != hipSuccess) return SRLA_APIRESULT_NG;
+        if (c.search) {
+            chain_build(1, sj.job, c.cs);
+            chain_slot_defaults(sj);
+            if (!prepare_job(sj, c.d_in ? c.d_in + c.tail_start : nullptr, c.d_stride, c.host_in, false) || !chain_stage_a(sj, 1, c.cs)) return false;
+            for (int st = ST_B; st <= ST_D; st++) if (!run_stage(sj, st)) return false;
+        }
+        c.begun = true;
+        return true;
+    }
+
+    /* the encode job up to its pricing; `first_job`: nothing was encoded before the window */
+    bool chain_encode_ad(uint8_t *out_direct, uint32_t init_pos, uint32_t data_size, bool first_job)
+    {
+        ChainRun &c = chain;
+        Slot &q = slot[kChainSlot], &sj = slot[kChainSlot + 1], &e = slot[kChainSlot + 2];
+        if (c.search) {
+            const auto tw = Clock::now();
+            if (hipEventSynchronize(sj.t1[ST_D]) != hipSuccess) return false;
+            static const bool trace = getenv("SRLA_MI355X_CHAIN_TRACE") != nullptr;
+            if (trace) fprintf(stderr, "[chain] waited %.3f ms for the search job (%u rounds)\n", ms_since(tw), c.cs.rounds);
             const SrlaWindowDesc &wd = sj.job.windows[0];
             std::vector<SrlaBlockRecord> recs(wd.num_nodes - 1);
             if (hipMemcpy(recs.data(), sj.d_blocks.as<SrlaBlockRecord>() + wd.block_base, recs.size() * sizeof(SrlaBlockRecord), hipMemcpyDeviceToHost) != hipSuccess)
-                return SRLA_APIRESULT_NG;
+                return false;
             std::vector<uint32_t> lens;
             uint32_t covered = 0;
             for (const SrlaBlockRecord &r : recs) if (r.valid) { lens.push_back(r.n); covered += r.n; }
-            if (covered != tail_n) { fprintf(stderr, "[srla-mi355x] internal error: the tail window's partitions cover %u of %u samples\n", covered, tail_n); return SRLA_APIRESULT_NG; }
+            if (covered != c.tail_n) { fprintf(stderr, "[srla-mi355x] internal error: the tail window's partitions cover %u of %u samples\n", covered, c.tail_n); return false; }
             sj.busy = false;
-            build_job(e.job, tail_start, tail_n, false, &lens);
+            const std::function<bool(uint32_t, uint32_t)> silent_tail = [&](uint32_t off, uint32_t n) { return chain_silent(c.tail_smp, c.tail_n, off, n); };
+            build_job(e.job, c.tail_start, c.tail_n, false, &lens);
             chain_append(2, e.job, silent_tail);
-            if (chain_pool_used * sizeof(double) > d_chain_pool.cap) return SRLA_APIRESULT_NG;
+            if (chain_pool_used * sizeof(double) > d_chain_pool.cap) return false;
         }
-        chain_build(2, e.job, ce);
-        setup(e);
-        e.out_direct = out_direct; e.out_first = first_job ? 1u : 0u; e.out_init_pos = init_pos; e.out_limit = data_size; e.out_boost = tail_boost;
-        if (!prepare_job(e, d_in ? d_in + tail_start : nullptr, d_stride, host_in, false) || !chain_stage_a(e, 2, ce)) return SRLA_APIRESULT_NG;
-        for (int st = ST_B; st <= ST_E; st++) if (!run_stage(e, st)) return SRLA_APIRESULT_NG;
-        if (!wait_job(e)) return SRLA_APIRESULT_NG;
         q.busy = false;
-        const uint32_t *window_bytes = nullptr;
-        return finish_job(e, data, write_off, wrote, &window_bytes);
+        chain_build(2, e.job, c.ce);
+        chain_slot_defaults(e);
+        e.out_direct = out_direct; e.out_first = first_job ? 1u : 0u; e.out_init_pos = init_pos; e.out_limit = data_size; e.out_boost = tail_boost;
+        if (!prepare_job(e, c.d_in ? c.d_in + c.tail_start : nullptr, c.d_stride, c.host_in, false) || !chain_stage_a(e, 2, c.ce)) return false;
+        for (int st = ST_B; st <= ST_D; st++) if (!run_stage(e, st)) return false;
+        c.ad_done = true;
+        return true;
+    }
+
+    bool chain_encode_e() { return run_stage(slot[kChainSlot + 2], ST_E); }
+
+    /* has the search job been priced (so that the encode job can be enqueued without waiting)? */
+    bool chain_search_done()
+    {
+        if (!chain.begun) return false;
+        if (!chain.search) return true;
+        const hipError_t e = hipEventQuery(slot[kChainSlot + 1].t1[ST_D]);
+        if (e != hipSuccess) (void)hipGetLastError();
+        return e == hipSuccess;
     }
 
     /* A finished job: check the device's verdict, move the bytes to `data + write_off` unless the device wrote
@@ -1215,6 +1275,9 @@ struct Impl {
             if (tn > 0 && par.ltp_order > 0 && grid > 256u && (window_len % grid) == 0 && ((tn - 1u) % grid) + 1u <= 256u && !no_chain) chain_n = tn;
         }
         const uint32_t body = num_samples - chain_n;
+        chain.active = chain_n != 0; chain.begun = false; chain.early = false; chain.ad_done = false;
+        chain.tail_start = body; chain.tail_n = chain_n; chain.search = search;
+        chain.host_in = host_in; chain.d_in = d_in; chain.d_stride = d_stride;
         struct JobPlan { uint32_t s0, ns, slot; };
         std::vector<JobPlan> plan;
         {
@@ -1237,6 +1300,7 @@ struct Impl {
         auto fail = [&](SRLAApiResult rc) {
             for (auto &st : streams) if (st) (void)hipStreamSynchronize(st);
             if (upload) (void)hipStreamSynchronize(upload);
+            if (chain_stream) (void)hipStreamSynchronize(chain_stream);
             for (auto &sl : slot) sl.busy = false;
             lshift_on_device = false;
             spec_or_active = false;
@@ -1272,6 +1336,17 @@ struct Impl {
             header_done = 1;
             return true;
         };
+        uint32_t chain_seed_off = 0, chain_seed_n = 0;
+        if (chain.active) {
+            /* The window's search does not depend on the jobs before it, except through the last block encoded before
+             * the window when the window's first history-dependent call can reach back that far: a window of a single
+             * candidate (search), or any window when every block is a window of its own.  Without searching that
+             * block is known now; otherwise it is read from the last regular job once that has been priced (below). */
+            const uint32_t nodes = search ? (chain_n + par.min_num_samples_per_block - 1) / par.min_num_samples_per_block + 1 : 2u;
+            if (body == 0 || (search && nodes >= 3)) chain.early = true;
+            else if (!search) { chain.early = true; chain_seed_off = body - par.max_num_samples_per_block; chain_seed_n = par.max_num_samples_per_block; }
+        }
+        static const bool chain_trace = getenv("SRLA_MI355X_CHAIN_TRACE") != nullptr;
         for (uint32_t t = 0; t < njobs + depth; t++) {
             const auto t_enq = Clock::now();
             if (t < njobs) {
@@ -1285,6 +1360,18 @@ struct Impl {
                 Slot &s = job_slot(t - 2);
                 if (!run_stage(s, ST_E)) return fail(SRLA_APIRESULT_NG);
             }
+            /* the host prepares the chain jobs while the device works on the first regular job */
+            if (chain.early && !chain.begun) {
+                const auto tc = Clock::now();
+                if (!chain_begin(chain_seed_off, chain_seed_n)) return fail(SRLA_APIRESULT_NG);
+                if (chain_trace) fprintf(stderr, "[chain] begin %.3f ms (%zu calls)\n", ms_since(tc), chain_calls.size());
+            }
+            if (chain.early && !chain.ad_done && (t == njobs || chain_search_done())) {
+                const auto tc = Clock::now();
+                if (!chain_encode_ad(out_direct, init_pos, data_size, njobs == 0)) return fail(SRLA_APIRESULT_NG);
+                if (chain_trace) fprintf(stderr, "[chain] encode_ad %.3f ms (%zu calls)\n", ms_since(tc), chain_calls.size());
+            }
+            if (chain.early && t == njobs + 1 && !chain_encode_e()) return fail(SRLA_APIRESULT_NG);
             stats.h2d_ms += ms_since(t_enq);       /* host time spent enqueueing (no H2D of samples on this path) */
             if (t < depth) continue;
             const uint32_t k = t - depth;
@@ -1305,26 +1392,32 @@ struct Impl {
             }
             write_off += wrote;
         }
-        if (chain_n) {
+        if (chain.active) {
             if (!write_header()) return fail(SRLA_APIRESULT_NG);
-            /* the last block encoded before the window: its final call is what the window's first odd call can inherit from */
-            uint32_t seed_off = 0, seed_n = 0;
-            if (body > 0 && !search) { seed_n = par.max_num_samples_per_block; seed_off = body - seed_n; }
-            else if (body > 0) {
+            if (!chain.early) {
+                /* the last block encoded before the window: its final call is what the window's only candidate inherits from */
+                uint32_t seed_off = 0, seed_n = 0;
                 Slot &ls = job_slot(njobs - 1);
                 const SrlaWindowDesc &wd = ls.job.windows.back();
                 std::vector<SrlaBlockRecord> recs(wd.num_nodes - 1);
                 if (hipMemcpy(recs.data(), ls.d_blocks.as<SrlaBlockRecord>() + wd.block_base, recs.size() * sizeof(SrlaBlockRecord), hipMemcpyDeviceToHost) != hipSuccess)
                     return fail(SRLA_APIRESULT_NG);
                 for (const SrlaBlockRecord &r : recs) if (r.valid) { seed_off = ls.job.s0 + r.sample_off; seed_n = r.n; }
+                if (!chain_begin(seed_off, seed_n) || !chain_encode_ad(out_direct, init_pos, data_size, false) || !chain_encode_e())
+                    return fail(SRLA_APIRESULT_NG);
             }
+            Slot &e = slot[kChainSlot + 2];
+            const auto tc = Clock::now();
+            if (!wait_job(e)) return fail(SRLA_APIRESULT_NG);
+            if (chain_trace) fprintf(stderr, "[chain] waited %.3f ms for the encode job\n", ms_since(tc));
             uint32_t wrote = 0;
-            const SRLAApiResult rc = chain_tail(host_in, d_in, d_stride, body, chain_n, search, seed_off, seed_n, data, data_size, out_direct,
-                                                init_pos, njobs == 0, write_off, &wrote);
+            const uint32_t *window_bytes = nullptr;
+            const SRLAApiResult rc = finish_job(e, data, write_off, &wrote, &window_bytes);
             if (rc != SRLA_APIRESULT_OK) return fail(rc);
             progress += chain_n;
             if (cb) cb(num_samples, progress, data + write_off, wrote);
             write_off += wrote;
+            chain.active = false;
         }
         lshift_on_device = false;
         if (spec_or_active) {
