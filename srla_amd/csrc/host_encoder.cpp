@@ -25,10 +25,12 @@
 #include <functional>
 #include <map>
 #include <mutex>
+#include <stdarg.h>
 #include <stddef.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -281,6 +283,18 @@ struct Impl {
     hipStream_t chain_stream = nullptr; /* autocorrelation rounds of chain mode */
     hipStream_t upload = nullptr;      /* H2D of host-input jobs: a DMA queue of its own, so uploads never wait behind kernels */
     hipEvent_t ev_or = nullptr;       /* offset-shift reduction done */
+    hipEvent_t ev_ref = nullptr;      /* SRLA_MI355X_TIMELINE: start of the stream on the wide stream */
+    bool timeline = false;
+    std::string tl_log;               /* printed when the stream is done: writing to stderr on the way distorts what is measured */
+    void tl_printf(const char *fmt, ...) __attribute__((format(printf, 2, 3)))
+    {
+        char buf[640];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof(buf), fmt, ap);
+        va_end(ap);
+        tl_log += buf;
+    }
     bool lshift_on_device = false;
     PinBuf h_or;
     uint32_t kSlots = 4;              /* job buffer sets (SRLA_MI355X_SLOTS); slot i runs on stream i % kStreams */
@@ -328,6 +342,7 @@ struct Impl {
             if (upload) (void)hipStreamDestroy(upload);
             if (chain_stream) { (void)hipStreamSynchronize(chain_stream); (void)hipStreamDestroy(chain_stream); }
             if (ev_or) (void)hipEventDestroy(ev_or);
+            if (ev_ref) (void)hipEventDestroy(ev_ref);
             h_or.release();
             d_tw.release(); d_geoms.release(); d_thr.release(); d_huff.release(); d_huffcode.release(); d_pos.release(); d_or.release();
             d_chain_pool.release(); d_chain_tab.release();
@@ -367,7 +382,9 @@ struct Impl {
             HIP_OK(hipStreamCreateWithPriority(&streams[1], hipStreamNonBlocking, pr[1]));
             HIP_OK(hipStreamCreateWithPriority(&streams[2], hipStreamNonBlocking, pr[2]));
         }
-        HIP_OK(hipEventCreateWithFlags(&ev_or, hipEventDisableTiming));
+        HIP_OK(hipEventCreate(&ev_or));
+        HIP_OK(hipEventCreate(&ev_ref));
+        timeline = getenv("SRLA_MI355X_TIMELINE") != nullptr;
         HIP_OK(hipStreamCreateWithFlags(&upload, hipStreamNonBlocking));
         {
             int lo = 0, hi = 0;
@@ -805,6 +822,19 @@ struct Impl {
         for (int st = 0; st < NUM_ST; st++)
             if ((s.timed || (timing && st == ST_C)) && hipEventElapsedTime(&t, s.t0[st], s.t1[st]) == hipSuccess) *acc[st] += t;
         if (s.timed) stats.timed_jobs++;
+        if (timeline) {
+            /* SRLA_MI355X_TIMELINE (with SRLA_MI355X_TIMING_STRIDE=1): where every stage of every job sat on the device's clock */
+            char line[512]; int o = snprintf(line, sizeof(line), "[timeline] job %u+%u:", s.job.s0, s.job.ns);
+            static const char *nm[NUM_ST] = { "A", "B", "C", "D", "E" };
+            for (int st = 0; st < NUM_ST; st++) {
+                float a = -1, b = 0;
+                if ((s.timed || st == ST_C) && hipEventElapsedTime(&a, ev_ref, s.t0[st]) != hipSuccess) { a = -1; (void)hipGetLastError(); }
+                if (hipEventElapsedTime(&b, ev_ref, s.t1[st]) == hipSuccess)
+                    o += snprintf(line + o, sizeof(line) - (size_t)o, "  %s %.3f-%.3f", nm[st], a, b);
+                else (void)hipGetLastError();
+            }
+            tl_printf("%s\n", line);
+        }
         stats.analyze_ms = stats.autocorr_ms + stats.solve_ms + stats.residual_ms;
         s.busy = false;
         return true;
@@ -1185,6 +1215,7 @@ struct Impl {
         const auto t0 = Clock::now();
         const uint32_t nch = par.num_channels;
         uint32_t write_off = 0;
+        if (timeline) (void)hipEventRecord(ev_ref, streams[0]);
         spec_or_active = false;
         in_pinned = false;
         if (host_in && !force_staging) {
@@ -1296,6 +1327,7 @@ struct Impl {
         }
         const uint32_t njobs = (uint32_t)plan.size();
         uint32_t progress = 0;
+        if (timeline) tl_printf("[timeline] stream of %u samples, %u jobs; host %.3f ms into the call\n", num_samples, njobs, ms_since(t0));
 
         auto fail = [&](SRLAApiResult rc) {
             for (auto &st : streams) if (st) (void)hipStreamSynchronize(st);
@@ -1373,11 +1405,17 @@ struct Impl {
             }
             if (chain.early && t == njobs + 1 && !chain_encode_e()) return fail(SRLA_APIRESULT_NG);
             stats.h2d_ms += ms_since(t_enq);       /* host time spent enqueueing (no H2D of samples on this path) */
+            if (timeline) tl_printf("[timeline] host: iteration %u enqueued at %.3f ms\n", t, ms_since(t0));
             if (t < depth) continue;
             const uint32_t k = t - depth;
             Slot &s = job_slot(k);
             if (!wait_job(s)) return fail(SRLA_APIRESULT_NG);
             if (!write_header()) return fail(SRLA_APIRESULT_NG);
+            if (timeline) {
+                float a = 0;
+                if (lshift_on_device && k == 0 && hipEventElapsedTime(&a, ev_ref, ev_or) == hipSuccess) tl_printf("[timeline] offset-shift reduction done at %.3f\n", a);
+                tl_printf("[timeline] host: job %u collected at %.3f ms\n", k, ms_since(t0));
+            }
             uint32_t wrote = 0;
             const uint32_t *window_bytes = nullptr;
             const SRLAApiResult rc = finish_job(s, data, write_off, &wrote, &window_bytes);
@@ -1435,6 +1473,7 @@ struct Impl {
         }
         *output_size = write_off;
         stats.total_ms += ms_since(t0);
+        if (timeline) { tl_printf("[timeline] call returned at %.3f ms\n", ms_since(t0)); fputs(tl_log.c_str(), stderr); tl_log.clear(); }
         return SRLA_APIRESULT_OK;
     }
 };

@@ -1131,7 +1131,10 @@ __device__ __forceinline__ uint32_t mad24(int32_t a, int32_t b, uint32_t acc)
     return r;
 }
 
-template <int FL>
+/* WIDE: samples beyond 24 bits (24-bit input: M/S, pre-emphasis and the LTP widen it to 28): every tap multiplies
+ * the two 16-bit halves of the sample separately on the 24-bit multiplier (x c = (x >> 16) c 2^16 + (x & 0xffff) c
+ * modulo 2^32), which is still twice as fast as 32-bit multiplies */
+template <int FL, bool WIDE>
 __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, const InputView &iv, const int32_t *__restrict__ in, const SrlaItemDesc &it,
                                    unsigned char *lds, const double *__restrict__ rice_thresholds,
                                    int32_t *__restrict__ res_ws, SrlaItemResult *__restrict__ out)
@@ -1208,9 +1211,10 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
         for (int i = 0; i < S; i++) acc[i] = (uint32_t)half;
 #pragma unroll
         for (int c = 0; c < FL; c++) cur[c] = *reinterpret_cast<const int4 *>(sig + sig_index<FL>(PADS + (int)s_base + 4 * c - (int)o4));
-        /* every sample fits in 24 bits (the fast path is only taken for bps <= 18: |x| < 2^(bps-1) per channel,
-         * S = R - L doubles it, pre-emphasis doubles again, the LTP at most quadruples) and the taps are 8-bit, so
-         * the full-rate 24-bit multiply gives the same low 32 bits as the wrap-around 32-bit product */
+        /* !WIDE: every sample fits in 24 bits (bps <= 18: |x| < 2^(bps-1) per channel, S = R - L doubles it,
+         * pre-emphasis doubles again, the LTP at most quadruples) and the taps are 8-bit, so the full-rate 24-bit
+         * multiply gives the same low 32 bits as the wrap-around 32-bit product */
+        if constexpr (!WIDE) {
         for (uint32_t kb = 0; kb < o4; kb += 4) {
             const int4 cf = *reinterpret_cast<const int4 *>(&sm->coefq[kb]);
 #pragma unroll
@@ -1223,6 +1227,39 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
                 acc[4 * c + 3] = mad24(cf.w, w6, mad24(cf.z, w5, mad24(cf.y, w4, mad24(cf.x, w3, acc[4 * c + 3]))));
                 cur[c] = nxt;
             }
+        }
+        } else {
+        int4 curh[FL];
+#pragma unroll
+        for (int c = 0; c < FL; c++) {
+            curh[c] = make_int4(cur[c].x >> 16, cur[c].y >> 16, cur[c].z >> 16, cur[c].w >> 16);
+            cur[c] = make_int4(cur[c].x & 0xFFFF, cur[c].y & 0xFFFF, cur[c].z & 0xFFFF, cur[c].w & 0xFFFF);
+        }
+        for (uint32_t kb = 0; kb < o4; kb += 4) {
+            const int4 cf = *reinterpret_cast<const int4 *>(&sm->coefq[kb]);
+#pragma unroll
+            for (int c = 0; c < FL; c++) {
+                const int4 nx = *reinterpret_cast<const int4 *>(sig + sig_index<FL>(PADS + (int)s_base + 4 * c - (int)o4 + (int)kb + 4));
+                const int4 nl = make_int4(nx.x & 0xFFFF, nx.y & 0xFFFF, nx.z & 0xFFFF, nx.w & 0xFFFF);
+                const int4 nh = make_int4(nx.x >> 16, nx.y >> 16, nx.z >> 16, nx.w >> 16);
+                {
+                    const int w0 = cur[c].x, w1 = cur[c].y, w2 = cur[c].z, w3 = cur[c].w, w4 = nl.x, w5 = nl.y, w6 = nl.z;
+                    acc[4 * c + 0] = mad24(cf.w, w3, mad24(cf.z, w2, mad24(cf.y, w1, mad24(cf.x, w0, acc[4 * c + 0]))));
+                    acc[4 * c + 1] = mad24(cf.w, w4, mad24(cf.z, w3, mad24(cf.y, w2, mad24(cf.x, w1, acc[4 * c + 1]))));
+                    acc[4 * c + 2] = mad24(cf.w, w5, mad24(cf.z, w4, mad24(cf.y, w3, mad24(cf.x, w2, acc[4 * c + 2]))));
+                    acc[4 * c + 3] = mad24(cf.w, w6, mad24(cf.z, w5, mad24(cf.y, w4, mad24(cf.x, w3, acc[4 * c + 3]))));
+                }
+                {
+                    /* the high halves' four products are summed on their own and enter shifted (one shift-add per group) */
+                    const int w0 = curh[c].x, w1 = curh[c].y, w2 = curh[c].z, w3 = curh[c].w, w4 = nh.x, w5 = nh.y, w6 = nh.z;
+                    acc[4 * c + 0] += mad24(cf.w, w3, mad24(cf.z, w2, mad24(cf.y, w1, mad24(cf.x, w0, 0u)))) << 16;
+                    acc[4 * c + 1] += mad24(cf.w, w4, mad24(cf.z, w3, mad24(cf.y, w2, mad24(cf.x, w1, 0u)))) << 16;
+                    acc[4 * c + 2] += mad24(cf.w, w5, mad24(cf.z, w4, mad24(cf.y, w3, mad24(cf.x, w2, 0u)))) << 16;
+                    acc[4 * c + 3] += mad24(cf.w, w6, mad24(cf.z, w5, mad24(cf.y, w4, mad24(cf.x, w3, 0u)))) << 16;
+                }
+                cur[c] = nl; curh[c] = nh;
+            }
+        }
         }
         const int32_t yprev = (tid == 0) ? 0 : sig[sig_index<FL>(PADS + (int)s_base - 1)];
         int32_t *res_out = res_ws + it.res_off + s_base;
@@ -1399,26 +1436,33 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(R >= 4 ? 2 :
         /* blocks of 1024 * FL samples take the register / shuffle fast path */
         const SrlaItemDesc itf = items[blockIdx.x];
         const uint32_t fl = itf.n >> 10;
-        if ((itf.n & 1023u) == 0 && fl >= 1 && fl <= 8 && fl <= (uint32_t)(2 * R) && jp.bits_per_sample <= 18) {
+        if ((itf.n & 1023u) == 0 && fl >= 1 && fl <= 8 && fl <= (uint32_t)(2 * R)) {
             const int32_t *inf = input + itf.sample_off;
             SrlaItemResult *outf = &results[blockIdx.x];
+#define FAST(FLV)                                                                                                   \
+            do {                                                                                                    \
+                if (jp.bits_per_sample <= 18) residual_cost_fast<FLV, false>(jp, iv, inf, itf, lds, rice_thresholds, res_ws, outf); \
+                else residual_cost_fast<FLV, true>(jp, iv, inf, itf, lds, rice_thresholds, res_ws, outf);          \
+                return;                                                                                             \
+            } while (0)
             switch (fl) {
-            case 1: residual_cost_fast<1>(jp, iv, inf, itf, lds, rice_thresholds, res_ws, outf); return;
-            case 2: residual_cost_fast<2>(jp, iv, inf, itf, lds, rice_thresholds, res_ws, outf); return;
-            case 3: residual_cost_fast<3>(jp, iv, inf, itf, lds, rice_thresholds, res_ws, outf); return;
-            case 4: residual_cost_fast<4>(jp, iv, inf, itf, lds, rice_thresholds, res_ws, outf); return;
+            case 1: FAST(1);
+            case 2: FAST(2);
+            case 3: FAST(3);
+            case 4: FAST(4);
             default:
                 /* only the 8192-sample class (R = 4) holds these instantiations */
                 if constexpr (R >= 4) {
                     switch (fl) {
-                    case 5: residual_cost_fast<5>(jp, iv, inf, itf, lds, rice_thresholds, res_ws, outf); return;
-                    case 6: residual_cost_fast<6>(jp, iv, inf, itf, lds, rice_thresholds, res_ws, outf); return;
-                    case 7: residual_cost_fast<7>(jp, iv, inf, itf, lds, rice_thresholds, res_ws, outf); return;
-                    default: residual_cost_fast<8>(jp, iv, inf, itf, lds, rice_thresholds, res_ws, outf); return;
+                    case 5: FAST(5);
+                    case 6: FAST(6);
+                    case 7: FAST(7);
+                    default: FAST(8);
                     }
                 }
                 return;
             }
+#undef FAST
         }
     }
     int32_t *sigA = (int32_t *)(lds + plan.y_off);        /* FIR_PAD zeros, then the signal */
@@ -2453,13 +2497,16 @@ extern "C" int srla_launch_pack(hipStream_t stream, const SrlaJobParams *jp, uin
     hipLaunchKernelGGL(srla_pack_blocks, dim3(num_slots), dim3(NT), lds, stream,
                        *jp, input, items, blocks, results, res_ws, huff_code, huff_len, block_off, ctl, stage, scratch, info,
                        lds_words);
-    static int out_wgs = 0, out_thr = 0, out_sleep = 0;
-    if (out_wgs == 0) {
-        const char *e = getenv("SRLA_MI355X_OUT_WGS"); out_wgs = e ? atoi(e) : 1; if (out_wgs < 1) out_wgs = 1;
+    static int out_wgs = -1, out_thr = 0, out_sleep = 0;
+    if (out_wgs < 0) {
+        const char *e = getenv("SRLA_MI355X_OUT_WGS"); out_wgs = e ? atoi(e) : 0; if (out_wgs < 0) out_wgs = 0;
         e = getenv("SRLA_MI355X_OUT_THREADS"); out_thr = e ? atoi(e) : NT; if (out_thr < 64 || out_thr > NT) out_thr = NT;
         e = getenv("SRLA_MI355X_OUT_SLEEP"); out_sleep = e ? atoi(e) : 0;
     }
-    hipExtLaunchKernelGGL(srla_stream_out, dim3((uint32_t)out_wgs * (out_boost ? out_boost : 1u)), dim3((uint32_t)out_thr), 0, stream, nullptr, ev_stop, 0, stage, ctl, dst, (uint32_t)out_sleep);
+    /* one workgroup keeps up with 16-bit streams (~12 GB/s of output at full speed) and leaves the PCIe write path calm
+     * enough for srla_autocorr (measured: more slow it down); 24-bit streams carry twice the bytes and need two */
+    const uint32_t wgs = out_wgs ? (uint32_t)out_wgs : (jp->bits_per_sample > 16 ? 2u : 1u);
+    hipExtLaunchKernelGGL(srla_stream_out, dim3(wgs * (out_boost ? out_boost : 1u)), dim3((uint32_t)out_thr), 0, stream, nullptr, ev_stop, 0, stage, ctl, dst, (uint32_t)out_sleep);
     return (hipGetLastError() == hipSuccess) ? 0 : -2;
 }
 
