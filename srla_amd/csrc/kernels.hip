@@ -603,14 +603,16 @@ __global__ __launch_bounds__(NTK) void srla_autocorr(
 /* ================================================================================================
  * K2p: srla_pitch_solve -- one lane per item (lpc.c:1473-1649, srla_encoder.c:1031-1047)
  * ============================================================================================== */
-#define PITCH_ITEMS 32u
+#define PITCH_ITEMS 8u
 __global__ __launch_bounds__(WAVE) void srla_pitch_solve(SrlaJobParams jp, const double *__restrict__ lags_ws,
                                                          SrlaItemResult *__restrict__ results,
                                                          const uint32_t *__restrict__ select, uint32_t round)
 {
     /* The scan below is a chain of data-dependent loads; out of global memory each one costs a full round trip
      * (measured 0.4 ms per job).  The wavefront first copies the lags of its PITCH_ITEMS items into LDS
-     * ([lag][item], 67 KB), then the first PITCH_ITEMS lanes scan from there. */
+     * ([lag][item], 17 KB), then the first PITCH_ITEMS lanes scan from there.  Few items per wavefront: the scan is a
+     * latency chain, so what counts is how many wavefronts a CU holds (32 items = 67 KB allowed two: 0.58 ms per job
+     * at -V 2 -P 3; 8 items: 0.34 ms; 4 the same, 2 slower). */
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     double *s_r = (double *)lds;
     const size_t stride = jp.num_items;
@@ -1140,7 +1142,8 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
                                    int32_t *__restrict__ res_ws, SrlaItemResult *__restrict__ out)
 {
     constexpr int S = 4 * FL;                                   /* samples per thread */
-    constexpr int PADS = ((FIR_PAD + S - 1) / S) * S;           /* front padding, a multiple of S */
+    constexpr int PADMIN = (FIR_PAD > SRLA_LTP_MAX_PERIOD + 2) ? FIR_PAD : (SRLA_LTP_MAX_PERIOD + 2);
+    constexpr int PADS = ((PADMIN + S - 1) / S) * S;            /* front padding, a multiple of S: covers the FIR's reach back and the LTP's */
     constexpr uint32_t SIG_WORDS = (uint32_t)((PADS + 1024 * FL) / S) * (S + 4) + 8;
     int32_t *sig = (int32_t *)lds;
     SmallF *sm = (SmallF *)(lds + ((SIG_WORDS * 4 + 15) & ~15u));
@@ -1184,13 +1187,30 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
         /* long-term predictor, srla_lpc_predict.c:267-294 (in place: read everything, barrier, rewrite) */
         const uint32_t taps = jp.ltp_order, half_order = taps >> 1;
         const int32_t c0 = out->ltp_coef[0], c1 = out->ltp_coef[1], c2 = out->ltp_coef[2];
+        /* the thread's S + 2 source samples are consecutive: one division locates the first one in the padded
+         * layout (a pad of four words after every S), the others follow by compare-and-step.  PADS >= the largest
+         * period + 2, so the first source index is never negative. */
+        const uint32_t base0 = (uint32_t)PADS + s_base - period - half_order;
+        const uint32_t q0 = base0 / (uint32_t)S, r0 = base0 - q0 * (uint32_t)S;
+        int32_t src[S + 2];
+#pragma unroll
+        for (int i = 0; i < S + 2; i++) {
+            const uint32_t step = (r0 + (uint32_t)i >= 2u * S) ? 8u : ((r0 + (uint32_t)i >= (uint32_t)S) ? 4u : 0u);
+            src[i] = (i < S || taps == 3) ? sig[base0 + 4u * q0 + (uint32_t)i + step] : 0;
+        }
 #pragma unroll
         for (int i = 0; i < S; i++) {
             const uint32_t s = s_base + i;
             if (s >= period + half_order + 1) {
-                const int base = PADS + (int)(s - period - half_order);
-                uint32_t acc = 16u + (uint32_t)c0 * (uint32_t)sig[sig_index<FL>(base)];
-                if (taps == 3) acc += (uint32_t)c1 * (uint32_t)sig[sig_index<FL>(base + 1)] + (uint32_t)c2 * (uint32_t)sig[sig_index<FL>(base + 2)];
+                uint32_t acc;
+                if constexpr (!WIDE) {
+                    /* 6-bit taps, samples within 24 bits (see the FIR below): the full-rate 24-bit multiplier */
+                    acc = mad24(c0, src[i], 16u);
+                    if (taps == 3) acc = mad24(c2, src[i + 2], mad24(c1, src[i + 1], acc));
+                } else {
+                    acc = 16u + (uint32_t)c0 * (uint32_t)src[i];
+                    if (taps == 3) acc += (uint32_t)c1 * (uint32_t)src[i + 1] + (uint32_t)c2 * (uint32_t)src[i + 2];
+                }
                 y[i] = (int32_t)((uint32_t)y[i] - (uint32_t)((int32_t)acc >> 5));
             }
         }
@@ -1418,7 +1438,8 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
 
 extern "C" uint32_t srla_kernel_fast_lds_bytes(uint32_t fl)
 {
-    const uint32_t S = 4 * fl, pads = ((FIR_PAD + S - 1) / S) * S;
+    const uint32_t padmin = (FIR_PAD > SRLA_LTP_MAX_PERIOD + 2) ? FIR_PAD : (SRLA_LTP_MAX_PERIOD + 2);
+    const uint32_t S = 4 * fl, pads = ((padmin + S - 1) / S) * S;
     const uint32_t sig_words = ((pads + 1024 * fl) / S) * (S + 4) + 8;
     return ((sig_words * 4 + 15) & ~15u) + (uint32_t)((sizeof(SmallF) + 15) & ~15u);
 }
