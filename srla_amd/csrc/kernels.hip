@@ -474,6 +474,10 @@ __global__ __launch_bounds__(NTK) void srla_autocorr(
         }
     } else {
         coef = out->preemph_coef;
+        /* No pitch found: the LPC analysis sees the very signal the LTP analysis saw, and its lags are the first of the
+         * 263 already stored by that pass (same transform, the pruning of the inverse only skips work).  Not in chain
+         * mode, where the call itself matters, nor when the lags are also wanted in the debug record. */
+        if (out->ltp_period == 0 && chain_pool == nullptr && dbg == nullptr) return;
     }
     /* Chain mode (the odd-length tail window of a stream, host_encoder.cpp): the launch reproduces one call of
      * the reference on its persistent FFT buffer (lpc.c:58,211).  chain_src - 1 is where the buffer's middle word
