@@ -1086,11 +1086,17 @@ struct SmallF {
     uint32_t pad[4];
 };
 
+/* LDS layout of the fast path's signal: every thread owns S = 4 FL consecutive samples.  For even FL a pad of four
+ * words follows every S samples, for odd FL none: the distance between the threads' 16-byte accesses is then 4, 12, 12,
+ * 20, 20, 28, 28, 36 words for FL = 1..8 -- never a multiple of 8, which would put every second or fourth lane on the
+ * same banks (the 3072-sample class, S = 12, measured 40 % slower per sample than its neighbours with the pad: 16
+ * words) -- and odd FL need no index arithmetic at all. */
 template <int FL>
 __device__ __forceinline__ uint32_t sig_index(int s_plus_pad)
 {
     constexpr int S = 4 * FL;
-    return (uint32_t)(s_plus_pad + (s_plus_pad / S) * 4);
+    if constexpr (FL & 1) return (uint32_t)s_plus_pad;
+    else return (uint32_t)(s_plus_pad + (s_plus_pad / S) * 4);
 }
 
 __device__ __forceinline__ uint32_t rice_param(double mean, uint32_t code_type, const double *thr)
@@ -1148,7 +1154,8 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
     constexpr int S = 4 * FL;                                   /* samples per thread */
     constexpr int PADMIN = (FIR_PAD > SRLA_LTP_MAX_PERIOD + 2) ? FIR_PAD : (SRLA_LTP_MAX_PERIOD + 2);
     constexpr int PADS = ((PADMIN + S - 1) / S) * S;            /* front padding, a multiple of S: covers the FIR's reach back and the LTP's */
-    constexpr uint32_t SIG_WORDS = (uint32_t)((PADS + 1024 * FL) / S) * (S + 4) + 8;
+    constexpr int PADW = (FL & 1) ? 0 : 4;                      /* see sig_index */
+    constexpr uint32_t SIG_WORDS = (uint32_t)((PADS + 1024 * FL) / S) * (S + PADW) + 8;
     int32_t *sig = (int32_t *)lds;
     SmallF *sm = (SmallF *)(lds + ((SIG_WORDS * 4 + 15) & ~15u));
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1180,7 +1187,7 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
     _Pragma("unroll") for (int c = 0; c < FL; c++)                                                               \
         *reinterpret_cast<int4 *>(sig + sig_index<FL>(PADS + (int)s_base + 4 * c)) = make_int4(y[4 * c], y[4 * c + 1], y[4 * c + 2], y[4 * c + 3]);
     PUBLISH_Y();
-    for (uint32_t i = tid; i < (uint32_t)(PADS / S) * (S + 4); i += NT) sig[i] = 0;    /* front padding */
+    for (uint32_t i = tid; i < (uint32_t)(PADS / S) * (S + PADW); i += NT) sig[i] = 0;    /* front padding */
     for (uint32_t k = tid; k < o4; k += NT) sm->coefq[k] = (k < o4 - order) ? 0 : (int32_t)out->lpc_coef[k - (o4 - order)];
     if (tid < 16) sm->level_bits[tid] = 0;
     if (tid >= 32 && tid < 64) sm->thr[tid - 32] = rice_thresholds[tid - 32];
@@ -1199,8 +1206,8 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
         int32_t src[S + 2];
 #pragma unroll
         for (int i = 0; i < S + 2; i++) {
-            const uint32_t step = (r0 + (uint32_t)i >= 2u * S) ? 8u : ((r0 + (uint32_t)i >= (uint32_t)S) ? 4u : 0u);
-            src[i] = (i < S || taps == 3) ? sig[base0 + 4u * q0 + (uint32_t)i + step] : 0;
+            const uint32_t step = (r0 + (uint32_t)i >= 2u * S) ? 2u * PADW : ((r0 + (uint32_t)i >= (uint32_t)S) ? (uint32_t)PADW : 0u);
+            src[i] = (i < S || taps == 3) ? sig[base0 + (uint32_t)PADW * q0 + (uint32_t)i + step] : 0;
         }
 #pragma unroll
         for (int i = 0; i < S; i++) {
@@ -1444,7 +1451,7 @@ extern "C" uint32_t srla_kernel_fast_lds_bytes(uint32_t fl)
 {
     const uint32_t padmin = (FIR_PAD > SRLA_LTP_MAX_PERIOD + 2) ? FIR_PAD : (SRLA_LTP_MAX_PERIOD + 2);
     const uint32_t S = 4 * fl, pads = ((padmin + S - 1) / S) * S;
-    const uint32_t sig_words = ((pads + 1024 * fl) / S) * (S + 4) + 8;
+    const uint32_t sig_words = ((pads + 1024 * fl) / S) * (S + ((fl & 1u) ? 0u : 4u)) + 8;
     return ((sig_words * 4 + 15) & ~15u) + (uint32_t)((sizeof(SmallF) + 15) & ~15u);
 }
 
