@@ -113,12 +113,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the MI355X path has no CPU fallback")
+    # SRLA_BENCH_SHARED_GPU=1 (test hook): ranks may share a device, so that the N > 1 flow can be exercised on a box with
+    # one GPU; RCCL refuses two ranks on one device, so the barrier / max-reduce then go through gloo
+    shared_gpu = os.environ.get("SRLA_BENCH_SHARED_GPU") == "1"
+    if shared_gpu:
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")   # RCCL; used only for the timing barrier / max-reduce
+        dist.init_process_group("gloo" if shared_gpu else "nccl")   # nccl = RCCL; used only for the timing barrier / max-reduce
 
     # one process per GPU, kept on the CPUs of the GPU's own NUMA node (doorbells, pinned buffers, pack threads)
     numa_cpus = None
@@ -190,7 +195,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if shared_gpu else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     lib.lib.SRLAMI355X_GetStats(enc, C.byref(st), 0)
