@@ -265,7 +265,7 @@ def main():
         if host_t:
             line["host_input"] = {"value": round(n / min(host_t) / 1e6, 3), "unit": "Msamples/s", "ms_per_call": round(1e3 * min(host_t), 3),
                               "same_bytes": bool(np.array_equal(out[:out_size.value], stream)),
-                              "note": "SRLAEncoder_EncodeWhole, pageable int32 planes in host memory: staging copies (which also gather the offset-shift OR) + H2D + the same device pipeline"}
+                              "note": "SRLAEncoder_EncodeWhole, pageable int32 planes in host memory: staging copies (which pack to int16 and gather the offset-shift OR) + H2D + widening + the same device pipeline"}
         if not args.no_cpu_baseline and world == 1:        # rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline(pcm, cli, args.cpu_seconds, rate, bps)
             line["speedup_vs_cpu_1core"] = round(value / line["cpu_baseline"]["value"], 2)

@@ -137,6 +137,54 @@ __attribute__((target("avx2"))) static uint32_t copy_or_avx2(int32_t *dst, const
     return m;
 }
 #endif
+/* The same for streams of at most 16 bits: the staging copy packs the samples to int16, which halves what crosses PCIe
+ * (the upload of a 600 s stream, 230 MB as int32, took as long as its whole encode); the device widens them again.
+ * *wide gets a non-zero value if a sample does not fit (the caller then stages that job as int32). */
+#if defined(__x86_64__)
+__attribute__((target("avx2"))) static uint32_t pack16_or_avx2(int16_t *dst, const int32_t *src, size_t n, uint32_t *wide)
+{
+    uint32_t m = 0, w = 0;
+    size_t k = 0;
+    while (k < n && (reinterpret_cast<uintptr_t>(dst + k) & 31u)) {
+        const int32_t x = src[k]; dst[k] = (int16_t)x; m |= (uint32_t)x; w |= ((uint32_t)x + 32768u) & 0xFFFF0000u; k++;
+    }
+    __m256i acc = _mm256_setzero_si256(), accw = _mm256_setzero_si256();
+    const __m256i bias = _mm256_set1_epi32(32768);
+    for (; k + 32 <= n; k += 32) {
+        const __m256i a = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(src + k));
+        const __m256i b = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(src + k + 8));
+        const __m256i c = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(src + k + 16));
+        const __m256i d = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(src + k + 24));
+        /* packs works inside the 128-bit halves: put the quarters back in order */
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(dst + k), _mm256_permute4x64_epi64(_mm256_packs_epi32(a, b), 0xD8));
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(dst + k + 16), _mm256_permute4x64_epi64(_mm256_packs_epi32(c, d), 0xD8));
+        acc = _mm256_or_si256(acc, _mm256_or_si256(_mm256_or_si256(a, b), _mm256_or_si256(c, d)));
+        accw = _mm256_or_si256(accw, _mm256_or_si256(_mm256_or_si256(_mm256_add_epi32(a, bias), _mm256_add_epi32(b, bias)),
+                                                     _mm256_or_si256(_mm256_add_epi32(c, bias), _mm256_add_epi32(d, bias))));
+    }
+    alignas(32) uint32_t lanes[8];
+    _mm256_store_si256(reinterpret_cast<__m256i *>(lanes), acc);
+    for (int i = 0; i < 8; i++) m |= lanes[i];
+    _mm256_store_si256(reinterpret_cast<__m256i *>(lanes), accw);
+    for (int i = 0; i < 8; i++) w |= lanes[i] & 0xFFFF0000u;
+    for (; k < n; k++) { const int32_t x = src[k]; dst[k] = (int16_t)x; m |= (uint32_t)x; w |= ((uint32_t)x + 32768u) & 0xFFFF0000u; }
+    _mm_sfence();
+    *wide = w;
+    return m;
+}
+#endif
+static uint32_t pack16_or(int16_t *dst, const int32_t *src, size_t n, uint32_t *wide)
+{
+#if defined(__x86_64__)
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    if (avx2) return pack16_or_avx2(dst, src, n, wide);
+#endif
+    uint32_t m = 0, w = 0;
+    for (size_t k = 0; k < n; k++) { const int32_t x = src[k]; dst[k] = (int16_t)x; m |= (uint32_t)x; w |= ((uint32_t)x + 32768u) & 0xFFFF0000u; }
+    *wide = w;
+    return m;
+}
+
 static uint32_t copy_or(int32_t *dst, const int32_t *src, size_t n)
 {
 #if defined(__x86_64__)
@@ -259,6 +307,7 @@ struct Slot {
     uint8_t *out_direct = nullptr;       /* device-visible caller buffer, or nullptr: stage through h_stream */
     uint32_t out_first = 1, out_init_pos = 0, out_limit = 0xFFFFFFFFu;
     uint32_t out_boost = 1;              /* stream-out workgroup multiplier (the last jobs of a stream drain faster) */
+    DevBuf d_input16;                    /* host input of at most 16 bits crosses PCIe as int16 and is widened into d_input */
     DevBuf d_input, d_items, d_cands, d_windows, d_results, d_res_ws, d_blocks, d_block_off, d_ctl, d_scratch, d_dbg, d_lags, d_err, d_class_index, d_stream;
     PinBuf h_in, h_stream, h_info;       /* h_info: SrlaJobInfo followed by the per-window byte counts */
     Job job;
@@ -313,6 +362,7 @@ struct Impl {
     int forced_lshift = -1;           /* >= 0: the shift is known (second attempt) */
     bool no_speculation = false;      /* SRLA_MI355X_NO_SPECULATION */
     bool force_staging = false;       /* SRLA_MI355X_STAGING: never write the caller's buffer from the device */
+    bool no_pack16 = false;           /* SRLA_MI355X_NO_PACK16: host input always crosses PCIe as int32 */
     std::map<uint32_t, uint32_t> tw_index;   /* nfft -> offset (double2) */
     std::vector<double> tw_host;
     bool tw_dirty = false;
@@ -332,6 +382,7 @@ struct Impl {
                 for (auto &e : s.t0) if (e) (void)hipEventDestroy(e);
                 for (auto &e : s.t1) if (e) (void)hipEventDestroy(e);
                 if (s.ev_in) (void)hipEventDestroy(s.ev_in);
+                s.d_input16.release();
                 DevBuf *db[] = { &s.d_input, &s.d_items, &s.d_cands, &s.d_windows, &s.d_results, &s.d_res_ws,
                                  &s.d_blocks, &s.d_block_off, &s.d_ctl, &s.d_scratch, &s.d_dbg, &s.d_lags, &s.d_err, &s.d_class_index, &s.d_stream };
                 for (auto *b : db) b->release();
@@ -417,6 +468,7 @@ struct Impl {
         if (!d_pos.ensure(64)) return false;
         HIP_OK(hipMemset(d_pos.p, 0, 64));
         force_staging = getenv("SRLA_MI355X_STAGING") != nullptr;
+        no_pack16 = getenv("SRLA_MI355X_NO_PACK16") != nullptr;
         no_speculation = getenv("SRLA_MI355X_NO_SPECULATION") != nullptr;
         timing = getenv("SRLA_MI355X_NO_TIMING") == nullptr;
         if (const char *e = getenv("SRLA_MI355X_TAIL_BOOST")) { unsigned a = 0, b = 0; if (sscanf(e, "%u,%u", &a, &b) == 2 && a >= 1) { tail_boost = a; tail_boost_jobs = b; } }
@@ -668,7 +720,7 @@ struct Impl {
         s.stride_cur = d_stride;
         s.used_h2d = false;
         if (!d_in) {
-            if ((!in_pinned && !s.h_in.ensure((size_t)nch * job.ns * 4)) || !s.d_input.ensure((size_t)nch * job.ns * 4)) return false;
+            if ((!in_pinned && !s.h_in.ensure((size_t)nch * job.ns * 4 + 64u * nch)) || !s.d_input.ensure((size_t)nch * job.ns * 4)) return false;
             if (in_pinned) {
                 /* the caller's planes are pinned: DMA straight out of them (the OR of the job's samples, when it is
                  * still being gathered, is computed by the pool threads meanwhile) */
@@ -689,17 +741,39 @@ struct Impl {
             } else {
                 /* pageable -> pinned staging on the pool threads, then one DMA on the upload stream */
                 const uint32_t chunk = 256u << 10, per_ch = (job.ns + chunk - 1) / chunk;
-                int32_t *dst = s.h_in.as<int32_t>();
                 const Job *jb = &job;
                 const bool track = spec_or_active;
-                pool->parallel_for(per_ch * nch, [&](uint32_t i) {
-                    const uint32_t ch = i / per_ch, o = (i % per_ch) * chunk, len = std::min(chunk, jb->ns - o);
-                    const int32_t *src = host_in[ch] + jb->s0 + o;
-                    int32_t *d = dst + (size_t)ch * jb->ns + o;
-                    const uint32_t m = copy_or(d, src, len);   /* the copy also gathers the OR of the samples it moves */
-                    if (track) spec_or.fetch_or(m, std::memory_order_relaxed);
-                });
-                HIP_OK(hipMemcpyAsync(s.d_input.p, s.h_in.p, (size_t)nch * job.ns * 4, hipMemcpyHostToDevice, upload));
+                bool packed = false;
+                if (par.bits_per_sample <= 16 && !no_pack16) {
+                    /* as int16 (planes padded to 16 samples so that every chunk starts 32-byte aligned) */
+                    const size_t stride16 = ((size_t)job.ns + 15u) & ~(size_t)15u;
+                    if (!s.d_input16.ensure(nch * stride16 * 2)) return false;
+                    int16_t *dst = s.h_in.as<int16_t>();
+                    std::atomic<uint32_t> wide{ 0 };
+                    pool->parallel_for(per_ch * nch, [&](uint32_t i) {
+                        const uint32_t ch = i / per_ch, o = (i % per_ch) * chunk, len = std::min(chunk, jb->ns - o);
+                        uint32_t w = 0;
+                        const uint32_t m = pack16_or(dst + (size_t)ch * stride16 + o, host_in[ch] + jb->s0 + o, len, &w);
+                        if (track) spec_or.fetch_or(m, std::memory_order_relaxed);
+                        if (w) wide.fetch_or(w, std::memory_order_relaxed);
+                    });
+                    if (wide.load() == 0) {
+                        HIP_OK(hipMemcpyAsync(s.d_input16.p, s.h_in.p, nch * stride16 * 2, hipMemcpyHostToDevice, upload));
+                        if (srla_launch_widen16(upload, s.d_input16.as<int16_t>(), stride16, s.d_input.as<int32_t>(), job.ns, nch) != 0) return false;
+                        packed = true;
+                    }   /* else: samples beyond 16 bits in a stream declared narrower -- the reference does not mind, nor do we */
+                }
+                if (!packed) {
+                    int32_t *dst = s.h_in.as<int32_t>();
+                    pool->parallel_for(per_ch * nch, [&](uint32_t i) {
+                        const uint32_t ch = i / per_ch, o = (i % per_ch) * chunk, len = std::min(chunk, jb->ns - o);
+                        const int32_t *src = host_in[ch] + jb->s0 + o;
+                        int32_t *d = dst + (size_t)ch * jb->ns + o;
+                        const uint32_t m = copy_or(d, src, len);   /* the copy also gathers the OR of the samples it moves */
+                        if (track) spec_or.fetch_or(m, std::memory_order_relaxed);
+                    });
+                    HIP_OK(hipMemcpyAsync(s.d_input.p, s.h_in.p, (size_t)nch * job.ns * 4, hipMemcpyHostToDevice, upload));
+                }
             }
             HIP_OK(hipEventRecord(s.ev_in, upload));
             s.in_cur = s.d_input.as<int32_t>();

@@ -36,6 +36,8 @@ int srla_launch_autocorr(hipStream_t stream, int rclass, const SrlaJobParams *jp
                          const SrlaAutocorrItem *class_items, uint32_t count, hipEvent_t ev_start, hipEvent_t ev_stop,
                          double *chain_pool /* null outside chain mode (device_layout.h: chain_src / chain_dump) */,
                          const uint32_t *chain_tab /* gather table of chain_lags */);
+/* int16 planes (stride16 elements apart) -> int32 planes (n apart): host input of at most 16 bits per sample */
+int srla_launch_widen16(hipStream_t stream, const int16_t *src, size_t stride16, int32_t *dst, uint32_t n, uint32_t num_channels);
 int srla_launch_pitch_solve(hipStream_t stream, const SrlaJobParams *jp, const double *lags_ws, SrlaItemResult *results,
                             hipEvent_t ev_start, hipEvent_t ev_stop,
                             const uint32_t *select /* null: every item; else only items with select[item] == round */, uint32_t round);

@@ -2408,6 +2408,28 @@ extern "C" int srla_launch_autocorr(hipStream_t stream, int rclass, const SrlaJo
     return (hipGetLastError() == hipSuccess) ? 0 : -2;
 }
 
+__global__ __launch_bounds__(NT) void srla_widen16(const int16_t *__restrict__ src, size_t stride16, int32_t *__restrict__ dst, uint32_t n)
+{
+    /* four samples per thread: one 8-byte load, four consecutive stores (the int32 planes need not be 16-byte aligned) */
+    const uint32_t ch = blockIdx.y;
+    const size_t i = ((size_t)blockIdx.x * NT + threadIdx.x) * 4u;
+    if (i >= n) return;
+    const short4 v = *reinterpret_cast<const short4 *>(src + (size_t)ch * stride16 + i);   /* planes are padded to 16 samples */
+    int32_t *d = dst + (size_t)ch * n + i;
+    d[0] = v.x;
+    if (i + 1 < n) d[1] = v.y;
+    if (i + 2 < n) d[2] = v.z;
+    if (i + 3 < n) d[3] = v.w;
+}
+
+extern "C" int srla_launch_widen16(hipStream_t stream, const int16_t *src, size_t stride16, int32_t *dst, uint32_t n, uint32_t num_channels)
+{
+    if (n == 0 || num_channels == 0) return 0;
+    const uint32_t per = NT * 4u;
+    hipLaunchKernelGGL(srla_widen16, dim3((n + per - 1) / per, num_channels), dim3(NT), 0, stream, src, stride16, dst, n);
+    return (hipGetLastError() == hipSuccess) ? 0 : -2;
+}
+
 extern "C" int srla_launch_pitch_solve(hipStream_t stream, const SrlaJobParams *jp, const double *lags_ws,
                                        SrlaItemResult *results, hipEvent_t ev_start, hipEvent_t ev_stop,
                                        const uint32_t *select, uint32_t round)

@@ -437,3 +437,20 @@ def test_output_buffer_in_device_memory(product):
     assert rc == capi.OK and size.value == want.size
     got = d_out.cpu().numpy()
     assert np.array_equal(got[:size.value], want) and (got[size.value:] == 0xEE).all()
+
+
+def test_host_input_crosses_pcie_as_int16_when_it_fits(product, monkeypatch):
+    """Host input of at most 16 bits is staged as int16 and widened on the device; a job with a sample beyond 16 bits
+    (the reference does not check) is staged as int32; both give the bytes of the int32-only path."""
+    pcm = helpers.synth(helpers.MUSIC, 93, 48000, 2, 16384 * 5 + 777)
+    a = product.encode(pcm, **M4)
+    assert np.array_equal(a, helpers.Oracle(2, **M4).encode_whole(pcm))
+    wide = pcm.copy()
+    wide[1, 40000] = 70000
+    wide[0, 123] = -40000
+    b = product.encode(wide, **M4)
+    assert np.array_equal(b, helpers.Oracle(2, **M4).encode_whole(wide))
+    monkeypatch.setenv("SRLA_MI355X_NO_PACK16", "1")
+    lib2 = capi.EncoderLib(helpers.PRODUCT_SO)
+    assert np.array_equal(lib2.encode(pcm, **M4), a)
+    assert np.array_equal(lib2.encode(wide, **M4), b)
