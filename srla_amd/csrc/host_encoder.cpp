@@ -357,7 +357,7 @@ struct Impl {
     /* Host input without a callback: the stream is encoded assuming offset shift 0 while the staging copies gather the
      * OR of all samples; only if that OR has trailing zeros (rare for audio) the stream is encoded again with the
      * right shift.  Saves a separate pass over the input before the first kernel can start. */
-    bool spec_or_active = false;
+    bool spec_or_active = false, spec_guessed = false;
     std::atomic<uint32_t> spec_or{ 0 };
     int forced_lshift = -1;           /* >= 0: the shift is known (second attempt) */
     bool no_speculation = false;      /* SRLA_MI355X_NO_SPECULATION */
@@ -786,6 +786,16 @@ struct Impl {
             HIP_OK(hipMemcpyAsync(s.d_cands.p, job.cands.data(), n_cands * sizeof(SrlaCandDesc), hipMemcpyHostToDevice, W));
             HIP_OK(hipMemcpyAsync(s.d_windows.p, job.windows.data(), n_win * sizeof(SrlaWindowDesc), hipMemcpyHostToDevice, W));
             job.uploaded = true;
+        }
+        if (spec_or_active && !spec_guessed) {
+            /* The first job's samples are staged: guess the stream's shift from them instead of assuming 0, so that a
+             * stream whose samples all carry the same trailing zeros (16-bit audio in a 24-bit container) is not encoded
+             * twice.  The whole stream's shift can only be smaller; if it is, the stream is encoded again (below). */
+            const uint32_t m = spec_or.load();
+            uint32_t sh = 0;
+            if (m != 0) while (((m >> sh) & 1u) == 0) sh++;
+            offset_lshift = sh;
+            spec_guessed = true;
         }
         s.jp = job_params(job, s.stride_cur);
         s.busy = true;
@@ -1309,8 +1319,9 @@ struct Impl {
                 mask = offset_lshift ? (1u << offset_lshift) : 1u;       /* reproduces the shift below */
             } else if (host_in && cb == nullptr && !no_speculation) {
                 spec_or_active = true;
+                spec_guessed = false;
                 spec_or.store(0);
-                mask = 1u;                                               /* assume shift 0 */
+                mask = 1u;                                               /* shift 0 until the first job's samples have been seen (prepare_job) */
             } else if (host_in) {
                 const uint32_t chunk = 1u << 20, per_ch = (num_samples + chunk - 1) / chunk;
                 std::atomic<uint32_t> acc{ 0 };
@@ -1537,8 +1548,8 @@ struct Impl {
             const uint32_t m = spec_or.load();
             uint32_t sh = 0;
             if (m != 0) while (((m >> sh) & 1u) == 0) sh++;
-            if (sh != 0) {
-                /* the assumption was wrong: encode again with the shift that the whole stream has */
+            if (sh != offset_lshift) {
+                /* the guess was wrong: encode again with the shift that the whole stream has */
                 forced_lshift = (int)sh;
                 const SRLAApiResult rc = encode_stream(host_in, d_in, d_stride, num_samples, data, data_size, output_size, cb, with_header, search);
                 forced_lshift = -1;

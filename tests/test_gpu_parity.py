@@ -454,3 +454,23 @@ def test_host_input_crosses_pcie_as_int16_when_it_fits(product, monkeypatch):
     lib2 = capi.EncoderLib(helpers.PRODUCT_SO)
     assert np.array_equal(lib2.encode(pcm, **M4), a)
     assert np.array_equal(lib2.encode(wide, **M4), b)
+
+
+@pytest.mark.parametrize("pinned", [False, True])
+def test_offset_shift_guessed_from_the_first_job(product, pinned, monkeypatch):
+    """The shift is guessed from the first job's samples; a later job with fewer trailing zeros makes the guess too
+    large and the stream is encoded again with the right one."""
+    import torch
+    monkeypatch.setenv("SRLA_MI355X_JOB_SAMPLES", "65536")
+    lib2 = capi.EncoderLib(helpers.PRODUCT_SO)
+    pcm = (helpers.synth(helpers.MUSIC, 99, 48000, 2, 400000) >> 3) << 3
+    for name, x in (("uniform shift", pcm.copy()), ("smaller shift later", pcm.copy()), ("silent first job", pcm.copy())):
+        if name == "smaller shift later":
+            x[1, 300001] |= 2
+        if name == "silent first job":
+            x[:, :70000] = 0
+        want = helpers.Oracle(2, **M4).encode_whole(x)
+        src = torch.from_numpy(x).pin_memory().numpy() if pinned else x
+        got = lib2.encode(src, **M4)
+        assert np.array_equal(got, want), name
+        assert got[24] == (1 if name == "smaller shift later" else 3)
