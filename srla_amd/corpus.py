@@ -87,28 +87,63 @@ def main_cli(lib, in_dir, out_dir, cli):
         def __call__(self):
             return self.path
 
-    def encode_path(path):
-        pcm, rate, bps = wavio.read_wav(path)
-        from . import capi
-        cfg, par = capi.cli_setup(pcm.shape[0], bps, rate, **cli)
-        enc = lib.create(cfg)
-        try:
-            if lib.set_parameter(enc, par) != capi.OK:
-                raise RuntimeError("SetEncodeParameter failed for %s" % path)
-            rc, data = lib.encode_whole(enc, pcm, cap=2 * os.path.getsize(path))
-            if rc != capi.OK:
-                raise RuntimeError("EncodeWhole -> %d for %s" % (rc, path))
-        finally:
-            lib.destroy(enc)
+    # One encoder per stream format, kept for the whole corpus (its device buffers and cached job tables are reused from
+    # file to file); the next file is read and parsed while the current one is encoded, finished streams are written by
+    # a thread of their own -- the encode call itself releases the GIL (ctypes).
+    from concurrent.futures import ThreadPoolExecutor
+    from . import capi
+    encoders = {}
+    reader = ThreadPoolExecutor(max_workers=1)
+    writer = ThreadPoolExecutor(max_workers=1)
+    pending_reads = {}
+    writes = []
+    my_paths = None
+
+    def prefetch(path):
+        if path is not None and path not in pending_reads:
+            pending_reads[path] = reader.submit(wavio.read_wav, path)
+
+    def write_out(path, data):
         rel = os.path.relpath(path, in_dir)
         out_path = os.path.join(out_dir, os.path.splitext(rel)[0] + ".srl")
         os.makedirs(os.path.dirname(out_path) or ".", exist_ok=True)
         with open(out_path, "wb") as f:
-            f.write(data.tobytes())
+            f.write(memoryview(data))
+
+    def encode_path(path):
+        nonlocal my_paths
+        if my_paths is None:
+            # the files this rank owns, in the order encode_corpus will ask for them
+            counts = [max(1, os.path.getsize(p)) for p in paths]
+            own = assign(counts, world)
+            my_paths = [p for p, o in zip(paths, own) if o == rank]
+        prefetch(path)
+        pcm, rate, bps = pending_reads.pop(path).result()
+        k = my_paths.index(path)
+        prefetch(my_paths[k + 1] if k + 1 < len(my_paths) else None)
+        key = (pcm.shape[0], bps, rate)
+        if key not in encoders:
+            cfg, par = capi.cli_setup(pcm.shape[0], bps, rate, **cli)
+            enc = lib.create(cfg)
+            if lib.set_parameter(enc, par) != capi.OK:
+                raise RuntimeError("SetEncodeParameter failed for %s" % path)
+            encoders[key] = enc
+        rc, data = lib.encode_whole(encoders[key], pcm, cap=2 * os.path.getsize(path))
+        if rc != capi.OK:
+            raise RuntimeError("EncodeWhole -> %d for %s" % (rc, path))
+        writes.append(writer.submit(write_out, path, data))
         return data
 
     t0 = time.perf_counter()
-    manifest, _ = encode_corpus(encode_path, [(p, Src(p)) for p in paths], rank=rank, world=world, group=group)
+    try:
+        manifest, _ = encode_corpus(encode_path, [(p, Src(p)) for p in paths], rank=rank, world=world, group=group)
+        for w in writes:
+            w.result()
+    finally:
+        reader.shutdown(wait=True)
+        writer.shutdown(wait=True)
+        for enc in encoders.values():
+            lib.destroy(enc)
     dt = time.perf_counter() - t0
     if rank == 0:
         total_out = sum(e["bytes"] for e in manifest)
