@@ -421,11 +421,13 @@ def test_offset_shift_found_after_the_fact(product, pinned, with_callback):
         assert sum(seen) == want.size - 30
 
 
-def test_output_buffer_in_device_memory(product):
-    """`data` may be device memory: the stream (header included) is left in HBM."""
+@pytest.mark.parametrize("n", [200000, 200001, 16384 * 3 + 77])
+def test_output_buffer_in_device_memory(product, n):
+    """`data` may be device memory: the stream (header included) is left in HBM (odd lengths: the chain-mode tail too)."""
     import torch
-    pcm = helpers.synth(helpers.MUSIC, 99, 48000, 2, 200000)
+    pcm = helpers.synth(helpers.MUSIC, 99, 48000, 2, n)
     want = product.encode(pcm, **M4)
+    assert np.array_equal(want, helpers.Oracle(2, **M4).encode_whole(pcm))
     cfg, par = capi.cli_setup(2, 16, 48000, **M4)
     enc = product.create(cfg)
     assert product.set_parameter(enc, par) == capi.OK
