@@ -1464,13 +1464,17 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(R >= 4 ? 2 :
     constexpr int CH = 2 * R;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const InputView iv = input_view(jp);
+    /* as in srla_autocorr: workgroups go to the XCDs round robin, so each XCD is given one contiguous range of items --
+     * the dozen items that read the same samples then share one L2 instead of pulling them into all eight */
+    const uint32_t block = xcd_position(blockIdx.x, jp.num_items);
+    if (block >= jp.num_items) return;
     {
         /* blocks of 1024 * FL samples take the register / shuffle fast path */
-        const SrlaItemDesc itf = items[blockIdx.x];
+        const SrlaItemDesc itf = items[block];
         const uint32_t fl = itf.n >> 10;
         if ((itf.n & 1023u) == 0 && fl >= 1 && fl <= 8 && fl <= (uint32_t)(2 * R)) {
             const int32_t *inf = input + itf.sample_off;
-            SrlaItemResult *outf = &results[blockIdx.x];
+            SrlaItemResult *outf = &results[block];
 #define FAST(FLV)                                                                                                   \
             do {                                                                                                    \
                 if (jp.bits_per_sample <= 18) residual_cost_fast<FLV, false>(jp, iv, inf, itf, lds, rice_thresholds, res_ws, outf); \
@@ -1503,7 +1507,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(R >= 4 ? 2 :
     SmallC *sm = (SmallC *)(lds + plan.small_off);
 
     const uint32_t tid = threadIdx.x, lane = tid & 63;
-    const uint32_t item_idx = blockIdx.x;
+    const uint32_t item_idx = block;
     const SrlaItemDesc it = items[item_idx];
     const SrlaGeom g = geoms[it.geom];
     const uint32_t n = it.n, bps = jp.bits_per_sample;
@@ -2486,7 +2490,7 @@ extern "C" int srla_launch_residual_cost(hipStream_t stream, int rclass, const S
                                          hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     if (jp->num_items == 0) return 0;
-    dim3 grid(jp->num_items), block(NT);
+    dim3 grid(8u * ((jp->num_items + 7u) >> 3)), block(NT);
 #define LAUNCH(RR)                                                                                           \
     do {                                                                                                     \
         SET_LDS_ATTR(srla_residual_cost<RR>);                                                                \
