@@ -132,9 +132,11 @@ SRLAApiResult SRLAEncoder_EncodeWhole(
  * (one process per GPU is the intended deployment; default device 0). Returns 0 on success. */
 int SRLAMI355X_SetDevice(int device_index);
 
-/* Number of host threads the bit-packer may use (default: min(8, usable CPUs / 2), or the
- * SRLA_MI355X_PACK_THREADS environment variable).  With several processes per node (one per GPU) give
- * each process hardware_threads / processes. */
+/* Number of host pool threads (default: min(8, usable CPUs / 2), or the SRLA_MI355X_PACK_THREADS environment
+ * variable).  The bitstream is assembled on the device; the pool only stages pageable input planes into pinned
+ * memory (packing them to int16 where they fit) and copies finished blocks out of the pinned staging buffer when
+ * the caller's output buffer is pageable.  With several processes per node (one per GPU) give each process
+ * hardware_threads / processes; with device-resident input and a pinned output buffer the pool is idle. */
 void SRLAMI355X_SetPackThreads(struct SRLAEncoder *encoder, uint32_t num_threads);
 
 /* EncodeWhole for samples already resident in HBM: d_input is a device pointer to planar
