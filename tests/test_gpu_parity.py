@@ -476,3 +476,17 @@ def test_offset_shift_guessed_from_the_first_job(product, pinned, monkeypatch):
         got = lib2.encode(src, **M4)
         assert np.array_equal(got, want), name
         assert got[24] == (1 if name == "smaller shift later" else 3)
+
+
+@pytest.mark.parametrize("cli_name", ["m4_B4096", "m4_B4096_V2_P3", "m5_B2048_V3", "m1_B512_V0"])
+def test_many_small_jobs_rotate_through_the_buffer_sets(product, cli_name, monkeypatch):
+    """Jobs of 64 Ki samples: a stream of a few hundred thousand samples then runs through every rotating buffer set
+    several times, the two tail sets and (odd length) the three chain-mode sets; bytes must not depend on the job size."""
+    monkeypatch.setenv("SRLA_MI355X_JOB_SAMPLES", "65536")
+    lib2 = capi.EncoderLib(helpers.PRODUCT_SO)
+    cli = CLIS[cli_name]
+    for nch, n in ((2, 16384 * 30 + 4097), (1, 16384 * 21), (3, 16384 * 17 + 300)):
+        pcm = helpers.synth(helpers.VARIED, 55 + nch, 48000, nch, n)
+        got = lib2.encode(pcm, **cli)
+        assert np.array_equal(got, helpers.Oracle(nch, **cli).encode_whole(pcm)), (cli_name, nch, n)
+        assert np.array_equal(got, product.encode(pcm, **cli))
