@@ -490,3 +490,36 @@ def test_many_small_jobs_rotate_through_the_buffer_sets(product, cli_name, monke
         got = lib2.encode(pcm, **cli)
         assert np.array_equal(got, helpers.Oracle(nch, **cli).encode_whole(pcm)), (cli_name, nch, n)
         assert np.array_equal(got, product.encode(pcm, **cli))
+
+
+def test_handles_of_several_threads_encode_concurrently(product):
+    """A handle is not re-entrant (like the reference's), but handles are independent: every one has its own HIP streams
+    and buffers, so threads with a handle each may encode at the same time."""
+    import threading
+    cli = dict(preset=4, max_block=4096, divisions=2, ltp_order=3)
+    files = [helpers.synth(helpers.VARIED, 300 + i, 48000, 2, 48000 * 2 + 1001 * i) for i in range(9)]
+    want = [helpers.Oracle(2, **cli).encode_whole(f) for f in files]
+    cfg, par = capi.cli_setup(2, 16, 48000, **cli)
+    encs = [product.create(cfg) for _ in range(3)]
+    for e in encs:
+        assert product.set_parameter(e, par) == capi.OK
+    out = [None] * len(files)
+    errs = []
+
+    def worker(k):
+        try:
+            for rep in range(2):
+                for i in range(k, len(files), 3):
+                    rc, data = product.encode_whole(encs[k], files[i])
+                    assert rc == capi.OK
+                    out[i] = data
+        except Exception as e:      # surfaced below: an assertion in a thread would otherwise be lost
+            errs.append(e)
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(3)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for e in encs:
+        product.destroy(e)
+    assert not errs, errs
+    for i in range(len(files)):
+        assert np.array_equal(out[i], want[i]), i
