@@ -1,30 +1,38 @@
 #!/usr/bin/env python3
 """bench.py -- encode throughput of the MI355X SRLA path on BASELINE.json's metric configuration.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config M|C1..C5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-Workload (config.workload): `srla -e -m 4 -B 4096` with the CLI defaults -V 1 -L 4 -P 0 on synthetic
-48 kHz / 16-bit stereo PCM (tools/synth, kind "music"), `--seconds` of audio per GPU per step.
+`python bench.py --gpus N` with N > 1 and no torchrun environment starts the N ranks itself (one process per GPU).
 
-A step is one complete encode of that batch: the planar int32 samples are already resident in HBM when
-the timed region starts (SRLAMI355X_EncodeWholeDevice); the step covers the offset-shift reduction, the
-item-analysis / pricing / gather kernels, the D2H of residuals and parameters and the multi-threaded host
-bit pack, and ends with the complete .srl stream in host memory.  Every rank encodes its own batch
-(frames shard embarrassingly: no collective on the data path), so scaling is weak; value = total sample
-instants (per channel) encoded by all ranks / max-over-ranks time.
+Workload (config.workload): by default the metric configuration `srla -e -m 4 -B 4096` (CLI defaults -V 1 -L 4 -P 0)
+on synthetic 48 kHz / 16-bit stereo PCM (tools/synth, kind "music"), `--seconds` of audio per GPU per step.
+`--config C1..C5` selects one of BASELINE.json's five configurations instead (C5: a corpus of 300 s files per GPU,
+encoded by one SRLAMI355X_EncodeBatch call per step).
+
+Timed region of `value`: SRLAEncoder_EncodeWhole -- planar int32 samples in ordinary (pageable) host
+memory in, the complete .srl stream in ordinary host memory out; staging, H2D, every kernel and the way back are
+inside.  K steps between barriers, max over ranks; value = sample instants encoded by all ranks / that time.
+Every rank encodes its own streams (windows and files are independent units: no collective on the data path), so
+scaling is weak.
 
 Extra objects on the JSON line:
-  roofline      dominant kernel (srla_analyze_items): algorithmic bytes = 16 B per stereo sample instant
-                 x instants per launch, over the launch duration measured with HIP events on
-                the launch stream inside the timed region; peak = 8000 GB/s HBM3E.
-  cpu_baseline  the compiled reference (oracle/_ref, "reference") or the oracle ("port") timed on ONE host
-                core on a bounded sample of the same workload.
+  roofline         dominant kernel (srla_residual_cost): algorithmic bytes = 16 B per stereo sample instant
+                   x instants per launch, over the average launch duration measured with HIP events attached to the
+                   dispatches inside the timed region; peak = 8000 GB/s HBM3E; traffic, valu_util and fp64_inst_frac from
+                   the committed rocprofv3 PMC summary (profiles/pmc_summary.json).
+  cpu_baseline     the compiled reference (oracle/_ref, "reference") or the oracle ("port") timed on ONE host core on
+                   a bounded sample of the same workload (rank 0, N = 1 only).
+  device_resident  the same encode with the samples already in HBM and a pinned output buffer
+                   (SRLAMI355X_EncodeWholeDevice), mean of a few calls outside the timed region -- never `value`.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,7 +40,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-import numpy as np  # noqa: E402
+# name -> (cli flags of `srla -e`, input description)
+CONFIGS = {
+    "M":  dict(cli=dict(preset=4, max_block=4096, divisions=1, ltp_order=0), rate=48000, nch=2, kind="music", seconds=600.0),
+    "C1": dict(cli=dict(preset=0, max_block=2048, divisions=1, ltp_order=0), rate=44100, nch=1, kind="sine", seconds=10.0),
+    "C2": dict(cli=dict(preset=2, max_block=4096, divisions=1, ltp_order=0), rate=48000, nch=2, kind="music", seconds=600.0),
+    "C3": dict(cli=dict(preset=4, max_block=4096, divisions=2, ltp_order=0), rate=48000, nch=2, kind="music", seconds=300.0),
+    "C4": dict(cli=dict(preset=4, max_block=8192, divisions=2, ltp_order=3), rate=48000, nch=2, kind="music", seconds=300.0),
+    "C5": dict(cli=dict(preset=4, max_block=4096, divisions=2, ltp_order=3), rate=48000, nch=2, kind="music", seconds=300.0, files=9),
+}
 
 
 class Stats(C.Structure):
@@ -42,7 +58,8 @@ class Stats(C.Structure):
                 ("analyze_ms", C.c_double), ("price_ms", C.c_double), ("gather_ms", C.c_double),
                 ("h2d_ms", C.c_double), ("d2h_ms", C.c_double), ("pack_ms", C.c_double), ("total_ms", C.c_double),
                 ("analyzed_samples", C.c_uint64), ("autocorr_ms", C.c_double), ("solve_ms", C.c_double),
-                ("residual_ms", C.c_double), ("timed_jobs", C.c_uint64)]
+                ("residual_ms", C.c_double), ("timed_jobs", C.c_uint64),
+                ("num_tie_resolved", C.c_uint64), ("num_tie_overrides", C.c_uint64), ("num_restarts", C.c_uint64)]
 
 
 def usable_cpus():
@@ -59,6 +76,7 @@ def usable_cpus():
 
 def cpu_baseline(pcm, cli, seconds, rate, bps=16):
     """Single-thread CPU encode of the first `seconds` of the workload (reference if it travelled here)."""
+    import numpy as np
     import helpers
     from srla_amd import capi
     n = min(pcm.shape[1], int(seconds * rate))
@@ -79,57 +97,122 @@ def cpu_baseline(pcm, cli, seconds, rate, bps=16):
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
     return {"value": round(n / best / 1e6, 4), "unit": "Msamples/s", "cores": 1, "kind": kind,
-            "sample": "first %.0f s of the same workload (%d samples/ch, stereo), best of 2, %s" %
-                      (n / rate, n, "AVX2 build of the reference, EncodeWhole in memory" if kind == "reference"
+            "sample": "first %.0f s of the same workload (%d samples/ch, %d ch), best of 2, %s" %
+                      (n / rate, n, clip.shape[0], "AVX2 build of the reference, EncodeWhole in memory" if kind == "reference"
                        else "oracle/srla_oracle.c, scalar C"),
             "bytes": int(out.size)}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks (one GPU each); default: WORLD_SIZE of the launcher, else 1")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--seconds", type=float, default=600.0, help="audio per GPU per step")
+    ap.add_argument("--config", default="M", choices=sorted(CONFIGS), help="M: the metric configuration; C1..C5: BASELINE.json's configs")
+    ap.add_argument("--seconds", type=float, default=None, help="audio per stream (default: the configuration's)")
+    ap.add_argument("--files", type=int, default=None, help="streams per GPU per step (> 1: one SRLAMI355X_EncodeBatch call per step)")
     ap.add_argument("--cpu-seconds", type=float, default=40.0, help="audio for the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--preset", type=int, default=4)
-    ap.add_argument("--block", type=int, default=4096)
-    ap.add_argument("--divisions", type=int, default=1)
-    ap.add_argument("--ltp", type=int, default=0)
+    ap.add_argument("--preset", type=int, default=None)
+    ap.add_argument("--block", type=int, default=None)
+    ap.add_argument("--divisions", type=int, default=None)
+    ap.add_argument("--ltp", type=int, default=None)
     ap.add_argument("--bps", type=int, default=16, choices=[8, 16, 24], help="bits per sample of the synthetic input (the metric is quoted at 16)")
     ap.add_argument("--no-numa-pin", action="store_true", help="do not restrict the process to the GPU-local NUMA node")
-    ap.add_argument("--pack-threads", type=int, default=0, help="host threads copying staged blocks when the output is pageable (default: min(8, usable CPUs / (2 * ranks)))")
-    ap.add_argument("--pageable-output", action="store_true", help="give the encoder an ordinary (pageable) output buffer: the device then "
-                    "writes the blocks into the library's pinned staging buffers and host threads copy them out")
-    args = ap.parse_args()
+    ap.add_argument("--pack-threads", type=int, default=0, help="host pool threads (staging copies; default: min(8, usable CPUs / (2 * ranks)))")
+    ap.add_argument("--pinned-io", action="store_true", help="headline with pinned input planes and a pinned output buffer (reported in config.workload)")
+    ap.add_argument("--dry-run", action="store_true", help="launch / rendezvous / reduce only, no GPU work (CPU test of the N-rank flow)")
+    return ap.parse_args(argv)
 
-    import torch
-    import helpers
-    from srla_amd import capi
 
+def spawn_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (what torchrun would set up)."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SRLA_BENCH_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    return rc
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and (args.gpus or 1) > 1:
+        raise SystemExit(spawn_ranks(args, argv))
+    world = int(env_world or "1")
+    if args.gpus is not None and args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the MI355X path has no CPU fallback")
-    # SRLA_BENCH_SHARED_GPU=1 (test hook): ranks may share a device, so that the N > 1 flow can be exercised on a box with
-    # one GPU; RCCL refuses two ranks on one device, so the barrier / max-reduce then go through gloo
-    shared_gpu = os.environ.get("SRLA_BENCH_SHARED_GPU") == "1"
-    if shared_gpu:
-        local_rank %= torch.cuda.device_count()
-    torch.cuda.set_device(local_rank)
+
+    conf = CONFIGS[args.config]
+    cli = dict(conf["cli"])
+    for k, v in (("preset", args.preset), ("max_block", args.block), ("divisions", args.divisions), ("ltp_order", args.ltp)):
+        if v is not None:
+            cli[k] = v
+    rate, nch, bps = conf["rate"], conf["nch"], args.bps
+    seconds = args.seconds if args.seconds is not None else conf["seconds"]
+    files = args.files if args.files is not None else conf.get("files", 1)
+    n = int(seconds * rate)
+    n -= n % 2
+    metric = "encode Msamples/s (-m %d -B %d -V %d -P %d, %s %g kHz %d-bit)" % (
+        cli["preset"], cli["max_block"], cli["divisions"], cli["ltp_order"], "stereo" if nch == 2 else "%d ch" % nch, rate / 1000.0, bps)
+
+    import numpy as np
+    import torch
     dist = None
+    shared_gpu = os.environ.get("SRLA_BENCH_SHARED_GPU") == "1"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo" if shared_gpu else "nccl")   # nccl = RCCL; used only for the timing barrier / max-reduce
+        # nccl = RCCL; used only for the timing barrier / max-reduce.  SRLA_BENCH_SHARED_GPU=1 (test hook): ranks may share
+        # a device (RCCL refuses two ranks on one device, so the barrier / max-reduce then go through gloo)
+        dist.init_process_group("gloo" if (shared_gpu or args.dry_run) else "nccl")
 
-    # one process per GPU, kept on the CPUs of the GPU's own NUMA node (doorbells, pinned buffers, pack threads)
+    def finish(line):
+        if rank == 0:
+            print(json.dumps(line), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+
+    base_line = {"metric": metric, "value": None, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                 "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32+f64",
+                 "data": "synthetic"}
+    if args.dry_run:
+        # the N-rank flow without a GPU: every rank "works" for a while, rank 0 reports the max
+        dist and dist.barrier()
+        t0 = time.perf_counter()
+        time.sleep(0.01 * (rank + 1))
+        dist and dist.barrier()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+        if dist is not None:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        base_line.update(ms_per_step=round(1e3 * float(t.item()), 3), dry_run=True, config={"workload": "dry run (no GPU work)"})
+        return finish(base_line)
+
+    import helpers
+    from srla_amd import capi
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the MI355X path has no CPU fallback")
+    if local_rank >= torch.cuda.device_count() and not shared_gpu:
+        raise SystemExit("bench.py: rank %d has no GPU of its own (%d visible)" % (local_rank, torch.cuda.device_count()))
+    local_dev = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(local_dev)
+
+    # one process per GPU, kept on the CPUs of the GPU's own NUMA node (doorbells, pinned buffers, pool threads)
     numa_cpus = None
     if not args.no_numa_pin:
         try:
-            pr = torch.cuda.get_device_properties(local_rank)
+            pr = torch.cuda.get_device_properties(local_dev)
             bdf = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
             cpus = set()
             for part in open("/sys/bus/pci/devices/%s/local_cpulist" % bdf).read().strip().split(","):
@@ -142,45 +225,46 @@ def main():
         except Exception:
             numa_cpus = None
     lib = capi.EncoderLib(helpers.PRODUCT_SO)
-    lib.lib.SRLAMI355X_SetDevice.argtypes = [C.c_int]
-    assert lib.lib.SRLAMI355X_SetDevice(local_rank) == 0
-    lib.lib.SRLAMI355X_EncodeWholeDevice.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p,
-                                                     C.c_uint32, C.POINTER(C.c_uint32), C.c_void_p]
-    lib.lib.SRLAMI355X_GetStats.argtypes = [C.c_void_p, C.POINTER(Stats), C.c_int]
+    L = lib.lib
+    L.SRLAMI355X_SetDevice.argtypes = [C.c_int]
+    assert L.SRLAMI355X_SetDevice(local_dev) == 0
+    L.SRLAMI355X_EncodeWholeDevice.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p,
+                                               C.c_uint32, C.POINTER(C.c_uint32), C.c_void_p]
+    L.SRLAMI355X_GetStats.argtypes = [C.c_void_p, C.POINTER(Stats), C.c_int]
+    L.SRLAMI355X_SetPackThreads.argtypes = [C.c_void_p, C.c_uint32]
 
-    rate, nch, bps = 48000, 2, args.bps
-    n = int(args.seconds * rate)
-    n -= n % 2  # even length (odd tails are history dependent in the reference)
-    cli = dict(preset=args.preset, max_block=args.block, divisions=args.divisions, ltp_order=args.ltp)
-    pcm = helpers.synth(helpers.MUSIC, 1000 + rank, rate, nch, n, bps)
-    d_pcm = torch.from_numpy(pcm).cuda()
-    torch.cuda.synchronize()
-
+    kind = helpers.SINE if conf["kind"] == "sine" else helpers.MUSIC
+    pcms = [helpers.synth(kind, 1000 + 97 * rank + f, rate, nch, n, bps) for f in range(files)]
+    if args.pinned_io:
+        pcms = [torch.from_numpy(p).pin_memory().numpy() for p in pcms]
     cfg, par = capi.cli_setup(nch, bps, rate, **cli)
     enc = lib.create(cfg)
     assert enc and lib.set_parameter(enc, par) == capi.OK
     pack_threads = args.pack_threads or max(1, min(8, usable_cpus() // (2 * max(1, world))))
-    lib.lib.SRLAMI355X_SetPackThreads.argtypes = [C.c_void_p, C.c_uint32]
-    lib.lib.SRLAMI355X_SetPackThreads(enc, pack_threads)
-    cap = 2 * pcm.size * 2 + 4096
-    if args.pageable_output:
-        out = np.zeros(cap, dtype=np.uint8)
-    else:
-        # pinned host memory: the pack kernel stores every block at its final offset of this buffer
-        out_t = torch.empty(cap, dtype=torch.uint8).pin_memory()
-        out = out_t.numpy()
-    out_size = C.c_uint32(0)
+    L.SRLAMI355X_SetPackThreads(enc, pack_threads)
+    cap = 2 * pcms[0].size * (bps // 8) + 4096
+    outs = [(torch.empty(cap, dtype=torch.uint8).pin_memory().numpy() if args.pinned_io else np.zeros(cap, dtype=np.uint8))
+            for _ in range(files)]
+    out_sizes = (C.c_uint32 * files)()
+    planes = [capi.planar_ptrs(p) for p in pcms]
 
-    def step():
-        rc = lib.lib.SRLAMI355X_EncodeWholeDevice(enc, C.c_void_p(d_pcm.data_ptr()), n, n,
-                                                  out.ctypes.data_as(C.c_void_p), cap, C.byref(out_size), None)
-        if rc != capi.OK:
-            raise SystemExit("SRLAMI355X_EncodeWholeDevice -> %d" % rc)
+    if files == 1:
+        def step():
+            rc = L.SRLAEncoder_EncodeWhole(enc, planes[0], n, outs[0].ctypes.data_as(C.c_void_p), cap, C.cast(out_sizes, C.POINTER(C.c_uint32)), None)
+            if rc != capi.OK:
+                raise SystemExit("SRLAEncoder_EncodeWhole -> %d" % rc)
+    else:
+        batch = capi.BatchCall(lib, pcms, outs)
+
+        def step():
+            rc = batch.run(enc, out_sizes)
+            if rc != capi.OK:
+                raise SystemExit("SRLAMI355X_EncodeBatch -> %d" % rc)
 
     for _ in range(args.warmup):
         step()
     st = Stats()
-    lib.lib.SRLAMI355X_GetStats(enc, C.byref(st), 1)  # reset counters
+    L.SRLAMI355X_GetStats(enc, C.byref(st), 1)  # reset counters
 
     def barrier():
         torch.cuda.synchronize()
@@ -198,81 +282,89 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if shared_gpu else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    lib.lib.SRLAMI355X_GetStats(enc, C.byref(st), 0)
-    stream = out[:out_size.value].copy()
+    L.SRLAMI355X_GetStats(enc, C.byref(st), 0)
+    streams = [outs[f][:out_sizes[f]].copy() for f in range(files)]
 
+    line = None
     if rank == 0:
-        # sanity inside the bench: the stream decodes back to the input (oracle decoder = checker only)
-        diag = bool(os.environ.get("SRLA_MI355X_K3_STOP"))          # kernel timing experiments: no stream is produced
-        lossless = None if diag else bool((helpers.oracle_decode(stream) == pcm).all())
-        total_instants = float(n) * args.steps * world
+        # sanity inside the bench: the streams decode back to the input (oracle decoder = checker only)
+        lossless = all(bool((helpers.oracle_decode(streams[f]) == pcms[f]).all()) for f in range(files))
+        total_instants = float(n) * files * args.steps * world
         value = total_instants / elapsed / 1e6
-        launches = max(1, st.analyze_launches)          # one launch of each analysis kernel per job
-        # HIP events recorded by the library on the stream each kernel runs on, inside the timed region
-        # the roofline line is about ONE kernel: srla_residual_cost, the longest single launch of a job
-        # srla_residual_cost is timed on every job, the other stages on one job in four (each start event costs
-        # stream time); srla_autocorr is two launches per job (one per FFT-size class)
+        launches = max(1, st.analyze_launches)          # one launch of srla_residual_cost per job
+        # HIP events attached by the library to the kernel dispatches, on the stream each kernel runs on, inside the timed
+        # region.  srla_residual_cost is timed on every job, the other stages on one job in four (each start event costs
+        # stream time); srla_autocorr is one launch per FFT-size class and pass.
         timed = max(1, st.timed_jobs)
-        per_job = {"srla_autocorr": st.autocorr_ms / timed, "srla_lpc_recursion+order_select+quantize": st.solve_ms / timed,
+        per_job = {"srla_autocorr": st.autocorr_ms / timed, "srla_lpc_solve": st.solve_ms / timed,
                    "srla_residual_cost": st.residual_ms / launches}
         dominant = "srla_residual_cost"
         avg_launch_ms = per_job[dominant]
-        instants_per_launch = float(n) * args.steps / launches
-        algo_bytes = 16.0 * instants_per_launch            # 8 B per channel-sample, stereo
+        instants_per_launch = float(n) * files * args.steps / launches
+        algo_bytes = 8.0 * nch * instants_per_launch            # 8 B per channel-sample
         achieved = algo_bytes / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = int(json.load(open(tpath))["bytes_per_instant"] * instants_per_launch)
-            except Exception:
-                traffic = None
-        line = {
-            "metric": "encode Msamples/s (-m %d -B %d -V %d -P %d, stereo 48 kHz %d-bit)" % (args.preset, args.block, args.divisions, args.ltp, bps),
-            "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "int32+f64", "data": "synthetic",
-            "config": {"workload": "srla -e -m %d -B %d -V %d -L 4 -P %d; %.0f s synthetic stereo 48 kHz/%d-bit (music-like) per GPU per step, "
-                                   "samples resident in HBM, complete .srl stream produced in %s host memory" %
-                                   (args.preset, args.block, args.divisions, args.ltp, n / rate, bps, "pageable" if args.pageable_output else "pinned"),
-                       "samples_per_channel_per_step": n, "parallelism": "windows sharded per GPU, no collective"},
-            "compression_ratio": round(out_size.value / float(pcm.size * (bps // 8)), 6),
+        roof = {"bound": "hbm", "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
+                "frac": round(achieved / 8000.0, 6), "traffic": None, "kernel": dominant, "avg_launch_ms": round(avg_launch_ms, 4),
+                "per_job_stage_ms": {k: round(v, 4) for k, v in per_job.items()},
+                "launches": int(st.analyze_launches), "algorithmic_bytes_per_launch": int(algo_bytes),
+                "items_per_launch": int(st.num_items / launches)}
+        try:
+            # measured with rocprofv3 --pmc in separate passes (tools/summarize_r02.py), committed under profiles/
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_summary.json")))
+            ent = pmc.get(args.config, {}).get(dominant)
+            if ent:
+                roof["traffic"] = int(ent["hbm_bytes_per_instant"] * instants_per_launch)
+                roof["valu_util"] = ent["valu_util"]
+                roof["fp64_inst_frac"] = ent.get("fp64_inst_frac")
+                roof["pmc_source"] = ent["source"]
+        except Exception:
+            pass
+        total_out = sum(int(s.size) for s in streams)
+        line = dict(base_line)
+        line.update({
+            "value": round(value, 3), "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "config": {"workload": "%s: srla -e -m %d -B %d -V %d -L 4 -P %d; %d x %.0f s synthetic %d-ch %g kHz/%d-bit (%s) per GPU per step; "
+                                   "%s: planar int32 in %s host memory -> complete .srl stream(s) in %s host memory" %
+                                   (args.config, cli["preset"], cli["max_block"], cli["divisions"], cli["ltp_order"], files, n / rate, nch,
+                                    rate / 1000.0, bps, conf["kind"], "SRLAEncoder_EncodeWhole" if files == 1 else "SRLAMI355X_EncodeBatch",
+                                    "pinned" if args.pinned_io else "pageable", "pinned" if args.pinned_io else "pageable"),
+                       "samples_per_channel_per_step": n * files, "streams_per_step": files,
+                       "parallelism": "windows / files sharded per GPU, no collective"},
+            "compression_ratio": round(total_out / float(sum(p.size for p in pcms) * (bps // 8)), 6),
             "lossless_roundtrip": lossless,
             "channel_samples_per_s_M": round(value * nch, 3),
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
-                         "frac": round(achieved / 8000.0, 6), "traffic": traffic,
-                         "kernel": dominant, "avg_launch_ms": round(avg_launch_ms, 4),
-                         "per_job_stage_ms": {k: round(v, 4) for k, v in per_job.items()},
-                         "launches": int(st.analyze_launches), "algorithmic_bytes_per_launch": int(algo_bytes),
-                         "items_per_launch": int(st.num_items / launches)},
+            "roofline": roof,
             "phase_ms_per_step": {"autocorr": round(st.autocorr_ms / timed * launches / args.steps, 3),
                                   "solve": round(st.solve_ms / timed * launches / args.steps, 3),
                                   "residual_cost": round(st.residual_ms / args.steps, 3), "price": round(st.price_ms / timed * launches / args.steps, 3),
                                   "pack_blocks": round(st.gather_ms / timed * launches / args.steps, 3),
-                                  "enqueue_host": round(st.h2d_ms / args.steps, 3), "collect_host": round(st.pack_ms / args.steps, 3), "total_host": round(st.total_ms / args.steps, 3)},
-            "host_cores": os.cpu_count(), "host_cpu_quota": usable_cpus(), "host_pack_threads": pack_threads, "numa_local_cpus": numa_cpus,
-            "tie_items": int(st.num_tie_items),
-        }
-        # PCIe-inclusive rate of the reference's own entry point (pageable host planes in, same output buffer), best of 3
-        # calls outside the timed region; reported beside `value`, never as `value`
-        host_t = []
-        for _ in range(0 if (diag or world > 1) else 3):     # single-GPU runs only
-            t1 = time.perf_counter()
-            rc = lib.lib.SRLAEncoder_EncodeWhole(enc, capi.planar_ptrs(pcm), n, out.ctypes.data_as(C.c_void_p), cap, C.byref(out_size), None)
-            host_t.append(time.perf_counter() - t1)
-            if rc != capi.OK:
-                raise SystemExit("SRLAEncoder_EncodeWhole -> %d" % rc)
-        if host_t:
-            line["host_input"] = {"value": round(n / min(host_t) / 1e6, 3), "unit": "Msamples/s", "ms_per_call": round(1e3 * min(host_t), 3),
-                              "same_bytes": bool(np.array_equal(out[:out_size.value], stream)),
-                              "note": "SRLAEncoder_EncodeWhole, pageable int32 planes in host memory: staging copies (which pack to int16 and gather the offset-shift OR) + H2D + widening + the same device pipeline"}
+                                  "enqueue_host": round(st.h2d_ms / args.steps, 3), "collect_host": round(st.pack_ms / args.steps, 3),
+                                  "total_host": round(st.total_ms / args.steps, 3)},
+            "host_cores": os.cpu_count(), "host_cpu_quota": usable_cpus(), "host_pool_threads": pack_threads, "numa_local_cpus": numa_cpus,
+            "tie_items": int(st.num_tie_items), "tie_resolved": int(st.num_tie_resolved), "tie_overrides": int(st.num_tie_overrides),
+        })
+        if world == 1 and files == 1:
+            # the same encode with the samples resident in HBM and a pinned output buffer (what a caller that already holds
+            # the samples on the device gets): reported beside `value`, never as `value`
+            d_pcm = torch.from_numpy(pcms[0]).cuda()
+            out_t = torch.empty(cap, dtype=torch.uint8).pin_memory()
+            dsz = C.c_uint32(0)
+            reps = max(1, min(args.steps, 5))
+            for k in range(reps + 1):
+                if k == 1:
+                    torch.cuda.synchronize(); t1 = time.perf_counter()
+                rc = L.SRLAMI355X_EncodeWholeDevice(enc, C.c_void_p(d_pcm.data_ptr()), n, n, C.c_void_p(out_t.data_ptr()), cap, C.byref(dsz), None)
+                if rc != capi.OK:
+                    raise SystemExit("SRLAMI355X_EncodeWholeDevice -> %d" % rc)
+            dt = (time.perf_counter() - t1) / reps
+            line["device_resident"] = {"value": round(n / dt / 1e6, 3), "unit": "Msamples/s", "ms_per_call": round(1e3 * dt, 3),
+                                       "same_bytes": bool(np.array_equal(out_t.numpy()[:dsz.value], streams[0])),
+                                       "note": "SRLAMI355X_EncodeWholeDevice: samples resident in HBM, pinned output buffer; mean of %d calls" % reps}
         if not args.no_cpu_baseline and world == 1:        # rank 0 at N = 1 only
-            line["cpu_baseline"] = cpu_baseline(pcm, cli, args.cpu_seconds, rate, bps)
+            line["cpu_baseline"] = cpu_baseline(pcms[0], cli, args.cpu_seconds, rate, bps)
             line["speedup_vs_cpu_1core"] = round(value / line["cpu_baseline"]["value"], 2)
-        print(json.dumps(line), flush=True)
     lib.destroy(enc)
-    if dist is not None:
-        dist.destroy_process_group()
+    finish(line)
 
 
 if __name__ == "__main__":

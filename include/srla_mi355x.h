@@ -153,7 +153,7 @@ struct SRLAMI355XStats {
     uint64_t num_blocks;         /* blocks written                                       */
     uint64_t num_raw_blocks;
     uint64_t num_silent_blocks;
-    uint64_t num_tie_items;      /* chosen items whose order choice was within libm tolerance */
+    uint64_t num_tie_items;      /* items whose order / LTP tap decision was within the libm tolerance (arbitrated on the host) */
     uint64_t num_odd_items;      /* chosen items with an odd block length                */
     uint64_t analyze_launches;   /* jobs enqueued (one launch of srla_residual_cost each)  */
     double   analyze_ms;         /* autocorr_ms + solve_ms + residual_ms                   */
@@ -168,6 +168,9 @@ struct SRLAMI355XStats {
     double   solve_ms;           /* recursion + order selection + quantiser, timed jobs only  */
     double   residual_ms;        /* srla_residual_cost, HIP events around the launch, every job */
     uint64_t timed_jobs;         /* jobs on which every stage was timed (one in four); residual_ms covers all jobs */
+    uint64_t num_tie_resolved;   /* flagged items (any candidate, not only chosen ones) whose decision the host libm confirmed */
+    uint64_t num_tie_overrides;  /* flagged items where the host libm decided otherwise: re-analysed with the host's decision */
+    uint64_t num_restarts;       /* times the stream loop went back to a job because of such an override            */
 };
 /* cumulative since Create or the last reset */
 void SRLAMI355X_GetStats(struct SRLAEncoder *encoder, struct SRLAMI355XStats *stats, int reset);

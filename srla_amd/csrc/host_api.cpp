@@ -1,0 +1,266 @@
+/*
+ * host_api.cpp -- the C ABI of include/srla_mi355x.h: argument checking exactly as the reference API
+ * (libs/srla_encoder/src/srla_encoder.c), then the host runtime (host_impl.h).
+ */
+#include "host_impl.h"
+
+#include <algorithm>
+#include <stdlib.h>
+#include <string.h>
+
+static_assert(sizeof(SrlaItemResult) == SRLAMI355X_ITEM_RECORD_BYTES, "record size");
+static_assert(SRLA_DBG_STRIDE == SRLAMI355X_DEBUG_DOUBLES, "debug stride");
+
+namespace {
+
+int32_t work_size_of(const SRLAEncoderConfig *config)
+{
+    /* validity rules of srla_encoder.c:468-496 */
+    if (config == NULL) return -1;
+    if (config->max_num_samples_per_block == 0 || config->min_num_samples_per_block == 0
+        || config->max_num_lookahead_samples == 0 || config->max_num_channels == 0) return -1;
+    if (config->max_num_parameters > config->max_num_samples_per_block) return -1;
+    if (config->min_num_samples_per_block > config->max_num_samples_per_block) return -1;
+    if (config->max_num_lookahead_samples < config->max_num_samples_per_block) return -1;
+    return (int32_t)(sizeof(SRLAEncoder) + 16);
+}
+
+Impl *impl_of(SRLAEncoder *e) { return (e && e->magic == SRLA_HANDLE_MAGIC) ? e->impl : nullptr; }
+
+}  // namespace
+
+extern "C" {
+
+const char *SRLAMI355X_Version(void) { return "srla-mi355x 0.1 (gfx950 HIP; SRLA codec 18 / format 10)"; }
+
+int SRLAMI355X_SetDevice(int device_index)
+{
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device_index < 0 || device_index >= count) return -1;
+    g_device_index = device_index;
+    return (hipSetDevice(device_index) == hipSuccess) ? 0 : -1;
+}
+
+SRLAApiResult SRLAEncoder_EncodeHeader(const struct SRLAHeader *header, uint8_t *data, uint32_t data_size)
+{
+    /* srla_encoder.c:85-165 */
+    if (header == NULL || data == NULL) return SRLA_APIRESULT_INVALID_ARGUMENT;
+    if (data_size < SRLA_HEADER_SIZE) return SRLA_APIRESULT_INSUFFICIENT_BUFFER;
+    if (header->num_channels == 0 || header->num_samples == 0 || header->sampling_rate == 0
+        || header->bits_per_sample == 0 || header->offset_lshift >= 32 || header->max_num_samples_per_block == 0
+        || header->preset >= SRLA_NUM_PARAMETER_PRESETS) return SRLA_APIRESULT_INVALID_FORMAT;
+    srla::StreamInfo si;
+    si.num_channels = header->num_channels; si.bits_per_sample = header->bits_per_sample;
+    si.sampling_rate = header->sampling_rate; si.num_samples = header->num_samples;
+    si.offset_lshift = header->offset_lshift; si.max_block = header->max_num_samples_per_block;
+    si.preset = header->preset; si.ltp_order = 0;
+    srla::write_stream_header(si, data);
+    return SRLA_APIRESULT_OK;
+}
+
+int32_t SRLAEncoder_CalculateWorkSize(const struct SRLAEncoderConfig *config) { return work_size_of(config); }
+
+struct SRLAEncoder *SRLAEncoder_Create(const struct SRLAEncoderConfig *config, void *work, int32_t work_size)
+{
+    /* srla_encoder.c:549-694 */
+    uint8_t own = 0;
+    if (work == NULL && work_size == 0) {
+        if ((work_size = work_size_of(config)) < 0) return NULL;
+        work = malloc((size_t)work_size);
+        own = 1;
+    }
+    if (config == NULL || work == NULL || work_size < work_size_of(config) || work_size_of(config) < 0) {
+        if (own) free(work);
+        return NULL;
+    }
+    SRLAEncoder *e = reinterpret_cast<SRLAEncoder *>(((uintptr_t)work + 15u) & ~(uintptr_t)15u);
+    e->magic = SRLA_HANDLE_MAGIC;
+    e->alloced_by_own = own;
+    e->work = work;
+    e->impl = new Impl();
+    e->impl->cfg = *config;
+    e->impl->device = g_device_index;
+    return e;
+}
+
+void SRLAEncoder_Destroy(struct SRLAEncoder *encoder)
+{
+    if (encoder == NULL || encoder->magic != SRLA_HANDLE_MAGIC) return;
+    delete encoder->impl;
+    encoder->impl = nullptr;
+    encoder->magic = 0;
+    if (encoder->alloced_by_own) free(encoder->work);
+}
+
+SRLAApiResult SRLAEncoder_SetEncodeParameter(struct SRLAEncoder *encoder, const struct SRLAEncodeParameter *p)
+{
+    /* srla_encoder.c:710-763 */
+    Impl *im = impl_of(encoder);
+    if (im == nullptr || p == NULL) return SRLA_APIRESULT_INVALID_ARGUMENT;
+    if (p->num_channels == 0 || p->bits_per_sample == 0 || p->sampling_rate == 0
+        || p->preset >= SRLA_NUM_PARAMETER_PRESETS) return SRLA_APIRESULT_INVALID_FORMAT;
+    if (p->min_num_samples_per_block == 0) return SRLA_APIRESULT_INVALID_FORMAT; /* the reference divides by it */
+    if (p->min_num_samples_per_block > p->max_num_samples_per_block
+        || p->num_lookahead_samples < p->max_num_samples_per_block
+        || (p->num_lookahead_samples % p->min_num_samples_per_block) != 0
+        || (p->ltp_order > 0 && (p->ltp_order % 2) == 0) || p->ltp_order > SRLA_MAX_LTP_ORDER)
+        return SRLA_APIRESULT_INVALID_FORMAT;
+    if (im->cfg.max_num_samples_per_block < p->max_num_samples_per_block
+        || im->cfg.min_num_samples_per_block > p->min_num_samples_per_block
+        || im->cfg.max_num_lookahead_samples < p->num_lookahead_samples
+        || im->cfg.max_num_channels < p->num_channels) return SRLA_APIRESULT_INSUFFICIENT_BUFFER;
+    /* limits of this implementation (documented in DESIGN.md) */
+    if (p->num_channels > SRLA_MAX_CH) return SRLA_APIRESULT_INSUFFICIENT_BUFFER;
+    if (p->max_num_samples_per_block > SRLA_MAX_FFT) {
+        fprintf(stderr, "[srla-mi355x] max block size %u exceeds the LDS-resident FFT limit of %u samples\n",
+                p->max_num_samples_per_block, SRLA_MAX_FFT);
+        return SRLA_APIRESULT_INSUFFICIENT_BUFFER;
+    }
+    if (p->num_lookahead_samples / p->min_num_samples_per_block + 1 > SRLA_MAX_NODES) {
+        fprintf(stderr, "[srla-mi355x] look-ahead / min block = %u exceeds %u search nodes\n",
+                p->num_lookahead_samples / p->min_num_samples_per_block, SRLA_MAX_NODES - 1);
+        return SRLA_APIRESULT_INSUFFICIENT_BUFFER;
+    }
+    if (p->bits_per_sample != 8 && p->bits_per_sample != 16 && p->bits_per_sample != 24) return SRLA_APIRESULT_INVALID_FORMAT;
+    if (p->num_svr_filter_learning_iteration != 0) {
+        fprintf(stderr, "[srla-mi355x] SVR coefficient refinement (--svr-filter-learning-iteration) is outside the "
+                        "accelerated path and is not implemented\n");
+        return SRLA_APIRESULT_NG;
+    }
+    im->par = *p;
+    im->param_generation++;
+    im->offset_lshift = 0;
+    im->set_parameter = true;
+    return SRLA_APIRESULT_OK;
+}
+
+static SRLAApiResult single_window(Impl *im, const int32_t *const *input, uint32_t num_samples, bool search,
+                                   uint8_t *data, uint32_t data_size, uint32_t *output_size, bool size_only)
+{
+    if (!im->init_device()) return SRLA_APIRESULT_NG;
+    if (!size_only)
+        return im->encode_stream(input, nullptr, 0, num_samples, data, data_size, output_size, nullptr, false, search);
+    /* ComputeBlockSize: run the job, read the block record, skip the pack */
+    if ((num_samples & 1u) || (im->par.ltp_order > 0 && num_samples <= 256u)) {
+        /* a history-dependent block (chain mode): its size is that of the block EncodeBlock would write */
+        std::vector<uint8_t> tmp((size_t)num_samples * im->par.num_channels * (im->par.bits_per_sample / 8) + 64);
+        return im->encode_stream(input, nullptr, 0, num_samples, tmp.data(), (uint32_t)tmp.size(), output_size, nullptr, false, search);
+    }
+    Slot &s = im->slot[0];
+    im->build_job(s.job, 0, num_samples, false);
+    s.out_direct = nullptr; s.out_first = 1; s.out_init_pos = 0; s.out_limit = 0xFFFFFFFFu; s.timed = im->timing; s.out_boost = 1;
+    if (!im->launch_job(s, nullptr, 0, input, false) || !im->wait_job(s)) return SRLA_APIRESULT_NG;
+    const SrlaJobInfo *info = s.h_info.as<SrlaJobInfo>();
+    if (info->error != 0 || info->num_blocks != 1) return SRLA_APIRESULT_NG;
+    *output_size = info->total_bytes;
+    return SRLA_APIRESULT_OK;
+}
+
+SRLAApiResult SRLAEncoder_ComputeBlockSize(struct SRLAEncoder *encoder, const int32_t *const *input,
+                                           uint32_t num_samples, uint32_t *output_size)
+{
+    /* srla_encoder.c:1477-1546 */
+    Impl *im = impl_of(encoder);
+    if (im == nullptr || input == NULL || num_samples == 0 || output_size == NULL) return SRLA_APIRESULT_INVALID_ARGUMENT;
+    if (!im->set_parameter) return SRLA_APIRESULT_PARAMETER_NOT_SET;
+    if (num_samples > im->par.max_num_samples_per_block) return SRLA_APIRESULT_INSUFFICIENT_BUFFER;
+    return single_window(im, input, num_samples, false, nullptr, 0, output_size, true);
+}
+
+SRLAApiResult SRLAEncoder_EncodeBlock(struct SRLAEncoder *encoder, const int32_t *const *input, uint32_t num_samples,
+                                      uint8_t *data, uint32_t data_size, uint32_t *output_size)
+{
+    /* srla_encoder.c:1549-1643 */
+    Impl *im = impl_of(encoder);
+    if (im == nullptr || input == NULL || num_samples == 0 || data == NULL || data_size == 0 || output_size == NULL)
+        return SRLA_APIRESULT_INVALID_ARGUMENT;
+    if (!im->set_parameter) return SRLA_APIRESULT_PARAMETER_NOT_SET;
+    if (num_samples > im->par.max_num_samples_per_block) return SRLA_APIRESULT_INSUFFICIENT_BUFFER;
+    return single_window(im, input, num_samples, false, data, data_size, output_size, false);
+}
+
+SRLAApiResult SRLAEncoder_EncodeOptimalPartitionedBlock(struct SRLAEncoder *encoder, const int32_t *const *input,
+                                                        uint32_t num_samples, uint8_t *data, uint32_t data_size,
+                                                        uint32_t *output_size)
+{
+    /* srla_encoder.c:1646-1698 */
+    Impl *im = impl_of(encoder);
+    if (im == nullptr || input == NULL || data == NULL || output_size == NULL) return SRLA_APIRESULT_INVALID_ARGUMENT;
+    if (!im->set_parameter) return SRLA_APIRESULT_PARAMETER_NOT_SET;
+    if (num_samples == 0 || num_samples > im->par.num_lookahead_samples) return SRLA_APIRESULT_NG;
+    return single_window(im, input, num_samples, true, data, data_size, output_size, false);
+}
+
+SRLAApiResult SRLAEncoder_EncodeWhole(struct SRLAEncoder *encoder, const int32_t *const *input, uint32_t num_samples,
+                                      uint8_t *data, uint32_t data_size, uint32_t *output_size,
+                                      SRLAEncoder_EncodeBlockCallback encode_callback)
+{
+    /* srla_encoder.c:1701-1788 */
+    Impl *im = impl_of(encoder);
+    if (im == nullptr || input == NULL || data == NULL || output_size == NULL) return SRLA_APIRESULT_INVALID_ARGUMENT;
+    if (!im->set_parameter) return SRLA_APIRESULT_PARAMETER_NOT_SET;
+    if (data_size < SRLA_HEADER_SIZE) return SRLA_APIRESULT_INSUFFICIENT_BUFFER;
+    if (num_samples == 0) return SRLA_APIRESULT_INVALID_FORMAT;
+    if (!im->init_device()) return SRLA_APIRESULT_NG;
+    return im->encode_stream(input, nullptr, 0, num_samples, data, data_size, output_size, encode_callback, true,
+                             im->search_enabled());
+}
+
+SRLAApiResult SRLAMI355X_EncodeWholeDevice(struct SRLAEncoder *encoder, const int32_t *d_input, uint32_t channel_stride,
+                                           uint32_t num_samples, uint8_t *data, uint32_t data_size, uint32_t *output_size,
+                                           SRLAEncoder_EncodeBlockCallback encode_callback)
+{
+    Impl *im = impl_of(encoder);
+    if (im == nullptr || d_input == NULL || data == NULL || output_size == NULL || channel_stride < num_samples)
+        return SRLA_APIRESULT_INVALID_ARGUMENT;
+    if (!im->set_parameter) return SRLA_APIRESULT_PARAMETER_NOT_SET;
+    if (data_size < SRLA_HEADER_SIZE) return SRLA_APIRESULT_INSUFFICIENT_BUFFER;
+    if (num_samples == 0) return SRLA_APIRESULT_INVALID_FORMAT;
+    if (!im->init_device()) return SRLA_APIRESULT_NG;
+    return im->encode_stream(nullptr, d_input, channel_stride, num_samples, data, data_size, output_size,
+                             encode_callback, true, im->search_enabled());
+}
+
+void SRLAMI355X_SetPackThreads(struct SRLAEncoder *encoder, uint32_t num_threads)
+{
+    Impl *im = impl_of(encoder);
+    if (!im) return;
+    im->pack_threads = num_threads;
+    if (im->pool) { delete im->pool; im->pool = new Pool(num_threads ? num_threads : 1); }
+}
+
+void SRLAMI355X_GetStats(struct SRLAEncoder *encoder, struct SRLAMI355XStats *stats, int reset)
+{
+    Impl *im = impl_of(encoder);
+    if (!im) return;
+    if (stats) *stats = im->stats;
+    if (reset) memset(&im->stats, 0, sizeof(im->stats));
+}
+
+SRLAApiResult SRLAMI355X_ProbeBlock(struct SRLAEncoder *encoder, const int32_t *const *input, uint32_t num_samples,
+                                    void *records, int32_t *residuals, double *debug)
+{
+    Impl *im = impl_of(encoder);
+    if (im == nullptr || input == NULL || num_samples == 0) return SRLA_APIRESULT_INVALID_ARGUMENT;
+    if (!im->set_parameter) return SRLA_APIRESULT_PARAMETER_NOT_SET;
+    if (num_samples > im->par.max_num_samples_per_block) return SRLA_APIRESULT_INSUFFICIENT_BUFFER;
+    if (num_samples <= im->preset_order()) return SRLA_APIRESULT_INVALID_ARGUMENT; /* RAW by length: nothing to analyse */
+    if (!im->init_device()) return SRLA_APIRESULT_NG;
+    Slot &s = im->slot[0];
+    im->build_job(s.job, 0, num_samples, false);
+    s.out_direct = nullptr; s.out_first = 1; s.out_init_pos = 0; s.out_limit = 0xFFFFFFFFu; s.timed = im->timing; s.out_boost = 1;
+    if (!im->launch_job(s, nullptr, 0, input, true) || !im->wait_job(s)) return SRLA_APIRESULT_NG;
+    const uint32_t nv = im->num_variants();
+    if (records && hipMemcpy(records, s.d_results.p, (size_t)nv * sizeof(SrlaItemResult), hipMemcpyDeviceToHost) != hipSuccess)
+        return SRLA_APIRESULT_NG;
+    if (debug && hipMemcpy(debug, s.d_dbg.p, (size_t)nv * SRLA_DBG_STRIDE * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+        return SRLA_APIRESULT_NG;
+    if (residuals) {
+        for (uint32_t v = 0; v < nv; v++)
+            if (hipMemcpy(residuals + (size_t)v * num_samples, s.d_res_ws.as<int32_t>() + s.job.items[v].res_off,
+                          (size_t)num_samples * 4, hipMemcpyDeviceToHost) != hipSuccess) return SRLA_APIRESULT_NG;
+    }
+    return SRLA_APIRESULT_OK;
+}
+
+}  /* extern "C" */

@@ -1,0 +1,272 @@
+/*
+ * host_chain.cpp -- chain mode: the history-dependent last window of a stream (see host_impl.h, struct ChainCall).
+ */
+#include "host_impl.h"
+
+#include <algorithm>
+#include <stdlib.h>
+#include <string.h>
+
+void Impl::chain_append(uint32_t jobidx, const Job &job, const std::function<bool(uint32_t, uint32_t)> &silent)
+{
+    const uint32_t nch = par.num_channels, nv = num_variants();
+    std::vector<uint32_t> pass1_round(job.items.size(), 0);
+    for (const SrlaCandDesc &cd : job.cands) {
+        if (cd.item_base == 0xFFFFFFFFu || silent(cd.sample_off, cd.n)) continue;   /* RAW by length / SILENT: no analysis (srla_encoder.c:766-796) */
+        for (uint32_t k = 0; k < nv; k++) {
+            const uint32_t v = (nch >= 2) ? ((k < 2) ? nch + k : k - 2) : k;        /* M, S, then the channels (srla_encoder.c:1229-1275) */
+            const uint32_t item = cd.item_base + v;
+            for (int pass = (par.ltp_order > 0) ? 1 : 0; pass >= 0; pass--) {
+                ChainCall c{};
+                c.job = jobidx; c.item = item; c.pass = (uint32_t)pass; c.n = cd.n; c.nfft = geoms[job.items[item].geom].nfft;
+                c.src = -1; c.dump = (uint32_t)chain_pool_used; chain_pool_used += c.nfft;
+                uint32_t round = (pass == 0 && par.ltp_order > 0) ? pass1_round[item] : 0;
+                if (c.n & 1u) {
+                    const uint32_t mid = c.n >> 1;
+                    for (int64_t j = (int64_t)chain_calls.size() - 1; j >= 0; j--)
+                        if (chain_calls[(size_t)j].nfft > mid) { c.src = (int32_t)j; break; }
+                    if (c.src >= 0 && chain_calls[(size_t)c.src].job == jobidx) {
+                        /* inside a round the LTP-lag launches come first, then the pitch solve, then the LPC-lag launches */
+                        const ChainCall &sc = chain_calls[(size_t)c.src];
+                        const uint32_t need = (pass == 0 && sc.pass == 1) ? sc.round : sc.round + 1;
+                        round = std::max(round, need);
+                    }
+                }
+                if (pass == 1 && c.nfft < SRLA_LTP_LAGS) {
+                    /* lpc.c:371-373 copies 263 lags out of a shorter FFT buffer: the words from nfft on are those
+                     * of the latest earlier calls that reached them (zero when none did) */
+                    c.lags = (uint32_t)chain_tab.size() + 1u;
+                    const size_t base = chain_tab.size();
+                    chain_tab.resize(base + (SRLA_LTP_LAGS - c.nfft), 0u);
+                    uint32_t lo = c.nfft;
+                    for (int64_t j = (int64_t)chain_calls.size() - 1; j >= 0 && lo < SRLA_LTP_LAGS; j--) {
+                        const ChainCall &sc = chain_calls[(size_t)j];
+                        if (sc.nfft <= lo) continue;
+                        const uint32_t hi = std::min<uint32_t>(sc.nfft, SRLA_LTP_LAGS);
+                        for (uint32_t i = lo; i < hi; i++) chain_tab[base + (i - c.nfft)] = sc.dump + i + 1u;
+                        lo = hi;
+                        if (sc.job == jobidx) round = std::max(round, sc.round + 1);
+                    }
+                }
+                c.round = round;
+                if (pass == 1) pass1_round[item] = round;
+                chain_calls.push_back(c);
+            }
+        }
+    }
+}
+
+void Impl::chain_build(uint32_t jobidx, const Job &job, ChainJob &cj)
+{
+    struct Entry { uint32_t round, pass, cls; SrlaAutocorrItem ai; };
+    std::vector<Entry> entries;
+    const bool ltp = par.ltp_order > 0;
+    std::vector<uint8_t> seen(job.items.size(), 0);
+    auto make = [&](uint32_t item) {
+        const SrlaItemDesc &it = job.items[item];
+        const SrlaGeom &gm = geoms[it.geom];
+        SrlaAutocorrItem ai{};
+        ai.item = item; ai.sample_off = it.sample_off; ai.n = it.n; ai.variant = it.variant;
+        ai.nfft = gm.nfft; ai.tw_off = gm.tw_off; ai.welch_divisor = gm.welch_divisor; ai.acorr_norm = gm.acorr_norm;
+        return ai;
+    };
+    auto cls_of = [](uint32_t nfft) { return (nfft <= 1024u) ? 0u : ((nfft <= 2048u) ? 1u : ((nfft <= 4096u) ? 2u : 3u)); };
+    cj.select.assign(std::max<size_t>(1, job.items.size()), 0xFFFFFFFFu);
+    cj.rounds = 1;
+    for (const ChainCall &c : chain_calls) {
+        if (c.job != jobidx) continue;
+        SrlaAutocorrItem ai = make(c.item);
+        ai.chain_dump = c.dump + 1u;
+        ai.chain_lags = c.lags;
+        if (c.src >= 0) ai.chain_src = chain_calls[(size_t)c.src].dump + (c.n >> 1) + 1u;
+        entries.push_back({ c.round, c.pass, cls_of(ai.nfft), ai });
+        if (c.pass == 1 || !ltp) cj.select[c.item] = c.round;
+        seen[c.item] = 1;
+        cj.rounds = std::max(cj.rounds, c.round + 1);
+    }
+    /* items of silent blocks: no call of the reference, but their records are still initialised by the kernel */
+    for (uint32_t i = 0; i < job.items.size(); i++)
+        if (!seen[i]) {
+            const SrlaAutocorrItem ai = make(i);
+            for (int pass = ltp ? 1 : 0; pass >= 0; pass--) entries.push_back({ 0u, (uint32_t)pass, cls_of(ai.nfft), ai });
+            cj.select[i] = 0;
+        }
+    /* one launch per round and pass, instantiated for the longest FFT among its items (shorter ones leave part of
+     * the workgroup idle): the launches are few and dependent, their number is what costs */
+    std::stable_sort(entries.begin(), entries.end(), [](const Entry &a, const Entry &b) {
+        if (a.round != b.round) return a.round < b.round;
+        return a.pass > b.pass;
+    });
+    cj.list.clear(); cj.launches.clear();
+    for (const Entry &e : entries) {
+        if (cj.launches.empty() || cj.launches.back().round != e.round || cj.launches.back().pass != e.pass)
+            cj.launches.push_back({ e.round, e.pass, e.cls, (uint32_t)cj.list.size(), 0u });
+        cj.launches.back().count++;
+        cj.launches.back().cls = std::max(cj.launches.back().cls, e.cls);
+        cj.list.push_back(e.ai);
+    }
+}
+
+bool Impl::chain_stage_a(Slot &s, uint32_t jobidx, const ChainJob &cj)
+{
+    /* many small dependent launches: on a stream of their own, so that the regular jobs' wide kernels do not queue
+     * behind them */
+    hipStream_t W = s.own_stream;
+    const SrlaJobParams &jp = s.jp;
+    if (!d_chain_list[jobidx].ensure(std::max<size_t>(1, cj.list.size()) * sizeof(SrlaAutocorrItem))) return false;
+    if (!d_chain_select[jobidx].ensure(cj.select.size() * 4)) return false;
+    if (!cj.list.empty()) HIP_OK(hipMemcpy(d_chain_list[jobidx].p, cj.list.data(), cj.list.size() * sizeof(SrlaAutocorrItem), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(d_chain_select[jobidx].p, cj.select.data(), cj.select.size() * 4, hipMemcpyHostToDevice));
+    if (chain_tab.size() > chain_tab_uploaded) {
+        /* only the new entries: kernels of the jobs before may still be reading theirs */
+        if (chain_tab.size() * 4 > d_chain_tab.cap) return false;
+        HIP_OK(hipMemcpy(d_chain_tab.as<uint32_t>() + chain_tab_uploaded, chain_tab.data() + chain_tab_uploaded,
+                         (chain_tab.size() - chain_tab_uploaded) * 4, hipMemcpyHostToDevice));
+        chain_tab_uploaded = chain_tab.size();
+    }
+    /* prepare_job put the descriptor uploads on the wide stream: everything after this stage must see them */
+    HIP_OK(hipEventRecord(s.t0[ST_A], streams[0]));
+    HIP_OK(hipStreamWaitEvent(W, s.t0[ST_A], 0));
+    if (lshift_on_device) HIP_OK(hipStreamWaitEvent(W, ev_or, 0));
+    if (s.used_h2d) HIP_OK(hipStreamWaitEvent(W, s.ev_in, 0));
+    static const int kClass[4] = { 0, 1, 2, 4 };
+    int rc = 0;
+    size_t li = 0;
+    for (uint32_t r = 0; r < cj.rounds; r++)
+        for (int pass = (par.ltp_order > 0) ? 1 : 0; pass >= 0; pass--) {
+            bool any = false;
+            for (; li < cj.launches.size() && cj.launches[li].round == r && cj.launches[li].pass == (uint32_t)pass; li++) {
+                const ChainLaunch &l = cj.launches[li];
+                rc |= srla_launch_autocorr(W, kClass[l.cls], &jp, s.in_cur, s.d_items.as<SrlaItemDesc>(), d_geoms.as<SrlaGeom>(), d_tw.p,
+                                           (uint32_t)pass, s.d_results.as<SrlaItemResult>(), s.d_lags.as<double>(), nullptr,
+                                           d_chain_list[jobidx].as<SrlaAutocorrItem>() + l.first, l.count, nullptr, nullptr,
+                                           d_chain_pool.as<double>(), d_chain_tab.as<uint32_t>());
+                any = true;
+            }
+            if (pass == 1 && any)
+                rc |= srla_launch_pitch_solve(W, &jp, s.d_lags.as<double>(), s.d_results.as<SrlaItemResult>(), nullptr, nullptr,
+                                              d_chain_select[jobidx].as<uint32_t>(), r);
+        }
+    HIP_OK(hipEventRecord(s.t1[ST_A], W));
+    if (rc != 0) { fprintf(stderr, "[srla-mi355x] kernel launch failed in a chain stage\n"); return false; }
+    return true;
+}
+
+bool Impl::chain_silent(const std::vector<int32_t> &v, uint32_t total, uint32_t off, uint32_t n) const
+{
+    for (uint32_t ch = 0; ch < par.num_channels; ch++) {
+        const int32_t *p = v.data() + (size_t)ch * total + off;
+        for (uint32_t i = 0; i < n; i++) if (p[i] != 0) return false;
+    }
+    return true;
+}
+
+void Impl::chain_slot_defaults(Slot &s)
+{
+    s.own_stream = streams[1];   /* the narrow stream: a stream of their own ended up sharing a hardware queue with the wide one and waited for the whole stream (measured) */
+    s.out_direct = nullptr; s.out_first = 1; s.out_init_pos = 0; s.out_limit = 0xFFFFFFFFu; s.timed = false; s.out_boost = 1;
+}
+
+bool Impl::chain_begin(uint32_t seed_off, uint32_t seed_n)
+{
+    ChainRun &c = chain;
+    const uint32_t nch = par.num_channels, nv = num_variants(), passes = par.ltp_order > 0 ? 2u : 1u;
+    /* which blocks are all zero decides which calls exist: look at the samples */
+    auto fetch = [&](uint32_t off, uint32_t n, std::vector<int32_t> &dst) -> bool {
+        dst.resize((size_t)nch * n);
+        for (uint32_t ch = 0; ch < nch; ch++) {
+            if (c.host_in) memcpy(dst.data() + (size_t)ch * n, c.host_in[ch] + off, (size_t)n * 4);
+            else if (hipMemcpy(dst.data() + (size_t)ch * n, c.d_in + (size_t)ch * c.d_stride + off, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) return false;
+        }
+        return true;
+    };
+    c.seed_n = seed_n;
+    if (!fetch(c.tail_start, c.tail_n, c.tail_smp) || (seed_n && !fetch(seed_off, seed_n, c.seed_smp))) return false;
+    const std::function<bool(uint32_t, uint32_t)> silent_tail = [&](uint32_t off, uint32_t n) { return chain_silent(c.tail_smp, c.tail_n, off, n); };
+    const std::function<bool(uint32_t, uint32_t)> silent_seed = [&](uint32_t off, uint32_t n) { return chain_silent(c.seed_smp, c.seed_n, off, n); };
+    chain_calls.clear();
+    chain_pool_used = 0;
+    chain_tab.clear();
+    chain_tab_uploaded = 0;
+    Slot &q = slot[kChainSlot], &sj = slot[kChainSlot + 1], &e = slot[kChainSlot + 2];
+    if (seed_n) {
+        const std::vector<uint32_t> lens{ seed_n };
+        build_job(q.job, seed_off, seed_n, false, &lens);
+        chain_append(0, q.job, silent_seed);
+    }
+    if (c.search) {
+        build_job(sj.job, c.tail_start, c.tail_n, true);
+        chain_append(1, sj.job, silent_tail);
+    } else {
+        const std::vector<uint32_t> lens{ c.tail_n };
+        build_job(e.job, c.tail_start, c.tail_n, false, &lens);
+        chain_append(2, e.job, silent_tail);
+    }
+    {
+        /* the encode job's calls are not known yet when searching: its blocks tile the window, an FFT is shorter
+         * than twice its block (or the smallest FFT size) */
+        const uint32_t max_parts = c.search ? (c.tail_n + par.min_num_samples_per_block - 1) / par.min_num_samples_per_block : 0u;
+        const uint64_t bound = chain_pool_used + (uint64_t)nv * passes * (2ull * c.tail_n + 64ull * max_parts);
+        if (!d_chain_pool.ensure(bound * sizeof(double))) return false;
+        const size_t tab_bound = chain_tab.size() + (size_t)std::max(1u, max_parts) * nv * SRLA_LTP_LAGS;
+        if (!d_chain_tab.ensure(tab_bound * 4)) return false;
+    }
+    if (seed_n) {
+        chain_build(0, q.job, c.cq);
+        chain_slot_defaults(q);
+        if (!prepare_job(q, c.d_in ? c.d_in + seed_off : nullptr, c.d_stride, c.host_in, false) || !chain_stage_a(q, 0, c.cq)) return false;
+    }
+    if (c.search) {
+        chain_build(1, sj.job, c.cs);
+        chain_slot_defaults(sj);
+        if (!prepare_job(sj, c.d_in ? c.d_in + c.tail_start : nullptr, c.d_stride, c.host_in, false) || !chain_stage_a(sj, 1, c.cs)) return false;
+        for (int st = ST_B; st <= ST_D; st++) if (!run_stage(sj, st)) return false;
+    }
+    c.begun = true;
+    return true;
+}
+
+bool Impl::chain_encode_ad(uint8_t *out_direct, uint32_t init_pos, uint32_t data_size, bool first_job)
+{
+    ChainRun &c = chain;
+    Slot &q = slot[kChainSlot], &sj = slot[kChainSlot + 1], &e = slot[kChainSlot + 2];
+    if (c.search) {
+        const auto tw = Clock::now();
+        if (hipEventSynchronize(sj.t1[ST_D]) != hipSuccess) return false;
+        static const bool trace = getenv("SRLA_MI355X_CHAIN_TRACE") != nullptr;
+        if (trace) fprintf(stderr, "[chain] waited %.3f ms for the search job (%u rounds)\n", ms_since(tw), c.cs.rounds);
+        const SrlaWindowDesc &wd = sj.job.windows[0];
+        std::vector<SrlaBlockRecord> recs(wd.num_nodes - 1);
+        if (hipMemcpy(recs.data(), sj.d_blocks.as<SrlaBlockRecord>() + wd.block_base, recs.size() * sizeof(SrlaBlockRecord), hipMemcpyDeviceToHost) != hipSuccess)
+            return false;
+        std::vector<uint32_t> lens;
+        uint32_t covered = 0;
+        for (const SrlaBlockRecord &r : recs) if (r.valid) { lens.push_back(r.n); covered += r.n; }
+        if (covered != c.tail_n) { fprintf(stderr, "[srla-mi355x] internal error: the tail window's partitions cover %u of %u samples\n", covered, c.tail_n); return false; }
+        sj.busy = false;
+        const std::function<bool(uint32_t, uint32_t)> silent_tail = [&](uint32_t off, uint32_t n) { return chain_silent(c.tail_smp, c.tail_n, off, n); };
+        build_job(e.job, c.tail_start, c.tail_n, false, &lens);
+        chain_append(2, e.job, silent_tail);
+        if (chain_pool_used * sizeof(double) > d_chain_pool.cap) return false;
+    }
+    q.busy = false;
+    chain_build(2, e.job, c.ce);
+    chain_slot_defaults(e);
+    e.out_direct = out_direct; e.out_first = first_job ? 1u : 0u; e.out_init_pos = init_pos; e.out_limit = data_size; e.out_boost = tail_boost;
+    if (!prepare_job(e, c.d_in ? c.d_in + c.tail_start : nullptr, c.d_stride, c.host_in, false) || !chain_stage_a(e, 2, c.ce)) return false;
+    for (int st = ST_B; st <= ST_D; st++) if (!run_stage(e, st)) return false;
+    c.ad_done = true;
+    return true;
+}
+
+bool Impl::chain_encode_e() { return run_stage(slot[kChainSlot + 2], ST_E); }
+
+bool Impl::chain_search_done()
+{
+    if (!chain.begun) return false;
+    if (!chain.search) return true;
+    const hipError_t e = hipEventQuery(slot[kChainSlot + 1].t1[ST_D]);
+    if (e != hipSuccess) (void)hipGetLastError();
+    return e == hipSuccess;
+}
+

@@ -1,0 +1,49 @@
+"""bench.py's own N-rank launch (`python bench.py --gpus N` without torchrun): rendezvous, barrier, max-reduce and the
+one JSON line of rank 0 -- exercised on the CPU with --dry-run (no GPU work); the real N = 2 flow on one shared GPU is
+a -m gpu test."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+import helpers
+
+BENCH = os.path.join(helpers.ROOT, "bench.py")
+
+
+def _run(args, env_extra=None, timeout=300):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, BENCH] + args, capture_output=True, text=True, timeout=timeout, env=env, cwd=helpers.ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout          # rank 0 prints ONE line, the other ranks nothing
+    return json.loads(lines[0])
+
+
+def test_gpus_2_spawns_two_ranks_without_a_launcher():
+    line = _run(["--gpus", "2", "--dry-run"])
+    assert line["n_gpus"] == 2 and line["dry_run"] is True
+    assert line["ms_per_step"] >= 20.0        # the max over ranks: rank 1 "worked" 20 ms, rank 0 only 10
+
+
+def test_gpus_1_is_the_default():
+    line = _run(["--dry-run"])
+    assert line["n_gpus"] == 1
+
+
+def test_gpus_must_match_the_launcher():
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-run"], capture_output=True, text=True, env=env, cwd=helpers.ROOT)
+    assert p.returncode != 0 and "launcher" in (p.stderr + p.stdout)
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_shared_gpu():
+    """the real flow, two ranks on the one GPU of the test box (SRLA_BENCH_SHARED_GPU: barrier / reduce over gloo)"""
+    line = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--seconds", "60", "--no-cpu-baseline"],
+                env_extra={"SRLA_BENCH_SHARED_GPU": "1"}, timeout=600)
+    assert line["n_gpus"] == 2 and line["lossless_roundtrip"] is True and line["value"] > 0
+    assert "EncodeWhole" in line["config"]["workload"]
