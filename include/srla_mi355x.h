@@ -146,6 +146,18 @@ SRLAApiResult SRLAMI355X_EncodeWholeDevice(
     struct SRLAEncoder *encoder, const int32_t *d_input, uint32_t channel_stride, uint32_t num_samples,
     uint8_t *data, uint32_t data_size, uint32_t *output_size, SRLAEncoder_EncodeBlockCallback encode_callback);
 
+/* Many streams in one call -- the way to encode a corpus of short files: windows of different streams share the device
+ * jobs, so a 10 s file costs what 10 s of a long stream cost instead of a whole pipeline fill and drain of its own.
+ * Every stream is what SRLAEncoder_EncodeWhole would write for it (tools/srla_codec/srla_codec.c:134 called once per
+ * file), byte for byte, into its own buffer data[i] of data_size[i] bytes; output_size[i] receives its size.
+ * inputs[i]: the stream's planar int32 channel pointers (host memory), num_samples[i] its length; all streams share the
+ * handle's parameters (channels, bits per sample, sampling rate, preset, block sizes).
+ * A stream whose buffer is too small gets results[i] = SRLA_APIRESULT_INSUFFICIENT_BUFFER (output_size[i] = 0) without
+ * disturbing the others, and the call returns that code; results may be NULL. */
+SRLAApiResult SRLAMI355X_EncodeBatch(
+    struct SRLAEncoder *encoder, uint32_t num_streams, const int32_t *const *const *inputs, const uint32_t *num_samples,
+    uint8_t *const *data, const uint32_t *data_size, uint32_t *output_size, SRLAApiResult *results);
+
 struct SRLAMI355XStats {
     uint64_t num_windows;
     uint64_t num_candidates;

@@ -55,7 +55,9 @@ typedef struct SrlaItemDesc {
     uint32_t geom;         /* index into the SrlaGeom table                      */
     uint64_t res_off;      /* element offset of this item's residual in scratch  */
     int32_t  forced_order; /* -1, or the order the host arbitrated (tie path)    */
-    uint32_t pad;
+    uint32_t lshift;       /* offset left shift of the item's stream (header.offset_lshift, srla_utility.c:177) */
+    uint32_t forced_ltp;   /* 0, or the LTP taps the host arbitrated: bit 31 | three 6-bit fields (stream order)  */
+    uint32_t seg;          /* segment (stream part) of the job the item belongs to */
 } SrlaItemDesc;
 
 /* What srla_autocorr needs to know about an item, in one record (item descriptor + the constants of its block
@@ -72,7 +74,7 @@ typedef struct SrlaAutocorrItem {
     uint32_t chain_dump;    /* chain mode: 1 + pool offset where the call leaves its whole FFT buffer, 0: not kept  */
     uint32_t chain_lags;    /* chain mode, LTP lags of an FFT shorter than the 263 lags: 1 + index into the gather table
                              * (one entry per lag from nfft on: 1 + pool offset of the word the reference reads, lpc.c:371-373) */
-    uint32_t pad0;
+    uint32_t lshift;        /* offset left shift of the item's stream */
     double   welch_divisor;
     double   acorr_norm;
 } SrlaAutocorrItem;        /* 56 bytes */
@@ -101,11 +103,18 @@ typedef struct SrlaItemResult {
 /* Job summary the device writes into pinned host memory (srla_block_offsets / srla_pack_blocks). */
 typedef struct SrlaJobInfo {
     uint32_t total_bytes;    /* bytes of all blocks of the job                          */
-    uint32_t base;           /* stream offset of the job's first block                  */
+    uint32_t base;           /* stream offset of the first block of the job's first segment */
     uint32_t num_blocks, num_raw, num_silent;
-    uint32_t num_tie_items, num_odd_items;   /* flagged items among the chosen blocks   */
-    uint32_t error;          /* SRLA_JOBERR_* bits                                      */
+    uint32_t num_tie_items, num_odd_items;   /* flagged items of the job (any candidate) / odd-length items among the chosen blocks */
+    uint32_t error;          /* SRLA_JOBERR_* bits (OVERFLOW: in at least one segment) */
 } SrlaJobInfo;
+/* per segment, behind SrlaJobInfo and the per-window byte counts */
+typedef struct SrlaSegInfo {
+    uint32_t bytes;          /* bytes of the segment's blocks                                           */
+    uint32_t pos;            /* offset of its first block in the stream's output buffer                  */
+    uint32_t stage_off;      /* where the segment starts in the job's staging buffer                     */
+    uint32_t skip;           /* 1: nothing written (the stream would not fit its buffer, or an earlier job of it did not) */
+} SrlaSegInfo;
 #define SRLA_JOBERR_OVERFLOW 1u  /* the stream would not fit the caller's buffer: nothing written from here on */
 #define SRLA_JOBERR_SIZE     2u  /* a packed block differs from its computed size (internal error)           */
 #define SRLA_JOBERR_COVER    4u  /* a window's chosen blocks do not tile it (internal error)                 */
@@ -126,8 +135,20 @@ typedef struct SrlaWindowDesc {
     uint32_t num_cands;
     uint32_t num_nodes;
     uint32_t block_base;    /* first slot of this window in the block table (num_nodes - 1 slots) */
-    uint32_t pad0, pad1;
+    uint32_t seg;           /* segment (stream part) of the job the window belongs to */
+    uint32_t pad1;
 } SrlaWindowDesc;
+
+/* A job holds windows of one or more streams: a segment is the run of consecutive windows that belong to one stream.
+ * The blocks of a segment go, back to back, to the stream's output buffer. */
+typedef struct SrlaSegDesc {
+    uint32_t first_window, num_windows;
+    uint32_t stream;        /* index into the device-resident stream positions (running offset + sticky skip flag) */
+    uint32_t use_init;      /* 1: the segment starts at init_pos (first job of the stream in this pass), 0: at the running offset */
+    uint32_t init_pos;
+    uint32_t limit;         /* size of the stream's output buffer */
+    uint64_t dst;           /* device-visible address of the stream's output buffer, 0: the job's pinned staging buffer */
+} SrlaSegDesc;              /* 32 bytes */
 
 /* One chosen block (srla_price_windows output, stream order inside a window). */
 typedef struct SrlaBlockRecord {
@@ -138,13 +159,14 @@ typedef struct SrlaBlockRecord {
     uint32_t ch_method;
     uint32_t bytes;         /* total block size incl. the 11-byte header */
     uint32_t item[SRLA_MAX_CH];  /* item index per output channel (compress blocks) */
-    uint32_t pad[2];
+    uint32_t seg;           /* segment of the job the block belongs to */
+    uint32_t pad;
 } SrlaBlockRecord;          /* 64 bytes */
 
 typedef struct SrlaJobParams {
     uint32_t num_channels;
     uint32_t bits_per_sample;
-    uint32_t offset_lshift;
+    uint32_t num_segs;        /* segments (stream parts) of the job */
     uint32_t max_order;       /* preset's max_num_parameters */
     uint32_t order_fixed;     /* preset 0: MAX_FIXED tactic   */
     uint32_t ltp_order;       /* 0, 1, 3 */
@@ -155,9 +177,14 @@ typedef struct SrlaJobParams {
     uint32_t num_items;
     uint32_t num_cands;
     uint32_t num_windows;
-    uint32_t out_stride;      /* unused */
-    const uint32_t *lshift_dev; /* when non-null the offset left shift is read from here (device memory): lets
-                               * a whole stream be enqueued before its OR-reduction has finished */
+    uint32_t out_stride;      /* SRLA_DIAG_STOP builds only: where srla_residual_cost stops (kernel timing experiments) */
+    const uint32_t *lshift_dev; /* when non-null the offset left shift is read from here (device memory) instead of the
+                               * item's: lets a whole device-resident stream be enqueued before its OR-reduction has finished */
+    /* near-tie detection (H2: decisions that hang on libm): an item is flagged, and arbitrated with the host libm, when the
+     * two best code-length estimates differ by less than tie_rel (relative), or an LTP tap lies within tie_ltp of a
+     * rounding boundary.  tie_logscale / tie_powscale (1.0 in production) deliberately falsify the device's log / x^-1/2:
+     * the tests use them to make the device decide differently from the host, so that the arbitration has work to do. */
+    double tie_rel, tie_ltp, tie_logscale, tie_powscale;
 } SrlaJobParams;
 
 /* LDS carve-up of kernel A for one FFT-size group (bytes, 16-byte aligned); host decides overlays */

@@ -134,37 +134,32 @@ SRLAApiResult SRLAEncoder_SetEncodeParameter(struct SRLAEncoder *encoder, const 
     return SRLA_APIRESULT_OK;
 }
 
-static SRLAApiResult single_window(Impl *im, const int32_t *const *input, uint32_t num_samples, bool search,
-                                   uint8_t *data, uint32_t data_size, uint32_t *output_size, bool size_only)
+/* one stream of host samples through encode_streams */
+static SRLAApiResult one_stream(Impl *im, const int32_t *const *input, const int32_t *d_input, uint32_t d_stride, uint32_t num_samples,
+                                uint8_t *data, uint32_t data_size, uint32_t *output_size, SRLAEncoder_EncodeBlockCallback cb,
+                                bool with_header, bool search)
 {
     if (!im->init_device()) return SRLA_APIRESULT_NG;
-    if (!size_only)
-        return im->encode_stream(input, nullptr, 0, num_samples, data, data_size, output_size, nullptr, false, search);
-    /* ComputeBlockSize: run the job, read the block record, skip the pack */
-    if ((num_samples & 1u) || (im->par.ltp_order > 0 && num_samples <= 256u)) {
-        /* a history-dependent block (chain mode): its size is that of the block EncodeBlock would write */
-        std::vector<uint8_t> tmp((size_t)num_samples * im->par.num_channels * (im->par.bits_per_sample / 8) + 64);
-        return im->encode_stream(input, nullptr, 0, num_samples, tmp.data(), (uint32_t)tmp.size(), output_size, nullptr, false, search);
-    }
-    Slot &s = im->slot[0];
-    im->build_job(s.job, 0, num_samples, false);
-    s.out_direct = nullptr; s.out_first = 1; s.out_init_pos = 0; s.out_limit = 0xFFFFFFFFu; s.timed = im->timing; s.out_boost = 1;
-    if (!im->launch_job(s, nullptr, 0, input, false) || !im->wait_job(s)) return SRLA_APIRESULT_NG;
-    const SrlaJobInfo *info = s.h_info.as<SrlaJobInfo>();
-    if (info->error != 0 || info->num_blocks != 1) return SRLA_APIRESULT_NG;
-    *output_size = info->total_bytes;
-    return SRLA_APIRESULT_OK;
+    StreamCtx st;
+    st.host_in = input; st.d_in = d_input; st.d_stride = d_stride; st.num_samples = num_samples;
+    st.data = data; st.data_size = data_size; st.with_header = with_header; st.cb = cb;
+    im->sx.clear();
+    im->sx.push_back(st);
+    const SRLAApiResult rc = im->encode_streams(search);
+    if (rc == SRLA_APIRESULT_OK && output_size) *output_size = im->sx[0].write_off;
+    return rc;
 }
 
 SRLAApiResult SRLAEncoder_ComputeBlockSize(struct SRLAEncoder *encoder, const int32_t *const *input,
                                            uint32_t num_samples, uint32_t *output_size)
 {
-    /* srla_encoder.c:1477-1546 */
+    /* srla_encoder.c:1477-1546: the size of the block EncodeBlock would write (no output buffer: the bytes stay in the
+     * library's staging memory) */
     Impl *im = impl_of(encoder);
     if (im == nullptr || input == NULL || num_samples == 0 || output_size == NULL) return SRLA_APIRESULT_INVALID_ARGUMENT;
     if (!im->set_parameter) return SRLA_APIRESULT_PARAMETER_NOT_SET;
     if (num_samples > im->par.max_num_samples_per_block) return SRLA_APIRESULT_INSUFFICIENT_BUFFER;
-    return single_window(im, input, num_samples, false, nullptr, 0, output_size, true);
+    return one_stream(im, input, nullptr, 0, num_samples, nullptr, 0, output_size, nullptr, false, false);
 }
 
 SRLAApiResult SRLAEncoder_EncodeBlock(struct SRLAEncoder *encoder, const int32_t *const *input, uint32_t num_samples,
@@ -176,7 +171,7 @@ SRLAApiResult SRLAEncoder_EncodeBlock(struct SRLAEncoder *encoder, const int32_t
         return SRLA_APIRESULT_INVALID_ARGUMENT;
     if (!im->set_parameter) return SRLA_APIRESULT_PARAMETER_NOT_SET;
     if (num_samples > im->par.max_num_samples_per_block) return SRLA_APIRESULT_INSUFFICIENT_BUFFER;
-    return single_window(im, input, num_samples, false, data, data_size, output_size, false);
+    return one_stream(im, input, nullptr, 0, num_samples, data, data_size, output_size, nullptr, false, false);
 }
 
 SRLAApiResult SRLAEncoder_EncodeOptimalPartitionedBlock(struct SRLAEncoder *encoder, const int32_t *const *input,
@@ -188,7 +183,7 @@ SRLAApiResult SRLAEncoder_EncodeOptimalPartitionedBlock(struct SRLAEncoder *enco
     if (im == nullptr || input == NULL || data == NULL || output_size == NULL) return SRLA_APIRESULT_INVALID_ARGUMENT;
     if (!im->set_parameter) return SRLA_APIRESULT_PARAMETER_NOT_SET;
     if (num_samples == 0 || num_samples > im->par.num_lookahead_samples) return SRLA_APIRESULT_NG;
-    return single_window(im, input, num_samples, true, data, data_size, output_size, false);
+    return one_stream(im, input, nullptr, 0, num_samples, data, data_size, output_size, nullptr, false, true);
 }
 
 SRLAApiResult SRLAEncoder_EncodeWhole(struct SRLAEncoder *encoder, const int32_t *const *input, uint32_t num_samples,
@@ -201,9 +196,7 @@ SRLAApiResult SRLAEncoder_EncodeWhole(struct SRLAEncoder *encoder, const int32_t
     if (!im->set_parameter) return SRLA_APIRESULT_PARAMETER_NOT_SET;
     if (data_size < SRLA_HEADER_SIZE) return SRLA_APIRESULT_INSUFFICIENT_BUFFER;
     if (num_samples == 0) return SRLA_APIRESULT_INVALID_FORMAT;
-    if (!im->init_device()) return SRLA_APIRESULT_NG;
-    return im->encode_stream(input, nullptr, 0, num_samples, data, data_size, output_size, encode_callback, true,
-                             im->search_enabled());
+    return one_stream(im, input, nullptr, 0, num_samples, data, data_size, output_size, encode_callback, true, im->search_enabled());
 }
 
 SRLAApiResult SRLAMI355X_EncodeWholeDevice(struct SRLAEncoder *encoder, const int32_t *d_input, uint32_t channel_stride,
@@ -216,9 +209,38 @@ SRLAApiResult SRLAMI355X_EncodeWholeDevice(struct SRLAEncoder *encoder, const in
     if (!im->set_parameter) return SRLA_APIRESULT_PARAMETER_NOT_SET;
     if (data_size < SRLA_HEADER_SIZE) return SRLA_APIRESULT_INSUFFICIENT_BUFFER;
     if (num_samples == 0) return SRLA_APIRESULT_INVALID_FORMAT;
+    return one_stream(im, nullptr, d_input, channel_stride, num_samples, data, data_size, output_size, encode_callback, true,
+                      im->search_enabled());
+}
+
+SRLAApiResult SRLAMI355X_EncodeBatch(struct SRLAEncoder *encoder, uint32_t num_streams, const int32_t *const *const *inputs,
+                                     const uint32_t *num_samples, uint8_t *const *data, const uint32_t *data_size,
+                                     uint32_t *output_size, SRLAApiResult *results)
+{
+    Impl *im = impl_of(encoder);
+    if (im == nullptr || num_streams == 0 || inputs == NULL || num_samples == NULL || data == NULL || data_size == NULL || output_size == NULL)
+        return SRLA_APIRESULT_INVALID_ARGUMENT;
+    if (!im->set_parameter) return SRLA_APIRESULT_PARAMETER_NOT_SET;
+    for (uint32_t i = 0; i < num_streams; i++) {
+        if (inputs[i] == NULL || data[i] == NULL) return SRLA_APIRESULT_INVALID_ARGUMENT;
+        if (num_samples[i] == 0) return SRLA_APIRESULT_INVALID_FORMAT;
+        if (data_size[i] < SRLA_HEADER_SIZE) return SRLA_APIRESULT_INSUFFICIENT_BUFFER;
+    }
     if (!im->init_device()) return SRLA_APIRESULT_NG;
-    return im->encode_stream(nullptr, d_input, channel_stride, num_samples, data, data_size, output_size,
-                             encode_callback, true, im->search_enabled());
+    im->sx.clear();
+    im->sx.resize(num_streams);
+    for (uint32_t i = 0; i < num_streams; i++) {
+        StreamCtx &st = im->sx[i];
+        st.host_in = inputs[i]; st.num_samples = num_samples[i];
+        st.data = data[i]; st.data_size = data_size[i]; st.with_header = true;
+    }
+    const SRLAApiResult rc = im->encode_streams(im->search_enabled());
+    if (rc != SRLA_APIRESULT_OK && rc != SRLA_APIRESULT_INSUFFICIENT_BUFFER) return rc;
+    for (uint32_t i = 0; i < num_streams; i++) {
+        output_size[i] = (im->sx[i].rc == SRLA_APIRESULT_OK) ? im->sx[i].write_off : 0u;
+        if (results) results[i] = im->sx[i].rc;
+    }
+    return rc;
 }
 
 void SRLAMI355X_SetPackThreads(struct SRLAEncoder *encoder, uint32_t num_threads)
@@ -246,10 +268,19 @@ SRLAApiResult SRLAMI355X_ProbeBlock(struct SRLAEncoder *encoder, const int32_t *
     if (num_samples > im->par.max_num_samples_per_block) return SRLA_APIRESULT_INSUFFICIENT_BUFFER;
     if (num_samples <= im->preset_order()) return SRLA_APIRESULT_INVALID_ARGUMENT; /* RAW by length: nothing to analyse */
     if (!im->init_device()) return SRLA_APIRESULT_NG;
+    StreamCtx st;
+    st.host_in = input; st.num_samples = num_samples; st.with_header = false;
+    st.lshift = im->offset_lshift; st.lshift_final = true;
+    im->sx.clear();
+    im->sx.push_back(st);
+    im->classify_buffers(im->sx[0]);
+    im->overrides.clear();
     Slot &s = im->slot[0];
-    im->build_job(s.job, 0, num_samples, false);
-    s.out_direct = nullptr; s.out_first = 1; s.out_init_pos = 0; s.out_limit = 0xFFFFFFFFu; s.timed = im->timing; s.out_boost = 1;
-    if (!im->launch_job(s, nullptr, 0, input, true) || !im->wait_job(s)) return SRLA_APIRESULT_NG;
+    JobPlan plan;
+    plan.segs.push_back({ 0u, 0u, num_samples, 0u });
+    plan.total = (num_samples + 15u) & ~15u;
+    s.emits = true; s.merge_cb = false;
+    if (!im->run_job_sync(s, plan, false, true, 0)) return SRLA_APIRESULT_NG;
     const uint32_t nv = im->num_variants();
     if (records && hipMemcpy(records, s.d_results.p, (size_t)nv * sizeof(SrlaItemResult), hipMemcpyDeviceToHost) != hipSuccess)
         return SRLA_APIRESULT_NG;

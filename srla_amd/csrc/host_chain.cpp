@@ -127,7 +127,7 @@ bool Impl::chain_stage_a(Slot &s, uint32_t jobidx, const ChainJob &cj)
     /* prepare_job put the descriptor uploads on the wide stream: everything after this stage must see them */
     HIP_OK(hipEventRecord(s.t0[ST_A], streams[0]));
     HIP_OK(hipStreamWaitEvent(W, s.t0[ST_A], 0));
-    if (lshift_on_device) HIP_OK(hipStreamWaitEvent(W, ev_or, 0));
+    if (jp.lshift_dev != nullptr) HIP_OK(hipStreamWaitEvent(W, ev_or, 0));
     if (s.used_h2d) HIP_OK(hipStreamWaitEvent(W, s.ev_in, 0));
     static const int kClass[4] = { 0, 1, 2, 4 };
     int rc = 0;
@@ -144,8 +144,8 @@ bool Impl::chain_stage_a(Slot &s, uint32_t jobidx, const ChainJob &cj)
                 any = true;
             }
             if (pass == 1 && any)
-                rc |= srla_launch_pitch_solve(W, &jp, s.d_lags.as<double>(), s.d_results.as<SrlaItemResult>(), nullptr, nullptr,
-                                              d_chain_select[jobidx].as<uint32_t>(), r);
+                rc |= srla_launch_pitch_solve(W, &jp, s.d_items.as<SrlaItemDesc>(), s.d_lags.as<double>(), s.d_results.as<SrlaItemResult>(), nullptr, nullptr,
+                                              d_chain_select[jobidx].as<uint32_t>(), r, s.d_ties.as<uint32_t>(), s.d_tie_data.as<double>());
         }
     HIP_OK(hipEventRecord(s.t1[ST_A], W));
     if (rc != 0) { fprintf(stderr, "[srla-mi355x] kernel launch failed in a chain stage\n"); return false; }
@@ -164,23 +164,43 @@ bool Impl::chain_silent(const std::vector<int32_t> &v, uint32_t total, uint32_t 
 void Impl::chain_slot_defaults(Slot &s)
 {
     s.own_stream = streams[1];   /* the narrow stream: a stream of their own ended up sharing a hardware queue with the wide one and waited for the whole stream (measured) */
-    s.out_direct = nullptr; s.out_first = 1; s.out_init_pos = 0; s.out_limit = 0xFFFFFFFFu; s.timed = false; s.out_boost = 1;
+    s.timed = false; s.out_boost = 1; s.emits = false; s.merge_cb = false;
+}
+
+static JobPlan one_segment(uint32_t stream, uint32_t s0, uint32_t ns)
+{
+    JobPlan p;
+    p.segs.push_back({ stream, s0, ns, 0u });
+    p.total = (ns + 15u) & ~15u;
+    return p;
+}
+
+/* samples -> device, offset shift settled, tables built (stage_input before build_job: the tables carry the shift) */
+bool Impl::chain_make_job(Slot &s, uint32_t s0, uint32_t ns, bool search, const std::vector<uint32_t> *lens)
+{
+    const JobPlan p = one_segment(chain.stream, s0, ns);
+    if (!stage_input(s, p)) return false;
+    std::vector<uint32_t> lsh;
+    settle_lshift(p, lsh);
+    build_job(s.job, p, lsh, search, lens);
+    return true;
 }
 
 bool Impl::chain_begin(uint32_t seed_off, uint32_t seed_n)
 {
     ChainRun &c = chain;
+    const StreamCtx &st = sx[c.stream];
     const uint32_t nch = par.num_channels, nv = num_variants(), passes = par.ltp_order > 0 ? 2u : 1u;
     /* which blocks are all zero decides which calls exist: look at the samples */
     auto fetch = [&](uint32_t off, uint32_t n, std::vector<int32_t> &dst) -> bool {
         dst.resize((size_t)nch * n);
         for (uint32_t ch = 0; ch < nch; ch++) {
-            if (c.host_in) memcpy(dst.data() + (size_t)ch * n, c.host_in[ch] + off, (size_t)n * 4);
-            else if (hipMemcpy(dst.data() + (size_t)ch * n, c.d_in + (size_t)ch * c.d_stride + off, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) return false;
+            if (st.host_in) memcpy(dst.data() + (size_t)ch * n, st.host_in[ch] + off, (size_t)n * 4);
+            else if (hipMemcpy(dst.data() + (size_t)ch * n, st.d_in + (size_t)ch * st.d_stride + off, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) return false;
         }
         return true;
     };
-    c.seed_n = seed_n;
+    c.seed_n = seed_n; c.seed_off = seed_off;
     if (!fetch(c.tail_start, c.tail_n, c.tail_smp) || (seed_n && !fetch(seed_off, seed_n, c.seed_smp))) return false;
     const std::function<bool(uint32_t, uint32_t)> silent_tail = [&](uint32_t off, uint32_t n) { return chain_silent(c.tail_smp, c.tail_n, off, n); };
     const std::function<bool(uint32_t, uint32_t)> silent_seed = [&](uint32_t off, uint32_t n) { return chain_silent(c.seed_smp, c.seed_n, off, n); };
@@ -189,17 +209,22 @@ bool Impl::chain_begin(uint32_t seed_off, uint32_t seed_n)
     chain_tab.clear();
     chain_tab_uploaded = 0;
     Slot &q = slot[kChainSlot], &sj = slot[kChainSlot + 1], &e = slot[kChainSlot + 2];
+    chain_slot_defaults(q); chain_slot_defaults(sj); chain_slot_defaults(e);
     if (seed_n) {
         const std::vector<uint32_t> lens{ seed_n };
-        build_job(q.job, seed_off, seed_n, false, &lens);
+        if (!chain_make_job(q, seed_off, seed_n, false, &lens)) return false;
+        (void)apply_overrides(q.job, kChainJobKey + 0);
         chain_append(0, q.job, silent_seed);
     }
     if (c.search) {
-        build_job(sj.job, c.tail_start, c.tail_n, true);
+        if (!chain_make_job(sj, c.tail_start, c.tail_n, true, nullptr)) return false;
+        sj.job.key = 0;              /* never mistaken for a regular job's tables */
+        (void)apply_overrides(sj.job, kChainJobKey + 1);
         chain_append(1, sj.job, silent_tail);
     } else {
         const std::vector<uint32_t> lens{ c.tail_n };
-        build_job(e.job, c.tail_start, c.tail_n, false, &lens);
+        if (!chain_make_job(e, c.tail_start, c.tail_n, false, &lens)) return false;
+        (void)apply_overrides(e.job, kChainJobKey + 2);
         chain_append(2, e.job, silent_tail);
     }
     {
@@ -213,20 +238,52 @@ bool Impl::chain_begin(uint32_t seed_off, uint32_t seed_n)
     }
     if (seed_n) {
         chain_build(0, q.job, c.cq);
-        chain_slot_defaults(q);
-        if (!prepare_job(q, c.d_in ? c.d_in + seed_off : nullptr, c.d_stride, c.host_in, false) || !chain_stage_a(q, 0, c.cq)) return false;
+        q.job.uploaded = false;
+        if (!prepare_job(q, false) || !chain_stage_a(q, 0, c.cq)) return false;
     }
     if (c.search) {
         chain_build(1, sj.job, c.cs);
-        chain_slot_defaults(sj);
-        if (!prepare_job(sj, c.d_in ? c.d_in + c.tail_start : nullptr, c.d_stride, c.host_in, false) || !chain_stage_a(sj, 1, c.cs)) return false;
-        for (int st = ST_B; st <= ST_D; st++) if (!run_stage(sj, st)) return false;
+        sj.job.uploaded = false;
+        if (!prepare_job(sj, false) || !chain_stage_a(sj, 1, c.cs)) return false;
+        for (int st2 = ST_B; st2 <= ST_D; st2++) if (!run_stage(sj, st2)) return false;
     }
     c.begun = true;
     return true;
 }
 
-bool Impl::chain_encode_ad(uint8_t *out_direct, uint32_t init_pos, uint32_t data_size, bool first_job)
+/* Near-ties of the seed and search jobs (they never reach the block assembly, which is where a regular job's tie count is
+ * reported): decided with the host libm once the search job has been priced; a job the host decides differently is run again. */
+bool Impl::chain_settle_ties()
+{
+    ChainRun &c = chain;
+    Slot &q = slot[kChainSlot], &sj = slot[kChainSlot + 1];
+    for (int attempt = 0; attempt < 6; attempt++) {
+        if (c.seed_n && hipEventSynchronize(q.t1[ST_A]) != hipSuccess) return false;
+        const int mq = c.seed_n ? arbitrate(q, kChainJobKey + 0) : 0;
+        const int ms = c.search ? arbitrate(sj, kChainJobKey + 1) : 0;
+        if (mq < 0 || ms < 0) return false;
+        if (mq == 0 && ms == 0) return true;
+        stats.num_restarts++;
+        if (mq > 0) {
+            (void)apply_overrides(q.job, kChainJobKey + 0);
+            q.job.uploaded = false;
+            if (!prepare_job(q, false) || !chain_stage_a(q, 0, c.cq)) return false;
+        }
+        if (c.search) {
+            /* the window's calls inherit from the seed's: the search job follows in any case */
+            (void)apply_overrides(sj.job, kChainJobKey + 1);
+            sj.job.uploaded = false;
+            if (!prepare_job(sj, false) || !chain_stage_a(sj, 1, c.cs)) return false;
+            for (int st2 = ST_B; st2 <= ST_D; st2++) if (!run_stage(sj, st2)) return false;
+            if (hipEventSynchronize(sj.t1[ST_D]) != hipSuccess) return false;
+        }
+    }
+    fprintf(stderr, "[srla-mi355x] internal error: near-tie arbitration of the chain-mode window did not settle\n");
+    return false;
+}
+
+/* the encode job up to its pricing */
+bool Impl::chain_encode_ad()
 {
     ChainRun &c = chain;
     Slot &q = slot[kChainSlot], &sj = slot[kChainSlot + 1], &e = slot[kChainSlot + 2];
@@ -235,6 +292,9 @@ bool Impl::chain_encode_ad(uint8_t *out_direct, uint32_t init_pos, uint32_t data
         if (hipEventSynchronize(sj.t1[ST_D]) != hipSuccess) return false;
         static const bool trace = getenv("SRLA_MI355X_CHAIN_TRACE") != nullptr;
         if (trace) fprintf(stderr, "[chain] waited %.3f ms for the search job (%u rounds)\n", ms_since(tw), c.cs.rounds);
+    }
+    if (!chain_settle_ties()) return false;
+    if (c.search) {
         const SrlaWindowDesc &wd = sj.job.windows[0];
         std::vector<SrlaBlockRecord> recs(wd.num_nodes - 1);
         if (hipMemcpy(recs.data(), sj.d_blocks.as<SrlaBlockRecord>() + wd.block_base, recs.size() * sizeof(SrlaBlockRecord), hipMemcpyDeviceToHost) != hipSuccess)
@@ -245,22 +305,24 @@ bool Impl::chain_encode_ad(uint8_t *out_direct, uint32_t init_pos, uint32_t data
         if (covered != c.tail_n) { fprintf(stderr, "[srla-mi355x] internal error: the tail window's partitions cover %u of %u samples\n", covered, c.tail_n); return false; }
         sj.busy = false;
         const std::function<bool(uint32_t, uint32_t)> silent_tail = [&](uint32_t off, uint32_t n) { return chain_silent(c.tail_smp, c.tail_n, off, n); };
-        build_job(e.job, c.tail_start, c.tail_n, false, &lens);
+        if (!chain_make_job(e, c.tail_start, c.tail_n, false, &lens)) return false;
+        (void)apply_overrides(e.job, kChainJobKey + 2);
         chain_append(2, e.job, silent_tail);
         if (chain_pool_used * sizeof(double) > d_chain_pool.cap) return false;
     }
     q.busy = false;
     chain_build(2, e.job, c.ce);
-    chain_slot_defaults(e);
-    e.out_direct = out_direct; e.out_first = first_job ? 1u : 0u; e.out_init_pos = init_pos; e.out_limit = data_size; e.out_boost = tail_boost;
-    if (!prepare_job(e, c.d_in ? c.d_in + c.tail_start : nullptr, c.d_stride, c.host_in, false) || !chain_stage_a(e, 2, c.ce)) return false;
-    for (int st = ST_B; st <= ST_D; st++) if (!run_stage(e, st)) return false;
+    e.out_boost = tail_boost; e.emits = true; e.merge_cb = true;
+    e.job.uploaded = false;
+    if (!prepare_job(e, false) || !chain_stage_a(e, 2, c.ce)) return false;
+    for (int st2 = ST_B; st2 <= ST_D; st2++) if (!run_stage(e, st2)) return false;
     c.ad_done = true;
     return true;
 }
 
 bool Impl::chain_encode_e() { return run_stage(slot[kChainSlot + 2], ST_E); }
 
+/* has the search job been priced (so that the encode job can be enqueued without waiting)? */
 bool Impl::chain_search_done()
 {
     if (!chain.begun) return false;
@@ -270,3 +332,24 @@ bool Impl::chain_search_done()
     return e == hipSuccess;
 }
 
+/* waits for the encode job, settles its near-ties (running it again where the host libm decides otherwise) and collects it */
+SRLAApiResult Impl::chain_collect()
+{
+    Slot &e = slot[kChainSlot + 2];
+    for (int attempt = 0;; attempt++) {
+        if (!wait_job(e)) return SRLA_APIRESULT_NG;
+        if (e.h_info.as<SrlaJobInfo>()->num_tie_items == 0) break;
+        const int m = arbitrate(e, kChainJobKey + 2);
+        if (m < 0) return SRLA_APIRESULT_NG;
+        if (m == 0) break;
+        if (attempt >= 6) { fprintf(stderr, "[srla-mi355x] internal error: near-tie arbitration of the chain-mode window did not settle\n"); return SRLA_APIRESULT_NG; }
+        stats.num_restarts++;
+        /* once more, from the place the host knows the stream has reached (every job before this one has been collected) */
+        sx[chain.stream].pass_started = false;
+        (void)apply_overrides(e.job, kChainJobKey + 2);
+        e.job.uploaded = false;
+        if (!prepare_job(e, false) || !chain_stage_a(e, 2, chain.ce)) return SRLA_APIRESULT_NG;
+        for (int st2 = ST_B; st2 <= ST_E; st2++) if (!run_stage(e, st2)) return SRLA_APIRESULT_NG;
+    }
+    return finish_job(e);
+}

@@ -2,7 +2,7 @@
  * host_impl.h -- the encoder handle behind the SRLAEncoder_* C ABI (include/srla_mi355x.h): its state and the
  * functions of the host runtime, which are defined in
  *   host_plan.cpp      tables of the block-division search for a range of windows (jobs), host-libm constants
- *   host_pipeline.cpp  device set-up, staging of host input, the staged execution of jobs, the stream loop
+ *   host_pipeline.cpp  device set-up, staging of host input, the staged execution of jobs, the loop over the jobs of a call
  *   host_chain.cpp     chain mode: the history-dependent last window of a stream
  *   host_ties.cpp      host-libm arbitration of decisions the device flagged as near-ties
  *   host_api.cpp       the C ABI itself
@@ -13,11 +13,12 @@
  *           host-libm constant tables, staging of host input, enqueueing, collecting finished jobs.
  *   device  everything between samples and finished stream bytes: kernels.hip.
  *
- * A stream is processed as a sequence of jobs (ranges of whole windows, ~4 M samples).  The stages of consecutive
- * jobs are enqueued skewed on three streams (software pipeline, see run_stage / encode_stream) with up to four jobs
- * in flight; the host thread only enqueues and waits for one event per job.  Windows carry no state
- * from one to the next, so jobs are independent; only the offset left shift is a
- * whole-stream quantity (device-resident for device input, speculated for host input).
+ * A call encodes one stream (SRLAEncoder_EncodeWhole) or many (SRLAMI355X_EncodeBatch).  The streams are cut into jobs:
+ * ranges of whole look-ahead windows, ~4 M samples, of one stream or of several short ones (a job's run of windows of
+ * one stream is a "segment").  The stages of consecutive jobs are enqueued skewed on three HIP streams (software
+ * pipeline, see run_stage / encode_streams) with up to four jobs in flight; the host thread only enqueues and waits for
+ * one event per job.  Windows carry no state from one to the next, so jobs are independent; only the
+ * offset left shift is a whole-stream quantity (device-resident for device input, speculated for host input).
  *
  * There is no CPU fallback: if no HIP device can be initialised every Encode* / ComputeBlockSize
  * call fails with SRLA_APIRESULT_NG and a message on stderr.
@@ -64,12 +65,25 @@ struct Group {
     SrlaLdsPlan plan;
 };
 
+/* samples [s0, s0 + ns) of stream `stream` of the call, standing at sample `base` of the job's input planes */
+struct SegPlan {
+    uint32_t stream, s0, ns, base;
+};
+struct JobPlan {
+    std::vector<SegPlan> segs;
+    uint32_t total = 0;               /* samples per channel plane of the job's input (segments + alignment gaps) */
+    uint32_t slot = 0;
+};
+
 struct Job {
-    uint32_t s0 = 0, ns = 0;          /* sample range inside the stream */
+    std::vector<SegPlan> segs;        /* what the tables below were built for */
+    std::vector<uint32_t> seg_lshift;
+    uint32_t total = 0;
     std::vector<SrlaWindowDesc> windows;
     std::vector<SrlaCandDesc> cands;
     std::vector<SrlaItemDesc> items;
     std::vector<Group> groups;
+    std::vector<uint32_t> seg_first_window;   /* per segment (+ one past the end) */
     uint32_t num_slots = 0;
     uint64_t res_elems = 0;
     uint64_t analyzed_samples = 0;
@@ -80,7 +94,6 @@ struct Job {
 };
 
 struct Slot {
-    hipStream_t stream = nullptr;
     hipStream_t own_stream = nullptr;    /* chain-mode jobs: every stage but the block assembly runs here */
     hipEvent_t t0[6] = {}, t1[6] = {};   /* start / end of the stages of the job (see Impl::run_stage) */
     hipEvent_t ev_in = nullptr;          /* the job's samples have arrived in d_input (host-input calls) */
@@ -89,16 +102,46 @@ struct Slot {
     SrlaJobParams jp{};
     bool want_dbg = false;
     bool timed = false;                  /* this job records start events for every stage (one job in four) */
-    /* where this job's blocks go (set when the job is begun, used by the pack stage) */
-    uint8_t *out_direct = nullptr;       /* device-visible caller buffer, or nullptr: stage through h_stream */
-    uint32_t out_first = 1, out_init_pos = 0, out_limit = 0xFFFFFFFFu;
     uint32_t out_boost = 1;              /* stream-out workgroup multiplier (the last jobs of a stream drain faster) */
     DevBuf d_input16;                    /* host input of at most 16 bits crosses PCIe as int16 and is widened into d_input */
-    DevBuf d_input, d_items, d_cands, d_windows, d_results, d_res_ws, d_blocks, d_block_off, d_ctl, d_scratch, d_dbg, d_lags, d_err, d_class_index, d_stream;
-    PinBuf h_in, h_stream, h_info;       /* h_info: SrlaJobInfo followed by the per-window byte counts */
+    DevBuf d_input, d_items, d_cands, d_windows, d_results, d_res_ws, d_blocks, d_block_off, d_scratch, d_dbg, d_lags, d_err, d_class_index, d_stream;
+    DevBuf d_segs, d_seg_ctl;            /* SrlaSegDesc per segment; device-side segment records of srla_block_offsets */
+    DevBuf d_ties, d_tie_data;           /* near-tie list of the job (count + entries), 8 doubles per entry for LTP entries */
+    PinBuf h_in, h_stream, h_info;       /* h_info: SrlaJobInfo, the per-window byte counts, SrlaSegInfo per segment */
+    PinBuf h_segs;                       /* host copy of the segment table (uploaded per job) */
     Job job;
     bool busy = false;
     bool used_h2d = false;
+    bool emits = true;                   /* the job runs the block assembly (chain mode's seed and search jobs do not) */
+    bool merge_cb = false;               /* one encode callback for the whole segment (chain mode's encode job: its windows are the partitions of ONE look-ahead window) */
+    const uint32_t *window_bytes() const { return reinterpret_cast<const uint32_t *>(h_info.as<SrlaJobInfo>() + 1); }
+    const SrlaSegInfo *seg_info() const { return reinterpret_cast<const SrlaSegInfo *>(window_bytes() + job.windows.size()); }
+};
+
+/* One stream of a call. */
+struct StreamCtx {
+    const int32_t *const *host_in = nullptr;   /* planar host planes, or */
+    const int32_t *d_in = nullptr;             /* planar device planes, d_stride elements apart */
+    uint32_t d_stride = 0;
+    uint32_t num_samples = 0;
+    uint8_t *data = nullptr;                   /* the stream's output buffer */
+    uint32_t data_size = 0;
+    uint8_t *out_direct = nullptr;             /* device-visible address of `data` (pinned / registered / device memory), or null */
+    bool out_in_hbm = false;
+    bool in_pinned = false;                    /* the input planes are pinned host memory: DMA reads them without staging */
+    bool with_header = true;                   /* EncodeWhole / EncodeBatch: header + offset shift; block calls: neither */
+    SRLAEncoder_EncodeBlockCallback cb = nullptr;
+    /* offset left shift (srla_utility.c:177): the OR of ALL samples decides it.  Host input is encoded while the staging
+     * copies are still gathering that OR: a stream whose first job does not hold all of it starts with the shift of what
+     * has been seen (lshift_spec) and is encoded again in the rare case that the rest of the stream lowers it */
+    uint32_t lshift = 0;
+    bool lshift_final = false, lshift_spec = false, lshift_on_device = false;
+    uint32_t or_mask = 0, or_covered = 0;      /* OR of samples [0, or_covered) */
+    /* progress as the host knows it (jobs collected) */
+    uint32_t write_off = 0, progress = 0;
+    bool pass_started = false;                 /* a segment of the stream has been enqueued in the current pass: later ones continue at the device's running offset */
+    uint32_t body = 0, chain_n = 0;            /* regular windows / history-dependent last window (chain mode) */
+    SRLAApiResult rc = SRLA_APIRESULT_OK;
 };
 
 }  // namespace srla
@@ -110,7 +153,7 @@ struct Impl {
     SRLAEncodeParameter par{};
     bool set_parameter = false;
     uint32_t param_generation = 0;    /* bumped by SetEncodeParameter: invalidates cached job tables */
-    uint32_t offset_lshift = 0;       /* encoder->header.offset_lshift of the reference */
+    uint32_t offset_lshift = 0;       /* encoder->header.offset_lshift of the reference: set by EncodeWhole, used by the block calls */
     uint32_t pack_threads = 0;
 
     int device = 0;                   /* HIP device of this handle (SRLAMI355X_SetDevice at the time of Create) */
@@ -121,29 +164,23 @@ struct Impl {
     hipStream_t chain_stream = nullptr; /* autocorrelation rounds of chain mode */
     hipStream_t upload = nullptr;      /* H2D of host-input jobs: a DMA queue of its own, so uploads never wait behind kernels */
     hipEvent_t ev_or = nullptr;       /* offset-shift reduction done */
-    hipEvent_t ev_ref = nullptr;      /* SRLA_MI355X_TIMELINE: start of the stream on the wide stream */
+    hipEvent_t ev_ref = nullptr;      /* SRLA_MI355X_TIMELINE: start of the call on the wide stream */
     bool timeline = false;
-    std::string tl_log;               /* printed when the stream is done: writing to stderr on the way distorts what is measured */
+    std::string tl_log;               /* printed when the call is done: writing to stderr on the way distorts what is measured */
     void tl_printf(const char *fmt, ...) __attribute__((format(printf, 2, 3)));
-    bool lshift_on_device = false;
     PinBuf h_or;
-    uint32_t kSlots = 4;              /* job buffer sets (SRLA_MI355X_SLOTS); slot i runs on stream i % kStreams */
+    uint32_t kSlots = 4;              /* job buffer sets (SRLA_MI355X_SLOTS) */
     uint64_t job_samples = 4ull << 20; /* samples per job (SRLA_MI355X_JOB_SAMPLES): fixed per-job latencies (serial solve chain, launch gaps) favour large jobs; measured best for long streams, and never worse than smaller ones for short streams */
     Slot slot[kMaxSlots];
     DevBuf d_tw, d_geoms, d_thr, d_huff, d_huffcode, d_pos, d_or;
     bool timing = true;               /* stage timing events (SRLA_MI355X_NO_TIMING drops them) */
     uint32_t tail_boost = 4, tail_boost_jobs = 3;   /* SRLA_MI355X_TAIL_BOOST="wgs,jobs" */
     uint32_t timing_stride = 4;       /* every n-th job carries start events on all stages (SRLA_MI355X_TIMING_STRIDE) */
-    bool in_pinned = false;           /* this call's input planes are pinned host memory */
-    /* Host input without a callback: the stream is encoded assuming offset shift 0 while the staging copies gather the
-     * OR of all samples; only if that OR has trailing zeros (rare for audio) the stream is encoded again with the
-     * right shift.  Saves a separate pass over the input before the first kernel can start. */
-    bool spec_or_active = false, spec_guessed = false;
-    std::atomic<uint32_t> spec_or{ 0 };
-    int forced_lshift = -1;           /* >= 0: the shift is known (second attempt) */
-    bool no_speculation = false;      /* SRLA_MI355X_NO_SPECULATION */
+    bool no_speculation = false;      /* SRLA_MI355X_NO_SPECULATION: the OR of a stream is always gathered before its first job */
     bool force_staging = false;       /* SRLA_MI355X_STAGING: never write the caller's buffer from the device */
     bool no_pack16 = false;           /* SRLA_MI355X_NO_PACK16: host input always crosses PCIe as int32 */
+    /* near-tie detection and its test hooks (SrlaJobParams; SRLA_MI355X_TIE_TEST="rel,ltp,logscale,powscale") */
+    double tie_rel = 1e-9, tie_ltp = 1e-9, tie_logscale = 1.0, tie_powscale = 1.0;
     std::map<uint32_t, uint32_t> tw_index;   /* nfft -> offset (double2) */
     std::vector<double> tw_host;
     bool tw_dirty = false;
@@ -165,33 +202,54 @@ struct Impl {
     uint32_t geom_for(uint32_t n);
     bool sync_tables();               /* tables are shared by all slots: waits for everything in flight before re-allocating them */
     SrlaLdsPlan lds_plan(uint32_t nfft) const;   /* LDS carve-up of srla_residual_cost for the largest FFT size of a job */
-    /* Candidate table of SearchOptimalBlockPartitions (srla_encoder.c:336-389) for the windows
-     * [first sample s0, s0+ns) of a stream; ns ends on a window boundary or at the stream end.
-     * `lens` (chain mode): the job's windows are these blocks, one candidate each, instead of the regular tiling */
-    void build_job(Job &job, uint32_t s0, uint32_t ns, bool search, const std::vector<uint32_t> *lens = nullptr);
-    SrlaJobParams job_params(const Job &job, uint32_t channel_stride) const;
+    /* Tables of SearchOptimalBlockPartitions (srla_encoder.c:336-389) for the windows of the plan's segments (each a range
+     * of whole windows of one stream, or the end of it); lshift[k]: offset left shift of segment k's stream.
+     * `lens` (chain mode, one segment): the job's windows are these blocks, one candidate each, instead of the regular tiling */
+    void build_job(Job &job, const JobPlan &plan, const std::vector<uint32_t> &lshift, bool search, const std::vector<uint32_t> *lens = nullptr);
+    SrlaJobParams job_params(const Job &job, uint32_t channel_stride, bool lshift_on_device) const;
     uint32_t windows_per_job(bool search) const;   /* bounded by scratch memory (~1.5 GB of residual scratch per slot) */
+    /* the jobs of a call: streams cut at window boundaries, short streams sharing jobs */
+    void plan_jobs(std::vector<JobPlan> &plan, bool search);
+
+    /* ---- the streams of the current call (host_pipeline.cpp) ---- */
+    std::vector<StreamCtx> sx;
+    /* Decisions of the host libm that differ from the device's (host_ties.cpp), by (job of the call, item): the job is
+     * analysed again with them.  Chain-mode jobs use the job numbers kChainJobKey + 0..2. */
+    struct Override { int32_t forced_order = -1; uint32_t forced_ltp = 0; };
+    std::map<uint64_t, Override> overrides;
+    static constexpr uint32_t kChainJobKey = 0xFFFFFFF0u;
+    static uint64_t override_key(uint32_t job, uint32_t item) { return ((uint64_t)job << 32) | item; }
+    bool apply_overrides(Job &job, uint32_t jobkey);   /* patches the job's item table; true if anything was patched */
+    /* Looks at the items the finished job flagged as near-ties, decides them with the host libm and records an override
+     * where the device decided otherwise.  Returns the number of new overrides, -1 on error. */
+    int arbitrate(Slot &s, uint32_t jobkey);
 
     /* ---- staged execution of one job (host_pipeline.cpp) --------------------------------------------------
-     * Three streams: W carries the wide kernels (autocorr, residual_cost), N the narrow ones
+     * Three HIP streams: W carries the wide kernels (autocorr, residual_cost), N the narrow ones
      * (Levinson / order / quantiser, pricing), C the block assembly and the stream-out.  A job's stages are chained
-     * with events; encode_stream enqueues the stages of consecutive jobs skewed (software pipeline), so that W always
+     * with events; encode_streams enqueues the stages of consecutive jobs skewed (software pipeline), so that W always
      * has a wide kernel to run while N works through the serial stages of the neighbouring job. */
     enum { ST_A = 0, ST_B, ST_C, ST_D, ST_E, NUM_ST };
-    /* d_in: device pointer to channel 0 of the job's first sample, or nullptr to upload host_in (planar pointers,
-     * absolute stream positions) */
-    bool prepare_job(Slot &s, const int32_t *d_in, uint32_t d_stride, const int32_t *const *host_in, bool want_dbg);
+    /* brings the samples of the plan's segments to the device (staging copy + H2D for host input; device input is used
+     * where it lies) and gathers the OR of what it moves */
+    bool stage_input(Slot &s, const JobPlan &plan);
+    /* settles the offset shift of the streams of the plan (final, or speculative: see StreamCtx) */
+    void settle_lshift(const JobPlan &plan, std::vector<uint32_t> &lshift);
+    /* buffers, table upload, segment table; `init_pos_of(stream)`: where a stream's first segment of this pass starts */
+    bool prepare_job(Slot &s, bool want_dbg);
     bool run_stage(Slot &s, int st);
-    bool launch_job(Slot &s, const int32_t *d_in, uint32_t d_stride, const int32_t *const *host_in, bool want_dbg);   /* all stages back to back */
     bool wait_job(Slot &s);
-    /* A finished job: check the device's verdict, move the bytes to `data + write_off` unless the device wrote
-     * them there itself, and report the per-window sizes. */
-    SRLAApiResult finish_job(Slot &s, uint8_t *data, uint32_t write_off, uint32_t *written, const uint32_t **window_bytes);
-    srla::StreamInfo stream_info(uint32_t num_samples) const;
-    /* The body shared by EncodeWhole (host input) and EncodeWholeDevice. */
-    SRLAApiResult encode_stream(const int32_t *const *host_in, const int32_t *d_in, uint32_t d_stride,
-                                uint32_t num_samples, uint8_t *data, uint32_t data_size, uint32_t *output_size,
-                                SRLAEncoder_EncodeBlockCallback cb, bool with_header, bool search);
+    /* one job from plan to finished bytes, synchronously (block calls, probes); arbitrates near-ties */
+    bool run_job_sync(Slot &s, const JobPlan &plan, bool search, bool want_dbg, uint32_t jobkey);
+    /* A finished job: checks the device's verdict and, segment by segment, moves the bytes into the stream's buffer unless
+     * the device wrote them there itself, delivers the callbacks and advances the stream's progress. */
+    SRLAApiResult finish_job(Slot &s);
+    srla::StreamInfo stream_info(const StreamCtx &st) const;
+    bool write_header(StreamCtx &st);
+    /* The body shared by EncodeWhole, EncodeWholeDevice, EncodeBatch and the block calls: encodes the streams in `sx`. */
+    SRLAApiResult encode_streams(bool search);
+    /* classifies the stream's buffers (pinned? device memory?) */
+    void classify_buffers(StreamCtx &st);
 
     /* ---- chain mode: the odd-length tail window ------------------------------------------------------------
      * The reference's Welch window never writes the middle word of an odd-length block (lpc.c:260-264), so that
@@ -232,19 +290,20 @@ struct Impl {
         bool active = false, begun = false, early = false, ad_done = false;
         uint32_t tail_start = 0, tail_n = 0;
         bool search = false;
-        const int32_t *const *host_in = nullptr;
-        const int32_t *d_in = nullptr;
-        uint32_t d_stride = 0;
+        uint32_t stream = 0;              /* index into sx */
         std::vector<int32_t> tail_smp, seed_smp;
-        uint32_t seed_n = 0;
+        uint32_t seed_n = 0, seed_off = 0;
         ChainJob cq, cs, ce;
     } chain;
     static constexpr uint32_t kChainSlot = kMaxSlots - 3;   /* seed, search, encode */
     bool chain_silent(const std::vector<int32_t> &v, uint32_t total, uint32_t off, uint32_t n) const;
     void chain_slot_defaults(Slot &s);
+    bool chain_make_job(Slot &s, uint32_t s0, uint32_t ns, bool search, const std::vector<uint32_t> *lens);
     bool chain_begin(uint32_t seed_off, uint32_t seed_n);
-    /* the encode job up to its pricing; `first_job`: nothing was encoded before the window */
-    bool chain_encode_ad(uint8_t *out_direct, uint32_t init_pos, uint32_t data_size, bool first_job);
+    bool chain_settle_ties();
+    SRLAApiResult chain_collect();
+    /* the encode job up to its pricing */
+    bool chain_encode_ad();
     bool chain_encode_e();
     bool chain_search_done();         /* has the search job been priced (so that the encode job can be enqueued without waiting)? */
 };

@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <memory>
 #include <thread>
 
 namespace srla {
@@ -36,9 +37,10 @@ Impl::~Impl()
             if (s.ev_in) (void)hipEventDestroy(s.ev_in);
             s.d_input16.release();
             DevBuf *db[] = { &s.d_input, &s.d_items, &s.d_cands, &s.d_windows, &s.d_results, &s.d_res_ws,
-                             &s.d_blocks, &s.d_block_off, &s.d_ctl, &s.d_scratch, &s.d_dbg, &s.d_lags, &s.d_err, &s.d_class_index, &s.d_stream };
+                             &s.d_blocks, &s.d_block_off, &s.d_scratch, &s.d_dbg, &s.d_lags, &s.d_err, &s.d_class_index, &s.d_stream,
+                             &s.d_segs, &s.d_seg_ctl, &s.d_ties, &s.d_tie_data };
             for (auto *b : db) b->release();
-            PinBuf *pb[] = { &s.h_in, &s.h_stream, &s.h_info };
+            PinBuf *pb[] = { &s.h_in, &s.h_stream, &s.h_info, &s.h_segs };
             for (auto *b : pb) b->release();
         }
         for (auto &st : streams) if (st) (void)hipStreamDestroy(st);
@@ -101,7 +103,6 @@ bool Impl::init_device()
     if (!h_or.ensure(64)) return false;
     for (uint32_t si = 0; si < kMaxSlots; si++) {
         Slot &s = slot[si];
-        s.stream = streams[0];
         for (auto &e : s.t0) HIP_OK(hipEventCreate(&e));
         for (auto &e : s.t1) HIP_OK(hipEventCreate(&e));
         HIP_OK(hipEventCreateWithFlags(&s.ev_in, hipEventDisableTiming));
@@ -126,6 +127,12 @@ bool Impl::init_device()
     force_staging = getenv("SRLA_MI355X_STAGING") != nullptr;
     no_pack16 = getenv("SRLA_MI355X_NO_PACK16") != nullptr;
     no_speculation = getenv("SRLA_MI355X_NO_SPECULATION") != nullptr;
+    if (const char *e = getenv("SRLA_MI355X_TIE_TEST")) {
+        /* "rel,ltp,logscale,powscale": widens the near-tie thresholds and falsifies the device's log / x^-1/2, so that the
+         * host arbitration has real work to do (tests/test_gpu_ties.py) */
+        double a = 0, b = 0, c = 1, d = 1;
+        if (sscanf(e, "%lf,%lf,%lf,%lf", &a, &b, &c, &d) == 4) { tie_rel = a; tie_ltp = b; tie_logscale = c; tie_powscale = d; }
+    }
     timing = getenv("SRLA_MI355X_NO_TIMING") == nullptr;
     if (const char *e = getenv("SRLA_MI355X_TAIL_BOOST")) { unsigned a = 0, b = 0; if (sscanf(e, "%u,%u", &a, &b) == 2 && a >= 1) { tail_boost = a; tail_boost_jobs = b; } }
     if (const char *e = getenv("SRLA_MI355X_TIMING_STRIDE")) { const int v = atoi(e); if (v >= 1) timing_stride = (uint32_t)v; }
@@ -150,13 +157,133 @@ bool Impl::init_device()
     return true;
 }
 
-bool Impl::prepare_job(Slot &s, const int32_t *d_in, uint32_t d_stride, const int32_t *const *host_in, bool want_dbg)
+static uint32_t shift_of(uint32_t mask)
+{
+    uint32_t sh = 0;
+    if (mask != 0) while (((mask >> sh) & 1u) == 0) sh++;
+    return sh;
+}
+
+/* Brings the samples of the plan's segments to the device.  Device-resident input (one segment) is used where it lies.
+ * Host input: pageable planes are staged into pinned memory by the pool threads (non-temporal stores; streams of at most
+ * 16 bits are packed to int16 on the way and widened again by a small kernel behind the upload) and cross PCIe on the
+ * upload stream; pinned planes are read by DMA directly.  The OR of the samples of streams whose offset shift is still
+ * open is gathered on the way. */
+bool Impl::stage_input(Slot &s, const JobPlan &plan)
+{
+    const uint32_t nch = par.num_channels;
+    s.used_h2d = false;
+    {
+        const StreamCtx &first = sx[plan.segs[0].stream];
+        if (first.d_in) {
+            s.in_cur = first.d_in + plan.segs[0].s0;
+            s.stride_cur = first.d_stride;
+            return true;
+        }
+    }
+    const uint32_t total = plan.total, nseg = (uint32_t)plan.segs.size();
+    if (!s.d_input.ensure((size_t)nch * total * 4)) return false;
+    bool all_pinned = true;
+    for (const SegPlan &sp : plan.segs) all_pinned = all_pinned && sx[sp.stream].in_pinned;
+    std::unique_ptr<std::atomic<uint32_t>[]> seg_or(new std::atomic<uint32_t>[nseg]);
+    for (uint32_t k = 0; k < nseg; k++) seg_or[k].store(0);
+    struct Task { uint32_t seg, ch, off, len; };
+    std::vector<Task> tasks;
+    const uint32_t chunk = 256u << 10;
+    auto list_tasks = [&](bool only_open) {
+        tasks.clear();
+        for (uint32_t k = 0; k < nseg; k++) {
+            const SegPlan &sp = plan.segs[k];
+            const StreamCtx &st = sx[sp.stream];
+            if (only_open && (st.lshift_final || sp.s0 != st.or_covered)) continue;
+            for (uint32_t ch = 0; ch < nch; ch++)
+                for (uint32_t o = 0; o < sp.ns; o += chunk) tasks.push_back({ k, ch, o, std::min(chunk, sp.ns - o) });
+        }
+    };
+    if (all_pinned) {
+        /* the caller's planes are pinned: DMA straight out of them (the OR of the samples, where it is still being
+         * gathered, is computed by the pool threads meanwhile) */
+        for (const SegPlan &sp : plan.segs)
+            for (uint32_t ch = 0; ch < nch; ch++)
+                HIP_OK(hipMemcpyAsync(s.d_input.as<int32_t>() + (size_t)ch * total + sp.base, sx[sp.stream].host_in[ch] + sp.s0,
+                                      (size_t)sp.ns * 4, hipMemcpyHostToDevice, upload));
+        list_tasks(true);
+        pool->parallel_for((uint32_t)tasks.size(), [&](uint32_t i) {
+            const Task &t = tasks[i];
+            const SegPlan &sp = plan.segs[t.seg];
+            seg_or[t.seg].fetch_or(or_reduce(sx[sp.stream].host_in[t.ch] + sp.s0 + t.off, t.len), std::memory_order_relaxed);
+        });
+    } else {
+        if (!s.h_in.ensure((size_t)nch * total * 4 + 64u * nch)) return false;
+        list_tasks(false);
+        bool packed = false;
+        if (par.bits_per_sample <= 16 && !no_pack16) {
+            /* as int16 (segments start on multiples of 16 samples, so every chunk starts 32-byte aligned) */
+            const size_t stride16 = total;
+            if (!s.d_input16.ensure(nch * stride16 * 2)) return false;
+            int16_t *dst = s.h_in.as<int16_t>();
+            std::atomic<uint32_t> wide{ 0 };
+            pool->parallel_for((uint32_t)tasks.size(), [&](uint32_t i) {
+                const Task &t = tasks[i];
+                const SegPlan &sp = plan.segs[t.seg];
+                uint32_t w = 0;
+                const uint32_t m = pack16_or(dst + (size_t)t.ch * stride16 + sp.base + t.off, sx[sp.stream].host_in[t.ch] + sp.s0 + t.off, t.len, &w);
+                seg_or[t.seg].fetch_or(m, std::memory_order_relaxed);
+                if (w) wide.fetch_or(w, std::memory_order_relaxed);
+            });
+            if (wide.load() == 0) {
+                HIP_OK(hipMemcpyAsync(s.d_input16.p, s.h_in.p, nch * stride16 * 2, hipMemcpyHostToDevice, upload));
+                if (srla_launch_widen16(upload, s.d_input16.as<int16_t>(), stride16, s.d_input.as<int32_t>(), total, nch) != 0) return false;
+                packed = true;
+            }   /* else: samples beyond 16 bits in a stream declared narrower -- the reference does not mind, nor do we */
+        }
+        if (!packed) {
+            int32_t *dst = s.h_in.as<int32_t>();
+            pool->parallel_for((uint32_t)tasks.size(), [&](uint32_t i) {
+                const Task &t = tasks[i];
+                const SegPlan &sp = plan.segs[t.seg];
+                /* the copy also gathers the OR of the samples it moves */
+                const uint32_t m = copy_or(dst + (size_t)t.ch * total + sp.base + t.off, sx[sp.stream].host_in[t.ch] + sp.s0 + t.off, t.len);
+                seg_or[t.seg].fetch_or(m, std::memory_order_relaxed);
+            });
+            HIP_OK(hipMemcpyAsync(s.d_input.p, s.h_in.p, (size_t)nch * total * 4, hipMemcpyHostToDevice, upload));
+        }
+    }
+    HIP_OK(hipEventRecord(s.ev_in, upload));
+    s.in_cur = s.d_input.as<int32_t>();
+    s.stride_cur = total;
+    s.used_h2d = true;
+    for (uint32_t k = 0; k < nseg; k++) {
+        const SegPlan &sp = plan.segs[k];
+        StreamCtx &st = sx[sp.stream];
+        if (!st.lshift_final && sp.s0 == st.or_covered) { st.or_mask |= seg_or[k].load(); st.or_covered += sp.ns; }
+    }
+    return true;
+}
+
+void Impl::settle_lshift(const JobPlan &plan, std::vector<uint32_t> &lshift)
+{
+    lshift.assign(plan.segs.size(), 0u);
+    for (size_t k = 0; k < plan.segs.size(); k++) {
+        StreamCtx &st = sx[plan.segs[k].stream];
+        if (st.lshift_on_device) continue;           /* read from device memory by the kernels (SrlaJobParams::lshift_dev) */
+        if (!st.lshift_final && !st.lshift_spec) {
+            /* the first job of the stream: final if it holds the whole stream, else the shift of what has been seen so far */
+            st.lshift = shift_of(st.or_mask);
+            if (st.or_covered >= st.num_samples) st.lshift_final = true;
+            else st.lshift_spec = true;
+        }
+        lshift[k] = st.lshift;
+    }
+}
+
+bool Impl::prepare_job(Slot &s, bool want_dbg)
 {
     Job &job = s.job;
     const uint32_t nch = par.num_channels;
-    hipStream_t W = streams[0];
+    hipStream_t W = streams[0], C = streams[2];
     if (!sync_tables()) return false;
-    const size_t n_items = job.items.size(), n_cands = job.cands.size(), n_win = job.windows.size();
+    const size_t n_items = job.items.size(), n_cands = job.cands.size(), n_win = job.windows.size(), nseg = job.segs.size();
     {
         const void *pi = s.d_items.p, *pc = s.d_cands.p, *pw = s.d_windows.p;
         if (!s.d_items.ensure(std::max<size_t>(1, n_items) * sizeof(SrlaItemDesc))) return false;
@@ -170,14 +297,20 @@ bool Impl::prepare_job(Slot &s, const int32_t *d_in, uint32_t d_stride, const in
     if (!s.d_res_ws.ensure(std::max<uint64_t>(4, job.res_elems) * 4)) return false;
     if (!s.d_blocks.ensure((size_t)job.num_slots * sizeof(SrlaBlockRecord))) return false;
     if (!s.d_block_off.ensure((size_t)job.num_slots * 4 + 16)) return false;
-    if (!s.d_ctl.ensure(64)) return false;
-    if (!s.h_info.ensure(sizeof(SrlaJobInfo) + n_win * 4)) return false;
+    if (!s.h_info.ensure(sizeof(SrlaJobInfo) + n_win * 4 + nseg * sizeof(SrlaSegInfo))) return false;
+    if (!s.d_segs.ensure(nseg * sizeof(SrlaSegDesc)) || !s.h_segs.ensure(nseg * sizeof(SrlaSegDesc))) return false;
+    if (!s.d_seg_ctl.ensure(nseg * SRLA_SEGCTL_WORDS_HOST * 4)) return false;
+    if (!s.d_ties.ensure((2 * std::max<size_t>(1, n_items) + 2) * 4)) return false;
+    if (par.ltp_order > 0 && !s.d_tie_data.ensure(std::max<size_t>(1, n_items) * 8 * sizeof(double))) return false;
     {
-        /* a block is never larger than its raw form (11 + n * nch * bytes): bound of the job's stream bytes */
-        const size_t bound = (size_t)job.ns * nch * (par.bits_per_sample / 8) + (size_t)job.num_slots * SRLA_PACK_SLACK + 64;
-        if (!s.out_direct && !s.h_stream.ensure(bound)) return false;
+        /* a block is never larger than its raw form (11 + n * nch * bytes): bound of the job's bytes (+ the slack between segments) */
+        uint64_t samples = 0;
+        bool need_host_stage = false;
+        for (const SegPlan &sp : job.segs) { samples += sp.ns; need_host_stage = need_host_stage || sx[sp.stream].out_direct == nullptr; }
+        const size_t bound = (size_t)samples * nch * (par.bits_per_sample / 8) + (size_t)job.num_slots * SRLA_PACK_SLACK + 64 + 32 * nseg;
+        if (need_host_stage && !s.h_stream.ensure(bound)) return false;
         if (!s.d_stream.ensure(bound + 32)) return false;
-        const SrlaJobParams probe = job_params(job, d_stride);
+        const SrlaJobParams probe = job_params(job, s.stride_cur, false);
         if (srla_pack_needs_scratch(&probe) && !s.d_scratch.ensure(bound)) return false;
     }
     if (want_dbg && !s.d_dbg.ensure(std::max<size_t>(1, n_items) * SRLA_DBG_STRIDE * sizeof(double))) return false;
@@ -185,70 +318,6 @@ bool Impl::prepare_job(Slot &s, const int32_t *d_in, uint32_t d_stride, const in
     if (!s.d_lags.ensure((size_t)lag_rows * std::max<size_t>(1, n_items) * sizeof(double))) return false;
     if (!s.d_err.ensure((size_t)(preset_order() + 1) * std::max<size_t>(1, n_items) * sizeof(double))) return false;
     s.want_dbg = want_dbg;
-    s.in_cur = d_in;
-    s.stride_cur = d_stride;
-    s.used_h2d = false;
-    if (!d_in) {
-        if ((!in_pinned && !s.h_in.ensure((size_t)nch * job.ns * 4 + 64u * nch)) || !s.d_input.ensure((size_t)nch * job.ns * 4)) return false;
-        if (in_pinned) {
-            /* the caller's planes are pinned: DMA straight out of them (the OR of the job's samples, when it is
-             * still being gathered, is computed by the pool threads meanwhile) */
-            for (uint32_t ch = 0; ch < nch; ch++)
-                HIP_OK(hipMemcpyAsync(s.d_input.as<int32_t>() + (size_t)ch * job.ns, host_in[ch] + job.s0, (size_t)job.ns * 4,
-                                      hipMemcpyHostToDevice, upload));
-            if (spec_or_active) {
-                const uint32_t chunk = 256u << 10, per_ch = (job.ns + chunk - 1) / chunk;
-                const Job *jb = &job;
-                pool->parallel_for(per_ch * nch, [&](uint32_t i) {
-                    const uint32_t ch = i / per_ch, o = (i % per_ch) * chunk, len = std::min(chunk, jb->ns - o);
-                    const int32_t *src = host_in[ch] + jb->s0 + o;
-                    uint32_t m = 0;
-                    for (uint32_t k = 0; k < len; k++) m |= (uint32_t)src[k];
-                    spec_or.fetch_or(m, std::memory_order_relaxed);
-                });
-            }
-        } else {
-            /* pageable -> pinned staging on the pool threads, then one DMA on the upload stream */
-            const uint32_t chunk = 256u << 10, per_ch = (job.ns + chunk - 1) / chunk;
-            const Job *jb = &job;
-            const bool track = spec_or_active;
-            bool packed = false;
-            if (par.bits_per_sample <= 16 && !no_pack16) {
-                /* as int16 (planes padded to 16 samples so that every chunk starts 32-byte aligned) */
-                const size_t stride16 = ((size_t)job.ns + 15u) & ~(size_t)15u;
-                if (!s.d_input16.ensure(nch * stride16 * 2)) return false;
-                int16_t *dst = s.h_in.as<int16_t>();
-                std::atomic<uint32_t> wide{ 0 };
-                pool->parallel_for(per_ch * nch, [&](uint32_t i) {
-                    const uint32_t ch = i / per_ch, o = (i % per_ch) * chunk, len = std::min(chunk, jb->ns - o);
-                    uint32_t w = 0;
-                    const uint32_t m = pack16_or(dst + (size_t)ch * stride16 + o, host_in[ch] + jb->s0 + o, len, &w);
-                    if (track) spec_or.fetch_or(m, std::memory_order_relaxed);
-                    if (w) wide.fetch_or(w, std::memory_order_relaxed);
-                });
-                if (wide.load() == 0) {
-                    HIP_OK(hipMemcpyAsync(s.d_input16.p, s.h_in.p, nch * stride16 * 2, hipMemcpyHostToDevice, upload));
-                    if (srla_launch_widen16(upload, s.d_input16.as<int16_t>(), stride16, s.d_input.as<int32_t>(), job.ns, nch) != 0) return false;
-                    packed = true;
-                }   /* else: samples beyond 16 bits in a stream declared narrower -- the reference does not mind, nor do we */
-            }
-            if (!packed) {
-                int32_t *dst = s.h_in.as<int32_t>();
-                pool->parallel_for(per_ch * nch, [&](uint32_t i) {
-                    const uint32_t ch = i / per_ch, o = (i % per_ch) * chunk, len = std::min(chunk, jb->ns - o);
-                    const int32_t *src = host_in[ch] + jb->s0 + o;
-                    int32_t *d = dst + (size_t)ch * jb->ns + o;
-                    const uint32_t m = copy_or(d, src, len);   /* the copy also gathers the OR of the samples it moves */
-                    if (track) spec_or.fetch_or(m, std::memory_order_relaxed);
-                });
-                HIP_OK(hipMemcpyAsync(s.d_input.p, s.h_in.p, (size_t)nch * job.ns * 4, hipMemcpyHostToDevice, upload));
-            }
-        }
-        HIP_OK(hipEventRecord(s.ev_in, upload));
-        s.in_cur = s.d_input.as<int32_t>();
-        s.stride_cur = job.ns;
-        s.used_h2d = true;
-    }
     if (!job.uploaded) {
         if (n_items) HIP_OK(hipMemcpyAsync(s.d_items.p, job.items.data(), n_items * sizeof(SrlaItemDesc), hipMemcpyHostToDevice, W));
         if (n_items) HIP_OK(hipMemcpyAsync(s.d_class_index.p, job.class_index.data(), n_items * sizeof(SrlaAutocorrItem), hipMemcpyHostToDevice, W));
@@ -256,17 +325,24 @@ bool Impl::prepare_job(Slot &s, const int32_t *d_in, uint32_t d_stride, const in
         HIP_OK(hipMemcpyAsync(s.d_windows.p, job.windows.data(), n_win * sizeof(SrlaWindowDesc), hipMemcpyHostToDevice, W));
         job.uploaded = true;
     }
-    if (spec_or_active && !spec_guessed) {
-        /* The first job's samples are staged: guess the stream's shift from them instead of assuming 0, so that a
-         * stream whose samples all carry the same trailing zeros (16-bit audio in a 24-bit container) is not encoded
-         * twice.  The whole stream's shift can only be smaller; if it is, the stream is encoded again (below). */
-        const uint32_t m = spec_or.load();
-        uint32_t sh = 0;
-        if (m != 0) while (((m >> sh) & 1u) == 0) sh++;
-        offset_lshift = sh;
-        spec_guessed = true;
+    HIP_OK(hipMemsetAsync(s.d_ties.p, 0, 4, W));
+    /* the segment table: where the blocks of each stream part go */
+    {
+        SrlaSegDesc *sd = s.h_segs.as<SrlaSegDesc>();
+        for (size_t k = 0; k < nseg; k++) {
+            StreamCtx &st = sx[job.segs[k].stream];
+            sd[k].first_window = job.seg_first_window[k];
+            sd[k].num_windows = job.seg_first_window[k + 1] - job.seg_first_window[k];
+            sd[k].stream = job.segs[k].stream;
+            sd[k].use_init = st.pass_started ? 0u : 1u;
+            sd[k].init_pos = st.write_off;
+            sd[k].limit = st.data ? st.data_size : 0xFFFFFFFFu;
+            sd[k].dst = (uint64_t)reinterpret_cast<uintptr_t>(st.out_direct);
+            if (s.emits) st.pass_started = true;
+        }
+        HIP_OK(hipMemcpyAsync(s.d_segs.p, s.h_segs.p, nseg * sizeof(SrlaSegDesc), hipMemcpyHostToDevice, C));
     }
-    s.jp = job_params(job, s.stride_cur);
+    s.jp = job_params(job, s.stride_cur, sx[job.segs[0].stream].lshift_on_device);
     s.busy = true;
     stats.num_windows += n_win; stats.num_candidates += n_cands; stats.num_items += n_items;
     stats.analyzed_samples += job.analyzed_samples;
@@ -278,11 +354,12 @@ bool Impl::run_stage(Slot &s, int st)
 {
     Job &job = s.job;
     /* chain-mode jobs keep to their own stream up to the pricing, so that the regular jobs never queue behind their
-     * many small dependent launches; the block assembly stays on C, where the order of the stream's blocks is made */
+     * many small dependent launches; the block assembly stays on C, where the order of a stream's blocks is made */
     hipStream_t W = s.own_stream ? s.own_stream : streams[0], N = s.own_stream ? s.own_stream : streams[1], C = streams[2];
     const SrlaJobParams &jp = s.jp;
     double *dbg = s.want_dbg ? s.d_dbg.as<double>() : nullptr;
     const bool have_items = !job.groups.empty();
+    const bool on_device = jp.lshift_dev != nullptr;
     int rc = 0;
     /* Stage events ride on the kernel dispatches themselves (hipExtLaunchKernel): the end event on the stage's last
      * launch, the start event (timed jobs only) on its first -- no separate marker packets between the kernels
@@ -290,7 +367,7 @@ bool Impl::run_stage(Slot &s, int st)
     hipEvent_t ev0 = s.timed ? s.t0[st] : nullptr;
     switch (st) {
     case ST_A: {
-        if (lshift_on_device) HIP_OK(hipStreamWaitEvent(W, ev_or, 0));
+        if (on_device) HIP_OK(hipStreamWaitEvent(W, ev_or, 0));
         if (s.used_h2d) HIP_OK(hipStreamWaitEvent(W, s.ev_in, 0));
         struct L { int kind, cls, pass; };                       /* kind 0: autocorr class launch, 1: pitch solve */
         L seq[12]; int nl = 0;
@@ -309,7 +386,8 @@ bool Impl::run_stage(Slot &s, int st)
                                            (uint32_t)seq[i].pass, s.d_results.as<SrlaItemResult>(), s.d_lags.as<double>(), dbg,
                                            s.d_class_index.as<SrlaAutocorrItem>() + job.class_first[c], job.class_count[c], e0, e1, nullptr, nullptr);
             } else {
-                rc |= srla_launch_pitch_solve(W, &jp, s.d_lags.as<double>(), s.d_results.as<SrlaItemResult>(), e0, e1, nullptr, 0);
+                rc |= srla_launch_pitch_solve(W, &jp, s.d_items.as<SrlaItemDesc>(), s.d_lags.as<double>(), s.d_results.as<SrlaItemResult>(), e0, e1,
+                                              nullptr, 0, s.d_ties.as<uint32_t>(), s.d_tie_data.as<double>());
             }
         }
         if (nl == 0) { if (ev0) HIP_OK(hipEventRecord(ev0, W)); HIP_OK(hipEventRecord(s.t1[ST_A], W)); }
@@ -318,7 +396,8 @@ bool Impl::run_stage(Slot &s, int st)
         HIP_OK(hipStreamWaitEvent(N, s.t1[ST_A], 0));
         if (have_items && jp.max_order > 0) {
             rc |= srla_launch_lpc_solve(N, &jp, s.d_items.as<SrlaItemDesc>(), d_geoms.as<SrlaGeom>(), s.d_lags.as<double>(),
-                                        s.d_err.as<double>(), d_huff.as<uint8_t>(), s.d_results.as<SrlaItemResult>(), dbg, ev0, s.t1[ST_B]);
+                                        s.d_err.as<double>(), d_huff.as<uint8_t>(), s.d_results.as<SrlaItemResult>(), dbg,
+                                        s.d_ties.as<uint32_t>(), ev0, s.t1[ST_B]);
         } else { if (ev0) HIP_OK(hipEventRecord(ev0, N)); HIP_OK(hipEventRecord(s.t1[ST_B], N)); }
         break;
     case ST_C:
@@ -339,30 +418,24 @@ bool Impl::run_stage(Slot &s, int st)
         } else { if (ev0) HIP_OK(hipEventRecord(ev0, N)); HIP_OK(hipEventRecord(s.t1[ST_D], N)); }
         break;
     case ST_E:
-        /* block offsets + complete blocks + stream-out to where the stream wants them (the caller's pinned buffer,
-         * or this slot's pinned staging buffer); runs on its own stream and leaves W to autocorr / residual_cost */
+        /* block offsets + complete blocks + stream-out to where the streams want them (their pinned buffers, or this
+         * slot's pinned staging buffer); runs on its own stream and leaves W to autocorr / residual_cost */
         HIP_OK(hipStreamWaitEvent(C, s.t1[ST_D], 0));
         if (job.num_slots) {
+            SrlaJobInfo *info = s.h_info.as<SrlaJobInfo>();
+            uint32_t *wbytes = reinterpret_cast<uint32_t *>(info + 1);
             rc |= srla_launch_pack(C, &jp, job.num_slots, s.in_cur, s.d_items.as<SrlaItemDesc>(), s.d_windows.as<SrlaWindowDesc>(),
                                    s.d_blocks.as<SrlaBlockRecord>(), s.d_results.as<SrlaItemResult>(), s.d_res_ws.as<int32_t>(),
                                    d_huffcode.as<uint32_t>(), d_huff.as<uint8_t>(), s.d_block_off.as<uint32_t>(),
-                                   d_pos.as<uint32_t>(), s.d_ctl.as<uint32_t>(), s.out_first, s.out_init_pos,
-                                   s.out_direct ? 1u : 0u, s.out_limit, s.d_stream.as<uint8_t>(), s.out_direct ? s.out_direct : s.h_stream.as<uint8_t>(),
-                                   s.d_scratch.as<uint8_t>(), s.h_info.as<SrlaJobInfo>(),
-                                   reinterpret_cast<uint32_t *>(s.h_info.as<SrlaJobInfo>() + 1), ev0, s.t1[ST_E], s.out_boost);
+                                   d_pos.as<uint32_t>(), s.d_segs.as<SrlaSegDesc>(), s.d_seg_ctl.as<uint32_t>(),
+                                   s.d_stream.as<uint8_t>(), s.h_stream.as<uint8_t>(), s.d_scratch.as<uint8_t>(), info, wbytes,
+                                   reinterpret_cast<SrlaSegInfo *>(wbytes + job.windows.size()), s.d_ties.as<uint32_t>(),
+                                   ev0, s.t1[ST_E], s.out_boost);
         } else { if (ev0) HIP_OK(hipEventRecord(ev0, C)); HIP_OK(hipEventRecord(s.t1[ST_E], C)); }
         break;
     default: return false;
     }
     if (rc != 0) { fprintf(stderr, "[srla-mi355x] kernel launch failed in stage %d\n", st); return false; }
-    return true;
-}
-
-bool Impl::launch_job(Slot &s, const int32_t *d_in, uint32_t d_stride, const int32_t *const *host_in, bool want_dbg)
-{
-    in_pinned = false;
-    if (!prepare_job(s, d_in, d_stride, host_in, want_dbg)) return false;
-    for (int st = 0; st < NUM_ST; st++) if (!run_stage(s, st)) return false;
     return true;
 }
 
@@ -376,7 +449,7 @@ bool Impl::wait_job(Slot &s)
     if (s.timed) stats.timed_jobs++;
     if (timeline) {
         /* SRLA_MI355X_TIMELINE (with SRLA_MI355X_TIMING_STRIDE=1): where every stage of every job sat on the device's clock */
-        char line[512]; int o = snprintf(line, sizeof(line), "[timeline] job %u+%u:", s.job.s0, s.job.ns);
+        char line[512]; int o = snprintf(line, sizeof(line), "[timeline] job of %u samples:", s.job.total);
         static const char *nm[NUM_ST] = { "A", "B", "C", "D", "E" };
         for (int st = 0; st < NUM_ST; st++) {
             float a = -1, b = 0;
@@ -392,313 +465,391 @@ bool Impl::wait_job(Slot &s)
     return true;
 }
 
-SRLAApiResult Impl::finish_job(Slot &s, uint8_t *data, uint32_t write_off, uint32_t *written, const uint32_t **window_bytes)
+bool Impl::run_job_sync(Slot &s, const JobPlan &plan, bool search, bool want_dbg, uint32_t jobkey)
+{
+    for (int attempt = 0; attempt < 6; attempt++) {
+        if (!stage_input(s, plan)) return false;
+        std::vector<uint32_t> lsh;
+        settle_lshift(plan, lsh);
+        build_job(s.job, plan, lsh, search);
+        if (apply_overrides(s.job, jobkey)) { s.job.uploaded = false; s.job.key = 0; }
+        s.own_stream = nullptr; s.timed = timing; s.out_boost = 1;
+        for (const SegPlan &sp : plan.segs) sx[sp.stream].pass_started = false;
+        if (!prepare_job(s, want_dbg)) return false;
+        for (int st = 0; st < NUM_ST; st++) if (!run_stage(s, st)) return false;
+        if (!wait_job(s)) return false;
+        const SrlaJobInfo *info = s.h_info.as<SrlaJobInfo>();
+        if (info->num_tie_items == 0) return true;
+        const int m = arbitrate(s, jobkey);
+        if (m < 0) return false;
+        if (m == 0) return true;
+        stats.num_restarts++;
+    }
+    fprintf(stderr, "[srla-mi355x] internal error: near-tie arbitration did not settle\n");
+    return false;
+}
+
+SRLAApiResult Impl::finish_job(Slot &s)
 {
     const auto t0 = Clock::now();
     const SrlaJobInfo info = *s.h_info.as<SrlaJobInfo>();
 #ifdef SRLA_DIAG_STOP
     static const bool diag = getenv("SRLA_MI355X_K3_STOP") != nullptr;   /* timing experiments: the stream is garbage */
-    if (diag) { *written = 0; *window_bytes = reinterpret_cast<const uint32_t *>(s.h_info.as<SrlaJobInfo>() + 1); return SRLA_APIRESULT_OK; }
+    if (diag) return SRLA_APIRESULT_OK;
 #endif
-    if (info.error & SRLA_JOBERR_OVERFLOW) return SRLA_APIRESULT_INSUFFICIENT_BUFFER;
-    if (info.error != 0 || info.base != write_off) {
-        fprintf(stderr, "[srla-mi355x] internal error: device pack reported 0x%x (%s%s), stream offset %u vs %u\n", info.error,
+    if (info.error & ~SRLA_JOBERR_OVERFLOW) {
+        fprintf(stderr, "[srla-mi355x] internal error: device pack reported 0x%x (%s%s)\n", info.error,
                 (info.error & SRLA_JOBERR_SIZE) ? "a packed block differs from its computed size " : "",
-                (info.error & SRLA_JOBERR_COVER) ? "a window's blocks do not cover it" : "", info.base, write_off);
+                (info.error & SRLA_JOBERR_COVER) ? "a window's blocks do not cover it" : "");
         return SRLA_APIRESULT_NG;
     }
-    if (!s.out_direct && data != nullptr) {
-        const uint8_t *src = s.h_stream.as<uint8_t>();
-        const uint32_t chunk = 256u << 10, total = info.total_bytes;
-        pool->parallel_for((total + chunk - 1) / chunk, [&](uint32_t i) {
-            const uint32_t o = i * chunk;
-            memcpy(data + write_off + o, src + o, std::min(chunk, total - o));
-        });
+    const SrlaSegInfo *si = s.seg_info();
+    const uint32_t *wb = s.window_bytes();
+    SRLAApiResult worst = SRLA_APIRESULT_OK;
+    for (size_t k = 0; k < s.job.segs.size(); k++) {
+        const SegPlan &sp = s.job.segs[k];
+        StreamCtx &st = sx[sp.stream];
+        if (si[k].skip) { st.rc = SRLA_APIRESULT_INSUFFICIENT_BUFFER; worst = st.rc; continue; }
+        if (si[k].pos != st.write_off) {
+            fprintf(stderr, "[srla-mi355x] internal error: stream %u continues at %u, the host expected %u\n", sp.stream, si[k].pos, st.write_off);
+            return SRLA_APIRESULT_NG;
+        }
+        if (!st.out_direct && st.data != nullptr) {
+            const uint8_t *src = s.h_stream.as<uint8_t>() + si[k].stage_off;
+            uint8_t *dst = st.data + si[k].pos;
+            const uint32_t chunk = 256u << 10, total = si[k].bytes;
+            pool->parallel_for((total + chunk - 1) / chunk, [&](uint32_t i) {
+                const uint32_t o = i * chunk;
+                memcpy(dst + o, src + o, std::min(chunk, total - o));
+            });
+        }
+        /* callbacks: once per window, in order, pointing into the caller's buffer (srla_encoder.c:1779-1782) */
+        uint32_t off = st.write_off, progress = st.progress;
+        if (s.merge_cb) {
+            progress += sp.ns;
+            if (st.cb) st.cb(st.num_samples, progress, st.data + off, si[k].bytes);
+        } else {
+            for (uint32_t w = s.job.seg_first_window[k]; w < s.job.seg_first_window[k + 1]; w++) {
+                progress += s.job.windows[w].n;
+                if (st.cb) st.cb(st.num_samples, progress, st.data + off, wb[w]);
+                off += wb[w];
+            }
+        }
+        st.write_off += si[k].bytes;
+        st.progress = progress;
     }
     stats.num_blocks += info.num_blocks; stats.num_raw_blocks += info.num_raw; stats.num_silent_blocks += info.num_silent;
     stats.num_tie_items += info.num_tie_items; stats.num_odd_items += info.num_odd_items;
     stats.pack_ms += ms_since(t0);
-    *written = info.total_bytes;
-    *window_bytes = reinterpret_cast<const uint32_t *>(s.h_info.as<SrlaJobInfo>() + 1);
-    return SRLA_APIRESULT_OK;
+    return worst;
 }
 
-srla::StreamInfo Impl::stream_info(uint32_t num_samples) const
+srla::StreamInfo Impl::stream_info(const StreamCtx &st) const
 {
     srla::StreamInfo si;
     si.num_channels = par.num_channels; si.bits_per_sample = par.bits_per_sample;
-    si.sampling_rate = par.sampling_rate; si.num_samples = num_samples; si.offset_lshift = offset_lshift;
+    si.sampling_rate = par.sampling_rate; si.num_samples = st.num_samples; si.offset_lshift = st.lshift;
     si.max_block = par.max_num_samples_per_block; si.preset = par.preset; si.ltp_order = par.ltp_order;
     return si;
 }
 
-SRLAApiResult Impl::encode_stream(const int32_t *const *host_in, const int32_t *d_in, uint32_t d_stride,
-                            uint32_t num_samples, uint8_t *data, uint32_t data_size, uint32_t *output_size,
-                            SRLAEncoder_EncodeBlockCallback cb, bool with_header, bool search)
+bool Impl::write_header(StreamCtx &st)
 {
-    const auto t0 = Clock::now();
-    const uint32_t nch = par.num_channels;
-    uint32_t write_off = 0;
-    if (timeline) (void)hipEventRecord(ev_ref, streams[0]);
-    spec_or_active = false;
-    in_pinned = false;
-    if (host_in && !force_staging) {
-        in_pinned = true;
-        for (uint32_t ch = 0; ch < nch && in_pinned; ch++) {
+    if (!st.with_header || st.data == nullptr) return true;
+    if (st.lshift_on_device) {
+        if (hipEventSynchronize(ev_or) != hipSuccess) return false;
+        st.lshift = h_or.as<uint32_t>()[1];
+    }
+    if (st.out_in_hbm) {
+        uint8_t hdr[SRLA_HEADER_SIZE];
+        srla::write_stream_header(stream_info(st), hdr);
+        if (hipMemcpy(st.data, hdr, SRLA_HEADER_SIZE, hipMemcpyHostToDevice) != hipSuccess) return false;
+    } else {
+        srla::write_stream_header(stream_info(st), st.data);
+    }
+    return true;
+}
+
+void Impl::classify_buffers(StreamCtx &st)
+{
+    st.in_pinned = false;
+    if (st.host_in && !force_staging) {
+        st.in_pinned = true;
+        for (uint32_t ch = 0; ch < par.num_channels && st.in_pinned; ch++) {
             hipPointerAttribute_t at;
             memset(&at, 0, sizeof(at));
-            if (hipPointerGetAttributes(&at, host_in[ch]) != hipSuccess || at.type != hipMemoryTypeHost) { in_pinned = false; (void)hipGetLastError(); }
+            if (hipPointerGetAttributes(&at, st.host_in[ch]) != hipSuccess || at.type != hipMemoryTypeHost) { st.in_pinned = false; (void)hipGetLastError(); }
         }
     }
-    if (with_header) {
-        /* offset left shift: OR of every sample (srla_utility.c:177-203) */
-        uint32_t mask = 0;
-        spec_or_active = false;
-        if (host_in && forced_lshift >= 0) {
-            offset_lshift = (uint32_t)forced_lshift;
-            mask = offset_lshift ? (1u << offset_lshift) : 1u;       /* reproduces the shift below */
-        } else if (host_in && cb == nullptr && !no_speculation) {
-            spec_or_active = true;
-            spec_guessed = false;
-            spec_or.store(0);
-            mask = 1u;                                               /* shift 0 until the first job's samples have been seen (prepare_job) */
-        } else if (host_in) {
-            const uint32_t chunk = 1u << 20, per_ch = (num_samples + chunk - 1) / chunk;
-            std::atomic<uint32_t> acc{ 0 };
-            pool->parallel_for(per_ch * nch, [&](uint32_t i) {
-                const uint32_t ch = i / per_ch, o = (i % per_ch) * chunk, len = std::min(chunk, num_samples - o);
-                const int32_t *p = host_in[ch] + o;
-                uint32_t m = 0;
-                for (uint32_t k = 0; k < len; k++) m |= (uint32_t)p[k];
-                acc.fetch_or(m, std::memory_order_relaxed);
-            });
-            mask = acc.load();
-        } else {
-            /* on the device, without a host round trip: the jobs read the shift from device memory */
-            hipStream_t st = streams[0];
-            if (hipMemsetAsync(d_or.p, 0, 8, st) != hipSuccess) return SRLA_APIRESULT_NG;
-            if (srla_launch_or_reduce(st, d_in, d_stride, num_samples, nch, d_or.as<uint32_t>()) != 0) return SRLA_APIRESULT_NG;
-            if (hipMemcpyAsync(h_or.p, d_or.p, 8, hipMemcpyDeviceToHost, st) != hipSuccess) return SRLA_APIRESULT_NG;
-            if (hipEventRecord(ev_or, st) != hipSuccess) return SRLA_APIRESULT_NG;
-            lshift_on_device = true;
-        }
-        if (!lshift_on_device) {
-            uint32_t sh = 0;
-            if (mask != 0) while (((mask >> sh) & 1u) == 0) sh++;
-            offset_lshift = sh;
-        }
-        write_off = SRLA_HEADER_SIZE;   /* the header itself is written once the shift is known (below) */
-    }
-    /* can the device store into the caller's buffer (pinned / registered host memory)? */
-    uint8_t *out_direct = nullptr;
-    bool out_in_hbm = false;
-    if (!force_staging) {
+    /* can the device store into the stream's buffer (pinned / registered host memory, or device memory)? */
+    st.out_direct = nullptr;
+    st.out_in_hbm = false;
+    if (st.data != nullptr) {
         hipPointerAttribute_t at;
         memset(&at, 0, sizeof(at));
-        const hipError_t pe = hipPointerGetAttributes(&at, data);
-        if (pe == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer != nullptr)
-            out_direct = static_cast<uint8_t *>(at.devicePointer);
+        const hipError_t pe = hipPointerGetAttributes(&at, st.data);
+        if (pe == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer != nullptr && !force_staging)
+            st.out_direct = static_cast<uint8_t *>(at.devicePointer);
         else if (pe == hipSuccess && at.type == hipMemoryTypeDevice) {
             /* the caller wants the stream in device memory: same path, only the header needs a copy */
-            out_direct = data;
-            out_in_hbm = true;
-        } else (void)hipGetLastError();
+            st.out_direct = st.data;
+            st.out_in_hbm = true;
+        } else if (pe != hipSuccess) (void)hipGetLastError();
     }
-    if (force_staging && data != nullptr) {
-        hipPointerAttribute_t at;
-        memset(&at, 0, sizeof(at));
-        if (hipPointerGetAttributes(&at, data) == hipSuccess && at.type == hipMemoryTypeDevice) { out_direct = data; out_in_hbm = true; }
-        else (void)hipGetLastError();
-    }
-    const uint32_t init_pos = write_off;
-    const uint32_t window_len = search ? par.num_lookahead_samples : par.max_num_samples_per_block;
-    const uint32_t wpj = windows_per_job(search);
-    const uint64_t job_len = (uint64_t)wpj * window_len;
-    /* Job plan: full jobs rotate through the kSlots buffer sets.  What is left at the end of the stream is cut
-     * once more so that the LAST job is small: after it nothing else runs on the wide stream, so its pricing,
-     * block assembly and stream-out are pure latency (0.27 ms for a full job, 8 % of a 600 s stream's time).
-     * The two tail jobs have buffer sets of their own, so that repeated calls of equal length keep finding
-     * their descriptor tables cached. */
-    /* an odd-length last window goes through chain mode (see chain_tail) once everything before it is out */
-    uint32_t chain_n = 0;
-    {
-        static const bool no_chain = getenv("SRLA_MI355X_NO_CHAIN") != nullptr;
-        const uint32_t tn = num_samples % window_len;
-        const uint32_t grid = search ? par.min_num_samples_per_block : par.max_num_samples_per_block;
-        if ((tn & 1u) && (grid & 1u) == 0 && (window_len % grid) == 0 && !no_chain) chain_n = tn;
-        /* likewise an LTP analysis of a block shorter than the 263 lags reads what earlier calls left beyond its FFT
-         * (lpc.c:371-373); with a minimum block above 256 samples only the window's last block can be that short */
-        if (tn > 0 && par.ltp_order > 0 && grid > 256u && (window_len % grid) == 0 && ((tn - 1u) % grid) + 1u <= 256u && !no_chain) chain_n = tn;
-    }
-    const uint32_t body = num_samples - chain_n;
-    chain.active = chain_n != 0; chain.begun = false; chain.early = false; chain.ad_done = false;
-    chain.tail_start = body; chain.tail_n = chain_n; chain.search = search;
-    chain.host_in = host_in; chain.d_in = d_in; chain.d_stride = d_stride;
-    struct JobPlan { uint32_t s0, ns, slot; };
-    std::vector<JobPlan> plan;
-    {
-        uint64_t nfull = body / job_len, rest = body - nfull * job_len;
-        if (rest == 0 && nfull > 0) { nfull--; rest = job_len; }
-        for (uint64_t k = 0; k < nfull; k++) plan.push_back({ (uint32_t)(k * job_len), (uint32_t)job_len, (uint32_t)(k % kSlots) });
-        const uint64_t small = (uint64_t)std::max<uint32_t>(1u, 262144u / window_len) * window_len;
-        const uint32_t tail0 = (uint32_t)(nfull * job_len);
-        if (nfull > 0 && rest > 2 * small) {
-            const uint32_t first = (uint32_t)(((rest - small) / window_len) * window_len);
-            plan.push_back({ tail0, first, kSlots });
-            plan.push_back({ tail0 + first, (uint32_t)(rest - first), kSlots + 1 });
-        } else if (rest > 0) {
-            plan.push_back({ tail0, (uint32_t)rest, nfull > 0 ? kSlots : 0u });
-        }
-    }
-    const uint32_t njobs = (uint32_t)plan.size();
-    uint32_t progress = 0;
-    if (timeline) tl_printf("[timeline] stream of %u samples, %u jobs; host %.3f ms into the call\n", num_samples, njobs, ms_since(t0));
+}
 
-    auto fail = [&](SRLAApiResult rc) {
+/* The last valid block of segment k's last window of a priced job: (offset inside the stream, length). */
+static bool last_block_of(Slot &ls, size_t k, uint32_t *off, uint32_t *n)
+{
+    const SegPlan &sp = ls.job.segs[k];
+    const SrlaWindowDesc &wd = ls.job.windows[ls.job.seg_first_window[k + 1] - 1];
+    std::vector<SrlaBlockRecord> recs(wd.num_nodes - 1);
+    if (hipMemcpy(recs.data(), ls.d_blocks.as<SrlaBlockRecord>() + wd.block_base, recs.size() * sizeof(SrlaBlockRecord), hipMemcpyDeviceToHost) != hipSuccess)
+        return false;
+    *off = 0; *n = 0;
+    for (const SrlaBlockRecord &r : recs) if (r.valid) { *off = sp.s0 + (r.sample_off - sp.base); *n = r.n; }
+    return true;
+}
+
+/* The body shared by every Encode* entry point: encodes the streams in `sx`. */
+SRLAApiResult Impl::encode_streams(bool search)
+{
+    const auto t0 = Clock::now();
+    const uint32_t nst = (uint32_t)sx.size(), nch = par.num_channels;
+    const bool single = nst == 1;
+    auto drain = [&]() {
         for (auto &st : streams) if (st) (void)hipStreamSynchronize(st);
         if (upload) (void)hipStreamSynchronize(upload);
         if (chain_stream) (void)hipStreamSynchronize(chain_stream);
+    };
+    if (timeline) (void)hipEventRecord(ev_ref, streams[0]);
+    if ((size_t)8 * nst > d_pos.cap) { drain(); if (!d_pos.ensure((size_t)8 * nst)) return SRLA_APIRESULT_NG; }
+    const uint32_t window_len = search ? par.num_lookahead_samples : par.max_num_samples_per_block;
+    const uint32_t grid = search ? par.min_num_samples_per_block : par.max_num_samples_per_block;
+    static const bool no_chain = getenv("SRLA_MI355X_NO_CHAIN") != nullptr;
+    for (StreamCtx &st : sx) {
+        classify_buffers(st);
+        st.write_off = st.with_header ? SRLA_HEADER_SIZE : 0u;
+        st.progress = 0; st.pass_started = false; st.rc = SRLA_APIRESULT_OK;
+        st.or_mask = 0; st.or_covered = 0; st.lshift_spec = false; st.lshift_on_device = false;
+        if (!st.with_header) { st.lshift = offset_lshift; st.lshift_final = true; }
+        else if (st.lshift_final) { /* known (second attempt after a failed speculation) */ }
+        else if (st.d_in) {
+            /* offset left shift: OR of every sample (srla_utility.c:177-203) on the device, without a host round trip: the
+             * jobs read the shift from device memory */
+            hipStream_t w = streams[0];
+            if (!single || hipMemsetAsync(d_or.p, 0, 8, w) != hipSuccess) return SRLA_APIRESULT_NG;
+            if (srla_launch_or_reduce(w, st.d_in, st.d_stride, st.num_samples, nch, d_or.as<uint32_t>()) != 0) return SRLA_APIRESULT_NG;
+            if (hipMemcpyAsync(h_or.p, d_or.p, 8, hipMemcpyDeviceToHost, w) != hipSuccess) return SRLA_APIRESULT_NG;
+            if (hipEventRecord(ev_or, w) != hipSuccess) return SRLA_APIRESULT_NG;
+            st.lshift_on_device = true;
+        } else if (st.cb != nullptr || no_speculation) {
+            /* delivered blocks cannot be taken back: the OR pass runs first */
+            const uint32_t chunk = 1u << 20, per_ch = (st.num_samples + chunk - 1) / chunk;
+            std::atomic<uint32_t> acc{ 0 };
+            pool->parallel_for(per_ch * nch, [&](uint32_t i) {
+                const uint32_t ch = i / per_ch, o = (i % per_ch) * chunk, len = std::min(chunk, st.num_samples - o);
+                acc.fetch_or(or_reduce(st.host_in[ch] + o, len), std::memory_order_relaxed);
+            });
+            st.lshift = shift_of(acc.load());
+            st.lshift_final = true;
+        }
+        /* the history-dependent last window goes through chain mode (host_chain.cpp) once everything before it is out: an
+         * odd-length one (lpc.c:260-264), or -- LTP on -- one whose last block is shorter than the 263 lags (lpc.c:371-373;
+         * with a minimum block above 256 samples only the window's last block can be that short) */
+        uint32_t chain_n = 0;
+        const uint32_t tn = st.num_samples % window_len;
+        if ((tn & 1u) && (grid & 1u) == 0 && (window_len % grid) == 0 && !no_chain) chain_n = tn;
+        if (tn > 0 && par.ltp_order > 0 && grid > 256u && (window_len % grid) == 0 && ((tn - 1u) % grid) + 1u <= 256u && !no_chain) chain_n = tn;
+        st.chain_n = chain_n;
+        st.body = st.num_samples - chain_n;
+    }
+    std::vector<JobPlan> plan;
+    plan_jobs(plan, search);
+    const uint32_t njobs = (uint32_t)plan.size();
+    overrides.clear();
+    if (timeline) tl_printf("[timeline] %u stream(s), %u jobs; host %.3f ms into the call\n", nst, njobs, ms_since(t0));
+
+    auto fail = [&](SRLAApiResult rc) {
+        drain();
         for (auto &sl : slot) sl.busy = false;
-        lshift_on_device = false;
-        spec_or_active = false;
+        chain.active = false;
         return rc;
     };
     auto job_slot = [&](uint32_t k) -> Slot & { return slot[plan[k].slot]; };
     auto begin = [&](uint32_t k) -> bool {
         Slot &s = job_slot(k);
-        const uint32_t s0 = plan[k].s0, ns = plan[k].ns;
-        build_job(s.job, s0, ns, search);
-        s.out_direct = out_direct; s.out_first = (k == 0); s.out_init_pos = init_pos; s.out_limit = data_size;
+        if (!stage_input(s, plan[k])) return false;
+        std::vector<uint32_t> lsh;
+        settle_lshift(plan[k], lsh);
+        build_job(s.job, plan[k], lsh, search);
+        if (apply_overrides(s.job, k)) { s.job.uploaded = false; s.job.key = 0; }
+        s.own_stream = nullptr; s.emits = true; s.merge_cb = false;
         s.timed = timing && (k % timing_stride == 0);
         s.out_boost = (k + tail_boost_jobs >= njobs) ? tail_boost : 1u;
-        return prepare_job(s, d_in ? d_in + s0 : nullptr, d_stride, host_in, false);
+        return prepare_job(s, false);
     };
-    /* Software pipeline over jobs: iteration t enqueues  autocorr + solve of job t,  residual_cost +
-     * pricing of job t-1,  block assembly of job t-2,  then collects job t-3.  Needs 4 buffer sets. */
-    const uint32_t depth = 3;
-    uint32_t header_done = with_header ? 0 : 1;
-    auto write_header = [&]() -> bool {
-        if (header_done) return true;
-        if (lshift_on_device) {
-            if (hipEventSynchronize(ev_or) != hipSuccess) return false;
-            offset_lshift = h_or.as<uint32_t>()[1];
-        }
-        if (out_in_hbm) {
-            uint8_t hdr[SRLA_HEADER_SIZE];
-            srla::write_stream_header(stream_info(num_samples), hdr);
-            if (hipMemcpy(data, hdr, SRLA_HEADER_SIZE, hipMemcpyHostToDevice) != hipSuccess) return false;
-        } else {
-            srla::write_stream_header(stream_info(num_samples), data);
-        }
-        header_done = 1;
-        return true;
-    };
+    /* chain mode of the (single) stream, overlapped with the regular jobs */
+    chain.active = single && sx[0].chain_n != 0;
+    chain.begun = false; chain.early = false; chain.ad_done = false;
     uint32_t chain_seed_off = 0, chain_seed_n = 0;
     if (chain.active) {
+        StreamCtx &st = sx[0];
+        chain.stream = 0; chain.tail_start = st.body; chain.tail_n = st.chain_n; chain.search = search;
         /* The window's search does not depend on the jobs before it, except through the last block encoded before
          * the window when the window's first history-dependent call can reach back that far: a window of a single
          * candidate (search), or any window when every block is a window of its own.  Without searching that
          * block is known now; otherwise it is read from the last regular job once that has been priced (below). */
-        const uint32_t nodes = search ? (chain_n + par.min_num_samples_per_block - 1) / par.min_num_samples_per_block + 1 : 2u;
-        if (body == 0 || (search && nodes >= 3)) chain.early = true;
-        else if (!search) { chain.early = true; chain_seed_off = body - par.max_num_samples_per_block; chain_seed_n = par.max_num_samples_per_block; }
+        const uint32_t nodes = search ? (st.chain_n + par.min_num_samples_per_block - 1) / par.min_num_samples_per_block + 1 : 2u;
+        if (st.body == 0 || (search && nodes >= 3)) chain.early = true;
+        else if (!search) { chain.early = true; chain_seed_off = st.body - par.max_num_samples_per_block; chain_seed_n = par.max_num_samples_per_block; }
     }
     static const bool chain_trace = getenv("SRLA_MI355X_CHAIN_TRACE") != nullptr;
-    for (uint32_t t = 0; t < njobs + depth; t++) {
+    /* the chain-mode window of stream `i`, synchronously: seed from the priced job in `ls` (segment k), or none */
+    auto chain_sync = [&](uint32_t i, Slot *ls, size_t k) -> SRLAApiResult {
+        StreamCtx &st = sx[i];
+        chain.active = true; chain.begun = false; chain.early = false; chain.ad_done = false;
+        chain.stream = i; chain.tail_start = st.body; chain.tail_n = st.chain_n; chain.search = search;
+        uint32_t seed_off = 0, seed_n = 0;
+        const uint32_t nodes = search ? (st.chain_n + par.min_num_samples_per_block - 1) / par.min_num_samples_per_block + 1 : 2u;
+        if (st.body == 0 || (search && nodes >= 3)) { /* nothing before the window matters */ }
+        else if (!search) { seed_off = st.body - par.max_num_samples_per_block; seed_n = par.max_num_samples_per_block; }
+        else if (ls == nullptr || !last_block_of(*ls, k, &seed_off, &seed_n)) return SRLA_APIRESULT_NG;
+        if (!chain_begin(seed_off, seed_n) || !chain_encode_ad() || !chain_encode_e()) return SRLA_APIRESULT_NG;
+        const SRLAApiResult rc = chain_collect();
+        chain.active = false;
+        return rc;
+    };
+
+    /* Software pipeline over jobs: iteration t enqueues  autocorr + solve of job t,  residual_cost +
+     * pricing of job t-1,  block assembly of job t-2,  then collects job t-3.  Needs 4 buffer sets.
+     * `base`: the jobs before it are complete; a job whose near-ties the host libm decides differently from the device
+     * (arbitrate) sends the loop back to it. */
+    const uint32_t depth = 3;
+    uint32_t base = 0, restarts = 0;
+    for (uint32_t t = 0; t < njobs + depth;) {
         const auto t_enq = Clock::now();
-        if (t < njobs) {
+        if (t < njobs && t >= base) {
             if (!begin(t) || !run_stage(job_slot(t), ST_A) || !run_stage(job_slot(t), ST_B)) return fail(SRLA_APIRESULT_NG);
         }
-        if (t >= 1 && t - 1 < njobs) {
+        if (t >= 1 && t - 1 < njobs && t - 1 >= base) {
             Slot &s = job_slot(t - 1);
             if (!run_stage(s, ST_C) || !run_stage(s, ST_D)) return fail(SRLA_APIRESULT_NG);
         }
-        if (t >= 2 && t - 2 < njobs) {
+        if (t >= 2 && t - 2 < njobs && t - 2 >= base) {
             Slot &s = job_slot(t - 2);
             if (!run_stage(s, ST_E)) return fail(SRLA_APIRESULT_NG);
         }
-        /* the host prepares the chain jobs while the device works on the first regular job */
-        if (chain.early && !chain.begun) {
-            const auto tc = Clock::now();
-            if (!chain_begin(chain_seed_off, chain_seed_n)) return fail(SRLA_APIRESULT_NG);
-            if (chain_trace) fprintf(stderr, "[chain] begin %.3f ms (%zu calls)\n", ms_since(tc), chain_calls.size());
+        if (single && chain.active && chain.early) {
+            /* the host prepares the chain jobs while the device works on the first regular job */
+            if (!chain.begun) {
+                const auto tc = Clock::now();
+                if (!chain_begin(chain_seed_off, chain_seed_n)) return fail(SRLA_APIRESULT_NG);
+                if (chain_trace) fprintf(stderr, "[chain] begin %.3f ms (%zu calls)\n", ms_since(tc), chain_calls.size());
+            }
+            if (!chain.ad_done && (t == njobs || chain_search_done())) {
+                const auto tc = Clock::now();
+                if (!chain_encode_ad()) return fail(SRLA_APIRESULT_NG);
+                if (chain_trace) fprintf(stderr, "[chain] encode_ad %.3f ms (%zu calls)\n", ms_since(tc), chain_calls.size());
+            }
+            if (t == njobs + 1 && !chain_encode_e()) return fail(SRLA_APIRESULT_NG);
         }
-        if (chain.early && !chain.ad_done && (t == njobs || chain_search_done())) {
-            const auto tc = Clock::now();
-            if (!chain_encode_ad(out_direct, init_pos, data_size, njobs == 0)) return fail(SRLA_APIRESULT_NG);
-            if (chain_trace) fprintf(stderr, "[chain] encode_ad %.3f ms (%zu calls)\n", ms_since(tc), chain_calls.size());
-        }
-        if (chain.early && t == njobs + 1 && !chain_encode_e()) return fail(SRLA_APIRESULT_NG);
-        stats.h2d_ms += ms_since(t_enq);       /* host time spent enqueueing (no H2D of samples on this path) */
+        stats.h2d_ms += ms_since(t_enq);       /* host time spent staging and enqueueing */
         if (timeline) tl_printf("[timeline] host: iteration %u enqueued at %.3f ms\n", t, ms_since(t0));
-        if (t < depth) continue;
+        if (t < depth || t - depth < base) { t++; continue; }
         const uint32_t k = t - depth;
         Slot &s = job_slot(k);
         if (!wait_job(s)) return fail(SRLA_APIRESULT_NG);
-        if (!write_header()) return fail(SRLA_APIRESULT_NG);
-        if (timeline) {
-            float a = 0;
-            if (lshift_on_device && k == 0 && hipEventElapsedTime(&a, ev_ref, ev_or) == hipSuccess) tl_printf("[timeline] offset-shift reduction done at %.3f\n", a);
-            tl_printf("[timeline] host: job %u collected at %.3f ms\n", k, ms_since(t0));
+        if (timeline) tl_printf("[timeline] host: job %u collected at %.3f ms\n", k, ms_since(t0));
+        if (s.h_info.as<SrlaJobInfo>()->num_tie_items != 0) {
+            const int m = arbitrate(s, k);
+            if (m < 0) return fail(SRLA_APIRESULT_NG);
+            if (m > 0) {
+                /* the host libm decided otherwise: everything from this job on is enqueued again (the jobs in flight behind it
+                 * were placed behind its bytes) */
+                if (++restarts > 16) { fprintf(stderr, "[srla-mi355x] internal error: near-tie arbitration did not settle\n"); return fail(SRLA_APIRESULT_NG); }
+                drain();
+                for (StreamCtx &st : sx) st.pass_started = false;
+                stats.num_restarts++;
+                base = k; t = k;
+                continue;
+            }
         }
-        uint32_t wrote = 0;
-        const uint32_t *window_bytes = nullptr;
-        const SRLAApiResult rc = finish_job(s, data, write_off, &wrote, &window_bytes);
-        if (rc != SRLA_APIRESULT_OK) return fail(rc);
-        /* callbacks: once per window, in order, pointing into the caller's buffer
-         * (srla_encoder.c:1779-1782) */
-        uint32_t off = write_off;
-        for (size_t w = 0; w < s.job.windows.size(); w++) {
-            progress += s.job.windows[w].n;
-            if (cb) cb(num_samples, progress, data + off, window_bytes[w]);
-            off += window_bytes[w];
+        const SRLAApiResult rc = finish_job(s);
+        if (rc != SRLA_APIRESULT_OK && (single || rc != SRLA_APIRESULT_INSUFFICIENT_BUFFER)) {
+            if (rc == SRLA_APIRESULT_INSUFFICIENT_BUFFER && sx[0].lshift_spec) { drain(); break; }   /* perhaps only because the shift was guessed wrong: see below */
+            return fail(rc);
         }
-        write_off += wrote;
+        if (!single) {
+            /* streams whose regular windows end in this job and that have a chain-mode window */
+            for (size_t g = 0; g < s.job.segs.size(); g++) {
+                const SegPlan &sp = s.job.segs[g];
+                StreamCtx &st = sx[sp.stream];
+                if (st.chain_n == 0 || sp.s0 + sp.ns != st.body || st.rc != SRLA_APIRESULT_OK) continue;
+                const SRLAApiResult crc = chain_sync(sp.stream, &s, g);
+                if (crc != SRLA_APIRESULT_OK && crc != SRLA_APIRESULT_INSUFFICIENT_BUFFER) return fail(crc);
+            }
+        }
+        t++;
     }
-    if (chain.active) {
-        if (!write_header()) return fail(SRLA_APIRESULT_NG);
+    if (single && chain.active && sx[0].rc == SRLA_APIRESULT_OK) {
         if (!chain.early) {
             /* the last block encoded before the window: its final call is what the window's only candidate inherits from */
             uint32_t seed_off = 0, seed_n = 0;
             Slot &ls = job_slot(njobs - 1);
-            const SrlaWindowDesc &wd = ls.job.windows.back();
-            std::vector<SrlaBlockRecord> recs(wd.num_nodes - 1);
-            if (hipMemcpy(recs.data(), ls.d_blocks.as<SrlaBlockRecord>() + wd.block_base, recs.size() * sizeof(SrlaBlockRecord), hipMemcpyDeviceToHost) != hipSuccess)
-                return fail(SRLA_APIRESULT_NG);
-            for (const SrlaBlockRecord &r : recs) if (r.valid) { seed_off = ls.job.s0 + r.sample_off; seed_n = r.n; }
-            if (!chain_begin(seed_off, seed_n) || !chain_encode_ad(out_direct, init_pos, data_size, false) || !chain_encode_e())
-                return fail(SRLA_APIRESULT_NG);
+            if (!last_block_of(ls, ls.job.segs.size() - 1, &seed_off, &seed_n)) return fail(SRLA_APIRESULT_NG);
+            if (!chain_begin(seed_off, seed_n) || !chain_encode_ad() || !chain_encode_e()) return fail(SRLA_APIRESULT_NG);
         }
-        Slot &e = slot[kChainSlot + 2];
-        const auto tc = Clock::now();
-        if (!wait_job(e)) return fail(SRLA_APIRESULT_NG);
-        if (chain_trace) fprintf(stderr, "[chain] waited %.3f ms for the encode job\n", ms_since(tc));
-        uint32_t wrote = 0;
-        const uint32_t *window_bytes = nullptr;
-        const SRLAApiResult rc = finish_job(e, data, write_off, &wrote, &window_bytes);
-        if (rc != SRLA_APIRESULT_OK) return fail(rc);
-        progress += chain_n;
-        if (cb) cb(num_samples, progress, data + write_off, wrote);
-        write_off += wrote;
-        chain.active = false;
+        const SRLAApiResult rc = chain_collect();
+        if (rc != SRLA_APIRESULT_OK && !(rc == SRLA_APIRESULT_INSUFFICIENT_BUFFER && sx[0].lshift_spec)) return fail(rc);
     }
-    lshift_on_device = false;
-    if (spec_or_active) {
-        spec_or_active = false;
-        const uint32_t m = spec_or.load();
-        uint32_t sh = 0;
-        if (m != 0) while (((m >> sh) & 1u) == 0) sh++;
-        if (sh != offset_lshift) {
-            /* the guess was wrong: encode again with the shift that the whole stream has */
-            forced_lshift = (int)sh;
-            const SRLAApiResult rc = encode_stream(host_in, d_in, d_stride, num_samples, data, data_size, output_size, cb, with_header, search);
-            forced_lshift = -1;
-            return rc;
+    chain.active = false;
+    if (!single) {
+        for (uint32_t i = 0; i < nst; i++)
+            if (sx[i].chain_n != 0 && sx[i].body == 0 && sx[i].rc == SRLA_APIRESULT_OK) {
+                const SRLAApiResult crc = chain_sync(i, nullptr, 0);
+                if (crc != SRLA_APIRESULT_OK && crc != SRLA_APIRESULT_INSUFFICIENT_BUFFER) return fail(crc);
+            }
+    }
+    /* headers; speculated offset shifts: finish the OR of the stream and, in the rare case that the shift the stream was
+     * encoded with is not the one the whole stream has, encode it again */
+    SRLAApiResult worst = SRLA_APIRESULT_OK;
+    for (uint32_t i = 0; i < nst; i++) {
+        StreamCtx &st = sx[i];
+        if (st.with_header && st.lshift_spec && !st.lshift_final) {
+            if (st.or_covered < st.num_samples) {
+                const uint32_t o0 = st.or_covered, len = st.num_samples - o0;
+                const uint32_t chunk = 1u << 20, per_ch = (len + chunk - 1) / chunk;
+                std::atomic<uint32_t> acc{ 0 };
+                pool->parallel_for(per_ch * nch, [&](uint32_t q) {
+                    const uint32_t ch = q / per_ch, o = (q % per_ch) * chunk;
+                    acc.fetch_or(or_reduce(st.host_in[ch] + o0 + o, std::min(chunk, len - o)), std::memory_order_relaxed);
+                });
+                st.or_mask |= acc.load();
+                st.or_covered = st.num_samples;
+            }
+            const uint32_t true_shift = shift_of(st.or_mask);
+            st.lshift_final = true;
+            if (true_shift != st.lshift) {
+                drain();
+                std::vector<StreamCtx> saved;
+                saved.swap(sx);
+                StreamCtx again = saved[i];
+                again.lshift = true_shift; again.lshift_final = true;
+                sx.push_back(again);
+                (void)encode_streams(search);
+                StreamCtx result = sx[0];
+                sx.swap(saved);
+                sx[i] = result;
+                if (sx[i].rc != SRLA_APIRESULT_OK) worst = sx[i].rc;
+                continue;               /* the nested call wrote the header */
+            }
         }
+        if (st.rc != SRLA_APIRESULT_OK) { worst = st.rc; continue; }
+        if (!write_header(st)) return fail(SRLA_APIRESULT_NG);
     }
-    *output_size = write_off;
+    if (single && sx[0].with_header && sx[0].rc == SRLA_APIRESULT_OK) offset_lshift = sx[0].lshift;   /* encoder->header of the reference */
     stats.total_ms += ms_since(t0);
     if (timeline) { tl_printf("[timeline] call returned at %.3f ms\n", ms_since(t0)); fputs(tl_log.c_str(), stderr); tl_log.clear(); }
-    return SRLA_APIRESULT_OK;
+    return worst;
 }
-

@@ -70,54 +70,78 @@ SrlaLdsPlan Impl::lds_plan(uint32_t nfft) const
     return p;
 }
 
-void Impl::build_job(Job &job, uint32_t s0, uint32_t ns, bool search, const std::vector<uint32_t> *lens)
+static uint64_t fnv64(uint64_t h, uint64_t v)
+{
+    for (int i = 0; i < 8; i++) { h ^= (v >> (8 * i)) & 0xFFu; h *= 1099511628211ull; }
+    return h;
+}
+
+/* Tables of SearchOptimalBlockPartitions (srla_encoder.c:336-389) for the windows of the plan's segments; all offsets are
+ * relative to the job's input planes, so jobs of equal shape share them (key). */
+void Impl::build_job(Job &job, const JobPlan &plan, const std::vector<uint32_t> &lshift, bool search, const std::vector<uint32_t> *lens)
 {
     const uint32_t minb = par.min_num_samples_per_block, maxb = par.max_num_samples_per_block;
     const uint32_t window_len = search ? par.num_lookahead_samples : maxb;
     const uint32_t nv = num_variants(), pmax = preset_order();
-    /* all tables are relative to the job's first sample, so jobs of equal length share them */
-    const uint64_t key = lens ? 1ull : (((uint64_t)ns << 24) ^ ((uint64_t)param_generation << 1) ^ (search ? 1u : 0u) ^ 0x8000000000000000ull);
-    job.s0 = s0;
-    if (!lens && job.key == key && job.ns == ns) return;
+    uint64_t key = 1469598103934665603ull;
+    key = fnv64(key, ((uint64_t)param_generation << 1) | (search ? 1u : 0u));
+    key = fnv64(key, plan.total);
+    for (size_t k = 0; k < plan.segs.size(); k++) {
+        key = fnv64(key, ((uint64_t)plan.segs[k].ns << 32) | plan.segs[k].base);
+        key = fnv64(key, lshift[k]);
+    }
+    if (lens) key = 0;                 /* chain-mode jobs are never reused */
+    if (!lens && job.key == key && key != 0 && job.segs.size() == plan.segs.size()) {
+        /* same shape: only the identity of the segments' streams may differ */
+        for (size_t k = 0; k < plan.segs.size(); k++) { job.segs[k].stream = plan.segs[k].stream; job.segs[k].s0 = plan.segs[k].s0; }
+        return;
+    }
     if (lens) search = false;
     job.key = key; job.uploaded = false;
-    job.ns = ns;
+    job.segs = plan.segs; job.seg_lshift = lshift; job.total = plan.total;
     job.windows.clear(); job.cands.clear(); job.items.clear(); job.groups.clear(); job.class_index.clear();
+    job.seg_first_window.clear();
     job.num_slots = 0; job.res_elems = 0; job.analyzed_samples = 0;
 
-    struct Pending { uint32_t cand; uint32_t nfft; };
+    struct Pending { uint32_t cand; uint32_t nfft; uint32_t seg; };
     std::vector<Pending> analysed;
-    for (uint32_t pos = 0, wi = 0; pos < ns; wi++) {
-        const uint32_t wn = lens ? (*lens)[wi] : std::min(window_len, ns - pos);
-        SrlaWindowDesc wd{};
-        wd.sample_off = pos; wd.n = wn;
-        wd.cand_base = (uint32_t)job.cands.size();
-        wd.num_nodes = search ? ((wn + minb - 1) / minb + 1) : 2;
-        wd.block_base = job.num_slots;
-        job.num_slots += wd.num_nodes - 1;
-        const uint32_t w = (uint32_t)job.windows.size();
-        auto add_cand = [&](uint32_t i, uint32_t j, uint32_t off, uint32_t n) {
-            SrlaCandDesc cd{};
-            cd.window = w; cd.node_i = i; cd.node_j = j; cd.sample_off = pos + off; cd.n = n;
-            cd.item_base = 0xFFFFFFFFu;
-            if (n > pmax) analysed.push_back({ (uint32_t)job.cands.size(), geoms[geom_for(n)].nfft });
-            job.cands.push_back(cd);
-        };
-        if (!search) add_cand(0, 1, 0, wn);
-        else {
-            for (uint32_t i = 0; i < wd.num_nodes; i++)
-                for (uint32_t j = i + 1; j < wd.num_nodes; j++) {
-                    uint32_t len = (j - i) * minb;
-                    if (len > maxb) continue;
-                    const uint32_t off = i * minb;
-                    len = std::min(len, wn - off);
-                    add_cand(i, j, off, len);
-                }
+    for (uint32_t sg = 0; sg < plan.segs.size(); sg++) {
+        const SegPlan &sp = plan.segs[sg];
+        job.seg_first_window.push_back((uint32_t)job.windows.size());
+        for (uint32_t pos = 0, wi = 0; pos < sp.ns; wi++) {
+            const uint32_t wn = lens ? (*lens)[wi] : std::min(window_len, sp.ns - pos);
+            SrlaWindowDesc wd{};
+            wd.sample_off = sp.base + pos; wd.n = wn;
+            wd.cand_base = (uint32_t)job.cands.size();
+            wd.num_nodes = search ? ((wn + minb - 1) / minb + 1) : 2;
+            wd.block_base = job.num_slots;
+            wd.seg = sg;
+            job.num_slots += wd.num_nodes - 1;
+            const uint32_t w = (uint32_t)job.windows.size();
+            auto add_cand = [&](uint32_t i, uint32_t j, uint32_t off, uint32_t n) {
+                SrlaCandDesc cd{};
+                cd.window = w; cd.node_i = i; cd.node_j = j; cd.sample_off = sp.base + pos + off; cd.n = n;
+                cd.item_base = 0xFFFFFFFFu;
+                if (n > pmax) analysed.push_back({ (uint32_t)job.cands.size(), geoms[geom_for(n)].nfft, sg });
+                job.cands.push_back(cd);
+            };
+            if (!search) add_cand(0, 1, 0, wn);
+            else {
+                for (uint32_t i = 0; i < wd.num_nodes; i++)
+                    for (uint32_t j = i + 1; j < wd.num_nodes; j++) {
+                        uint32_t len = (j - i) * minb;
+                        if (len > maxb) continue;
+                        const uint32_t off = i * minb;
+                        len = std::min(len, wn - off);
+                        add_cand(i, j, off, len);
+                    }
+            }
+            wd.num_cands = (uint32_t)job.cands.size() - wd.cand_base;
+            job.windows.push_back(wd);
+            pos += wn;
         }
-        wd.num_cands = (uint32_t)job.cands.size() - wd.cand_base;
-        job.windows.push_back(wd);
-        pos += wn;
     }
+    job.seg_first_window.push_back((uint32_t)job.windows.size());
     /* one launch analyses every item of the job: the LDS plan and the FFT register class are
      * those of the largest FFT present (smaller items simply leave part of them idle) */
     uint32_t max_nfft = 0;
@@ -128,15 +152,20 @@ void Impl::build_job(Job &job, uint32_t s0, uint32_t ns, bool search, const std:
         g.first = 0;
         g.rclass = (int)std::max(1u, g.nfft / 2048u);
         g.plan = lds_plan(g.nfft);
+        job.items.reserve(analysed.size() * nv);
         for (const Pending &p : analysed) {
             SrlaCandDesc &cd = job.cands[p.cand];
             cd.item_base = (uint32_t)job.items.size();
+            const uint32_t gi = geom_for(cd.n);
             for (uint32_t v = 0; v < nv; v++) {
                 SrlaItemDesc it{};
                 it.sample_off = cd.sample_off; it.n = cd.n; it.variant = v;
-                it.geom = geom_for(cd.n);
+                it.geom = gi;
                 it.res_off = job.res_elems;
                 it.forced_order = -1;
+                it.lshift = lshift[p.seg];
+                it.forced_ltp = 0;
+                it.seg = p.seg;
                 job.res_elems += (cd.n + 3u) & ~3u;
                 job.analyzed_samples += cd.n;
                 job.items.push_back(it);
@@ -146,17 +175,19 @@ void Impl::build_job(Job &job, uint32_t s0, uint32_t ns, bool search, const std:
         job.groups.push_back(g);
     }
     job.class_index.clear();
+    job.class_index.reserve(job.items.size());
     for (int c = 0; c < 4; c++) {
         job.class_first[c] = (uint32_t)job.class_index.size();
         for (uint32_t i = 0; i < job.items.size(); i++) {
-            const uint32_t nfft = geoms[job.items[i].geom].nfft;
+            const SrlaItemDesc &it = job.items[i];
+            const SrlaGeom &gm = geoms[it.geom];
+            const uint32_t nfft = gm.nfft;
             const int cls = (nfft <= 1024u) ? 0 : ((nfft <= 2048u) ? 1 : ((nfft <= 4096u) ? 2 : 3));
             if (cls == c) {
-                const SrlaItemDesc &it = job.items[i];
-                const SrlaGeom &gm = geoms[it.geom];
                 SrlaAutocorrItem ai{};
                 ai.item = i; ai.sample_off = it.sample_off; ai.n = it.n; ai.variant = it.variant;
                 ai.nfft = gm.nfft; ai.tw_off = gm.tw_off; ai.welch_divisor = gm.welch_divisor; ai.acorr_norm = gm.acorr_norm;
+                ai.lshift = it.lshift;
                 job.class_index.push_back(ai);
             }
         }
@@ -164,16 +195,16 @@ void Impl::build_job(Job &job, uint32_t s0, uint32_t ns, bool search, const std:
     }
 }
 
-SrlaJobParams Impl::job_params(const Job &job, uint32_t channel_stride) const
+SrlaJobParams Impl::job_params(const Job &job, uint32_t channel_stride, bool lshift_on_device) const
 {
     SrlaJobParams jp{};
     jp.num_channels = par.num_channels;
     jp.bits_per_sample = par.bits_per_sample;
-    jp.offset_lshift = offset_lshift;
+    jp.num_segs = (uint32_t)job.segs.size();
     jp.max_order = preset_order();
     jp.order_fixed = (par.preset == 0) ? 1u : 0u;
     jp.ltp_order = par.ltp_order;
-    jp.num_samples = job.ns;
+    jp.num_samples = job.total;
     jp.channel_stride = channel_stride;
     jp.max_block = par.max_num_samples_per_block;
     jp.min_block = par.min_num_samples_per_block;
@@ -184,9 +215,11 @@ SrlaJobParams Impl::job_params(const Job &job, uint32_t channel_stride) const
     { static const char *e = getenv("SRLA_MI355X_K3_STOP"); jp.out_stride = e ? (uint32_t)atoi(e) : 0u; }   /* kernel timing experiments only */
 #endif
     jp.lshift_dev = lshift_on_device ? (d_or.as<uint32_t>() + 1) : nullptr;
+    jp.tie_rel = tie_rel; jp.tie_ltp = tie_ltp; jp.tie_logscale = tie_logscale; jp.tie_powscale = tie_powscale;
     return jp;
 }
 
+/* windows per job: bounded by scratch memory (~1.5 GB of residual scratch per slot) */
 uint32_t Impl::windows_per_job(bool search) const
 {
     const uint32_t window_len = search ? par.num_lookahead_samples : par.max_num_samples_per_block;
@@ -199,4 +232,58 @@ uint32_t Impl::windows_per_job(bool search) const
     const uint64_t cap_samples = job_samples;  /* several jobs per stream so that the GPU and the host pack overlap */
     w = std::min<uint64_t>(w, std::max<uint64_t>(1, cap_samples / window_len));
     return (uint32_t)std::max<uint64_t>(1, w);
+}
+
+/* The jobs of a call.  One stream: full jobs rotate through the kSlots buffer sets; what is left at the end of the stream
+ * is cut once more so that the LAST job is small -- after it nothing else runs on the wide stream, so its pricing, block
+ * assembly and stream-out are pure latency (0.27 ms for a full job, 8 % of a 600 s stream's time); the two tail jobs have
+ * buffer sets of their own, so that repeated calls of equal length keep finding their descriptor tables cached.
+ * Several streams: jobs are filled greedily in stream order, a stream is cut at a window boundary when the job is full,
+ * segments start on multiples of 16 samples of the job's planes (aligned 16-byte loads, 32-byte aligned staging stores). */
+void Impl::plan_jobs(std::vector<JobPlan> &plan, bool search)
+{
+    plan.clear();
+    const uint32_t window_len = search ? par.num_lookahead_samples : par.max_num_samples_per_block;
+    const uint64_t job_len = (uint64_t)windows_per_job(search) * window_len;
+    auto al16 = [](uint64_t v) { return (uint32_t)((v + 15u) & ~(uint64_t)15u); };
+    if (sx.size() == 1) {
+        const uint32_t body = sx[0].body;
+        uint64_t nfull = body / job_len, rest = body - nfull * job_len;
+        if (rest == 0 && nfull > 0) { nfull--; rest = job_len; }
+        auto one = [&](uint32_t s0, uint32_t ns, uint32_t slot_index) {
+            JobPlan jp; jp.segs.push_back({ 0u, s0, ns, 0u }); jp.total = al16(ns); jp.slot = slot_index; plan.push_back(jp);
+        };
+        for (uint64_t k = 0; k < nfull; k++) one((uint32_t)(k * job_len), (uint32_t)job_len, (uint32_t)(k % kSlots));
+        const uint64_t small = (uint64_t)std::max<uint32_t>(1u, 262144u / window_len) * window_len;
+        const uint32_t tail0 = (uint32_t)(nfull * job_len);
+        if (nfull > 0 && rest > 2 * small) {
+            const uint32_t first = (uint32_t)(((rest - small) / window_len) * window_len);
+            one(tail0, first, kSlots);
+            one(tail0 + first, (uint32_t)(rest - first), kSlots + 1);
+        } else if (rest > 0) {
+            one(tail0, (uint32_t)rest, nfull > 0 ? kSlots : 0u);
+        }
+        return;
+    }
+    JobPlan cur;
+    auto close = [&]() {
+        if (cur.segs.empty()) return;
+        cur.slot = (uint32_t)(plan.size() % kSlots);
+        plan.push_back(cur);
+        cur = JobPlan();
+    };
+    for (uint32_t i = 0; i < sx.size(); i++) {
+        uint32_t s0 = 0, remaining = sx[i].body;
+        while (remaining > 0) {
+            const uint64_t room = (job_len > cur.total) ? job_len - cur.total : 0;
+            uint32_t take = remaining;
+            if (take > room) take = (uint32_t)((room / window_len) * window_len);
+            if (take == 0) { close(); continue; }
+            cur.segs.push_back({ i, s0, take, cur.total });
+            cur.total = al16((uint64_t)cur.total + take);
+            s0 += take; remaining -= take;
+            if (cur.total >= job_len) close();
+        }
+    }
+    close();
 }

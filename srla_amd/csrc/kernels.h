@@ -38,12 +38,14 @@ int srla_launch_autocorr(hipStream_t stream, int rclass, const SrlaJobParams *jp
                          const uint32_t *chain_tab /* gather table of chain_lags */);
 /* int16 planes (stride16 elements apart) -> int32 planes (n apart): host input of at most 16 bits per sample */
 int srla_launch_widen16(hipStream_t stream, const int16_t *src, size_t stride16, int32_t *dst, uint32_t n, uint32_t num_channels);
-int srla_launch_pitch_solve(hipStream_t stream, const SrlaJobParams *jp, const double *lags_ws, SrlaItemResult *results,
-                            hipEvent_t ev_start, hipEvent_t ev_stop,
-                            const uint32_t *select /* null: every item; else only items with select[item] == round */, uint32_t round);
+/* ties / tie_data: the job's near-tie list (device_layout.h: SrlaJobParams::tie_rel), may be null */
+int srla_launch_pitch_solve(hipStream_t stream, const SrlaJobParams *jp, const SrlaItemDesc *items, const double *lags_ws,
+                            SrlaItemResult *results, hipEvent_t ev_start, hipEvent_t ev_stop,
+                            const uint32_t *select /* null: every item; else only items with select[item] == round */, uint32_t round,
+                            uint32_t *ties, double *tie_data);
 int srla_launch_lpc_solve(hipStream_t stream, const SrlaJobParams *jp, const SrlaItemDesc *items,
                           const SrlaGeom *geoms, const double *lags_ws, double *err_ws, const uint8_t *huff_len,
-                          SrlaItemResult *results, double *dbg, hipEvent_t ev_start, hipEvent_t ev_stop);
+                          SrlaItemResult *results, double *dbg, uint32_t *ties, hipEvent_t ev_start, hipEvent_t ev_stop);
 int srla_launch_residual_cost(hipStream_t stream, int rclass, const SrlaJobParams *jp, const int32_t *input,
                               const SrlaItemDesc *items, const SrlaGeom *geoms, const SrlaLdsPlan *plan,
                               const double *rice_thresholds, int32_t *res_ws, SrlaItemResult *results,
@@ -54,22 +56,25 @@ int srla_launch_price(hipStream_t stream, const SrlaJobParams *jp, const SrlaWin
                       hipEvent_t ev_start, hipEvent_t ev_stop);
 
 /* srla_block_offsets + srla_pack_blocks + srla_stream_out: the job's blocks, complete, assembled in the device
- * buffer `stage` and then moved to their byte offsets of the stream in host memory `dst`.
- *   stream_pos  device u32[2], running output offset + sticky overflow flag, carried from job to job
- *   first/init_pos  the first job of a stream starts the running offset at init_pos
- *   absolute    1: `dst` is the caller's (device-visible) stream buffer and blocks land at running offset + prefix;
- *               0: `dst` is a per-job pinned staging buffer and blocks land at their prefix inside the job
- *   limit       size of the caller's buffer: a job that would exceed it writes nothing and reports OVERFLOW
- *   info / window_bytes  job summary and per-window sizes (device-visible pinned host memory)
+ * buffer `stage` and then moved, segment by segment (device_layout.h: SrlaSegDesc), to their byte offsets of their
+ * streams' output buffers.
+ *   stream_pos  device u32[2] per stream: running output offset + sticky skip flag, carried from job to job
+ *   segs        the job's segments (device copy); seg_ctl: device scratch, 8 words per segment
+ *   host_stage  pinned staging buffer of the job, for segments whose stream has no device-visible output buffer (dst = 0):
+ *               they land there at their stage_off and the host copies them out
+ *   info / window_bytes / seg_info  job summary, per-window and per-segment results (device-visible pinned host memory)
+ *   ties        the job's near-tie list (its count goes into the summary), may be null
  *   out_boost   > 1: that many times the usual number of stream-out workgroups (the last jobs of a stream, when the
  *               wide kernels are about to run dry and PCIe back-pressure no longer slows anything down)      */
 int srla_launch_pack(hipStream_t stream, const SrlaJobParams *jp, uint32_t num_slots,
                      const int32_t *input, const SrlaItemDesc *items, const SrlaWindowDesc *windows,
                      const SrlaBlockRecord *blocks, const SrlaItemResult *results, const int32_t *res_ws,
                      const uint32_t *huff_code, const uint8_t *huff_len, uint32_t *block_off,
-                     uint32_t *stream_pos, uint32_t *ctl, uint32_t first, uint32_t init_pos, uint32_t absolute,
-                     uint32_t limit, uint8_t *stage, uint8_t *dst, uint8_t *scratch, SrlaJobInfo *info, uint32_t *window_bytes,
+                     uint32_t *stream_pos, const SrlaSegDesc *segs, uint32_t *seg_ctl,
+                     uint8_t *stage, uint8_t *host_stage, uint8_t *scratch, SrlaJobInfo *info,
+                     uint32_t *window_bytes, SrlaSegInfo *seg_info, const uint32_t *ties,
                      hipEvent_t ev_start, hipEvent_t ev_stop, uint32_t out_boost);
+#define SRLA_SEGCTL_WORDS_HOST 8
 uint32_t srla_pack_lds_words(const SrlaJobParams *jp);
 int srla_pack_needs_scratch(const SrlaJobParams *jp);   /* blocks may exceed the LDS staging: allocate the scratch */
 

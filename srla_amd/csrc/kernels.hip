@@ -111,12 +111,12 @@ __device__ __forceinline__ uint32_t xcd_position(uint32_t b, uint32_t count)
 struct InputView {
     uint32_t nch, stride, sh;
 };
-__device__ __forceinline__ InputView input_view(const SrlaJobParams &jp)
+__device__ __forceinline__ InputView input_view(const SrlaJobParams &jp, uint32_t item_lshift)
 {
     InputView v;
     v.nch = jp.num_channels;
     v.stride = jp.channel_stride;
-    v.sh = jp.lshift_dev ? *jp.lshift_dev : jp.offset_lshift;
+    v.sh = jp.lshift_dev ? *jp.lshift_dev : item_lshift;
     return v;
 }
 
@@ -335,13 +335,14 @@ __device__ void autocorr_in_place(cplx *buf, uint32_t nfft, const cplx *__restri
 
 /* ------------------------------------------------------------ order choice (H2: libm) ----- */
 /* srla_encoder.c:873-885 */
-__device__ __forceinline__ double geometric_entropy(double mean_abs, uint32_t bps)
+/* logscale: 1.0 (exact) in production; the tie tests falsify the device's log with it (SrlaJobParams) */
+__device__ __forceinline__ double geometric_entropy(double mean_abs, uint32_t bps, double logscale)
 {
     const double intmean = mean_abs * (double)(1 << (bps - 1));
     const double rho = 1.0 / (1.0 + intmean);
     const double invrho = 1.0 - rho;
     if (mean_abs < 1e-16) return 0.0;
-    return -(invrho * (log(invrho) * 1.4426950408889634) + rho * (log(rho) * 1.4426950408889634)) / rho;
+    return -(invrho * ((log(invrho) * logscale) * 1.4426950408889634) + rho * ((log(rho) * logscale) * 1.4426950408889634)) / rho;
 }
 
 /* correctly rounded x^-0.5 for the 3x3 LTP solve (lpc.c:591 uses pow(sum, -0.5)) */
@@ -378,7 +379,6 @@ __global__ __launch_bounds__(NTK) void srla_autocorr(
 {
     constexpr int CH = 2 * R;   /* chunks of four samples per thread: covers 8 * R * NTK >= nfft */
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    const InputView iv = input_view(jp);
     cplx *buf = (cplx *)lds;
     SmallA *sm = (SmallA *)(lds + fft_bytes);
 
@@ -386,6 +386,7 @@ __global__ __launch_bounds__(NTK) void srla_autocorr(
     const uint32_t pos = xcd_position(blockIdx.x, count);
     if (pos >= count) return;
     const SrlaAutocorrItem it = class_items[pos];                    /* items of one FFT-size class */
+    const InputView iv = input_view(jp, it.lshift);
     const uint32_t item_idx = it.item;
     const struct { uint32_t nfft, tw_off; double welch_divisor, acorr_norm; } g = { it.nfft, it.tw_off, it.welch_divisor, it.acorr_norm };
     const uint32_t n = it.n, nfft = g.nfft, bps = jp.bits_per_sample;
@@ -608,9 +609,21 @@ __global__ __launch_bounds__(NTK) void srla_autocorr(
  * K2p: srla_pitch_solve -- one lane per item (lpc.c:1473-1649, srla_encoder.c:1031-1047)
  * ============================================================================================== */
 #define PITCH_ITEMS 8u
-__global__ __launch_bounds__(WAVE) void srla_pitch_solve(SrlaJobParams jp, const double *__restrict__ lags_ws,
+/* Near-ties (H2): an item whose decision hangs on a libm function the device cannot reproduce bit for bit is appended to
+ * the job's tie list -- ties[0] = count, ties[1 + k] = item | kind << 31 (kind 1: LTP taps) -- and, for LTP items, the
+ * numbers the host needs to redo the 3x3 solve with its own pow() go to tie_data[8 k ..]. */
+__device__ __forceinline__ uint32_t tie_append(uint32_t *__restrict__ ties, uint32_t item, uint32_t kind)
+{
+    const uint32_t k = atomicAdd(&ties[0], 1u);
+    ties[1u + k] = item | (kind << 31);
+    return k;
+}
+
+__global__ __launch_bounds__(WAVE) void srla_pitch_solve(SrlaJobParams jp, const SrlaItemDesc *__restrict__ items,
+                                                         const double *__restrict__ lags_ws,
                                                          SrlaItemResult *__restrict__ results,
-                                                         const uint32_t *__restrict__ select, uint32_t round)
+                                                         const uint32_t *__restrict__ select, uint32_t round,
+                                                         uint32_t *__restrict__ ties, double *__restrict__ tie_data)
 {
     /* The scan below is a chain of data-dependent loads; out of global memory each one costs a full round trip
      * (measured 0.4 ms per job).  The wavefront first copies the lags of its PITCH_ITEMS items into LDS
@@ -669,7 +682,7 @@ __global__ __launch_bounds__(WAVE) void srla_pitch_solve(SrlaJobParams jp, const
             double sum = am[i2][i2];
             for (int k = i2 - 1; k >= 0; k--) sum -= am[i2][k] * am[i2][k];
             if (sum <= 0.0) { ok = false; break; }
-            inv_diag[i2] = inv_sqrt_cr(sum);
+            inv_diag[i2] = inv_sqrt_cr(sum) * jp.tie_powscale;   /* lpc.c:591: pow(sum, -0.5) of the platform libm */
             for (int j = i2 + 1; j < dim; j++) {
                 sum = am[i2][j];
                 for (int k = i2 - 1; k >= 0; k--) sum -= am[i2][k] * am[j][k];
@@ -696,12 +709,25 @@ __global__ __launch_bounds__(WAVE) void srla_pitch_solve(SrlaJobParams jp, const
             for (int i2 = 0; i2 < dim; i2++) {
                 const double scaled = xs[i2] * 32.0;
                 const double fr = fabs(scaled) + 0.5;
-                if (fabs(fr - floor(fr + 0.5)) < 1e-9 && fabs(scaled) < 40.0) flags |= SRLA_ITEM_LTP_TIE;
+                if (fabs(fr - floor(fr + 0.5)) < jp.tie_ltp && fabs(scaled) < 40.0) flags |= SRLA_ITEM_LTP_TIE;
                 int32_t c = (int32_t)round_half_away(scaled);
                 c = (c < -32) ? -32 : ((c > 31) ? 31 : c);
                 q[i2] = c;
             }
             for (int i2 = 0; i2 < dim / 2; i2++) { const int32_t t = q[i2]; q[i2] = q[dim - 1 - i2]; q[dim - 1 - i2] = t; }
+            const uint32_t forced = items[idx].forced_ltp;
+            if (forced >> 31) {
+                /* the host has redone the solve with its libm (host_ties.cpp) */
+                for (int i2 = 0; i2 < 3; i2++) q[i2] = ((int32_t)((forced >> (6 * i2)) << 26)) >> 26;
+                flags &= ~SRLA_ITEM_LTP_TIE;
+            } else if ((flags & SRLA_ITEM_LTP_TIE) && ties != nullptr) {
+                const uint32_t k = tie_append(ties, idx, 1u);
+                double *td = tie_data + 8u * (size_t)k;
+                td[0] = r0; td[1] = R(1); td[2] = R(2);
+                td[3] = R(period - 1); td[4] = R(period); td[5] = R(period + 1);
+                td[6] = (double)period;
+                td[7] = (double)(((uint32_t)q[0] & 63u) | (((uint32_t)q[1] & 63u) << 6) | (((uint32_t)q[2] & 63u) << 12));
+            }
         }
     }
     out->ltp_period = period;
@@ -768,65 +794,6 @@ __device__ __forceinline__ void levinson_lane(double *a, double *r, uint32_t lan
     }
 }
 
-/* Register-resident variant for max order P <= 64: the predictor a[] lives in VGPRs (fully unrolled
- * recursion, static indices), the lags r[] stay in LDS column-major -- their loads do not depend on the
- * running sum, so the only serial chain left is the index-ordered accumulation itself.  `upto` may differ
- * per lane (exec-masked steps); orders above the wave's maximum are skipped. */
-template <int P>
-__device__ __forceinline__ void levinson_regs(double (&a)[P + 2], const double *r, uint32_t lane, double r0, uint32_t upto,
-                                              double *err_out, size_t stride)
-{
-    constexpr int L = WAVE;
-    const double r1 = R_(1);
-    const double a1 = -r1 / r0;
-    a[0] = 1.0; a[1] = a1; a[2] = 0.0;
-    double e = r0 + r1 * a1;
-    if (err_out) err_out[stride] = e;
-#pragma unroll
-    for (int k = 1; k < P; k++) {
-        if ((uint32_t)k < upto) {
-            double gamma = 0.0;
-#pragma unroll
-            for (int i = 0; i <= k; i++) gamma += a[i] * R_(k + 1 - i);          /* index order, lpc.c:420-423 */
-            gamma /= -e;
-            e = e * (1.0 - gamma * gamma);
-#pragma unroll
-            for (int i = 0; i <= (k + 1) / 2; i++) {
-                const int j = k + 1 - i;
-                const double ai = a[i], aj = a[j];
-                a[i] = ai + gamma * aj;
-                if (i != j) a[j] = aj + gamma * ai;
-            }
-            a[k + 2 <= P + 1 ? k + 2 : P + 1] = (k + 2 <= P + 1) ? 0.0 : a[P + 1];
-            if (err_out) err_out[(size_t)(k + 1) * stride] = e;
-        }
-    }
-}
-
-template <int P>
-__global__ __launch_bounds__(WAVE) void srla_lpc_recursion_regs(SrlaJobParams jp, const double *__restrict__ lags_ws,
-                                                                double *__restrict__ err_ws)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    constexpr int L = WAVE;
-    const uint32_t lane = threadIdx.x;
-    const uint32_t idx = blockIdx.x * WAVE + lane;
-    if (idx >= jp.num_items) return;
-    double *r = (double *)lds;
-    const size_t stride = jp.num_items;
-#pragma unroll 8
-    for (uint32_t i = 0; i <= (uint32_t)P; i++) R_(i) = lags_ws[(size_t)i * stride + idx];
-    const double r0 = R_(0) * (1.0 + 1e-5);          /* ridge, lpc.c:483 */
-    double *err = err_ws + idx;
-    err[0] = r0;
-    if (fabs(r0) < (double)FLT_EPSILON) {
-        for (uint32_t o = 1; o <= (uint32_t)P; o++) err[(size_t)o * stride] = r0;   /* lpc.c:395-405 */
-        return;
-    }
-    double a[P + 2];
-    levinson_regs<P>(a, r, lane, r0, (uint32_t)P, err, stride);
-}
-
 template <int L>
 __global__ __launch_bounds__(WAVE) void srla_lpc_recursion(SrlaJobParams jp, const double *__restrict__ lags_ws,
                                                            double *__restrict__ err_ws)
@@ -852,7 +819,8 @@ __global__ __launch_bounds__(WAVE) void srla_lpc_recursion(SrlaJobParams jp, con
 
 __global__ __launch_bounds__(WAVE) void srla_order_select(
     SrlaJobParams jp, const SrlaItemDesc *__restrict__ items, const SrlaGeom *__restrict__ geoms,
-    const double *__restrict__ err_ws, SrlaItemResult *__restrict__ results, double *__restrict__ dbg)
+    const double *__restrict__ err_ws, SrlaItemResult *__restrict__ results, double *__restrict__ dbg,
+    uint32_t *__restrict__ ties)
 {
     const uint32_t idx = blockIdx.x, lane = threadIdx.x;
     const SrlaItemDesc it = items[idx];
@@ -872,7 +840,7 @@ __global__ __launch_bounds__(WAVE) void srla_order_select(
         if (o <= p) {
             const double ev = err_ws[(size_t)o * stride + idx] * comp;          /* lpc.c:490-497 */
             const double mabse = 2.0 * sqrt(ev / 2.0);
-            double l = geometric_entropy(mabse, bps) * (double)n;
+            double l = geometric_entropy(mabse, bps, jp.tie_logscale) * (double)n;
             l += (double)(8u * o);
             if (dbg_item) { dbg_item[SRLA_DBG_ERRVARS + o] = ev; dbg_item[SRLA_DBG_LENS + o] = l; }
             if (l < (double)FLT_MAX) len = l;
@@ -896,7 +864,10 @@ __global__ __launch_bounds__(WAVE) void srla_order_select(
         uint32_t order = (best < kInf) ? best_order : 0u;
         uint32_t flags = 0;
         if (jp.order_fixed) order = p;
-        else if (order != 0 && (second - best) <= 1e-9 * fabs(best) + 1e-9) flags |= SRLA_ITEM_ORDER_TIE;
+        else if (it.forced_order < 0 && order != 0 && (second - best) <= jp.tie_rel * fabs(best) + 1e-9) {
+            flags |= SRLA_ITEM_ORDER_TIE;
+            if (ties) (void)tie_append(ties, idx, 0u);
+        }
         if (it.forced_order >= 0) order = (uint32_t)it.forced_order;
         results[idx].lpc_order = order;
         if (flags) results[idx].flags |= flags;
@@ -953,39 +924,107 @@ __device__ __forceinline__ void quantize_and_price(uint32_t order, bool silent, 
     out->pad[0] = coef_bits;
 }
 
+/* The whole solve chain of one item in ONE pass, one LANE per item, everything but the snapshot in registers (orders 8, 16,
+ * 32, 64): the recursion (lags r[] and predictor a[] in VGPRs, static indices), and after every step the code-length
+ * estimate of that order (it needs only the step's error variance, srla_encoder.c:940-950) -- whenever the estimate
+ * improves, i.e. at every order the reference's sequential `minlen > len` scan would adopt, the predictor is copied to LDS.
+ * What is in LDS at the end is the predictor of the chosen order: no second recursion, no separate order-selection launch.
+ * Then the 8-bit quantiser and the tap cost, with the static Huffman lengths in LDS. */
 template <int P>
-__global__ __launch_bounds__(WAVE) void srla_lpc_quantize_regs(
-    SrlaJobParams jp, const double *__restrict__ lags_ws, const uint8_t *__restrict__ huff_len,
-    SrlaItemResult *__restrict__ results)
+__global__ __launch_bounds__(WAVE) void srla_lpc_solve_regs(
+    SrlaJobParams jp, const SrlaItemDesc *__restrict__ items, const SrlaGeom *__restrict__ geoms,
+    const double *__restrict__ lags_ws, double *__restrict__ err_ws, const uint8_t *__restrict__ huff_len,
+    SrlaItemResult *__restrict__ results, double *__restrict__ dbg, uint32_t *__restrict__ ties)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int L = WAVE;
     const uint32_t lane = threadIdx.x;
+    uint8_t *s_huff = lds;                                   /* 512 bytes: plain, pair-summed code lengths */
+    double *snap = (double *)(lds + 512);                    /* snap[i * L + lane], i < P: taps of the best order so far */
+    int32_t *q = (int32_t *)(snap + (size_t)P * L);          /* q[i * L + lane]: quantised taps */
+    for (uint32_t i = lane; i < 128; i += WAVE) ((uint32_t *)s_huff)[i] = ((const uint32_t *)huff_len)[i];
+    __syncthreads();
     const uint32_t idx = blockIdx.x * WAVE + lane;
-    if (idx >= jp.num_items) return;
-    double *r = (double *)lds;                       /* r[i * 64 + lane], i <= P; later: a copy of the taps */
+    if (idx >= jp.num_items) return;                         /* no barriers below: lanes are independent */
     const size_t stride = jp.num_items;
-    SrlaItemResult *out = &results[idx];
-    const uint32_t order = out->lpc_order;
-    bool silent = true;
-    if (order > 0) {
-        for (uint32_t i = 0; i <= order; i++) R_(i) = lags_ws[(size_t)i * stride + idx];
-        const double r0 = R_(0) * (1.0 + 1e-5);
-        silent = fabs(r0) < (double)FLT_EPSILON;
-        double a[P + 2];
-        if (!silent) {
-            levinson_regs<P>(a, r, lane, r0, order, nullptr, 0);
-            /* taps to LDS (dynamic indexing from here on); r[] is no longer needed */
+    double r[P + 1];
 #pragma unroll
-            for (int i = 0; i < P; i++) if ((uint32_t)i < order) R_(i) = a[1 + i];
+    for (int i = 0; i <= P; i++) r[i] = lags_ws[(size_t)i * stride + idx];
+    const SrlaItemDesc it = items[idx];
+    const double comp = geoms[it.geom].welch_comp;
+    const uint32_t n = it.n, bps = jp.bits_per_sample;
+    const int32_t forced = it.forced_order;
+    const double r0 = r[0] * (1.0 + 1e-5);                   /* ridge, lpc.c:483 */
+    double *err = err_ws + idx;
+    err[0] = r0;
+    double *dbg_item = dbg ? dbg + (size_t)idx * SRLA_DBG_STRIDE : nullptr;
+    if (dbg_item) dbg_item[SRLA_DBG_ERRVARS] = r0 * comp;
+    const bool silent = fabs(r0) < (double)FLT_EPSILON;
+
+    /* srla_encoder.c:934-957: minlen = FLT_MAX; for order = 1..p: if (minlen > len) adopt -- literally, plus the runner-up
+     * length for the near-tie test */
+    double best = (double)FLT_MAX, second = __builtin_inf();
+    uint32_t best_order = 0;
+    auto consider = [&](uint32_t order, double e) -> bool {
+        const double ev = e * comp;                                              /* lpc.c:490-497 */
+        const double mabse = 2.0 * sqrt(ev / 2.0);
+        double l = geometric_entropy(mabse, bps, jp.tie_logscale) * (double)n;
+        l += (double)(8u * order);
+        if (dbg_item) { dbg_item[SRLA_DBG_ERRVARS + order] = ev; dbg_item[SRLA_DBG_LENS + order] = l; }
+        const bool better = best > l;
+        if (better) { second = best; best = l; }
+        else if (l < second) second = l;
+        const bool take = (forced >= 0) ? (order == (uint32_t)forced) : better;
+        if (take) best_order = order;
+        return take;
+    };
+
+    if (silent) {
+        /* lpc.c:395-405: every error variance is r0, every predictor zero */
+        for (uint32_t o = 1; o <= (uint32_t)P; o++) { err[(size_t)o * stride] = r0; (void)consider(o, r0); }
+    } else {
+        double a[P + 2];
+        const double a1 = -r[1] / r0;
+        a[0] = 1.0; a[1] = a1; a[2] = 0.0;
+        double e = r0 + r[1] * a1;
+        err[stride] = e;
+        if (consider(1u, e)) snap[lane] = a[1];
+#pragma unroll
+        for (int k = 1; k < P; k++) {
+            double gamma = 0.0;
+#pragma unroll
+            for (int i = 0; i <= k; i++) gamma += a[i] * r[k + 1 - i];          /* index order, lpc.c:420-423 */
+            gamma /= -e;
+            e = e * (1.0 - gamma * gamma);
+#pragma unroll
+            for (int i = 0; i <= (k + 1) / 2; i++) {
+                const int j = k + 1 - i;
+                const double ai = a[i], aj = a[j];
+                a[i] = ai + gamma * aj;
+                if (i != j) a[j] = aj + gamma * ai;
+            }
+            a[k + 2] = 0.0;
+            err[(size_t)(k + 1) * stride] = e;
+            if (consider((uint32_t)(k + 1), e)) {
+#pragma unroll
+                for (int i = 0; i <= k; i++) snap[(size_t)i * L + lane] = a[1 + i];
+            }
         }
     }
-    double *taps = r;
-    int32_t *q = (int32_t *)(r + (size_t)(P + 1) * L);
+    uint32_t order = best_order;
+    uint32_t flags = 0;
+    if (jp.order_fixed) order = (uint32_t)P;
+    else if (forced < 0 && order != 0 && (second - best) <= jp.tie_rel * fabs(best) + 1e-9) {
+        flags |= SRLA_ITEM_ORDER_TIE;
+        if (ties) (void)tie_append(ties, idx, 0u);
+    }
+    SrlaItemResult *out = &results[idx];
+    out->lpc_order = order;
+    if (flags) out->flags |= flags;
     quantize_and_price(order, silent,
-                       [&](uint32_t i) -> double { return taps[(size_t)i * L + lane]; },
+                       [&](uint32_t i) -> double { return snap[(size_t)i * L + lane]; },
                        [&](uint32_t i, int32_t v) { q[(size_t)i * L + lane] = v; },
-                       [&](uint32_t i) -> int32_t { return q[(size_t)i * L + lane]; }, huff_len, out);
+                       [&](uint32_t i) -> int32_t { return q[(size_t)i * L + lane]; }, s_huff, out);
 }
 
 template <int L>
@@ -1473,14 +1512,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(R >= 4 ? 2 :
 {
     constexpr int CH = 2 * R;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    const InputView iv = input_view(jp);
     /* as in srla_autocorr: workgroups go to the XCDs round robin, so each XCD is given one contiguous range of items --
      * the dozen items that read the same samples then share one L2 instead of pulling them into all eight */
     const uint32_t block = xcd_position(blockIdx.x, jp.num_items);
     if (block >= jp.num_items) return;
+    const SrlaItemDesc itf = items[block];
+    const InputView iv = input_view(jp, itf.lshift);
     {
         /* blocks of 1024 * FL samples take the register / shuffle fast path */
-        const SrlaItemDesc itf = items[block];
         const uint32_t fl = itf.n >> 10;
         if ((itf.n & 1023u) == 0 && fl >= 1 && fl <= 8 && fl <= (uint32_t)(2 * R)) {
             const int32_t *inf = input + itf.sample_off;
@@ -1518,7 +1557,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(R >= 4 ? 2 :
 
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t item_idx = block;
-    const SrlaItemDesc it = items[item_idx];
+    const SrlaItemDesc it = itf;
     const SrlaGeom g = geoms[it.geom];
     const uint32_t n = it.n, bps = jp.bits_per_sample;
     const int32_t *in = input + it.sample_off;
@@ -1908,30 +1947,34 @@ __global__ __launch_bounds__(WAVE) void srla_price_windows(SrlaJobParams jp, con
             }
             rec->item[ch] = it;
         }
-        rec->pad[0] = 0; rec->pad[1] = 0;
+        rec->seg = wd.seg; rec->pad = 0;
     }
 }
 
 /* ------------------------------------------------------------------------- pack ----------- */
-/* srla_block_offsets (one workgroup per job): exclusive prefix sum of the chosen blocks' byte sizes in
- * stream order, the job's position in the output stream (a device-resident running offset, so jobs can be
- * enqueued back to back without a host round trip), per-window byte counts for the encode callback, block
- * statistics and the overflow / coverage checks of SRLAEncoder_EncodeWhole (srla_encoder.c:1756-1783). */
+/* srla_block_offsets (one workgroup per job): exclusive prefix sum of the chosen blocks' byte sizes in stream order;
+ * per-window byte counts for the encode callback; then, per SEGMENT of the job (the run of windows that belong to one
+ * stream): where its blocks go in the stream's output buffer -- at init_pos, or behind what the earlier jobs of the stream
+ * wrote (a device-resident running offset per stream, so jobs are enqueued back to back without a host round trip) --, the
+ * overflow check of SRLAEncoder_EncodeWhole (srla_encoder.c:1756-1783), and where the segment is assembled in the job's
+ * staging buffer: with the 16-byte phase of its final address, so that srla_stream_out moves it with aligned 16-byte
+ * accesses.  block_off[] ends up as offsets into the staging buffer. */
+#define SRLA_SEGCTL_WORDS 8   /* device-side record per segment: bytes, pos, stage_off, skip, rel_start, - - - */
 __global__ __launch_bounds__(NT) void srla_block_offsets(
     SrlaJobParams jp, const SrlaWindowDesc *__restrict__ windows, const SrlaBlockRecord *__restrict__ blocks,
     const SrlaItemResult *__restrict__ results, uint32_t num_slots, uint32_t *__restrict__ block_off,
-    uint32_t *__restrict__ stream_pos /* [0] running offset, [1] sticky overflow flag */,
-    uint32_t *__restrict__ ctl /* [0] phase added to block_off by the pack kernel, [1] skip, [2] job bytes, [3] offset in dst */,
-    uint32_t first, uint32_t init_pos, uint32_t absolute, uint32_t limit, uint64_t dst_addr, SrlaJobInfo *__restrict__ info,
-    uint32_t *__restrict__ window_bytes)
+    uint32_t *__restrict__ stream_pos /* per stream: [0] running offset, [1] sticky skip flag */,
+    const SrlaSegDesc *__restrict__ segs, uint32_t *__restrict__ seg_ctl, uint64_t stage_addr,
+    SrlaJobInfo *__restrict__ info, uint32_t *__restrict__ window_bytes, SrlaSegInfo *__restrict__ seg_info,
+    const uint32_t *__restrict__ ties)
 {
     __shared__ uint32_t s_wave[NWAVES];
-    __shared__ uint32_t s_cnt[5];
+    __shared__ uint32_t s_cnt[6];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nch = jp.num_channels;
-    if (tid < 5) s_cnt[tid] = 0;
+    if (tid < 6) s_cnt[tid] = 0;
     __syncthreads();
     uint32_t carry = 0;
-    uint32_t nblk = 0, nraw = 0, nsil = 0, ntie = 0, nodd = 0;
+    uint32_t nblk = 0, nraw = 0, nsil = 0, nodd = 0;
     for (uint32_t base = 0; base < num_slots; base += NT) {
         const uint32_t i = base + tid;
         uint32_t b = 0;
@@ -1943,7 +1986,6 @@ __global__ __launch_bounds__(NT) void srla_block_offsets(
             else if (rec->block_type == SRLA_BLOCK_SILENT) nsil++;
             else for (uint32_t ch = 0; ch < nch; ch++) {
                 const uint32_t f = results[rec->item[ch]].flags;
-                if (f & SRLA_ITEM_ORDER_TIE) ntie++;
                 if (f & SRLA_ITEM_ODD_LENGTH) nodd++;
             }
         }
@@ -1959,8 +2001,8 @@ __global__ __launch_bounds__(NT) void srla_block_offsets(
     }
     const uint32_t total = carry;
     {
-        const uint32_t v[5] = { nblk, nraw, nsil, ntie, nodd };
-        for (int k = 0; k < 5; k++) { const uint32_t s = wave_sum_u32(v[k]); if (lane == 0 && s) atomicAdd(&s_cnt[k], s); }
+        const uint32_t v[4] = { nblk, nraw, nsil, nodd };
+        for (int k = 0; k < 4; k++) { const uint32_t s = wave_sum_u32(v[k]); if (lane == 0 && s) atomicAdd(&s_cnt[k], s); }
     }
     __syncthreads();
     /* per-window sizes + coverage: the chosen blocks of a window must tile it exactly */
@@ -1975,31 +2017,48 @@ __global__ __launch_bounds__(NT) void srla_block_offsets(
         if (covered != wd.n) bad = 1;
     }
     bad = wave_max_u32(bad);
-    if (lane == 0 && bad) atomicOr(&s_cnt[0], 0x80000000u);
+    if (lane == 0 && bad) atomicOr(&s_cnt[4], 1u);
     __syncthreads();
+    const uint32_t cover_bad = s_cnt[4];
+    /* segments */
+    for (uint32_t sg = tid; sg < jp.num_segs; sg += NT) {
+        const SrlaSegDesc sd = segs[sg];
+        const SrlaWindowDesc w0 = windows[sd.first_window], w1 = windows[sd.first_window + sd.num_windows - 1];
+        const uint32_t b0 = w0.block_base, b1 = w1.block_base + w1.num_nodes - 1;
+        const uint32_t rel_start = block_off[b0], rel_end = (b1 < num_slots) ? block_off[b1] : total;
+        const uint32_t bytes = rel_end - rel_start;
+        const uint32_t pos = sd.use_init ? sd.init_pos : stream_pos[2u * sd.stream];
+        uint32_t skip = sd.use_init ? 0u : stream_pos[2u * sd.stream + 1u];
+        if ((uint64_t)pos + bytes > (uint64_t)sd.limit) { skip = 1; atomicOr(&s_cnt[5], SRLA_JOBERR_OVERFLOW); }
+        if (cover_bad) skip = 1;
+        stream_pos[2u * sd.stream] = skip ? pos : pos + bytes;
+        stream_pos[2u * sd.stream + 1u] = skip;
+        /* segment k starts at rel_start + 16 k + adj (adj < 16 gives it the phase of its destination): segments never overlap */
+        const uint32_t phase = sd.dst ? (uint32_t)((sd.dst + pos) & 15u) : 0u;
+        const uint32_t base = rel_start + 16u * sg;
+        const uint32_t stage_off = base + ((phase - (uint32_t)((stage_addr + base) & 15u)) & 15u);
+        uint32_t *c = seg_ctl + (size_t)SRLA_SEGCTL_WORDS * sg;
+        c[0] = bytes; c[1] = pos; c[2] = stage_off; c[3] = skip; c[4] = rel_start;
+        seg_info[sg].bytes = bytes; seg_info[sg].pos = pos; seg_info[sg].stage_off = stage_off; seg_info[sg].skip = skip;
+    }
+    __syncthreads();
+    __threadfence_block();
+    /* block offsets: from job-relative to staging-buffer positions */
+    for (uint32_t w = tid; w < jp.num_windows; w += NT) {
+        const SrlaWindowDesc wd = windows[w];
+        const uint32_t *c = seg_ctl + (size_t)SRLA_SEGCTL_WORDS * wd.seg;
+        const uint32_t delta = c[2] - c[4];
+        for (uint32_t k = wd.block_base; k < wd.block_base + wd.num_nodes - 1; k++) block_off[k] += delta;
+    }
     if (tid == 0) {
-        const uint32_t pos = first ? init_pos : stream_pos[0];
-        uint32_t err = (s_cnt[0] & 0x80000000u) ? SRLA_JOBERR_COVER : 0u;
-        uint32_t skip = first ? 0u : stream_pos[1];
-        if ((uint64_t)pos + total > (uint64_t)limit) { err |= SRLA_JOBERR_OVERFLOW; skip = 1; }
-        if (err & SRLA_JOBERR_COVER) skip = 1;
-        stream_pos[0] = skip ? pos : pos + total;
-        stream_pos[1] = skip;
-        /* the pack kernel assembles the job's bytes in a device buffer with the same 16-byte phase as their final
-         * address, so that srla_stream_out moves them with aligned 16-byte accesses */
-        const uint32_t dst_off = absolute ? pos : 0u;
-        ctl[0] = (uint32_t)((dst_addr + dst_off) & 15u);
-        ctl[1] = skip;
-        ctl[2] = total;
-        ctl[3] = dst_off;
         info->total_bytes = total;
-        info->base = pos;
-        info->num_blocks = s_cnt[0] & 0x7FFFFFFFu;
+        info->base = seg_ctl[1];
+        info->num_blocks = s_cnt[0];
         info->num_raw = s_cnt[1];
         info->num_silent = s_cnt[2];
-        info->num_tie_items = s_cnt[3];
-        info->num_odd_items = s_cnt[4];
-        info->error = err;
+        info->num_tie_items = ties ? ties[0] : 0u;
+        info->num_odd_items = s_cnt[3];
+        info->error = s_cnt[5] | (cover_bad ? SRLA_JOBERR_COVER : 0u);
     }
 }
 
@@ -2287,7 +2346,7 @@ __global__ __launch_bounds__(NT) void srla_pack_blocks(
     SrlaJobParams jp, const int32_t *__restrict__ input, const SrlaItemDesc *__restrict__ items,
     const SrlaBlockRecord *__restrict__ blocks, const SrlaItemResult *__restrict__ results,
     const int32_t *__restrict__ res_ws, const uint32_t *__restrict__ huff_code, const uint8_t *__restrict__ huff_len,
-    const uint32_t *__restrict__ block_off, const uint32_t *__restrict__ ctl, uint8_t *__restrict__ out,
+    const uint32_t *__restrict__ block_off, const uint32_t *__restrict__ seg_ctl, uint8_t *__restrict__ out,
     uint8_t *__restrict__ scratch, SrlaJobInfo *__restrict__ info, uint32_t lds_words)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -2296,8 +2355,8 @@ __global__ __launch_bounds__(NT) void srla_pack_blocks(
     uint32_t *words = kpar + 512;                            /* lds_words entries */
     const uint32_t slot = blockIdx.x;
     const SrlaBlockRecord *recp = &blocks[slot];
-    if (!recp->valid || ctl[1]) return;
-    uint8_t *dst = out + (size_t)ctl[0] + block_off[slot];
+    if (!recp->valid || seg_ctl[(size_t)SRLA_SEGCTL_WORDS * recp->seg + 3u]) return;
+    uint8_t *dst = out + block_off[slot];
     const uint32_t nwords = ((recp->bytes + 3u) >> 2) + 1u;
     if (nwords <= lds_words) {
         pack_block_body<false>(jp, recp, input, items, results, res_ws, huff_code, huff_len, words, aux, kpar, dst, info);
@@ -2307,21 +2366,16 @@ __global__ __launch_bounds__(NT) void srla_pack_blocks(
     }
 }
 
-/* srla_stream_out: the job's finished bytes, device buffer -> their place in host memory (the caller's pinned
- * buffer or the pinned staging buffer).  A handful of workgroups keep the PCIe link busy; letting the 1000+ pack
- * workgroups store to host memory themselves kept them (and their LDS) resident for the duration of the link
+/* srla_stream_out: the job's finished bytes, device buffer -> their place in host memory (the stream's pinned buffer, or
+ * the job's pinned staging buffer), segment by segment.  A handful of workgroups keep the PCIe link busy; letting the
+ * 1000+ pack workgroups store to host memory themselves kept them (and their LDS) resident for the duration of the link
  * transfer and slowed the concurrently running srla_autocorr by 30 %. */
-__global__ __launch_bounds__(NT) void srla_stream_out(const uint8_t *__restrict__ stage, const uint32_t *__restrict__ ctl,
-                                                      uint8_t *__restrict__ dst, uint32_t pause)
+__device__ __forceinline__ void copy_same_phase(const uint8_t *__restrict__ src, uint8_t *__restrict__ d, uint32_t total,
+                                                uint32_t gtid, uint32_t gsize, uint32_t pause)
 {
-    if (ctl[1]) return;
-    const uint8_t *src = stage + ctl[0];
-    uint8_t *d = dst + ctl[3];
-    const uint32_t total = ctl[2];
     uint32_t head = (16u - (uint32_t)(reinterpret_cast<uintptr_t>(d) & 15u)) & 15u;    /* src has the same phase */
     if (head > total) head = total;
     const uint32_t nvec = (total - head) >> 4, tail0 = head + (nvec << 4);
-    const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x, gsize = gridDim.x * blockDim.x;
     if (gtid < head) d[gtid] = src[gtid];
     if (gtid >= 32 && gtid - 32 < total - tail0) d[tail0 + gtid - 32] = src[tail0 + gtid - 32];
     const uint4 *s4 = reinterpret_cast<const uint4 *>(src + head);
@@ -2333,6 +2387,25 @@ __global__ __launch_bounds__(NT) void srla_stream_out(const uint8_t *__restrict_
         for (uint32_t z = 0; z < pause; z++) __builtin_amdgcn_s_sleep(8);
     }
     for (; v < nvec; v += gsize) d4[v] = s4[v];
+}
+
+__global__ __launch_bounds__(NT) void srla_stream_out(const uint8_t *__restrict__ stage, const uint32_t *__restrict__ seg_ctl,
+                                                      const SrlaSegDesc *__restrict__ segs, uint32_t num_segs,
+                                                      uint8_t *__restrict__ host_stage, uint32_t pause)
+{
+    if (num_segs == 1) {
+        /* the usual case: every workgroup of the launch works on the one segment */
+        if (seg_ctl[3]) return;
+        uint8_t *d = segs[0].dst ? reinterpret_cast<uint8_t *>(segs[0].dst) + seg_ctl[1] : host_stage + seg_ctl[2];
+        copy_same_phase(stage + seg_ctl[2], d, seg_ctl[0], blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x, pause);
+        return;
+    }
+    for (uint32_t sg = blockIdx.x; sg < num_segs; sg += gridDim.x) {
+        const uint32_t *c = seg_ctl + (size_t)SRLA_SEGCTL_WORDS * sg;
+        if (c[3]) continue;
+        uint8_t *d = segs[sg].dst ? reinterpret_cast<uint8_t *>(segs[sg].dst) + c[1] : host_stage + c[2];
+        copy_same_phase(stage + c[2], d, c[0], threadIdx.x, blockDim.x, pause);
+    }
 }
 
 /* ------------------------------------------------------------------- offset left shift ---- */
@@ -2444,32 +2517,32 @@ extern "C" int srla_launch_widen16(hipStream_t stream, const int16_t *src, size_
     return (hipGetLastError() == hipSuccess) ? 0 : -2;
 }
 
-extern "C" int srla_launch_pitch_solve(hipStream_t stream, const SrlaJobParams *jp, const double *lags_ws,
+extern "C" int srla_launch_pitch_solve(hipStream_t stream, const SrlaJobParams *jp, const SrlaItemDesc *items, const double *lags_ws,
                                        SrlaItemResult *results, hipEvent_t ev_start, hipEvent_t ev_stop,
-                                       const uint32_t *select, uint32_t round)
+                                       const uint32_t *select, uint32_t round, uint32_t *ties, double *tie_data)
 {
     if (jp->num_items == 0) return 0;
     const uint32_t lds = SRLA_LTP_LAGS * PITCH_ITEMS * 8u;
     SET_LDS_ATTR(srla_pitch_solve);
-    hipExtLaunchKernelGGL(srla_pitch_solve, dim3((jp->num_items + PITCH_ITEMS - 1) / PITCH_ITEMS), dim3(WAVE), lds, stream, ev_start, ev_stop, 0, *jp, lags_ws, results, select, round);
+    hipExtLaunchKernelGGL(srla_pitch_solve, dim3((jp->num_items + PITCH_ITEMS - 1) / PITCH_ITEMS), dim3(WAVE), lds, stream, ev_start, ev_stop, 0,
+                          *jp, items, lags_ws, results, select, round, ties, tie_data);
     return (hipGetLastError() == hipSuccess) ? 0 : -2;
 }
 
 extern "C" int srla_launch_lpc_solve(hipStream_t stream, const SrlaJobParams *jp, const SrlaItemDesc *items,
                                      const SrlaGeom *geoms, const double *lags_ws, double *err_ws, const uint8_t *huff_len,
-                                     SrlaItemResult *results, double *dbg, hipEvent_t ev_start, hipEvent_t ev_stop)
+                                     SrlaItemResult *results, double *dbg, uint32_t *ties, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     if (jp->num_items == 0) return 0;
     const uint32_t p = jp->max_order;
     const dim3 g64((jp->num_items + 63) / 64), blk(WAVE);
+    /* orders 8 .. 64: the whole chain in one launch (srla_lpc_solve_regs) */
 #define REGS_PATH(PP)                                                                                                    \
     do {                                                                                                                 \
-        const uint32_t lds_a = (PP + 1) * 8 * 64, lds_c = (PP + 1) * 8 * 64 + PP * 4 * 64;                               \
-        SET_LDS_ATTR(srla_lpc_recursion_regs<PP>);                                                                       \
-        SET_LDS_ATTR(srla_lpc_quantize_regs<PP>);                                                                        \
-        hipExtLaunchKernelGGL(srla_lpc_recursion_regs<PP>, g64, blk, lds_a, stream, ev_start, nullptr, 0, *jp, lags_ws, err_ws);                  \
-        hipLaunchKernelGGL(srla_order_select, dim3(jp->num_items), blk, 0, stream, *jp, items, geoms, err_ws, results, dbg); \
-        hipExtLaunchKernelGGL(srla_lpc_quantize_regs<PP>, g64, blk, lds_c, stream, nullptr, ev_stop, 0, *jp, lags_ws, huff_len, results);        \
+        const uint32_t lds = 512 + PP * 8 * 64 + PP * 4 * 64;                                                            \
+        SET_LDS_ATTR(srla_lpc_solve_regs<PP>);                                                                           \
+        hipExtLaunchKernelGGL(srla_lpc_solve_regs<PP>, g64, blk, lds, stream, ev_start, ev_stop, 0, *jp, items, geoms, lags_ws, err_ws, \
+                              huff_len, results, dbg, ties);                                                             \
     } while (0)
     if (p == 8) REGS_PATH(8);
     else if (p == 16) REGS_PATH(16);
@@ -2480,14 +2553,14 @@ extern "C" int srla_launch_lpc_solve(hipStream_t stream, const SrlaJobParams *jp
         SET_LDS_ATTR(srla_lpc_recursion<64>);
         SET_LDS_ATTR(srla_lpc_quantize<64>);
         hipExtLaunchKernelGGL(srla_lpc_recursion<64>, g64, blk, lds, stream, ev_start, nullptr, 0, *jp, lags_ws, err_ws);
-        hipLaunchKernelGGL(srla_order_select, dim3(jp->num_items), blk, 0, stream, *jp, items, geoms, err_ws, results, dbg);
+        hipLaunchKernelGGL(srla_order_select, dim3(jp->num_items), blk, 0, stream, *jp, items, geoms, err_ws, results, dbg, ties);
         hipExtLaunchKernelGGL(srla_lpc_quantize<64>, g64, blk, lds, stream, nullptr, ev_stop, 0, *jp, lags_ws, huff_len, results);
     } else {
         const uint32_t lds = (2 * p + 3) * 8 * 32;
         SET_LDS_ATTR(srla_lpc_recursion<32>);
         SET_LDS_ATTR(srla_lpc_quantize<32>);
         hipExtLaunchKernelGGL(srla_lpc_recursion<32>, dim3((jp->num_items + 31) / 32), blk, lds, stream, ev_start, nullptr, 0, *jp, lags_ws, err_ws);
-        hipLaunchKernelGGL(srla_order_select, dim3(jp->num_items), blk, 0, stream, *jp, items, geoms, err_ws, results, dbg);
+        hipLaunchKernelGGL(srla_order_select, dim3(jp->num_items), blk, 0, stream, *jp, items, geoms, err_ws, results, dbg, ties);
         hipExtLaunchKernelGGL(srla_lpc_quantize<32>, dim3((jp->num_items + 31) / 32), blk, lds, stream, nullptr, ev_stop, 0, *jp, lags_ws, huff_len, results);
     }
 #undef REGS_PATH
@@ -2552,18 +2625,19 @@ extern "C" int srla_launch_pack(hipStream_t stream, const SrlaJobParams *jp, uin
                                 const int32_t *input, const SrlaItemDesc *items, const SrlaWindowDesc *windows,
                                 const SrlaBlockRecord *blocks, const SrlaItemResult *results, const int32_t *res_ws,
                                 const uint32_t *huff_code, const uint8_t *huff_len, uint32_t *block_off,
-                                uint32_t *stream_pos, uint32_t *ctl, uint32_t first, uint32_t init_pos, uint32_t absolute,
-                                uint32_t limit, uint8_t *stage, uint8_t *dst, uint8_t *scratch, SrlaJobInfo *info,
-                                uint32_t *window_bytes, hipEvent_t ev_start, hipEvent_t ev_stop, uint32_t out_boost)
+                                uint32_t *stream_pos, const SrlaSegDesc *segs, uint32_t *seg_ctl,
+                                uint8_t *stage, uint8_t *host_stage, uint8_t *scratch, SrlaJobInfo *info,
+                                uint32_t *window_bytes, SrlaSegInfo *seg_info, const uint32_t *ties,
+                                hipEvent_t ev_start, hipEvent_t ev_stop, uint32_t out_boost)
 {
     if (num_slots == 0) return 0;
     hipExtLaunchKernelGGL(srla_block_offsets, dim3(1), dim3(NT), 0, stream, ev_start, nullptr, 0, *jp, windows, blocks, results, num_slots, block_off,
-                       stream_pos, ctl, first, init_pos, absolute, limit, (uint64_t)reinterpret_cast<uintptr_t>(dst), info, window_bytes);
+                       stream_pos, segs, seg_ctl, (uint64_t)reinterpret_cast<uintptr_t>(stage), info, window_bytes, seg_info, ties);
     const uint32_t lds_words = srla_pack_lds_words(jp);
     const uint32_t lds = (lds_words + 32 + 512) * 4;
     SET_LDS_ATTR(srla_pack_blocks);
     hipLaunchKernelGGL(srla_pack_blocks, dim3(num_slots), dim3(NT), lds, stream,
-                       *jp, input, items, blocks, results, res_ws, huff_code, huff_len, block_off, ctl, stage, scratch, info,
+                       *jp, input, items, blocks, results, res_ws, huff_code, huff_len, block_off, seg_ctl, stage, scratch, info,
                        lds_words);
     static int out_wgs = -1, out_thr = 0, out_sleep = 0;
     if (out_wgs < 0) {
@@ -2574,7 +2648,8 @@ extern "C" int srla_launch_pack(hipStream_t stream, const SrlaJobParams *jp, uin
     /* one workgroup keeps up with 16-bit streams (~12 GB/s of output at full speed) and leaves the PCIe write path calm
      * enough for srla_autocorr (measured: more slow it down); 24-bit streams carry twice the bytes and need two */
     const uint32_t wgs = out_wgs ? (uint32_t)out_wgs : (jp->bits_per_sample > 16 ? 2u : 1u);
-    hipExtLaunchKernelGGL(srla_stream_out, dim3(wgs * (out_boost ? out_boost : 1u)), dim3((uint32_t)out_thr), 0, stream, nullptr, ev_stop, 0, stage, ctl, dst, (uint32_t)out_sleep);
+    hipExtLaunchKernelGGL(srla_stream_out, dim3(wgs * (out_boost ? out_boost : 1u)), dim3((uint32_t)out_thr), 0, stream, nullptr, ev_stop, 0,
+                          stage, seg_ctl, segs, jp->num_segs, host_stage, (uint32_t)out_sleep);
     return (hipGetLastError() == hipSuccess) ? 0 : -2;
 }
 
