@@ -177,3 +177,38 @@ class DecoderLib:
         if rc != OK:
             raise RuntimeError("DecodeWhole -> %d" % rc)
         return out, hdr
+
+
+class BatchCall:
+    """SRLAMI355X_EncodeBatch (include/srla_mi355x.h): many streams of one format in one call.  Holds the pointer tables
+    of a fixed set of input arrays / output buffers so that repeated calls cost nothing on the Python side."""
+
+    def __init__(self, lib, pcms, outs):
+        self.lib = lib
+        fn = lib.lib.SRLAMI355X_EncodeBatch
+        fn.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        fn.restype = C.c_int
+        self.fn = fn
+        n = len(pcms)
+        self.n = n
+        self._keep = [planar_ptrs(p) for p in pcms]
+        self.inputs = (C.c_void_p * n)(*[C.cast(p, C.c_void_p) for p in self._keep])
+        self.num_samples = (C.c_uint32 * n)(*[p.shape[1] for p in pcms])
+        self.data = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+        self.data_size = (C.c_uint32 * n)(*[o.size for o in outs])
+        self.results = (C.c_int * n)()
+        self._outs = outs
+        self._pcms = pcms
+
+    def run(self, enc, out_sizes):
+        return self.fn(enc, self.n, self.inputs, self.num_samples, self.data, self.data_size, out_sizes, self.results)
+
+
+def encode_batch(lib, enc, pcms, caps=None):
+    """-> (rc, [stream bytes or None], [per-stream result codes])"""
+    outs = [np.zeros(int(caps[i] if caps else 2 * p.size * 4 + 1024), dtype=np.uint8) for i, p in enumerate(pcms)]
+    call = BatchCall(lib, pcms, outs)
+    sizes = (C.c_uint32 * len(pcms))()
+    rc = call.run(enc, sizes)
+    res = list(call.results)
+    return rc, [outs[i][:sizes[i]].copy() if res[i] == OK else None for i in range(len(pcms))], res

@@ -68,6 +68,7 @@ void Impl::chain_build(uint32_t jobidx, const Job &job, ChainJob &cj)
         SrlaAutocorrItem ai{};
         ai.item = item; ai.sample_off = it.sample_off; ai.n = it.n; ai.variant = it.variant;
         ai.nfft = gm.nfft; ai.tw_off = gm.tw_off; ai.welch_divisor = gm.welch_divisor; ai.acorr_norm = gm.acorr_norm;
+        ai.lshift = it.lshift;
         return ai;
     };
     auto cls_of = [](uint32_t nfft) { return (nfft <= 1024u) ? 0u : ((nfft <= 2048u) ? 1u : ((nfft <= 4096u) ? 2u : 3u)); };

@@ -1,0 +1,82 @@
+"""Host-libm arbitration of near-ties (srla_amd/csrc/host_ties.cpp).  On ordinary input nothing is ever flagged,
+so the tests widen the tie thresholds and falsify the device's log / x^-1/2 (SRLA_MI355X_TIE_TEST): the device then really
+decides some items differently from the reference, the host libm overrules it, the affected jobs are analysed again -- and
+the bytes must still be the oracle's."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import bench
+import helpers
+from srla_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+
+def _stats(product, enc, reset=0):
+    st = bench.Stats()
+    fn = product.lib.SRLAMI355X_GetStats
+    fn.argtypes = [C.c_void_p, C.POINTER(bench.Stats), C.c_int]
+    fn(enc, C.byref(st), reset)
+    return st
+
+
+def _run(product, pcm, **cli):
+    cfg, par = capi.cli_setup(pcm.shape[0], 16, 48000, **cli)
+    enc = product.create(cfg)
+    assert product.set_parameter(enc, par) == capi.OK
+    rc, got = product.encode_whole(enc, pcm)
+    st = _stats(product, enc)
+    product.destroy(enc)
+    assert rc == capi.OK
+    return got, st
+
+
+CASES = [
+    ("order", "0.05,1e-9,1.01,1.0", dict(preset=4, max_block=4096, divisions=1)),
+    ("order_small_jobs", "0.05,1e-9,1.01,1.0", dict(preset=2, max_block=2048, divisions=2)),
+    ("ltp", "1e-9,0.25,1.0,1.001", dict(preset=4, max_block=4096, divisions=1, ltp_order=3)),
+    ("both", "0.05,0.25,1.01,1.001", dict(preset=4, max_block=4096, divisions=2, ltp_order=3)),
+    ("ltp1", "0.02,0.25,0.995,0.999", dict(preset=3, max_block=2048, divisions=1, ltp_order=1)),
+]
+
+
+@pytest.mark.parametrize("name,hook,cli", CASES, ids=[c[0] for c in CASES])
+def test_falsified_device_decisions_are_overruled(product, monkeypatch, name, hook, cli):
+    monkeypatch.setenv("SRLA_MI355X_TIE_TEST", hook)
+    if "small_jobs" in name:
+        monkeypatch.setenv("SRLA_MI355X_JOB_SAMPLES", "65536")      # several jobs in flight: the loop has to go back
+    for kind, n in ((helpers.MUSIC, 300000), (helpers.VARIED, 200001)):
+        pcm = helpers.synth(kind, 31, 48000, 2, n)
+        got, st = _run(product, pcm, **cli)
+        want = helpers.Oracle(2, **cli).encode_whole(pcm)
+        assert np.array_equal(got, want), (name, kind, n)
+        assert st.num_tie_items > 0 and st.num_tie_resolved > 0
+        if kind == helpers.MUSIC and name.startswith("order"):
+            assert st.num_tie_overrides > 0 and st.num_restarts > 0, (name, st.num_tie_items, st.num_tie_resolved)
+
+
+def test_block_calls_arbitrate_too(product, monkeypatch):
+    monkeypatch.setenv("SRLA_MI355X_TIE_TEST", "0.05,0.25,1.01,1.001")
+    cli = dict(preset=4, max_block=4096, divisions=0, ltp_order=3)
+    cfg, par = capi.cli_setup(2, 16, 48000, **cli)
+    enc = product.create(cfg)
+    assert product.set_parameter(enc, par) == capi.OK
+    o = helpers.Oracle(2, **cli)
+    total = 0
+    for seed in range(12):
+        pcm = helpers.synth(helpers.MUSIC, 50 + seed, 48000, 2, 4096)
+        rc, got = product.encode_block(enc, pcm)
+        assert rc == capi.OK and np.array_equal(got, o.encode_block(pcm)), seed
+        rc, size = product.compute_block_size(enc, pcm)
+        assert rc == capi.OK and size == got.size
+    st = _stats(product, enc)
+    product.destroy(enc)
+    assert st.num_tie_items > 0
+
+
+def test_nothing_is_flagged_in_production(product):
+    pcm = helpers.synth(helpers.MUSIC, 32, 48000, 2, 480000)
+    got, st = _run(product, pcm, preset=4, max_block=4096, divisions=2, ltp_order=3)
+    assert st.num_tie_items == 0 and st.num_restarts == 0
