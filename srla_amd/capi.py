@@ -65,11 +65,23 @@ def cli_setup(num_channels, bits_per_sample, sampling_rate, preset=4, max_block=
     return cfg, par
 
 
+def _one_hip_runtime():
+    """A process must hold ONE HIP runtime.  PyTorch wheels bundle their own libamdhip64.so and ask for it under a name that
+    does not match an already loaded system copy, so "this library first, torch later" ends with two runtimes, and whichever
+    comes second finds no GPU.  The other order is fine (the encoder library then binds to the copy torch loaded, by
+    SONAME) -- so if torch is installed, it is loaded first.  C / C++ users of the library are not concerned."""
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
+
+
 class EncoderLib:
     """The nine SRLAEncoder_* entry points of include/srla_encoder.h:41-79."""
 
     def __init__(self, path):
         self.path = path
+        _one_hip_runtime()
         lib = self.lib = C.CDLL(path)
         lib.SRLAEncoder_EncodeHeader.argtypes = [C.POINTER(SRLAHeader), C.c_void_p, C.c_uint32]
         lib.SRLAEncoder_EncodeHeader.restype = C.c_int

@@ -182,9 +182,10 @@ typedef struct SrlaJobParams {
                                * item's: lets a whole device-resident stream be enqueued before its OR-reduction has finished */
     /* near-tie detection (H2: decisions that hang on libm): an item is flagged, and arbitrated with the host libm, when the
      * two best code-length estimates differ by less than tie_rel (relative), or an LTP tap lies within tie_ltp of a
-     * rounding boundary.  tie_logscale / tie_powscale (1.0 in production) deliberately falsify the device's log / x^-1/2:
-     * the tests use them to make the device decide differently from the host, so that the arbitration has work to do. */
-    double tie_rel, tie_ltp, tie_logscale, tie_powscale;
+     * rounding boundary.  tie_logscale (1.0 in production) and tie_ltpbias (0.0) deliberately falsify the device's log and
+     * its scaled LTP taps: the tests use them to make the device decide differently from the host, so that the arbitration
+     * has work to do. */
+    double tie_rel, tie_ltp, tie_logscale, tie_ltpbias;
 } SrlaJobParams;
 
 /* LDS carve-up of kernel A for one FFT-size group (bytes, 16-byte aligned); host decides overlays */

@@ -179,8 +179,8 @@ struct Impl {
     bool no_speculation = false;      /* SRLA_MI355X_NO_SPECULATION: the OR of a stream is always gathered before its first job */
     bool force_staging = false;       /* SRLA_MI355X_STAGING: never write the caller's buffer from the device */
     bool no_pack16 = false;           /* SRLA_MI355X_NO_PACK16: host input always crosses PCIe as int32 */
-    /* near-tie detection and its test hooks (SrlaJobParams; SRLA_MI355X_TIE_TEST="rel,ltp,logscale,powscale") */
-    double tie_rel = 1e-9, tie_ltp = 1e-9, tie_logscale = 1.0, tie_powscale = 1.0;
+    /* near-tie detection and its test hooks (SrlaJobParams; SRLA_MI355X_TIE_TEST="rel,ltp,logscale,ltpbias") */
+    double tie_rel = 1e-9, tie_ltp = 1e-9, tie_logscale = 1.0, tie_ltpbias = 0.0;
     std::map<uint32_t, uint32_t> tw_index;   /* nfft -> offset (double2) */
     std::vector<double> tw_host;
     bool tw_dirty = false;

@@ -128,10 +128,10 @@ bool Impl::init_device()
     no_pack16 = getenv("SRLA_MI355X_NO_PACK16") != nullptr;
     no_speculation = getenv("SRLA_MI355X_NO_SPECULATION") != nullptr;
     if (const char *e = getenv("SRLA_MI355X_TIE_TEST")) {
-        /* "rel,ltp,logscale,powscale": widens the near-tie thresholds and falsifies the device's log / x^-1/2, so that the
-         * host arbitration has real work to do (tests/test_gpu_ties.py) */
-        double a = 0, b = 0, c = 1, d = 1;
-        if (sscanf(e, "%lf,%lf,%lf,%lf", &a, &b, &c, &d) == 4) { tie_rel = a; tie_ltp = b; tie_logscale = c; tie_powscale = d; }
+        /* "rel,ltp,logscale,ltpbias": widens the near-tie thresholds and falsifies the device's log / its scaled LTP taps, so
+         * that the host arbitration has real work to do (tests/test_gpu_ties.py) */
+        double a = 0, b = 0, c = 1, d = 0;
+        if (sscanf(e, "%lf,%lf,%lf,%lf", &a, &b, &c, &d) == 4) { tie_rel = a; tie_ltp = b; tie_logscale = c; tie_ltpbias = d; }
     }
     timing = getenv("SRLA_MI355X_NO_TIMING") == nullptr;
     if (const char *e = getenv("SRLA_MI355X_TAIL_BOOST")) { unsigned a = 0, b = 0; if (sscanf(e, "%u,%u", &a, &b) == 2 && a >= 1) { tail_boost = a; tail_boost_jobs = b; } }

@@ -215,7 +215,7 @@ SrlaJobParams Impl::job_params(const Job &job, uint32_t channel_stride, bool lsh
     { static const char *e = getenv("SRLA_MI355X_K3_STOP"); jp.out_stride = e ? (uint32_t)atoi(e) : 0u; }   /* kernel timing experiments only */
 #endif
     jp.lshift_dev = lshift_on_device ? (d_or.as<uint32_t>() + 1) : nullptr;
-    jp.tie_rel = tie_rel; jp.tie_ltp = tie_ltp; jp.tie_logscale = tie_logscale; jp.tie_powscale = tie_powscale;
+    jp.tie_rel = tie_rel; jp.tie_ltp = tie_ltp; jp.tie_logscale = tie_logscale; jp.tie_ltpbias = tie_ltpbias;
     return jp;
 }
 

@@ -130,30 +130,41 @@ int Impl::arbitrate(Slot &s, uint32_t jobkey)
     }
     int mismatches = 0;
     std::vector<double> col(P + 1);
+    /* LTP entries first: an item whose taps the host overrules is filtered differently next time, so what the device
+     * decided about its LPC order in this run says nothing -- it is looked at again (and flagged again, if close) in the next */
+    std::vector<uint8_t> retaken(n_items, 0);
     for (uint32_t k = 0; k < count; k++) {
         const uint32_t item = list[k] & 0x7FFFFFFFu, kind = list[k] >> 31;
         if (item >= n_items) return -1;
-        if (kind == 0) {
-            uint32_t dev_order = 0;
-            if (bulk) {
-                for (uint32_t o = 0; o <= P; o++) col[o] = err[(size_t)o * n_items + item];
-                dev_order = orders[item];
-            } else {
-                if (hipMemcpy2D(col.data(), 8, s.d_err.as<double>() + item, n_items * 8, 8, P + 1, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-                if (hipMemcpy(&dev_order, reinterpret_cast<const uint8_t *>(s.d_results.as<SrlaItemResult>() + item) + offsetof(SrlaItemResult, lpc_order), 4,
-                              hipMemcpyDeviceToHost) != hipSuccess) return -1;
-            }
-            const SrlaItemDesc &it = s.job.items[item];
-            const uint32_t host_order = select_order(col.data(), P, geoms[it.geom].welch_comp, it.n, par.bits_per_sample);
-            if (host_order == dev_order) stats.num_tie_resolved++;
-            else { overrides[override_key(jobkey, item)].forced_order = (int32_t)host_order; stats.num_tie_overrides++; mismatches++; }
-        } else {
-            double td[8];
-            if (hipMemcpy(td, s.d_tie_data.as<double>() + 8 * (size_t)k, sizeof(td), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-            const uint32_t host_q = ltp_taps(td, par.ltp_order), dev_q = (uint32_t)td[7];
-            if (host_q == 0xFFFFFFFFu || host_q == dev_q) stats.num_tie_resolved++;
-            else { overrides[override_key(jobkey, item)].forced_ltp = 0x80000000u | host_q; stats.num_tie_overrides++; mismatches++; }
+        if (kind != 1) continue;
+        double td[8];
+        if (hipMemcpy(td, s.d_tie_data.as<double>() + 8 * (size_t)k, sizeof(td), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        const uint32_t host_q = ltp_taps(td, par.ltp_order), dev_q = (uint32_t)td[7];
+        if (host_q == 0xFFFFFFFFu || host_q == dev_q) stats.num_tie_resolved++;
+        else {
+            Override &ov = overrides[override_key(jobkey, item)];
+            ov.forced_ltp = 0x80000000u | host_q;
+            ov.forced_order = -1;
+            retaken[item] = 1;
+            stats.num_tie_overrides++; mismatches++;
         }
+    }
+    for (uint32_t k = 0; k < count; k++) {
+        const uint32_t item = list[k] & 0x7FFFFFFFu, kind = list[k] >> 31;
+        if (kind != 0 || retaken[item]) continue;
+        uint32_t dev_order = 0;
+        if (bulk) {
+            for (uint32_t o = 0; o <= P; o++) col[o] = err[(size_t)o * n_items + item];
+            dev_order = orders[item];
+        } else {
+            if (hipMemcpy2D(col.data(), 8, s.d_err.as<double>() + item, n_items * 8, 8, P + 1, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+            if (hipMemcpy(&dev_order, reinterpret_cast<const uint8_t *>(s.d_results.as<SrlaItemResult>() + item) + offsetof(SrlaItemResult, lpc_order), 4,
+                          hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        }
+        const SrlaItemDesc &it = s.job.items[item];
+        const uint32_t host_order = select_order(col.data(), P, geoms[it.geom].welch_comp, it.n, par.bits_per_sample);
+        if (host_order == dev_order) stats.num_tie_resolved++;
+        else { overrides[override_key(jobkey, item)].forced_order = (int32_t)host_order; stats.num_tie_overrides++; mismatches++; }
     }
     return mismatches;
 }

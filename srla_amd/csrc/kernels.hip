@@ -682,7 +682,7 @@ __global__ __launch_bounds__(WAVE) void srla_pitch_solve(SrlaJobParams jp, const
             double sum = am[i2][i2];
             for (int k = i2 - 1; k >= 0; k--) sum -= am[i2][k] * am[i2][k];
             if (sum <= 0.0) { ok = false; break; }
-            inv_diag[i2] = inv_sqrt_cr(sum) * jp.tie_powscale;   /* lpc.c:591: pow(sum, -0.5) of the platform libm */
+            inv_diag[i2] = inv_sqrt_cr(sum);                     /* lpc.c:591: pow(sum, -0.5) of the platform libm */
             for (int j = i2 + 1; j < dim; j++) {
                 sum = am[i2][j];
                 for (int k = i2 - 1; k >= 0; k--) sum -= am[i2][k] * am[j][k];
@@ -707,7 +707,7 @@ __global__ __launch_bounds__(WAVE) void srla_pitch_solve(SrlaJobParams jp, const
                 xs[i2] = sum * inv_diag[i2];
             }
             for (int i2 = 0; i2 < dim; i2++) {
-                const double scaled = xs[i2] * 32.0;
+                const double scaled = xs[i2] * 32.0 + jp.tie_ltpbias;   /* bias: 0.0 in production (tie tests) */
                 const double fr = fabs(scaled) + 0.5;
                 if (fabs(fr - floor(fr + 0.5)) < jp.tie_ltp && fabs(scaled) < 40.0) flags |= SRLA_ITEM_LTP_TIE;
                 int32_t c = (int32_t)round_half_away(scaled);

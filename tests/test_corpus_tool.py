@@ -1,0 +1,77 @@
+"""`srla_amd/srla_corpus`, the native corpus front end (tools/srla_codec/srla_codec.c:75-158 for many files,
+libs/wav/src/wav.c reader): WAV files of mixed formats in, one .srl per file out, each byte-equal to the oracle's stream;
+sharded deterministically over ranks without communication."""
+import hashlib
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import helpers
+from test_cli_wav import _write_wav
+
+TOOL = os.path.join(helpers.ROOT, "srla_amd", "srla_corpus")
+
+
+def _make_corpus(root):
+    files = {}
+    specs = [("a/one.wav", 2, 16, 48000, 90000, helpers.MUSIC), ("a/two.wav", 2, 16, 48000, 33001, helpers.VARIED),
+             ("b/three.wav", 1, 16, 44100, 50000, helpers.SINE), ("b/deep/four.wav", 2, 24, 48000, 40000, helpers.MUSIC),
+             ("five.WAV", 2, 16, 48000, 4097, helpers.NOISE), ("six.wav", 2, 8, 22050, 30000, helpers.VARIED),
+             ("seven.wav", 2, 16, 48000, 250000, helpers.MUSIC)]
+    for i, (rel, nch, bps, rate, n, kind) in enumerate(specs):
+        pcm = helpers.synth(kind, 300 + i, rate, nch, n, bps)
+        path = os.path.join(root, rel)
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        _write_wav(path, pcm, rate, bps, extensible=(i == 3), extra_chunk=(i == 1))
+        files[rel] = (pcm, bps, rate)
+    return files
+
+
+def test_tool_is_built_and_fails_loudly_without_a_gpu(tmp_path):
+    assert os.path.exists(TOOL), "srla_amd/srla_corpus is not built (run __graft_entry__.build())"
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    (tmp_path / "in").mkdir()
+    p = subprocess.run([TOOL, "-e", str(tmp_path / "in"), str(tmp_path / "out")], capture_output=True, text=True)
+    assert p.returncode != 0 and "no CPU fallback" in p.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [1, 2])
+def test_corpus_encodes_like_the_oracle(tmp_path, world):
+    files = _make_corpus(str(tmp_path / "in"))
+    cli = dict(preset=4, max_block=4096, divisions=2, ltp_order=3)
+    seen = {}
+    for rank in range(world):
+        man = str(tmp_path / ("manifest%d.json" % rank))
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+        p = subprocess.run([TOOL, "-e", "-m", "4", "-B", "4096", "-V", "2", "-P", "3", "--manifest", man, "--batch-samples", "100000",
+                            str(tmp_path / "in"), str(tmp_path / "out")], capture_output=True, text=True, env=env)
+        assert p.returncode == 0, p.stderr
+        assert "finished:" in p.stdout
+        for e in json.load(open(man))["files"]:
+            assert e["name"] not in seen and e["error"] == ""
+            seen[e["name"]] = e
+    assert sorted(seen) == sorted(files)                      # every file exactly once over the ranks
+    for rel, (pcm, bps, rate) in files.items():
+        want = helpers.Oracle(pcm.shape[0], bits_per_sample=bps, sampling_rate=rate, **cli).encode_whole(pcm)
+        got = np.fromfile(os.path.join(str(tmp_path / "out"), os.path.splitext(rel)[0] + ".srl"), dtype=np.uint8)
+        assert np.array_equal(got, want), rel
+        assert seen[rel]["bytes"] == want.size and seen[rel]["sha256"] == hashlib.sha256(want.tobytes()).hexdigest()
+
+
+@pytest.mark.gpu
+def test_bad_files_are_reported_not_fatal(tmp_path):
+    root = tmp_path / "in"
+    root.mkdir()
+    pcm = helpers.synth(helpers.MUSIC, 1, 48000, 2, 20000)
+    _write_wav(str(root / "good.wav"), pcm, 48000, 16)
+    (root / "bad.wav").write_bytes(b"RIFF\x00\x00\x00\x00WAVEjunk" + bytes(64))
+    p = subprocess.run([TOOL, "-e", str(root), str(tmp_path / "out")], capture_output=True, text=True)
+    assert p.returncode == 1 and "bad.wav" in p.stderr
+    want = helpers.Oracle(2, preset=4, max_block=4096, divisions=1).encode_whole(pcm)
+    assert np.array_equal(np.fromfile(str(tmp_path / "out" / "good.srl"), dtype=np.uint8), want)

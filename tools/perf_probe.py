@@ -40,7 +40,6 @@ else:
     out = (torch.empty(cap, dtype=torch.uint8).pin_memory().numpy() if mode == "pinned" else np.zeros(cap, np.uint8))
     planes = capi.planar_ptrs(src)
     run = lambda: L.SRLAEncoder_EncodeWhole(enc, planes, n, out.ctypes.data_as(C.c_void_p), cap, C.byref(sz), None)
-quiet = os.environ.pop("SRLA_MI355X_TIMELINE", None)
 for r in range(reps):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
