@@ -7,13 +7,13 @@
  *                    reference hands to SRLAEncoder_EncodeWhole)
  *   main thread      gathers the loaded files of one format into batches and calls SRLAMI355X_EncodeBatch (windows of
  *                    different files share the device jobs); one encoder handle per format, kept for the whole corpus
- *   writer thread    writes <out>/<relative name>.srl, optionally hashing the streams for the manifest
+ *   writer threads   write <out>/<relative name>.srl, optionally hashing the streams for the manifest
  *
  * Same options, defaults and output-buffer rule (2 x the input file size) as `srla -e`.  One process per GPU: with
  * RANK / WORLD_SIZE / LOCAL_RANK in the environment (torchrun, or --rank / --world) every rank encodes the files the
  * deterministic longest-first assignment gives it (the same one as srla_amd/corpus.py) -- no communication at all.
  *
- *   srla_corpus -e [-m 4] [-B 4096] [-V 1] [-L 4] [-P 0] [--manifest FILE] [--batch-samples N] [--readers N] IN_DIR OUT_DIR
+ *   srla_corpus -e [-m 4] [-B 4096] [-V 1] [-L 4] [-P 0] [--manifest FILE [--sha256]] [--batch-samples N] [--readers N] [--writers N] IN_DIR OUT_DIR
  */
 #include <algorithm>
 #include <atomic>
@@ -185,6 +185,14 @@ public:
         out = std::move(q_.front()); q_.pop_front();
         return true;
     }
+    /* without waiting: 1 = got one, 0 = nothing there right now, -1 = closed and drained */
+    int try_pop(T &out)
+    {
+        std::lock_guard<std::mutex> l(m_);
+        if (q_.empty()) return closed_ ? -1 : 0;
+        out = std::move(q_.front()); q_.pop_front();
+        return 1;
+    }
     void close() { { std::lock_guard<std::mutex> l(m_); closed_ = true; } cv_.notify_all(); }
 private:
     std::mutex m_; std::condition_variable cv_; std::deque<T> q_; bool closed_ = false;
@@ -192,7 +200,8 @@ private:
 
 struct Encoded {
     std::unique_ptr<Pcm> pcm;
-    std::vector<uint8_t> data;
+    std::unique_ptr<uint8_t[]> data;       /* not value-initialised: the pages are touched by whoever writes them */
+    size_t cap = 0;
     uint32_t size = 0;
     SRLAApiResult rc = SRLA_APIRESULT_OK;
 };
@@ -202,13 +211,14 @@ struct Options {
     uint32_t max_block = 4096;
     std::string in_dir, out_dir, manifest;
     uint64_t batch_samples = 96ull << 20;   /* sample frames per EncodeBatch call */
-    unsigned readers = 4;
+    unsigned readers = 4, writers = 2;
+    bool sha = false, verbose = false;
     int rank = 0, world = 1, local_rank = 0;
 };
 
 int usage()
 {
-    fprintf(stderr, "usage: srla_corpus -e [-m 4] [-B 4096] [-V 1] [-L 4] [-P 0] [--manifest FILE] [--batch-samples N] [--readers N] IN_DIR OUT_DIR\n");
+    fprintf(stderr, "usage: srla_corpus -e [-m 4] [-B 4096] [-V 1] [-L 4] [-P 0] [--manifest FILE] [--sha256] [--batch-samples N] [--readers N] [--writers N] [--verbose] IN_DIR OUT_DIR\n");
     return 1;
 }
 
@@ -234,6 +244,9 @@ int main(int argc, char **argv)
         else if (a == "--manifest") o.manifest = val();
         else if (a == "--batch-samples") o.batch_samples = strtoull(val(), nullptr, 10);
         else if (a == "--readers") o.readers = (unsigned)std::max(1, atoi(val()));
+        else if (a == "--writers") o.writers = (unsigned)std::max(1, atoi(val()));
+        else if (a == "--sha256") o.sha = true;
+        else if (a == "--verbose") o.verbose = true;
         else if (a == "--rank") o.rank = atoi(val());
         else if (a == "--world") o.world = std::max(1, atoi(val()));
         else if (a == "--device") o.local_rank = atoi(val());
@@ -306,30 +319,34 @@ int main(int argc, char **argv)
     Queue<std::unique_ptr<Encoded>> finished;
     struct Entry { std::string rel; uint64_t in_bytes, samples; uint32_t out_bytes; std::string sha, error; };
     std::vector<Entry> manifest;
-    std::thread writer([&] {
-        std::unique_ptr<Encoded> e;
-        while (finished.pop(e)) {
-            Entry en{ e->pcm->rel, e->pcm->file_size, e->pcm->n, 0, "", e->pcm->error };
-            if (en.error.empty() && e->rc != SRLA_APIRESULT_OK) en.error = "encode failed: " + std::to_string((int)e->rc);
-            if (en.error.empty()) {
-                fs::path out = fs::path(o.out_dir) / fs::path(e->pcm->rel);
-                out.replace_extension(".srl");
-                std::error_code ec;
-                fs::create_directories(out.parent_path(), ec);
-                FILE *fp = fopen(out.string().c_str(), "wb");
-                if (!fp || fwrite(e->data.data(), 1, e->size, fp) != e->size) en.error = "cannot write " + out.string();
-                if (fp) fclose(fp);
-                en.out_bytes = e->size;
-                if (!o.manifest.empty()) { Sha256 s; s.update(e->data.data(), e->size); en.sha = s.hex(); }
+    std::mutex manifest_m;
+    std::vector<std::thread> writers;
+    for (unsigned t = 0; t < o.writers; t++)
+        writers.emplace_back([&] {
+            std::unique_ptr<Encoded> e;
+            while (finished.pop(e)) {
+                Entry en{ e->pcm->rel, e->pcm->file_size, e->pcm->n, 0, "", e->pcm->error };
+                if (en.error.empty() && e->rc != SRLA_APIRESULT_OK) en.error = "encode failed: " + std::to_string((int)e->rc);
+                if (en.error.empty()) {
+                    fs::path out = fs::path(o.out_dir) / fs::path(e->pcm->rel);
+                    out.replace_extension(".srl");
+                    std::error_code ec;
+                    fs::create_directories(out.parent_path(), ec);
+                    FILE *fp = fopen(out.string().c_str(), "wb");
+                    if (!fp || fwrite(e->data.get(), 1, e->size, fp) != e->size) en.error = "cannot write " + out.string();
+                    if (fp) fclose(fp);
+                    en.out_bytes = e->size;
+                    if (o.sha) { Sha256 s; s.update(e->data.get(), e->size); en.sha = s.hex(); }
+                }
+                const int64_t bytes = (int64_t)e->pcm->nch * e->pcm->n * 4;
+                e.reset();
+                in_flight_bytes.fetch_sub(bytes);
+                { std::lock_guard<std::mutex> l(flight_m); }
+                flight_cv.notify_all();
+                std::lock_guard<std::mutex> l(manifest_m);
+                manifest.push_back(en);
             }
-            const int64_t bytes = (int64_t)e->pcm->nch * e->pcm->n * 4;
-            e.reset();
-            in_flight_bytes.fetch_sub(bytes);
-            { std::lock_guard<std::mutex> l(flight_m); }
-            flight_cv.notify_all();
-            manifest.push_back(en);
-        }
-    });
+        });
 
     /* main: batches per format */
     struct Key { uint32_t nch, bps, rate; bool operator<(const Key &k) const { return std::tie(nch, bps, rate) < std::tie(k.nch, k.bps, k.rate); } };
@@ -370,12 +387,20 @@ int main(int argc, char **argv)
         std::vector<SRLAApiResult> res(ns, SRLA_APIRESULT_NG);
         for (uint32_t i = 0; i < ns; i++) {
             outs[i].reset(new Encoded());
-            outs[i]->data.resize(2 * (size_t)files[i]->file_size);             /* srla_codec.c:125-129 */
+            outs[i]->cap = 2 * (size_t)files[i]->file_size;                    /* srla_codec.c:125-129 */
+            outs[i]->data.reset(new uint8_t[outs[i]->cap]);
             inputs[i] = files[i]->planes.data(); nsmp[i] = files[i]->n;
-            datas[i] = outs[i]->data.data(); caps[i] = (uint32_t)std::min<uint64_t>(outs[i]->data.size(), 0xFFFFFFFFull);
+            datas[i] = outs[i]->data.get(); caps[i] = (uint32_t)std::min<uint64_t>(outs[i]->cap, 0xFFFFFFFFull);
         }
         SRLAApiResult rc = SRLA_APIRESULT_NG;
+        const auto tb = std::chrono::steady_clock::now();
         if (enc) rc = SRLAMI355X_EncodeBatch(enc, ns, inputs.data(), nsmp.data(), datas.data(), caps.data(), sizes_out.data(), res.data());
+        if (o.verbose) {
+            uint64_t tot = 0; for (uint32_t i = 0; i < ns; i++) tot += nsmp[i];
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb).count();
+            fprintf(stderr, "[srla_corpus] batch of %u files, %llu samples: %.2f ms (%.0f Msamples/s), at %.3f s\n", ns, (unsigned long long)tot, ms, (double)tot / ms / 1e3,
+                    std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+        }
         if (rc != SRLA_APIRESULT_OK && rc != SRLA_APIRESULT_INSUFFICIENT_BUFFER) for (auto &r : res) r = rc;
         for (uint32_t i = 0; i < ns; i++) {
             outs[i]->size = sizes_out[i]; outs[i]->rc = res[i];
@@ -386,7 +411,17 @@ int main(int argc, char **argv)
     };
     {
         std::unique_ptr<Pcm> f;
-        while (loaded.pop(f)) {
+        for (;;) {
+            /* a batch goes out when it is full -- or when the readers have nothing more ready: the GPU should not wait for
+             * a batch to fill up while files are still being read */
+            const int got = loaded.try_pop(f);
+            if (got < 0) break;
+            if (got == 0) {
+                const Key *fullest = nullptr; uint64_t most = 0;
+                for (auto &kv : pending_samples) if (kv.second > most) { most = kv.second; fullest = &kv.first; }
+                if (fullest) { const Key k = *fullest; flush(k); continue; }
+                if (!loaded.pop(f)) break;
+            }
             if (!f->error.empty()) {
                 fprintf(stderr, "srla_corpus: %s: %s\n", f->path.c_str(), f->error.c_str());
                 failures++;
@@ -406,7 +441,7 @@ int main(int argc, char **argv)
     }
     for (auto &t : readers) t.join();
     finished.close();
-    writer.join();
+    for (auto &t : writers) t.join();
     for (auto &kv : encoders) if (kv.second) SRLAEncoder_Destroy(kv.second);
 
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

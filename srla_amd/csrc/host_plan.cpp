@@ -238,8 +238,9 @@ uint32_t Impl::windows_per_job(bool search) const
  * is cut once more so that the LAST job is small -- after it nothing else runs on the wide stream, so its pricing, block
  * assembly and stream-out are pure latency (0.27 ms for a full job, 8 % of a 600 s stream's time); the two tail jobs have
  * buffer sets of their own, so that repeated calls of equal length keep finding their descriptor tables cached.
- * Several streams: jobs are filled greedily in stream order, a stream is cut at a window boundary when the job is full,
- * segments start on multiples of 16 samples of the job's planes (aligned 16-byte loads, 32-byte aligned staging stores). */
+ * Several streams: whole jobs first, then the remainders packed greedily in stream order (a remainder is cut at a window
+ * boundary when the job is full); segments start on multiples of 16 samples of the job's planes (aligned 16-byte loads,
+ * 32-byte aligned staging stores). */
 void Impl::plan_jobs(std::vector<JobPlan> &plan, bool search)
 {
     plan.clear();
@@ -265,6 +266,19 @@ void Impl::plan_jobs(std::vector<JobPlan> &plan, bool search)
         }
         return;
     }
+    /* First the parts of the streams that fill whole jobs -- one segment of job_len samples each: jobs of ONE shape, so after
+     * the first few every job finds its descriptor tables built and uploaded --, then what is left of every stream, packed
+     * together.  A stream's segments stay in order, which is all its device-resident output position needs. */
+    for (uint32_t i = 0; i < sx.size(); i++) {
+        const uint64_t nfull = sx[i].body / job_len;
+        for (uint64_t k = 0; k < nfull; k++) {
+            JobPlan jp;
+            jp.segs.push_back({ i, (uint32_t)(k * job_len), (uint32_t)job_len, 0u });
+            jp.total = al16(job_len);
+            jp.slot = (uint32_t)(plan.size() % kSlots);
+            plan.push_back(jp);
+        }
+    }
     JobPlan cur;
     auto close = [&]() {
         if (cur.segs.empty()) return;
@@ -273,7 +287,8 @@ void Impl::plan_jobs(std::vector<JobPlan> &plan, bool search)
         cur = JobPlan();
     };
     for (uint32_t i = 0; i < sx.size(); i++) {
-        uint32_t s0 = 0, remaining = sx[i].body;
+        const uint64_t nfull = sx[i].body / job_len;
+        uint32_t s0 = (uint32_t)(nfull * job_len), remaining = sx[i].body - s0;
         while (remaining > 0) {
             const uint64_t room = (job_len > cur.total) ? job_len - cur.total : 0;
             uint32_t take = remaining;

@@ -49,7 +49,7 @@ def test_corpus_encodes_like_the_oracle(tmp_path, world):
     for rank in range(world):
         man = str(tmp_path / ("manifest%d.json" % rank))
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
-        p = subprocess.run([TOOL, "-e", "-m", "4", "-B", "4096", "-V", "2", "-P", "3", "--manifest", man, "--batch-samples", "100000",
+        p = subprocess.run([TOOL, "-e", "-m", "4", "-B", "4096", "-V", "2", "-P", "3", "--manifest", man, "--sha256", "--batch-samples", "100000",
                             str(tmp_path / "in"), str(tmp_path / "out")], capture_output=True, text=True, env=env)
         assert p.returncode == 0, p.stderr
         assert "finished:" in p.stdout
