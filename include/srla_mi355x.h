@@ -146,6 +146,18 @@ SRLAApiResult SRLAMI355X_EncodeWholeDevice(
     struct SRLAEncoder *encoder, const int32_t *d_input, uint32_t channel_stride, uint32_t num_samples,
     uint8_t *data, uint32_t data_size, uint32_t *output_size, SRLAEncoder_EncodeBlockCallback encode_callback);
 
+/* A RANGE of a stream's look-ahead windows, without the stream header: exactly the bytes SRLAEncoder_EncodeWhole
+ * (libs/srla_encoder/src/srla_encoder.c:1756-1783) writes for these windows when the whole stream has the offset left
+ * shift `offset_lshift` (the trailing zeros of the OR of ALL its samples, srla_utility.c:177).  With it one long stream
+ * is sharded over several GPUs: cut it at multiples of the look-ahead (num_lookahead_samples; the maximum block size when
+ * min == max), give every process / GPU a contiguous range, concatenate the results in order behind the 30-byte header
+ * (SRLAEncoder_EncodeHeader) -- srla_amd/multigpu.py does exactly that with one rank per GPU.  input points at the
+ * first sample of the range.  is_stream_end: the range ends the stream (only then may it hold a partial window; give it
+ * the stream's last two windows at least, the reference's analysis of an odd-length last window looks back one block). */
+SRLAApiResult SRLAMI355X_EncodeWindows(
+    struct SRLAEncoder *encoder, const int32_t *const *input, uint32_t num_samples, uint32_t offset_lshift, int is_stream_end,
+    uint8_t *data, uint32_t data_size, uint32_t *output_size);
+
 /* Many streams in one call -- the way to encode a corpus of short files: windows of different streams share the device
  * jobs, so a 10 s file costs what 10 s of a long stream cost instead of a whole pipeline fill and drain of its own.
  * Every stream is what SRLAEncoder_EncodeWhole would write for it (tools/srla_codec/srla_codec.c:134 called once per

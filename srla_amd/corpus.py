@@ -25,10 +25,12 @@ def assign(sample_counts, world):
     return owner
 
 
-def encode_corpus(encode_fn, files, rank=0, world=1, group=None):
+def encode_corpus(encode_fn, files, rank=0, world=1, group=None, keep_streams=True):
     """files: list of (name, loader) where loader() -> int32 [ch][n] array, or (name, array).
     encode_fn(pcm) -> uint8 array (.srl bytes).  Every rank returns the full manifest
-    [{name, owner, samples, bytes, sha256}] in file order; `streams` holds this rank's own outputs."""
+    [{name, owner, samples, bytes, sha256, error}] in file order; `streams` holds this rank's own outputs (keep_streams=False:
+    nothing is retained -- a large corpus must not pile up in host memory).  A file that fails (unreadable WAV, encoder error)
+    is recorded in the manifest with its error and the rank goes on: every rank must reach the final exchange."""
     counts = []
     for name, src in files:
         counts.append(int(src.shape[1]) if hasattr(src, "shape") else int(getattr(src, "num_samples")))
@@ -38,11 +40,16 @@ def encode_corpus(encode_fn, files, rank=0, world=1, group=None):
     for i, (name, src) in enumerate(files):
         if owner[i] != rank:
             continue
-        pcm = src if hasattr(src, "shape") else src()
-        data = np.ascontiguousarray(encode_fn(pcm), dtype=np.uint8)
-        streams[name] = data
+        try:
+            pcm = src if hasattr(src, "shape") else src()
+            data = np.ascontiguousarray(encode_fn(pcm), dtype=np.uint8)
+        except Exception as e:                      # noqa: BLE001 -- whatever went wrong with this file stays with this file
+            mine.append(dict(index=i, name=name, owner=rank, samples=counts[i], bytes=0, sha256="", error="%s: %s" % (type(e).__name__, e)))
+            continue
+        if keep_streams:
+            streams[name] = data
         mine.append(dict(index=i, name=name, owner=rank, samples=counts[i], bytes=int(data.size),
-                         sha256=hashlib.sha256(data.tobytes()).hexdigest()))
+                         sha256=hashlib.sha256(data.tobytes()).hexdigest(), error=""))
     if world > 1:
         import torch.distributed as dist
         gathered = [None] * world
@@ -59,6 +66,7 @@ def main_cli(lib, in_dir, out_dir, cli):
     below IN is encoded to OUT/<relative name>.srl by the rank that owns it; rank 0 prints the manifest summary."""
     import ctypes as C
     import os
+    import sys
     import time
 
     from . import wavio
@@ -136,7 +144,7 @@ def main_cli(lib, in_dir, out_dir, cli):
 
     t0 = time.perf_counter()
     try:
-        manifest, _ = encode_corpus(encode_path, [(p, Src(p)) for p in paths], rank=rank, world=world, group=group)
+        manifest, _ = encode_corpus(encode_path, [(p, Src(p)) for p in paths], rank=rank, world=world, group=group, keep_streams=False)
         for w in writes:
             w.result()
     finally:
@@ -146,6 +154,9 @@ def main_cli(lib, in_dir, out_dir, cli):
             lib.destroy(enc)
     dt = time.perf_counter() - t0
     if rank == 0:
+        for e in manifest:
+            if e.get("error"):
+                print("failed: %s: %s" % (e["name"], e["error"]), file=sys.stderr)
         total_out = sum(e["bytes"] for e in manifest)
         total_in = sum(os.path.getsize(e["name"]) for e in manifest)
         print("finished: %d files, %d -> %d (%6.2f %%) in %.2f s on %d GPU(s)"
@@ -153,4 +164,4 @@ def main_cli(lib, in_dir, out_dir, cli):
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
-    return 0
+    return 1 if any(e.get("error") for e in manifest) else 0

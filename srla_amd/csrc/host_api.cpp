@@ -213,6 +213,27 @@ SRLAApiResult SRLAMI355X_EncodeWholeDevice(struct SRLAEncoder *encoder, const in
                       im->search_enabled());
 }
 
+SRLAApiResult SRLAMI355X_EncodeWindows(struct SRLAEncoder *encoder, const int32_t *const *input, uint32_t num_samples,
+                                       uint32_t offset_lshift, int is_stream_end, uint8_t *data, uint32_t data_size, uint32_t *output_size)
+{
+    Impl *im = impl_of(encoder);
+    if (im == nullptr || input == NULL || data == NULL || output_size == NULL || offset_lshift >= 32) return SRLA_APIRESULT_INVALID_ARGUMENT;
+    if (!im->set_parameter) return SRLA_APIRESULT_PARAMETER_NOT_SET;
+    if (num_samples == 0) return SRLA_APIRESULT_INVALID_FORMAT;
+    const bool search = im->search_enabled();
+    const uint32_t window_len = search ? im->par.num_lookahead_samples : im->par.max_num_samples_per_block;
+    if (!is_stream_end && (num_samples % window_len) != 0) return SRLA_APIRESULT_INVALID_ARGUMENT;   /* only the stream's end may hold a partial window */
+    if (!im->init_device()) return SRLA_APIRESULT_NG;
+    StreamCtx st;
+    st.host_in = input; st.num_samples = num_samples; st.data = data; st.data_size = data_size; st.with_header = false;
+    st.lshift = offset_lshift; st.lshift_final = true;
+    im->sx.clear();
+    im->sx.push_back(st);
+    const SRLAApiResult rc = im->encode_streams(search);
+    if (rc == SRLA_APIRESULT_OK) *output_size = im->sx[0].write_off;
+    return rc;
+}
+
 SRLAApiResult SRLAMI355X_EncodeBatch(struct SRLAEncoder *encoder, uint32_t num_streams, const int32_t *const *const *inputs,
                                      const uint32_t *num_samples, uint8_t *const *data, const uint32_t *data_size,
                                      uint32_t *output_size, SRLAApiResult *results)

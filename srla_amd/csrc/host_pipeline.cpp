@@ -632,8 +632,8 @@ SRLAApiResult Impl::encode_streams(bool search)
         st.write_off = st.with_header ? SRLA_HEADER_SIZE : 0u;
         st.progress = 0; st.pass_started = false; st.rc = SRLA_APIRESULT_OK;
         st.or_mask = 0; st.or_covered = 0; st.lshift_spec = false; st.lshift_on_device = false;
-        if (!st.with_header) { st.lshift = offset_lshift; st.lshift_final = true; }
-        else if (st.lshift_final) { /* known (second attempt after a failed speculation) */ }
+        if (st.lshift_final) { /* known: given by the caller (EncodeWindows), or the second attempt after a failed speculation */ }
+        else if (!st.with_header) { st.lshift = offset_lshift; st.lshift_final = true; }   /* block calls: encoder->header.offset_lshift */
         else if (st.d_in) {
             /* offset left shift: OR of every sample (srla_utility.c:177-203) on the device, without a host round trip: the
              * jobs read the shift from device memory */

@@ -67,3 +67,16 @@ def test_two_ranks_produce_the_single_process_result():
         assert not (owned & set(mine))
         owned |= set(mine)
     assert owned == {name for name, _ in FILES}
+
+
+def test_a_failing_file_is_recorded_and_the_rest_goes_on():
+    files = [(name, _make(spec)) for name, spec in FILES[:3]]
+
+    def enc(pcm):
+        if pcm.shape[1] == files[1][1].shape[1]:
+            raise ValueError("broken file")
+        return _encode(pcm)
+
+    manifest, streams = corpus.encode_corpus(enc, files, 0, 1, keep_streams=False)
+    assert [bool(e["error"]) for e in manifest] == [False, True, False] and streams == {}
+    assert manifest[0]["sha256"] == hashlib.sha256(_encode(files[0][1]).tobytes()).hexdigest()

@@ -523,3 +523,34 @@ def test_handles_of_several_threads_encode_concurrently(product):
     assert not errs, errs
     for i in range(len(files)):
         assert np.array_equal(out[i], want[i]), i
+
+
+def test_too_few_job_buffer_sets_are_refused_not_raced(product, monkeypatch):
+    """SRLA_MI355X_SLOTS below the pipeline depth + 1 would reuse a buffer set before its job is collected: such values are
+    ignored (message on stderr) and the stream still comes out right."""
+    monkeypatch.setenv("SRLA_MI355X_JOB_SAMPLES", "65536")
+    cli = dict(preset=4, max_block=4096, divisions=1)
+    pcm = helpers.synth(helpers.MUSIC, 55, 48000, 2, 1_000_000)
+    want = helpers.Oracle(2, **cli).encode_whole(pcm)
+    for slots in ("2", "3", "5"):
+        monkeypatch.setenv("SRLA_MI355X_SLOTS", slots)
+        assert np.array_equal(product.encode(pcm, **cli), want), slots
+
+
+def test_wrong_shift_guess_that_overflows_the_buffer_is_retried(product, monkeypatch):
+    """Host input without callback is encoded with the offset shift of its FIRST job while the OR of the rest is still being
+    gathered.  16-bit audio in a 24-bit container behind leading digital silence: the guess (0) makes the stream much larger
+    than the true shift (8) does -- too large for a buffer the right stream fits; the library must notice and encode again
+    instead of reporting INSUFFICIENT_BUFFER."""
+    monkeypatch.setenv("SRLA_MI355X_JOB_SAMPLES", "65536")
+    cli = dict(preset=4, max_block=4096, divisions=1)
+    pcm = helpers.synth(helpers.NOISE, 56, 48000, 2, 400_000) << 8
+    pcm[:, :100_000] = 0
+    want = helpers.Oracle(2, bits_per_sample=24, **cli).encode_whole(pcm)
+    assert want[24] == 8
+    cfg, par = capi.cli_setup(2, 24, 48000, **cli)
+    enc = product.create(cfg)
+    assert product.set_parameter(enc, par) == capi.OK
+    rc, got = product.encode_whole(enc, pcm, cap=int(want.size * 1.1))
+    product.destroy(enc)
+    assert rc == capi.OK and np.array_equal(got, want)
