@@ -1102,10 +1102,10 @@ int oracle_dijkstra(const double *adj, uint32_t n, uint32_t start, uint32_t goal
 {
     /* srla_encoder.c:249-307: dense O(n^2) Dijkstra, lowest index wins ties, the relaxation
      * also visits settled nodes, strict comparisons throughout. */
-    double cost[64];
-    uint8_t used[64];
+    double cost[ORACLE_MAX_NODES];
+    uint8_t used[ORACLE_MAX_NODES];
     uint32_t i, target = start;
-    if (n > 64) return -1;
+    if (n > ORACLE_MAX_NODES) return -1;
     for (i = 0; i < n; i++) { used[i] = 0; path[i] = ~0u; cost[i] = BIG_WEIGHT; }
     cost[start] = 0.0;
     for (;;) {
@@ -1130,10 +1130,10 @@ int oracle_search_partitions(struct Oracle *o, const int32_t *const *input, uint
     /* srla_encoder.c:310-424 */
     const uint32_t minb = o->cfg.min_block, maxb = o->cfg.max_block, nch = o->cfg.num_channels;
     const uint32_t nodes = ((n + minb - 1) / minb) + 1;
-    double adj[64 * 64];
-    uint32_t path[64];
+    static double adj[ORACLE_MAX_NODES * ORACLE_MAX_NODES];   /* test infrastructure: one encoder at a time */
+    uint32_t path[ORACLE_MAX_NODES];
     uint32_t i, j, ch, count, node;
-    if (nodes > 64) return -1;
+    if (nodes > ORACLE_MAX_NODES) return -1;
     for (i = 0; i < nodes * nodes; i++) adj[i] = BIG_WEIGHT;
     for (i = 0; i < nodes; i++)
         for (j = i + 1; j < nodes; j++) {
@@ -1196,7 +1196,7 @@ int oracle_encode_whole(struct Oracle *o, const int32_t *const *input, uint32_t 
             if (oracle_encode_block(o, ptr, count, data + offset, data_size - offset, &wrote) != 0) return -1;
         } else {
             /* srla_encoder.c:1646-1698: search, then encode every partition again */
-            uint32_t parts[64], nparts = 0, k, done = 0;
+            uint32_t parts[ORACLE_MAX_NODES], nparts = 0, k, done = 0;
             if (oracle_search_partitions(o, ptr, count, &nparts, parts) != 0) return -1;
             for (k = 0; k < nparts; k++) {
                 const int32_t *bp[ORACLE_MAX_CHANNELS];

@@ -112,7 +112,7 @@ SRLAApiResult SRLAEncoder_SetEncodeParameter(struct SRLAEncoder *encoder, const 
     /* limits of this implementation (documented in DESIGN.md) */
     if (p->num_channels > SRLA_MAX_CH) return SRLA_APIRESULT_INSUFFICIENT_BUFFER;
     if (p->max_num_samples_per_block > SRLA_MAX_FFT) {
-        fprintf(stderr, "[srla-mi355x] max block size %u exceeds the LDS-resident FFT limit of %u samples\n",
+        fprintf(stderr, "[srla-mi355x] max block size %u exceeds this implementation's limit of %u samples\n",
                 p->max_num_samples_per_block, SRLA_MAX_FFT);
         return SRLA_APIRESULT_INSUFFICIENT_BUFFER;
     }

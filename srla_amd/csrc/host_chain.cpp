@@ -71,7 +71,7 @@ void Impl::chain_build(uint32_t jobidx, const Job &job, ChainJob &cj)
         ai.lshift = it.lshift;
         return ai;
     };
-    auto cls_of = [](uint32_t nfft) { return (nfft <= 1024u) ? 0u : ((nfft <= 2048u) ? 1u : ((nfft <= 4096u) ? 2u : 3u)); };
+    auto cls_of = [](uint32_t nfft) { return (nfft <= 1024u) ? 0u : ((nfft <= 2048u) ? 1u : ((nfft <= 4096u) ? 2u : ((nfft <= 8192u) ? 3u : ((nfft <= 16384u) ? 4u : 5u)))); };
     cj.select.assign(std::max<size_t>(1, job.items.size()), 0xFFFFFFFFu);
     cj.rounds = 1;
     for (const ChainCall &c : chain_calls) {
@@ -138,6 +138,11 @@ bool Impl::chain_stage_a(Slot &s, uint32_t jobidx, const ChainJob &cj)
             bool any = false;
             for (; li < cj.launches.size() && cj.launches[li].round == r && cj.launches[li].pass == (uint32_t)pass; li++) {
                 const ChainLaunch &l = cj.launches[li];
+                if (l.cls >= 4)
+                    rc |= srla_launch_autocorr_big(W, &jp, s.in_cur, d_tw.p, (uint32_t)pass, s.d_results.as<SrlaItemResult>(), s.d_lags.as<double>(), nullptr,
+                                                   d_chain_list[jobidx].as<SrlaAutocorrItem>() + l.first, l.count, l.cls == 4 ? 16384u : 32768u, nullptr, nullptr,
+                                                   d_chain_pool.as<double>(), d_chain_tab.as<uint32_t>(), s.d_big_scratch.p, SRLA_BIG_GROUPS);
+                else
                 rc |= srla_launch_autocorr(W, kClass[l.cls], &jp, s.in_cur, s.d_items.as<SrlaItemDesc>(), d_geoms.as<SrlaGeom>(), d_tw.p,
                                            (uint32_t)pass, s.d_results.as<SrlaItemResult>(), s.d_lags.as<double>(), nullptr,
                                            d_chain_list[jobidx].as<SrlaAutocorrItem>() + l.first, l.count, nullptr, nullptr,

@@ -43,7 +43,8 @@
 #include "kernels.h"
 
 #define SRLA_HANDLE_MAGIC 0x53524C41u /* 'SRLA' */
-#define SRLA_MAX_FFT      8192u       /* largest block the LDS-resident FFT handles */
+#define SRLA_MAX_FFT      32768u      /* largest block (above 8192 samples: the global-memory slow paths of kernels.hip) */
+#define SRLA_BIG_GROUPS   384u        /* persistent workgroups (scratch regions) of srla_autocorr_big */
 
 struct SRLAEncoder {
     uint32_t magic;
@@ -88,7 +89,9 @@ struct Job {
     uint64_t res_elems = 0;
     uint64_t analyzed_samples = 0;
     std::vector<SrlaAutocorrItem> class_index; /* the items grouped by FFT-size class (srla_autocorr launches per class) */
-    uint32_t class_first[4] = {}, class_count[4] = {};   /* N' <= 1024, 2048, 4096, 8192 */
+    uint32_t class_first[6] = {}, class_count[6] = {};   /* N' <= 1024, 2048, 4096, 8192, 16384, 32768 */
+    std::vector<uint32_t> big_items;  /* items of more than 8192 samples (srla_residual_cost_big) */
+    uint32_t big_max_n = 0;
     uint64_t key = 0;                 /* geometry signature: equal keys => identical descriptor tables */
     bool uploaded = false;            /* the slot's device copies match the tables above */
 };
@@ -106,6 +109,7 @@ struct Slot {
     DevBuf d_input16;                    /* host input of at most 16 bits crosses PCIe as int16 and is widened into d_input */
     DevBuf d_input, d_items, d_cands, d_windows, d_results, d_res_ws, d_blocks, d_block_off, d_scratch, d_dbg, d_lags, d_err, d_class_index, d_stream;
     DevBuf d_segs, d_seg_ctl;            /* SrlaSegDesc per segment; device-side segment records of srla_block_offsets */
+    DevBuf d_big_scratch, d_big_items;   /* blocks above 8192 samples: FFT scratch in global memory, indices of the big items */
     DevBuf d_ties, d_tie_data;           /* near-tie list of the job (count + entries), 8 doubles per entry for LTP entries */
     PinBuf h_in, h_stream, h_info;       /* h_info: SrlaJobInfo, the per-window byte counts, SrlaSegInfo per segment */
     PinBuf h_segs;                       /* host copy of the segment table (uploaded per job) */

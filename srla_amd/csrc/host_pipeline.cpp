@@ -38,7 +38,7 @@ Impl::~Impl()
             s.d_input16.release();
             DevBuf *db[] = { &s.d_input, &s.d_items, &s.d_cands, &s.d_windows, &s.d_results, &s.d_res_ws,
                              &s.d_blocks, &s.d_block_off, &s.d_scratch, &s.d_dbg, &s.d_lags, &s.d_err, &s.d_class_index, &s.d_stream,
-                             &s.d_segs, &s.d_seg_ctl, &s.d_ties, &s.d_tie_data };
+                             &s.d_segs, &s.d_seg_ctl, &s.d_ties, &s.d_tie_data, &s.d_big_scratch, &s.d_big_items };
             for (auto *b : db) b->release();
             PinBuf *pb[] = { &s.h_in, &s.h_stream, &s.h_info, &s.h_segs };
             for (auto *b : pb) b->release();
@@ -313,6 +313,13 @@ bool Impl::prepare_job(Slot &s, bool want_dbg)
         const SrlaJobParams probe = job_params(job, s.stride_cur, false);
         if (srla_pack_needs_scratch(&probe) && !s.d_scratch.ensure(bound)) return false;
     }
+    if (!job.big_items.empty()) {
+        const uint32_t nfft_max = job.big_max_n > 16384u ? 32768u : 16384u;
+        if (!s.d_big_scratch.ensure((size_t)SRLA_BIG_GROUPS * nfft_max * 16u)) return false;
+        const void *pb = s.d_big_items.p;
+        if (!s.d_big_items.ensure(job.big_items.size() * 4)) return false;
+        if (pb != s.d_big_items.p) job.uploaded = false;
+    }
     if (want_dbg && !s.d_dbg.ensure(std::max<size_t>(1, n_items) * SRLA_DBG_STRIDE * sizeof(double))) return false;
     const uint32_t lag_rows = std::max<uint32_t>(par.ltp_order > 0 ? SRLA_LTP_LAGS : 0u, preset_order() + 1);
     if (!s.d_lags.ensure((size_t)lag_rows * std::max<size_t>(1, n_items) * sizeof(double))) return false;
@@ -323,6 +330,7 @@ bool Impl::prepare_job(Slot &s, bool want_dbg)
         if (n_items) HIP_OK(hipMemcpyAsync(s.d_class_index.p, job.class_index.data(), n_items * sizeof(SrlaAutocorrItem), hipMemcpyHostToDevice, W));
         HIP_OK(hipMemcpyAsync(s.d_cands.p, job.cands.data(), n_cands * sizeof(SrlaCandDesc), hipMemcpyHostToDevice, W));
         HIP_OK(hipMemcpyAsync(s.d_windows.p, job.windows.data(), n_win * sizeof(SrlaWindowDesc), hipMemcpyHostToDevice, W));
+        if (!job.big_items.empty()) HIP_OK(hipMemcpyAsync(s.d_big_items.p, job.big_items.data(), job.big_items.size() * 4, hipMemcpyHostToDevice, W));
         job.uploaded = true;
     }
     HIP_OK(hipMemsetAsync(s.d_ties.p, 0, 4, W));
@@ -370,10 +378,10 @@ bool Impl::run_stage(Slot &s, int st)
         if (on_device) HIP_OK(hipStreamWaitEvent(W, ev_or, 0));
         if (s.used_h2d) HIP_OK(hipStreamWaitEvent(W, s.ev_in, 0));
         struct L { int kind, cls, pass; };                       /* kind 0: autocorr class launch, 1: pitch solve */
-        L seq[12]; int nl = 0;
+        L seq[16]; int nl = 0;
         if (have_items) {
             for (int pass = (par.ltp_order > 0) ? 1 : 0; pass >= 0; pass--) {
-                for (int c = 0; c < 4; c++) if (job.class_count[c]) seq[nl++] = { 0, c, pass };
+                for (int c = 0; c < 6; c++) if (job.class_count[c]) seq[nl++] = { 0, c, pass };
                 if (pass == 1) seq[nl++] = { 1, 0, 1 };
             }
         }
@@ -382,6 +390,11 @@ bool Impl::run_stage(Slot &s, int st)
             hipEvent_t e0 = (i == 0) ? ev0 : nullptr, e1 = (i == nl - 1) ? s.t1[ST_A] : nullptr;
             if (seq[i].kind == 0) {
                 const int c = seq[i].cls;
+                if (c >= 4)
+                    rc |= srla_launch_autocorr_big(W, &jp, s.in_cur, d_tw.p, (uint32_t)seq[i].pass, s.d_results.as<SrlaItemResult>(), s.d_lags.as<double>(), dbg,
+                                                   s.d_class_index.as<SrlaAutocorrItem>() + job.class_first[c], job.class_count[c], c == 4 ? 16384u : 32768u,
+                                                   e0, e1, nullptr, nullptr, s.d_big_scratch.p, SRLA_BIG_GROUPS);
+                else
                 rc |= srla_launch_autocorr(W, kClass[c], &jp, s.in_cur, s.d_items.as<SrlaItemDesc>(), d_geoms.as<SrlaGeom>(), d_tw.p,
                                            (uint32_t)seq[i].pass, s.d_results.as<SrlaItemResult>(), s.d_lags.as<double>(), dbg,
                                            s.d_class_index.as<SrlaAutocorrItem>() + job.class_first[c], job.class_count[c], e0, e1, nullptr, nullptr);
@@ -405,9 +418,14 @@ bool Impl::run_stage(Slot &s, int st)
         if (have_items) {
             const Group &g = job.groups[0];
             /* the roofline kernel: start event on every job */
+            const bool big = !job.big_items.empty();
             rc |= srla_launch_residual_cost(W, g.rclass, &jp, s.in_cur, s.d_items.as<SrlaItemDesc>(), d_geoms.as<SrlaGeom>(), &g.plan,
                                             d_thr.as<double>(), s.d_res_ws.as<int32_t>(), s.d_results.as<SrlaItemResult>(),
-                                            timing ? s.t0[ST_C] : nullptr, s.t1[ST_C]);
+                                            timing ? s.t0[ST_C] : nullptr, big ? nullptr : s.t1[ST_C]);
+            if (big)
+                rc |= srla_launch_residual_cost_big(W, &jp, s.in_cur, s.d_items.as<SrlaItemDesc>(), d_geoms.as<SrlaGeom>(), d_thr.as<double>(),
+                                                    s.d_res_ws.as<int32_t>(), s.d_results.as<SrlaItemResult>(), s.d_big_items.as<uint32_t>(),
+                                                    (uint32_t)job.big_items.size(), job.big_max_n, nullptr, s.t1[ST_C]);
         } else { if (timing) HIP_OK(hipEventRecord(s.t0[ST_C], W)); HIP_OK(hipEventRecord(s.t1[ST_C], W)); }
         break;
     case ST_D:

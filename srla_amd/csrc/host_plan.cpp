@@ -150,8 +150,8 @@ void Impl::build_job(Job &job, const JobPlan &plan, const std::vector<uint32_t> 
         Group g{};
         g.nfft = max_nfft;
         g.first = 0;
-        g.rclass = (int)std::max(1u, g.nfft / 2048u);
-        g.plan = lds_plan(g.nfft);
+        g.rclass = (int)std::min(4u, std::max(1u, g.nfft / 2048u));     /* larger items go to srla_residual_cost_big */
+        g.plan = lds_plan(std::min(g.nfft, 8192u));
         job.items.reserve(analysed.size() * nv);
         for (const Pending &p : analysed) {
             SrlaCandDesc &cd = job.cands[p.cand];
@@ -174,15 +174,18 @@ void Impl::build_job(Job &job, const JobPlan &plan, const std::vector<uint32_t> 
         g.count = (uint32_t)job.items.size();
         job.groups.push_back(g);
     }
+    job.big_items.clear(); job.big_max_n = 0;
+    for (uint32_t i = 0; i < job.items.size(); i++)
+        if (job.items[i].n > 8192u) { job.big_items.push_back(i); job.big_max_n = std::max(job.big_max_n, job.items[i].n); }
     job.class_index.clear();
     job.class_index.reserve(job.items.size());
-    for (int c = 0; c < 4; c++) {
+    for (int c = 0; c < 6; c++) {
         job.class_first[c] = (uint32_t)job.class_index.size();
         for (uint32_t i = 0; i < job.items.size(); i++) {
             const SrlaItemDesc &it = job.items[i];
             const SrlaGeom &gm = geoms[it.geom];
             const uint32_t nfft = gm.nfft;
-            const int cls = (nfft <= 1024u) ? 0 : ((nfft <= 2048u) ? 1 : ((nfft <= 4096u) ? 2 : 3));
+            const int cls = (nfft <= 1024u) ? 0 : ((nfft <= 2048u) ? 1 : ((nfft <= 4096u) ? 2 : ((nfft <= 8192u) ? 3 : ((nfft <= 16384u) ? 4 : 5))));
             if (cls == c) {
                 SrlaAutocorrItem ai{};
                 ai.item = i; ai.sample_off = it.sample_off; ai.n = it.n; ai.variant = it.variant;

@@ -36,6 +36,16 @@ int srla_launch_autocorr(hipStream_t stream, int rclass, const SrlaJobParams *jp
                          const SrlaAutocorrItem *class_items, uint32_t count, hipEvent_t ev_start, hipEvent_t ev_stop,
                          double *chain_pool /* null outside chain mode (device_layout.h: chain_src / chain_dump) */,
                          const uint32_t *chain_tab /* gather table of chain_lags */);
+/* items of 16384 / 32768 points (blocks above 8192 samples): the global-memory slow path; scratch: scratch_groups x nfft
+ * complex doubles, one region per (persistent) workgroup */
+int srla_launch_autocorr_big(hipStream_t stream, const SrlaJobParams *jp, const int32_t *input, const void *twiddles, uint32_t pass,
+                             SrlaItemResult *results, double *lags_ws, double *dbg, const SrlaAutocorrItem *class_items,
+                             uint32_t count, uint32_t nfft, hipEvent_t ev_start, hipEvent_t ev_stop, double *chain_pool,
+                             const uint32_t *chain_tab, void *scratch, uint32_t scratch_groups);
+/* the items of more than 8192 samples (big_items: their indices), which srla_residual_cost leaves alone */
+int srla_launch_residual_cost_big(hipStream_t stream, const SrlaJobParams *jp, const int32_t *input, const SrlaItemDesc *items,
+                                  const SrlaGeom *geoms, const double *rice_thresholds, int32_t *res_ws, SrlaItemResult *results,
+                                  const uint32_t *big_items, uint32_t count, uint32_t max_n, hipEvent_t ev_start, hipEvent_t ev_stop);
 /* int16 planes (stride16 elements apart) -> int32 planes (n apart): host input of at most 16 bits per sample */
 int srla_launch_widen16(hipStream_t stream, const int16_t *src, size_t stride16, int32_t *dst, uint32_t n, uint32_t num_channels);
 /* ties / tie_data: the job's near-tie list (device_layout.h: SrlaJobParams::tie_rel), may be null */

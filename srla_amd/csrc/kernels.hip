@@ -1504,6 +1504,150 @@ extern "C" uint32_t srla_kernel_fast_lds_bytes(uint32_t fl)
     return ((sig_words * 4 + 15) & ~15u) + (uint32_t)((sizeof(SmallF) + 15) & ~15u);
 }
 
+/* The partitioned (recursive) Rice parameter search of SRLACoder_ComputeCodeLength (srla_coder.c:349-484) over the zig-zag
+ * mapped residual u[0..n) in LDS, and the channel's code length (srla_encoder.c:1121-1187): the tail shared by the
+ * LDS paths of srla_residual_cost and srla_residual_cost_big.  NT threads; sm->max_u and sm->level_bits are set up by
+ * the caller. */
+__device__ __forceinline__ void rice_search_finish(const uint32_t *u, const SrlaGeom &g, double *means, SmallC *sm,
+                                                   const double *__restrict__ rice_thresholds, uint32_t bps, uint32_t period,
+                                                   uint32_t ltp_order, SrlaItemResult *__restrict__ out)
+{
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    /* ---- partitioned (recursive) Rice search, srla_coder.c:349-484 -------------------------------- */
+    const uint32_t mp = g.max_porder, nparts = 1u << mp, fl = g.fine_len;
+    unsigned long long *sums = (unsigned long long *)(means + (nparts - 1));
+    const uint32_t tpp = (nparts >= NT) ? 1u : (NT / nparts);     /* threads per finest partition */
+    if (tpp > 1) { for (uint32_t p = tid; p < nparts; p += NT) sums[p] = 0ull; }
+    __syncthreads();
+    if (tpp == 1) {
+        for (uint32_t p = tid; p < nparts; p += NT) {
+            unsigned long long s = 0;
+            const uint32_t *up = u + p * fl;
+            for (uint32_t i = 0; i < fl; i++) s += up[i];
+            means[(nparts - 1) + p] = (double)s / (double)fl;     /* exact integer sum, srla_coder.c:373-381 */
+        }
+    } else {
+        const uint32_t p = tid / tpp, j = tid % tpp;
+        unsigned long long s = 0;
+        const uint32_t *up = u + p * fl;
+        for (uint32_t i = j; i < fl; i += tpp) s += up[i];
+        atomicAdd(&sums[p], s);
+        __syncthreads();
+        for (uint32_t q = tid; q < nparts; q += NT) { const unsigned long long t = sums[q]; means[(nparts - 1) + q] = (double)t / (double)fl; }
+    }
+    __syncthreads();
+    const uint32_t max_u_all = sm->max_u;
+    uint32_t code_type;
+    /* pairwise mean tree (srla_coder.c:385-389): wide levels by the whole workgroup, the narrow top by one wave */
+    int lvl = (int)mp - 1;
+    for (; lvl >= 0 && (1u << lvl) >= WAVE; lvl--) {
+        const uint32_t cnt = 1u << lvl;
+        for (uint32_t p = tid; p < cnt; p += NT)
+            means[(cnt - 1) + p] = (means[(2 * cnt - 1) + 2 * p] + means[(2 * cnt - 1) + 2 * p + 1]) / 2.0;
+        __syncthreads();
+    }
+    if (tid < WAVE) {
+        for (; lvl >= 0; lvl--) {
+            const uint32_t cnt = 1u << lvl;
+            if (tid < cnt) means[(cnt - 1) + tid] = (means[(2 * cnt - 1) + 2 * tid] + means[(2 * cnt - 1) + 2 * tid + 1]) / 2.0;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        }
+    }
+    __syncthreads();
+    if (max_u_all == 0) code_type = SRLA_CODE_ALLZERO;
+    else if (means[0] < 2) code_type = SRLA_CODE_RICE;
+    else code_type = SRLA_CODE_RECURSIVE_RICE;
+
+    uint32_t best_porder = 0, best_bits = 0;
+    if (code_type != SRLA_CODE_ALLZERO) {
+        /* parameter per (level, partition) */
+        for (uint32_t e = tid; e < 2 * nparts - 1; e += NT) {
+            const double mean = means[e];
+            uint32_t k;
+            if (code_type == SRLA_CODE_RICE) {
+                k = 0;   /* srla_coder.c:262-276 through the host-derived monotone thresholds */
+                for (int t = 0; t < 32; t++) k += (mean >= rice_thresholds[t]) ? 1u : 0u;
+            } else {
+                const double gp = 0.66794162356 * (1.0 + mean);   /* srla_coder.c:298-311 */
+                const uint32_t golomb = (uint32_t)((1.0 > gp) ? 1.0 : gp);
+                k = 31u - (uint32_t)__clz((int)golomb);
+            }
+            sm->ktab[e] = (uint8_t)k;
+        }
+        __syncthreads();
+        /* cost of every partition order in one pass over the residual; side information per level:
+         * 10 bits of partition order, 5 bits for the first parameter, zig-zag(delta) + 1 per further
+         * partition (srla_coder.c:415-427) */
+        uint32_t acc[SRLA_MAX_PORDER + 1];
+#pragma unroll
+        for (int l = 0; l <= SRLA_MAX_PORDER; l++) acc[l] = 0;
+        {
+            uint32_t p_first, p_step, j_first, j_step;
+            if (tpp == 1) { p_first = tid; p_step = NT; j_first = 0; j_step = 1; }
+            else { p_first = tid / tpp; p_step = nparts; j_first = tid % tpp; j_step = tpp; }
+            for (uint32_t p = p_first; p < nparts; p += p_step) {
+                const uint32_t *up = u + p * fl;
+                uint32_t kk[SRLA_MAX_PORDER + 1];
+#pragma unroll
+                for (int l = 0; l <= SRLA_MAX_PORDER; l++) {
+                    kk[l] = 0;
+                    if ((uint32_t)l <= mp) {
+                        const uint32_t pl = p >> (mp - l), e = ((1u << l) - 1) + pl;
+                        kk[l] = sm->ktab[e];
+                        /* the first thread of the first fine partition of a level-l partition books its side info */
+                        if (j_first == 0 && (p & ((1u << (mp - l)) - 1)) == 0)
+                            acc[l] += (pl == 0) ? 15u : (zigzag32((int32_t)kk[l] - (int32_t)sm->ktab[e - 1]) + 1u);
+                    }
+                }
+                for (uint32_t i = j_first; i < fl; i += j_step) {
+                    const uint32_t val = up[i];
+#pragma unroll
+                    for (int l = 0; l <= SRLA_MAX_PORDER; l++) {
+                        if ((uint32_t)l <= mp) {
+                            const uint32_t k = kk[l];
+                            if (code_type == SRLA_CODE_RICE) {
+                                acc[l] += 1u + k + (val >> k);                      /* srla_coder.c:327-330 */
+                            } else {
+                                int32_t over = (int32_t)val - (int32_t)(2u << k);  /* srla_coder.c:333-347 */
+                                over = (over > 0) ? over : 0;
+                                acc[l] += (k + 2u) + ((uint32_t)over >> k);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int l = 0; l <= SRLA_MAX_PORDER; l++) {
+            if ((uint32_t)l <= mp) {
+                const uint32_t s = wave_sum_u32(acc[l]);
+                if (lane == 0) atomicAdd(&sm->level_bits[l], s);
+            }
+        }
+        __syncthreads();
+        best_bits = 0xFFFFFFFFu;
+        for (uint32_t l = 0; l <= mp; l++) {
+            const uint32_t b = sm->level_bits[l];
+            if (b < best_bits) { best_bits = b; best_porder = l; }
+        }
+        for (uint32_t p = tid; p < (1u << best_porder); p += NT) out->kparam[p] = sm->ktab[((1u << best_porder) - 1) + p];
+    }
+    if (tid == 0) {
+        const uint32_t res_bits = best_bits + 2u;
+        uint32_t bits = res_bits;                 /* srla_encoder.c:1121-1187 */
+        bits += bps + 1u;                         /* pre-emphasis state */
+        bits += 5u;                               /* pre-emphasis tap   */
+        bits += 8u + 4u + 1u;                     /* order, shift, sum flag */
+        bits += out->pad[0];                      /* tap codes (srla_lpc_solve) */
+        bits += 1u;                               /* LTP flag */
+        if (period > 0) bits += 1u + 8u + ltp_order * 6u;
+        out->code_length = bits;
+        out->res_code_type = code_type;
+        out->res_porder = best_porder;
+        out->res_bits = res_bits;
+    }
+}
+
 template <int R>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(R >= 4 ? 2 : 5, 8))) void srla_residual_cost(
     SrlaJobParams jp, const int32_t *__restrict__ input, const SrlaItemDesc *__restrict__ items,
@@ -1517,6 +1661,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(R >= 4 ? 2 :
     const uint32_t block = xcd_position(blockIdx.x, jp.num_items);
     if (block >= jp.num_items) return;
     const SrlaItemDesc itf = items[block];
+    if (itf.n > 8192u) return;                       /* srla_residual_cost_big takes these */
     const InputView iv = input_view(jp, itf.lshift);
     {
         /* blocks of 1024 * FL samples take the register / shuffle fast path */
@@ -1680,139 +1825,283 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(R >= 4 ? 2 :
         if (i4 < n) *reinterpret_cast<uint4 *>(u + i4) = make_uint4(uz[c][0], uz[c][1], uz[c][2], uz[c][3]);
     }
 
-    /* ---- partitioned (recursive) Rice search, srla_coder.c:349-484 -------------------------------- */
-    const uint32_t mp = g.max_porder, nparts = 1u << mp, fl = g.fine_len;
-    unsigned long long *sums = (unsigned long long *)(means + (nparts - 1));
-    const uint32_t tpp = (nparts >= NT) ? 1u : (NT / nparts);     /* threads per finest partition */
-    if (tpp > 1) { for (uint32_t p = tid; p < nparts; p += NT) sums[p] = 0ull; }
-    __syncthreads();
-    if (tpp == 1) {
-        for (uint32_t p = tid; p < nparts; p += NT) {
-            unsigned long long s = 0;
-            const uint32_t *up = u + p * fl;
-            for (uint32_t i = 0; i < fl; i++) s += up[i];
-            means[(nparts - 1) + p] = (double)s / (double)fl;     /* exact integer sum, srla_coder.c:373-381 */
-        }
-    } else {
-        const uint32_t p = tid / tpp, j = tid % tpp;
-        unsigned long long s = 0;
-        const uint32_t *up = u + p * fl;
-        for (uint32_t i = j; i < fl; i += tpp) s += up[i];
-        atomicAdd(&sums[p], s);
-        __syncthreads();
-        for (uint32_t q = tid; q < nparts; q += NT) { const unsigned long long t = sums[q]; means[(nparts - 1) + q] = (double)t / (double)fl; }
-    }
-    __syncthreads();
-    const uint32_t max_u_all = sm->max_u;
-    uint32_t code_type;
-    /* pairwise mean tree (srla_coder.c:385-389): wide levels by the whole workgroup, the narrow top by one wave */
-    int lvl = (int)mp - 1;
-    for (; lvl >= 0 && (1u << lvl) >= WAVE; lvl--) {
-        const uint32_t cnt = 1u << lvl;
-        for (uint32_t p = tid; p < cnt; p += NT)
-            means[(cnt - 1) + p] = (means[(2 * cnt - 1) + 2 * p] + means[(2 * cnt - 1) + 2 * p + 1]) / 2.0;
-        __syncthreads();
-    }
-    if (tid < WAVE) {
-        for (; lvl >= 0; lvl--) {
-            const uint32_t cnt = 1u << lvl;
-            if (tid < cnt) means[(cnt - 1) + tid] = (means[(2 * cnt - 1) + 2 * tid] + means[(2 * cnt - 1) + 2 * tid + 1]) / 2.0;
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        }
-    }
-    __syncthreads();
-    if (max_u_all == 0) code_type = SRLA_CODE_ALLZERO;
-    else if (means[0] < 2) code_type = SRLA_CODE_RICE;
-    else code_type = SRLA_CODE_RECURSIVE_RICE;
+    rice_search_finish(u, g, means, sm, rice_thresholds, bps, period, jp.ltp_order, out);
+}
 
-    uint32_t best_porder = 0, best_bits = 0;
-    if (code_type != SRLA_CODE_ALLZERO) {
-        /* parameter per (level, partition) */
-        for (uint32_t e = tid; e < 2 * nparts - 1; e += NT) {
-            const double mean = means[e];
-            uint32_t k;
-            if (code_type == SRLA_CODE_RICE) {
-                k = 0;   /* srla_coder.c:262-276 through the host-derived monotone thresholds */
-                for (int t = 0; t < 32; t++) k += (mean >= rice_thresholds[t]) ? 1u : 0u;
+/* ================================================================================================
+ * Blocks above 8192 samples (-B 16384, -B 32768): the slow paths.  Nothing of such a block fits the LDS-resident
+ * schemes above (a 32768-point transform is 256 KB), so the transform works in a global scratch buffer -- ping-pong, one
+ * workgroup per item, the same butterflies in the same order -- and the residual / code-length pass keeps ONE int32
+ * buffer in LDS that is rewritten in place from the top down.  Correct and complete (chain mode included), not fast.
+ * ============================================================================================== */
+#define NTB 1024
+
+/* complex FFT of m points, src -> dst ping-pong in global memory (fft.c:71-136); returns where the result stands */
+__device__ cplx *fft_complex_global(cplx *src, cplx *dst, uint32_t m, int flag, const cplx *__restrict__ tw)
+{
+    const uint32_t tid = threadIdx.x;
+    uint32_t n = m, s = 1, log2s = 0;
+    const uint32_t nb = m >> 2, m4 = m >> 2;
+    while (n > 2) {
+        const uint32_t n1 = n >> 2;
+        for (uint32_t bf = tid; bf < nb; bf += NTB) {
+            const uint32_t q = bf & (s - 1), p = bf >> log2s;
+            const cplx w1 = tw[p], w2 = tw[n1 + p], w3 = tw[2 * n1 + p];
+            const cplx a = src[bf], b = src[bf + m4], c = src[bf + 2 * m4], d = src[bf + 3 * m4];
+            const cplx apc = c_add(a, c), amc = c_sub(a, c), bpd = c_add(b, d), bmd = c_sub(b, d);
+            const cplx jbmd = (flag < 0) ? make_double2(-bmd.y, bmd.x) : make_double2(bmd.y, -bmd.x);
+            const uint32_t wb = 4u * bf - 3u * q;
+            dst[wb] = c_add(apc, bpd);
+            dst[wb + s] = c_mul(w1, c_sub(amc, jbmd));
+            dst[wb + 2 * s] = c_mul(w2, c_sub(apc, bpd));
+            dst[wb + 3 * s] = c_mul(w3, c_add(amc, jbmd));
+        }
+        __syncthreads();
+        cplx *t = src; src = dst; dst = t;
+        tw += 3 * n1;
+        n >>= 2; s <<= 2; log2s += 2;
+    }
+    if (n == 2) {
+        for (uint32_t q = tid; q < s; q += NTB) {
+            const cplx a = src[q], b = src[q + s];
+            dst[q] = c_add(a, b);
+            dst[q + s] = c_sub(a, b);
+        }
+        __syncthreads();
+        cplx *t = src; src = dst; dst = t;
+    }
+    return src;
+}
+
+/* srla_autocorr for items of more than 8192 points: persistent workgroups (each owns 2 x nfft / 2 complex of scratch) */
+__global__ __launch_bounds__(NTB) void srla_autocorr_big(
+    SrlaJobParams jp, const int32_t *__restrict__ input, const cplx *__restrict__ twiddles, uint32_t pass,
+    SrlaItemResult *__restrict__ results, double *__restrict__ lags_ws, double *__restrict__ dbg,
+    const SrlaAutocorrItem *__restrict__ class_items, uint32_t count, double *__restrict__ chain_pool,
+    const uint32_t *__restrict__ chain_tab, cplx *__restrict__ scratch, uint32_t scratch_stride /* cplx per workgroup */)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    int32_t *ylds = (int32_t *)lds;                               /* nfft words: the pre-emphasised signal (LTP filter) */
+    __shared__ long long s_l[2 * (NTB / WAVE)];
+    __shared__ uint32_t s_u[NTB / WAVE];
+    __shared__ int32_t s_coef;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    cplx *bufA = scratch + (size_t)blockIdx.x * scratch_stride, *bufB = bufA + (scratch_stride >> 1);
+    for (uint32_t pos = blockIdx.x; pos < count; pos += gridDim.x) {
+        const SrlaAutocorrItem it = class_items[pos];
+        const InputView iv = input_view(jp, it.lshift);
+        const uint32_t n = it.n, nfft = it.nfft, bps = jp.bits_per_sample, item_idx = it.item;
+        const int32_t *in = input + it.sample_off;
+        const bool first_pass = (pass == 1) || (jp.ltp_order == 0);
+        SrlaItemResult *out = &results[item_idx];
+        const bool chain = chain_pool != nullptr;
+        int32_t coef;
+        __syncthreads();                                           /* the previous item's last reads of LDS / scratch are done */
+        if (first_pass) {
+            long long r0 = 0, r1 = 0;
+            uint32_t absmax = 0;
+            for (uint32_t i = tid; i < n; i += NTB) {
+                const long long x = load_variant(in, iv, it.variant, i);
+                const long long y = (i + 1 < n) ? (long long)load_variant(in, iv, it.variant, i + 1) : 0;
+                r0 += x * x; r1 += x * y;
+                const uint32_t a = (x < 0) ? (uint32_t)(-x) : (uint32_t)x;
+                absmax = (a > absmax) ? a : absmax;
+            }
+            r0 = wave_sum_i64(r0); r1 = wave_sum_i64(r1); absmax = wave_max_u32(absmax);
+            if (lane == 0) { s_l[wave] = r0; s_l[NTB / WAVE + wave] = r1; s_u[wave] = absmax; }
+            __syncthreads();
+            long long t0 = 0, t1 = 0; uint32_t am = 0;
+            for (int w = 0; w < NTB / WAVE; w++) { t0 += s_l[w]; t1 += s_l[NTB / WAVE + w]; am = (s_u[w] > am) ? s_u[w] : am; }
+            uint32_t flags = (n & 1u) ? SRLA_ITEM_ODD_LENGTH : 0u;
+            if (am == 0) flags |= SRLA_ITEM_INPUT_ZERO;
+            if (am < (1u << 23) && t0 < (1LL << 53)) {
+                const double d0 = (double)t0, d1 = (double)t1;
+                int32_t c = 0;
+                if (!(d0 < 1e-6)) { c = (int32_t)round_half_away((d1 / d0) * 16.0); c = (c < -16) ? -16 : ((c > 15) ? 15 : c); }
+                coef = c;
             } else {
-                const double gp = 0.66794162356 * (1.0 + mean);   /* srla_coder.c:298-311 */
-                const uint32_t golomb = (uint32_t)((1.0 > gp) ? 1.0 : gp);
-                k = 31u - (uint32_t)__clz((int)golomb);
+                /* srla_utility.c:226-240 literally (rounding depends on the order): one lane */
+                if (tid == 0) {
+                    double curr = load_variant(in, iv, it.variant, 0), succ = load_variant(in, iv, it.variant, 1);
+                    double d0 = 0.0, d1 = 0.0;
+                    for (uint32_t i = 0; i + 2 < n; i++) {
+                        const double nn = load_variant(in, iv, it.variant, i + 2);
+                        d0 += curr * curr; d1 += curr * succ; curr = succ; succ = nn;
+                    }
+                    d0 += curr * curr; d1 += curr * succ; curr = succ; d0 += curr * curr;
+                    int32_t c = 0;
+                    if (!(d0 < 1e-6)) { c = (int32_t)round_half_away((d1 / d0) * 16.0); c = (c < -16) ? -16 : ((c > 15) ? 15 : c); }
+                    s_coef = c;
+                }
+                __syncthreads();
+                coef = s_coef;
             }
-            sm->ktab[e] = (uint8_t)k;
+            if (tid == 0) {
+                out->preemph_prev = load_variant(in, iv, it.variant, 0);
+                out->preemph_coef = coef;
+                out->lpc_order = 0; out->lpc_rshift = 0; out->use_sum = 0; out->ltp_period = 0;
+                out->ltp_coef[0] = 0; out->ltp_coef[1] = 0; out->ltp_coef[2] = 0;
+                out->code_length = 0; out->res_code_type = 0; out->res_porder = 0; out->res_bits = 0;
+                out->flags = flags; out->pad[0] = 0; out->pad[1] = 0;
+            }
+        } else {
+            coef = out->preemph_coef;
+            if (out->ltp_period == 0 && !chain && dbg == nullptr) continue;   /* the LPC lags are the first of the LTP lags (see srla_autocorr) */
+        }
+        if (pass == 0 && jp.max_order == 0 && !chain) continue;
+        /* pre-emphasis (srla_utility.c:342) into LDS; optional long-term predictor (srla_lpc_predict.c:267-294) read from there */
+        for (uint32_t i = tid; i < n; i += NTB) {
+            const int32_t cur = load_variant(in, iv, it.variant, i);
+            const int32_t prev = (i == 0) ? cur : load_variant(in, iv, it.variant, i - 1);
+            ylds[i] = (int32_t)((uint32_t)cur - (uint32_t)((int32_t)((uint32_t)prev * (uint32_t)coef) >> 4));
         }
         __syncthreads();
-        /* cost of every partition order in one pass over the residual; side information per level:
-         * 10 bits of partition order, 5 bits for the first parameter, zig-zag(delta) + 1 per further
-         * partition (srla_coder.c:415-427) */
-        uint32_t acc[SRLA_MAX_PORDER + 1];
-#pragma unroll
-        for (int l = 0; l <= SRLA_MAX_PORDER; l++) acc[l] = 0;
+        const uint32_t period = (pass == 0 && jp.ltp_order > 0) ? out->ltp_period : 0u;
+        const uint32_t taps = jp.ltp_order, half_order = taps >> 1;
+        const int32_t c0 = out->ltp_coef[0], c1 = out->ltp_coef[1], c2 = out->ltp_coef[2];
+        /* Welch window (lpc.c:256-266) on the [-1,1) normalised signal, zero padded to nfft, into the scratch buffer */
         {
-            uint32_t p_first, p_step, j_first, j_step;
-            if (tpp == 1) { p_first = tid; p_step = NT; j_first = 0; j_step = 1; }
-            else { p_first = tid / tpp; p_step = nparts; j_first = tid % tpp; j_step = tpp; }
-            for (uint32_t p = p_first; p < nparts; p += p_step) {
-                const uint32_t *up = u + p * fl;
-                uint32_t kk[SRLA_MAX_PORDER + 1];
-#pragma unroll
-                for (int l = 0; l <= SRLA_MAX_PORDER; l++) {
-                    kk[l] = 0;
-                    if ((uint32_t)l <= mp) {
-                        const uint32_t pl = p >> (mp - l), e = ((1u << l) - 1) + pl;
-                        kk[l] = sm->ktab[e];
-                        /* the first thread of the first fine partition of a level-l partition books its side info */
-                        if (j_first == 0 && (p & ((1u << (mp - l)) - 1)) == 0)
-                            acc[l] += (pl == 0) ? 15u : (zigzag32((int32_t)kk[l] - (int32_t)sm->ktab[e - 1]) + 1u);
+            const double norm_bps = __builtin_ldexp(1.0, -(int)(bps - 1));
+            const uint32_t half = n >> 1;
+            double *dA = (double *)bufA;
+            for (uint32_t e = tid; e < nfft; e += NTB) {
+                double val = 0.0;
+                if (e < n) {
+                    int32_t y = ylds[e];
+                    if (period > 0 && e >= period + half_order + 1) {
+                        const uint32_t base = e - period - half_order;
+                        uint32_t acc = 16u + (uint32_t)c0 * (uint32_t)ylds[base];
+                        if (taps == 3) acc += (uint32_t)c1 * (uint32_t)ylds[base + 1] + (uint32_t)c2 * (uint32_t)ylds[base + 2];
+                        y = (int32_t)((uint32_t)y - (uint32_t)((int32_t)acc >> 5));
+                    }
+                    uint32_t smpl; bool touched = true;
+                    if (e < half) smpl = e;
+                    else if (e >= n - half) smpl = n - 1 - e;
+                    else { smpl = 0; touched = false; }           /* middle sample of an odd block */
+                    if (touched) {
+                        const double in_d = (double)y * norm_bps;
+                        const double wt = it.welch_divisor * (double)smpl * (double)(n - 1 - smpl);
+                        val = in_d * wt;
+                    } else if (chain && it.chain_src) {
+                        val = chain_pool[it.chain_src - 1u];
                     }
                 }
-                for (uint32_t i = j_first; i < fl; i += j_step) {
-                    const uint32_t val = up[i];
-#pragma unroll
-                    for (int l = 0; l <= SRLA_MAX_PORDER; l++) {
-                        if ((uint32_t)l <= mp) {
-                            const uint32_t k = kk[l];
-                            if (code_type == SRLA_CODE_RICE) {
-                                acc[l] += 1u + k + (val >> k);                      /* srla_coder.c:327-330 */
-                            } else {
-                                int32_t over = (int32_t)val - (int32_t)(2u << k);  /* srla_coder.c:333-347 */
-                                over = (over > 0) ? over : 0;
-                                acc[l] += (k + 2u) + ((uint32_t)over >> k);
-                            }
-                        }
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int l = 0; l <= SRLA_MAX_PORDER; l++) {
-            if ((uint32_t)l <= mp) {
-                const uint32_t s = wave_sum_u32(acc[l]);
-                if (lane == 0) atomicAdd(&sm->level_bits[l], s);
+                dA[e] = val;
             }
         }
         __syncthreads();
-        best_bits = 0xFFFFFFFFu;
-        for (uint32_t l = 0; l <= mp; l++) {
-            const uint32_t b = sm->level_bits[l];
-            if (b < best_bits) { best_bits = b; best_porder = l; }
+        /* circular autocorrelation (lpc.c:330-376): real FFT = complex FFT of nfft / 2 points + symmetry pass, |X|^2, inverse */
+        const uint32_t m = nfft >> 1, ct = complex_table_len(m), quarter = nfft >> 2;
+        const cplx *twbase = twiddles + it.tw_off;
+        cplx *res = fft_complex_global(bufA, bufB, m, -1, twbase);
+        spectrum_power_pass<NTB>(res, nfft, twbase + 2 * ct, twbase + 2 * ct + quarter);
+        cplx *other = (res == bufA) ? bufB : bufA;
+        res = fft_complex_global(res, other, m, 1, twbase + ct);
+        const uint32_t num_lags = (pass == 1) ? SRLA_LTP_LAGS : (jp.max_order + 1);
+        if (chain && it.chain_dump) {
+            double *dst = chain_pool + (it.chain_dump - 1u);
+            for (uint32_t i = tid; i < nfft; i += NTB) { const cplx z = res[i >> 1]; dst[i] = (i & 1u) ? z.y : z.x; }
         }
-        for (uint32_t p = tid; p < (1u << best_porder); p += NT) out->kparam[p] = sm->ktab[((1u << best_porder) - 1) + p];
+        const size_t stride = jp.num_items;
+        for (uint32_t i = tid; i < num_lags; i += NTB) {
+            double lag = 0.0;
+            if (i < nfft) { const cplx z = res[i >> 1]; lag = ((i & 1u) ? z.y : z.x) * it.acorr_norm; }
+            else if (chain && it.chain_lags) {
+                const uint32_t o = chain_tab[it.chain_lags - 1u + (i - nfft)];
+                if (o) lag = chain_pool[o - 1u] * it.acorr_norm;
+            }
+            lags_ws[(size_t)i * stride + item_idx] = lag;
+            if (dbg) dbg[(size_t)item_idx * SRLA_DBG_STRIDE + ((pass == 1) ? SRLA_DBG_LTPLAGS : SRLA_DBG_LAGS) + i] = lag;
+        }
     }
-    if (tid == 0) {
-        const uint32_t res_bits = best_bits + 2u;
-        uint32_t bits = res_bits;                 /* srla_encoder.c:1121-1187 */
-        bits += bps + 1u;                         /* pre-emphasis state */
-        bits += 5u;                               /* pre-emphasis tap   */
-        bits += 8u + 4u + 1u;                     /* order, shift, sum flag */
-        bits += out->pad[0];                      /* tap codes (srla_lpc_solve) */
-        bits += 1u;                               /* LTP flag */
-        if (period > 0) bits += 1u + 8u + jp.ltp_order * 6u;
-        out->code_length = bits;
-        out->res_code_type = code_type;
-        out->res_porder = best_porder;
-        out->res_bits = res_bits;
+}
+
+/* srla_residual_cost for blocks of more than 8192 samples: ONE int32 buffer in LDS (pre-emphasised signal -> long-term
+ * predictor -> FIR residual -> zig-zag residual, each rewritten in place from the top of the block down: every output reads
+ * only lower indices), then the shared Rice search. */
+__global__ __launch_bounds__(NT) void srla_residual_cost_big(
+    SrlaJobParams jp, const int32_t *__restrict__ input, const SrlaItemDesc *__restrict__ items,
+    const SrlaGeom *__restrict__ geoms, const double *__restrict__ rice_thresholds, int32_t *__restrict__ res_ws,
+    SrlaItemResult *__restrict__ results, const uint32_t *__restrict__ big_items, uint32_t count, uint32_t sig_words)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    int32_t *sig = (int32_t *)lds;                                  /* FIR_PAD zeros, then the block */
+    double *means = (double *)(lds + (size_t)sig_words * 4);
+    SmallC *sm = (SmallC *)(lds + (size_t)sig_words * 4 + 8u * 2048u);
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    if (blockIdx.x >= count) return;
+    const uint32_t item_idx = big_items[blockIdx.x];
+    const SrlaItemDesc it = items[item_idx];
+    const InputView iv = input_view(jp, it.lshift);
+    const SrlaGeom g = geoms[it.geom];
+    const uint32_t n = it.n, bps = jp.bits_per_sample;
+    const int32_t *in = input + it.sample_off;
+    SrlaItemResult *out = &results[item_idx];
+    const int32_t coef = out->preemph_coef;
+    const uint32_t order = out->lpc_order, rshift = out->lpc_rshift, period = out->ltp_period;
+    const uint32_t o4 = (order + 3u) & ~3u;
+    int32_t *y = sig + FIR_PAD;
+    for (uint32_t i = tid; i < FIR_PAD; i += NT) sig[i] = 0;
+    for (uint32_t i = tid; i < n; i += NT) {
+        const int32_t cur = load_variant(in, iv, it.variant, i);
+        const int32_t prev = (i == 0) ? cur : load_variant(in, iv, it.variant, i - 1);
+        y[i] = (int32_t)((uint32_t)cur - (uint32_t)((int32_t)((uint32_t)prev * (uint32_t)coef) >> 4));
     }
+    for (uint32_t k = tid; k < o4; k += NT) sm->coefq[k] = (k < o4 - order) ? 0 : (int32_t)out->lpc_coef[k - (o4 - order)];
+    if (tid < 16) sm->level_bits[tid] = 0;
+    if (tid == 0) sm->max_u = 0;
+    __syncthreads();
+    const uint32_t nblk = (n + NT - 1) / NT;
+    if (period > 0) {
+        /* long-term predictor, srla_lpc_predict.c:267-294 */
+        const uint32_t taps = jp.ltp_order, half_order = taps >> 1;
+        const int32_t c0 = out->ltp_coef[0], c1 = out->ltp_coef[1], c2 = out->ltp_coef[2];
+        for (uint32_t b = nblk; b-- > 0;) {
+            const uint32_t s = b * NT + tid;
+            int32_t v = 0;
+            const bool act = s < n && s >= period + half_order + 1;
+            if (act) {
+                const uint32_t base = s - period - half_order;
+                uint32_t acc = 16u + (uint32_t)c0 * (uint32_t)y[base];
+                if (taps == 3) acc += (uint32_t)c1 * (uint32_t)y[base + 1] + (uint32_t)c2 * (uint32_t)y[base + 2];
+                v = (int32_t)((uint32_t)y[s] - (uint32_t)((int32_t)acc >> 5));
+            }
+            __syncthreads();
+            if (act) y[s] = v;
+            __syncthreads();
+        }
+    }
+    /* int32 wrap-around FIR (srla_lpc_predict.c:118-265), then the zig-zag residual in place */
+    {
+        const int32_t half = (int32_t)(1u << ((rshift - 1u) & 31u));
+        int32_t *res_out = res_ws + it.res_off;
+        uint32_t max_u = 0;
+        for (uint32_t b = nblk; b-- > 0;) {
+            const uint32_t s = b * NT + tid;
+            uint32_t z = 0;
+            if (s < n) {
+                int32_t rv;
+                if (order == 0 || s == 0) rv = y[s];
+                else if (s < order) rv = (int32_t)((uint32_t)y[s] - (uint32_t)y[s - 1]);
+                else {
+                    uint32_t acc = (uint32_t)half;
+                    const int32_t *w = y + (int)s - (int)o4;           /* FIR_PAD zeros in front cover s < o4 */
+                    for (uint32_t k = 0; k < o4; k++) acc += (uint32_t)sm->coefq[k] * (uint32_t)w[k];
+                    rv = (int32_t)((uint32_t)y[s] + (uint32_t)((int32_t)acc >> rshift));
+                }
+                res_out[s] = rv;
+                z = zigzag32(rv);
+                max_u = (z > max_u) ? z : max_u;
+            }
+            __syncthreads();
+            if (s < n) y[s] = (int32_t)z;
+            __syncthreads();
+        }
+        max_u = wave_max_u32(max_u);
+        if (lane == 0) atomicMax(&sm->max_u, max_u);
+    }
+    __syncthreads();
+    rice_search_finish((const uint32_t *)y, g, means, sm, rice_thresholds, bps, period, jp.ltp_order, out);
 }
 
 /* ------------------------------------------------------------------------- pricing -------- */
@@ -2587,6 +2876,32 @@ extern "C" int srla_launch_residual_cost(hipStream_t stream, int rclass, const S
     default: return -1;
     }
 #undef LAUNCH
+    return (hipGetLastError() == hipSuccess) ? 0 : -2;
+}
+
+extern "C" int srla_launch_autocorr_big(hipStream_t stream, const SrlaJobParams *jp, const int32_t *input, const void *twiddles, uint32_t pass,
+                                        SrlaItemResult *results, double *lags_ws, double *dbg, const SrlaAutocorrItem *class_items,
+                                        uint32_t count, uint32_t nfft, hipEvent_t ev_start, hipEvent_t ev_stop, double *chain_pool,
+                                        const uint32_t *chain_tab, void *scratch, uint32_t scratch_groups)
+{
+    if (count == 0) return 0;
+    const uint32_t groups = std::min(count, scratch_groups);
+    SET_LDS_ATTR(srla_autocorr_big);
+    hipExtLaunchKernelGGL(srla_autocorr_big, dim3(groups), dim3(NTB), nfft * 4u, stream, ev_start, ev_stop, 0, *jp, input, (const cplx *)twiddles, pass,
+                          results, lags_ws, dbg, class_items, count, chain_pool, chain_tab, (cplx *)scratch, nfft);
+    return (hipGetLastError() == hipSuccess) ? 0 : -2;
+}
+
+extern "C" int srla_launch_residual_cost_big(hipStream_t stream, const SrlaJobParams *jp, const int32_t *input, const SrlaItemDesc *items,
+                                              const SrlaGeom *geoms, const double *rice_thresholds, int32_t *res_ws, SrlaItemResult *results,
+                                              const uint32_t *big_items, uint32_t count, uint32_t max_n, hipEvent_t ev_start, hipEvent_t ev_stop)
+{
+    if (count == 0) return 0;
+    const uint32_t sig_words = FIR_PAD + ((max_n + 3u) & ~3u) + 8u;
+    const uint32_t lds = sig_words * 4u + 8u * 2048u + srla_kernel_small_c_bytes();
+    SET_LDS_ATTR(srla_residual_cost_big);
+    hipExtLaunchKernelGGL(srla_residual_cost_big, dim3(count), dim3(NT), lds, stream, ev_start, ev_stop, 0, *jp, input, items, geoms, rice_thresholds,
+                          res_ws, results, big_items, count, sig_words);
     return (hipGetLastError() == hipSuccess) ? 0 : -2;
 }
 
