@@ -2886,7 +2886,12 @@ extern "C" int srla_launch_autocorr_big(hipStream_t stream, const SrlaJobParams 
 {
     if (count == 0) return 0;
     const uint32_t groups = std::min(count, scratch_groups);
-    SET_LDS_ATTR(srla_autocorr_big);
+    {
+        /* the kernel also has a few hundred bytes of static LDS: ask for what is left of the 160 KB */
+        static bool done_ = false;
+        if (!done_) { (void)hipFuncSetAttribute((const void *)srla_autocorr_big, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); done_ = true; }
+        (void)hipGetLastError();
+    }
     hipExtLaunchKernelGGL(srla_autocorr_big, dim3(groups), dim3(NTB), nfft * 4u, stream, ev_start, ev_stop, 0, *jp, input, (const cplx *)twiddles, pass,
                           results, lags_ws, dbg, class_items, count, chain_pool, chain_tab, (cplx *)scratch, nfft);
     return (hipGetLastError() == hipSuccess) ? 0 : -2;

@@ -554,3 +554,20 @@ def test_wrong_shift_guess_that_overflows_the_buffer_is_retried(product, monkeyp
     rc, got = product.encode_whole(enc, pcm, cap=int(want.size * 1.1))
     product.destroy(enc)
     assert rc == capi.OK and np.array_equal(got, want)
+
+
+BIG = [dict(preset=4, max_block=16384, divisions=1), dict(preset=4, max_block=32768, divisions=2, ltp_order=3),
+       dict(preset=2, max_block=32768, divisions=0), dict(preset=4, max_block=2048, divisions=3, lookahead_factor=16),
+       dict(preset=4, max_block=16384, divisions=0, ltp_order=1)]
+
+
+@pytest.mark.parametrize("cli", BIG, ids=["B16384_V1", "B32768_V2_P3", "B32768_V0", "B2048_V3_L16", "B16384_V0_P1"])
+def test_blocks_above_8192_samples_and_128_search_nodes(product, cli):
+    """-B 16384 / -B 32768 (global-memory FFT, in-place residual pass) and look-ahead / minimum block up to 128: the reference
+    accepts any of these (srla_encoder.c:727-741); odd lengths end in a chain-mode window, 3 channels, a shifted stream"""
+    for nch, n, shift in ((2, 150001, 0), (3, 70000, 0), (2, 98304, 2)):
+        pcm = helpers.synth(helpers.VARIED if nch == 3 else helpers.MUSIC, 5, 48000, nch, n)
+        pcm = np.ascontiguousarray((pcm >> shift) << shift)
+        got = product.encode(pcm, **cli)
+        want = helpers.Oracle(nch, **cli).encode_whole(pcm)
+        assert np.array_equal(got, want), (cli, nch, n)

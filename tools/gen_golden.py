@@ -86,6 +86,11 @@ CLI = {
     "m6_B1024_V1_P1": dict(preset=6, max_block=1024, divisions=1, lookahead_factor=2, ltp_order=1),
     "m1_B8192_V2_P3": dict(preset=1, max_block=8192, divisions=2, ltp_order=3),
     "m3_B4096_V2_P3": dict(preset=3, max_block=4096, divisions=2, ltp_order=3),
+    # blocks above 8192 samples and more than 64 search nodes per window (the reference accepts any -B / -V / -L)
+    "m4_B16384_V1": dict(preset=4, max_block=16384, divisions=1),
+    "m4_B32768_V2_P3": dict(preset=4, max_block=32768, divisions=2, ltp_order=3),
+    "m2_B32768_V0": dict(preset=2, max_block=32768, divisions=0),
+    "m4_B2048_V3_L16": dict(preset=4, max_block=2048, divisions=3, lookahead_factor=16),
 }
 
 cases = []
@@ -122,6 +127,8 @@ for e in ("silence", "const_pos", "const_neg", "nyquist", "impulse", "one_silent
             continue
         add("edge_%s_%dch" % (e, nch), dict(edge=e, nch=nch, n=8500 - 500 * nch, bps=16, rate=48000), "m4_B4096_V2_P3" if e != "lshift3" else "m4_B4096",
             store_bytes=(nch == 2 and e in ("silence", "nyquist", "lshift3")))
+for c in ("m4_B16384_V1", "m4_B32768_V2_P3", "m2_B32768_V0", "m4_B2048_V3_L16"):
+    add("big_music_" + c, dict(kind=MUSIC, seed=61, rate=48000, nch=2, n=300000, bps=16), c)
 # odd lengths: the reference is history dependent here (LPC window skips the middle sample); the
 # oracle reproduces it, the device path documents the deviation
 add("odd_tail_music", dict(kind=MUSIC, seed=31, rate=48000, nch=2, n=20001, bps=16), "m4_B4096")

@@ -20,16 +20,14 @@ import helpers  # noqa: E402
 from srla_amd import capi  # noqa: E402
 
 
-def sweep(cases, seed, max_samples=6_000_000):
+def cases(count, seed, max_samples=6_000_000):
+    """the sweep's random configurations: (case number, nch, bps, n, kind, cli, shifted)"""
     rnd = random.Random(seed)
-    lib = capi.EncoderLib(helpers.PRODUCT_SO)
-    bad = 0
-    done = 0
-    for case in range(cases):
+    for case in range(count):
         nch = rnd.choice([1, 2, 2, 2, 3, 5, 8])
         bps = rnd.choice([16, 16, 16, 8, 24])
         preset = rnd.choice([0, 1, 2, 3, 4, 4, 4, 5, 6])
-        log2b = rnd.choice([8, 9, 10, 11, 12, 12, 13])
+        log2b = rnd.choice([8, 9, 10, 11, 12, 12, 13, 13, 14, 15])
         divisions = rnd.choice([0, 1, 1, 2, 3])
         ltp = rnd.choice([0, 0, 0, 1, 3])
         max_block = 1 << log2b
@@ -41,8 +39,8 @@ def sweep(cases, seed, max_samples=6_000_000):
         order = [0, 8, 16, 32, 64, 128, 255][preset]
         if order > min_block:
             continue
-        lookahead_factor = rnd.choice([1, 2, 4]) if divisions else 4
-        if (max_block * lookahead_factor) // min_block + 1 > 65:
+        lookahead_factor = rnd.choice([1, 2, 4, 8, 16]) if divisions else 4
+        if (max_block * lookahead_factor) // min_block + 1 > 129:
             continue
         # length: whole min blocks plus any tail
         nblocks = rnd.randint(0, max(2, min(600000 // min_block, 3 * (2 << 20) // min_block // 4)))
@@ -54,9 +52,22 @@ def sweep(cases, seed, max_samples=6_000_000):
             continue
         kind = rnd.choice([helpers.MUSIC, helpers.VARIED, helpers.VARIED, helpers.NOISE, helpers.SINE])
         cli = dict(preset=preset, max_block=max_block, divisions=divisions, ltp_order=ltp, lookahead_factor=lookahead_factor)
-        pcm = helpers.synth(kind, 5000 + case, 48000, nch, n, bps)
-        if rnd.random() < 0.15:
-            pcm = (pcm >> 3) << 3                       # exercises the offset left shift
+        yield case, nch, bps, n, kind, cli, rnd.random() < 0.15
+
+
+def make_pcm(case, nch, bps, n, kind, shifted):
+    pcm = helpers.synth(kind, 5000 + case, 48000, nch, n, bps)
+    if shifted:
+        pcm = (pcm >> 3) << 3                           # exercises the offset left shift
+    return pcm
+
+
+def sweep(count, seed, max_samples=6_000_000):
+    lib = capi.EncoderLib(helpers.PRODUCT_SO)
+    bad = 0
+    done = 0
+    for case, nch, bps, n, kind, cli, shifted in cases(count, seed, max_samples):
+        pcm = make_pcm(case, nch, bps, n, kind, shifted)
         try:
             got = lib.encode(pcm, bits_per_sample=bps, **cli)
         except RuntimeError as e:                        # limits of the implementation are refused loudly
@@ -66,7 +77,7 @@ def sweep(cases, seed, max_samples=6_000_000):
         done += 1
         if not np.array_equal(got, want):
             bad += 1
-            print("MISMATCH case %d: nch=%d bps=%d n=%d kind=%d %s sizes %d vs %d" % (case, nch, bps, n, kind, cli, got.size, want.size), flush=True)
+            print("MISMATCH case %d (seed %d): nch=%d bps=%d n=%d kind=%d %s sizes %d vs %d" % (case, seed, nch, bps, n, kind, cli, got.size, want.size), flush=True)
     return done, bad
 
 
