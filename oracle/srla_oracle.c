@@ -48,6 +48,7 @@ static const uint32_t k_preset_order[7] = { 0, 8, 16, 32, 64, 128, 255 };
 struct Oracle {
     OracleConfig cfg;
     uint32_t offset_lshift;
+    uint32_t svr_iterations; /* --svr-filter-learning-iteration (0: off, the default) */
     uint32_t fft_cap;      /* next pow2 >= max_block */
     double *fftbuf;        /* LPCCalculator::buffer: persistent across calls (lpc.c:58,211)   */
     double *fftwork;       /* LPCCalculator::work_buffer                                      */
@@ -826,6 +827,116 @@ void oracle_destroy(struct Oracle *o)
 }
 
 void oracle_set_offset_lshift(struct Oracle *o, uint32_t lshift) { o->offset_lshift = lshift; }
+void oracle_set_svr_iterations(struct Oracle *o, uint32_t iterations) { o->svr_iterations = iterations; }
+
+/* ---- SVR refinement of the predictor (--svr-filter-learning-iteration), libs/lpc/src/lpc.c:987-1136 -------------------- */
+/* lpc.c:1023-1033 (BITS_PER_SAMPLE is the constant 16 there, :1042) */
+static double svr_rgr_mean_code_length(double mean_abs_error, uint32_t bps)
+{
+    const double intmean = mean_abs_error * (1 << bps);
+    const double rho = 1.0 / (1.0 + intmean);
+    const double l2 = log(log(0.5127629514) / log(1.0 - rho)) * 1.4426950408889634;      /* LPC_Log2, lpc.c:71-76 */
+    const uint32_t k2 = (uint32_t)((0 > l2) ? 0 : l2);
+    const uint32_t k1 = k2 + 1;
+    const double k1factor = pow(1.0 - rho, (double)(1 << k1));
+    const double k2factor = pow(1.0 - rho, (double)(1 << k2));
+    return (1.0 + k1) * (1.0 - k1factor) + (1.0 + k2 + (1.0 / (1.0 - k2factor))) * k1factor;
+}
+
+/* The reference keeps residual / best_coef / init_coef in the calculator's persistent buffer, work_buffer and auto_corr
+ * (lpc.c:1044-1050): what they hold afterwards is part of the history an odd-length block inherits, so the same three
+ * arrays are used here (NULL: private scratch, for the stage-level tests). */
+int oracle_svr_refine_in(const double *data, uint32_t num_samples, double *coef, uint32_t order, uint32_t max_iter,
+                         double *persistent_buffer, double *persistent_work, double *persistent_acorr);
+
+int oracle_svr_refine(const double *data, uint32_t num_samples, double *coef, uint32_t order, uint32_t max_iter)
+{
+    return oracle_svr_refine_in(data, num_samples, coef, order, max_iter, NULL, NULL, NULL);
+}
+
+int oracle_svr_refine_in(const double *data, uint32_t num_samples, double *coef, uint32_t order, uint32_t max_iter,
+                         double *persistent_buffer, double *persistent_work, double *persistent_acorr)
+{
+    static const double margin_list[] = { 0.0, 1.0 / 4096, 1.0 / 1024, 1.0 / 256, 1.0 / 64, 1.0 / 16 };   /* srla_internal.c:27 */
+    const uint32_t p = order;
+    double *cov, *low, *r_vec, *delta, *init_coef, *best_coef, *residual;
+    double min_obj, prev_obj, obj;
+    uint32_t i, j, smpl, itr, m;
+    int k;
+    if (max_iter == 0) return 0;                                                             /* lpc.c:1058-1061 */
+    cov = (double *)calloc((size_t)p * p + 5 * (size_t)p + num_samples, sizeof(double));
+    low = cov + (size_t)p * p; r_vec = low + p; delta = r_vec + p; init_coef = delta + p; best_coef = init_coef + p;
+    residual = best_coef + p;
+    if (persistent_buffer) residual = persistent_buffer;
+    if (persistent_work) best_coef = persistent_work;
+    if (persistent_acorr) init_coef = persistent_acorr;
+#define COV(a, b) cov[(size_t)(a) * p + (b)]
+    /* covariance, lpc.c:987-1020 */
+    for (smpl = 0; smpl < num_samples - p; smpl++) {
+        const double *pd = &data[smpl];
+        for (i = 0; i < p; i++) {
+            const double sv = pd[i];
+            for (j = i; j < p; j++) COV(i, j) += sv * pd[j];
+        }
+    }
+    for (i = 0; i < p; i++) for (j = i + 1; j < p; j++) COV(j, i) = COV(i, j);
+    for (i = 0; i < p; i++) COV(i, i) *= (1.0 + RIDGE);                                      /* lpc.c:1067-1069 */
+    /* Cholesky, lpc.c:573-600 */
+    for (i = 0; i < p; i++) {
+        double sum = COV(i, i);
+        for (k = (int)i - 1; k >= 0; k--) sum -= COV(i, k) * COV(i, k);
+        if (sum <= 0.0) { for (j = 0; j < p; j++) coef[j] = 0.0; free(cov); return 0; }       /* lpc.c:1071-1077 */
+        low[i] = pow(sum, -0.5);
+        for (j = i + 1; j < p; j++) {
+            sum = COV(i, j);
+            for (k = (int)i - 1; k >= 0; k--) sum -= COV(i, k) * COV(j, k);
+            COV(j, i) = sum * low[i];
+        }
+    }
+    memcpy(init_coef, coef, sizeof(double) * p);
+    memcpy(best_coef, init_coef, sizeof(double) * p);
+    min_obj = FLT_MAX;
+    for (m = 0; m < sizeof(margin_list) / sizeof(margin_list[0]); m++) {
+        const double margin = margin_list[m];
+        prev_obj = FLT_MAX;
+        memcpy(coef, init_coef, sizeof(double) * p);
+        for (itr = 0; itr < max_iter; itr++) {
+            double mabse = 0.0;
+            memcpy(residual, data, sizeof(double) * num_samples);
+            for (i = 0; i < p; i++) r_vec[i] = 0.0;
+            for (smpl = p; smpl < num_samples; smpl++) {
+                double r, a;
+                for (i = 0; i < p; i++) residual[smpl] += coef[i] * data[smpl - i - 1];
+                r = residual[smpl];
+                a = (r > 0) ? r : -r;
+                mabse += a;
+                r = (double)((r > 0) - (r < 0)) * (((a - margin) > 0.0) ? (a - margin) : 0.0);  /* LPC_SOFT_THRESHOLD, lpc.c:34 */
+                residual[smpl] = r;
+                for (i = 0; i < p; i++) r_vec[i] += r * data[smpl - i - 1];
+            }
+            obj = svr_rgr_mean_code_length(mabse / num_samples, 16);
+            /* cov delta = r_vec, lpc.c:605-631 */
+            for (i = 0; i < p; i++) {
+                double sum = r_vec[i];
+                for (k = (int)i - 1; k >= 0; k--) sum -= COV(i, k) * delta[k];
+                delta[i] = sum * low[i];
+            }
+            for (k = (int)p - 1; k >= 0; k--) {
+                double sum = delta[k];
+                for (j = (uint32_t)k + 1; j < p; j++) sum -= COV(j, k) * delta[j];
+                delta[k] = sum * low[k];
+            }
+            if (obj < min_obj) { memcpy(best_coef, coef, sizeof(double) * p); min_obj = obj; }
+            if ((prev_obj < obj) || (fabs(prev_obj - obj) < 1e-8)) break;
+            for (i = 0; i < p; i++) coef[i] += delta[i];
+            prev_obj = obj;
+        }
+    }
+    memcpy(coef, best_coef, sizeof(double) * p);
+#undef COV
+    free(cov);
+    return 0;
+}
 
 int oracle_analyze_channel(struct Oracle *o, int32_t *buf, uint32_t n, int32_t *residual, OracleChannelParams *out)
 {
@@ -881,6 +992,9 @@ int oracle_analyze_channel(struct Oracle *o, int32_t *buf, uint32_t n, int32_t *
     if (order > 0) {
         int32_t q[ORACLE_MAX_ORDER];
         uint32_t rshift;
+        /* srla_encoder.c:1084-1097 (a no-op at the default of 0 iterations) */
+        if (o->svr_iterations > 0)
+            oracle_svr_refine_in(o->dsig, n, &o->coefs[(size_t)(order - 1) * max_order], order, o->svr_iterations, o->fftbuf, o->fftwork, o->acorr);
         oracle_quantize(&o->coefs[(size_t)(order - 1) * max_order], order, q, &rshift);
         for (i = 0; i < order / 2; i++) { const int32_t t = q[i]; q[i] = q[order - 1 - i]; q[order - 1 - i] = t; }
         oracle_lpc_predict(buf, n, q, order, residual, rshift);

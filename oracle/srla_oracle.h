@@ -66,6 +66,8 @@ struct Oracle;
 struct Oracle *oracle_create(const OracleConfig *cfg);
 void oracle_destroy(struct Oracle *o);
 void oracle_set_offset_lshift(struct Oracle *o, uint32_t lshift);
+void oracle_set_svr_iterations(struct Oracle *o, uint32_t iterations);   /* --svr-filter-learning-iteration (lpc.c:1036-1136) */
+int oracle_svr_refine(const double *data, uint32_t num_samples, double *coef, uint32_t order, uint32_t max_iter);
 
 /* --- whole path ------------------------------------------------------------------------ */
 int oracle_encode_whole(struct Oracle *o, const int32_t *const *input, uint32_t num_samples,

@@ -66,6 +66,8 @@ def oracle_lib():
         lib.oracle_create.argtypes = [C.POINTER(OracleConfig)]
         lib.oracle_destroy.argtypes = [C.c_void_p]
         lib.oracle_set_offset_lshift.argtypes = [C.c_void_p, C.c_uint32]
+        lib.oracle_set_svr_iterations.argtypes = [C.c_void_p, C.c_uint32]
+        lib.oracle_svr_refine.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32]
         pp = C.POINTER(C.POINTER(C.c_int32))
         lib.oracle_encode_whole.argtypes = [C.c_void_p, pp, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
         lib.oracle_encode_block.argtypes = lib.oracle_encode_whole.argtypes
@@ -156,7 +158,7 @@ class Oracle:
     """Handle-style wrapper over oracle/liboracle.so taking the same knobs as `srla -e`."""
 
     def __init__(self, num_channels, bits_per_sample=16, sampling_rate=48000, preset=4, max_block=4096,
-                 divisions=1, lookahead_factor=4, ltp_order=0, min_block=None, lookahead=None):
+                 divisions=1, lookahead_factor=4, ltp_order=0, min_block=None, lookahead=None, svr_iterations=0):
         self.lib = oracle_lib()
         minb = (max_block >> divisions) if min_block is None else min_block
         look = lookahead_factor * max_block if lookahead is None else lookahead
@@ -164,6 +166,8 @@ class Oracle:
         self.h = self.lib.oracle_create(C.byref(self.cfg))
         if not self.h:
             raise ValueError("oracle_create rejected the configuration")
+        if svr_iterations:
+            self.lib.oracle_set_svr_iterations(self.h, svr_iterations)
 
     def close(self):
         if self.h:

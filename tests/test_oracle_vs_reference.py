@@ -74,3 +74,19 @@ def test_block_level_api_matches():
     assert rc == rc2 == capi.OK
     assert o.compute_block_size(pcm) == size == data.size
     assert np.array_equal(o.encode_block(pcm), data)
+
+
+SVR = [dict(preset=2, max_block=4096, divisions=1, svr_iterations=1), dict(preset=4, max_block=4096, divisions=1, svr_iterations=5),
+       dict(preset=4, max_block=4096, divisions=2, ltp_order=3, svr_iterations=2), dict(preset=6, max_block=2048, divisions=0, svr_iterations=3),
+       dict(preset=3, max_block=8192, divisions=1, svr_iterations=10)]
+
+
+@pytest.mark.parametrize("cli", SVR, ids=["m2_i1", "m4_i5", "m4_V2_P3_i2", "m6_i3", "m3_B8192_i10"])
+def test_svr_refinement_matches(cli):
+    """--svr-filter-learning-iteration (lpc.c:1036-1136): off by default, the oracle restates it all the same.  Odd lengths too:
+    the refinement leaves its residual in the calculator's persistent buffer, which is what an odd block then inherits."""
+    for kind, nch, n, bps in ((helpers.MUSIC, 2, 40000, 16), (helpers.VARIED, 2, 30001, 16), (helpers.MUSIC, 1, 9000, 24), (helpers.NOISE, 3, 8192, 16)):
+        pcm = helpers.synth(kind, 9, 48000, nch, n, bps)
+        want = helpers.reference_encode_fresh(pcm, bits_per_sample=bps, **cli)
+        got = helpers.Oracle(nch, bits_per_sample=bps, **cli).encode_whole(pcm)
+        assert np.array_equal(got, want), (cli, kind, nch, n, bps)
