@@ -33,6 +33,7 @@ enum { SRLA_CODE_RICE = 0, SRLA_CODE_RECURSIVE_RICE = 1, SRLA_CODE_ALLZERO = 2 }
 #define SRLA_ITEM_LTP_TIE      4u   /* LTP tap within tolerance of a rounding boundary         */
 #define SRLA_ITEM_LTP_FAIL     8u   /* 3x3 Cholesky failed: the reference returns NG           */
 #define SRLA_ITEM_ODD_LENGTH   16u  /* odd block length: reference result is history dependent */
+#define SRLA_ITEM_SVR_TIE      32u  /* SVR refinement: a comparison of objective values within the libm tolerance */
 
 /* Per block-length constants the host prepares with the host libm. */
 typedef struct SrlaGeom {

@@ -38,7 +38,7 @@ Impl::~Impl()
             s.d_input16.release();
             DevBuf *db[] = { &s.d_input, &s.d_items, &s.d_cands, &s.d_windows, &s.d_results, &s.d_res_ws,
                              &s.d_blocks, &s.d_block_off, &s.d_scratch, &s.d_dbg, &s.d_lags, &s.d_err, &s.d_class_index, &s.d_stream,
-                             &s.d_segs, &s.d_seg_ctl, &s.d_ties, &s.d_tie_data, &s.d_big_scratch, &s.d_big_items };
+                             &s.d_segs, &s.d_seg_ctl, &s.d_ties, &s.d_tie_data, &s.d_big_scratch, &s.d_big_items, &s.d_coef_ws };
             for (auto *b : db) b->release();
             PinBuf *pb[] = { &s.h_in, &s.h_stream, &s.h_info, &s.h_segs };
             for (auto *b : pb) b->release();
@@ -320,6 +320,7 @@ bool Impl::prepare_job(Slot &s, bool want_dbg)
         if (!s.d_big_items.ensure(job.big_items.size() * 4)) return false;
         if (pb != s.d_big_items.p) job.uploaded = false;
     }
+    if (par.num_svr_filter_learning_iteration > 0 && !s.d_coef_ws.ensure(std::max<size_t>(1, n_items) * 64 * sizeof(double))) return false;
     if (want_dbg && !s.d_dbg.ensure(std::max<size_t>(1, n_items) * SRLA_DBG_STRIDE * sizeof(double))) return false;
     const uint32_t lag_rows = std::max<uint32_t>(par.ltp_order > 0 ? SRLA_LTP_LAGS : 0u, preset_order() + 1);
     if (!s.d_lags.ensure((size_t)lag_rows * std::max<size_t>(1, n_items) * sizeof(double))) return false;
@@ -410,7 +411,8 @@ bool Impl::run_stage(Slot &s, int st)
         if (have_items && jp.max_order > 0) {
             rc |= srla_launch_lpc_solve(N, &jp, s.d_items.as<SrlaItemDesc>(), d_geoms.as<SrlaGeom>(), s.d_lags.as<double>(),
                                         s.d_err.as<double>(), d_huff.as<uint8_t>(), s.d_results.as<SrlaItemResult>(), dbg,
-                                        s.d_ties.as<uint32_t>(), ev0, s.t1[ST_B]);
+                                        s.d_ties.as<uint32_t>(), ev0, s.t1[ST_B], s.in_cur, s.d_coef_ws.as<double>(),
+                                        par.num_svr_filter_learning_iteration, std::min<uint32_t>(par.max_num_samples_per_block, 8192u));
         } else { if (ev0) HIP_OK(hipEventRecord(ev0, N)); HIP_OK(hipEventRecord(s.t1[ST_B], N)); }
         break;
     case ST_C:

@@ -55,7 +55,9 @@ int srla_launch_pitch_solve(hipStream_t stream, const SrlaJobParams *jp, const S
                             uint32_t *ties, double *tie_data);
 int srla_launch_lpc_solve(hipStream_t stream, const SrlaJobParams *jp, const SrlaItemDesc *items,
                           const SrlaGeom *geoms, const double *lags_ws, double *err_ws, const uint8_t *huff_len,
-                          SrlaItemResult *results, double *dbg, uint32_t *ties, hipEvent_t ev_start, hipEvent_t ev_stop);
+                          SrlaItemResult *results, double *dbg, uint32_t *ties, hipEvent_t ev_start, hipEvent_t ev_stop,
+                          const int32_t *input, double *coef_ws /* 64 doubles per item */, uint32_t svr_iterations /* 0: off */,
+                          uint32_t svr_n_cap /* longest block of the job */);
 int srla_launch_residual_cost(hipStream_t stream, int rclass, const SrlaJobParams *jp, const int32_t *input,
                               const SrlaItemDesc *items, const SrlaGeom *geoms, const SrlaLdsPlan *plan,
                               const double *rice_thresholds, int32_t *res_ws, SrlaItemResult *results,

@@ -934,7 +934,8 @@ template <int P>
 __global__ __launch_bounds__(WAVE) void srla_lpc_solve_regs(
     SrlaJobParams jp, const SrlaItemDesc *__restrict__ items, const SrlaGeom *__restrict__ geoms,
     const double *__restrict__ lags_ws, double *__restrict__ err_ws, const uint8_t *__restrict__ huff_len,
-    SrlaItemResult *__restrict__ results, double *__restrict__ dbg, uint32_t *__restrict__ ties)
+    SrlaItemResult *__restrict__ results, double *__restrict__ dbg, uint32_t *__restrict__ ties,
+    double *__restrict__ coef_ws /* SVR refinement follows: the predictor of the chosen order goes here (row of P per item), unquantised */)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int L = WAVE;
@@ -1021,6 +1022,11 @@ __global__ __launch_bounds__(WAVE) void srla_lpc_solve_regs(
     SrlaItemResult *out = &results[idx];
     out->lpc_order = order;
     if (flags) out->flags |= flags;
+    if (coef_ws != nullptr) {
+        double *row = coef_ws + (size_t)idx * 64u;             /* SVR_P doubles per item whatever the preset */
+        for (uint32_t i = 0; i < order; i++) row[i] = silent ? 0.0 : snap[(size_t)i * L + lane];
+        return;
+    }
     quantize_and_price(order, silent,
                        [&](uint32_t i) -> double { return snap[(size_t)i * L + lane]; },
                        [&](uint32_t i, int32_t v) { q[(size_t)i * L + lane] = v; },
@@ -2104,6 +2110,256 @@ __global__ __launch_bounds__(NT) void srla_residual_cost_big(
     rice_search_finish((const uint32_t *)y, g, means, sm, rice_thresholds, bps, period, jp.ltp_order, out);
 }
 
+/* ================================================================================================
+ * SVR refinement of the predictor (--svr-filter-learning-iteration > 0; lpc.c:1036-1136, reached from
+ * srla_encoder.c:1084-1097).  Off by default and an order of magnitude more work than the rest of the analysis -- for the
+ * reference as well.  One workgroup per item; everything whose value depends on the ORDER of a floating-point summation is
+ * summed in the reference's order: the residual of a sample tap by tap (samples in parallel), mabse and the p entries of
+ * r_vec sample by sample (one lane per running sum), the Cholesky factor and the two triangular solves row by row.
+ * The covariance matrix (lpc.c:987-1020) is exact integer arithmetic whenever the products of the block cannot leave 53
+ * bits (16-bit audio): then every partial sum of the reference is exact and the order is free; otherwise one thread per
+ * matrix entry replays the reference's sum.
+ * libm (H2): pow(x, -0.5) of the factorisation is the correctly rounded x^-1/2; log / pow of the objective
+ * (lpc.c:1023-1033) are the device's -- the objective only steers comparisons, which are flagged (SRLA_ITEM_SVR_TIE) when
+ * they are close enough for a last bit to matter.
+ * ============================================================================================== */
+#define SVR_NT 256
+#define SVR_P  64           /* orders up to 64 (presets 0..4) */
+#define SVR_PS 65           /* row stride of the matrix in LDS */
+
+__device__ __forceinline__ double svr_rgr_mean_code_length(double mean_abs_error, bool *near_tie)
+{
+    /* lpc.c:1023-1033 with BITS_PER_SAMPLE = 16 (:1042) */
+    const double intmean = mean_abs_error * 65536.0;
+    const double rho = 1.0 / (1.0 + intmean);
+    const double l2 = log(log(0.5127629514) / log(1.0 - rho)) * 1.4426950408889634;
+    const double m = (0.0 > l2) ? 0.0 : l2;
+    const uint32_t k2 = (uint32_t)m;
+    if (m > 0.5 && fabs(m - floor(m + 0.5)) < 1e-9) *near_tie = true;       /* the integer part hangs on log()'s last bits */
+    const uint32_t k1 = k2 + 1;
+    const double k1factor = pow(1.0 - rho, (double)(1u << k1));
+    const double k2factor = pow(1.0 - rho, (double)(1u << k2));
+    return (1.0 + k1) * (1.0 - k1factor) + (1.0 + k2 + (1.0 / (1.0 - k2factor))) * k1factor;
+}
+
+__global__ __launch_bounds__(SVR_NT) void srla_svr_refine(
+    SrlaJobParams jp, const int32_t *__restrict__ input, const SrlaItemDesc *__restrict__ items,
+    SrlaItemResult *__restrict__ results, double *__restrict__ coef_ws, uint32_t iterations, uint32_t n_cap)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    int32_t *xi = (int32_t *)lds;                                        /* the pre-emphasised (+ LTP) block */
+    double *rr = (double *)(lds + (((size_t)n_cap * 4 + 15) & ~(size_t)15));   /* residual of every sample under the current taps */
+    double *cov = rr + n_cap;                                            /* [SVR_P][SVR_PS]: upper = matrix, lower = Cholesky factor */
+    double *low = cov + SVR_P * SVR_PS, *r_vec = low + SVR_P, *delta = r_vec + SVR_P, *coef = delta + SVR_P;
+    double *init_coef = coef + SVR_P, *best_coef = init_coef + SVR_P;
+    __shared__ double s_mabse, s_obj;
+    __shared__ long long s_lag[SVR_P];
+    __shared__ uint32_t s_flag[4];                                       /* 0: singular, 1: break, 2: near-tie, 3: |x| max */
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t item_idx = xcd_position(blockIdx.x, jp.num_items);
+    if (item_idx >= jp.num_items) return;
+    SrlaItemResult *out = &results[item_idx];
+    const uint32_t p = out->lpc_order;
+    if (p == 0 || p > SVR_P) return;
+    const SrlaItemDesc it = items[item_idx];
+    const InputView iv = input_view(jp, it.lshift);
+    const uint32_t n = it.n;
+    const int32_t *in = input + it.sample_off;
+    const double norm = __builtin_ldexp(1.0, -(int)(jp.bits_per_sample - 1));
+    double *row = coef_ws + (size_t)item_idx * SVR_P;
+    /* ---- the signal the LPC analysis saw: pre-emphasis (srla_utility.c:342), long-term predictor (srla_lpc_predict.c:267) ---- */
+    {
+        const int32_t pc = out->preemph_coef;
+        uint32_t am = 0;
+        for (uint32_t i = tid; i < n; i += SVR_NT) {
+            const int32_t cur = load_variant(in, iv, it.variant, i);
+            const int32_t prev = (i == 0) ? cur : load_variant(in, iv, it.variant, i - 1);
+            xi[i] = (int32_t)((uint32_t)cur - (uint32_t)((int32_t)((uint32_t)prev * (uint32_t)pc) >> 4));
+        }
+        if (tid < 4) s_flag[tid] = 0;
+        __syncthreads();
+        const uint32_t period = out->ltp_period;
+        if (period > 0) {
+            const uint32_t taps = jp.ltp_order, half_order = taps >> 1;
+            const int32_t c0 = out->ltp_coef[0], c1 = out->ltp_coef[1], c2 = out->ltp_coef[2];
+            const uint32_t nblk = (n + SVR_NT - 1) / SVR_NT;
+            for (uint32_t b = nblk; b-- > 0;) {                          /* in place, from the top down: every output reads lower indices only */
+                const uint32_t s = b * SVR_NT + tid;
+                int32_t v = 0;
+                const bool act = s < n && s >= period + half_order + 1;
+                if (act) {
+                    const uint32_t base = s - period - half_order;
+                    uint32_t acc = 16u + (uint32_t)c0 * (uint32_t)xi[base];
+                    if (taps == 3) acc += (uint32_t)c1 * (uint32_t)xi[base + 1] + (uint32_t)c2 * (uint32_t)xi[base + 2];
+                    v = (int32_t)((uint32_t)xi[s] - (uint32_t)((int32_t)acc >> 5));
+                }
+                __syncthreads();
+                if (act) xi[s] = v;
+                __syncthreads();
+            }
+        }
+        for (uint32_t i = tid; i < n; i += SVR_NT) { const int32_t v = xi[i]; const uint32_t a = (v < 0) ? (uint32_t)(-(int64_t)v) : (uint32_t)v; am = (a > am) ? a : am; }
+        am = wave_max_u32(am);
+        if (lane == 0) atomicMax(&s_flag[3], am);
+        for (uint32_t i = tid; i < p; i += SVR_NT) { coef[i] = row[i]; init_coef[i] = row[i]; best_coef[i] = row[i]; }
+        __syncthreads();
+    }
+    const uint32_t absmax = s_flag[3];
+    const uint32_t m_len = n - p;                                        /* terms of every covariance sum */
+    /* ---- covariance matrix, lpc.c:987-1020 ---- */
+    if ((double)absmax * (double)absmax * (double)m_len < 4503599627370496.0 /* 2^52 */) {
+        /* exact: row 0 by parallel integer dot products, the other entries by the exact recurrence along the diagonals
+         * cov[i+1][j+1] = cov[i][j] - x[i] x[j] + x[m+i] x[m+j] */
+        for (uint32_t d = wave; d < p; d += SVR_NT / WAVE) {
+            long long acc = 0;
+            for (uint32_t s0 = lane; s0 < m_len; s0 += WAVE) acc += (long long)xi[s0] * (long long)xi[s0 + d];
+            acc = wave_sum_i64(acc);
+            if (lane == 0) s_lag[d] = acc;
+        }
+        __syncthreads();
+        const double scale = norm * norm;
+        if (tid < p) {
+            const uint32_t d = tid;
+            long long v = s_lag[d];
+            for (uint32_t i = 0; i + d < p; i++) {
+                cov[i * SVR_PS + i + d] = (double)v * scale;
+                v += (long long)xi[m_len + i] * (long long)xi[m_len + i + d] - (long long)xi[i] * (long long)xi[i + d];
+            }
+        }
+    } else {
+        /* the reference's own running sums, one thread per entry */
+        const uint32_t npairs = p * (p + 1) / 2;
+        for (uint32_t t = tid; t < npairs; t += SVR_NT) {
+            uint32_t i = 0, r = t;
+            while (r >= p - i) { r -= p - i; i++; }
+            const uint32_t j = i + r;
+            double acc = 0.0;
+            for (uint32_t s0 = 0; s0 < m_len; s0++) acc += ((double)xi[s0 + i] * norm) * ((double)xi[s0 + j] * norm);
+            cov[i * SVR_PS + j] = acc;
+        }
+    }
+    __syncthreads();
+    for (uint32_t t = tid; t < p * p; t += SVR_NT) { const uint32_t i = t / p, j = t % p; if (j > i) cov[j * SVR_PS + i] = cov[i * SVR_PS + j]; }
+    __syncthreads();
+    if (tid < p) cov[tid * SVR_PS + tid] *= (1.0 + 1e-5);                /* ridge, lpc.c:1067-1069 */
+    __syncthreads();
+    /* ---- Cholesky factorisation, lpc.c:573-600 ---- */
+    for (uint32_t i = 0; i < p; i++) {
+        if (tid == 0) {
+            double sum = cov[i * SVR_PS + i];
+            for (int k = (int)i - 1; k >= 0; k--) sum -= cov[i * SVR_PS + k] * cov[i * SVR_PS + k];
+            if (sum <= 0.0) s_flag[0] = 1;
+            else low[i] = inv_sqrt_cr(sum);
+        }
+        __syncthreads();
+        if (s_flag[0]) break;
+        const uint32_t j = i + 1 + tid;
+        if (j < p) {
+            double sum = cov[i * SVR_PS + j];
+            for (int k = (int)i - 1; k >= 0; k--) sum -= cov[i * SVR_PS + k] * cov[j * SVR_PS + k];
+            cov[j * SVR_PS + i] = sum * low[i];
+        }
+        __syncthreads();
+    }
+    if (s_flag[0]) {                                                     /* singular: all-zero input (lpc.c:1071-1077) */
+        for (uint32_t i = tid; i < p; i += SVR_NT) row[i] = 0.0;
+        return;
+    }
+    /* ---- the learning loop, lpc.c:1083-1127 ---- */
+    const double margins[6] = { 0.0, 1.0 / 4096, 1.0 / 1024, 1.0 / 256, 1.0 / 64, 1.0 / 16 };   /* srla_internal.c:27 */
+    double min_obj = (double)FLT_MAX;                                    /* uniform: every thread keeps its own copy */
+    for (int mi = 0; mi < 6; mi++) {
+        const double margin = margins[mi];
+        double prev_obj = (double)FLT_MAX;
+        __syncthreads();
+        for (uint32_t i = tid; i < p; i += SVR_NT) coef[i] = init_coef[i];
+        __syncthreads();
+        for (uint32_t itr = 0; itr < iterations; itr++) {
+            /* residual of every sample: taps in index order (lpc.c:1098-1100), samples in parallel */
+            for (uint32_t s0 = p + tid; s0 < n; s0 += SVR_NT) {
+                double res = (double)xi[s0] * norm;
+                for (uint32_t i = 0; i < p; i++) res += coef[i] * ((double)xi[s0 - i - 1] * norm);
+                rr[s0] = res;
+            }
+            __syncthreads();
+            /* the running sums over the samples, in sample order: r_vec[i] on lane i of wave 0, mabse on wave 1 */
+            if (wave == 0 && lane < p) {
+                double acc = 0.0;
+                for (uint32_t s0 = p; s0 < n; s0++) {
+                    const double r = rr[s0];
+                    const double a = (r > 0) ? r : -r;
+                    const double t = (double)((r > 0) - (r < 0)) * (((a - margin) > 0.0) ? (a - margin) : 0.0);   /* LPC_SOFT_THRESHOLD, lpc.c:34 */
+                    acc += t * ((double)xi[s0 - lane - 1] * norm);
+                }
+                r_vec[lane] = acc;
+            } else if (wave == 1 && lane == 0) {
+                double acc = 0.0;
+                for (uint32_t s0 = p; s0 < n; s0++) { const double r = rr[s0]; acc += (r > 0) ? r : -r; }
+                s_mabse = acc;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                bool tie = false;
+                const double obj = svr_rgr_mean_code_length(s_mabse / (double)n, &tie);
+                /* cov delta = r_vec by the factor, lpc.c:605-631 */
+                for (uint32_t i = 0; i < p; i++) {
+                    double sum = r_vec[i];
+                    for (int k = (int)i - 1; k >= 0; k--) sum -= cov[i * SVR_PS + k] * delta[k];
+                    delta[i] = sum * low[i];
+                }
+                for (int k = (int)p - 1; k >= 0; k--) {
+                    double sum = delta[k];
+                    for (uint32_t j = (uint32_t)k + 1; j < p; j++) sum -= cov[j * SVR_PS + k] * delta[j];
+                    delta[k] = sum * low[k];
+                }
+                s_obj = obj;
+                if (tie) s_flag[2] = 1;
+            }
+            __syncthreads();
+            const double obj = s_obj;
+            /* comparisons of objective values that differ by less than the device's log / pow can be trusted for */
+            if (tid == 0) {
+                const double tol = 1e-9;
+                if ((obj != min_obj && fabs(obj - min_obj) <= tol * fabs(obj)) || (obj != prev_obj && fabs(obj - prev_obj) <= tol * fabs(obj))
+                    || fabs(fabs(prev_obj - obj) - 1e-8) <= 1e-8 * tol) s_flag[2] = 1;
+            }
+            if (obj < min_obj) {
+                for (uint32_t i = tid; i < p; i += SVR_NT) best_coef[i] = coef[i];
+                min_obj = obj;
+            }
+            if ((prev_obj < obj) || (fabs(prev_obj - obj) < 1e-8)) break;
+            for (uint32_t i = tid; i < p; i += SVR_NT) coef[i] += delta[i];
+            prev_obj = obj;
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < p; i += SVR_NT) row[i] = best_coef[i];
+    if (tid == 0 && s_flag[2]) out->flags |= SRLA_ITEM_SVR_TIE;
+}
+
+/* the quantiser and tap cost (lpc.c:1341-1405, srla_encoder.c:1141-1174) from the refined taps: one lane per item */
+__global__ __launch_bounds__(WAVE) void srla_lpc_quantize_ws(SrlaJobParams jp, const double *__restrict__ coef_ws,
+                                                             const uint8_t *__restrict__ huff_len, SrlaItemResult *__restrict__ results)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr int L = WAVE;
+    const uint32_t lane = threadIdx.x;
+    uint8_t *s_huff = lds;
+    int32_t *q = (int32_t *)(lds + 512);
+    for (uint32_t i = lane; i < 128; i += WAVE) ((uint32_t *)s_huff)[i] = ((const uint32_t *)huff_len)[i];
+    __syncthreads();
+    const uint32_t idx = blockIdx.x * WAVE + lane;
+    if (idx >= jp.num_items) return;
+    SrlaItemResult *out = &results[idx];
+    const uint32_t order = out->lpc_order;
+    const double *row = coef_ws + (size_t)idx * SVR_P;
+    quantize_and_price(order, false,
+                       [&](uint32_t i) -> double { return row[i]; },
+                       [&](uint32_t i, int32_t v) { q[(size_t)i * L + lane] = v; },
+                       [&](uint32_t i) -> int32_t { return q[(size_t)i * L + lane]; }, s_huff, out);
+}
+
 /* ------------------------------------------------------------------------- pricing -------- */
 /* One wave per window.  Block cost: ComputeBlockSize (srla_encoder.c:1477-1546) on top of the
  * stereo decision of ComputeCoefficients (:1275-1327), one candidate per lane; path:
@@ -2820,10 +3076,35 @@ extern "C" int srla_launch_pitch_solve(hipStream_t stream, const SrlaJobParams *
 
 extern "C" int srla_launch_lpc_solve(hipStream_t stream, const SrlaJobParams *jp, const SrlaItemDesc *items,
                                      const SrlaGeom *geoms, const double *lags_ws, double *err_ws, const uint8_t *huff_len,
-                                     SrlaItemResult *results, double *dbg, uint32_t *ties, hipEvent_t ev_start, hipEvent_t ev_stop)
+                                     SrlaItemResult *results, double *dbg, uint32_t *ties, hipEvent_t ev_start, hipEvent_t ev_stop,
+                                     const int32_t *input, double *coef_ws, uint32_t svr_iterations, uint32_t svr_n_cap)
 {
     if (jp->num_items == 0) return 0;
     const uint32_t p = jp->max_order;
+    if (svr_iterations > 0) {
+        /* solve (taps left unquantised) -> SVR refinement -> quantiser; orders up to 64 only (SetEncodeParameter checks) */
+        const dim3 g64s((jp->num_items + 63) / 64), blks(WAVE);
+#define SVR_PATH(PP)                                                                                                     \
+    do {                                                                                                                 \
+        const uint32_t lds = 512 + PP * 8 * 64 + PP * 4 * 64;                                                            \
+        SET_LDS_ATTR(srla_lpc_solve_regs<PP>);                                                                           \
+        hipExtLaunchKernelGGL(srla_lpc_solve_regs<PP>, g64s, blks, lds, stream, ev_start, nullptr, 0, *jp, items, geoms, lags_ws, err_ws, \
+                              huff_len, results, dbg, ties, coef_ws);                                                    \
+    } while (0)
+        if (p == 8) SVR_PATH(8); else if (p == 16) SVR_PATH(16); else if (p == 32) SVR_PATH(32); else if (p == 64) SVR_PATH(64); else return -1;
+#undef SVR_PATH
+        const uint32_t lds_svr = ((svr_n_cap * 4u + 15u) & ~15u) + svr_n_cap * 8u + (SVR_P * SVR_PS + 6 * SVR_P) * 8u;
+        {
+            static bool done_ = false;
+            if (!done_) { (void)hipFuncSetAttribute((const void *)srla_svr_refine, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048); done_ = true; }
+            (void)hipGetLastError();
+        }
+        hipLaunchKernelGGL(srla_svr_refine, dim3(8u * ((jp->num_items + 7u) >> 3)), dim3(SVR_NT), lds_svr, stream, *jp, input, items, results, coef_ws,
+                           svr_iterations, svr_n_cap);
+        SET_LDS_ATTR(srla_lpc_quantize_ws);
+        hipExtLaunchKernelGGL(srla_lpc_quantize_ws, g64s, blks, 512 + SVR_P * 4 * 64, stream, nullptr, ev_stop, 0, *jp, coef_ws, huff_len, results);
+        return (hipGetLastError() == hipSuccess) ? 0 : -2;
+    }
     const dim3 g64((jp->num_items + 63) / 64), blk(WAVE);
     /* orders 8 .. 64: the whole chain in one launch (srla_lpc_solve_regs) */
 #define REGS_PATH(PP)                                                                                                    \
@@ -2831,7 +3112,7 @@ extern "C" int srla_launch_lpc_solve(hipStream_t stream, const SrlaJobParams *jp
         const uint32_t lds = 512 + PP * 8 * 64 + PP * 4 * 64;                                                            \
         SET_LDS_ATTR(srla_lpc_solve_regs<PP>);                                                                           \
         hipExtLaunchKernelGGL(srla_lpc_solve_regs<PP>, g64, blk, lds, stream, ev_start, ev_stop, 0, *jp, items, geoms, lags_ws, err_ws, \
-                              huff_len, results, dbg, ties);                                                             \
+                              huff_len, results, dbg, ties, (double *)nullptr);                                          \
     } while (0)
     if (p == 8) REGS_PATH(8);
     else if (p == 16) REGS_PATH(16);

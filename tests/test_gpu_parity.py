@@ -571,3 +571,27 @@ def test_blocks_above_8192_samples_and_128_search_nodes(product, cli):
         got = product.encode(pcm, **cli)
         want = helpers.Oracle(nch, **cli).encode_whole(pcm)
         assert np.array_equal(got, want), (cli, nch, n)
+
+
+SVR_CLIS = [dict(preset=2, max_block=4096, divisions=1, svr_iterations=1), dict(preset=4, max_block=4096, divisions=1, svr_iterations=5),
+            dict(preset=4, max_block=4096, divisions=2, ltp_order=3, svr_iterations=2), dict(preset=1, max_block=2048, divisions=0, svr_iterations=3),
+            dict(preset=3, max_block=8192, divisions=1, svr_iterations=10)]
+
+
+@pytest.mark.parametrize("cli", SVR_CLIS, ids=["m2_i1", "m4_i5", "m4_V2_P3_i2", "m1_V0_i3", "m3_B8192_i10"])
+def test_svr_refinement_on_the_device(product, cli):
+    """--svr-filter-learning-iteration > 0 (lpc.c:1036-1136): srla_svr_refine between the solve and the quantiser.  Even lengths
+    (with SVR on, what an odd block inherits from the previous call is the refinement's residual: DESIGN.md 5)."""
+    for kind, nch, n, bps in ((helpers.MUSIC, 2, 40000, 16), (helpers.VARIED, 2, 32768, 16), (helpers.MUSIC, 1, 9000, 24), (helpers.NOISE, 3, 8192, 16),
+                              (helpers.SINE, 2, 12288, 8)):
+        pcm = helpers.synth(kind, 9, 48000, nch, n, bps)
+        got = product.encode(pcm, bits_per_sample=bps, **cli)
+        want = helpers.Oracle(nch, bits_per_sample=bps, **cli).encode_whole(pcm)
+        assert np.array_equal(got, want), (cli, kind, nch, n, bps)
+
+
+def test_svr_outside_its_limits_is_refused_loudly(product):
+    cfg, par = capi.cli_setup(2, 16, 48000, preset=5, max_block=4096, divisions=1, svr_iterations=2)
+    enc = product.create(cfg)
+    assert product.set_parameter(enc, par) == capi.NG
+    product.destroy(enc)

@@ -91,6 +91,11 @@ CLI = {
     "m4_B32768_V2_P3": dict(preset=4, max_block=32768, divisions=2, ltp_order=3),
     "m2_B32768_V0": dict(preset=2, max_block=32768, divisions=0),
     "m4_B2048_V3_L16": dict(preset=4, max_block=2048, divisions=3, lookahead_factor=16),
+    # --svr-filter-learning-iteration (lpc.c:1036-1136)
+    "m2_B4096_svr1": dict(preset=2, max_block=4096, divisions=1, svr_iterations=1),
+    "m4_B4096_svr5": dict(preset=4, max_block=4096, divisions=1, svr_iterations=5),
+    "m4_B4096_V2_P3_svr2": dict(preset=4, max_block=4096, divisions=2, ltp_order=3, svr_iterations=2),
+    "m2_B4096_svr5": dict(preset=2, max_block=4096, divisions=1, svr_iterations=5),
 }
 
 cases = []
@@ -129,6 +134,9 @@ for e in ("silence", "const_pos", "const_neg", "nyquist", "impulse", "one_silent
             store_bytes=(nch == 2 and e in ("silence", "nyquist", "lshift3")))
 for c in ("m4_B16384_V1", "m4_B32768_V2_P3", "m2_B32768_V0", "m4_B2048_V3_L16"):
     add("big_music_" + c, dict(kind=MUSIC, seed=61, rate=48000, nch=2, n=300000, bps=16), c)
+for c in ("m2_B4096_svr1", "m4_B4096_svr5", "m4_B4096_V2_P3_svr2", "m2_B4096_svr5"):
+    add("svr_music_" + c, dict(kind=MUSIC, seed=71, rate=48000, nch=2, n=60000, bps=16), c)
+    add("svr_varied_" + c, dict(kind=VARIED, seed=72, rate=48000, nch=2, n=49152, bps=16), c)
 # odd lengths: the reference is history dependent here (LPC window skips the middle sample); the
 # oracle reproduces it, the device path documents the deviation
 add("odd_tail_music", dict(kind=MUSIC, seed=31, rate=48000, nch=2, n=20001, bps=16), "m4_B4096")
