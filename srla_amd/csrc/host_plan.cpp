@@ -60,7 +60,7 @@ SrlaLdsPlan Impl::lds_plan(uint32_t nfft) const
     SrlaLdsPlan p{};
     uint32_t off = 0;
     p.y_off = off; off += al(sig_bytes);
-    p.fft_off = off; if (par.ltp_order > 0) off += al(sig_bytes);
+    p.fft_off = off;
     p.lev_off = 0;
     p.means_off = off; off += al(means_bytes);
     p.small_off = off; off += srla_kernel_small_c_bytes();

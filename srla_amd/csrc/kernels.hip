@@ -1701,8 +1701,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(R >= 4 ? 2 :
 #undef FAST
         }
     }
-    int32_t *sigA = (int32_t *)(lds + plan.y_off);        /* FIR_PAD zeros, then the signal */
-    int32_t *sigB = (int32_t *)(lds + plan.fft_off);      /* LTP output (only when LTP is on) */
+    int32_t *sigA = (int32_t *)(lds + plan.y_off);        /* FIR_PAD zeros, then the signal (the LTP rewrites it in place) */
     double *means = (double *)(lds + plan.means_off);
     SmallC *sm = (SmallC *)(lds + plan.small_off);
 
@@ -1732,7 +1731,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(R >= 4 ? 2 :
         }
         if (i4 < g.nfft) *reinterpret_cast<int4 *>(sigA + FIR_PAD + i4) = make_int4(v[c][0], v[c][1], v[c][2], v[c][3]);
     }
-    for (uint32_t i = tid; i < FIR_PAD; i += NT) { sigA[i] = 0; if (period > 0) sigB[i] = 0; }
+    for (uint32_t i = tid; i < FIR_PAD; i += NT) sigA[i] = 0;
     /* taps, zero padded in FRONT so that the tap loop runs in aligned groups of four */
     for (uint32_t k = tid; k < o4; k += NT) sm->coefq[k] = (k < o4 - order) ? 0 : (int32_t)out->lpc_coef[k - (o4 - order)];
     if (tid < 16) sm->level_bits[tid] = 0;
@@ -1757,10 +1756,16 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(R >= 4 ? 2 :
                     v[c][i] = (int32_t)((uint32_t)v[c][i] - (uint32_t)((int32_t)acc >> 5));
                 }
             }
-            if (i4 < g.nfft) *reinterpret_cast<int4 *>(sigB + FIR_PAD + i4) = make_int4(v[c][0], v[c][1], v[c][2], v[c][3]);
+        }
+        /* every thread has read its sources: the filtered signal replaces the unfiltered one in place (a second buffer
+         * used to cost the whole launch -- the register path included -- a third of its workgroups per CU) */
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+            const uint32_t i4 = 4u * (tid + (uint32_t)c * NT);
+            if (i4 < g.nfft) *reinterpret_cast<int4 *>(sigA + FIR_PAD + i4) = make_int4(v[c][0], v[c][1], v[c][2], v[c][3]);
         }
         __syncthreads();
-        src = sigB + FIR_PAD;
     }
 
     /* ---- int32 wrap-around FIR (srla_lpc_predict.c:118-265), four outputs per group, taps in fours ---- */
