@@ -119,7 +119,7 @@ def parse_args(argv=None):
     ap.add_argument("--ltp", type=int, default=None)
     ap.add_argument("--bps", type=int, default=16, choices=[8, 16, 24], help="bits per sample of the synthetic input (the metric is quoted at 16)")
     ap.add_argument("--no-numa-pin", action="store_true", help="do not restrict the process to the GPU-local NUMA node")
-    ap.add_argument("--pack-threads", type=int, default=0, help="host pool threads (staging copies; default: min(8, usable CPUs / (2 * ranks)))")
+    ap.add_argument("--pack-threads", type=int, default=0, help="host pool threads (staging copies; default: min(8, usable CPUs / ranks))")
     ap.add_argument("--pinned-io", action="store_true", help="headline with pinned input planes and a pinned output buffer (reported in config.workload)")
     ap.add_argument("--dry-run", action="store_true", help="launch / rendezvous / reduce only, no GPU work (CPU test of the N-rank flow)")
     return ap.parse_args(argv)
@@ -240,7 +240,7 @@ def main(argv=None):
     cfg, par = capi.cli_setup(nch, bps, rate, **cli)
     enc = lib.create(cfg)
     assert enc and lib.set_parameter(enc, par) == capi.OK
-    pack_threads = args.pack_threads or max(1, min(8, usable_cpus() // (2 * max(1, world))))
+    pack_threads = args.pack_threads or max(1, min(8, usable_cpus() // max(1, world)))   # the calling thread works too: one CPU per pool thread
     L.SRLAMI355X_SetPackThreads(enc, pack_threads)
     cap = 2 * pcms[0].size * (bps // 8) + 4096
     outs = [(torch.empty(cap, dtype=torch.uint8).pin_memory().numpy() if args.pinned_io else np.zeros(cap, dtype=np.uint8))

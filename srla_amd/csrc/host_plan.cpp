@@ -172,6 +172,18 @@ void Impl::build_job(Job &job, const JobPlan &plan, const std::vector<uint32_t> 
             }
         }
         g.count = (uint32_t)job.items.size();
+        {
+            /* LDS of the launch: when every item takes the register path of srla_residual_cost (blocks of 1024 * FL samples)
+             * only that path's needs count -- the generic path's partition-mean tree would cost a workgroup per CU */
+            bool all_fast = true;
+            uint32_t fast_bytes = 0;
+            for (const SrlaItemDesc &it : job.items) {
+                const uint32_t fl = it.n >> 10;
+                if ((it.n & 1023u) != 0 || fl < 1 || fl > 8 || fl > 2u * (uint32_t)g.rclass) { all_fast = false; break; }
+                fast_bytes = std::max(fast_bytes, srla_kernel_fast_lds_bytes(fl));
+            }
+            if (all_fast) g.plan.total = fast_bytes;
+        }
         job.groups.push_back(g);
     }
     job.big_items.clear(); job.big_max_n = 0;
