@@ -15,6 +15,7 @@
 #ifndef SRLA_MI355X_H_INCLUDED
 #define SRLA_MI355X_H_INCLUDED
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -169,6 +170,19 @@ SRLAApiResult SRLAMI355X_EncodeWindows(
 SRLAApiResult SRLAMI355X_EncodeBatch(
     struct SRLAEncoder *encoder, uint32_t num_streams, const int32_t *const *const *inputs, const uint32_t *num_samples,
     uint8_t *const *data, const uint32_t *data_size, uint32_t *output_size, SRLAApiResult *results);
+
+/* The same with the OR of every stream's samples supplied by the caller (sample_or[i]; NULL: gathered by the library).  A
+ * front end that touches every sample anyway -- a WAV reader de-interleaving into planes -- gets the OR for free; with it and
+ * with input planes in pinned memory (below) the library's host threads do no per-sample work at all: the planes are read by
+ * DMA where they lie. */
+SRLAApiResult SRLAMI355X_EncodeBatchEx(
+    struct SRLAEncoder *encoder, uint32_t num_streams, const int32_t *const *const *inputs, const uint32_t *num_samples,
+    const uint32_t *sample_or, uint8_t *const *data, const uint32_t *data_size, uint32_t *output_size, SRLAApiResult *results);
+
+/* Pinned (page-locked, device-visible) host memory for callers that do not link HIP themselves: input planes in it are read
+ * by DMA without a staging copy, output buffers in it are written by the device directly.  NULL when no device is usable. */
+void *SRLAMI355X_AllocHost(size_t bytes);
+void SRLAMI355X_FreeHost(void *p);
 
 struct SRLAMI355XStats {
     uint64_t num_windows;

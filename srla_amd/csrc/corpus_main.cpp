@@ -4,7 +4,8 @@
  * native and multi-threaded, on top of the C ABI of libsrla_mi355x.so:
  *
  *   reader threads   mmap a .wav, parse it as WAV_CreateFromFile does, de-interleave to planar int32 (what the
- *                    reference hands to SRLAEncoder_EncodeWhole)
+ *                    reference hands to SRLAEncoder_EncodeWhole) in pinned memory, gathering the OR of the samples on the
+ *                    way: the library then reads the planes by DMA and its host threads touch no sample
  *   main thread      gathers the loaded files of one format into batches and calls SRLAMI355X_EncodeBatch (windows of
  *                    different files share the device jobs); one encoder handle per format, kept for the whole corpus
  *   writer threads   write <out>/<relative name>.srl, optionally hashing the streams for the manifest
@@ -95,14 +96,41 @@ struct Sha256 {
 };
 
 /* ---- WAV ------------------------------------------------------------------------------------------------- */
+/* Pinned buffers for the planes (SRLAMI355X_AllocHost: the device reads them by DMA, no staging copy in the library), kept
+ * on a free list: page-locking memory is slow, files of a corpus are of similar size. */
+class PinnedPool {
+public:
+    void *take(size_t bytes, size_t *cap)
+    {
+        {
+            std::lock_guard<std::mutex> l(m_);
+            for (size_t i = 0; i < free_.size(); i++)
+                if (free_[i].second >= bytes && free_[i].second <= 2 * bytes + (1u << 20)) {
+                    const auto e = free_[i]; free_.erase(free_.begin() + (long)i); *cap = e.second; return e.first;
+                }
+        }
+        const size_t want = bytes + bytes / 8 + 4096;
+        void *p = SRLAMI355X_AllocHost(want);
+        *cap = p ? want : 0;
+        return p;
+    }
+    void give(void *p, size_t cap) { if (p) { std::lock_guard<std::mutex> l(m_); free_.emplace_back(p, cap); } }
+private:
+    std::mutex m_;
+    std::vector<std::pair<void *, size_t>> free_;
+};
+PinnedPool g_pinned;
+
 struct Pcm {
     std::string path, rel;
     uint32_t nch = 0, bps = 0, rate = 0, n = 0;
     uint64_t file_size = 0;
-    int32_t *samples = nullptr;            /* planar [nch][n] */
+    int32_t *samples = nullptr;            /* planar [nch][n], pinned */
+    size_t samples_cap = 0;
+    uint32_t sample_or = 0;                /* OR of every sample (the offset left shift comes from it, srla_utility.c:177) */
     std::vector<const int32_t *> planes;
     std::string error;
-    ~Pcm() { free(samples); }
+    ~Pcm() { g_pinned.give(samples, samples_cap); }
 };
 
 uint32_t rd16(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
@@ -150,24 +178,31 @@ bool load_wav(Pcm &f)
     if (pos + data_size > size) return done("truncated data chunk");
     f.n = data_size / frame;
     if (f.n == 0) return done("no samples");
-    if (posix_memalign(reinterpret_cast<void **>(&f.samples), 64, (size_t)f.nch * f.n * 4 + 64) != 0) { f.samples = nullptr; return done("out of memory"); }
+    f.samples = static_cast<int32_t *>(g_pinned.take((size_t)f.nch * f.n * 4 + 64, &f.samples_cap));
+    if (f.samples == nullptr) return done("out of (pinned) memory");
     const uint8_t *d = b + pos;
     const uint32_t nch = f.nch, n = f.n;
+    uint32_t m = 0;
     if (f.bps == 16 && nch == 2) {
         int32_t *l = f.samples, *r = f.samples + n;
-        for (uint32_t i = 0; i < n; i++) { const uint32_t v = rd32(d + 4 * (size_t)i); l[i] = (int16_t)(v & 0xFFFFu); r[i] = (int16_t)(v >> 16); }
+        for (uint32_t i = 0; i < n; i++) {
+            const uint32_t v = rd32(d + 4 * (size_t)i);
+            const int32_t a = (int16_t)(v & 0xFFFFu), c = (int16_t)(v >> 16);
+            l[i] = a; r[i] = c; m |= (uint32_t)a | (uint32_t)c;
+        }
     } else {
         for (uint32_t ch = 0; ch < nch; ch++) {
             int32_t *o = f.samples + (size_t)ch * n;
             const uint8_t *s = d + (size_t)ch * bytes_ps;
             switch (f.bps) {
-            case 8:  for (uint32_t i = 0; i < n; i++) o[i] = (int32_t)s[(size_t)i * frame] - 128; break;
-            case 16: for (uint32_t i = 0; i < n; i++) o[i] = (int16_t)rd16(s + (size_t)i * frame); break;
-            case 24: for (uint32_t i = 0; i < n; i++) { const uint8_t *p = s + (size_t)i * frame; o[i] = ((int32_t)(((uint32_t)p[0] << 8) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 24))) >> 8; } break;
-            default: for (uint32_t i = 0; i < n; i++) o[i] = (int32_t)rd32(s + (size_t)i * frame); break;
+            case 8:  for (uint32_t i = 0; i < n; i++) { o[i] = (int32_t)s[(size_t)i * frame] - 128; m |= (uint32_t)o[i]; } break;
+            case 16: for (uint32_t i = 0; i < n; i++) { o[i] = (int16_t)rd16(s + (size_t)i * frame); m |= (uint32_t)o[i]; } break;
+            case 24: for (uint32_t i = 0; i < n; i++) { const uint8_t *p = s + (size_t)i * frame; o[i] = ((int32_t)(((uint32_t)p[0] << 8) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 24))) >> 8; m |= (uint32_t)o[i]; } break;
+            default: for (uint32_t i = 0; i < n; i++) { o[i] = (int32_t)rd32(s + (size_t)i * frame); m |= (uint32_t)o[i]; } break;
             }
         }
     }
+    f.sample_or = m;
     for (uint32_t ch = 0; ch < nch; ch++) f.planes.push_back(f.samples + (size_t)ch * n);
     return done(nullptr);
 }
@@ -200,9 +235,10 @@ private:
 
 struct Encoded {
     std::unique_ptr<Pcm> pcm;
-    std::unique_ptr<uint8_t[]> data;       /* not value-initialised: the pages are touched by whoever writes them */
+    uint8_t *data = nullptr;               /* 2 x the file size (srla_codec.c:125-129); not initialised: pages are touched by whoever writes them */
     size_t cap = 0;
     uint32_t size = 0;
+    ~Encoded() { delete[] data; }
     SRLAApiResult rc = SRLA_APIRESULT_OK;
 };
 
@@ -210,8 +246,8 @@ struct Options {
     int mode = 4, lookahead = 4, divisions = 1, ltp = 0;
     uint32_t max_block = 4096;
     std::string in_dir, out_dir, manifest;
-    uint64_t batch_samples = 96ull << 20;   /* sample frames per EncodeBatch call */
-    unsigned readers = 4, writers = 2;
+    uint64_t batch_samples = 48ull << 20;   /* sample frames per EncodeBatch call (about a dozen device jobs) */
+    unsigned readers = 6, writers = 2;
     bool sha = false, verbose = false;
     int rank = 0, world = 1, local_rank = 0;
 };
@@ -333,10 +369,10 @@ int main(int argc, char **argv)
                     std::error_code ec;
                     fs::create_directories(out.parent_path(), ec);
                     FILE *fp = fopen(out.string().c_str(), "wb");
-                    if (!fp || fwrite(e->data.get(), 1, e->size, fp) != e->size) en.error = "cannot write " + out.string();
+                    if (!fp || fwrite(e->data, 1, e->size, fp) != e->size) en.error = "cannot write " + out.string();
                     if (fp) fclose(fp);
                     en.out_bytes = e->size;
-                    if (o.sha) { Sha256 s; s.update(e->data.get(), e->size); en.sha = s.hex(); }
+                    if (o.sha) { Sha256 s; s.update(e->data, e->size); en.sha = s.hex(); }
                 }
                 const int64_t bytes = (int64_t)e->pcm->nch * e->pcm->n * 4;
                 e.reset();
@@ -382,19 +418,19 @@ int main(int argc, char **argv)
         const uint32_t ns = (uint32_t)files.size();
         std::vector<std::unique_ptr<Encoded>> outs(ns);
         std::vector<const int32_t *const *> inputs(ns);
-        std::vector<uint32_t> nsmp(ns), caps(ns), sizes_out(ns, 0);
+        std::vector<uint32_t> nsmp(ns), caps(ns), sizes_out(ns, 0), ors(ns);
         std::vector<uint8_t *> datas(ns);
         std::vector<SRLAApiResult> res(ns, SRLA_APIRESULT_NG);
         for (uint32_t i = 0; i < ns; i++) {
             outs[i].reset(new Encoded());
             outs[i]->cap = 2 * (size_t)files[i]->file_size;                    /* srla_codec.c:125-129 */
-            outs[i]->data.reset(new uint8_t[outs[i]->cap]);
-            inputs[i] = files[i]->planes.data(); nsmp[i] = files[i]->n;
-            datas[i] = outs[i]->data.get(); caps[i] = (uint32_t)std::min<uint64_t>(outs[i]->cap, 0xFFFFFFFFull);
+            outs[i]->data = new uint8_t[outs[i]->cap];
+            inputs[i] = files[i]->planes.data(); nsmp[i] = files[i]->n; ors[i] = files[i]->sample_or;
+            datas[i] = outs[i]->data; caps[i] = (uint32_t)std::min<uint64_t>(outs[i]->cap, 0xFFFFFFFFull);
         }
         SRLAApiResult rc = SRLA_APIRESULT_NG;
         const auto tb = std::chrono::steady_clock::now();
-        if (enc) rc = SRLAMI355X_EncodeBatch(enc, ns, inputs.data(), nsmp.data(), datas.data(), caps.data(), sizes_out.data(), res.data());
+        if (enc) rc = SRLAMI355X_EncodeBatchEx(enc, ns, inputs.data(), nsmp.data(), ors.data(), datas.data(), caps.data(), sizes_out.data(), res.data());
         if (o.verbose) {
             uint64_t tot = 0; for (uint32_t i = 0; i < ns; i++) tot += nsmp[i];
             const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb).count();
@@ -439,10 +475,14 @@ int main(int argc, char **argv)
         for (auto &kv : pending) keys.push_back(kv.first);
         for (const Key &k : keys) flush(k);
     }
+    auto stamp = [&](const char *what) {
+        if (o.verbose) fprintf(stderr, "[srla_corpus] %s at %.3f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    };
+    stamp("all batches encoded");
     for (auto &t : readers) t.join();
     finished.close();
     for (auto &t : writers) t.join();
-    for (auto &kv : encoders) if (kv.second) SRLAEncoder_Destroy(kv.second);
+    stamp("all files written");
 
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     std::sort(manifest.begin(), manifest.end(), [](const Entry &a, const Entry &b) { return a.rel < b.rel; });
@@ -463,5 +503,8 @@ int main(int argc, char **argv)
             fclose(fp);
         }
     }
-    return failures ? 1 : 0;
+    /* Everything is on disk.  Unpinning a few GB of buffers and tearing the device context down takes a quarter of a second
+     * that buys nothing at the end of a process: the operating system releases it all. */
+    fflush(stdout); fflush(stderr);
+    _exit(failures ? 1 : 0);
 }

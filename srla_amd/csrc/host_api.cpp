@@ -242,6 +242,25 @@ SRLAApiResult SRLAMI355X_EncodeBatch(struct SRLAEncoder *encoder, uint32_t num_s
                                      const uint32_t *num_samples, uint8_t *const *data, const uint32_t *data_size,
                                      uint32_t *output_size, SRLAApiResult *results)
 {
+    return SRLAMI355X_EncodeBatchEx(encoder, num_streams, inputs, num_samples, NULL, data, data_size, output_size, results);
+}
+
+void *SRLAMI355X_AllocHost(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipSetDevice(g_device_index) != hipSuccess || hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return NULL; }
+    return p;
+}
+
+void SRLAMI355X_FreeHost(void *p)
+{
+    if (p) (void)hipHostFree(p);
+}
+
+SRLAApiResult SRLAMI355X_EncodeBatchEx(struct SRLAEncoder *encoder, uint32_t num_streams, const int32_t *const *const *inputs,
+                                       const uint32_t *num_samples, const uint32_t *sample_or, uint8_t *const *data,
+                                       const uint32_t *data_size, uint32_t *output_size, SRLAApiResult *results)
+{
     Impl *im = impl_of(encoder);
     if (im == nullptr || num_streams == 0 || inputs == NULL || num_samples == NULL || data == NULL || data_size == NULL || output_size == NULL)
         return SRLA_APIRESULT_INVALID_ARGUMENT;
@@ -258,6 +277,12 @@ SRLAApiResult SRLAMI355X_EncodeBatch(struct SRLAEncoder *encoder, uint32_t num_s
         StreamCtx &st = im->sx[i];
         st.host_in = inputs[i]; st.num_samples = num_samples[i];
         st.data = data[i]; st.data_size = data_size[i]; st.with_header = true;
+        if (sample_or != NULL) {
+            /* the caller gathered the OR of the stream's samples already (srla_utility.c:177): the offset shift is known */
+            uint32_t sh = 0;
+            if (sample_or[i] != 0) while (((sample_or[i] >> sh) & 1u) == 0) sh++;
+            st.lshift = sh; st.lshift_final = true;
+        }
     }
     const SRLAApiResult rc = im->encode_streams(im->search_enabled());
     if (rc != SRLA_APIRESULT_OK && rc != SRLA_APIRESULT_INSUFFICIENT_BUFFER) return rc;
