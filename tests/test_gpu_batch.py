@@ -129,3 +129,47 @@ def test_batch_argument_errors(product):
         assert fn(None, 1, None, None, None, None, None, None) == capi.INVALID_ARGUMENT
     finally:
         product.destroy(enc)
+
+
+def test_batch_ex_with_pinned_planes_and_given_or_masks(product):
+    """SRLAMI355X_EncodeBatchEx: planes in SRLAMI355X_AllocHost memory (read by DMA where they lie) and the OR of every
+    stream's samples supplied by the caller -- the library's host threads then touch no sample (what srla_corpus does)."""
+    L = product.lib
+    L.SRLAMI355X_AllocHost.restype = C.c_void_p
+    L.SRLAMI355X_AllocHost.argtypes = [C.c_size_t]
+    L.SRLAMI355X_FreeHost.argtypes = [C.c_void_p]
+    fn = L.SRLAMI355X_EncodeBatchEx
+    fn.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    fn.restype = C.c_int
+    cli = CLIS["m4_B4096_V2_P3"]
+    base = [helpers.synth(helpers.MUSIC, 950 + i, 48000, 2, n) for i, n in enumerate((70000, 16384 * 3, 123457, 5000))]
+    shifts = [0, 2, 0, 5]
+    pcms = [np.ascontiguousarray((p >> s) << s) for p, s in zip(base, shifts)]
+    enc = _encoder(product, 2, **cli)
+    pinned = []
+    try:
+        views = []
+        for p in pcms:
+            ptr = L.SRLAMI355X_AllocHost(p.nbytes)
+            assert ptr
+            pinned.append(ptr)
+            v = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_int32)), shape=p.shape)
+            v[:] = p
+            views.append(v)
+        n = len(pcms)
+        keep = [capi.planar_ptrs(v) for v in views]
+        inputs = (C.c_void_p * n)(*[C.cast(k, C.c_void_p) for k in keep])
+        nsmp = (C.c_uint32 * n)(*[p.shape[1] for p in pcms])
+        ors = (C.c_uint32 * n)(*[int(np.bitwise_or.reduce(p.astype(np.int64).ravel() & 0xFFFFFFFF)) for p in pcms])
+        outs = [np.zeros(4 * p.size + 1024, np.uint8) for p in pcms]
+        data = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+        caps = (C.c_uint32 * n)(*[o.size for o in outs])
+        sizes = (C.c_uint32 * n)()
+        res = (C.c_int * n)()
+        assert fn(enc, n, inputs, nsmp, ors, data, caps, sizes, res) == capi.OK
+        for i, p in enumerate(pcms):
+            assert np.array_equal(outs[i][:sizes[i]], _oracle(p, **cli)), i
+    finally:
+        product.destroy(enc)
+        for ptr in pinned:
+            L.SRLAMI355X_FreeHost(ptr)
