@@ -178,6 +178,9 @@ typedef struct SrlaJobParams {
     uint32_t num_items;
     uint32_t num_cands;
     uint32_t num_windows;
+    uint32_t keep_residuals;  /* srla_residual_cost stores every item's residual and srla_pack_blocks reads the chosen ones (the
+                               * default, and what SRLAMI355X_ProbeBlock returns); 0 (SRLA_MI355X_RECOMPUTE_RESIDUALS): none are
+                               * stored and srla_pack_blocks recomputes the chosen blocks' (blocks > 8192 samples always keep) */
     uint32_t out_stride;      /* SRLA_DIAG_STOP builds only: where srla_residual_cost stops (kernel timing experiments) */
     const uint32_t *lshift_dev; /* when non-null the offset left shift is read from here (device memory) instead of the
                                * item's: lets a whole device-resident stream be enqueued before its OR-reduction has finished */

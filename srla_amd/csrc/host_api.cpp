@@ -330,7 +330,10 @@ SRLAApiResult SRLAMI355X_ProbeBlock(struct SRLAEncoder *encoder, const int32_t *
     plan.segs.push_back({ 0u, 0u, num_samples, 0u });
     plan.total = (num_samples + 15u) & ~15u;
     s.emits = true; s.merge_cb = false;
-    if (!im->run_job_sync(s, plan, false, true, 0)) return SRLA_APIRESULT_NG;
+    im->keep_residuals = residuals != nullptr;
+    const bool ran = im->run_job_sync(s, plan, false, true, 0);
+    im->keep_residuals = false;
+    if (!ran) return SRLA_APIRESULT_NG;
     const uint32_t nv = im->num_variants();
     if (records && hipMemcpy(records, s.d_results.p, (size_t)nv * sizeof(SrlaItemResult), hipMemcpyDeviceToHost) != hipSuccess)
         return SRLA_APIRESULT_NG;

@@ -87,6 +87,7 @@ struct Job {
     std::vector<uint32_t> seg_first_window;   /* per segment (+ one past the end) */
     uint32_t num_slots = 0;
     uint64_t res_elems = 0;
+    bool keep_residuals = false;
     uint64_t analyzed_samples = 0;
     std::vector<SrlaAutocorrItem> class_index; /* the items grouped by FFT-size class (srla_autocorr launches per class) */
     uint32_t class_first[6] = {}, class_count[6] = {};   /* N' <= 1024, 2048, 4096, 8192, 16384, 32768 */
@@ -158,6 +159,8 @@ struct Impl {
     SRLAEncodeParameter par{};
     bool set_parameter = false;
     uint32_t param_generation = 0;    /* bumped by SetEncodeParameter: invalidates cached job tables */
+    bool keep_residuals_always = true;  /* false with SRLA_MI355X_RECOMPUTE_RESIDUALS */
+    bool keep_residuals = false;      /* SRLAMI355X_ProbeBlock with a residual buffer: srla_residual_cost stores what it prices */
     uint32_t offset_lshift = 0;       /* encoder->header.offset_lshift of the reference: set by EncodeWhole, used by the block calls */
     uint32_t pack_threads = 0;
 

@@ -94,6 +94,9 @@ bool Impl::init_device()
     HIP_OK(hipEventCreate(&ev_or));
     HIP_OK(hipEventCreate(&ev_ref));
     timeline = getenv("SRLA_MI355X_TIMELINE") != nullptr;
+    /* experiment kept as an option: no residuals in HBM, srla_pack_blocks recomputes the chosen blocks' (HBM
+     * traffic / 3, throughput -1..-8 %: these kernels are not bound by HBM) */
+    keep_residuals_always = getenv("SRLA_MI355X_RECOMPUTE_RESIDUALS") == nullptr;
     HIP_OK(hipStreamCreateWithFlags(&upload, hipStreamNonBlocking));
     {
         int lo = 0, hi = 0;

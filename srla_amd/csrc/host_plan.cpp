@@ -84,7 +84,7 @@ void Impl::build_job(Job &job, const JobPlan &plan, const std::vector<uint32_t> 
     const uint32_t window_len = search ? par.num_lookahead_samples : maxb;
     const uint32_t nv = num_variants(), pmax = preset_order();
     uint64_t key = 1469598103934665603ull;
-    key = fnv64(key, ((uint64_t)param_generation << 1) | (search ? 1u : 0u));
+    key = fnv64(key, ((uint64_t)param_generation << 2) | ((keep_residuals || keep_residuals_always) ? 2u : 0u) | (search ? 1u : 0u));
     key = fnv64(key, plan.total);
     for (size_t k = 0; k < plan.segs.size(); k++) {
         key = fnv64(key, ((uint64_t)plan.segs[k].ns << 32) | plan.segs[k].base);
@@ -102,6 +102,7 @@ void Impl::build_job(Job &job, const JobPlan &plan, const std::vector<uint32_t> 
     job.windows.clear(); job.cands.clear(); job.items.clear(); job.groups.clear(); job.class_index.clear();
     job.seg_first_window.clear();
     job.num_slots = 0; job.res_elems = 0; job.analyzed_samples = 0;
+    job.keep_residuals = keep_residuals || keep_residuals_always;
 
     struct Pending { uint32_t cand; uint32_t nfft; uint32_t seg; };
     std::vector<Pending> analysed;
@@ -166,7 +167,7 @@ void Impl::build_job(Job &job, const JobPlan &plan, const std::vector<uint32_t> 
                 it.lshift = lshift[p.seg];
                 it.forced_ltp = 0;
                 it.seg = p.seg;
-                job.res_elems += (cd.n + 3u) & ~3u;
+                if (job.keep_residuals || cd.n > 8192u) job.res_elems += (cd.n + 3u) & ~3u;   /* see SrlaJobParams::keep_residuals */
                 job.analyzed_samples += cd.n;
                 job.items.push_back(it);
             }
@@ -230,6 +231,7 @@ SrlaJobParams Impl::job_params(const Job &job, uint32_t channel_stride, bool lsh
     { static const char *e = getenv("SRLA_MI355X_K3_STOP"); jp.out_stride = e ? (uint32_t)atoi(e) : 0u; }   /* kernel timing experiments only */
 #endif
     jp.lshift_dev = lshift_on_device ? (d_or.as<uint32_t>() + 1) : nullptr;
+    jp.keep_residuals = job.keep_residuals ? 1u : 0u;
     jp.tie_rel = tie_rel; jp.tie_ltp = tie_ltp; jp.tie_logscale = tie_logscale; jp.tie_ltpbias = tie_ltpbias;
     return jp;
 }

@@ -1353,8 +1353,9 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
             u[i] = zigzag32(rv);
             max_u = (u[i] > max_u) ? u[i] : max_u;
         }
+        if (jp.keep_residuals)
 #pragma unroll
-        for (int c = 0; c < FL; c++) *reinterpret_cast<int4 *>(res_out + 4 * c) = make_int4(rr[4 * c], rr[4 * c + 1], rr[4 * c + 2], rr[4 * c + 3]);
+            for (int c = 0; c < FL; c++) *reinterpret_cast<int4 *>(res_out + 4 * c) = make_int4(rr[4 * c], rr[4 * c + 1], rr[4 * c + 2], rr[4 * c + 3]);
     }
 #ifdef SRLA_DIAG_STOP
     if (jp.out_stride == 2) { if (max_u == 0x7fffffff) out->pad[1] = 1; return; }   /* kernel timing experiments (make EXTRA=-DSRLA_DIAG_STOP): never in the shipped library */
@@ -1821,7 +1822,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(R >= 4 ? 2 :
                     uz[c][i] = z;
                     max_u = (z > max_u) ? z : max_u;
                 }
-                if (i4 + 4 <= n) *reinterpret_cast<int4 *>(res_out + i4) = make_int4(rr[0], rr[1], rr[2], rr[3]);
+                if (!jp.keep_residuals) { }
+                else if (i4 + 4 <= n) *reinterpret_cast<int4 *>(res_out + i4) = make_int4(rr[0], rr[1], rr[2], rr[3]);
                 else { for (int i = 0; i < 4; i++) if (i4 + i < n) res_out[i4 + i] = rr[i]; }
             }
         }
@@ -2643,12 +2645,111 @@ __device__ __forceinline__ uint32_t get_word(const uint32_t *w, uint32_t i)
     return w[i];
 }
 
+/* SRLA_MI355X_RECOMPUTE_RESIDUALS only (jp.keep_residuals == 0).  The residual of one channel of a chosen block (<= 8192
+ * samples), recomputed into LDS by the block's pack workgroup -- pre-emphasis (srla_utility.c:342), long-term predictor
+ * (srla_lpc_predict.c:267-294), int32 wrap-around FIR (:118-265), each stage rewriting the buffer in place from the top of
+ * the block down (every output reads lower indices only).  In this mode srla_residual_cost prices every candidate x variant
+ * and writes nothing but the item record; only the chosen blocks' residuals ever exist, here, on their way into the
+ * bitstream.  Measured: HBM traffic of the analysis / 3, whole-job throughput -8 % (M) .. -1 % (C5), because
+ * the pack workgroups hold twice the LDS for longer on a chip whose kernels are bound by VALU and LDS, not by HBM: hence an
+ * option, not the default.  rl: FIR_PAD zeros, then the block. */
+__device__ void pack_residual_lds(const SrlaJobParams &jp, const int32_t *__restrict__ input, const SrlaItemDesc &it,
+                                  const SrlaItemResult *__restrict__ ir, int32_t *rl, int32_t *coefq)
+{
+    const uint32_t tid = threadIdx.x, n = it.n;
+    const InputView iv = input_view(jp, it.lshift);
+    const int32_t *in = input + it.sample_off;
+    const bool aligned = input_aligned(in, iv);
+    const int32_t pc = ir->preemph_coef;
+    const uint32_t order = ir->lpc_order, rshift = ir->lpc_rshift, period = ir->ltp_period;
+    const uint32_t o4 = (order + 3u) & ~3u;
+    int32_t *y = rl + FIR_PAD;
+    __syncthreads();                                             /* the previous channel's readers are done with the buffer */
+    for (uint32_t i = tid; i < FIR_PAD; i += NT) rl[i] = 0;
+    for (uint32_t i4 = 4u * tid; i4 < n; i4 += 4u * NT) {
+        int32_t t4[4];
+        load_chunk(in, iv, it.variant, i4, n, aligned, t4);
+        int32_t prev = (i4 == 0) ? t4[0] : load_variant(in, iv, it.variant, i4 - 1);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int32_t cur = t4[i];
+            t4[i] = (i4 + (uint32_t)i < n) ? (int32_t)((uint32_t)cur - (uint32_t)((int32_t)((uint32_t)prev * (uint32_t)pc) >> 4)) : 0;
+            prev = cur;
+        }
+        *reinterpret_cast<int4 *>(y + i4) = make_int4(t4[0], t4[1], t4[2], t4[3]);
+    }
+    for (uint32_t k = tid; k < o4; k += NT) coefq[k] = (k < o4 - order) ? 0 : (int32_t)ir->lpc_coef[k - (o4 - order)];
+    __syncthreads();
+    const uint32_t nblk = (n + 4u * NT - 1u) / (4u * NT);
+    if (period > 0) {
+        const uint32_t taps = jp.ltp_order, half_order = taps >> 1;
+        const int32_t c0 = ir->ltp_coef[0], c1 = ir->ltp_coef[1], c2 = ir->ltp_coef[2];
+        for (uint32_t b = nblk; b-- > 0;) {
+            const uint32_t i4 = 4u * (b * NT + tid);
+            int32_t v[4] = { 0, 0, 0, 0 };
+            if (i4 < n) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const uint32_t sidx = i4 + (uint32_t)i;
+                    int32_t cur = y[sidx];
+                    if (sidx < n && sidx >= period + half_order + 1) {
+                        const uint32_t base = sidx - period - half_order;
+                        uint32_t acc = 16u + (uint32_t)c0 * (uint32_t)y[base];
+                        if (taps == 3) acc += (uint32_t)c1 * (uint32_t)y[base + 1] + (uint32_t)c2 * (uint32_t)y[base + 2];
+                        cur = (int32_t)((uint32_t)cur - (uint32_t)((int32_t)acc >> 5));
+                    }
+                    v[i] = cur;
+                }
+            }
+            __syncthreads();
+            if (i4 < n) *reinterpret_cast<int4 *>(y + i4) = make_int4(v[0], v[1], v[2], v[3]);
+            __syncthreads();
+        }
+    }
+    const int32_t half = (int32_t)(1u << ((rshift - 1u) & 31u));
+    for (uint32_t b = nblk; b-- > 0;) {
+        const uint32_t i4 = 4u * (b * NT + tid);
+        int32_t rr[4] = { 0, 0, 0, 0 };
+        if (i4 < n) {
+            uint32_t acc[4] = { (uint32_t)half, (uint32_t)half, (uint32_t)half, (uint32_t)half };
+            int4 cur = *reinterpret_cast<const int4 *>(y + (int)i4 - (int)o4);
+            for (uint32_t kb = 0; kb < o4; kb += 4) {
+                const int4 cf = *reinterpret_cast<const int4 *>(&coefq[kb]);
+                const int4 nxt = *reinterpret_cast<const int4 *>(y + (int)i4 - (int)o4 + (int)kb + 4);
+                const uint32_t w0 = (uint32_t)cur.x, w1 = (uint32_t)cur.y, w2 = (uint32_t)cur.z, w3 = (uint32_t)cur.w;
+                const uint32_t w4 = (uint32_t)nxt.x, w5 = (uint32_t)nxt.y, w6 = (uint32_t)nxt.z;
+                const uint32_t f0 = (uint32_t)cf.x, f1 = (uint32_t)cf.y, f2 = (uint32_t)cf.z, f3 = (uint32_t)cf.w;
+                acc[0] += f0 * w0 + f1 * w1 + f2 * w2 + f3 * w3;
+                acc[1] += f0 * w1 + f1 * w2 + f2 * w3 + f3 * w4;
+                acc[2] += f0 * w2 + f1 * w3 + f2 * w4 + f3 * w5;
+                acc[3] += f0 * w3 + f1 * w4 + f2 * w5 + f3 * w6;
+                cur = nxt;
+            }
+            const int32_t y4[4] = { cur.x, cur.y, cur.z, cur.w };        /* after the tap loop: y[i4 .. i4 + 3] */
+            const int32_t ym1 = (i4 > 0) ? y[i4 - 1] : 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t sidx = i4 + (uint32_t)i;
+                int32_t rv;
+                if (order == 0 || sidx == 0) rv = y4[i];
+                else if (sidx < order) rv = (int32_t)((uint32_t)y4[i] - (uint32_t)((i == 0) ? ym1 : y4[i - 1]));
+                else rv = (int32_t)((uint32_t)y4[i] + (uint32_t)((int32_t)acc[i] >> rshift));
+                rr[i] = (sidx < n) ? rv : 0;
+            }
+        }
+        __syncthreads();
+        if (i4 < n) *reinterpret_cast<int4 *>(y + i4) = make_int4(rr[0], rr[1], rr[2], rr[3]);
+        __syncthreads();
+    }
+}
+
 template <bool G>
 __device__ __forceinline__ void pack_block_body(
     const SrlaJobParams &jp, const SrlaBlockRecord *__restrict__ recp, const int32_t *__restrict__ input,
     const SrlaItemDesc *__restrict__ items, const SrlaItemResult *__restrict__ results, const int32_t *__restrict__ res_ws,
     const uint32_t *__restrict__ huff_code, const uint8_t *__restrict__ huff_len, uint32_t *w, uint32_t *aux, uint32_t *kpar,
-    uint8_t *__restrict__ dst, SrlaJobInfo *__restrict__ info)
+    uint8_t *__restrict__ dst, SrlaJobInfo *__restrict__ info, int32_t *rl /* LDS for the recomputed residual, + 264 words of taps behind it */,
+    uint32_t rl_samples)
 {
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     /* scalars of the record; item[] stays in memory (dynamic indexing of a by-value copy would spill) */
@@ -2747,7 +2848,13 @@ __device__ __forceinline__ void pack_block_body(
                     uint32_t *d32 = reinterpret_cast<uint32_t *>(kp);
                     for (uint32_t i = tid; i < (((1u << porder) + 3u) >> 2); i += NT) d32[i] = src[i];
                 }
+                /* blocks of at most 8192 samples: the residual is recomputed here (pack_residual_lds); larger ones were
+                 * kept in HBM by srla_residual_cost_big */
                 const int32_t *res = res_ws + items[item].res_off;
+                if (n <= 8192u && !jp.keep_residuals) {
+                    pack_residual_lds(jp, input, items[item], ir, rl, rl + FIR_PAD + rl_samples + 8);
+                    res = rl + FIR_PAD;
+                }
                 const uint32_t plen = n >> porder;
                 const uint32_t per = (n + NT - 1) / NT;                  /* contiguous samples per thread */
                 const uint32_t s0 = (tid * per < n) ? tid * per : n, s1 = (s0 + per < n) ? (s0 + per) : n;
@@ -2897,22 +3004,23 @@ __global__ __launch_bounds__(NT) void srla_pack_blocks(
     const SrlaBlockRecord *__restrict__ blocks, const SrlaItemResult *__restrict__ results,
     const int32_t *__restrict__ res_ws, const uint32_t *__restrict__ huff_code, const uint8_t *__restrict__ huff_len,
     const uint32_t *__restrict__ block_off, const uint32_t *__restrict__ seg_ctl, uint8_t *__restrict__ out,
-    uint8_t *__restrict__ scratch, SrlaJobInfo *__restrict__ info, uint32_t lds_words)
+    uint8_t *__restrict__ scratch, SrlaJobInfo *__restrict__ info, uint32_t lds_words, uint32_t rl_samples)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     uint32_t *aux = (uint32_t *)lds;                         /* 32 words: wave sums */
     uint32_t *kpar = aux + 32;                               /* 2 x 1024 bytes: partition parameters of the channel in work */
-    uint32_t *words = kpar + 512;                            /* lds_words entries */
+    int32_t *rl = (int32_t *)(kpar + 512);                   /* FIR_PAD + rl_samples + 8 words: recomputed residual; 264 words: taps */
+    uint32_t *words = (uint32_t *)(rl + FIR_PAD + rl_samples + 8 + FIR_PAD + 8);   /* lds_words entries */
     const uint32_t slot = blockIdx.x;
     const SrlaBlockRecord *recp = &blocks[slot];
     if (!recp->valid || seg_ctl[(size_t)SRLA_SEGCTL_WORDS * recp->seg + 3u]) return;
     uint8_t *dst = out + block_off[slot];
     const uint32_t nwords = ((recp->bytes + 3u) >> 2) + 1u;
     if (nwords <= lds_words) {
-        pack_block_body<false>(jp, recp, input, items, results, res_ws, huff_code, huff_len, words, aux, kpar, dst, info);
+        pack_block_body<false>(jp, recp, input, items, results, res_ws, huff_code, huff_len, words, aux, kpar, dst, info, rl, rl_samples);
     } else {
         const size_t off = ((size_t)recp->sample_off * jp.num_channels * (jp.bits_per_sample >> 3) + (size_t)slot * SRLA_PACK_SLACK + 3u) & ~(size_t)3u;
-        pack_block_body<true>(jp, recp, input, items, results, res_ws, huff_code, huff_len, (uint32_t *)(scratch + off), aux, kpar, dst, info);
+        pack_block_body<true>(jp, recp, input, items, results, res_ws, huff_code, huff_len, (uint32_t *)(scratch + off), aux, kpar, dst, info, rl, rl_samples);
     }
 }
 
@@ -3240,11 +3348,12 @@ extern "C" int srla_launch_pack(hipStream_t stream, const SrlaJobParams *jp, uin
     hipExtLaunchKernelGGL(srla_block_offsets, dim3(1), dim3(NT), 0, stream, ev_start, nullptr, 0, *jp, windows, blocks, results, num_slots, block_off,
                        stream_pos, segs, seg_ctl, (uint64_t)reinterpret_cast<uintptr_t>(stage), info, window_bytes, seg_info, ties);
     const uint32_t lds_words = srla_pack_lds_words(jp);
-    const uint32_t lds = (lds_words + 32 + 512) * 4;
+    const uint32_t rl_samples = jp->keep_residuals ? 0u : ((jp->max_block < 8192u ? jp->max_block : 8192u) + 3u) & ~3u;
+    const uint32_t lds = (lds_words + 32 + 512 + (FIR_PAD + rl_samples + 8) + (FIR_PAD + 8)) * 4;
     SET_LDS_ATTR(srla_pack_blocks);
     hipLaunchKernelGGL(srla_pack_blocks, dim3(num_slots), dim3(NT), lds, stream,
                        *jp, input, items, blocks, results, res_ws, huff_code, huff_len, block_off, seg_ctl, stage, scratch, info,
-                       lds_words);
+                       lds_words, rl_samples);
     static int out_wgs = -1, out_thr = 0, out_sleep = 0;
     if (out_wgs < 0) {
         const char *e = getenv("SRLA_MI355X_OUT_WGS"); out_wgs = e ? atoi(e) : 0; if (out_wgs < 0) out_wgs = 0;

@@ -537,6 +537,25 @@ def test_too_few_job_buffer_sets_are_refused_not_raced(product, monkeypatch):
         assert np.array_equal(product.encode(pcm, **cli), want), slots
 
 
+@pytest.mark.parametrize("cli,bits,nch", [(dict(preset=4, max_block=4096, divisions=1), 16, 2),
+                                          (dict(preset=4, max_block=4096, divisions=2, ltp_order=3), 16, 2),
+                                          (dict(preset=6, max_block=8192, divisions=3, ltp_order=1), 24, 3),
+                                          (dict(preset=1, max_block=1024, divisions=0), 8, 1)],
+                         ids=["m4_V1", "m4_V2_P3", "m6_B8192_V3_P1_24bit_3ch", "m1_B1024_V0_8bit_mono"])
+def test_pack_side_residual_recompute_option_gives_the_same_bytes(product, monkeypatch, cli, bits, nch):
+    """SRLA_MI355X_RECOMPUTE_RESIDUALS: srla_residual_cost keeps no residuals, srla_pack_blocks recomputes the chosen blocks'
+    (pre-emphasis, LTP, FIR in LDS).  Same stream, odd length included (chain-mode tail)."""
+    monkeypatch.setenv("SRLA_MI355X_RECOMPUTE_RESIDUALS", "1")
+    monkeypatch.setenv("SRLA_MI355X_JOB_SAMPLES", "131072")
+    pcm = helpers.synth(helpers.MUSIC if nch == 2 else helpers.VARIED, 77, 48000, nch, 300_001)
+    if bits == 24:
+        pcm = pcm << 6
+    elif bits == 8:
+        pcm = pcm >> 8
+    want = helpers.Oracle(nch, bits_per_sample=bits, **cli).encode_whole(pcm)
+    assert np.array_equal(product.encode(pcm, bits_per_sample=bits, **cli), want)
+
+
 def test_wrong_shift_guess_that_overflows_the_buffer_is_retried(product, monkeypatch):
     """Host input without callback is encoded with the offset shift of its FIRST job while the OR of the rest is still being
     gathered.  16-bit audio in a 24-bit container behind leading digital silence: the guess (0) makes the stream much larger
