@@ -556,6 +556,17 @@ def test_pack_side_residual_recompute_option_gives_the_same_bytes(product, monke
     assert np.array_equal(product.encode(pcm, bits_per_sample=bits, **cli), want)
 
 
+@pytest.mark.parametrize("cli", [dict(preset=4, max_block=4096, divisions=2, ltp_order=3), dict(preset=4, max_block=2048, divisions=0),
+                                 dict(preset=2, max_block=8192, divisions=1)], ids=["B4096_V2_P3", "B2048_V0", "B8192_V1"])
+def test_fused_fft_option_gives_the_same_bytes(product, monkeypatch, cli):
+    """SRLA_MI355X_FUSED_FFT: two radix-4 stages per LDS round trip (lane pairs exchanging through v_permlane32_swap) for the
+    2048- and 4096-point transforms, pruned inverse included; same butterflies, same bits.  Odd length: chain-mode tail."""
+    monkeypatch.setenv("SRLA_MI355X_FUSED_FFT", "1")
+    pcm = helpers.synth(helpers.MUSIC, 78, 48000, 2, 500_001)
+    want = helpers.Oracle(2, **cli).encode_whole(pcm)
+    assert np.array_equal(product.encode(pcm, **cli), want)
+
+
 def test_wrong_shift_guess_that_overflows_the_buffer_is_retried(product, monkeypatch):
     """Host input without callback is encoded with the offset shift of its FIRST job while the OR of the rest is still being
     gathered.  16-bit audio in a 24-bit container behind leading digital silence: the guess (0) makes the stream much larger
