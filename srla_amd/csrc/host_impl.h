@@ -100,11 +100,14 @@ struct Job {
 struct Slot {
     hipStream_t own_stream = nullptr;    /* chain-mode jobs: every stage but the block assembly runs here */
     hipEvent_t t0[6] = {}, t1[6] = {};   /* start / end of the stages of the job (see Impl::run_stage) */
+    hipEvent_t ev_a1 = nullptr, ev_p0 = nullptr, ev_p = nullptr, ev_a0 = nullptr;   /* stage A of an LTP job in two parts (run_stage): end of the
+                                          * LTP-pass autocorrelation, start / end of the pitch solve, start of the LPC-pass autocorrelation */
     hipEvent_t ev_in = nullptr;          /* the job's samples have arrived in d_input (host-input calls) */
     const int32_t *in_cur = nullptr;     /* device input of the current job */
     uint32_t stride_cur = 0;
     SrlaJobParams jp{};
     bool want_dbg = false;
+    bool split_a = false;                /* stage A was enqueued in two parts (run_stage) */
     bool timed = false;                  /* this job records start events for every stage (one job in four) */
     uint32_t out_boost = 1;              /* stream-out workgroup multiplier (the last jobs of a stream drain faster) */
     DevBuf d_input16;                    /* host input of at most 16 bits crosses PCIe as int16 and is widened into d_input */
@@ -159,6 +162,7 @@ struct Impl {
     SRLAEncodeParameter par{};
     bool set_parameter = false;
     uint32_t param_generation = 0;    /* bumped by SetEncodeParameter: invalidates cached job tables */
+    bool split_ltp_stage = true;        /* SRLA_MI355X_NO_LTP_SKEW: stage A of LTP jobs in one piece on W, as before */
     bool keep_residuals_always = true;  /* false with SRLA_MI355X_RECOMPUTE_RESIDUALS */
     bool keep_residuals = false;      /* SRLAMI355X_ProbeBlock with a residual buffer: srla_residual_cost stores what it prices */
     uint32_t offset_lshift = 0;       /* encoder->header.offset_lshift of the reference: set by EncodeWhole, used by the block calls */
@@ -177,7 +181,7 @@ struct Impl {
     std::string tl_log;               /* printed when the call is done: writing to stderr on the way distorts what is measured */
     void tl_printf(const char *fmt, ...) __attribute__((format(printf, 2, 3)));
     PinBuf h_or;
-    uint32_t kSlots = 4;              /* job buffer sets (SRLA_MI355X_SLOTS) */
+    uint32_t kSlots = 5;              /* job buffer sets (SRLA_MI355X_SLOTS) */
     uint64_t job_samples = 4ull << 20; /* samples per job (SRLA_MI355X_JOB_SAMPLES): fixed per-job latencies (serial solve chain, launch gaps) favour large jobs; measured best for long streams, and never worse than smaller ones for short streams */
     Slot slot[kMaxSlots];
     DevBuf d_tw, d_geoms, d_thr, d_huff, d_huffcode, d_pos, d_or;
@@ -245,7 +249,11 @@ struct Impl {
     void settle_lshift(const JobPlan &plan, std::vector<uint32_t> &lshift);
     /* buffers, table upload, segment table; `init_pos_of(stream)`: where a stream's first segment of this pass starts */
     bool prepare_job(Slot &s, bool want_dbg);
-    bool run_stage(Slot &s, int st);
+    /* part (stage A of a job with the long-term predictor only): 0 = the whole stage on W; 1 = the LTP-pass autocorrelation
+     * on W and the pitch solve behind it on N; 2 = the LPC-pass autocorrelation on W behind the pitch solve.  The job loop
+     * enqueues part 2 one iteration after part 1, so that W runs the neighbouring jobs' wide kernels while the pitch solve
+     * (a latency chain of a few wavefronts, 0.6 ms per job at -P 3) works on N. */
+    bool run_stage(Slot &s, int st, int part = 0);
     bool wait_job(Slot &s);
     /* one job from plan to finished bytes, synchronously (block calls, probes); arbitrates near-ties */
     bool run_job_sync(Slot &s, const JobPlan &plan, bool search, bool want_dbg, uint32_t jobkey);

@@ -35,6 +35,7 @@ Impl::~Impl()
             for (auto &e : s.t0) if (e) (void)hipEventDestroy(e);
             for (auto &e : s.t1) if (e) (void)hipEventDestroy(e);
             if (s.ev_in) (void)hipEventDestroy(s.ev_in);
+            for (hipEvent_t e : { s.ev_a1, s.ev_p0, s.ev_p, s.ev_a0 }) if (e) (void)hipEventDestroy(e);
             s.d_input16.release();
             DevBuf *db[] = { &s.d_input, &s.d_items, &s.d_cands, &s.d_windows, &s.d_results, &s.d_res_ws,
                              &s.d_blocks, &s.d_block_off, &s.d_scratch, &s.d_dbg, &s.d_lags, &s.d_err, &s.d_class_index, &s.d_stream,
@@ -67,8 +68,8 @@ bool Impl::init_device()
         /* the software pipeline of encode_stream keeps depth + 1 = 4 jobs in flight: fewer buffer sets would be reused before
          * their job has been collected; + 2 slots for the tail jobs, + 3 for chain mode */
         const int v = atoi(e);
-        if (v >= 4 && v + 5 <= (int)kMaxSlots) kSlots = (uint32_t)v;
-        else fprintf(stderr, "[srla-mi355x] SRLA_MI355X_SLOTS=%d ignored: %d..%d job buffer sets are supported\n", v, 4, (int)kMaxSlots - 5);
+        if (v >= 5 && v + 5 <= (int)kMaxSlots) kSlots = (uint32_t)v;
+        else fprintf(stderr, "[srla-mi355x] SRLA_MI355X_SLOTS=%d ignored: %d..%d job buffer sets are supported\n", v, 5, (int)kMaxSlots - 5);
     }
     if (const char *e = getenv("SRLA_MI355X_JOB_SAMPLES")) { const long long v = atoll(e); if (v >= 65536) job_samples = (uint64_t)v; }
     int count = 0;
@@ -97,6 +98,7 @@ bool Impl::init_device()
     /* experiment kept as an option: no residuals in HBM, srla_pack_blocks recomputes the chosen blocks' (HBM
      * traffic / 3, throughput -1..-8 %: these kernels are not bound by HBM) */
     keep_residuals_always = getenv("SRLA_MI355X_RECOMPUTE_RESIDUALS") == nullptr;
+    split_ltp_stage = getenv("SRLA_MI355X_NO_LTP_SKEW") == nullptr;
     HIP_OK(hipStreamCreateWithFlags(&upload, hipStreamNonBlocking));
     {
         int lo = 0, hi = 0;
@@ -109,6 +111,7 @@ bool Impl::init_device()
         for (auto &e : s.t0) HIP_OK(hipEventCreate(&e));
         for (auto &e : s.t1) HIP_OK(hipEventCreate(&e));
         HIP_OK(hipEventCreateWithFlags(&s.ev_in, hipEventDisableTiming));
+        HIP_OK(hipEventCreate(&s.ev_a1)); HIP_OK(hipEventCreate(&s.ev_p0)); HIP_OK(hipEventCreate(&s.ev_p)); HIP_OK(hipEventCreate(&s.ev_a0));
     }
     double thr[32];
     srla::build_rice_thresholds(thr);
@@ -362,7 +365,7 @@ bool Impl::prepare_job(Slot &s, bool want_dbg)
     return true;
 }
 
-bool Impl::run_stage(Slot &s, int st)
+bool Impl::run_stage(Slot &s, int st, int part)
 {
     Job &job = s.job;
     /* chain-mode jobs keep to their own stream up to the pricing, so that the regular jobs never queue behind their
@@ -379,8 +382,10 @@ bool Impl::run_stage(Slot &s, int st)
     hipEvent_t ev0 = s.timed ? s.t0[st] : nullptr;
     switch (st) {
     case ST_A: {
-        if (on_device) HIP_OK(hipStreamWaitEvent(W, ev_or, 0));
-        if (s.used_h2d) HIP_OK(hipStreamWaitEvent(W, s.ev_in, 0));
+        if (part != 2) {
+            if (on_device) HIP_OK(hipStreamWaitEvent(W, ev_or, 0));
+            if (s.used_h2d) HIP_OK(hipStreamWaitEvent(W, s.ev_in, 0));
+        }
         struct L { int kind, cls, pass; };                       /* kind 0: autocorr class launch, 1: pitch solve */
         L seq[16]; int nl = 0;
         if (have_items) {
@@ -389,9 +394,21 @@ bool Impl::run_stage(Slot &s, int st)
                 if (pass == 1) seq[nl++] = { 1, 0, 1 };
             }
         }
+        /* the two-part form only for what it is made for: items, two passes */
+        const bool split = part != 0 && have_items && par.ltp_order > 0;
+        if (part == 2 && !split) break;                          /* part 1 did the whole stage */
+        int first = 0, last = nl - 1, pitch_at = -1;
+        for (int i = 0; i < nl; i++) if (seq[i].kind == 1) pitch_at = i;
+        if (split && part == 1) last = pitch_at;
+        if (split && part == 2) { first = pitch_at + 1; HIP_OK(hipStreamWaitEvent(W, s.ev_p, 0)); }
         static const int kClass[4] = { 0, 1, 2, 4 };     /* FFT size / 2048 (0: at most 1024 points) */
-        for (int i = 0; i < nl; i++) {
+        for (int i = first; i <= last; i++) {
             hipEvent_t e0 = (i == 0) ? ev0 : nullptr, e1 = (i == nl - 1) ? s.t1[ST_A] : nullptr;
+            if (split) {
+                if (i == pitch_at - 1) e1 = s.ev_a1;             /* the last launch of the LTP pass */
+                if (i == pitch_at) { e0 = s.ev_p0; e1 = s.ev_p; }
+                if (i == pitch_at + 1 && s.timed) e0 = s.ev_a0;
+            }
             if (seq[i].kind == 0) {
                 const int c = seq[i].cls;
                 if (c >= 4)
@@ -403,10 +420,13 @@ bool Impl::run_stage(Slot &s, int st)
                                            (uint32_t)seq[i].pass, s.d_results.as<SrlaItemResult>(), s.d_lags.as<double>(), dbg,
                                            s.d_class_index.as<SrlaAutocorrItem>() + job.class_first[c], job.class_count[c], e0, e1, nullptr, nullptr);
             } else {
-                rc |= srla_launch_pitch_solve(W, &jp, s.d_items.as<SrlaItemDesc>(), s.d_lags.as<double>(), s.d_results.as<SrlaItemResult>(), e0, e1,
+                hipStream_t ps = W;
+                if (split) { ps = N; HIP_OK(hipStreamWaitEvent(N, s.ev_a1, 0)); }
+                rc |= srla_launch_pitch_solve(ps, &jp, s.d_items.as<SrlaItemDesc>(), s.d_lags.as<double>(), s.d_results.as<SrlaItemResult>(), e0, e1,
                                               nullptr, 0, s.d_ties.as<uint32_t>(), s.d_tie_data.as<double>());
             }
         }
+        s.split_a = split;
         if (nl == 0) { if (ev0) HIP_OK(hipEventRecord(ev0, W)); HIP_OK(hipEventRecord(s.t1[ST_A], W)); }
         break; }
     case ST_B:
@@ -467,8 +487,17 @@ bool Impl::wait_job(Slot &s)
     HIP_OK(hipEventSynchronize(s.t1[ST_E]));
     float t = 0;
     double *acc[NUM_ST] = { &stats.autocorr_ms, &stats.solve_ms, &stats.residual_ms, &stats.price_ms, &stats.gather_ms };
-    for (int st = 0; st < NUM_ST; st++)
+    for (int st = 0; st < NUM_ST; st++) {
+        if (st == ST_A && s.split_a) {
+            /* stage A in two parts: the two autocorrelation passes (other jobs' kernels ran on W in between), the pitch solve on N */
+            if (!s.timed) continue;
+            if (hipEventElapsedTime(&t, s.t0[ST_A], s.ev_a1) == hipSuccess) stats.autocorr_ms += t;
+            if (hipEventElapsedTime(&t, s.ev_a0, s.t1[ST_A]) == hipSuccess) stats.autocorr_ms += t;
+            if (hipEventElapsedTime(&t, s.ev_p0, s.ev_p) == hipSuccess) stats.solve_ms += t;
+            continue;
+        }
         if ((s.timed || (timing && st == ST_C)) && hipEventElapsedTime(&t, s.t0[st], s.t1[st]) == hipSuccess) *acc[st] += t;
+    }
     if (s.timed) stats.timed_jobs++;
     if (timeline) {
         /* SRLA_MI355X_TIMELINE (with SRLA_MI355X_TIMING_STRIDE=1): where every stage of every job sat on the device's clock */
@@ -745,22 +774,30 @@ SRLAApiResult Impl::encode_streams(bool search)
     };
 
     /* Software pipeline over jobs: iteration t enqueues  autocorr + solve of job t,  residual_cost +
-     * pricing of job t-1,  block assembly of job t-2,  then collects job t-3.  Needs 4 buffer sets.
+     * pricing of job t-1,  block assembly of job t-2,  then collects job t-3.  With the long-term predictor one step more:
+     * LTP-pass autocorr (W) + pitch solve (N) of job t,  LPC-pass autocorr + solve of job t-1,  residual_cost + pricing of
+     * job t-2,  block assembly of job t-3,  collect job t-4 -- W never waits for the pitch solve.  Needs depth + 1 buffer sets.
      * `base`: the jobs before it are complete; a job whose near-ties the host libm decides differently from the device
      * (arbitrate) sends the loop back to it. */
-    const uint32_t depth = 3;
+    const uint32_t ltp_skew = (par.ltp_order > 0 && split_ltp_stage) ? 1u : 0u;
+    const uint32_t depth = 3 + ltp_skew;
     uint32_t base = 0, restarts = 0;
+    auto in_flight = [&](uint32_t t, uint32_t back) { return t >= back && t - back < njobs && t - back >= base; };
     for (uint32_t t = 0; t < njobs + depth;) {
         const auto t_enq = Clock::now();
-        if (t < njobs && t >= base) {
-            if (!begin(t) || !run_stage(job_slot(t), ST_A) || !run_stage(job_slot(t), ST_B)) return fail(SRLA_APIRESULT_NG);
+        if (in_flight(t, 0)) {
+            if (!begin(t) || !run_stage(job_slot(t), ST_A, ltp_skew ? 1 : 0)) return fail(SRLA_APIRESULT_NG);
         }
-        if (t >= 1 && t - 1 < njobs && t - 1 >= base) {
-            Slot &s = job_slot(t - 1);
+        if (in_flight(t, ltp_skew)) {
+            Slot &s = job_slot(t - ltp_skew);
+            if ((ltp_skew && !run_stage(s, ST_A, 2)) || !run_stage(s, ST_B)) return fail(SRLA_APIRESULT_NG);
+        }
+        if (in_flight(t, 1 + ltp_skew)) {
+            Slot &s = job_slot(t - 1 - ltp_skew);
             if (!run_stage(s, ST_C) || !run_stage(s, ST_D)) return fail(SRLA_APIRESULT_NG);
         }
-        if (t >= 2 && t - 2 < njobs && t - 2 >= base) {
-            Slot &s = job_slot(t - 2);
+        if (in_flight(t, 2 + ltp_skew)) {
+            Slot &s = job_slot(t - 2 - ltp_skew);
             if (!run_stage(s, ST_E)) return fail(SRLA_APIRESULT_NG);
         }
         if (single && chain.active && chain.early) {
@@ -775,7 +812,7 @@ SRLAApiResult Impl::encode_streams(bool search)
                 if (!chain_encode_ad()) return fail(SRLA_APIRESULT_NG);
                 if (chain_trace) fprintf(stderr, "[chain] encode_ad %.3f ms (%zu calls)\n", ms_since(tc), chain_calls.size());
             }
-            if (t == njobs + 1 && !chain_encode_e()) return fail(SRLA_APIRESULT_NG);
+            if (t == njobs + depth - 2 && !chain_encode_e()) return fail(SRLA_APIRESULT_NG);   /* right behind the last job's block assembly */
         }
         stats.h2d_ms += ms_since(t_enq);       /* host time spent staging and enqueueing */
         if (timeline) tl_printf("[timeline] host: iteration %u enqueued at %.3f ms\n", t, ms_since(t0));
