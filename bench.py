@@ -59,7 +59,8 @@ class Stats(C.Structure):
                 ("h2d_ms", C.c_double), ("d2h_ms", C.c_double), ("pack_ms", C.c_double), ("total_ms", C.c_double),
                 ("analyzed_samples", C.c_uint64), ("autocorr_ms", C.c_double), ("solve_ms", C.c_double),
                 ("residual_ms", C.c_double), ("timed_jobs", C.c_uint64),
-                ("num_tie_resolved", C.c_uint64), ("num_tie_overrides", C.c_uint64), ("num_restarts", C.c_uint64)]
+                ("num_tie_resolved", C.c_uint64), ("num_tie_overrides", C.c_uint64), ("num_restarts", C.c_uint64),
+                ("num_inplace_pins", C.c_uint64)]
 
 
 def usable_cpus():
@@ -135,10 +136,19 @@ def spawn_ranks(args, argv):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
+    # a rank that dies (no GPU of its own, a failed encode) must not leave the others waiting in a barrier for ever
     rc = 0
-    for p in procs:
-        p.wait()
-        rc = rc or p.returncode
+    alive = list(procs)
+    while alive:
+        time.sleep(0.1)
+        for p in list(alive):
+            if p.poll() is None:
+                continue
+            alive.remove(p)
+            if p.returncode != 0 and rc == 0:
+                rc = p.returncode
+                for q in alive:
+                    q.terminate()
     return rc
 
 
@@ -342,6 +352,10 @@ def main(argv=None):
                                   "total_host": round(st.total_ms / args.steps, 3)},
             "host_cores": os.cpu_count(), "host_cpu_quota": usable_cpus(), "host_pool_threads": pack_threads, "numa_local_cpus": numa_cpus,
             "tie_items": int(st.num_tie_items), "tie_resolved": int(st.num_tie_resolved), "tie_overrides": int(st.num_tie_overrides),
+            # how the pageable buffers reached the device: staged through pinned buffers by the pool threads, or -- when the
+            # ranks' share of the CPU quota is too small for that -- page-locked in place for the call and read by DMA
+            "host_buffers": ("page-locked in place per call (hipHostRegister), no host copies" if st.num_inplace_pins else
+                             "staged through pinned buffers by %d host threads" % pack_threads) if not args.pinned_io else "pinned by the caller",
         })
         if world == 1 and files == 1:
             # the same encode with the samples resident in HBM and a pinned output buffer (what a caller that already holds

@@ -146,6 +146,9 @@ struct StreamCtx {
     uint32_t lshift = 0;
     bool lshift_final = false, lshift_spec = false, lshift_on_device = false;
     uint32_t or_mask = 0, or_covered = 0;      /* OR of samples [0, or_covered) */
+    uint32_t or_dev_end = 0;                   /* samples [0, or_dev_end) have gone through that reduction */
+    bool or_on_device = false;                 /* pinned input: the OR of what the jobs upload is gathered by srla_or_reduce into
+                                                * d_oracc[stream] (the host looked at a short prefix only) and read back at the end */
     /* progress as the host knows it (jobs collected) */
     uint32_t write_off = 0, progress = 0;
     bool pass_started = false;                 /* a segment of the stream has been enqueued in the current pass: later ones continue at the device's running offset */
@@ -162,6 +165,11 @@ struct Impl {
     SRLAEncodeParameter par{};
     bool set_parameter = false;
     uint32_t param_generation = 0;    /* bumped by SetEncodeParameter: invalidates cached job tables */
+    /* Pageable input planes / output buffers are page-locked in place for the duration of a call (hipHostRegister) and then
+     * read by DMA / written by the device where they lie: no host thread touches a sample.  -1: decided per call -- when the
+     * pool has too few threads to stage at the GPU's pace (N ranks sharing a CPU quota); 0 / 1: SRLA_MI355X_PIN_INPLACE */
+    int pin_inplace = -1;
+    bool pin_too_slow = false;          /* registration measured slower than staging would be (no huge pages): not tried again */
     bool split_ltp_stage = true;        /* SRLA_MI355X_NO_LTP_SKEW: stage A of LTP jobs in one piece on W, as before */
     bool keep_residuals_always = true;  /* false with SRLA_MI355X_RECOMPUTE_RESIDUALS */
     bool keep_residuals = false;      /* SRLAMI355X_ProbeBlock with a residual buffer: srla_residual_cost stores what it prices */
@@ -184,7 +192,7 @@ struct Impl {
     uint32_t kSlots = 5;              /* job buffer sets (SRLA_MI355X_SLOTS) */
     uint64_t job_samples = 4ull << 20; /* samples per job (SRLA_MI355X_JOB_SAMPLES): fixed per-job latencies (serial solve chain, launch gaps) favour large jobs; measured best for long streams, and never worse than smaller ones for short streams */
     Slot slot[kMaxSlots];
-    DevBuf d_tw, d_geoms, d_thr, d_huff, d_huffcode, d_pos, d_or;
+    DevBuf d_tw, d_geoms, d_thr, d_huff, d_huffcode, d_pos, d_or, d_oracc;
     bool timing = true;               /* stage timing events (SRLA_MI355X_NO_TIMING drops them) */
     uint32_t tail_boost = 4, tail_boost_jobs = 3;   /* SRLA_MI355X_TAIL_BOOST="wgs,jobs" */
     uint32_t timing_stride = 4;       /* every n-th job carries start events on all stages (SRLA_MI355X_TIMING_STRIDE) */

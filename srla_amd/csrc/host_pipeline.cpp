@@ -50,7 +50,7 @@ Impl::~Impl()
         if (ev_or) (void)hipEventDestroy(ev_or);
         if (ev_ref) (void)hipEventDestroy(ev_ref);
         h_or.release();
-        d_tw.release(); d_geoms.release(); d_thr.release(); d_huff.release(); d_huffcode.release(); d_pos.release(); d_or.release();
+        d_tw.release(); d_geoms.release(); d_thr.release(); d_huff.release(); d_huffcode.release(); d_pos.release(); d_or.release(); d_oracc.release();
         d_chain_pool.release(); d_chain_tab.release();
         for (auto &b : d_chain_list) b.release();
         for (auto &b : d_chain_select) b.release();
@@ -99,6 +99,7 @@ bool Impl::init_device()
      * traffic / 3, throughput -1..-8 %: these kernels are not bound by HBM) */
     keep_residuals_always = getenv("SRLA_MI355X_RECOMPUTE_RESIDUALS") == nullptr;
     split_ltp_stage = getenv("SRLA_MI355X_NO_LTP_SKEW") == nullptr;
+    if (const char *e = getenv("SRLA_MI355X_PIN_INPLACE")) pin_inplace = atoi(e) != 0 ? 1 : 0;
     HIP_OK(hipStreamCreateWithFlags(&upload, hipStreamNonBlocking));
     {
         int lo = 0, hi = 0;
@@ -209,16 +210,18 @@ bool Impl::stage_input(Slot &s, const JobPlan &plan)
     if (all_pinned) {
         /* the caller's planes are pinned: DMA straight out of them (the OR of the samples, where it is still being
          * gathered, is computed by the pool threads meanwhile) */
+        /* (one stream: the channels' copies spread over two streams / SDMA engines were 15 % slower) */
         for (const SegPlan &sp : plan.segs)
             for (uint32_t ch = 0; ch < nch; ch++)
                 HIP_OK(hipMemcpyAsync(s.d_input.as<int32_t>() + (size_t)ch * total + sp.base, sx[sp.stream].host_in[ch] + sp.s0,
                                       (size_t)sp.ns * 4, hipMemcpyHostToDevice, upload));
-        list_tasks(true);
-        pool->parallel_for((uint32_t)tasks.size(), [&](uint32_t i) {
-            const Task &t = tasks[i];
-            const SegPlan &sp = plan.segs[t.seg];
-            seg_or[t.seg].fetch_or(or_reduce(sx[sp.stream].host_in[t.ch] + sp.s0 + t.off, t.len), std::memory_order_relaxed);
-        });
+        /* the OR of the samples, where it is still being gathered: on the device, from the uploaded copy */
+        for (const SegPlan &sp : plan.segs) {
+            const StreamCtx &st = sx[sp.stream];
+            if (st.lshift_final || !st.or_on_device) continue;
+            sx[sp.stream].or_dev_end = std::max(sx[sp.stream].or_dev_end, sp.s0 + sp.ns);
+            if (srla_launch_or_accumulate(upload, s.d_input.as<int32_t>() + sp.base, total, sp.ns, nch, d_oracc.as<uint32_t>() + 2u * sp.stream) != 0) return false;
+        }
     } else {
         if (!s.h_in.ensure((size_t)nch * total * 4 + 64u * nch)) return false;
         list_tasks(false);
@@ -262,7 +265,9 @@ bool Impl::stage_input(Slot &s, const JobPlan &plan)
     for (uint32_t k = 0; k < nseg; k++) {
         const SegPlan &sp = plan.segs[k];
         StreamCtx &st = sx[sp.stream];
-        if (!st.lshift_final && sp.s0 == st.or_covered) { st.or_mask |= seg_or[k].load(); st.or_covered += sp.ns; }
+        if (!st.lshift_final && !st.or_on_device && sp.s0 == st.or_covered) { st.or_mask |= seg_or[k].load(); st.or_covered += sp.ns; }
+        /* a pinned stream in a job that was staged after all (another stream of the job is not pinned) */
+        if (!st.lshift_final && st.or_on_device && !all_pinned) { st.or_mask |= seg_or[k].load(); st.or_dev_end = std::max(st.or_dev_end, sp.s0 + sp.ns); }
     }
     return true;
 }
@@ -679,11 +684,48 @@ SRLAApiResult Impl::encode_streams(bool search)
     const uint32_t window_len = search ? par.num_lookahead_samples : par.max_num_samples_per_block;
     const uint32_t grid = search ? par.min_num_samples_per_block : par.max_num_samples_per_block;
     static const bool no_chain = getenv("SRLA_MI355X_NO_CHAIN") != nullptr;
-    for (StreamCtx &st : sx) {
+    /* page-lock pageable planes / buffers in place for this call (Impl::pin_inplace); dropped again when the call leaves */
+    struct PinGuard {
+        std::vector<const void *> held;
+        ~PinGuard() { for (const void *p : held) host_pin_release(p); }
+    } pins;
+    const bool want_pins = !force_staging && !pin_too_slow && (pin_inplace == 1 || (pin_inplace < 0 && pool->size() < 6));
+    bool need_oracc = false;
+    for (uint32_t si = 0; si < nst; si++) {
+        StreamCtx &st = sx[si];
         classify_buffers(st);
+        if (want_pins && st.host_in && !st.in_pinned && st.num_samples > 0) {
+            const size_t before = pins.held.size();
+            bool ok = true;
+            double us_per_mb = 0.0;
+            for (uint32_t ch = 0; ch < nch && ok; ch++) {
+                ok = host_pin_acquire(st.host_in[ch], (size_t)st.num_samples * 4, &us_per_mb);
+                if (ok) { pins.held.push_back(st.host_in[ch]); stats.num_inplace_pins++; }
+                /* without huge pages locking costs more than the staging copy it saves: remember, stage */
+                if (ok && us_per_mb > 40.0) { pin_too_slow = true; ok = false; }
+            }
+            if (!ok) { while (pins.held.size() > before) { host_pin_release(pins.held.back()); pins.held.pop_back(); } }
+            else st.in_pinned = true;
+        }
+        if (want_pins && !pin_too_slow && st.data != nullptr && st.out_direct == nullptr && st.data_size > 0) {
+            /* a stream never exceeds its raw size + block headers: no need to lock more of a generous buffer */
+            const uint64_t blocks = (uint64_t)st.num_samples / std::max<uint32_t>(1u, par.min_num_samples_per_block) + 2u;
+            const uint64_t bound = SRLA_HEADER_SIZE + ((uint64_t)st.num_samples * nch * par.bits_per_sample + 7u) / 8u + 16u * blocks + 4096u;
+            const size_t bytes = (size_t)std::min<uint64_t>(st.data_size, bound);
+            if (host_pin_acquire(st.data, bytes, nullptr)) {
+                pins.held.push_back(st.data);
+                stats.num_inplace_pins++;
+                hipPointerAttribute_t at;
+                memset(&at, 0, sizeof(at));
+                if (hipPointerGetAttributes(&at, st.data) == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer != nullptr)
+                    st.out_direct = static_cast<uint8_t *>(at.devicePointer);
+                else (void)hipGetLastError();
+            }
+        }
         st.write_off = st.with_header ? SRLA_HEADER_SIZE : 0u;
         st.progress = 0; st.pass_started = false; st.rc = SRLA_APIRESULT_OK;
         st.or_mask = 0; st.or_covered = 0; st.lshift_spec = false; st.lshift_on_device = false;
+        st.or_on_device = false; st.or_dev_end = 0;
         if (st.lshift_final) { /* known: given by the caller (EncodeWindows), or the second attempt after a failed speculation */ }
         else if (!st.with_header) { st.lshift = offset_lshift; st.lshift_final = true; }   /* block calls: encoder->header.offset_lshift */
         else if (st.d_in) {
@@ -695,6 +737,15 @@ SRLAApiResult Impl::encode_streams(bool search)
             if (hipMemcpyAsync(h_or.p, d_or.p, 8, hipMemcpyDeviceToHost, w) != hipSuccess) return SRLA_APIRESULT_NG;
             if (hipEventRecord(ev_or, w) != hipSuccess) return SRLA_APIRESULT_NG;
             st.lshift_on_device = true;
+        } else if (st.in_pinned && st.cb == nullptr && !no_speculation) {
+            /* pinned planes: the host looks at the first 64 Ki samples per channel only; the device gathers the OR of
+             * everything it uploads (stage_input) and the guess is checked against that at the end */
+            const uint32_t look = std::min<uint32_t>(st.num_samples, 65536u);
+            uint32_t m = 0;
+            for (uint32_t ch = 0; ch < nch; ch++) m |= or_reduce(st.host_in[ch], look);
+            st.or_mask = m; st.or_covered = look;
+            if (look == st.num_samples) { st.lshift = shift_of(m); st.lshift_final = true; }
+            else { st.or_on_device = true; need_oracc = true; }
         } else if (st.cb != nullptr || no_speculation) {
             /* delivered blocks cannot be taken back: the OR pass runs first */
             const uint32_t chunk = 1u << 20, per_ch = (st.num_samples + chunk - 1) / chunk;
@@ -715,6 +766,10 @@ SRLAApiResult Impl::encode_streams(bool search)
         if (tn > 0 && par.ltp_order > 0 && grid > 256u && (window_len % grid) == 0 && ((tn - 1u) % grid) + 1u <= 256u && !no_chain) chain_n = tn;
         st.chain_n = chain_n;
         st.body = st.num_samples - chain_n;
+    }
+    if (need_oracc) {
+        if ((size_t)8 * nst > d_oracc.cap) { drain(); if (!d_oracc.ensure((size_t)8 * nst)) return SRLA_APIRESULT_NG; }
+        if (hipMemsetAsync(d_oracc.p, 0, (size_t)8 * nst, upload) != hipSuccess) return SRLA_APIRESULT_NG;
     }
     std::vector<JobPlan> plan;
     plan_jobs(plan, search);
@@ -877,6 +932,14 @@ SRLAApiResult Impl::encode_streams(bool search)
     for (uint32_t i = 0; i < nst; i++) {
         StreamCtx &st = sx[i];
         if (st.with_header && st.lshift_spec && !st.lshift_final) {
+            if (st.or_on_device && st.or_dev_end >= st.num_samples) {
+                /* every job has been collected, so every reduction launch on the upload stream is complete */
+                uint32_t m = 0;
+                if (hipStreamSynchronize(upload) != hipSuccess || hipMemcpy(&m, d_oracc.as<uint32_t>() + 2u * i, 4, hipMemcpyDeviceToHost) != hipSuccess)
+                    return fail(SRLA_APIRESULT_NG);
+                st.or_mask |= m;
+                st.or_covered = st.num_samples;
+            } else if (st.or_on_device) st.or_covered = 0;      /* the stream ended early: the host looks at all of it */
             if (st.or_covered < st.num_samples) {
                 const uint32_t o0 = st.or_covered, len = st.num_samples - o0;
                 const uint32_t chunk = 1u << 20, per_ch = (len + chunk - 1) / chunk;

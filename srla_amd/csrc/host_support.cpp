@@ -3,6 +3,9 @@
  */
 #include "host_support.h"
 
+#include <algorithm>
+#include <map>
+
 #if defined(__x86_64__)
 #include <immintrin.h>
 #endif
@@ -103,6 +106,43 @@ uint32_t or_reduce(const int32_t *src, size_t n)
     uint32_t m = 0;
     for (size_t k = 0; k < n; k++) m |= (uint32_t)src[k];
     return m;
+}
+
+
+namespace {
+struct PinEntry { size_t bytes; uint32_t refs; };
+std::mutex g_pin_mutex;
+std::map<const void *, PinEntry> g_pins;
+}
+
+bool host_pin_acquire(const void *p, size_t bytes, double *us_per_mb)
+{
+    std::lock_guard<std::mutex> lock(g_pin_mutex);
+    auto it = g_pins.find(p);
+    if (it != g_pins.end()) {
+        if (it->second.bytes < bytes) return false;
+        it->second.refs++;
+        return true;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    if (hipHostRegister(const_cast<void *>(p), bytes, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (us_per_mb) {
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        *us_per_mb = us / std::max(1.0, (double)bytes / 1048576.0);
+    }
+    g_pins.emplace(p, PinEntry{ bytes, 1u });
+    return true;
+}
+
+void host_pin_release(const void *p)
+{
+    std::lock_guard<std::mutex> lock(g_pin_mutex);
+    auto it = g_pins.find(p);
+    if (it == g_pins.end()) return;
+    if (--it->second.refs == 0) {
+        if (hipHostUnregister(const_cast<void *>(p)) != hipSuccess) (void)hipGetLastError();
+        g_pins.erase(it);
+    }
 }
 
 }  // namespace srla

@@ -68,6 +68,12 @@ struct PinBuf {
     template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
+/* Temporary page-locking of a caller's buffer for the duration of a call (hipHostRegister), process-wide and reference
+ * counted: two handles working on the same buffer at the same time share one registration, and it is dropped when the
+ * last of them is done.  acquire() fails (false) where registration does -- the caller then stages as usual. */
+bool host_pin_acquire(const void *p, size_t bytes, double *us_per_mb);
+void host_pin_release(const void *p);
+
 /* staging copies (host_support.cpp): return the OR of the samples they move */
 uint32_t copy_or(int32_t *dst, const int32_t *src, size_t n);
 /* the same, packing to int16 (streams of at most 16 bits per sample cross PCIe at half the size; the device widens them

@@ -3583,6 +3583,17 @@ extern "C" int srla_launch_pack(hipStream_t stream, const SrlaJobParams *jp, uin
     return (hipGetLastError() == hipSuccess) ? 0 : -2;
 }
 
+/* the same without the conversion: *out |= OR of the samples (several launches accumulate into one word) */
+extern "C" int srla_launch_or_accumulate(hipStream_t stream, const int32_t *in, size_t channel_stride, size_t count,
+                                         uint32_t num_channels, uint32_t *out)
+{
+    size_t blocks = (count + NT * 64 - 1) / (NT * 64);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(srla_or_reduce, dim3((uint32_t)blocks, num_channels), dim3(NT), 0, stream, in, channel_stride, count, out);
+    return (hipGetLastError() == hipSuccess) ? 0 : -2;
+}
+
 extern "C" int srla_launch_or_reduce(hipStream_t stream, const int32_t *in, size_t channel_stride, size_t count,
                                      uint32_t num_channels, uint32_t *out)
 {

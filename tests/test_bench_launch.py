@@ -40,6 +40,16 @@ def test_gpus_must_match_the_launcher():
     assert p.returncode != 0 and "launcher" in (p.stderr + p.stdout)
 
 
+def test_a_rank_that_dies_ends_the_run_instead_of_hanging_it():
+    """more ranks than GPUs (none here, one on the test box): the rank without a device exits, and the launcher must take
+    the others down with it -- they would wait in the rendezvous / barrier for ever"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "SRLA_BENCH_SHARED_GPU")}
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0", "--seconds", "10", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=240, env=env, cwd=helpers.ROOT)
+    assert p.returncode != 0
+    assert "GPU" in p.stderr
+
+
 @pytest.mark.gpu
 def test_two_ranks_on_one_shared_gpu():
     """the real flow, two ranks on the one GPU of the test box (SRLA_BENCH_SHARED_GPU: barrier / reduce over gloo)"""

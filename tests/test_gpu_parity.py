@@ -625,3 +625,38 @@ def test_svr_outside_its_limits_is_refused_loudly(product):
     enc = product.create(cfg)
     assert product.set_parameter(enc, par) == capi.NG
     product.destroy(enc)
+
+
+def test_pageable_buffers_locked_in_place_for_the_call(product, monkeypatch):
+    """SRLA_MI355X_PIN_INPLACE=1 (the default when the host pool is too small to stage at the GPU's pace): the caller's pageable
+    planes and output buffer are registered for the call, read / written by the device where they lie, and released again.
+    Two handles working on the SAME planes at the same time share the registration.  A stream whose first 64 Ki samples
+    suggest a larger offset shift than the whole stream has is encoded again (the OR is gathered on the device)."""
+    import threading
+    import torch
+    monkeypatch.setenv("SRLA_MI355X_PIN_INPLACE", "1")
+    cli = dict(preset=4, max_block=4096, divisions=1)
+    pcm = helpers.synth(helpers.MUSIC, 91, 48000, 2, 1_500_001)
+    want = helpers.Oracle(2, **cli).encode_whole(pcm)
+    got, errs = [None, None], []
+
+    def worker(i):
+        try:
+            got[i] = product.encode(pcm, **cli)
+        except Exception as e:      # surfaced below
+            errs.append(e)
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    assert np.array_equal(got[0], want) and np.array_equal(got[1], want)
+    # nothing stays registered: registering the planes ourselves succeeds
+    rt = torch.cuda.cudart()
+    assert int(rt.cudaHostRegister(pcm.ctypes.data, pcm.nbytes, 0)) == 0
+    assert int(rt.cudaHostUnregister(pcm.ctypes.data)) == 0
+    # the first 100 000 samples are multiples of 256, the rest are not: the prefix guess (shift 8) is wrong
+    odd = helpers.synth(helpers.NOISE, 92, 48000, 2, 400_000)
+    odd[:, :100_000] = (odd[:, :100_000] >> 8) << 8
+    want = helpers.Oracle(2, **cli).encode_whole(odd)
+    assert want[24] == 0
+    assert np.array_equal(product.encode(odd, **cli), want)
