@@ -122,15 +122,8 @@ SRLAApiResult SRLAEncoder_SetEncodeParameter(struct SRLAEncoder *encoder, const 
         return SRLA_APIRESULT_INSUFFICIENT_BUFFER;
     }
     if (p->bits_per_sample != 8 && p->bits_per_sample != 16 && p->bits_per_sample != 24) return SRLA_APIRESULT_INVALID_FORMAT;
-    if (p->num_svr_filter_learning_iteration != 0) {
-        /* SVR refinement (lpc.c:1036-1136) runs on the device for the presets with orders up to 64 and LDS-resident blocks */
-        const uint32_t order = srla::kPresetOrder[p->preset];
-        if (order > 64u || p->max_num_samples_per_block > 8192u) {
-            fprintf(stderr, "[srla-mi355x] SVR coefficient refinement (--svr-filter-learning-iteration) is implemented for presets 0..4 "
-                            "(order <= 64) and blocks of at most 8192 samples; preset %u / block %u is not\n", (unsigned)p->preset, p->max_num_samples_per_block);
-            return SRLA_APIRESULT_NG;
-        }
-    }
+    /* SVR refinement (--svr-filter-learning-iteration, lpc.c:1036-1136): every preset and block size; orders above 64 and
+     * blocks above 8192 samples take the global-memory version of the kernel */
     im->par = *p;
     im->param_generation++;
     im->offset_lshift = 0;

@@ -193,6 +193,8 @@ struct Impl {
     uint64_t job_samples = 4ull << 20; /* samples per job (SRLA_MI355X_JOB_SAMPLES): fixed per-job latencies (serial solve chain, launch gaps) favour large jobs; measured best for long streams, and never worse than smaller ones for short streams */
     Slot slot[kMaxSlots];
     DevBuf d_tw, d_geoms, d_thr, d_huff, d_huffcode, d_pos, d_or, d_oracc;
+    DevBuf d_svr_scratch;              /* srla_svr_refine_big (orders above 64, blocks above 8192 samples): kSvrGroups regions */
+    static constexpr uint32_t kSvrGroups = 256;
     bool timing = true;               /* stage timing events (SRLA_MI355X_NO_TIMING drops them) */
     uint32_t tail_boost = 4, tail_boost_jobs = 3;   /* SRLA_MI355X_TAIL_BOOST="wgs,jobs" */
     uint32_t timing_stride = 4;       /* every n-th job carries start events on all stages (SRLA_MI355X_TIMING_STRIDE) */

@@ -50,7 +50,7 @@ Impl::~Impl()
         if (ev_or) (void)hipEventDestroy(ev_or);
         if (ev_ref) (void)hipEventDestroy(ev_ref);
         h_or.release();
-        d_tw.release(); d_geoms.release(); d_thr.release(); d_huff.release(); d_huffcode.release(); d_pos.release(); d_or.release(); d_oracc.release();
+        d_tw.release(); d_geoms.release(); d_thr.release(); d_huff.release(); d_huffcode.release(); d_pos.release(); d_or.release(); d_oracc.release(); d_svr_scratch.release();
         d_chain_pool.release(); d_chain_tab.release();
         for (auto &b : d_chain_list) b.release();
         for (auto &b : d_chain_select) b.release();
@@ -331,7 +331,12 @@ bool Impl::prepare_job(Slot &s, bool want_dbg)
         if (!s.d_big_items.ensure(job.big_items.size() * 4)) return false;
         if (pb != s.d_big_items.p) job.uploaded = false;
     }
-    if (par.num_svr_filter_learning_iteration > 0 && !s.d_coef_ws.ensure(std::max<size_t>(1, n_items) * 64 * sizeof(double))) return false;
+    if (par.num_svr_filter_learning_iteration > 0) {
+        const uint32_t max_order = preset_order();
+        if (!s.d_coef_ws.ensure(std::max<size_t>(1, n_items) * (max_order <= 64 ? 64 : 256) * sizeof(double))) return false;
+        if ((max_order > 64 || par.max_num_samples_per_block > 8192u) &&
+            !d_svr_scratch.ensure((size_t)kSvrGroups * srla_svr_big_scratch_bytes(par.max_num_samples_per_block))) return false;
+    }
     if (want_dbg && !s.d_dbg.ensure(std::max<size_t>(1, n_items) * SRLA_DBG_STRIDE * sizeof(double))) return false;
     const uint32_t lag_rows = std::max<uint32_t>(par.ltp_order > 0 ? SRLA_LTP_LAGS : 0u, preset_order() + 1);
     if (!s.d_lags.ensure((size_t)lag_rows * std::max<size_t>(1, n_items) * sizeof(double))) return false;
@@ -440,7 +445,8 @@ bool Impl::run_stage(Slot &s, int st, int part)
             rc |= srla_launch_lpc_solve(N, &jp, s.d_items.as<SrlaItemDesc>(), d_geoms.as<SrlaGeom>(), s.d_lags.as<double>(),
                                         s.d_err.as<double>(), d_huff.as<uint8_t>(), s.d_results.as<SrlaItemResult>(), dbg,
                                         s.d_ties.as<uint32_t>(), ev0, s.t1[ST_B], s.in_cur, s.d_coef_ws.as<double>(),
-                                        par.num_svr_filter_learning_iteration, std::min<uint32_t>(par.max_num_samples_per_block, 8192u));
+                                        par.num_svr_filter_learning_iteration, std::min<uint32_t>(par.max_num_samples_per_block, 8192u),
+                                        d_svr_scratch.p, kSvrGroups);
         } else { if (ev0) HIP_OK(hipEventRecord(ev0, N)); HIP_OK(hipEventRecord(s.t1[ST_B], N)); }
         break;
     case ST_C:

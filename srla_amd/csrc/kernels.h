@@ -56,8 +56,10 @@ int srla_launch_pitch_solve(hipStream_t stream, const SrlaJobParams *jp, const S
 int srla_launch_lpc_solve(hipStream_t stream, const SrlaJobParams *jp, const SrlaItemDesc *items,
                           const SrlaGeom *geoms, const double *lags_ws, double *err_ws, const uint8_t *huff_len,
                           SrlaItemResult *results, double *dbg, uint32_t *ties, hipEvent_t ev_start, hipEvent_t ev_stop,
-                          const int32_t *input, double *coef_ws /* 64 doubles per item */, uint32_t svr_iterations /* 0: off */,
-                          uint32_t svr_n_cap /* longest block of the job */);
+                          const int32_t *input, double *coef_ws /* 64 doubles per item (256 for orders above 64) */,
+                          uint32_t svr_iterations /* 0: off */, uint32_t svr_n_cap /* longest LDS-resident block of the job */,
+                          void *svr_scratch, uint32_t svr_groups /* srla_svr_refine_big: groups x srla_svr_big_scratch_bytes(max block) */);
+size_t srla_svr_big_scratch_bytes(uint32_t n_max);
 int srla_launch_residual_cost(hipStream_t stream, int rclass, const SrlaJobParams *jp, const int32_t *input,
                               const SrlaItemDesc *items, const SrlaGeom *geoms, const SrlaLdsPlan *plan,
                               const double *rice_thresholds, int32_t *res_ws, SrlaItemResult *results,

@@ -1244,7 +1244,7 @@ __global__ __launch_bounds__(WAVE) void srla_lpc_solve_regs(
 template <int L>
 __global__ __launch_bounds__(WAVE) void srla_lpc_quantize(
     SrlaJobParams jp, const double *__restrict__ lags_ws, const uint8_t *__restrict__ huff_len,
-    SrlaItemResult *__restrict__ results)
+    SrlaItemResult *__restrict__ results, double *__restrict__ coef_ws /* SVR refinement follows: the taps of the chosen order, unquantised, rows of 256 */)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const uint32_t lane = threadIdx.x;
@@ -1262,6 +1262,11 @@ __global__ __launch_bounds__(WAVE) void srla_lpc_quantize(
         const double r0 = R_(0) * (1.0 + 1e-5);
         const bool silent = fabs(r0) < (double)FLT_EPSILON;
         if (!silent) levinson_lane<L>(a, r, lane, r0, order, nullptr, 0);
+        if (coef_ws != nullptr) {
+            double *row = coef_ws + (size_t)idx * 256u;
+            for (uint32_t i = 0; i < order; i++) row[i] = silent ? 0.0 : A_(1 + i);
+            return;
+        }
         /* 8-bit quantisation with error feedback from the last tap (lpc.c:1341-1405); q[] reuses r[] */
         int32_t *q = (int32_t *)r;
 #define Q_(i) q[(size_t)(i) * (2 * L) + lane]
@@ -2357,31 +2362,23 @@ __device__ __forceinline__ double svr_rgr_mean_code_length(double mean_abs_error
     return (1.0 + k1) * (1.0 - k1factor) + (1.0 + k2 + (1.0 / (1.0 - k2factor))) * k1factor;
 }
 
-__global__ __launch_bounds__(SVR_NT) void srla_svr_refine(
-    SrlaJobParams jp, const int32_t *__restrict__ input, const SrlaItemDesc *__restrict__ items,
-    SrlaItemResult *__restrict__ results, double *__restrict__ coef_ws, uint32_t iterations, uint32_t n_cap)
+/* BIG = false: orders up to 64 and blocks up to n_cap <= 8192 samples, everything in LDS, one workgroup per item.
+ * BIG = true: the other items (orders 128 / 255, blocks up to 32768 samples): block, residuals and the matrix live in a
+ * region of global scratch per (persistent) workgroup, the vectors in LDS; the same code.  ws_stride: doubles per row of coef_ws. */
+#define SVR_PMAX 256
+template <bool BIG>
+__device__ void svr_refine_item(const SrlaJobParams &jp, const int32_t *__restrict__ input, const SrlaItemDesc &it, SrlaItemResult *out,
+                                double *row, const uint32_t iterations, int32_t *xi, double *rr, double *cov, const uint32_t PS,
+                                double *low, double *r_vec, double *delta, double *coef, double *init_coef, double *best_coef,
+                                double *s_scalar, long long *s_lag, uint32_t *s_flag)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    int32_t *xi = (int32_t *)lds;                                        /* the pre-emphasised (+ LTP) block */
-    double *rr = (double *)(lds + (((size_t)n_cap * 4 + 15) & ~(size_t)15));   /* residual of every sample under the current taps */
-    double *cov = rr + n_cap;                                            /* [SVR_P][SVR_PS]: upper = matrix, lower = Cholesky factor */
-    double *low = cov + SVR_P * SVR_PS, *r_vec = low + SVR_P, *delta = r_vec + SVR_P, *coef = delta + SVR_P;
-    double *init_coef = coef + SVR_P, *best_coef = init_coef + SVR_P;
-    __shared__ double s_mabse, s_obj;
-    __shared__ long long s_lag[SVR_P];
-    __shared__ uint32_t s_flag[4];                                       /* 0: singular, 1: break, 2: near-tie, 3: |x| max */
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t item_idx = xcd_position(blockIdx.x, jp.num_items);
-    if (item_idx >= jp.num_items) return;
-    SrlaItemResult *out = &results[item_idx];
     const uint32_t p = out->lpc_order;
-    if (p == 0 || p > SVR_P) return;
-    const SrlaItemDesc it = items[item_idx];
     const InputView iv = input_view(jp, it.lshift);
     const uint32_t n = it.n;
     const int32_t *in = input + it.sample_off;
     const double norm = __builtin_ldexp(1.0, -(int)(jp.bits_per_sample - 1));
-    double *row = coef_ws + (size_t)item_idx * SVR_P;
+    __syncthreads();                                                     /* a persistent workgroup: the previous item is done with the buffers */
     /* ---- the signal the LPC analysis saw: pre-emphasis (srla_utility.c:342), long-term predictor (srla_lpc_predict.c:267) ---- */
     {
         const int32_t pc = out->preemph_coef;
@@ -2437,7 +2434,7 @@ __global__ __launch_bounds__(SVR_NT) void srla_svr_refine(
             const uint32_t d = tid;
             long long v = s_lag[d];
             for (uint32_t i = 0; i + d < p; i++) {
-                cov[i * SVR_PS + i + d] = (double)v * scale;
+                cov[i * PS + i + d] = (double)v * scale;
                 v += (long long)xi[m_len + i] * (long long)xi[m_len + i + d] - (long long)xi[i] * (long long)xi[i + d];
             }
         }
@@ -2450,19 +2447,19 @@ __global__ __launch_bounds__(SVR_NT) void srla_svr_refine(
             const uint32_t j = i + r;
             double acc = 0.0;
             for (uint32_t s0 = 0; s0 < m_len; s0++) acc += ((double)xi[s0 + i] * norm) * ((double)xi[s0 + j] * norm);
-            cov[i * SVR_PS + j] = acc;
+            cov[i * PS + j] = acc;
         }
     }
     __syncthreads();
-    for (uint32_t t = tid; t < p * p; t += SVR_NT) { const uint32_t i = t / p, j = t % p; if (j > i) cov[j * SVR_PS + i] = cov[i * SVR_PS + j]; }
+    for (uint32_t t = tid; t < p * p; t += SVR_NT) { const uint32_t i = t / p, j = t % p; if (j > i) cov[j * PS + i] = cov[i * PS + j]; }
     __syncthreads();
-    if (tid < p) cov[tid * SVR_PS + tid] *= (1.0 + 1e-5);                /* ridge, lpc.c:1067-1069 */
+    if (tid < p) cov[tid * PS + tid] *= (1.0 + 1e-5);                /* ridge, lpc.c:1067-1069 */
     __syncthreads();
     /* ---- Cholesky factorisation, lpc.c:573-600 ---- */
     for (uint32_t i = 0; i < p; i++) {
         if (tid == 0) {
-            double sum = cov[i * SVR_PS + i];
-            for (int k = (int)i - 1; k >= 0; k--) sum -= cov[i * SVR_PS + k] * cov[i * SVR_PS + k];
+            double sum = cov[i * PS + i];
+            for (int k = (int)i - 1; k >= 0; k--) sum -= cov[i * PS + k] * cov[i * PS + k];
             if (sum <= 0.0) s_flag[0] = 1;
             else low[i] = inv_sqrt_cr(sum);
         }
@@ -2470,9 +2467,9 @@ __global__ __launch_bounds__(SVR_NT) void srla_svr_refine(
         if (s_flag[0]) break;
         const uint32_t j = i + 1 + tid;
         if (j < p) {
-            double sum = cov[i * SVR_PS + j];
-            for (int k = (int)i - 1; k >= 0; k--) sum -= cov[i * SVR_PS + k] * cov[j * SVR_PS + k];
-            cov[j * SVR_PS + i] = sum * low[i];
+            double sum = cov[i * PS + j];
+            for (int k = (int)i - 1; k >= 0; k--) sum -= cov[i * PS + k] * cov[j * PS + k];
+            cov[j * PS + i] = sum * low[i];
         }
         __syncthreads();
     }
@@ -2498,40 +2495,40 @@ __global__ __launch_bounds__(SVR_NT) void srla_svr_refine(
             }
             __syncthreads();
             /* the running sums over the samples, in sample order: r_vec[i] on lane i of wave 0, mabse on wave 1 */
-            if (wave == 0 && lane < p) {
+            if (tid < p) {
                 double acc = 0.0;
                 for (uint32_t s0 = p; s0 < n; s0++) {
                     const double r = rr[s0];
                     const double a = (r > 0) ? r : -r;
                     const double t = (double)((r > 0) - (r < 0)) * (((a - margin) > 0.0) ? (a - margin) : 0.0);   /* LPC_SOFT_THRESHOLD, lpc.c:34 */
-                    acc += t * ((double)xi[s0 - lane - 1] * norm);
+                    acc += t * ((double)xi[s0 - tid - 1] * norm);
                 }
-                r_vec[lane] = acc;
-            } else if (wave == 1 && lane == 0) {
+                r_vec[tid] = acc;
+            } else if (tid == SVR_NT - 1) {                               /* p <= 255: this thread has no r_vec entry */
                 double acc = 0.0;
                 for (uint32_t s0 = p; s0 < n; s0++) { const double r = rr[s0]; acc += (r > 0) ? r : -r; }
-                s_mabse = acc;
+                s_scalar[0] = acc;
             }
             __syncthreads();
             if (tid == 0) {
                 bool tie = false;
-                const double obj = svr_rgr_mean_code_length(s_mabse / (double)n, &tie);
+                const double obj = svr_rgr_mean_code_length(s_scalar[0] / (double)n, &tie);
                 /* cov delta = r_vec by the factor, lpc.c:605-631 */
                 for (uint32_t i = 0; i < p; i++) {
                     double sum = r_vec[i];
-                    for (int k = (int)i - 1; k >= 0; k--) sum -= cov[i * SVR_PS + k] * delta[k];
+                    for (int k = (int)i - 1; k >= 0; k--) sum -= cov[i * PS + k] * delta[k];
                     delta[i] = sum * low[i];
                 }
                 for (int k = (int)p - 1; k >= 0; k--) {
                     double sum = delta[k];
-                    for (uint32_t j = (uint32_t)k + 1; j < p; j++) sum -= cov[j * SVR_PS + k] * delta[j];
+                    for (uint32_t j = (uint32_t)k + 1; j < p; j++) sum -= cov[j * PS + k] * delta[j];
                     delta[k] = sum * low[k];
                 }
-                s_obj = obj;
+                s_scalar[1] = obj;
                 if (tie) s_flag[2] = 1;
             }
             __syncthreads();
-            const double obj = s_obj;
+            const double obj = s_scalar[1];
             /* comparisons of objective values that differ by less than the device's log / pow can be trusted for */
             if (tid == 0) {
                 const double tol = 1e-9;
@@ -2553,8 +2550,65 @@ __global__ __launch_bounds__(SVR_NT) void srla_svr_refine(
     if (tid == 0 && s_flag[2]) out->flags |= SRLA_ITEM_SVR_TIE;
 }
 
+
+__global__ __launch_bounds__(SVR_NT) void srla_svr_refine(
+    SrlaJobParams jp, const int32_t *__restrict__ input, const SrlaItemDesc *__restrict__ items,
+    SrlaItemResult *__restrict__ results, double *__restrict__ coef_ws, uint32_t ws_stride, uint32_t iterations, uint32_t n_cap)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    int32_t *xi = (int32_t *)lds;                                        /* the pre-emphasised (+ LTP) block */
+    double *rr = (double *)(lds + (((size_t)n_cap * 4 + 15) & ~(size_t)15));   /* residual of every sample under the current taps */
+    double *cov = rr + n_cap;                                            /* [SVR_P][SVR_PS]: upper = matrix, lower = Cholesky factor */
+    double *low = cov + SVR_P * SVR_PS, *r_vec = low + SVR_P, *delta = r_vec + SVR_P, *coef = delta + SVR_P;
+    double *init_coef = coef + SVR_P, *best_coef = init_coef + SVR_P;
+    __shared__ double s_scalar[2];
+    __shared__ long long s_lag[SVR_P];
+    __shared__ uint32_t s_flag[4];                                       /* 0: singular, 1: break, 2: near-tie, 3: |x| max */
+    const uint32_t item_idx = xcd_position(blockIdx.x, jp.num_items);
+    if (item_idx >= jp.num_items) return;
+    SrlaItemResult *out = &results[item_idx];
+    const uint32_t p = out->lpc_order;
+    const SrlaItemDesc it = items[item_idx];
+    if (p == 0 || p > SVR_P || it.n > n_cap) return;                     /* the others: srla_svr_refine_big */
+    svr_refine_item<false>(jp, input, it, out, coef_ws + (size_t)item_idx * ws_stride, iterations, xi, rr, cov, SVR_PS,
+                           low, r_vec, delta, coef, init_coef, best_coef, s_scalar, s_lag, s_flag);
+}
+
+/* per workgroup in `scratch`: n_max int32, n_max doubles, SVR_PMAX x (SVR_PMAX + 1) doubles */
+__device__ __forceinline__ size_t srla_svr_big_scratch_bytes_dev(uint32_t n_max)
+{
+    return (((size_t)n_max * 4 + 15) & ~(size_t)15) + (size_t)n_max * 8 + (size_t)SVR_PMAX * (SVR_PMAX + 1) * 8;
+}
+extern "C" size_t srla_svr_big_scratch_bytes(uint32_t n_max)
+{
+    return (((size_t)n_max * 4 + 15) & ~(size_t)15) + (size_t)n_max * 8 + (size_t)SVR_PMAX * (SVR_PMAX + 1) * 8;
+}
+
+__global__ __launch_bounds__(SVR_NT) void srla_svr_refine_big(
+    SrlaJobParams jp, const int32_t *__restrict__ input, const SrlaItemDesc *__restrict__ items,
+    SrlaItemResult *__restrict__ results, double *__restrict__ coef_ws, uint32_t ws_stride, uint32_t iterations, uint32_t n_cap,
+    unsigned char *__restrict__ scratch, uint32_t n_max)
+{
+    __shared__ double vec[6][SVR_PMAX];
+    __shared__ double s_scalar[2];
+    __shared__ long long s_lag[SVR_PMAX];
+    __shared__ uint32_t s_flag[4];
+    unsigned char *mine = scratch + (size_t)blockIdx.x * srla_svr_big_scratch_bytes_dev(n_max);
+    int32_t *xi = (int32_t *)mine;
+    double *rr = (double *)(mine + (((size_t)n_max * 4 + 15) & ~(size_t)15));
+    double *cov = rr + n_max;
+    for (uint32_t item_idx = blockIdx.x; item_idx < jp.num_items; item_idx += gridDim.x) {
+        SrlaItemResult *out = &results[item_idx];
+        const uint32_t p = out->lpc_order;
+        const SrlaItemDesc it = items[item_idx];
+        if (p == 0 || (p <= SVR_P && it.n <= n_cap)) continue;           /* done by srla_svr_refine */
+        svr_refine_item<true>(jp, input, it, out, coef_ws + (size_t)item_idx * ws_stride, iterations, xi, rr, cov, SVR_PMAX + 1,
+                              vec[0], vec[1], vec[2], vec[3], vec[4], vec[5], s_scalar, s_lag, s_flag);
+    }
+}
+
 /* the quantiser and tap cost (lpc.c:1341-1405, srla_encoder.c:1141-1174) from the refined taps: one lane per item */
-__global__ __launch_bounds__(WAVE) void srla_lpc_quantize_ws(SrlaJobParams jp, const double *__restrict__ coef_ws,
+__global__ __launch_bounds__(WAVE) void srla_lpc_quantize_ws(SrlaJobParams jp, const double *__restrict__ coef_ws, uint32_t ws_stride,
                                                              const uint8_t *__restrict__ huff_len, SrlaItemResult *__restrict__ results)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -2568,7 +2622,7 @@ __global__ __launch_bounds__(WAVE) void srla_lpc_quantize_ws(SrlaJobParams jp, c
     if (idx >= jp.num_items) return;
     SrlaItemResult *out = &results[idx];
     const uint32_t order = out->lpc_order;
-    const double *row = coef_ws + (size_t)idx * SVR_P;
+    const double *row = coef_ws + (size_t)idx * ws_stride;
     quantize_and_price(order, false,
                        [&](uint32_t i) -> double { return row[i]; },
                        [&](uint32_t i, int32_t v) { q[(size_t)i * L + lane] = v; },
@@ -3405,13 +3459,15 @@ extern "C" int srla_launch_pitch_solve(hipStream_t stream, const SrlaJobParams *
 extern "C" int srla_launch_lpc_solve(hipStream_t stream, const SrlaJobParams *jp, const SrlaItemDesc *items,
                                      const SrlaGeom *geoms, const double *lags_ws, double *err_ws, const uint8_t *huff_len,
                                      SrlaItemResult *results, double *dbg, uint32_t *ties, hipEvent_t ev_start, hipEvent_t ev_stop,
-                                     const int32_t *input, double *coef_ws, uint32_t svr_iterations, uint32_t svr_n_cap)
+                                     const int32_t *input, double *coef_ws, uint32_t svr_iterations, uint32_t svr_n_cap,
+                                     void *svr_scratch, uint32_t svr_groups)
 {
     if (jp->num_items == 0) return 0;
     const uint32_t p = jp->max_order;
     if (svr_iterations > 0) {
-        /* solve (taps left unquantised) -> SVR refinement -> quantiser; orders up to 64 only (SetEncodeParameter checks) */
+        /* solve (taps left unquantised) -> SVR refinement -> quantiser */
         const dim3 g64s((jp->num_items + 63) / 64), blks(WAVE);
+        const uint32_t ws_stride = (p <= 64) ? 64u : 256u;
 #define SVR_PATH(PP)                                                                                                     \
     do {                                                                                                                 \
         const uint32_t lds = 512 + PP * 8 * 64 + PP * 4 * 64;                                                            \
@@ -3419,18 +3475,42 @@ extern "C" int srla_launch_lpc_solve(hipStream_t stream, const SrlaJobParams *jp
         hipExtLaunchKernelGGL(srla_lpc_solve_regs<PP>, g64s, blks, lds, stream, ev_start, nullptr, 0, *jp, items, geoms, lags_ws, err_ws, \
                               huff_len, results, dbg, ties, coef_ws);                                                    \
     } while (0)
-        if (p == 8) SVR_PATH(8); else if (p == 16) SVR_PATH(16); else if (p == 32) SVR_PATH(32); else if (p == 64) SVR_PATH(64); else return -1;
-#undef SVR_PATH
-        const uint32_t lds_svr = ((svr_n_cap * 4u + 15u) & ~15u) + svr_n_cap * 8u + (SVR_P * SVR_PS + 6 * SVR_P) * 8u;
-        {
-            static bool done_ = false;
-            if (!done_) { (void)hipFuncSetAttribute((const void *)srla_svr_refine, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048); done_ = true; }
-            (void)hipGetLastError();
+        if (p == 8) SVR_PATH(8); else if (p == 16) SVR_PATH(16); else if (p == 32) SVR_PATH(32); else if (p == 64) SVR_PATH(64);
+        else if (p <= 128) {
+            const uint32_t lds = (2 * p + 3) * 8 * 64;
+            SET_LDS_ATTR(srla_lpc_recursion<64>);
+            SET_LDS_ATTR(srla_lpc_quantize<64>);
+            hipExtLaunchKernelGGL(srla_lpc_recursion<64>, g64s, blks, lds, stream, ev_start, nullptr, 0, *jp, lags_ws, err_ws);
+            hipLaunchKernelGGL(srla_order_select, dim3(jp->num_items), blks, 0, stream, *jp, items, geoms, err_ws, results, dbg, ties);
+            hipLaunchKernelGGL(srla_lpc_quantize<64>, g64s, blks, lds, stream, *jp, lags_ws, huff_len, results, coef_ws);
+        } else {
+            const uint32_t lds = (2 * p + 3) * 8 * 32;
+            SET_LDS_ATTR(srla_lpc_recursion<32>);
+            SET_LDS_ATTR(srla_lpc_quantize<32>);
+            hipExtLaunchKernelGGL(srla_lpc_recursion<32>, dim3((jp->num_items + 31) / 32), blks, lds, stream, ev_start, nullptr, 0, *jp, lags_ws, err_ws);
+            hipLaunchKernelGGL(srla_order_select, dim3(jp->num_items), blks, 0, stream, *jp, items, geoms, err_ws, results, dbg, ties);
+            hipLaunchKernelGGL(srla_lpc_quantize<32>, dim3((jp->num_items + 31) / 32), blks, lds, stream, *jp, lags_ws, huff_len, results, coef_ws);
         }
-        hipLaunchKernelGGL(srla_svr_refine, dim3(8u * ((jp->num_items + 7u) >> 3)), dim3(SVR_NT), lds_svr, stream, *jp, input, items, results, coef_ws,
-                           svr_iterations, svr_n_cap);
+#undef SVR_PATH
+        {   /* items of order <= 64 in blocks that fit LDS, whatever the preset's maximum */
+            const uint32_t lds_svr = ((svr_n_cap * 4u + 15u) & ~15u) + svr_n_cap * 8u + (SVR_P * SVR_PS + 6 * SVR_P) * 8u;
+            {
+                static bool done_ = false;
+                if (!done_) { (void)hipFuncSetAttribute((const void *)srla_svr_refine, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048); done_ = true; }
+                (void)hipGetLastError();
+            }
+            hipLaunchKernelGGL(srla_svr_refine, dim3(8u * ((jp->num_items + 7u) >> 3)), dim3(SVR_NT), lds_svr, stream, *jp, input, items, results, coef_ws,
+                               ws_stride, svr_iterations, svr_n_cap);
+        }
+        if (p > 64 || jp->max_block > svr_n_cap) {
+            /* orders 128 / 255, blocks above 8192 samples: persistent workgroups on global scratch */
+            if (svr_scratch == nullptr || svr_groups == 0) return -1;
+            const uint32_t groups = jp->num_items < svr_groups ? jp->num_items : svr_groups;
+            hipLaunchKernelGGL(srla_svr_refine_big, dim3(groups), dim3(SVR_NT), 0, stream, *jp, input, items, results, coef_ws,
+                               ws_stride, svr_iterations, svr_n_cap, (unsigned char *)svr_scratch, jp->max_block);
+        }
         SET_LDS_ATTR(srla_lpc_quantize_ws);
-        hipExtLaunchKernelGGL(srla_lpc_quantize_ws, g64s, blks, 512 + SVR_P * 4 * 64, stream, nullptr, ev_stop, 0, *jp, coef_ws, huff_len, results);
+        hipExtLaunchKernelGGL(srla_lpc_quantize_ws, g64s, blks, 512 + (p < 64 ? 64 : p) * 4 * 64, stream, nullptr, ev_stop, 0, *jp, coef_ws, ws_stride, huff_len, results);
         return (hipGetLastError() == hipSuccess) ? 0 : -2;
     }
     const dim3 g64((jp->num_items + 63) / 64), blk(WAVE);
@@ -3452,14 +3532,14 @@ extern "C" int srla_launch_lpc_solve(hipStream_t stream, const SrlaJobParams *jp
         SET_LDS_ATTR(srla_lpc_quantize<64>);
         hipExtLaunchKernelGGL(srla_lpc_recursion<64>, g64, blk, lds, stream, ev_start, nullptr, 0, *jp, lags_ws, err_ws);
         hipLaunchKernelGGL(srla_order_select, dim3(jp->num_items), blk, 0, stream, *jp, items, geoms, err_ws, results, dbg, ties);
-        hipExtLaunchKernelGGL(srla_lpc_quantize<64>, g64, blk, lds, stream, nullptr, ev_stop, 0, *jp, lags_ws, huff_len, results);
+        hipExtLaunchKernelGGL(srla_lpc_quantize<64>, g64, blk, lds, stream, nullptr, ev_stop, 0, *jp, lags_ws, huff_len, results, (double *)nullptr);
     } else {
         const uint32_t lds = (2 * p + 3) * 8 * 32;
         SET_LDS_ATTR(srla_lpc_recursion<32>);
         SET_LDS_ATTR(srla_lpc_quantize<32>);
         hipExtLaunchKernelGGL(srla_lpc_recursion<32>, dim3((jp->num_items + 31) / 32), blk, lds, stream, ev_start, nullptr, 0, *jp, lags_ws, err_ws);
         hipLaunchKernelGGL(srla_order_select, dim3(jp->num_items), blk, 0, stream, *jp, items, geoms, err_ws, results, dbg, ties);
-        hipExtLaunchKernelGGL(srla_lpc_quantize<32>, dim3((jp->num_items + 31) / 32), blk, lds, stream, nullptr, ev_stop, 0, *jp, lags_ws, huff_len, results);
+        hipExtLaunchKernelGGL(srla_lpc_quantize<32>, dim3((jp->num_items + 31) / 32), blk, lds, stream, nullptr, ev_stop, 0, *jp, lags_ws, huff_len, results, (double *)nullptr);
     }
 #undef REGS_PATH
     return (hipGetLastError() == hipSuccess) ? 0 : -2;

@@ -620,11 +620,19 @@ def test_svr_refinement_on_the_device(product, cli):
         assert np.array_equal(got, want), (cli, kind, nch, n, bps)
 
 
-def test_svr_outside_its_limits_is_refused_loudly(product):
-    cfg, par = capi.cli_setup(2, 16, 48000, preset=5, max_block=4096, divisions=1, svr_iterations=2)
-    enc = product.create(cfg)
-    assert product.set_parameter(enc, par) == capi.NG
-    product.destroy(enc)
+SVR_BIG = [dict(preset=5, max_block=4096, divisions=1, svr_iterations=2), dict(preset=6, max_block=2048, divisions=0, svr_iterations=3),
+           dict(preset=4, max_block=16384, divisions=1, svr_iterations=2), dict(preset=5, max_block=16384, divisions=0, ltp_order=1, svr_iterations=1)]
+
+
+@pytest.mark.parametrize("cli", SVR_BIG, ids=["m5_i2", "m6_V0_i3", "m4_B16384_i2", "m5_B16384_P1_i1"])
+def test_svr_refinement_with_orders_above_64_and_blocks_above_8192(product, cli):
+    """presets 5 / 6 (orders 128 / 255) and blocks that do not fit LDS: srla_svr_refine_big (block, residuals and the matrix in
+    global scratch, persistent workgroups), behind the three-kernel solve for those orders"""
+    for kind, nch, n, bps in ((helpers.MUSIC, 2, 49152, 16), (helpers.VARIED, 2, 32768, 16), (helpers.MUSIC, 1, 16384, 24)):
+        pcm = helpers.synth(kind, 19, 48000, nch, n, bps)
+        got = product.encode(pcm, bits_per_sample=bps, **cli)
+        want = helpers.Oracle(nch, bits_per_sample=bps, **cli).encode_whole(pcm)
+        assert np.array_equal(got, want), (cli, kind, nch, n, bps)
 
 
 def test_pageable_buffers_locked_in_place_for_the_call(product, monkeypatch):

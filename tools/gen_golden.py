@@ -96,6 +96,9 @@ CLI = {
     "m4_B4096_svr5": dict(preset=4, max_block=4096, divisions=1, svr_iterations=5),
     "m4_B4096_V2_P3_svr2": dict(preset=4, max_block=4096, divisions=2, ltp_order=3, svr_iterations=2),
     "m2_B4096_svr5": dict(preset=2, max_block=4096, divisions=1, svr_iterations=5),
+    "m5_B4096_svr2": dict(preset=5, max_block=4096, divisions=1, svr_iterations=2),
+    "m6_B2048_V0_svr3": dict(preset=6, max_block=2048, divisions=0, svr_iterations=3),
+    "m4_B16384_svr2": dict(preset=4, max_block=16384, divisions=1, svr_iterations=2),
 }
 
 cases = []
@@ -137,6 +140,8 @@ for c in ("m4_B16384_V1", "m4_B32768_V2_P3", "m2_B32768_V0", "m4_B2048_V3_L16"):
 for c in ("m2_B4096_svr1", "m4_B4096_svr5", "m4_B4096_V2_P3_svr2", "m2_B4096_svr5"):
     add("svr_music_" + c, dict(kind=MUSIC, seed=71, rate=48000, nch=2, n=60000, bps=16), c)
     add("svr_varied_" + c, dict(kind=VARIED, seed=72, rate=48000, nch=2, n=49152, bps=16), c)
+for c in ("m5_B4096_svr2", "m6_B2048_V0_svr3", "m4_B16384_svr2"):
+    add("svrbig_music_" + c, dict(kind=MUSIC, seed=73, rate=48000, nch=2, n=49152, bps=16), c)
 # odd lengths: the reference is history dependent here (LPC window skips the middle sample); the
 # oracle reproduces it, the device path documents the deviation
 add("odd_tail_music", dict(kind=MUSIC, seed=31, rate=48000, nch=2, n=20001, bps=16), "m4_B4096")
