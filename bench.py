@@ -80,17 +80,24 @@ def cpu_baseline(pcm, cli, seconds, rate, bps=16):
     import numpy as np
     import helpers
     from srla_amd import capi
+    kind = "reference" if os.path.exists(helpers.REF_SO) else "port"
+    ref = capi.EncoderLib(helpers.REF_SO) if kind == "reference" else None
+
+    def encode(clip):
+        if ref is not None:
+            return ref.encode(clip, bits_per_sample=bps, sampling_rate=rate, **cli)
+        return helpers.Oracle(clip.shape[0], bits_per_sample=bps, sampling_rate=rate, **cli).encode_whole(clip)
+    if seconds <= 0:
+        # a short probe (it also pages the library in) sizes the sample: two timed runs of about 6 s of CPU work each
+        probe = np.ascontiguousarray(pcm[:, :min(pcm.shape[1], 10 * rate)])
+        t0 = time.perf_counter()
+        encode(probe)
+        seconds = max(10.0, 6.0 * probe.shape[1] / (time.perf_counter() - t0) / rate)
     n = min(pcm.shape[1], int(seconds * rate))
     clip = np.ascontiguousarray(pcm[:, :n])
-    kind = "port"
-    if os.path.exists(helpers.REF_SO):
-        ref = capi.EncoderLib(helpers.REF_SO)
-        run = lambda: ref.encode(clip, bits_per_sample=bps, sampling_rate=rate, **cli)
-        kind = "reference"
-    else:
-        def run():
-            return helpers.Oracle(clip.shape[0], bits_per_sample=bps, sampling_rate=rate, **cli).encode_whole(clip)
-    run()  # warm caches / page in
+    run = lambda: encode(clip)
+    if n <= 20 * rate:
+        run()  # warm caches / page in
     best = None
     for _ in range(2):
         t0 = time.perf_counter()
@@ -112,7 +119,8 @@ def parse_args(argv=None):
     ap.add_argument("--config", default="M", choices=sorted(CONFIGS), help="M: the metric configuration; C1..C5: BASELINE.json's configs")
     ap.add_argument("--seconds", type=float, default=None, help="audio per stream (default: the configuration's)")
     ap.add_argument("--files", type=int, default=None, help="streams per GPU per step (> 1: one SRLAMI355X_EncodeBatch call per step)")
-    ap.add_argument("--cpu-seconds", type=float, default=40.0, help="audio for the CPU baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=0.0,
+                    help="audio for the CPU baseline sample (default: sized by a probe for two timed runs of about 6 s of CPU work each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--preset", type=int, default=None)
     ap.add_argument("--block", type=int, default=None)
