@@ -700,7 +700,9 @@ SRLAApiResult Impl::encode_streams(bool search)
     for (uint32_t si = 0; si < nst; si++) {
         StreamCtx &st = sx[si];
         classify_buffers(st);
-        if (want_pins && st.host_in && !st.in_pinned && st.num_samples > 0) {
+        /* (streams of less than a few MB are not worth a registration: staging them costs microseconds) */
+        const bool worth_pinning = (uint64_t)st.num_samples * nch * 4u >= (4u << 20);
+        if (want_pins && worth_pinning && st.host_in && !st.in_pinned) {
             const size_t before = pins.held.size();
             bool ok = true;
             double us_per_mb = 0.0;
@@ -713,7 +715,7 @@ SRLAApiResult Impl::encode_streams(bool search)
             if (!ok) { while (pins.held.size() > before) { host_pin_release(pins.held.back()); pins.held.pop_back(); } }
             else st.in_pinned = true;
         }
-        if (want_pins && !pin_too_slow && st.data != nullptr && st.out_direct == nullptr && st.data_size > 0) {
+        if (want_pins && worth_pinning && !pin_too_slow && st.data != nullptr && st.out_direct == nullptr && st.data_size > 0) {
             /* a stream never exceeds its raw size + block headers: no need to lock more of a generous buffer */
             const uint64_t blocks = (uint64_t)st.num_samples / std::max<uint32_t>(1u, par.min_num_samples_per_block) + 2u;
             const uint64_t bound = SRLA_HEADER_SIZE + ((uint64_t)st.num_samples * nch * par.bits_per_sample + 7u) / 8u + 16u * blocks + 4096u;
