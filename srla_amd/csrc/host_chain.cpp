@@ -296,8 +296,7 @@ bool Impl::chain_encode_ad()
     if (c.search) {
         const auto tw = Clock::now();
         if (hipEventSynchronize(sj.t1[ST_D]) != hipSuccess) return false;
-        static const bool trace = getenv("SRLA_MI355X_CHAIN_TRACE") != nullptr;
-        if (trace) fprintf(stderr, "[chain] waited %.3f ms for the search job (%u rounds)\n", ms_since(tw), c.cs.rounds);
+        if (chain_trace) fprintf(stderr, "[chain] waited %.3f ms for the search job (%u rounds)\n", ms_since(tw), c.cs.rounds);
     }
     if (!chain_settle_ties()) return false;
     if (c.search) {

@@ -198,6 +198,11 @@ struct Impl {
     bool timing = true;               /* stage timing events (SRLA_MI355X_NO_TIMING drops them) */
     uint32_t tail_boost = 4, tail_boost_jobs = 3;   /* SRLA_MI355X_TAIL_BOOST="wgs,jobs" */
     uint32_t timing_stride = 4;       /* every n-th job carries start events on all stages (SRLA_MI355X_TIMING_STRIDE) */
+    void read_environment();          /* host_tuning.cpp: the one place that reads the environment */
+    bool no_chain = false;            /* SRLA_MI355X_NO_CHAIN */
+    bool chain_trace = false;         /* SRLA_MI355X_CHAIN_TRACE */
+    uint32_t env_pack_threads = 0;    /* SRLA_MI355X_PACK_THREADS (0: not set) */
+    uint32_t diag_stop = 0;           /* SRLA_MI355X_K3_STOP, builds with -DSRLA_DIAG_STOP only */
     bool no_speculation = false;      /* SRLA_MI355X_NO_SPECULATION: the OR of a stream is always gathered before its first job */
     bool force_staging = false;       /* SRLA_MI355X_STAGING: never write the caller's buffer from the device */
     bool no_pack16 = false;           /* SRLA_MI355X_NO_PACK16: host input always crosses PCIe as int32 */

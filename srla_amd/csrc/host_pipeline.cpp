@@ -64,14 +64,7 @@ bool Impl::init_device()
     if (dev_ready) return hipSetDevice(device) == hipSuccess;
     if (dev_failed) return false;
     dev_failed = true;
-    if (const char *e = getenv("SRLA_MI355X_SLOTS")) {
-        /* the software pipeline of encode_stream keeps depth + 1 = 4 jobs in flight: fewer buffer sets would be reused before
-         * their job has been collected; + 2 slots for the tail jobs, + 3 for chain mode */
-        const int v = atoi(e);
-        if (v >= 5 && v + 5 <= (int)kMaxSlots) kSlots = (uint32_t)v;
-        else fprintf(stderr, "[srla-mi355x] SRLA_MI355X_SLOTS=%d ignored: %d..%d job buffer sets are supported\n", v, 5, (int)kMaxSlots - 5);
-    }
-    if (const char *e = getenv("SRLA_MI355X_JOB_SAMPLES")) { const long long v = atoll(e); if (v >= 65536) job_samples = (uint64_t)v; }
+    read_environment();                                      /* host_tuning.cpp: every environment variable, in one place */
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
         fprintf(stderr, "[srla-mi355x] no HIP device available: the MI355X encode path cannot run "
@@ -81,25 +74,16 @@ bool Impl::init_device()
     HIP_OK(hipSetDevice(device));
     {
         /* W (critical path) and N (its few wavefronts gate the next wide kernel) run at high priority, the block
-         * assembly on C at low priority: measured +2 % over every other assignment (SRLA_MI355X_PRIO to experiment) */
+         * assembly on C at low priority: measured +2 % over every other assignment */
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        int pr[3] = { hi, hi, lo };
-        if (const char *e = getenv("SRLA_MI355X_PRIO")) {       /* experiment: e.g. "hlh": h = high, l = low, m = middle */
-            for (int i = 0; i < 3 && e[i]; i++) pr[i] = (e[i] == 'h') ? hi : ((e[i] == 'm') ? (lo + hi) / 2 : lo);
-        }
+        const int pr[3] = { hi, hi, lo };
         HIP_OK(hipStreamCreateWithPriority(&streams[0], hipStreamNonBlocking, pr[0]));
         HIP_OK(hipStreamCreateWithPriority(&streams[1], hipStreamNonBlocking, pr[1]));
         HIP_OK(hipStreamCreateWithPriority(&streams[2], hipStreamNonBlocking, pr[2]));
     }
     HIP_OK(hipEventCreate(&ev_or));
     HIP_OK(hipEventCreate(&ev_ref));
-    timeline = getenv("SRLA_MI355X_TIMELINE") != nullptr;
-    /* experiment kept as an option: no residuals in HBM, srla_pack_blocks recomputes the chosen blocks' (HBM
-     * traffic / 3, throughput -1..-8 %: these kernels are not bound by HBM) */
-    keep_residuals_always = getenv("SRLA_MI355X_RECOMPUTE_RESIDUALS") == nullptr;
-    split_ltp_stage = getenv("SRLA_MI355X_NO_LTP_SKEW") == nullptr;
-    if (const char *e = getenv("SRLA_MI355X_PIN_INPLACE")) pin_inplace = atoi(e) != 0 ? 1 : 0;
     HIP_OK(hipStreamCreateWithFlags(&upload, hipStreamNonBlocking));
     {
         int lo = 0, hi = 0;
@@ -131,18 +115,6 @@ bool Impl::init_device()
     }
     if (!d_pos.ensure(64)) return false;
     HIP_OK(hipMemset(d_pos.p, 0, 64));
-    force_staging = getenv("SRLA_MI355X_STAGING") != nullptr;
-    no_pack16 = getenv("SRLA_MI355X_NO_PACK16") != nullptr;
-    no_speculation = getenv("SRLA_MI355X_NO_SPECULATION") != nullptr;
-    if (const char *e = getenv("SRLA_MI355X_TIE_TEST")) {
-        /* "rel,ltp,logscale,ltpbias": widens the near-tie thresholds and falsifies the device's log / its scaled LTP taps, so
-         * that the host arbitration has real work to do (tests/test_gpu_ties.py) */
-        double a = 0, b = 0, c = 1, d = 0;
-        if (sscanf(e, "%lf,%lf,%lf,%lf", &a, &b, &c, &d) == 4) { tie_rel = a; tie_ltp = b; tie_logscale = c; tie_ltpbias = d; }
-    }
-    timing = getenv("SRLA_MI355X_NO_TIMING") == nullptr;
-    if (const char *e = getenv("SRLA_MI355X_TAIL_BOOST")) { unsigned a = 0, b = 0; if (sscanf(e, "%u,%u", &a, &b) == 2 && a >= 1) { tail_boost = a; tail_boost_jobs = b; } }
-    if (const char *e = getenv("SRLA_MI355X_TIMING_STRIDE")) { const int v = atoi(e); if (v >= 1) timing_stride = (uint32_t)v; }
     if (!d_or.ensure(64)) return false;
     unsigned hw = std::thread::hardware_concurrency();
     /* a container's CPU quota (cgroup v2 cpu.max = "<quota> <period>") bounds the useful thread count */
@@ -157,7 +129,7 @@ bool Impl::init_device()
     /* half of the usable CPUs, at most 8: the enqueueing thread and the HIP runtime's own helper threads
      * need the rest (measured: more pack threads than that makes launches and D2H completion slower) */
     unsigned nthreads = pack_threads ? pack_threads : std::max(1u, std::min((hw ? hw : 2u) / 2u, 8u));
-    if (const char *e = getenv("SRLA_MI355X_PACK_THREADS")) { const int v = atoi(e); if (v > 0) nthreads = (unsigned)v; }
+    if (env_pack_threads) nthreads = env_pack_threads;
     pool = new Pool(nthreads);
     dev_failed = false;
     dev_ready = true;
@@ -557,8 +529,7 @@ SRLAApiResult Impl::finish_job(Slot &s)
     const auto t0 = Clock::now();
     const SrlaJobInfo info = *s.h_info.as<SrlaJobInfo>();
 #ifdef SRLA_DIAG_STOP
-    static const bool diag = getenv("SRLA_MI355X_K3_STOP") != nullptr;   /* timing experiments: the stream is garbage */
-    if (diag) return SRLA_APIRESULT_OK;
+    if (diag_stop) return SRLA_APIRESULT_OK;                  /* timing experiments: the stream is garbage */
 #endif
     if (info.error & ~SRLA_JOBERR_OVERFLOW) {
         fprintf(stderr, "[srla-mi355x] internal error: device pack reported 0x%x (%s%s)\n", info.error,
@@ -689,7 +660,6 @@ SRLAApiResult Impl::encode_streams(bool search)
     if ((size_t)8 * nst > d_pos.cap) { drain(); if (!d_pos.ensure((size_t)8 * nst)) return SRLA_APIRESULT_NG; }
     const uint32_t window_len = search ? par.num_lookahead_samples : par.max_num_samples_per_block;
     const uint32_t grid = search ? par.min_num_samples_per_block : par.max_num_samples_per_block;
-    static const bool no_chain = getenv("SRLA_MI355X_NO_CHAIN") != nullptr;
     /* page-lock pageable planes / buffers in place for this call (Impl::pin_inplace); dropped again when the call leaves */
     struct PinGuard {
         std::vector<const void *> held;
@@ -819,7 +789,6 @@ SRLAApiResult Impl::encode_streams(bool search)
         if (st.body == 0 || (search && nodes >= 3)) chain.early = true;
         else if (!search) { chain.early = true; chain_seed_off = st.body - par.max_num_samples_per_block; chain_seed_n = par.max_num_samples_per_block; }
     }
-    static const bool chain_trace = getenv("SRLA_MI355X_CHAIN_TRACE") != nullptr;
     /* the chain-mode window of stream `i`, synchronously: seed from the priced job in `ls` (segment k), or none */
     auto chain_sync = [&](uint32_t i, Slot *ls, size_t k) -> SRLAApiResult {
         StreamCtx &st = sx[i];

@@ -228,7 +228,7 @@ SrlaJobParams Impl::job_params(const Job &job, uint32_t channel_stride, bool lsh
     jp.num_cands = (uint32_t)job.cands.size();
     jp.num_windows = (uint32_t)job.windows.size();
 #ifdef SRLA_DIAG_STOP
-    { static const char *e = getenv("SRLA_MI355X_K3_STOP"); jp.out_stride = e ? (uint32_t)atoi(e) : 0u; }   /* kernel timing experiments only */
+    jp.out_stride = diag_stop;                               /* kernel timing experiments only */
 #endif
     jp.lshift_dev = lshift_on_device ? (d_or.as<uint32_t>() + 1) : nullptr;
     jp.keep_residuals = job.keep_residuals ? 1u : 0u;

@@ -1,0 +1,69 @@
+/*
+ * host_tuning.cpp -- every environment variable the library reads, in one place.
+ *
+ * Impl::read_environment() runs once per handle (from init_device) and fills the handle's fields; what the kernel
+ * launchers need goes to kernels.hip through srla_set_launch_tuning.  INTEGRATION.md lists the same names for users.
+ */
+#include "host_impl.h"
+
+#include <algorithm>
+#include <stdio.h>
+#include <stdlib.h>
+
+namespace {
+bool is_set(const char *name) { return getenv(name) != nullptr; }
+long long number(const char *name, long long fallback)
+{
+    const char *e = getenv(name);
+    return e ? atoll(e) : fallback;
+}
+}
+
+void Impl::read_environment()
+{
+    /* ---- behaviour ------------------------------------------------------------------------------------------------- */
+    no_chain = is_set("SRLA_MI355X_NO_CHAIN");                 /* history-dependent last windows analysed with zeros */
+    no_speculation = is_set("SRLA_MI355X_NO_SPECULATION");     /* host input: the OR pass for the offset shift always runs first */
+    no_pack16 = is_set("SRLA_MI355X_NO_PACK16");               /* host input always crosses PCIe as int32 */
+    force_staging = is_set("SRLA_MI355X_STAGING");             /* never let the device read / write the caller's buffers */
+    if (is_set("SRLA_MI355X_PIN_INPLACE")) pin_inplace = number("SRLA_MI355X_PIN_INPLACE", 0) != 0 ? 1 : 0;   /* else by pool size */
+
+    /* ---- sizing ---------------------------------------------------------------------------------------------------- */
+    if (is_set("SRLA_MI355X_SLOTS")) {
+        /* the software pipeline keeps up to depth + 1 = 5 jobs in flight: fewer buffer sets would be reused before their
+         * job has been collected; + 2 slots for the tail jobs, + 3 for chain mode */
+        const int v = (int)number("SRLA_MI355X_SLOTS", 0);
+        if (v >= 5 && v + 5 <= (int)kMaxSlots) kSlots = (uint32_t)v;
+        else fprintf(stderr, "[srla-mi355x] SRLA_MI355X_SLOTS=%d ignored: %d..%d job buffer sets are supported\n", v, 5, (int)kMaxSlots - 5);
+    }
+    { const long long v = number("SRLA_MI355X_JOB_SAMPLES", 0); if (v >= 65536) job_samples = (uint64_t)v; }
+    { const long long v = number("SRLA_MI355X_PACK_THREADS", 0); if (v > 0) env_pack_threads = (uint32_t)v; }
+    if (const char *e = getenv("SRLA_MI355X_TAIL_BOOST")) {     /* "wgs,jobs": stream-out workgroup multiplier of the last jobs */
+        unsigned a = 0, b = 0;
+        if (sscanf(e, "%u,%u", &a, &b) == 2 && a >= 1) { tail_boost = a; tail_boost_jobs = b; }
+    }
+
+    /* ---- measured alternatives kept as options -------------------------------------------------------- */
+    keep_residuals_always = !is_set("SRLA_MI355X_RECOMPUTE_RESIDUALS");   /* set: no residual scratch, the pack kernel recomputes */
+    split_ltp_stage = !is_set("SRLA_MI355X_NO_LTP_SKEW");                 /* set: the pitch solve back on stream W */
+    SrlaLaunchTuning lt;
+    lt.fused_fft = number("SRLA_MI355X_FUSED_FFT", 0) != 0 ? 1u : 0u;     /* two FFT stages per LDS round trip */
+    lt.pack_lds_cap_words = (uint32_t)std::max<long long>(0, number("SRLA_MI355X_PACK_LDS_WORDS", 0));   /* tests: reach the global-memory pack path */
+    lt.out_wgs = (uint32_t)std::max<long long>(0, number("SRLA_MI355X_OUT_WGS", 0));
+    srla_set_launch_tuning(&lt);
+
+    /* ---- diagnostics ------------------------------------------------------------------------------------------------ */
+    timeline = is_set("SRLA_MI355X_TIMELINE");                 /* device-clock start / end of every stage of every job */
+    timing = !is_set("SRLA_MI355X_NO_TIMING");
+    { const long long v = number("SRLA_MI355X_TIMING_STRIDE", 0); if (v >= 1) timing_stride = (uint32_t)v; }
+    chain_trace = is_set("SRLA_MI355X_CHAIN_TRACE");
+    if (const char *e = getenv("SRLA_MI355X_TIE_TEST")) {
+        /* "rel,ltp,logscale,ltpbias": widens the near-tie thresholds and falsifies the device's log / its scaled LTP taps, so
+         * that the host arbitration has real work to do (tests/test_gpu_ties.py) */
+        double a = 0, b = 0, c = 1, d = 0;
+        if (sscanf(e, "%lf,%lf,%lf,%lf", &a, &b, &c, &d) == 4) { tie_rel = a; tie_ltp = b; tie_logscale = c; tie_ltpbias = d; }
+    }
+#ifdef SRLA_DIAG_STOP
+    diag_stop = (uint32_t)std::max<long long>(0, number("SRLA_MI355X_K3_STOP", 0));   /* kernel timing experiments: the stream is garbage */
+#endif
+}

@@ -88,6 +88,13 @@ int srla_launch_pack(hipStream_t stream, const SrlaJobParams *jp, uint32_t num_s
                      uint8_t *stage, uint8_t *host_stage, uint8_t *scratch, SrlaJobInfo *info,
                      uint32_t *window_bytes, SrlaSegInfo *seg_info, const uint32_t *ties,
                      hipEvent_t ev_start, hipEvent_t ev_stop, uint32_t out_boost);
+/* What the launchers take from the environment (read in ONE place, host_tuning.cpp, and handed over here): */
+typedef struct {
+    uint32_t fused_fft;            /* SRLA_MI355X_FUSED_FFT: fft_complex_lds16 for 2048- and 4096-point items */
+    uint32_t pack_lds_cap_words;   /* SRLA_MI355X_PACK_LDS_WORDS: 0 = the default cap (24 Ki words) */
+    uint32_t out_wgs;              /* SRLA_MI355X_OUT_WGS: stream-out workgroups, 0 = by sample width */
+} SrlaLaunchTuning;
+void srla_set_launch_tuning(const SrlaLaunchTuning *t);
 #define SRLA_SEGCTL_WORDS_HOST 8
 uint32_t srla_pack_lds_words(const SrlaJobParams *jp);
 int srla_pack_needs_scratch(const SrlaJobParams *jp);   /* blocks may exceed the LDS staging: allocate the scratch */

@@ -3378,6 +3378,9 @@ __global__ void srla_mask_to_shift(uint32_t *__restrict__ out)
 }
 
 /* --------------------------------------------------------------------------- launchers ---- */
+static SrlaLaunchTuning g_tune = { 0u, 0u, 0u };
+extern "C" void srla_set_launch_tuning(const SrlaLaunchTuning *t) { if (t) g_tune = *t; }
+
 #define SET_LDS_ATTR(fn)                                                                                     \
     do {                                                                                                     \
         static bool done_ = false;                                                                           \
@@ -3405,8 +3408,7 @@ extern "C" int srla_launch_autocorr(hipStream_t stream, int rclass, const SrlaJo
     /* SRLA_MI355X_FUSED_FFT=1: fft_complex_lds16 (two stages per LDS round trip) for 2048- and 4096-point items.  Bit-identical
      * and half the LDS cycles, but 21 % more VALU instructions and, for 2048 points, half the wavefronts per item: measured
      * 163 vs 159 us (4096) and 80 vs 61 us (2048) per launch at the metric configuration -- an option, not the default. */
-    const char *fe = getenv("SRLA_MI355X_FUSED_FFT");
-    const int fused = (fe && atoi(fe) != 0) ? 1 : 0;
+    const int fused = g_tune.fused_fft ? 1 : 0;
     switch (rclass * 10 + fused) {
     case 0: case 1: LAUNCH(1, 128, false); break;     /* <= 1024 points: 128 threads (one butterfly each and stage), 8 KB of LDS */
     case 10: LAUNCH(1, 256, false); break;
@@ -3613,9 +3615,8 @@ extern "C" int srla_launch_price(hipStream_t stream, const SrlaJobParams *jp, co
  * global scratch region.  SRLA_MI355X_PACK_LDS_WORDS lowers the cap (tests use it to reach the global path). */
 static uint32_t pack_lds_cap()
 {
-    uint32_t cap = 24 * 1024;                               /* <= 96 KB */
-    if (const char *e = getenv("SRLA_MI355X_PACK_LDS_WORDS")) { const int v = atoi(e); if (v >= 8 && v < (int)cap) cap = (uint32_t)v; }
-    return cap;
+    const uint32_t cap = 24 * 1024;                         /* <= 96 KB */
+    return (g_tune.pack_lds_cap_words >= 8u && g_tune.pack_lds_cap_words < cap) ? g_tune.pack_lds_cap_words : cap;
 }
 
 extern "C" uint32_t srla_pack_lds_words(const SrlaJobParams *jp)
@@ -3649,17 +3650,11 @@ extern "C" int srla_launch_pack(hipStream_t stream, const SrlaJobParams *jp, uin
     hipLaunchKernelGGL(srla_pack_blocks, dim3(num_slots), dim3(NT), lds, stream,
                        *jp, input, items, blocks, results, res_ws, huff_code, huff_len, block_off, seg_ctl, stage, scratch, info,
                        lds_words, rl_samples);
-    static int out_wgs = -1, out_thr = 0, out_sleep = 0;
-    if (out_wgs < 0) {
-        const char *e = getenv("SRLA_MI355X_OUT_WGS"); out_wgs = e ? atoi(e) : 0; if (out_wgs < 0) out_wgs = 0;
-        e = getenv("SRLA_MI355X_OUT_THREADS"); out_thr = e ? atoi(e) : NT; if (out_thr < 64 || out_thr > NT) out_thr = NT;
-        e = getenv("SRLA_MI355X_OUT_SLEEP"); out_sleep = e ? atoi(e) : 0;
-    }
     /* one workgroup keeps up with 16-bit streams (~12 GB/s of output at full speed) and leaves the PCIe write path calm
      * enough for srla_autocorr (measured: more slow it down); 24-bit streams carry twice the bytes and need two */
-    const uint32_t wgs = out_wgs ? (uint32_t)out_wgs : (jp->bits_per_sample > 16 ? 2u : 1u);
-    hipExtLaunchKernelGGL(srla_stream_out, dim3(wgs * (out_boost ? out_boost : 1u)), dim3((uint32_t)out_thr), 0, stream, nullptr, ev_stop, 0,
-                          stage, seg_ctl, segs, jp->num_segs, host_stage, (uint32_t)out_sleep);
+    const uint32_t wgs = g_tune.out_wgs ? g_tune.out_wgs : (jp->bits_per_sample > 16 ? 2u : 1u);
+    hipExtLaunchKernelGGL(srla_stream_out, dim3(wgs * (out_boost ? out_boost : 1u)), dim3(NT), 0, stream, nullptr, ev_stop, 0,
+                          stage, seg_ctl, segs, jp->num_segs, host_stage, 0u);
     return (hipGetLastError() == hipSuccess) ? 0 : -2;
 }
 
