@@ -104,7 +104,15 @@ def cpu_baseline(pcm, cli, seconds, rate, bps=16):
         out = run()
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
-    return {"value": round(n / best / 1e6, 4), "unit": "Msamples/s", "cores": 1, "kind": kind,
+    model = "unknown"
+    try:
+        for l in open("/proc/cpuinfo"):
+            if l.startswith("model name"):
+                model = l.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": round(n / best / 1e6, 4), "unit": "Msamples/s", "cores": 1, "kind": kind, "cpu_model": model,
             "sample": "first %.0f s of the same workload (%d samples/ch, %d ch), best of 2, %s" %
                       (n / rate, n, clip.shape[0], "AVX2 build of the reference, EncodeWhole in memory" if kind == "reference"
                        else "oracle/srla_oracle.c, scalar C"),
