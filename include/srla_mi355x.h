@@ -179,6 +179,16 @@ SRLAApiResult SRLAMI355X_EncodeBatchEx(
     struct SRLAEncoder *encoder, uint32_t num_streams, const int32_t *const *const *inputs, const uint32_t *num_samples,
     const uint32_t *sample_or, uint8_t *const *data, const uint32_t *data_size, uint32_t *output_size, SRLAApiResult *results);
 
+/* The same for streams given as what a WAV `data` chunk holds: interleaved little-endian PCM frames (bytes_per_sample = 1, 2 or 3
+ * and equal to the handle's bits_per_sample / 8; 8-bit samples are unsigned with offset 128, the others signed -- the conversion
+ * of libs/wav/src/wav.c:707 that tools/srla_codec/srla_codec.c:75-134 runs before SRLAEncoder_EncodeWhole).  The frames cross the
+ * link as they are and are de-interleaved, widened and OR-reduced on the device: a front end only has to read() its files into
+ * memory.  Frames in page-locked memory (SRLAMI355X_AllocHost) are read where they lie; pageable ones are locked in place for the
+ * call (or, where that is refused, de-interleaved on the host).  frames[i] points at the first frame of stream i. */
+SRLAApiResult SRLAMI355X_EncodeBatchPcm(
+    struct SRLAEncoder *encoder, uint32_t num_streams, const void *const *frames, const uint32_t *num_samples,
+    uint32_t bytes_per_sample, uint8_t *const *data, const uint32_t *data_size, uint32_t *output_size, SRLAApiResult *results);
+
 /* Pinned (page-locked, device-visible) host memory for callers that do not link HIP themselves: input planes in it are read
  * by DMA without a staging copy, output buffers in it are written by the device directly.  NULL when no device is usable. */
 void *SRLAMI355X_AllocHost(size_t bytes);

@@ -3,18 +3,19 @@
  * (tools/srla_codec/srla_codec.c:75-158 runs once per file; its WAV reader is libs/wav/src/wav.c:136-282, :479-556),
  * native and multi-threaded, on top of the C ABI of libsrla_mi355x.so:
  *
- *   reader threads   mmap a .wav, parse it as WAV_CreateFromFile does, de-interleave to planar int32 (what the
- *                    reference hands to SRLAEncoder_EncodeWhole) in pinned memory, gathering the OR of the samples on the
- *                    way: the library then reads the planes by DMA and its host threads touch no sample
- *   main thread      gathers the loaded files of one format into batches and calls SRLAMI355X_EncodeBatch (windows of
- *                    different files share the device jobs); one encoder handle per format, kept for the whole corpus
+ *   reader threads   read() a .wav into pinned memory and parse its header as WAV_CreateFromFile does -- nothing else: the data
+ *                    chunk goes to the device as it is (SRLAMI355X_EncodeBatchPcm de-interleaves, widens and OR-reduces it
+ *                    there), so this read is the only time the host touches a sample.  --host-deinterleave: mmap the file
+ *                    and de-interleave to planar int32 in pinned memory on the host instead (SRLAMI355X_EncodeBatchEx)
+ *   main thread      gathers the loaded files of one format into batches (windows of different files share the device
+ *                    jobs); one encoder handle per format, kept for the whole corpus
  *   writer threads   write <out>/<relative name>.srl, optionally hashing the streams for the manifest
  *
  * Same options, defaults and output-buffer rule (2 x the input file size) as `srla -e`.  One process per GPU: with
  * RANK / WORLD_SIZE / LOCAL_RANK in the environment (torchrun, or --rank / --world) every rank encodes the files the
  * deterministic longest-first assignment gives it (the same one as srla_amd/corpus.py) -- no communication at all.
  *
- *   srla_corpus -e [-m 4] [-B 4096] [-V 1] [-L 4] [-P 0] [--manifest FILE [--sha256]] [--batch-samples N] [--readers N] [--writers N] IN_DIR OUT_DIR
+ *   srla_corpus -e [-m 4] [-B 4096] [-V 1] [-L 4] [-P 0] [--manifest FILE [--sha256]] [--batch-samples N] [--readers N] [--writers N] [--host-deinterleave] IN_DIR OUT_DIR
  */
 #include <algorithm>
 #include <atomic>
@@ -125,12 +126,17 @@ struct Pcm {
     std::string path, rel;
     uint32_t nch = 0, bps = 0, rate = 0, n = 0;
     uint64_t file_size = 0;
-    int32_t *samples = nullptr;            /* planar [nch][n], pinned */
+    /* default: the file as read, in pinned memory; `frames` points at its data chunk (handed to SRLAMI355X_EncodeBatchPcm: the
+     * device de-interleaves).  --host-deinterleave: planar [nch][n] samples, pinned, and their OR (SRLAMI355X_EncodeBatchEx) */
+    uint8_t *raw = nullptr;
+    size_t raw_cap = 0;
+    const uint8_t *frames = nullptr;
+    int32_t *samples = nullptr;
     size_t samples_cap = 0;
     uint32_t sample_or = 0;                /* OR of every sample (the offset left shift comes from it, srla_utility.c:177) */
     std::vector<const int32_t *> planes;
     std::string error;
-    ~Pcm() { g_pinned.give(samples, samples_cap); }
+    ~Pcm() { g_pinned.give(samples, samples_cap); g_pinned.give(raw, raw_cap); }
 };
 
 uint32_t rd16(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
@@ -140,6 +146,8 @@ uint32_t rd32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) 
  * (format tag 1) or 40 bytes (tag 0xFFFE with a 22-byte extension); chunks between `fmt ` and `data` are skipped by
  * their raw size; 8-bit samples are offset binary, 16 / 24 / 32-bit little endian two's complement (:479-556); the
  * samples come out planar and sign-extended, not left-justified (:848-852). */
+bool g_host_deinterleave = false;
+
 bool load_wav(Pcm &f)
 {
     const int fd = open(f.path.c_str(), O_RDONLY);
@@ -147,11 +155,27 @@ bool load_wav(Pcm &f)
     struct stat sb;
     if (fstat(fd, &sb) != 0 || sb.st_size < 44) { close(fd); f.error = "not a RIFF/WAVE file"; return false; }
     f.file_size = (uint64_t)sb.st_size;
-    const uint8_t *b = static_cast<const uint8_t *>(mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0));
-    close(fd);
-    if (b == MAP_FAILED) { f.error = "mmap failed"; return false; }
     const size_t size = (size_t)sb.st_size;
-    auto done = [&](const char *err) { munmap(const_cast<uint8_t *>(b), size); if (err) f.error = err; return err == nullptr; };
+    const uint8_t *b = nullptr;
+    if (g_host_deinterleave) {
+        b = static_cast<const uint8_t *>(mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0));
+        close(fd);
+        if (b == MAP_FAILED) { f.error = "mmap failed"; return false; }
+    } else {
+        /* the whole file into pinned memory: this read() is the only time the host touches the samples */
+        f.raw = static_cast<uint8_t *>(g_pinned.take(size + 64, &f.raw_cap));
+        if (f.raw == nullptr) { close(fd); f.error = "out of (pinned) memory"; return false; }
+        size_t got = 0;
+        while (got < size) {
+            const ssize_t r = read(fd, f.raw + got, size - got);
+            if (r <= 0) break;
+            got += (size_t)r;
+        }
+        close(fd);
+        if (got != size) { f.error = "read failed"; return false; }
+        b = f.raw;
+    }
+    auto done = [&](const char *err) { if (g_host_deinterleave) munmap(const_cast<uint8_t *>(b), size); if (err) f.error = err; return err == nullptr; };
     if (memcmp(b, "RIFF", 4) != 0 || memcmp(b + 8, "WAVE", 4) != 0) return done("not a RIFF/WAVE file");
     size_t pos = 12;
     if (memcmp(b + pos, "fmt ", 4) != 0) return done("'fmt ' chunk expected right after 'WAVE'");
@@ -178,6 +202,7 @@ bool load_wav(Pcm &f)
     if (pos + data_size > size) return done("truncated data chunk");
     f.n = data_size / frame;
     if (f.n == 0) return done("no samples");
+    if (!g_host_deinterleave) { f.frames = b + pos; return done(nullptr); }
     f.samples = static_cast<int32_t *>(g_pinned.take((size_t)f.nch * f.n * 4 + 64, &f.samples_cap));
     if (f.samples == nullptr) return done("out of (pinned) memory");
     const uint8_t *d = b + pos;
@@ -254,7 +279,7 @@ struct Options {
 
 int usage()
 {
-    fprintf(stderr, "usage: srla_corpus -e [-m 4] [-B 4096] [-V 1] [-L 4] [-P 0] [--manifest FILE] [--sha256] [--batch-samples N] [--readers N] [--writers N] [--verbose] IN_DIR OUT_DIR\n");
+    fprintf(stderr, "usage: srla_corpus -e [-m 4] [-B 4096] [-V 1] [-L 4] [-P 0] [--manifest FILE] [--sha256] [--batch-samples N] [--readers N] [--writers N] [--host-deinterleave] [--verbose] IN_DIR OUT_DIR\n");
     return 1;
 }
 
@@ -283,6 +308,7 @@ int main(int argc, char **argv)
         else if (a == "--writers") o.writers = (unsigned)std::max(1, atoi(val()));
         else if (a == "--sha256") o.sha = true;
         else if (a == "--verbose") o.verbose = true;
+        else if (a == "--host-deinterleave") g_host_deinterleave = true;
         else if (a == "--rank") o.rank = atoi(val());
         else if (a == "--world") o.world = std::max(1, atoi(val()));
         else if (a == "--device") o.local_rank = atoi(val());
@@ -430,7 +456,11 @@ int main(int argc, char **argv)
         }
         SRLAApiResult rc = SRLA_APIRESULT_NG;
         const auto tb = std::chrono::steady_clock::now();
-        if (enc) rc = SRLAMI355X_EncodeBatchEx(enc, ns, inputs.data(), nsmp.data(), ors.data(), datas.data(), caps.data(), sizes_out.data(), res.data());
+        if (enc && !g_host_deinterleave) {
+            std::vector<const void *> frames(ns);
+            for (uint32_t i = 0; i < ns; i++) frames[i] = files[i]->frames;
+            rc = SRLAMI355X_EncodeBatchPcm(enc, ns, frames.data(), nsmp.data(), k.bps / 8u, datas.data(), caps.data(), sizes_out.data(), res.data());
+        } else if (enc) rc = SRLAMI355X_EncodeBatchEx(enc, ns, inputs.data(), nsmp.data(), ors.data(), datas.data(), caps.data(), sizes_out.data(), res.data());
         if (o.verbose) {
             uint64_t tot = 0; for (uint32_t i = 0; i < ns; i++) tot += nsmp[i];
             const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb).count();

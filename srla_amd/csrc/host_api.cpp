@@ -250,6 +250,67 @@ void SRLAMI355X_FreeHost(void *p)
     if (p) (void)hipHostFree(p);
 }
 
+SRLAApiResult SRLAMI355X_EncodeBatchPcm(struct SRLAEncoder *encoder, uint32_t num_streams, const void *const *frames,
+                                        const uint32_t *num_samples, uint32_t bytes_per_sample, uint8_t *const *data,
+                                        const uint32_t *data_size, uint32_t *output_size, SRLAApiResult *results)
+{
+    Impl *im = impl_of(encoder);
+    if (im == nullptr || num_streams == 0 || frames == NULL || num_samples == NULL || data == NULL || data_size == NULL || output_size == NULL)
+        return SRLA_APIRESULT_INVALID_ARGUMENT;
+    if (!im->set_parameter) return SRLA_APIRESULT_PARAMETER_NOT_SET;
+    if (bytes_per_sample * 8u != im->par.bits_per_sample) return SRLA_APIRESULT_INVALID_FORMAT;   /* the container is the sample format */
+    for (uint32_t i = 0; i < num_streams; i++) {
+        if (frames[i] == NULL || data[i] == NULL) return SRLA_APIRESULT_INVALID_ARGUMENT;
+        if (num_samples[i] == 0) return SRLA_APIRESULT_INVALID_FORMAT;
+        if (data_size[i] < SRLA_HEADER_SIZE) return SRLA_APIRESULT_INSUFFICIENT_BUFFER;
+    }
+    if (!im->init_device()) return SRLA_APIRESULT_NG;
+    const uint32_t nch = im->par.num_channels;
+    /* the frames must be readable by DMA: page-locked already (SRLAMI355X_AllocHost, hipHostMalloc, hipHostRegister), or locked
+     * in place for the call */
+    struct Pins { std::vector<const void *> held; ~Pins() { for (const void *p : held) host_pin_release(p); } } pins;
+    bool dma = !im->force_staging;
+    for (uint32_t i = 0; i < num_streams && dma; i++) {
+        hipPointerAttribute_t at;
+        memset(&at, 0, sizeof(at));
+        if (hipPointerGetAttributes(&at, frames[i]) == hipSuccess && at.type == hipMemoryTypeHost) continue;
+        (void)hipGetLastError();
+        if (host_pin_acquire(frames[i], (size_t)num_samples[i] * nch * bytes_per_sample, nullptr)) pins.held.push_back(frames[i]);
+        else dma = false;
+    }
+    /* otherwise (locking refused, SRLA_MI355X_STAGING): de-interleave on the host and take the ordinary path */
+    std::vector<std::vector<int32_t>> planes;
+    std::vector<std::vector<const int32_t *>> plane_ptrs;
+    if (!dma) {
+        planes.resize(num_streams); plane_ptrs.resize(num_streams);
+        for (uint32_t i = 0; i < num_streams; i++) {
+            planes[i].resize((size_t)nch * num_samples[i]);
+            plane_ptrs[i].resize(nch);
+            for (uint32_t ch = 0; ch < nch; ch++) {
+                int32_t *dst = planes[i].data() + (size_t)ch * num_samples[i];
+                (void)pcm_channel(static_cast<const uint8_t *>(frames[i]), bytes_per_sample, nch, ch, 0, num_samples[i], dst);
+                plane_ptrs[i][ch] = dst;
+            }
+        }
+    }
+    im->sx.clear();
+    im->sx.resize(num_streams);
+    for (uint32_t i = 0; i < num_streams; i++) {
+        StreamCtx &st = im->sx[i];
+        if (dma) { st.pcm = static_cast<const uint8_t *>(frames[i]); st.pcm_bytes = bytes_per_sample; }
+        else st.host_in = plane_ptrs[i].data();
+        st.num_samples = num_samples[i];
+        st.data = data[i]; st.data_size = data_size[i]; st.with_header = true;
+    }
+    const SRLAApiResult rc = im->encode_streams(im->search_enabled());
+    if (rc != SRLA_APIRESULT_OK && rc != SRLA_APIRESULT_INSUFFICIENT_BUFFER) return rc;
+    for (uint32_t i = 0; i < num_streams; i++) {
+        output_size[i] = (im->sx[i].rc == SRLA_APIRESULT_OK) ? im->sx[i].write_off : 0u;
+        if (results) results[i] = im->sx[i].rc;
+    }
+    return rc;
+}
+
 SRLAApiResult SRLAMI355X_EncodeBatchEx(struct SRLAEncoder *encoder, uint32_t num_streams, const int32_t *const *const *inputs,
                                        const uint32_t *num_samples, const uint32_t *sample_or, uint8_t *const *data,
                                        const uint32_t *data_size, uint32_t *output_size, SRLAApiResult *results)

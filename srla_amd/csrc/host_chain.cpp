@@ -201,7 +201,8 @@ bool Impl::chain_begin(uint32_t seed_off, uint32_t seed_n)
     auto fetch = [&](uint32_t off, uint32_t n, std::vector<int32_t> &dst) -> bool {
         dst.resize((size_t)nch * n);
         for (uint32_t ch = 0; ch < nch; ch++) {
-            if (st.host_in) memcpy(dst.data() + (size_t)ch * n, st.host_in[ch] + off, (size_t)n * 4);
+            if (st.pcm) (void)pcm_channel(st.pcm, st.pcm_bytes, nch, ch, off, n, dst.data() + (size_t)ch * n);
+            else if (st.host_in) memcpy(dst.data() + (size_t)ch * n, st.host_in[ch] + off, (size_t)n * 4);
             else if (hipMemcpy(dst.data() + (size_t)ch * n, st.d_in + (size_t)ch * st.d_stride + off, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) return false;
         }
         return true;

@@ -110,6 +110,7 @@ struct Slot {
     bool split_a = false;                /* stage A was enqueued in two parts (run_stage) */
     bool timed = false;                  /* this job records start events for every stage (one job in four) */
     uint32_t out_boost = 1;              /* stream-out workgroup multiplier (the last jobs of a stream drain faster) */
+    DevBuf d_pcm;                        /* PCM input: the job's frames as uploaded, de-interleaved into d_input by srla_deinterleave */
     DevBuf d_input16;                    /* host input of at most 16 bits crosses PCIe as int16 and is widened into d_input */
     DevBuf d_input, d_items, d_cands, d_windows, d_results, d_res_ws, d_blocks, d_block_off, d_scratch, d_dbg, d_lags, d_err, d_class_index, d_stream;
     DevBuf d_segs, d_seg_ctl;            /* SrlaSegDesc per segment; device-side segment records of srla_block_offsets */
@@ -130,7 +131,9 @@ struct Slot {
 /* One stream of a call. */
 struct StreamCtx {
     const int32_t *const *host_in = nullptr;   /* planar host planes, or */
-    const int32_t *d_in = nullptr;             /* planar device planes, d_stride elements apart */
+    const int32_t *d_in = nullptr;             /* planar device planes, d_stride elements apart, or */
+    const uint8_t *pcm = nullptr;              /* interleaved little-endian PCM frames in page-locked host memory (EncodeBatchPcm) */
+    uint32_t pcm_bytes = 0;                    /* bytes per sample of those frames (1: unsigned + 128, 2, 3, 4: signed) */
     uint32_t d_stride = 0;
     uint32_t num_samples = 0;
     uint8_t *data = nullptr;                   /* the stream's output buffer */

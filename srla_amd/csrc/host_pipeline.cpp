@@ -36,7 +36,7 @@ Impl::~Impl()
             for (auto &e : s.t1) if (e) (void)hipEventDestroy(e);
             if (s.ev_in) (void)hipEventDestroy(s.ev_in);
             for (hipEvent_t e : { s.ev_a1, s.ev_p0, s.ev_p, s.ev_a0 }) if (e) (void)hipEventDestroy(e);
-            s.d_input16.release();
+            s.d_input16.release(); s.d_pcm.release();
             DevBuf *db[] = { &s.d_input, &s.d_items, &s.d_cands, &s.d_windows, &s.d_results, &s.d_res_ws,
                              &s.d_blocks, &s.d_block_off, &s.d_scratch, &s.d_dbg, &s.d_lags, &s.d_err, &s.d_class_index, &s.d_stream,
                              &s.d_segs, &s.d_seg_ctl, &s.d_ties, &s.d_tie_data, &s.d_big_scratch, &s.d_big_items, &s.d_coef_ws };
@@ -159,6 +159,29 @@ bool Impl::stage_input(Slot &s, const JobPlan &plan)
             s.stride_cur = first.d_stride;
             return true;
         }
+    }
+    if (sx[plan.segs[0].stream].pcm) {
+        /* interleaved PCM frames in page-locked host memory (every stream of such a call): the frames cross the link as
+         * they are (2 bytes per 16-bit sample instead of 4), srla_deinterleave writes the planes, srla_or_reduce gathers
+         * the OR for the offset shift -- no host thread touches a sample */
+        const uint32_t total = plan.total, B = sx[plan.segs[0].stream].pcm_bytes;
+        const size_t frame = (size_t)B * nch;
+        if (!s.d_input.ensure((size_t)nch * total * 4) || !s.d_pcm.ensure((size_t)total * frame + 64)) return false;
+        for (const SegPlan &sp : plan.segs) {
+            StreamCtx &st = sx[sp.stream];
+            uint8_t *raw = s.d_pcm.as<uint8_t>() + (size_t)sp.base * frame;
+            HIP_OK(hipMemcpyAsync(raw, st.pcm + (size_t)sp.s0 * frame, (size_t)sp.ns * frame, hipMemcpyHostToDevice, upload));
+            if (srla_launch_deinterleave(upload, raw, B, nch, sp.ns, s.d_input.as<int32_t>() + sp.base, total) != 0) return false;
+            if (!st.lshift_final && st.or_on_device) {
+                st.or_dev_end = std::max(st.or_dev_end, sp.s0 + sp.ns);
+                if (srla_launch_or_accumulate(upload, s.d_input.as<int32_t>() + sp.base, total, sp.ns, nch, d_oracc.as<uint32_t>() + 2u * sp.stream) != 0) return false;
+            }
+        }
+        HIP_OK(hipEventRecord(s.ev_in, upload));
+        s.in_cur = s.d_input.as<int32_t>();
+        s.stride_cur = total;
+        s.used_h2d = true;
+        return true;
     }
     const uint32_t total = plan.total, nseg = (uint32_t)plan.segs.size();
     if (!s.d_input.ensure((size_t)nch * total * 4)) return false;
@@ -715,6 +738,15 @@ SRLAApiResult Impl::encode_streams(bool search)
             if (hipMemcpyAsync(h_or.p, d_or.p, 8, hipMemcpyDeviceToHost, w) != hipSuccess) return SRLA_APIRESULT_NG;
             if (hipEventRecord(ev_or, w) != hipSuccess) return SRLA_APIRESULT_NG;
             st.lshift_on_device = true;
+        } else if (st.pcm) {
+            /* as for pinned planes below: a short look by the host (the whole stream with SRLA_MI355X_NO_SPECULATION), the
+             * device gathers the rest */
+            const uint32_t look = no_speculation ? st.num_samples : std::min<uint32_t>(st.num_samples, 65536u);
+            uint32_t m = 0;
+            for (uint32_t ch = 0; ch < nch; ch++) m |= pcm_channel(st.pcm, st.pcm_bytes, nch, ch, 0, look, nullptr);
+            st.or_mask = m; st.or_covered = look;
+            if (look == st.num_samples) { st.lshift = shift_of(m); st.lshift_final = true; }
+            else { st.or_on_device = true; need_oracc = true; }
         } else if (st.in_pinned && st.cb == nullptr && !no_speculation) {
             /* pinned planes: the host looks at the first 64 Ki samples per channel only; the device gathers the OR of
              * everything it uploads (stage_input) and the guess is checked against that at the end */
@@ -923,7 +955,9 @@ SRLAApiResult Impl::encode_streams(bool search)
                 std::atomic<uint32_t> acc{ 0 };
                 pool->parallel_for(per_ch * nch, [&](uint32_t q) {
                     const uint32_t ch = q / per_ch, o = (q % per_ch) * chunk;
-                    acc.fetch_or(or_reduce(st.host_in[ch] + o0 + o, std::min(chunk, len - o)), std::memory_order_relaxed);
+                    const uint32_t m = st.pcm ? pcm_channel(st.pcm, st.pcm_bytes, nch, ch, (size_t)o0 + o, std::min(chunk, len - o), nullptr)
+                                              : or_reduce(st.host_in[ch] + o0 + o, std::min(chunk, len - o));
+                    acc.fetch_or(m, std::memory_order_relaxed);
                 });
                 st.or_mask |= acc.load();
                 st.or_covered = st.num_samples;

@@ -109,6 +109,23 @@ uint32_t or_reduce(const int32_t *src, size_t n)
 }
 
 
+uint32_t pcm_channel(const uint8_t *frames, uint32_t B, uint32_t nch, uint32_t ch, size_t first, size_t n, int32_t *dst)
+{
+    const size_t frame = (size_t)B * nch;
+    const uint8_t *p = frames + first * frame + (size_t)ch * B;
+    uint32_t m = 0;
+    for (size_t i = 0; i < n; i++, p += frame) {
+        int32_t v;
+        if (B == 1) v = (int32_t)p[0] - 128;
+        else if (B == 2) v = (int16_t)((uint32_t)p[0] | ((uint32_t)p[1] << 8));
+        else if (B == 3) v = ((int32_t)(((uint32_t)p[0] << 8) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 24))) >> 8;
+        else v = (int32_t)((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24));
+        if (dst) dst[i] = v;
+        m |= (uint32_t)v;
+    }
+    return m;
+}
+
 namespace {
 struct PinEntry { size_t bytes; uint32_t refs; };
 std::mutex g_pin_mutex;

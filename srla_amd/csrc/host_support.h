@@ -79,6 +79,8 @@ uint32_t copy_or(int32_t *dst, const int32_t *src, size_t n);
 /* the same, packing to int16 (streams of at most 16 bits per sample cross PCIe at half the size; the device widens them
  * again); *wide gets a non-zero value if a sample does not fit (the caller then stages that job as int32) */
 uint32_t pack16_or(int16_t *dst, const int32_t *src, size_t n, uint32_t *wide);
+/* interleaved little-endian PCM frames -> one channel's samples (libs/wav/src/wav.c: 8-bit unsigned + 128, else signed); returns their OR */
+uint32_t pcm_channel(const uint8_t *frames, uint32_t bytes_per_sample, uint32_t num_channels, uint32_t ch, size_t first, size_t n, int32_t *dst /* may be null */);
 /* OR of n samples (no copy) */
 uint32_t or_reduce(const int32_t *src, size_t n);
 

@@ -3658,6 +3658,49 @@ extern "C" int srla_launch_pack(hipStream_t stream, const SrlaJobParams *jp, uin
     return (hipGetLastError() == hipSuccess) ? 0 : -2;
 }
 
+/* Interleaved little-endian PCM frames (what a WAV data chunk holds, uploaded as they are) -> planar int32: the conversion of
+ * libs/wav/src/wav.c (8-bit samples are unsigned with offset 128, the others signed), four frames per thread, one
+ * 16-byte store per channel.  dst points at the first sample of the segment in plane 0 (16-byte aligned), planes `stride` apart. */
+template <int B>
+__global__ __launch_bounds__(NT) void srla_deinterleave(const uint8_t *__restrict__ src, uint32_t num_channels, uint32_t count,
+                                                        int32_t *__restrict__ dst, size_t stride)
+{
+    const uint32_t f0 = 4u * (blockIdx.x * NT + threadIdx.x);
+    if (f0 >= count) return;
+    const uint32_t frame = (uint32_t)B * num_channels;
+    for (uint32_t ch = 0; ch < num_channels; ch++) {
+        int32_t v[4] = { 0, 0, 0, 0 };
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if (f0 + (uint32_t)i >= count) break;
+            const uint8_t *p = src + (size_t)(f0 + (uint32_t)i) * frame + (size_t)ch * B;
+            if (B == 1) v[i] = (int32_t)p[0] - 128;
+            else if (B == 2) v[i] = (int16_t)((uint32_t)p[0] | ((uint32_t)p[1] << 8));
+            else if (B == 3) v[i] = ((int32_t)(((uint32_t)p[0] << 8) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 24))) >> 8;
+            else v[i] = (int32_t)((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24));
+        }
+        int32_t *o = dst + (size_t)ch * stride + f0;
+        if (f0 + 4u <= count) *reinterpret_cast<int4 *>(o) = make_int4(v[0], v[1], v[2], v[3]);
+        else for (uint32_t i = 0; f0 + i < count; i++) o[i] = v[i];
+    }
+}
+
+extern "C" int srla_launch_deinterleave(hipStream_t stream, const void *src, uint32_t bytes_per_sample, uint32_t num_channels,
+                                        uint32_t count, int32_t *dst, size_t stride)
+{
+    if (count == 0) return 0;
+    const dim3 grid((count + 4u * NT - 1u) / (4u * NT)), blk(NT);
+    const uint8_t *s8 = (const uint8_t *)src;
+    switch (bytes_per_sample) {
+    case 1: hipLaunchKernelGGL(srla_deinterleave<1>, grid, blk, 0, stream, s8, num_channels, count, dst, stride); break;
+    case 2: hipLaunchKernelGGL(srla_deinterleave<2>, grid, blk, 0, stream, s8, num_channels, count, dst, stride); break;
+    case 3: hipLaunchKernelGGL(srla_deinterleave<3>, grid, blk, 0, stream, s8, num_channels, count, dst, stride); break;
+    case 4: hipLaunchKernelGGL(srla_deinterleave<4>, grid, blk, 0, stream, s8, num_channels, count, dst, stride); break;
+    default: return -1;
+    }
+    return (hipGetLastError() == hipSuccess) ? 0 : -2;
+}
+
 /* the same without the conversion: *out |= OR of the samples (several launches accumulate into one word) */
 extern "C" int srla_launch_or_accumulate(hipStream_t stream, const int32_t *in, size_t channel_stride, size_t count,
                                          uint32_t num_channels, uint32_t *out)

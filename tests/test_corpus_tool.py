@@ -41,16 +41,18 @@ def test_tool_is_built_and_fails_loudly_without_a_gpu(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [1, 2])
-def test_corpus_encodes_like_the_oracle(tmp_path, world):
+@pytest.mark.parametrize("world,extra", [(1, []), (2, []), (1, ["--host-deinterleave"])], ids=["one_rank", "two_ranks", "host_deinterleave"])
+def test_corpus_encodes_like_the_oracle(tmp_path, world, extra):
+    """default: the files' data chunks go to the device as read (SRLAMI355X_EncodeBatchPcm); --host-deinterleave: planar int32
+    made on the host (SRLAMI355X_EncodeBatchEx)"""
     files = _make_corpus(str(tmp_path / "in"))
     cli = dict(preset=4, max_block=4096, divisions=2, ltp_order=3)
     seen = {}
     for rank in range(world):
         man = str(tmp_path / ("manifest%d.json" % rank))
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
-        p = subprocess.run([TOOL, "-e", "-m", "4", "-B", "4096", "-V", "2", "-P", "3", "--manifest", man, "--sha256", "--batch-samples", "100000",
-                            str(tmp_path / "in"), str(tmp_path / "out")], capture_output=True, text=True, env=env)
+        p = subprocess.run([TOOL, "-e", "-m", "4", "-B", "4096", "-V", "2", "-P", "3", "--manifest", man, "--sha256", "--batch-samples", "100000"] + extra +
+                           [str(tmp_path / "in"), str(tmp_path / "out")], capture_output=True, text=True, env=env)
         assert p.returncode == 0, p.stderr
         assert "finished:" in p.stdout
         for e in json.load(open(man))["files"]:

@@ -173,3 +173,71 @@ def test_batch_ex_with_pinned_planes_and_given_or_masks(product):
         product.destroy(enc)
         for ptr in pinned:
             L.SRLAMI355X_FreeHost(ptr)
+
+
+def _interleave(pcm, bps):
+    """planar int32 -> the bytes of a WAV data chunk (8-bit: unsigned + 128; else signed little endian)"""
+    nch, n = pcm.shape
+    t = np.ascontiguousarray(pcm.T)                     # frames
+    if bps == 8:
+        return (t + 128).astype(np.uint8).tobytes()
+    if bps == 16:
+        return t.astype("<i2").tobytes()
+    b = t.astype("<i4").view(np.uint8).reshape(n, nch, 4)[:, :, :3]
+    return np.ascontiguousarray(b).tobytes()
+
+
+@pytest.mark.parametrize("how", ["pageable", "pinned", "staged"])
+@pytest.mark.parametrize("bps,nch", [(16, 2), (24, 3), (8, 1)])
+def test_batch_of_interleaved_pcm_frames(product, monkeypatch, how, bps, nch):
+    """SRLAMI355X_EncodeBatchPcm: streams given as WAV data chunks.  The frames are uploaded as they are and de-interleaved,
+    widened and OR-reduced on the device (pageable: locked in place for the call; pinned: SRLAMI355X_AllocHost memory; staged:
+    SRLA_MI355X_STAGING, de-interleaved on the host).  Odd lengths (chain-mode tails), a stream shorter than a window, and one
+    whose first 64 Ki frames suggest an offset shift the whole stream does not have."""
+    if how == "staged":
+        monkeypatch.setenv("SRLA_MI355X_STAGING", "1")
+    L = product.lib
+    L.SRLAMI355X_AllocHost.restype = C.c_void_p
+    L.SRLAMI355X_AllocHost.argtypes = [C.c_size_t]
+    L.SRLAMI355X_FreeHost.argtypes = [C.c_void_p]
+    fn = L.SRLAMI355X_EncodeBatchPcm
+    fn.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    fn.restype = C.c_int
+    cli = dict(preset=4, max_block=4096, divisions=1) if bps != 16 else CLIS["m4_B4096_V2_P3"]
+    pcms = [helpers.synth(helpers.MUSIC if nch == 2 else helpers.VARIED, 970 + i, 48000, nch, n, bps) for i, n in enumerate((150001, 49152, 3000, 200000))]
+    if bps > 8:
+        pcms[3][:, :100000] = (pcms[3][:, :100000] >> 4) << 4           # the prefix looks shifted, the stream is not
+        pcms[1] = np.ascontiguousarray((pcms[1] >> 2) << 2)               # this one really is
+    raw = [_interleave(p, bps) for p in pcms]
+    enc = _encoder(product, nch, bps=bps, **cli)
+    pinned, keep = [], []
+    try:
+        ptrs = []
+        for r in raw:
+            if how == "pinned":
+                ptr = L.SRLAMI355X_AllocHost(len(r))
+                assert ptr
+                pinned.append(ptr)
+                C.memmove(ptr, r, len(r))
+                ptrs.append(ptr)
+            else:
+                a = np.frombuffer(r, np.uint8).copy()
+                keep.append(a)
+                ptrs.append(a.ctypes.data)
+        n = len(pcms)
+        frames = (C.c_void_p * n)(*ptrs)
+        nsmp = (C.c_uint32 * n)(*[p.shape[1] for p in pcms])
+        outs = [np.zeros(4 * p.size + 1024, np.uint8) for p in pcms]
+        data = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+        caps = (C.c_uint32 * n)(*[o.size for o in outs])
+        sizes = (C.c_uint32 * n)()
+        res = (C.c_int * n)()
+        assert fn(enc, n, frames, nsmp, bps // 8, data, caps, sizes, res) == capi.OK
+        for i, p in enumerate(pcms):
+            assert np.array_equal(outs[i][:sizes[i]], _oracle(p, bps=bps, **cli)), i
+        # the container must be the sample format
+        assert fn(enc, n, frames, nsmp, (bps // 8) % 3 + 1, data, caps, sizes, res) == capi.INVALID_FORMAT
+    finally:
+        product.destroy(enc)
+        for ptr in pinned:
+            L.SRLAMI355X_FreeHost(ptr)
