@@ -20,7 +20,7 @@ from srla_amd import capi  # noqa: E402
 ORACLE_SO = os.path.join(ROOT, "oracle", "liboracle.so")
 REF_SO = os.path.join(ROOT, "oracle", "_ref", "libsrla_ref.so")
 SYNTH_SO = os.path.join(ROOT, "tools", "synth", "libsynth.so")
-PRODUCT_SO = os.path.join(ROOT, "srla_amd", "libsrla_mi355x.so")
+PRODUCT_SO = os.environ.get("SRLA_PRODUCT_SO", os.path.join(ROOT, "srla_amd", "libsrla_mi355x.so"))   # override: A/B runs of two builds
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 MAX_ORDER = 255
