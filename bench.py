@@ -60,7 +60,7 @@ class Stats(C.Structure):
                 ("analyzed_samples", C.c_uint64), ("autocorr_ms", C.c_double), ("solve_ms", C.c_double),
                 ("residual_ms", C.c_double), ("timed_jobs", C.c_uint64),
                 ("num_tie_resolved", C.c_uint64), ("num_tie_overrides", C.c_uint64), ("num_restarts", C.c_uint64),
-                ("num_inplace_pins", C.c_uint64)]
+                ("num_inplace_pins", C.c_uint64), ("num_inplace_out_pins", C.c_uint64)]
 
 
 def usable_cpus():
@@ -370,8 +370,10 @@ def main(argv=None):
             "tie_items": int(st.num_tie_items), "tie_resolved": int(st.num_tie_resolved), "tie_overrides": int(st.num_tie_overrides),
             # how the pageable buffers reached the device: staged through pinned buffers by the pool threads, or -- when the
             # ranks' share of the CPU quota is too small for that -- page-locked in place for the call and read by DMA
-            "host_buffers": ("page-locked in place per call (hipHostRegister), no host copies" if st.num_inplace_pins else
-                             "staged through pinned buffers by %d host threads" % pack_threads) if not args.pinned_io else "pinned by the caller",
+            "host_buffers": ("pinned by the caller" if args.pinned_io else "input: %s; output: %s" % (
+                "page-locked in place per call (hipHostRegister), read by DMA" if st.num_inplace_pins else
+                "staged through pinned buffers by %d host threads" % pack_threads,
+                "page-locked in place per call, written by the device" if st.num_inplace_out_pins else "copied out of pinned staging buffers")),
         })
         if world == 1 and files == 1:
             # the same encode with the samples resident in HBM and a pinned output buffer (what a caller that already holds

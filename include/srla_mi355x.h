@@ -219,7 +219,8 @@ struct SRLAMI355XStats {
     uint64_t num_tie_resolved;   /* flagged items (any candidate, not only chosen ones) whose decision the host libm confirmed */
     uint64_t num_tie_overrides;  /* flagged items where the host libm decided otherwise: re-analysed with the host's decision */
     uint64_t num_restarts;       /* times the stream loop went back to a job because of such an override            */
-    uint64_t num_inplace_pins;   /* pageable input planes / output buffers page-locked in place for a call (instead of staged) */
+    uint64_t num_inplace_pins;   /* pageable input planes page-locked in place for a call (instead of staged) */
+    uint64_t num_inplace_out_pins;  /* pageable output buffers page-locked in place for a call (written by the device directly) */
 };
 /* cumulative since Create or the last reset */
 void SRLAMI355X_GetStats(struct SRLAEncoder *encoder, struct SRLAMI355XStats *stats, int reset);

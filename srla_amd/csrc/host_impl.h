@@ -169,8 +169,9 @@ struct Impl {
     bool set_parameter = false;
     uint32_t param_generation = 0;    /* bumped by SetEncodeParameter: invalidates cached job tables */
     /* Pageable input planes / output buffers are page-locked in place for the duration of a call (hipHostRegister) and then
-     * read by DMA / written by the device where they lie: no host thread touches a sample.  -1: decided per call -- when the
-     * pool has too few threads to stage at the GPU's pace (N ranks sharing a CPU quota); 0 / 1: SRLA_MI355X_PIN_INPLACE */
+     * read by DMA / written by the device where they lie: no host thread touches a sample.  -1: decided per call -- output
+     * buffers always, input planes when the pool has too few threads to stage at the GPU's pace (N ranks sharing a CPU quota);
+     * 0 / 1: never / always (SRLA_MI355X_PIN_INPLACE) */
     int pin_inplace = -1;
     bool pin_too_slow = false;          /* registration measured slower than staging would be (no huge pages): not tried again */
     bool split_ltp_stage = true;        /* SRLA_MI355X_NO_LTP_SKEW: stage A of LTP jobs in one piece on W, as before */
