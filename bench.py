@@ -122,8 +122,8 @@ def cpu_baseline(pcm, cli, seconds, rate, bps=16):
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=None, help="ranks (one GPU each); default: WORLD_SIZE of the launcher, else 1")
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="M", choices=sorted(CONFIGS), help="M: the metric configuration; C1..C5: BASELINE.json's configs")
     ap.add_argument("--seconds", type=float, default=None, help="audio per stream (default: the configuration's)")
     ap.add_argument("--files", type=int, default=None, help="streams per GPU per step (> 1: one SRLAMI355X_EncodeBatch call per step)")
