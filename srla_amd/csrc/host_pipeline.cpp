@@ -208,13 +208,8 @@ bool Impl::stage_input(Slot &s, const JobPlan &plan)
         /* (one stream: the channels' copies spread over two streams / SDMA engines were 15 % slower) */
         for (const SegPlan &sp : plan.segs)
             for (uint32_t ch = 0; ch < nch; ch++)
-            {
-                static const int copy_wgs = getenv("SRLA_MI355X_COPY_WGS") ? atoi(getenv("SRLA_MI355X_COPY_WGS")) : 0;   /* EXPERIMENT */
-                if (copy_wgs > 0) { if (srla_launch_copy_in(upload, sx[sp.stream].host_in[ch] + sp.s0, s.d_input.as<int32_t>() + (size_t)ch * total + sp.base, sp.ns, (uint32_t)copy_wgs) != 0) return false; }
-                else
                 HIP_OK(hipMemcpyAsync(s.d_input.as<int32_t>() + (size_t)ch * total + sp.base, sx[sp.stream].host_in[ch] + sp.s0,
                                       (size_t)sp.ns * 4, hipMemcpyHostToDevice, upload));
-            }
         /* the OR of the samples, where it is still being gathered: on the device, from the uploaded copy */
         for (const SegPlan &sp : plan.segs) {
             const StreamCtx &st = sx[sp.stream];

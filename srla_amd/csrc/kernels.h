@@ -101,7 +101,6 @@ int srla_pack_needs_scratch(const SrlaJobParams *jp);   /* blocks may exceed the
 
 int srla_launch_deinterleave(hipStream_t stream, const void *src /* device */, uint32_t bytes_per_sample, uint32_t num_channels,
                              uint32_t count, int32_t *dst, size_t stride);   /* interleaved LE PCM frames -> planar int32 */
-int srla_launch_copy_in(hipStream_t stream, const int32_t *src, int32_t *dst, uint32_t count, uint32_t wgs);   /* EXPERIMENT */
 int srla_launch_or_accumulate(hipStream_t stream, const int32_t *in, size_t channel_stride, size_t count,
                               uint32_t num_channels, uint32_t *out);   /* *out |= OR of the samples */
 int srla_launch_or_reduce(hipStream_t stream, const int32_t *in, size_t channel_stride, size_t count,

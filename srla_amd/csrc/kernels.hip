@@ -3701,32 +3701,6 @@ extern "C" int srla_launch_deinterleave(hipStream_t stream, const void *src, uin
     return (hipGetLastError() == hipSuccess) ? 0 : -2;
 }
 
-/* EXPERIMENT: host (pinned) -> device copy by a kernel instead of an SDMA engine */
-__global__ __launch_bounds__(NT) void srla_copy_in(const int32_t *__restrict__ src, int32_t *__restrict__ dst, uint32_t count)
-{
-    const uint32_t gsize = gridDim.x * NT, gtid = blockIdx.x * NT + threadIdx.x;
-    if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15u) == 0) {
-        const uint32_t n4 = count >> 2;
-        const int4 *s4 = reinterpret_cast<const int4 *>(src);
-        int4 *d4 = reinterpret_cast<int4 *>(dst);
-        uint32_t i = gtid;
-        for (; i + 3u * gsize < n4; i += 4u * gsize) {
-            const int4 a = s4[i], b = s4[i + gsize];
-            const int4 c = s4[i + 2u * gsize], d = s4[i + 3u * gsize];
-            d4[i] = a; d4[i + gsize] = b; d4[i + 2u * gsize] = c; d4[i + 3u * gsize] = d;
-        }
-        for (; i < n4; i += gsize) d4[i] = s4[i];
-        for (uint32_t k = (n4 << 2) + gtid; k < count; k += gsize) dst[k] = src[k];
-    } else {
-        for (uint32_t k = gtid; k < count; k += gsize) dst[k] = src[k];
-    }
-}
-extern "C" int srla_launch_copy_in(hipStream_t stream, const int32_t *src, int32_t *dst, uint32_t count, uint32_t wgs)
-{
-    hipLaunchKernelGGL(srla_copy_in, dim3(wgs), dim3(NT), 0, stream, src, dst, count);
-    return (hipGetLastError() == hipSuccess) ? 0 : -2;
-}
-
 /* the same without the conversion: *out |= OR of the samples (several launches accumulate into one word) */
 extern "C" int srla_launch_or_accumulate(hipStream_t stream, const int32_t *in, size_t channel_stride, size_t count,
                                          uint32_t num_channels, uint32_t *out)
