@@ -804,7 +804,10 @@ SRLAApiResult Impl::encode_streams(bool search)
         settle_lshift(plan[k], lsh);
         build_job(s.job, plan[k], lsh, search);
         if (apply_overrides(s.job, k)) { s.job.uploaded = false; s.job.key = 0; }
-        s.own_stream = nullptr; s.emits = true; s.merge_cb = false;
+        /* a call of one job has nothing to overlap: its stages run on ONE stream, without the cross-stream hand-overs
+         * (about 13 us each; a 10 s stream: 0.49 -> 0.465 ms) */
+        s.own_stream = (njobs == 1) ? streams[0] : nullptr;
+        s.emits = true; s.merge_cb = false;
         s.timed = timing && (k % timing_stride == 0);
         s.out_boost = (k + tail_boost_jobs >= njobs) ? tail_boost : 1u;
         return prepare_job(s, false);
