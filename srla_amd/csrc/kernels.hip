@@ -1426,10 +1426,15 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
 
     /* load + pre-emphasis (srla_utility.c:342) */
     int32_t y[S];
+#ifdef SRLA_DIAG_STOP
+    const uint32_t load_variant_as = (jp.out_stride >= 21 && jp.out_stride <= 26) ? 0u : it.variant;   /* what would cheaper loads buy? */
+#else
+    const uint32_t load_variant_as = it.variant;
+#endif
 #pragma unroll
     for (int c = 0; c < FL; c++) {
         int32_t t4[4];
-        load_chunk(in, iv, it.variant, s_base + 4 * c, n, aligned, t4);
+        load_chunk(in, iv, load_variant_as, s_base + 4 * c, n, aligned, t4);
         y[4 * c] = t4[0]; y[4 * c + 1] = t4[1]; y[4 * c + 2] = t4[2]; y[4 * c + 3] = t4[3];
     }
     {
@@ -1451,7 +1456,7 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
     if (tid >= 32 && tid < 64) sm->thr[tid - 32] = rice_thresholds[tid - 32];
     __syncthreads();
 #ifdef SRLA_DIAG_STOP
-    if (jp.out_stride == 1) { if (y[0] == 0x7fffffff) out->pad[1] = 1; return; }   /* kernel timing experiments (make EXTRA=-DSRLA_DIAG_STOP): never in the shipped library */
+    if (jp.out_stride == 1 || jp.out_stride == 22) { if (y[0] == 0x7fffffff) out->pad[1] = 1; return; }   /* kernel timing experiments (make EXTRA=-DSRLA_DIAG_STOP): never in the shipped library */
 #endif
 
     if (period > 0) {

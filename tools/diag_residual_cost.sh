@@ -6,7 +6,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/diag_rc
 mkdir -p $O
 rm -f $O/result.txt
-for st in 1 2 3 4 5 0; do
+for st in ${STOPS:-1 2 3 4 5 0}; do
   if [ $st = 0 ]; then unset SRLA_MI355X_K3_STOP; else export SRLA_MI355X_K3_STOP=$st; fi
   rm -rf /tmp/dd; timeout 120 rocprofv3 --kernel-trace --pmc SQ_WAVES --output-format csv -d /tmp/dd -o run -- python $R/tools/perf_probe.py 174.8 device 4 ${1:-1} ${2:-0} ${3:-4096} > /tmp/dd.log 2>&1
   python - "$st" >> $O/result.txt <<'PY'
