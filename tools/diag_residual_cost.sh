@@ -1,5 +1,6 @@
 # kernel timing experiment (DIAG build only: make EXTRA=-DSRLA_DIAG_STOP): duration of the largest srla_residual_cost dispatches
-# cut short at successive points (SRLA_MI355X_K3_STOP=1..5), kernels serialised by the counter collection
+# cut short at successive points (SRLA_MI355X_K3_STOP=1..5; 21: the whole kernel with every variant loaded as one channel, 22: the
+# same cut after the loads), kernels serialised by the counter collection.  STOPS="1 22 0 21" selects
 #   gpurun -- bash tools/diag_residual_cost.sh [V] [P] [B]
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
