@@ -668,3 +668,23 @@ def test_pageable_buffers_locked_in_place_for_the_call(product, monkeypatch):
     want = helpers.Oracle(2, **cli).encode_whole(odd)
     assert want[24] == 0
     assert np.array_equal(product.encode(odd, **cli), want)
+
+
+def test_buffer_too_small_for_a_stream_that_is_locked_in_place(product):
+    """a stream large enough for its output buffer to be page-locked for the call (only as much of it as a stream can need):
+    too small a buffer is INSUFFICIENT_BUFFER, the exact size and a generous one give the stream"""
+    cli = dict(preset=4, max_block=4096, divisions=1)
+    pcm = helpers.synth(helpers.MUSIC, 5, 48000, 2, 3_000_001)
+    want = helpers.Oracle(2, **cli).encode_whole(pcm)
+    cfg, par = capi.cli_setup(2, 16, 48000, **cli)
+    enc = product.create(cfg)
+    assert product.set_parameter(enc, par) == capi.OK
+    try:
+        for cap in (1000, want.size // 2, want.size - 1):
+            rc, _ = product.encode_whole(enc, pcm, cap=cap)
+            assert rc == capi.INSUFFICIENT_BUFFER, cap
+        for cap in (want.size, want.size + 5, 16 * pcm.size):
+            rc, got = product.encode_whole(enc, pcm, cap=cap)
+            assert rc == capi.OK and np.array_equal(got, want), cap
+    finally:
+        product.destroy(enc)
