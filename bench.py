@@ -23,7 +23,8 @@ Extra objects on the JSON line:
                    dispatches inside the timed region; peak = 8000 GB/s HBM3E; traffic, valu_util and fp64_inst_frac from
                    the committed rocprofv3 PMC summary (profiles/pmc_summary.json).
   cpu_baseline     the compiled reference (oracle/_ref, "reference") or the oracle ("port") timed on ONE host core on
-                   a bounded sample of the same workload (rank 0, N = 1 only).
+                   a bounded sample of the same workload (rank 0, N = 1 only); `all_cores`: for context, the same on
+                   every usable core at once (one handle per thread).
   device_resident  the same encode with the samples already in HBM and a pinned output buffer
                    (SRLAMI355X_EncodeWholeDevice), mean of a few calls outside the timed region -- never `value`.
 """
@@ -104,6 +105,25 @@ def cpu_baseline(pcm, cli, seconds, rate, bps=16):
         out = run()
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
+    # for context: the same clip on every usable core at once, one handle per thread (ctypes releases the GIL)
+    all_cores = None
+    ncores = usable_cpus()
+    if ref is not None and ncores > 1:
+        import threading
+        short = np.ascontiguousarray(clip[:, :max(10 * rate, n // 4)])
+        times = [0.0] * ncores
+
+        def work(i):
+            t0 = time.perf_counter()
+            ref.encode(short, bits_per_sample=bps, sampling_rate=rate, **cli)
+            times[i] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        th = [threading.Thread(target=work, args=(i,)) for i in range(ncores)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        wall = time.perf_counter() - t0
+        all_cores = {"value": round(ncores * short.shape[1] / wall / 1e6, 3), "unit": "Msamples/s", "cores": ncores,
+                     "sample": "%d threads, one handle and one copy of the first %.0f s each" % (ncores, short.shape[1] / rate)}
     model = "unknown"
     try:
         for l in open("/proc/cpuinfo"):
@@ -116,7 +136,7 @@ def cpu_baseline(pcm, cli, seconds, rate, bps=16):
             "sample": "first %.0f s of the same workload (%d samples/ch, %d ch), best of 2, %s" %
                       (n / rate, n, clip.shape[0], "AVX2 build of the reference, EncodeWhole in memory" if kind == "reference"
                        else "oracle/srla_oracle.c, scalar C"),
-            "bytes": int(out.size)}
+            "bytes": int(out.size), "all_cores": all_cores}
 
 
 def parse_args(argv=None):
