@@ -286,7 +286,9 @@ def main(argv=None):
     cfg, par = capi.cli_setup(nch, bps, rate, **cli)
     enc = lib.create(cfg)
     assert enc and lib.set_parameter(enc, par) == capi.OK
-    pack_threads = args.pack_threads or max(1, min(8, usable_cpus() // max(1, world)))   # the calling thread works too: one CPU per pool thread
+    # the rank's share of the usable CPUs, less two for the HIP runtime's own threads (the calling thread is one of the pool):
+    # 16 CPUs -> 8 / 6 / 2 / 1 threads at 1 / 2 / 4 / 8 ranks; below 6 the library stops staging and locks the input in place
+    pack_threads = args.pack_threads or max(1, min(8, usable_cpus() // max(1, world) - (2 if world > 1 else 0)))
     L.SRLAMI355X_SetPackThreads(enc, pack_threads)
     cap = 2 * pcms[0].size * (bps // 8) + 4096
     outs = [(torch.empty(cap, dtype=torch.uint8).pin_memory().numpy() if args.pinned_io else np.zeros(cap, dtype=np.uint8))
