@@ -224,3 +224,23 @@ def encode_batch(lib, enc, pcms, caps=None):
     rc = call.run(enc, sizes)
     res = list(call.results)
     return rc, [outs[i][:sizes[i]].copy() if res[i] == OK else None for i in range(len(pcms))], res
+
+
+def encode_batch_pcm(lib, enc, frames, num_samples, bytes_per_sample, caps=None):
+    """SRLAMI355X_EncodeBatchPcm: `frames` = one bytes-like object per stream holding interleaved little-endian PCM frames (a
+    WAV data chunk).  -> (rc, [stream bytes or None], [per-stream result codes])"""
+    n = len(frames)
+    fn = lib.lib.SRLAMI355X_EncodeBatchPcm
+    fn.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    fn.restype = C.c_int
+    keep = [np.frombuffer(f, dtype=np.uint8) for f in frames]
+    ptrs = (C.c_void_p * n)(*[k.ctypes.data for k in keep])
+    nsmp = (C.c_uint32 * n)(*[int(x) for x in num_samples])
+    outs = [np.zeros(int(caps[i] if caps else 2 * len(frames[i]) + 4096), dtype=np.uint8) for i in range(n)]
+    data = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+    sizes_in = (C.c_uint32 * n)(*[o.size for o in outs])
+    sizes = (C.c_uint32 * n)()
+    res = (C.c_int * n)()
+    rc = fn(enc, n, ptrs, nsmp, int(bytes_per_sample), data, sizes_in, sizes, res)
+    return rc, [outs[i][:sizes[i]].copy() if res[i] == OK else None for i in range(n)], list(res)
+
