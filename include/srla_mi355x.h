@@ -208,7 +208,7 @@ struct SRLAMI355XStats {
     double   price_ms;           /* srla_price_windows (timed jobs only)                   */
     double   gather_ms;          /* srla_block_offsets + srla_pack_blocks (timed jobs only) */
     double   h2d_ms;             /* host wall time spent enqueueing                        */
-    double   d2h_ms;             /* unused (no copies on the data path)                    */
+    double   history_ms;         /* host wall time inside history mode (parameters whose analysis depends on earlier blocks: window by window) */
     double   pack_ms;            /* host wall time collecting finished jobs                */
     double   total_ms;           /* host wall time inside Encode*                        */
     uint64_t analyzed_samples;   /* sum of item lengths                                  */
@@ -221,7 +221,21 @@ struct SRLAMI355XStats {
     uint64_t num_restarts;       /* times the stream loop went back to a job because of such an override            */
     uint64_t num_inplace_pins;   /* pageable input planes page-locked in place for a call (instead of staged) */
     uint64_t num_inplace_out_pins;  /* pageable output buffers page-locked in place for a call (written by the device directly) */
+    /* Bit-identity with the reference is the contract.  Where a call runs under parameters for which the output is valid and
+     * lossless but NOT guaranteed to be the reference's bytes, SRLAEncoder_SetEncodeParameter says so on stderr, every
+     * Encode* call made under them is counted here and the reasons are OR-ed into nonidentical_reasons (SRLAMI355X_NONIDENTICAL_*). */
+    uint64_t num_nonidentical_calls;
+    uint64_t nonidentical_reasons;
+    uint64_t num_svr_tie_items;     /* SVR refinement: items with an objective comparison inside the libm tolerance (arbitrated on the host) */
+    uint64_t num_history_windows;   /* look-ahead windows encoded in history mode (in the reference's own call order, window by window) */
 };
+/* reasons (SRLAMI355XStats::nonidentical_reasons, SRLAMI355X_NonIdenticalReasons) */
+#define SRLAMI355X_NONIDENTICAL_SVR_HISTORY 1u  /* SVR refinement on and blocks whose analysis depends on the call before them (an odd-length
+                                                 * last window, an odd minimum block, the long-term predictor with blocks of at most 256
+                                                 * samples): the refinement's residual is what such a block inherits in the reference (lpc.c:1047) */
+/* The reasons for which a stream of `num_samples` samples per channel encoded under the handle's current parameters would not be
+ * guaranteed bit-identical to the reference (0: it is); num_samples = 0 asks about the parameters alone. */
+uint32_t SRLAMI355X_NonIdenticalReasons(struct SRLAEncoder *encoder, uint32_t num_samples);
 /* cumulative since Create or the last reset */
 void SRLAMI355X_GetStats(struct SRLAEncoder *encoder, struct SRLAMI355XStats *stats, int reset);
 

@@ -128,7 +128,21 @@ SRLAApiResult SRLAEncoder_SetEncodeParameter(struct SRLAEncoder *encoder, const 
     im->param_generation++;
     im->offset_lshift = 0;
     im->set_parameter = true;
+    /* bit-identity is the contract: parameters under which it cannot be promised are named here, loudly, and every call made
+     * under them is counted (SRLAMI355XStats::num_nonidentical_calls) */
+    im->warned_reasons = 0;
+    if (const uint32_t r = im->nonidentical_reasons(0)) {
+        im->warned_reasons = r;
+        fprintf(stderr, "[srla-mi355x] WARNING: with these parameters the output is valid and lossless but NOT guaranteed bit-identical to the reference: %s\n",
+                Impl::nonidentical_text(r).c_str());
+    }
     return SRLA_APIRESULT_OK;
+}
+
+uint32_t SRLAMI355X_NonIdenticalReasons(struct SRLAEncoder *encoder, uint32_t num_samples)
+{
+    Impl *im = impl_of(encoder);
+    return (im && im->set_parameter) ? im->nonidentical_reasons(num_samples) : 0u;
 }
 
 /* one stream of host samples through encode_streams */
@@ -220,6 +234,13 @@ SRLAApiResult SRLAMI355X_EncodeWindows(struct SRLAEncoder *encoder, const int32_
     const bool search = im->search_enabled();
     const uint32_t window_len = search ? im->par.num_lookahead_samples : im->par.max_num_samples_per_block;
     if (!is_stream_end && (num_samples % window_len) != 0) return SRLA_APIRESULT_INVALID_ARGUMENT;   /* only the stream's end may hold a partial window */
+    if (im->history_regime(search)) {
+        /* an odd minimum block, or LTP with blocks of at most 256 samples: every window's analysis depends on the windows before
+         * it, so a range of windows cannot be encoded on its own */
+        fprintf(stderr, "[srla-mi355x] SRLAMI355X_EncodeWindows: under these parameters the windows of a stream are not independent "
+                        "(history mode); encode the stream with SRLAEncoder_EncodeWhole\n");
+        return SRLA_APIRESULT_INVALID_FORMAT;
+    }
     if (!im->init_device()) return SRLA_APIRESULT_NG;
     StreamCtx st;
     st.host_in = input; st.num_samples = num_samples; st.data = data; st.data_size = data_size; st.with_header = false;

@@ -359,3 +359,179 @@ SRLAApiResult Impl::chain_collect()
     }
     return finish_job(e);
 }
+
+/* ================================================================================================================
+ * History mode (host_impl.h): every window of the stream in the reference's own call order.
+ * ============================================================================================================== */
+
+bool Impl::history_regime(bool search) const
+{
+    if (no_chain) return false;
+    const uint32_t grid = search ? par.min_num_samples_per_block : par.max_num_samples_per_block;
+    if (grid & 1u) return true;                                   /* odd blocks anywhere: lpc.c:260-264 */
+    if (par.ltp_order > 0 && grid <= 256u) return true;           /* blocks shorter than the 263 LTP lags anywhere: lpc.c:371-373 */
+    return false;
+}
+
+/* a new phase: its calls see the buffer (chain_calls[0]) and each other; the pool behind the buffer is theirs */
+void Impl::history_phase_reset()
+{
+    chain_calls.resize(1);
+    chain_pool_used = kHistoryWords;
+    chain_tab.clear();
+    chain_tab_uploaded = 0;
+}
+
+/* folds the calls of job `jobidx` into the buffer: word i <- the last call whose transform was longer than i */
+bool Impl::history_commit(uint32_t jobidx, hipStream_t stream)
+{
+    uint32_t src[17], top = 0;
+    for (uint32_t &v : src) v = 0xFFFFFFFFu;
+    for (size_t j = 1; j < chain_calls.size(); j++) {
+        const ChainCall &c = chain_calls[j];
+        if (c.job != jobidx) continue;
+        for (uint32_t k = 0; k < 17 && (1u << k) <= c.nfft; k++) src[k] = c.dump;
+        top = std::max(top, c.nfft);
+    }
+    if (top == 0) return true;                                    /* a silent / RAW window: no call, the buffer stays */
+    return srla_launch_chain_commit(stream, d_chain_pool.as<double>(), src, top) == 0;
+}
+
+SRLAApiResult Impl::history_window(uint32_t stream, uint32_t pos, uint32_t n, bool search)
+{
+    ChainRun &c = chain;
+    StreamCtx &st = sx[stream];
+    const uint32_t nch = par.num_channels;
+    c.active = true; c.stream = stream; c.tail_start = pos; c.tail_n = n; c.search = search; c.seed_n = 0;
+    /* which blocks are all zero decides which calls exist (srla_encoder.c:766-796): look at the samples */
+    c.tail_smp.resize((size_t)nch * n);
+    for (uint32_t ch = 0; ch < nch; ch++) {
+        int32_t *dst = c.tail_smp.data() + (size_t)ch * n;
+        if (st.pcm) (void)pcm_channel(st.pcm, st.pcm_bytes, nch, ch, pos, n, dst);
+        else if (st.host_in) memcpy(dst, st.host_in[ch] + pos, (size_t)n * 4);
+        else if (hipMemcpy(dst, st.d_in + (size_t)ch * st.d_stride + pos, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) return SRLA_APIRESULT_NG;
+    }
+    const std::function<bool(uint32_t, uint32_t)> silent = [&](uint32_t off, uint32_t len) { return chain_silent(c.tail_smp, c.tail_n, off, len); };
+    Slot &sj = slot[kChainSlot + 1], &e = slot[kChainSlot + 2];
+    chain_slot_defaults(sj); chain_slot_defaults(e);
+    hipStream_t hs = sj.own_stream;
+    /* the host's decisions about the window before this one are not about this one */
+    overrides.erase(overrides.lower_bound(override_key(kChainJobKey, 0)), overrides.end());
+
+    std::vector<uint32_t> lens;
+    if (search) {
+        /* SRLAEncoder_SearchOptimalBlockPartitions (srla_encoder.c:310-424): every candidate, then Dijkstra */
+        history_phase_reset();
+        if (!chain_make_job(sj, pos, n, true, nullptr)) return SRLA_APIRESULT_NG;
+        sj.job.key = 0;
+        chain_append(1, sj.job, silent);
+        if (chain_pool_used * sizeof(double) > d_chain_pool.cap || chain_tab.size() * 4 > d_chain_tab.cap) {
+            fprintf(stderr, "[srla-mi355x] internal error: history pool too small (%llu words)\n", (unsigned long long)chain_pool_used);
+            return SRLA_APIRESULT_NG;
+        }
+        chain_build(1, sj.job, c.cs);
+        for (int attempt = 0;; attempt++) {
+            (void)apply_overrides(sj.job, kChainJobKey + 1);
+            sj.job.uploaded = false;
+            chain_tab_uploaded = 0;
+            if (!prepare_job(sj, false) || !chain_stage_a(sj, 1, c.cs)) return SRLA_APIRESULT_NG;
+            for (int st2 = ST_B; st2 <= ST_D; st2++) if (!run_stage(sj, st2)) return SRLA_APIRESULT_NG;
+            if (hipEventSynchronize(sj.t1[ST_D]) != hipSuccess) return SRLA_APIRESULT_NG;
+            const int m = arbitrate(sj, kChainJobKey + 1);
+            if (m < 0) return SRLA_APIRESULT_NG;
+            if (m == 0) break;
+            if (attempt >= 6) { fprintf(stderr, "[srla-mi355x] internal error: near-tie arbitration of a history-mode window did not settle\n"); return SRLA_APIRESULT_NG; }
+            stats.num_restarts++;
+        }
+        sj.busy = false;
+        if (!history_commit(1, hs)) return SRLA_APIRESULT_NG;
+        const SrlaWindowDesc &wd = sj.job.windows[0];
+        std::vector<SrlaBlockRecord> recs(wd.num_nodes - 1);
+        if (hipMemcpy(recs.data(), sj.d_blocks.as<SrlaBlockRecord>() + wd.block_base, recs.size() * sizeof(SrlaBlockRecord), hipMemcpyDeviceToHost) != hipSuccess)
+            return SRLA_APIRESULT_NG;
+        uint32_t covered = 0;
+        for (const SrlaBlockRecord &r : recs) if (r.valid) { lens.push_back(r.n); covered += r.n; }
+        if (covered != n) { fprintf(stderr, "[srla-mi355x] internal error: a window's partitions cover %u of %u samples\n", covered, n); return SRLA_APIRESULT_NG; }
+    } else lens.push_back(n);
+
+    /* SRLAEncoder_EncodeBlock for every block of the partition (srla_encoder.c:1676-1692): analysed again, where they now stand */
+    history_phase_reset();
+    if (!chain_make_job(e, pos, n, false, &lens)) return SRLA_APIRESULT_NG;
+    chain_append(2, e.job, silent);
+    if (chain_pool_used * sizeof(double) > d_chain_pool.cap || chain_tab.size() * 4 > d_chain_tab.cap) {
+        fprintf(stderr, "[srla-mi355x] internal error: history pool too small (%llu words)\n", (unsigned long long)chain_pool_used);
+        return SRLA_APIRESULT_NG;
+    }
+    chain_build(2, e.job, c.ce);
+    e.emits = true; e.merge_cb = true; e.out_boost = 1;
+    for (int attempt = 0;; attempt++) {
+        (void)apply_overrides(e.job, kChainJobKey + 2);
+        e.job.uploaded = false;
+        chain_tab_uploaded = 0;
+        st.pass_started = false;                                 /* the window goes where the host knows the stream has reached */
+        if (!prepare_job(e, false) || !chain_stage_a(e, 2, c.ce)) return SRLA_APIRESULT_NG;
+        for (int st2 = ST_B; st2 <= ST_E; st2++) if (!run_stage(e, st2)) return SRLA_APIRESULT_NG;
+        if (!wait_job(e)) return SRLA_APIRESULT_NG;
+        if (e.h_info.as<SrlaJobInfo>()->num_tie_items == 0) break;
+        const int m = arbitrate(e, kChainJobKey + 2);
+        if (m < 0) return SRLA_APIRESULT_NG;
+        if (m == 0) break;
+        if (attempt >= 6) { fprintf(stderr, "[srla-mi355x] internal error: near-tie arbitration of a history-mode window did not settle\n"); return SRLA_APIRESULT_NG; }
+        stats.num_restarts++;
+    }
+    if (!history_commit(2, hs)) return SRLA_APIRESULT_NG;
+    stats.num_history_windows++;
+    return finish_job(e);
+}
+
+SRLAApiResult Impl::history_encode(bool search)
+{
+    const auto t0 = Clock::now();
+    const uint32_t minb = par.min_num_samples_per_block, maxb = par.max_num_samples_per_block;
+    const uint32_t window_len = search ? par.num_lookahead_samples : maxb;
+    const uint32_t nv = num_variants(), passes = par.ltp_order > 0 ? 2u : 1u;
+    auto drain = [&]() { for (auto &q : streams) if (q) (void)hipStreamSynchronize(q); if (upload) (void)hipStreamSynchronize(upload); };
+    {
+        /* the pool: the buffer + room for the complete FFT buffer of every call of the larger phase (the search phase: its
+         * candidates include every block a partition can hold); sized once -- growing it would lose the buffer */
+        uint64_t words = 0, calls = 0;
+        auto pow2 = [](uint32_t v) { uint32_t p = 1; while (p < v) p <<= 1; return p; };
+        if (!search) { words = pow2(maxb); calls = 1; }
+        else {
+            const uint32_t nodes = window_len / minb + 1;
+            for (uint32_t i = 0; i < nodes; i++)
+                for (uint32_t j = i + 1; j < nodes; j++) {
+                    uint32_t len = (j - i) * minb;
+                    if (len > maxb) break;
+                    words += pow2(std::min(len, window_len - i * minb)); calls++;
+                }
+        }
+        drain();
+        if (!d_chain_pool.ensure((kHistoryWords + (uint64_t)nv * passes * words + 1024u) * sizeof(double))) return SRLA_APIRESULT_NG;
+        if (!d_chain_tab.ensure(((size_t)calls * nv * SRLA_LTP_LAGS + 1024u) * 4)) return SRLA_APIRESULT_NG;
+    }
+    SRLAApiResult worst = SRLA_APIRESULT_OK;
+    chain.active = false;
+    for (uint32_t i = 0; i < sx.size(); i++) {
+        StreamCtx &st = sx[i];
+        /* a fresh handle: the reference's buffer starts as zero pages (the `srla` tool creates its encoder per file) */
+        if (hipMemsetAsync(d_chain_pool.p, 0, (size_t)kHistoryWords * sizeof(double), streams[1]) != hipSuccess) return SRLA_APIRESULT_NG;
+        chain_calls.clear();
+        ChainCall buffer{};
+        buffer.job = 0xFFFFFFFFu; buffer.nfft = kHistoryWords; buffer.src = -1; buffer.dump = 0;
+        chain_calls.push_back(buffer);
+        for (uint32_t pos = 0; pos < st.num_samples && st.rc == SRLA_APIRESULT_OK; pos += window_len) {
+            const SRLAApiResult rc = history_window(i, pos, std::min(window_len, st.num_samples - pos), search);
+            if (rc == SRLA_APIRESULT_INSUFFICIENT_BUFFER) st.rc = rc;
+            else if (rc != SRLA_APIRESULT_OK) { drain(); for (auto &sl : slot) sl.busy = false; chain.active = false; return rc; }
+        }
+        chain.active = false;
+        if (st.rc != SRLA_APIRESULT_OK) { worst = st.rc; continue; }
+        if (!write_header(st)) return SRLA_APIRESULT_NG;
+    }
+    drain();
+    for (auto &sl : slot) sl.busy = false;
+    if (sx.size() == 1 && sx[0].with_header && sx[0].rc == SRLA_APIRESULT_OK) offset_lshift = sx[0].lshift;
+    stats.history_ms += ms_since(t0);
+    return worst;
+}

@@ -341,6 +341,31 @@ struct Impl {
     bool chain_encode_ad();
     bool chain_encode_e();
     bool chain_search_done();         /* has the search job been priced (so that the encode job can be enqueued without waiting)? */
+
+    /* ---- history mode: every window in the reference's own call order -------------------------------------------
+     * Chain mode covers streams whose ONLY history-dependent window is the last one.  Two parameter regimes make blocks
+     * anywhere in the stream depend on the calls before them:
+     *   an odd minimum block (every odd block inherits its middle word, lpc.c:260-264), and
+     *   the long-term predictor with blocks of at most 256 samples (263 lags copied out of a shorter FFT, lpc.c:371-373).
+     * Such streams are encoded window by window, each window as the reference does it -- search phase (every candidate),
+     * Dijkstra, encode phase (the chosen partition analysed again, srla_encoder.c:1646-1698) -- with the chain-mode
+     * machinery, and the state the reference carries from call to call, its persistent FFT buffer (lpc.c:58,211), is kept
+     * on the device: the first kHistoryWords doubles of the chain pool ARE that buffer as the next phase finds it
+     * (srla_chain_commit folds a phase's calls into it).  chain_calls[0] then stands for "whatever the buffer holds":
+     * a call that reaches back beyond its own phase reads the buffer.  Slow (two small jobs and two host round trips per
+     * window) and exact; the windows of a stream are a dependency chain in these regimes, in the reference as here. */
+    uint32_t chain_tail(uint32_t num_samples, bool search) const;   /* the history-dependent last window outside the history regimes (0: none) */
+    /* bit-identity that cannot be promised (SRLAMI355X_NONIDENTICAL_*): said on stderr, counted in the statistics */
+    uint32_t nonidentical_reasons(uint32_t num_samples) const;
+    void note_nonidentical(uint32_t num_samples);
+    static std::string nonidentical_text(uint32_t reasons);
+    uint32_t warned_reasons = 0;
+    static constexpr uint32_t kHistoryWords = 65536;
+    bool history_regime(bool search) const;
+    void history_phase_reset();
+    bool history_commit(uint32_t jobidx, hipStream_t stream);
+    SRLAApiResult history_window(uint32_t stream, uint32_t pos, uint32_t n, bool search);
+    SRLAApiResult history_encode(bool search);
 };
 
 #endif /* SRLA_HOST_IMPL_H */

@@ -655,6 +655,57 @@ void Impl::classify_buffers(StreamCtx &st)
     }
 }
 
+/* The history-dependent last window of a stream of num_samples samples (0: none) outside the history regimes: an odd-length
+ * one (lpc.c:260-264), or -- LTP on -- one whose last block is shorter than the 263 lags (lpc.c:371-373; with a minimum block
+ * above 256 samples only the window's last block can be that short). */
+uint32_t Impl::chain_tail(uint32_t num_samples, bool search) const
+{
+    const uint32_t window_len = search ? par.num_lookahead_samples : par.max_num_samples_per_block;
+    const uint32_t grid = search ? par.min_num_samples_per_block : par.max_num_samples_per_block;
+    if (no_chain || (window_len % grid) != 0) return 0;
+    const uint32_t tn = num_samples % window_len;
+    if ((tn & 1u) && (grid & 1u) == 0) return tn;
+    if (tn > 0 && par.ltp_order > 0 && grid > 256u && ((tn - 1u) % grid) + 1u <= 256u) return tn;
+    return 0;
+}
+
+/* Why a stream of num_samples samples (0: the parameters alone) would not be guaranteed the reference's bytes (0: it is). */
+uint32_t Impl::nonidentical_reasons(uint32_t num_samples) const
+{
+    uint32_t r = 0;
+    const bool search = search_enabled();
+    if (par.num_svr_filter_learning_iteration > 0) {
+        /* the refinement leaves its residual in the buffer the next history-dependent call inherits from (lpc.c:1047): not modelled */
+        if (history_regime(search)) r |= SRLAMI355X_NONIDENTICAL_SVR_HISTORY;
+        else if (num_samples != 0 && chain_tail(num_samples, search) != 0) r |= SRLAMI355X_NONIDENTICAL_SVR_HISTORY;
+    }
+    return r;
+}
+
+/* counts a call made under such parameters and says so once per handle and reason */
+void Impl::note_nonidentical(uint32_t num_samples)
+{
+    const uint32_t r = nonidentical_reasons(num_samples);
+    if (r == 0) return;
+    stats.num_nonidentical_calls++;
+    stats.nonidentical_reasons |= r;
+    if ((warned_reasons & r) != r) {
+        warned_reasons |= r;
+        fprintf(stderr, "[srla-mi355x] WARNING: output valid and lossless but NOT guaranteed bit-identical to the reference: %s\n",
+                nonidentical_text(r).c_str());
+    }
+}
+
+std::string Impl::nonidentical_text(uint32_t r)
+{
+    std::string t;
+    if (r & SRLAMI355X_NONIDENTICAL_SVR_HISTORY)
+        t += "SVR refinement (--svr-filter-learning-iteration) together with blocks whose analysis depends on the call before them "
+             "(odd block lengths, or the long-term predictor with blocks of at most 256 samples): the reference's refinement leaves its "
+             "residual where those blocks look (lpc.c:1047), which this library does not reproduce";
+    return t;
+}
+
 /* The last valid block of segment k's last window of a priced job: (offset inside the stream, length). */
 static bool last_block_of(Slot &ls, size_t k, uint32_t *off, uint32_t *n)
 {
@@ -681,8 +732,6 @@ SRLAApiResult Impl::encode_streams(bool search)
     };
     if (timeline) (void)hipEventRecord(ev_ref, streams[0]);
     if ((size_t)8 * nst > d_pos.cap) { drain(); if (!d_pos.ensure((size_t)8 * nst)) return SRLA_APIRESULT_NG; }
-    const uint32_t window_len = search ? par.num_lookahead_samples : par.max_num_samples_per_block;
-    const uint32_t grid = search ? par.min_num_samples_per_block : par.max_num_samples_per_block;
     /* page-lock pageable planes / buffers in place for this call (Impl::pin_inplace); dropped again when the call leaves */
     struct PinGuard {
         std::vector<const void *> held;
@@ -690,6 +739,8 @@ SRLAApiResult Impl::encode_streams(bool search)
     } pins;
     const bool want_pins = !force_staging && !pin_too_slow && (pin_inplace == 1 || (pin_inplace < 0 && pool->size() < 6));
     bool need_oracc = false;
+    /* parameters under which blocks anywhere in the stream depend on the calls before them: window by window (host_chain.cpp) */
+    const bool history = history_regime(search);
     for (uint32_t si = 0; si < nst; si++) {
         StreamCtx &st = sx[si];
         classify_buffers(st);
@@ -744,13 +795,13 @@ SRLAApiResult Impl::encode_streams(bool search)
         } else if (st.pcm) {
             /* as for pinned planes below: a short look by the host (the whole stream with SRLA_MI355X_NO_SPECULATION), the
              * device gathers the rest */
-            const uint32_t look = no_speculation ? st.num_samples : std::min<uint32_t>(st.num_samples, 65536u);
+            const uint32_t look = (no_speculation || history) ? st.num_samples : std::min<uint32_t>(st.num_samples, 65536u);
             uint32_t m = 0;
             for (uint32_t ch = 0; ch < nch; ch++) m |= pcm_channel(st.pcm, st.pcm_bytes, nch, ch, 0, look, nullptr);
             st.or_mask = m; st.or_covered = look;
             if (look == st.num_samples) { st.lshift = shift_of(m); st.lshift_final = true; }
             else { st.or_on_device = true; need_oracc = true; }
-        } else if (st.in_pinned && st.cb == nullptr && !no_speculation) {
+        } else if (st.in_pinned && st.cb == nullptr && !no_speculation && !history) {
             /* pinned planes: the host looks at the first 64 Ki samples per channel only; the device gathers the OR of
              * everything it uploads (stage_input) and the guess is checked against that at the end */
             const uint32_t look = std::min<uint32_t>(st.num_samples, 65536u);
@@ -759,7 +810,7 @@ SRLAApiResult Impl::encode_streams(bool search)
             st.or_mask = m; st.or_covered = look;
             if (look == st.num_samples) { st.lshift = shift_of(m); st.lshift_final = true; }
             else { st.or_on_device = true; need_oracc = true; }
-        } else if (st.cb != nullptr || no_speculation) {
+        } else if (st.cb != nullptr || no_speculation || history) {
             /* delivered blocks cannot be taken back: the OR pass runs first */
             const uint32_t chunk = 1u << 20, per_ch = (st.num_samples + chunk - 1) / chunk;
             std::atomic<uint32_t> acc{ 0 };
@@ -773,12 +824,16 @@ SRLAApiResult Impl::encode_streams(bool search)
         /* the history-dependent last window goes through chain mode (host_chain.cpp) once everything before it is out: an
          * odd-length one (lpc.c:260-264), or -- LTP on -- one whose last block is shorter than the 263 lags (lpc.c:371-373;
          * with a minimum block above 256 samples only the window's last block can be that short) */
-        uint32_t chain_n = 0;
-        const uint32_t tn = st.num_samples % window_len;
-        if ((tn & 1u) && (grid & 1u) == 0 && (window_len % grid) == 0 && !no_chain) chain_n = tn;
-        if (tn > 0 && par.ltp_order > 0 && grid > 256u && (window_len % grid) == 0 && ((tn - 1u) % grid) + 1u <= 256u && !no_chain) chain_n = tn;
+        uint32_t chain_n = history ? 0u : chain_tail(st.num_samples, search);
         st.chain_n = chain_n;
         st.body = st.num_samples - chain_n;
+    }
+    for (const StreamCtx &st : sx) if (st.with_header) note_nonidentical(st.num_samples);
+    if (history) {
+        overrides.clear();
+        const SRLAApiResult rc = history_encode(search);
+        stats.total_ms += ms_since(t0);
+        return rc;
     }
     if (need_oracc) {
         if ((size_t)8 * nst > d_oracc.cap) { drain(); if (!d_oracc.ensure((size_t)8 * nst)) return SRLA_APIRESULT_NG; }

@@ -3382,6 +3382,31 @@ __global__ void srla_mask_to_shift(uint32_t *__restrict__ out)
     out[1] = mask ? (uint32_t)(__ffs((int)mask) - 1) : 0u;
 }
 
+/* ---------------------------------------------------------------------- history mode ---- */
+/* The reference's persistent FFT buffer (lpc.c:58,211) as it stands after a phase of calls, kept in the first `top` words
+ * of the chain pool: word i becomes what the LAST call of the phase whose transform was longer than i left there (every call
+ * left its complete buffer at its own place in the pool); words no call of the phase reached keep what they held.
+ * src[k]: pool offset of the buffer of the last call with nfft >= 2^k, i.e. of the owner of the words [2^(k-1), 2^k)
+ * (k = 0: word 0), or 0xFFFFFFFF. */
+struct SrlaCommitTable { uint32_t src[17]; };
+__global__ __launch_bounds__(256) void srla_chain_commit(double *__restrict__ pool, SrlaCommitTable tab, uint32_t top)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= top) return;
+    const uint32_t k = (i == 0) ? 0u : (32u - (uint32_t)__clz((int)i));
+    const uint32_t src = tab.src[k];
+    if (src != 0xFFFFFFFFu) pool[i] = pool[(size_t)src + i];
+}
+
+extern "C" int srla_launch_chain_commit(hipStream_t stream, double *pool, const uint32_t *src17, uint32_t top)
+{
+    SrlaCommitTable tab;
+    for (int k = 0; k < 17; k++) tab.src[k] = src17[k];
+    if (top == 0) return 0;
+    hipLaunchKernelGGL(srla_chain_commit, dim3((top + 255u) / 256u), dim3(256), 0, stream, pool, tab, top);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 /* --------------------------------------------------------------------------- launchers ---- */
 static SrlaLaunchTuning g_tune = { 0u, 0u, 0u };
 extern "C" void srla_set_launch_tuning(const SrlaLaunchTuning *t) { if (t) g_tune = *t; }
