@@ -57,11 +57,13 @@ class Stats(C.Structure):
                 ("num_blocks", C.c_uint64), ("num_raw_blocks", C.c_uint64), ("num_silent_blocks", C.c_uint64),
                 ("num_tie_items", C.c_uint64), ("num_odd_items", C.c_uint64), ("analyze_launches", C.c_uint64),
                 ("analyze_ms", C.c_double), ("price_ms", C.c_double), ("gather_ms", C.c_double),
-                ("h2d_ms", C.c_double), ("d2h_ms", C.c_double), ("pack_ms", C.c_double), ("total_ms", C.c_double),
+                ("h2d_ms", C.c_double), ("history_ms", C.c_double), ("pack_ms", C.c_double), ("total_ms", C.c_double),
                 ("analyzed_samples", C.c_uint64), ("autocorr_ms", C.c_double), ("solve_ms", C.c_double),
                 ("residual_ms", C.c_double), ("timed_jobs", C.c_uint64),
                 ("num_tie_resolved", C.c_uint64), ("num_tie_overrides", C.c_uint64), ("num_restarts", C.c_uint64),
-                ("num_inplace_pins", C.c_uint64), ("num_inplace_out_pins", C.c_uint64)]
+                ("num_inplace_pins", C.c_uint64), ("num_inplace_out_pins", C.c_uint64),
+                ("num_nonidentical_calls", C.c_uint64), ("nonidentical_reasons", C.c_uint64), ("num_svr_tie_items", C.c_uint64),
+                ("num_history_windows", C.c_uint64)]
 
 
 def usable_cpus():

@@ -233,6 +233,9 @@ struct SRLAMI355XStats {
 #define SRLAMI355X_NONIDENTICAL_SVR_HISTORY 1u  /* SVR refinement on and blocks whose analysis depends on the call before them (an odd-length
                                                  * last window, an odd minimum block, the long-term predictor with blocks of at most 256
                                                  * samples): the refinement's residual is what such a block inherits in the reference (lpc.c:1047) */
+#define SRLAMI355X_NONIDENTICAL_LTP_TINY_BUFFER 2u  /* long-term predictor on an encoder created for blocks of at most 256 samples: the
+                                                     * reference's FFT buffer is then shorter than the 263 lags it copies out of it
+                                                     * (lpc.c:371-373 reads beyond the buffer, into the transform's scratch area) */
 /* The reasons for which a stream of `num_samples` samples per channel encoded under the handle's current parameters would not be
  * guaranteed bit-identical to the reference (0: it is); num_samples = 0 asks about the parameters alone. */
 uint32_t SRLAMI355X_NonIdenticalReasons(struct SRLAEncoder *encoder, uint32_t num_samples);

@@ -56,12 +56,14 @@ def planar_ptrs(arr):
 
 
 def cli_setup(num_channels, bits_per_sample, sampling_rate, preset=4, max_block=4096,
-              divisions=1, lookahead_factor=4, ltp_order=0, svr_iterations=0):
+              divisions=1, lookahead_factor=4, ltp_order=0, svr_iterations=0, min_block=None, lookahead=None):
     """(config, parameter) exactly as `srla -e -m -B -V -L -P` builds them
-    (tools/srla_codec/srla_codec.c:91-116)."""
-    cfg = SRLAEncoderConfig(8, max_block >> divisions, max_block, lookahead_factor * max_block, 255)
-    par = SRLAEncodeParameter(num_channels, bits_per_sample, sampling_rate, max_block >> divisions,
-                              max_block, lookahead_factor * max_block, ltp_order, svr_iterations, preset)
+    (tools/srla_codec/srla_codec.c:91-116).  min_block / lookahead: what the API accepts beyond the tool's
+    max >> divisions and factor * max (srla_encoder.c:727-741)."""
+    minb = (max_block >> divisions) if min_block is None else min_block
+    look = lookahead_factor * max_block if lookahead is None else lookahead
+    cfg = SRLAEncoderConfig(8, minb, max_block, look, min(255, max_block))
+    par = SRLAEncodeParameter(num_channels, bits_per_sample, sampling_rate, minb, max_block, look, ltp_order, svr_iterations, preset)
     return cfg, par
 
 

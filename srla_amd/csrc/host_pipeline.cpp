@@ -679,6 +679,13 @@ uint32_t Impl::nonidentical_reasons(uint32_t num_samples) const
         if (history_regime(search)) r |= SRLAMI355X_NONIDENTICAL_SVR_HISTORY;
         else if (num_samples != 0 && chain_tail(num_samples, search) != 0) r |= SRLAMI355X_NONIDENTICAL_SVR_HISTORY;
     }
+    if (par.ltp_order > 0) {
+        /* lpcc->buffer holds RoundUp2Powered(config max block) doubles (lpc.c:211): at most 256 of them => the 263 lags of
+         * lpc.c:371-373 end in the transform's scratch buffer behind it */
+        uint32_t p2 = 1;
+        while (p2 < cfg.max_num_samples_per_block) p2 <<= 1;
+        if (p2 < SRLA_LTP_LAGS) r |= SRLAMI355X_NONIDENTICAL_LTP_TINY_BUFFER;
+    }
     return r;
 }
 
@@ -703,6 +710,12 @@ std::string Impl::nonidentical_text(uint32_t r)
         t += "SVR refinement (--svr-filter-learning-iteration) together with blocks whose analysis depends on the call before them "
              "(odd block lengths, or the long-term predictor with blocks of at most 256 samples): the reference's refinement leaves its "
              "residual where those blocks look (lpc.c:1047), which this library does not reproduce";
+    if (r & SRLAMI355X_NONIDENTICAL_LTP_TINY_BUFFER) {
+        if (!t.empty()) t += "; ";
+        t += "long-term predictor on an encoder created for blocks of at most 256 samples: the reference's FFT buffer is shorter than "
+             "the 263 lags it copies out of it (lpc.c:371-373 reads its transform's scratch memory), which this library does not reproduce "
+             "-- create the encoder with max_num_samples_per_block > 256 and the output is bit-identical";
+    }
     return t;
 }
 

@@ -290,3 +290,43 @@ def reference_encode_fresh(pcm, bits_per_sample=16, sampling_rate=48000, **cli):
                 % (os.path.join(ROOT, "tests"), src, dst))
         subprocess.check_call([sys.executable, "-c", code])
         return np.load(dst)
+
+
+REF_TOOL = os.path.join(ROOT, "oracle", "_ref", "srla_ref")
+
+
+def write_wav(path, pcm, rate, bps):
+    """planar int32 [ch][n] -> a PCMWAVEFORMAT RIFF file (what the reference's tool reads, libs/wav/src/wav.c)"""
+    import struct
+    nch = pcm.shape[0]
+    inter = pcm.T.reshape(-1)
+    if bps == 8:
+        body = (inter + 128).astype(np.uint8).tobytes()
+    elif bps == 16:
+        body = inter.astype("<i2").tobytes()
+    else:
+        u = inter.astype(np.int64) & 0xFFFFFF
+        body = np.stack([u & 0xFF, (u >> 8) & 0xFF, (u >> 16) & 0xFF], axis=1).astype(np.uint8).tobytes()
+    b = bps // 8
+    fmt = struct.pack("<HHIIHH", 1, nch, rate, rate * nch * b, nch * b, bps)
+    chunks = b"fmt " + struct.pack("<I", len(fmt)) + fmt + b"data" + struct.pack("<I", len(body)) + body
+    with open(path, "wb") as f:
+        f.write(b"RIFF" + struct.pack("<I", 4 + len(chunks)) + b"WAVE" + chunks)
+
+
+def reference_tool_encode(pcm, bits_per_sample=16, sampling_rate=48000, preset=4, max_block=4096, divisions=1,
+                          lookahead_factor=4, ltp_order=0, svr_iterations=0):
+    """`srla -e` itself: the reference's own tool (oracle/_ref/srla_ref, `make -C oracle ref_tool`), WAV file in, .srl out.
+    Its encoder's work area is one fresh allocation of zero pages, the behaviour the oracle models for the words the
+    reference reads without having written them."""
+    import tempfile
+    if not os.path.exists(REF_TOOL):
+        subprocess.check_call("make -s ref_tool", cwd=os.path.join(ROOT, "oracle"), shell=True)
+    with tempfile.TemporaryDirectory() as d:
+        wav, srl = os.path.join(d, "in.wav"), os.path.join(d, "out.srl")
+        write_wav(wav, pcm, sampling_rate, bits_per_sample)
+        cmd = [REF_TOOL, "-e", "-m", str(preset), "-B", str(max_block), "-V", str(divisions), "-L", str(lookahead_factor), "-P", str(ltp_order)]
+        if svr_iterations:
+            cmd += ["--svr-filter-learning-iteration", str(svr_iterations)]
+        subprocess.check_call(cmd + [wav, srl], stdout=subprocess.DEVNULL)
+        return np.fromfile(srl, dtype=np.uint8)

@@ -4,8 +4,9 @@
     python tools/gpu_sweep.py [cases] [seed]
 
 Any length, odd ones included (the last window of such a stream is history dependent in the reference and goes
-through the library's chain mode); LTP only with minimum blocks of at least 264 samples (shorter blocks
-anywhere in the stream read stale lags in the reference, DESIGN.md 5.2).  Prints one line per mismatch and a summary;
+through the library's chain mode); LTP with any minimum block and odd block sizes (history mode: every
+window in the reference's call order).  Left out: what the library itself names as not bit-identical (SVR together with
+history-dependent blocks, LTP with a maximum block of at most 256 samples).  Prints one line per mismatch and a summary;
 exit status 1 on any mismatch."""
 import os
 import random
@@ -34,8 +35,14 @@ def cases(count, seed, max_samples=6_000_000):
         min_block = max_block >> divisions
         if min_block < 64:
             continue
-        if ltp and min_block < 264:
-            ltp = 0                                      # shorter blocks + LTP: the reference reads stale lags
+        if ltp and max_block <= 256:
+            ltp = 0                                      # the reference's FFT buffer itself is shorter than the lags
+        # odd block sizes in one case out of eight (a generator of its own: the other cases stay what they were)
+        rnd3 = random.Random(seed * 104729 + case)
+        odd_blocks = rnd3.random() < 0.125 and max_block >= 512
+        if odd_blocks:
+            max_block = rnd3.choice([max_block - 1, max_block - 24, 3 * (max_block >> 2) + (1 << divisions)])
+            min_block = max_block >> divisions
         order = [0, 8, 16, 32, 64, 128, 255][preset]
         if order > min_block:
             continue
@@ -56,7 +63,8 @@ def cases(count, seed, max_samples=6_000_000):
         # SVR refinement in one case out of eight (a generator of its own: the other cases stay what they were); even
         # lengths only, and short ones: the oracle's covariance matrices take their time
         rnd2 = random.Random(seed * 7919 + case)
-        if rnd2.random() < 0.125 and preset > 0:
+        history = (min_block & 1) or (ltp and min_block <= 256)
+        if rnd2.random() < 0.125 and preset > 0 and not history:
             cli["svr_iterations"] = rnd2.choice([1, 2, 3, 5])
             n = min(n, 200_000 // nch)
             n -= n % 2
