@@ -63,7 +63,7 @@ class Stats(C.Structure):
                 ("num_tie_resolved", C.c_uint64), ("num_tie_overrides", C.c_uint64), ("num_restarts", C.c_uint64),
                 ("num_inplace_pins", C.c_uint64), ("num_inplace_out_pins", C.c_uint64),
                 ("num_nonidentical_calls", C.c_uint64), ("nonidentical_reasons", C.c_uint64), ("num_svr_tie_items", C.c_uint64),
-                ("num_history_windows", C.c_uint64)]
+                ("num_history_windows", C.c_uint64), ("pitch_ms", C.c_double)]
 
 
 def usable_cpus():
@@ -139,6 +139,66 @@ def cpu_baseline(pcm, cli, seconds, rate, bps=16):
                       (n / rate, n, clip.shape[0], "AVX2 build of the reference, EncodeWhole in memory" if kind == "reference"
                        else "oracle/srla_oracle.c, scalar C"),
             "bytes": int(out.size), "all_cores": all_cores}
+
+
+# stage of a job -> (Stats field with its HIP-event time, "timed jobs only"?, kernels of the stage as rocprofv3 names them)
+STAGES = (
+    ("srla_autocorr",      "autocorr_ms", True,  ("srla_autocorr",), sum),
+    ("srla_pitch_solve",   "pitch_ms",    True,  ("srla_pitch_solve",), sum),
+    ("srla_lpc_solve",     "solve_ms",    True,  ("srla_lpc_solve_regs", "srla_lpc_recursion", "srla_order_select", "srla_lpc_quantize", "srla_svr_refine"), sum),
+    ("srla_residual_cost", "residual_ms", False, ("srla_residual_cost<", "srla_residual_cost_big"), max),   # one block-length class per job
+    ("srla_price_windows", "price_ms",    True,  ("srla_price_windows",), sum),
+    ("srla_pack_blocks",   "gather_ms",   True,  ("srla_block_offsets", "srla_pack_blocks", "srla_stream_out"), sum),
+)
+PMC_JOB_INSTANTS = 4194304.0      # a full job of the PMC command (tools/collect_profiles_r03.sh: two jobs of 4 Mi sample instants)
+
+
+def roofline_object(st, config, launches, instants_per_launch, algo_bytes, end_to_end_gbs, peak=8000.0):
+    """The roofline object of the JSON line.  Every stage of a job is priced against the same contract -- SURVEY 8d's 16 B per
+    stereo sample instant x the instants one job (= one launch of every analysis kernel) covers, over the stage's average
+    duration per job measured with HIP events attached to the dispatches inside the timed region (srla_residual_cost on every
+    job, the other stages on one job in four: each start event costs stream time).  `kernel` is the stage with the LONGEST
+    measured duration per job; counters (HBM traffic, VALU / LDS utilisation) come from the committed rocprofv3 PMC passes
+    (profiles/pmc_summary.json), summed over the kernels of the stage and scaled to this run's instants per launch."""
+    timed = max(1, st.timed_jobs)
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_summary.json"))).get(config, {})
+    except Exception:
+        pmc = {}
+    stages = {}
+    for name, field, timed_only, kernels, combine in STAGES:
+        ms = getattr(st, field) / (timed if timed_only else launches)
+        if ms <= 0:
+            continue
+        gbs = algo_bytes / (ms * 1e-3) / 1e9
+        e = {"ms_per_job": round(ms, 4), "achieved": round(gbs, 2), "frac": round(gbs / peak, 6), "traffic": None}
+        ents = [(k, v) for k, v in pmc.items() if any(k.startswith(p) for p in kernels)]
+        # one launch per FFT-size class / pack kernel and job: the stage's traffic is the sum over its kernels' full-job launches
+        # (srla_residual_cost: one block-length class per job, so the largest)
+        if ents and all("hbm_bytes_per_launch" in v for _, v in ents):
+            e["traffic"] = int(combine([v["hbm_bytes_per_launch"] for _, v in ents]) * instants_per_launch / PMC_JOB_INSTANTS)
+            e["traffic_over_algorithmic"] = round(e["traffic"] / algo_bytes, 2)
+        if ents:
+            big = max(ents, key=lambda kv: kv[1].get("avg_duration_us", 0.0))[1]
+            for key in ("valu_util", "lds_util", "lds_bank_conflict_frac", "wait_frac", "fp64_inst_frac"):
+                if big.get(key) is not None:
+                    e[key] = big[key]
+        stages[name] = e
+    analysis = [k for k in ("srla_autocorr", "srla_pitch_solve", "srla_lpc_solve", "srla_residual_cost") if k in stages]
+    dominant = max(analysis, key=lambda k: stages[k]["ms_per_job"]) if analysis else None
+    d = stages.get(dominant, {"ms_per_job": 0.0, "achieved": 0.0, "frac": 0.0, "traffic": None})
+    roof = {"bound": "hbm", "achieved": d["achieved"], "peak": peak, "unit": "GB/s", "frac": d["frac"], "traffic": d["traffic"],
+            "kernel": dominant, "avg_launch_ms": d["ms_per_job"],
+            "launches": int(st.analyze_launches), "algorithmic_bytes_per_launch": int(algo_bytes),
+            "items_per_launch": int(st.num_items / launches),
+            "stages": stages,
+            # the whole path against the same contract: algorithmic bytes of everything one rank encoded / its wall time
+            "end_to_end": {"achieved": round(end_to_end_gbs, 2), "frac": round(end_to_end_gbs / peak, 6)},
+            "pmc_source": "profiles/pmc_summary.json[%s] (rocprofv3 --pmc, separate passes)" % config if pmc else None}
+    for key in ("valu_util", "fp64_inst_frac"):
+        if key in d:
+            roof[key] = d[key]
+    return roof
 
 
 def parse_args(argv=None):
@@ -328,10 +388,18 @@ def main(argv=None):
         step()
     barrier()
     elapsed = time.perf_counter() - t0
+    rank_ms = None
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if shared_gpu else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # every rank's own time inside the library per step and how its buffers reached the device (for the N > 1 line)
+        L.SRLAMI355X_GetStats(enc, C.byref(st), 0)
+        mine = torch.tensor([st.total_ms / max(1, args.steps), float(st.num_inplace_pins > 0), float(st.num_inplace_out_pins > 0)],
+                            dtype=torch.float64, device="cpu" if shared_gpu else "cuda")
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        rank_ms = [[float(x) for x in r.cpu()] for r in allr]
     L.SRLAMI355X_GetStats(enc, C.byref(st), 0)
     streams = [outs[f][:out_sizes[f]].copy() for f in range(files)]
 
@@ -342,33 +410,11 @@ def main(argv=None):
         total_instants = float(n) * files * args.steps * world
         value = total_instants / elapsed / 1e6
         launches = max(1, st.analyze_launches)          # one launch of srla_residual_cost per job
-        # HIP events attached by the library to the kernel dispatches, on the stream each kernel runs on, inside the timed
-        # region.  srla_residual_cost is timed on every job, the other stages on one job in four (each start event costs
-        # stream time); srla_autocorr is one launch per FFT-size class and pass.
         timed = max(1, st.timed_jobs)
-        per_job = {"srla_autocorr": st.autocorr_ms / timed, "srla_lpc_solve": st.solve_ms / timed,
-                   "srla_residual_cost": st.residual_ms / launches}
-        dominant = "srla_residual_cost"
-        avg_launch_ms = per_job[dominant]
         instants_per_launch = float(n) * files * args.steps / launches
         algo_bytes = 8.0 * nch * instants_per_launch            # 8 B per channel-sample
-        achieved = algo_bytes / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
-        roof = {"bound": "hbm", "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(achieved / 8000.0, 6), "traffic": None, "kernel": dominant, "avg_launch_ms": round(avg_launch_ms, 4),
-                "per_job_stage_ms": {k: round(v, 4) for k, v in per_job.items()},
-                "launches": int(st.analyze_launches), "algorithmic_bytes_per_launch": int(algo_bytes),
-                "items_per_launch": int(st.num_items / launches)}
-        try:
-            # measured with rocprofv3 --pmc in separate passes (tools/summarize_r02.py), committed under profiles/
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_summary.json")))
-            ent = pmc.get(args.config, {}).get(dominant)
-            if ent:
-                roof["traffic"] = int(ent["hbm_bytes_per_instant"] * instants_per_launch)
-                roof["valu_util"] = ent["valu_util"]
-                roof["fp64_inst_frac"] = ent.get("fp64_inst_frac")
-                roof["pmc_source"] = ent["source"]
-        except Exception:
-            pass
+        roof = roofline_object(st, args.config, launches, instants_per_launch, algo_bytes,
+                               8.0 * nch * total_instants / world / elapsed / 1e9)
         total_out = sum(int(s.size) for s in streams)
         line = dict(base_line)
         line.update({
@@ -391,6 +437,10 @@ def main(argv=None):
                                   "enqueue_host": round(st.h2d_ms / args.steps, 3), "collect_host": round(st.pack_ms / args.steps, 3),
                                   "total_host": round(st.total_ms / args.steps, 3)},
             "host_cores": os.cpu_count(), "host_cpu_quota": usable_cpus(), "host_pool_threads": pack_threads, "numa_local_cpus": numa_cpus,
+            "per_rank": None if rank_ms is None else {
+                "encode_ms_per_step_min": round(min(r[0] for r in rank_ms), 3), "encode_ms_per_step_max": round(max(r[0] for r in rank_ms), 3),
+                "ranks_input_locked_in_place": int(sum(r[1] for r in rank_ms)), "ranks_output_locked_in_place": int(sum(r[2] for r in rank_ms)),
+                "host_pool_threads_per_rank": pack_threads},
             "tie_items": int(st.num_tie_items), "tie_resolved": int(st.num_tie_resolved), "tie_overrides": int(st.num_tie_overrides),
             # how the pageable buffers reached the device: staged through pinned buffers by the pool threads, or -- when the
             # ranks' share of the CPU quota is too small for that -- page-locked in place for the call and read by DMA
@@ -419,6 +469,28 @@ def main(argv=None):
             line["device_resident"] = {"value": round(n / dt / 1e6, 3), "unit": "Msamples/s", "ms_per_call": round(1e3 * dt, 3),
                                        "same_bytes": bool(np.array_equal(out_t.numpy()[:dsz.value], streams[0])),
                                        "note": "SRLAMI355X_EncodeWholeDevice: samples resident in HBM, pinned output buffer; median of %d calls" % reps}
+        if world == 1 and files == 1:
+            # SURVEY 8d's own input length (60 s; and 10 s) through the same unchanged SRLAEncoder_EncodeWhole, pageable host
+            # memory to pageable host memory: short streams cannot hide the pipeline's fill and drain.  Beside `value`, never it.
+            for secs in (60, 10):
+                m = min(n, secs * rate)
+                if m >= n:
+                    continue
+                clip = np.ascontiguousarray(pcms[0][:, :m])
+                cp = capi.planar_ptrs(clip)
+                sz = C.c_uint32(0)
+                times = []
+                for k in range(23):
+                    t1 = time.perf_counter()
+                    rc = L.SRLAEncoder_EncodeWhole(enc, cp, m, outs[0].ctypes.data_as(C.c_void_p), cap, C.byref(sz), None)
+                    if rc != capi.OK:
+                        raise SystemExit("SRLAEncoder_EncodeWhole (%d s) -> %d" % (secs, rc))
+                    if k >= 3:
+                        times.append(time.perf_counter() - t1)
+                dt = sorted(times)[len(times) // 2]
+                line["stream_%ds" % secs] = {"value": round(m / dt / 1e6, 3), "unit": "Msamples/s", "ms_per_call": round(1e3 * dt, 3),
+                                             "lossless_roundtrip": bool((helpers.oracle_decode(outs[0][:sz.value].copy()) == clip).all()),
+                                             "note": "one %d s stream per SRLAEncoder_EncodeWhole call, pageable -> pageable; median of %d calls" % (secs, len(times))}
         if not args.no_cpu_baseline and world == 1:        # rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline(pcms[0], cli, args.cpu_seconds, rate, bps)
             line["speedup_vs_cpu_1core"] = round(value / line["cpu_baseline"]["value"], 2)

@@ -228,6 +228,7 @@ struct SRLAMI355XStats {
     uint64_t nonidentical_reasons;
     uint64_t num_svr_tie_items;     /* SVR refinement: items with an objective comparison inside the libm tolerance (arbitrated on the host) */
     uint64_t num_history_windows;   /* look-ahead windows encoded in history mode (in the reference's own call order, window by window) */
+    double   pitch_ms;              /* srla_pitch_solve, timed jobs only (jobs whose stage A runs in two parts; otherwise inside autocorr_ms) */
 };
 /* reasons (SRLAMI355XStats::nonidentical_reasons, SRLAMI355X_NonIdenticalReasons) */
 #define SRLAMI355X_NONIDENTICAL_SVR_HISTORY 1u  /* SVR refinement on and blocks whose analysis depends on the call before them (an odd-length

@@ -44,6 +44,18 @@ namespace fs = std::filesystem;
 
 namespace {
 
+/* file names and error texts inside the manifest's JSON strings */
+std::string json_escape(const std::string &in)
+{
+    std::string out;
+    for (unsigned char c : in) {
+        if (c == '"' || c == '\\') { out += '\\'; out += (char)c; }
+        else if (c < 0x20) { char b[8]; snprintf(b, sizeof(b), "\\u%04x", c); out += b; }
+        else out += (char)c;
+    }
+    return out;
+}
+
 /* ---- SHA-256 (FIPS 180-4), for the manifest ------------------------------------------------------------- */
 struct Sha256 {
     uint32_t h[8]; uint64_t len = 0; uint8_t buf[64]; size_t fill = 0;
@@ -383,6 +395,7 @@ int main(int argc, char **argv)
     std::vector<Entry> manifest;
     std::mutex manifest_m;
     std::vector<std::thread> writers;
+    std::atomic<int> write_failures{ 0 };        /* feeds the exit status like every other failure */
     for (unsigned t = 0; t < o.writers; t++)
         writers.emplace_back([&] {
             std::unique_ptr<Encoded> e;
@@ -396,8 +409,9 @@ int main(int argc, char **argv)
                     fs::create_directories(out.parent_path(), ec);
                     FILE *fp = fopen(out.string().c_str(), "wb");
                     if (!fp || fwrite(e->data, 1, e->size, fp) != e->size) en.error = "cannot write " + out.string();
-                    if (fp) fclose(fp);
-                    en.out_bytes = e->size;
+                    if (fp && fclose(fp) != 0 && en.error.empty()) en.error = "cannot write " + out.string();
+                    if (!en.error.empty()) { write_failures.fetch_add(1); if (fp) fs::remove(out, ec); }   /* no partial .srl left behind */
+                    else en.out_bytes = e->size;
                     if (o.sha) { Sha256 s; s.update(e->data, e->size); en.sha = s.hex(); }
                 }
                 const int64_t bytes = (int64_t)e->pcm->nch * e->pcm->n * 4;
@@ -526,8 +540,8 @@ int main(int argc, char **argv)
             fprintf(fp, "{\"rank\": %d, \"world\": %d, \"seconds\": %.6f, \"samples\": %llu, \"files\": [\n", o.rank, o.world, dt, (unsigned long long)tsmp);
             for (size_t i = 0; i < manifest.size(); i++) {
                 const Entry &e = manifest[i];
-                fprintf(fp, "  {\"name\": \"%s\", \"samples\": %llu, \"in_bytes\": %llu, \"bytes\": %u, \"sha256\": \"%s\", \"error\": \"%s\"}%s\n", e.rel.c_str(),
-                        (unsigned long long)e.samples, (unsigned long long)e.in_bytes, e.out_bytes, e.sha.c_str(), e.error.c_str(), i + 1 < manifest.size() ? "," : "");
+                fprintf(fp, "  {\"name\": \"%s\", \"samples\": %llu, \"in_bytes\": %llu, \"bytes\": %u, \"sha256\": \"%s\", \"error\": \"%s\"}%s\n", json_escape(e.rel).c_str(),
+                        (unsigned long long)e.samples, (unsigned long long)e.in_bytes, e.out_bytes, e.sha.c_str(), json_escape(e.error).c_str(), i + 1 < manifest.size() ? "," : "");
             }
             fprintf(fp, "]}\n");
             fclose(fp);
@@ -536,5 +550,5 @@ int main(int argc, char **argv)
     /* Everything is on disk.  Unpinning a few GB of buffers and tearing the device context down takes a quarter of a second
      * that buys nothing at the end of a process: the operating system releases it all. */
     fflush(stdout); fflush(stderr);
-    _exit(failures ? 1 : 0);
+    _exit((failures || write_failures.load()) ? 1 : 0);
 }

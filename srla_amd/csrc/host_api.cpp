@@ -294,7 +294,11 @@ SRLAApiResult SRLAMI355X_EncodeBatchPcm(struct SRLAEncoder *encoder, uint32_t nu
     for (uint32_t i = 0; i < num_streams && dma; i++) {
         hipPointerAttribute_t at;
         memset(&at, 0, sizeof(at));
-        if (hipPointerGetAttributes(&at, frames[i]) == hipSuccess && at.type == hipMemoryTypeHost) continue;
+        if (hipPointerGetAttributes(&at, frames[i]) == hipSuccess && at.type == hipMemoryTypeHost) {
+            /* locked by another handle's call (the registry)?  keep it locked for this one too */
+            if (const void *key = host_pin_addref(frames[i])) pins.held.push_back(key);
+            continue;
+        }
         (void)hipGetLastError();
         if (host_pin_acquire(frames[i], (size_t)num_samples[i] * nch * bytes_per_sample, nullptr)) pins.held.push_back(frames[i]);
         else dma = false;
@@ -398,7 +402,8 @@ SRLAApiResult SRLAMI355X_ProbeBlock(struct SRLAEncoder *encoder, const int32_t *
     st.lshift = im->offset_lshift; st.lshift_final = true;
     im->sx.clear();
     im->sx.push_back(st);
-    im->classify_buffers(im->sx[0]);
+    struct Pins { std::vector<const void *> held; ~Pins() { for (const void *p : held) host_pin_release(p); } } pins;
+    im->classify_buffers(im->sx[0], pins.held);
     im->overrides.clear();
     Slot &s = im->slot[0];
     JobPlan plan;

@@ -284,7 +284,7 @@ struct Impl {
     /* The body shared by EncodeWhole, EncodeWholeDevice, EncodeBatch and the block calls: encodes the streams in `sx`. */
     SRLAApiResult encode_streams(bool search);
     /* classifies the stream's buffers (pinned? device memory?) */
-    void classify_buffers(StreamCtx &st);
+    void classify_buffers(StreamCtx &st, std::vector<const void *> &held);
 
     /* ---- chain mode: the odd-length tail window ------------------------------------------------------------
      * The reference's Welch window never writes the middle word of an odd-length block (lpc.c:260-264), so that

@@ -499,7 +499,7 @@ bool Impl::wait_job(Slot &s)
             if (!s.timed) continue;
             if (hipEventElapsedTime(&t, s.t0[ST_A], s.ev_a1) == hipSuccess) stats.autocorr_ms += t;
             if (hipEventElapsedTime(&t, s.ev_a0, s.t1[ST_A]) == hipSuccess) stats.autocorr_ms += t;
-            if (hipEventElapsedTime(&t, s.ev_p0, s.ev_p) == hipSuccess) stats.solve_ms += t;
+            if (hipEventElapsedTime(&t, s.ev_p0, s.ev_p) == hipSuccess) stats.pitch_ms += t;
             continue;
         }
         if ((s.timed || (timing && st == ST_C)) && hipEventElapsedTime(&t, s.t0[st], s.t1[st]) == hipSuccess) *acc[st] += t;
@@ -518,7 +518,7 @@ bool Impl::wait_job(Slot &s)
         }
         tl_printf("%s\n", line);
     }
-    stats.analyze_ms = stats.autocorr_ms + stats.solve_ms + stats.residual_ms;
+    stats.analyze_ms = stats.autocorr_ms + stats.pitch_ms + stats.solve_ms + stats.residual_ms;
     s.busy = false;
     return true;
 }
@@ -627,16 +627,22 @@ bool Impl::write_header(StreamCtx &st)
     return true;
 }
 
-void Impl::classify_buffers(StreamCtx &st)
+void Impl::classify_buffers(StreamCtx &st, std::vector<const void *> &held)
 {
+    /* memory that another handle's call locked in place (the process-wide registry of host_support.cpp) stays locked only as
+     * long as somebody holds a reference: take one for this call before enqueueing DMA on it */
+    auto keep = [&](const void *p) { if (const void *key = host_pin_addref(p)) held.push_back(key); };
     st.in_pinned = false;
     if (st.host_in && !force_staging) {
         st.in_pinned = true;
+        const size_t before = held.size();
         for (uint32_t ch = 0; ch < par.num_channels && st.in_pinned; ch++) {
             hipPointerAttribute_t at;
             memset(&at, 0, sizeof(at));
             if (hipPointerGetAttributes(&at, st.host_in[ch]) != hipSuccess || at.type != hipMemoryTypeHost) { st.in_pinned = false; (void)hipGetLastError(); }
+            else keep(st.host_in[ch]);
         }
+        if (!st.in_pinned) while (held.size() > before) { host_pin_release(held.back()); held.pop_back(); }
     }
     /* can the device store into the stream's buffer (pinned / registered host memory, or device memory)? */
     st.out_direct = nullptr;
@@ -645,9 +651,10 @@ void Impl::classify_buffers(StreamCtx &st)
         hipPointerAttribute_t at;
         memset(&at, 0, sizeof(at));
         const hipError_t pe = hipPointerGetAttributes(&at, st.data);
-        if (pe == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer != nullptr && !force_staging)
+        if (pe == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer != nullptr && !force_staging) {
             st.out_direct = static_cast<uint8_t *>(at.devicePointer);
-        else if (pe == hipSuccess && at.type == hipMemoryTypeDevice) {
+            keep(st.data);
+        } else if (pe == hipSuccess && at.type == hipMemoryTypeDevice) {
             /* the caller wants the stream in device memory: same path, only the header needs a copy */
             st.out_direct = st.data;
             st.out_in_hbm = true;
@@ -756,7 +763,7 @@ SRLAApiResult Impl::encode_streams(bool search)
     const bool history = history_regime(search);
     for (uint32_t si = 0; si < nst; si++) {
         StreamCtx &st = sx[si];
-        classify_buffers(st);
+        classify_buffers(st, pins.held);
         /* (streams of less than a few MB are not worth a registration: staging them costs microseconds) */
         const bool worth_pinning = (uint64_t)st.num_samples * nch * 4u >= (4u << 20);
         if (want_pins && worth_pinning && st.host_in && !st.in_pinned) {
@@ -975,7 +982,7 @@ SRLAApiResult Impl::encode_streams(bool search)
         }
         const SRLAApiResult rc = finish_job(s);
         if (rc != SRLA_APIRESULT_OK && (single || rc != SRLA_APIRESULT_INSUFFICIENT_BUFFER)) {
-            if (rc == SRLA_APIRESULT_INSUFFICIENT_BUFFER && sx[0].lshift_spec) { drain(); break; }   /* perhaps only because the shift was guessed wrong: see below */
+            if (rc == SRLA_APIRESULT_INSUFFICIENT_BUFFER && sx[0].lshift_spec) { drain(); sx[0].or_dev_end = 0; /* not every job was staged: the device's OR is partial, the host looks at the whole stream */ break; }   /* perhaps only because the shift was guessed wrong: see below */
             return fail(rc);
         }
         if (!single) {
@@ -1045,10 +1052,18 @@ SRLAApiResult Impl::encode_streams(bool search)
                 StreamCtx again = saved[i];
                 again.lshift = true_shift; again.lshift_final = true;
                 sx.push_back(again);
-                (void)encode_streams(search);
+                /* the nested call is this stream's alone: it must not count as a call of its own in the statistics, nor leave
+                 * its shift in the handle as if the whole call had been a single stream */
+                const uint32_t handle_lshift = offset_lshift;
+                const double total_before = stats.total_ms;
+                const SRLAApiResult nrc = encode_streams(search);
                 StreamCtx result = sx[0];
                 sx.swap(saved);
                 sx[i] = result;
+                stats.total_ms = total_before;
+                if (!single) offset_lshift = handle_lshift;
+                if (nrc != SRLA_APIRESULT_OK && nrc != SRLA_APIRESULT_INSUFFICIENT_BUFFER) return fail(nrc);   /* launch / allocation / HIP error */
+                if (nrc != SRLA_APIRESULT_OK && sx[i].rc == SRLA_APIRESULT_OK) sx[i].rc = nrc;
                 if (sx[i].rc != SRLA_APIRESULT_OK) worst = sx[i].rc;
                 continue;               /* the nested call wrote the header */
             }

@@ -151,6 +151,18 @@ bool host_pin_acquire(const void *p, size_t bytes, double *us_per_mb)
     return true;
 }
 
+const void *host_pin_addref(const void *p)
+{
+    std::lock_guard<std::mutex> lock(g_pin_mutex);
+    auto it = g_pins.upper_bound(p);
+    if (it == g_pins.begin()) return nullptr;
+    --it;
+    const char *base = static_cast<const char *>(it->first);
+    if (static_cast<const char *>(p) >= base + it->second.bytes) return nullptr;
+    it->second.refs++;
+    return it->first;
+}
+
 void host_pin_release(const void *p)
 {
     std::lock_guard<std::mutex> lock(g_pin_mutex);

@@ -72,6 +72,10 @@ struct PinBuf {
  * counted: two handles working on the same buffer at the same time share one registration, and it is dropped when the
  * last of them is done.  acquire() fails (false) where registration does -- the caller then stages as usual. */
 bool host_pin_acquire(const void *p, size_t bytes, double *us_per_mb);
+/* A pointer that HIP reports as page-locked host memory may lie in a range THIS registry locked for another handle's call:
+ * takes a reference on that registration (so it outlives the other call) and returns its key for host_pin_release; nullptr
+ * when the memory is not the registry's (the caller's own hipHostMalloc / hipHostRegister: theirs to keep alive). */
+const void *host_pin_addref(const void *p);
 void host_pin_release(const void *p);
 
 /* staging copies (host_support.cpp): return the OR of the samples they move */

@@ -45,19 +45,40 @@ def offset_lshift_of(mask):
     return sh
 
 
+_host_group = None
+
+
+def host_group(group=None):
+    """The process group for the two host-side exchanges (a single integer and the finished bytes).  They are CPU objects:
+    on a job whose default backend is nccl (= RCCL, device tensors only, no bitwise reductions) a gloo group over the same
+    ranks is created once -- collectively, by every rank's first call -- and reused."""
+    global _host_group
+    import torch.distributed as dist
+    if group is not None:
+        return group
+    if dist.get_backend() != "nccl":
+        return None
+    if _host_group is None:
+        _host_group = dist.new_group(backend="gloo")
+    return _host_group
+
+
 def encode_stream_sharded(encode_range, pcm, header_fn, window_len, rank=0, world=1, group=None):
     """encode_range(range_pcm, offset_lshift, is_stream_end) -> uint8 array (blocks of the range);
-    header_fn(offset_lshift) -> 30 header bytes.  Returns the complete stream on rank 0, None elsewhere."""
+    header_fn(offset_lshift) or header_fn(offset_lshift, num_samples) -> 30 header bytes.  Returns the complete stream on
+    rank 0, None elsewhere."""
     n = pcm.shape[1]
     first, count = shard_ranges(n, window_len, world)[rank]
     mine = np.ascontiguousarray(pcm[:, first:first + count])
     mask = int(np.bitwise_or.reduce(mine.astype(np.int64).ravel() & 0xFFFFFFFF)) if count else 0
     if world > 1:
-        import torch
         import torch.distributed as dist
-        t = torch.tensor([mask], dtype=torch.int64)
-        dist.all_reduce(t, op=dist.ReduceOp.BOR, group=group)
-        mask = int(t.item())
+        group = host_group(group)
+        masks = [None] * world
+        dist.all_gather_object(masks, mask, group=group)       # one integer per rank, OR-ed on the host
+        mask = 0
+        for m in masks:
+            mask |= int(m)
     shift = offset_lshift_of(mask)
     blocks = encode_range(mine, shift, first + count == n) if count else np.zeros(0, np.uint8)
     if world > 1:
@@ -69,7 +90,10 @@ def encode_stream_sharded(encode_range, pcm, header_fn, window_len, rank=0, worl
         body = b"".join(parts)
     else:
         body = np.ascontiguousarray(blocks, dtype=np.uint8).tobytes()
-    return np.frombuffer(bytes(header_fn(shift)) + body, dtype=np.uint8).copy()
+    import inspect
+    takes_length = len(inspect.signature(header_fn).parameters) >= 2
+    hdr = header_fn(shift, n) if takes_length else header_fn(shift)
+    return np.frombuffer(bytes(hdr) + body, dtype=np.uint8).copy()
 
 
 class WindowEncoder:
@@ -98,7 +122,12 @@ class WindowEncoder:
             raise RuntimeError("SRLAMI355X_EncodeWindows -> %d" % rc)
         return buf[:out.value].copy()
 
-    def header(self, shift):
+    def header(self, shift, num_samples=None):
+        """The 30 header bytes of a stream of `num_samples` samples per channel (default: self.num_samples)."""
+        if num_samples is not None:
+            self.num_samples = int(num_samples)
+        if self.num_samples <= 0:
+            raise ValueError("WindowEncoder.header: the stream's length (num_samples) is needed")
         hdr = capi.SRLAHeader(10, 18, self.par.num_channels, self.num_samples, self.par.sampling_rate, self.par.bits_per_sample,
                               shift, self.par.max_num_samples_per_block, self.par.preset)
         buf = np.zeros(capi.HEADER_SIZE, np.uint8)
