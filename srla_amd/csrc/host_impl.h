@@ -90,7 +90,7 @@ struct Job {
     bool keep_residuals = false;
     uint64_t analyzed_samples = 0;
     std::vector<SrlaAutocorrItem> class_index; /* the items grouped by FFT-size class (srla_autocorr launches per class) */
-    uint32_t class_first[6] = {}, class_count[6] = {};   /* N' <= 1024, 2048, 4096, 8192, 16384, 32768 */
+    uint32_t class_first[7] = {}, class_count[7] = {};   /* N' < 1024, 2048, 4096, 8192, 16384, 32768; N' = 1024 */
     std::vector<uint32_t> big_items;  /* items of more than 8192 samples (srla_residual_cost_big) */
     uint32_t big_max_n = 0;
     uint64_t key = 0;                 /* geometry signature: equal keys => identical descriptor tables */
@@ -174,6 +174,8 @@ struct Impl {
      * 0 / 1: never / always (SRLA_MI355X_PIN_INPLACE) */
     int pin_inplace = -1;
     bool pin_too_slow = false;          /* registration measured slower than staging would be (no huge pages): not tried again */
+    bool wave_fft = false;              /* SRLA_MI355X_WAVE_FFT=1: 1024- to 8192-point items on srla_autocorr_w (register-resident transform, autocorr_wave.hip)
+                                         * instead of srla_autocorr: bit-identical, measured slower -- an option, not the default */
     bool split_ltp_stage = true;        /* SRLA_MI355X_NO_LTP_SKEW: stage A of LTP jobs in one piece on W, as before */
     bool keep_residuals_always = true;  /* false with SRLA_MI355X_RECOMPUTE_RESIDUALS */
     bool keep_residuals = false;      /* SRLAMI355X_ProbeBlock with a residual buffer: srla_residual_cost stores what it prices */

@@ -392,10 +392,10 @@ bool Impl::run_stage(Slot &s, int st, int part)
             if (s.used_h2d) HIP_OK(hipStreamWaitEvent(W, s.ev_in, 0));
         }
         struct L { int kind, cls, pass; };                       /* kind 0: autocorr class launch, 1: pitch solve */
-        L seq[16]; int nl = 0;
+        L seq[20]; int nl = 0;
         if (have_items) {
             for (int pass = (par.ltp_order > 0) ? 1 : 0; pass >= 0; pass--) {
-                for (int c = 0; c < 6; c++) if (job.class_count[c]) seq[nl++] = { 0, c, pass };
+                for (int c = 0; c < 7; c++) if (job.class_count[c]) seq[nl++] = { 0, c, pass };
                 if (pass == 1) seq[nl++] = { 1, 0, 1 };
             }
         }
@@ -406,7 +406,8 @@ bool Impl::run_stage(Slot &s, int st, int part)
         for (int i = 0; i < nl; i++) if (seq[i].kind == 1) pitch_at = i;
         if (split && part == 1) last = pitch_at;
         if (split && part == 2) { first = pitch_at + 1; HIP_OK(hipStreamWaitEvent(W, s.ev_p, 0)); }
-        static const int kClass[4] = { 0, 1, 2, 4 };     /* FFT size / 2048 (0: at most 1024 points) */
+        static const int kClass[7] = { 0, 1, 2, 4, 0, 0, 0 };     /* FFT size / 2048 (0: at most 1024 points) */
+        static const uint32_t kWaveFft[7] = { 0u, 2048u, 4096u, 8192u, 0u, 0u, 1024u };   /* classes of ONE size that srla_autocorr_w takes */
         for (int i = first; i <= last; i++) {
             hipEvent_t e0 = (i == 0) ? ev0 : nullptr, e1 = (i == nl - 1) ? s.t1[ST_A] : nullptr;
             if (split) {
@@ -416,10 +417,13 @@ bool Impl::run_stage(Slot &s, int st, int part)
             }
             if (seq[i].kind == 0) {
                 const int c = seq[i].cls;
-                if (c >= 4)
+                if (c == 4 || c == 5)
                     rc |= srla_launch_autocorr_big(W, &jp, s.in_cur, d_tw.p, (uint32_t)seq[i].pass, s.d_results.as<SrlaItemResult>(), s.d_lags.as<double>(), dbg,
                                                    s.d_class_index.as<SrlaAutocorrItem>() + job.class_first[c], job.class_count[c], c == 4 ? 16384u : 32768u,
                                                    e0, e1, nullptr, nullptr, s.d_big_scratch.p, SRLA_BIG_GROUPS);
+                else if (wave_fft && kWaveFft[c])
+                    rc |= srla_launch_autocorr_wave(W, kWaveFft[c], &jp, s.in_cur, d_tw.p, (uint32_t)seq[i].pass, s.d_results.as<SrlaItemResult>(),
+                                                    s.d_lags.as<double>(), dbg, s.d_class_index.as<SrlaAutocorrItem>() + job.class_first[c], job.class_count[c], e0, e1);
                 else
                 rc |= srla_launch_autocorr(W, kClass[c], &jp, s.in_cur, s.d_items.as<SrlaItemDesc>(), d_geoms.as<SrlaGeom>(), d_tw.p,
                                            (uint32_t)seq[i].pass, s.d_results.as<SrlaItemResult>(), s.d_lags.as<double>(), dbg,

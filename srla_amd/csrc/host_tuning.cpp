@@ -45,6 +45,7 @@ void Impl::read_environment()
 
     /* ---- measured alternatives kept as options -------------------------------------------------------- */
     keep_residuals_always = !is_set("SRLA_MI355X_RECOMPUTE_RESIDUALS");   /* set: no residual scratch, the pack kernel recomputes */
+    if (is_set("SRLA_MI355X_WAVE_FFT")) wave_fft = number("SRLA_MI355X_WAVE_FFT", 1) != 0;   /* 1: srla_autocorr_w for 1024..8192-point items */
     split_ltp_stage = !is_set("SRLA_MI355X_NO_LTP_SKEW");                 /* set: the pitch solve back on stream W */
     SrlaLaunchTuning lt;
     lt.fused_fft = number("SRLA_MI355X_FUSED_FFT", 0) != 0 ? 1u : 0u;     /* two FFT stages per LDS round trip */

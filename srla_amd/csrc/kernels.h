@@ -36,6 +36,11 @@ int srla_launch_autocorr(hipStream_t stream, int rclass, const SrlaJobParams *jp
                          const SrlaAutocorrItem *class_items, uint32_t count, hipEvent_t ev_start, hipEvent_t ev_stop,
                          double *chain_pool /* null outside chain mode (device_layout.h: chain_src / chain_dump) */,
                          const uint32_t *chain_tab /* gather table of chain_lags */);
+/* The same for the items of ONE transform size nfft = 1024, 2048 or 4096 outside chain mode: nfft / 64 lanes of one wavefront per
+ * item, the transform in registers, no barriers (autocorr_wave.hip). */
+int srla_launch_autocorr_wave(hipStream_t stream, uint32_t nfft, const SrlaJobParams *jp, const int32_t *input, const void *twiddles,
+                              uint32_t pass, SrlaItemResult *results, double *lags_ws, double *dbg,
+                              const SrlaAutocorrItem *class_items, uint32_t count, hipEvent_t ev_start, hipEvent_t ev_stop);
 /* items of 16384 / 32768 points (blocks above 8192 samples): the global-memory slow path; scratch: scratch_groups x nfft
  * complex doubles, one region per (persistent) workgroup */
 int srla_launch_autocorr_big(hipStream_t stream, const SrlaJobParams *jp, const int32_t *input, const void *twiddles, uint32_t pass,
