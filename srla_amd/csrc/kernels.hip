@@ -694,7 +694,6 @@ __global__ __launch_bounds__(NTK) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
 /* ================================================================================================
  * K2p: srla_pitch_solve -- one lane per item (lpc.c:1473-1649, srla_encoder.c:1031-1047)
  * ============================================================================================== */
-#define PITCH_ITEMS 8u
 /* Near-ties (H2): an item whose decision hangs on a libm function the device cannot reproduce bit for bit is appended to
  * the job's tie list -- ties[0] = count, ties[1 + k] = item | kind << 31 (kind 1: LTP taps) -- and, for LTP items, the
  * numbers the host needs to redo the 3x3 solve with its own pow() go to tie_data[8 k ..]. */
@@ -705,54 +704,89 @@ __device__ __forceinline__ uint32_t tie_append(uint32_t *__restrict__ ties, uint
     return k;
 }
 
+/* One step of the pitch scan (lpc.c:1486-1527) as a state machine over the lag index j = 8 .. 263, so that every lane of a
+ * wavefront walks the lags in the same order with loads that do not depend on the data.  The reference's loops: from i, the
+ * first upward zero crossing `start` (262 when there is none); from start + 1 the first downward one `end` (at most 261, or
+ * start + 1 when that is larger); the largest local maximum above zero of [start, end] is a candidate; on with i = end + 1
+ * while i < 262 and fewer than 20 candidates.  rm, rc, rn = R(j - 1), R(j), R(j + 1); returns true when a candidate is
+ * complete (value *cand_val at *cand_at). */
+struct PitchScan {
+    uint32_t start, peak_at, ncand;
+    double peak;
+    bool in_seg, done;
+};
+__device__ __forceinline__ bool pitch_scan_step(PitchScan &st, const uint32_t j, const double rm, const double rc, const double rn,
+                                                uint32_t *cand_at, double *cand_val)
+{
+    bool cand = false;
+    if (!st.done) {
+        if (!st.in_seg) {
+            /* (j == 262: no crossing in [i, 261], the reference goes on with start = 262, end = 263) */
+            if (j >= SRLA_LTP_MAX_PERIOD || (rm < 0.0 && rc > 0.0)) { st.start = j; st.in_seg = true; st.peak = 0.0; st.peak_at = 0; }
+        }
+        if (st.in_seg) {
+            if (rc > rm && rc > rn && rc > st.peak) { st.peak = rc; st.peak_at = j; }
+            if (j > st.start && (j >= SRLA_LTP_MAX_PERIOD - 1u || (rc > 0.0 && rn < 0.0))) {
+                if (st.peak_at != 0) { cand = true; *cand_at = st.peak_at; *cand_val = st.peak; st.ncand++; }
+                st.in_seg = false;
+                if (j + 1u >= SRLA_LTP_MAX_PERIOD || st.ncand >= 20u) st.done = true;
+            }
+        }
+    }
+    return cand;
+}
+
 __global__ __launch_bounds__(WAVE) void srla_pitch_solve(SrlaJobParams jp, const SrlaItemDesc *__restrict__ items,
                                                          const double *__restrict__ lags_ws,
                                                          SrlaItemResult *__restrict__ results,
                                                          const uint32_t *__restrict__ select, uint32_t round,
                                                          uint32_t *__restrict__ ties, double *__restrict__ tie_data)
 {
-    /* The scan below is a chain of data-dependent loads; out of global memory each one costs a full round trip
-     * (measured 0.4 ms per job).  The wavefront first copies the lags of its PITCH_ITEMS items into LDS
-     * ([lag][item], 17 KB), then the first PITCH_ITEMS lanes scan from there.  Few items per wavefront: the scan is a
-     * latency chain, so what counts is how many wavefronts a CU holds (32 items = 67 KB allowed two: 0.58 ms per job
-     * at -V 2 -P 3; 8 items: 0.34 ms; 4 the same, 2 slower). */
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    double *s_r = (double *)lds;
+    /* One LANE per item, 64 items per wavefront.  The lag table is [lag][item], so the lanes of a wavefront read one lag of
+     * their 64 items with one coalesced load, and because the scan visits the lags in a fixed order (pitch_scan_step) the
+     * loads run ahead of the arithmetic instead of forming a chain of data-dependent round trips (round 2: the lags of 8 items
+     * staged in LDS and scanned by 8 lanes: 0.4 ms per job alone, 0.77 ms in flight at -V 2 -P 3).  Two passes over the lags:
+     * the first finds the largest candidate peak, the second the first candidate within 0.9 of it (lpc.c:1540-1546) -- no
+     * candidate list, whose dynamic indexing would live in scratch memory. */
     const size_t stride = jp.num_items;
-    const uint32_t first = blockIdx.x * PITCH_ITEMS;
-    for (uint32_t e = threadIdx.x; e < SRLA_LTP_LAGS * PITCH_ITEMS; e += WAVE) {
-        const uint32_t j = e / PITCH_ITEMS, it = e % PITCH_ITEMS;
-        s_r[e] = (first + it < jp.num_items) ? lags_ws[(size_t)j * stride + first + it] : 0.0;
-    }
-    __syncthreads();
-    const uint32_t idx = first + threadIdx.x;
-    if (threadIdx.x >= PITCH_ITEMS || idx >= jp.num_items) return;
+    const uint32_t idx = blockIdx.x * WAVE + threadIdx.x;
+    if (idx >= jp.num_items) return;
     if (select != nullptr && select[idx] != round) return;   /* chain mode: only the items whose LTP lags this round produced */
-    const uint32_t lane = threadIdx.x;
+    const double *lg = lags_ws + idx;
     /* words 263 and 264 of the reference's lag buffer are never written: zero (fresh pages) */
-    auto R = [&](uint32_t j) -> double { return (j < SRLA_LTP_LAGS) ? s_r[j * PITCH_ITEMS + lane] : 0.0; };
+    auto R = [&](uint32_t j) -> double { return (j < SRLA_LTP_LAGS) ? lg[(size_t)j * stride] : 0.0; };
     SrlaItemResult *out = &results[idx];
     const double r0 = R(0);
     uint32_t period = 0;
     if (!(fabs(r0) <= (double)FLT_MIN)) {
-        uint32_t cand[20]; uint32_t ncand = 0, i = SRLA_LTP_MIN_PERIOD; double best = 0.0;
-        const uint32_t maxp = SRLA_LTP_MAX_PERIOD;
-        while (i < maxp && ncand < 20) {
-            uint32_t start, end, peak_at = 0; double peak = 0.0;
-            for (start = i; start < maxp; start++) if (R(start - 1) < 0.0 && R(start) > 0.0) break;
-            for (end = start + 1; end < maxp - 1; end++) if (R(end) > 0.0 && R(end + 1) < 0.0) break;
-            double rm = R(start - 1), rc = R(start);
-            for (uint32_t j = start; j <= end; j++) {
-                const double rn = R(j + 1);
-                if (rc > rm && rc > rn && rc > peak) { peak_at = j; peak = rc; }
-                rm = rc; rc = rn;
+        double best = 0.0;
+        uint32_t ncand = 0;
+        for (int pass = 0; pass < 2; pass++) {
+            PitchScan st;
+            st.start = 0; st.peak_at = 0; st.ncand = 0; st.peak = 0.0; st.in_seg = false; st.done = false;
+            double rm = R(SRLA_LTP_MIN_PERIOD - 1u), rc = R(SRLA_LTP_MIN_PERIOD);
+            bool found = false;
+            /* j = 8 .. 263 in blocks of 8: the eight loads of a block are issued together */
+            for (uint32_t j0 = SRLA_LTP_MIN_PERIOD; j0 < SRLA_LTP_MAX_PERIOD + 2u; j0 += 8u) {
+                double nx[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) nx[u] = R(j0 + 1u + (uint32_t)u);
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    uint32_t at = 0; double val = 0.0;
+                    if (pitch_scan_step(st, j0 + (uint32_t)u, rm, rc, nx[u], &at, &val)) {
+                        if (pass == 0) { if (val > best) best = val; }
+                        else if (!found && val >= 0.9 * best) { period = at; found = true; }
+                    }
+                    rm = rc; rc = nx[u];
+                }
+                /* (a wavefront leaves the loop when all of its lanes are done) */
+                if (st.done || found) break;
             }
-            if (peak_at != 0) { cand[ncand++] = peak_at; if (peak > best) best = peak; }
-            i = end + 1;
-        }
-        if (ncand > 0 && !(best < 0.1 * r0)) {
-            for (uint32_t k = 0; k < ncand; k++)
-                if (R(cand[k]) >= 0.9 * best) { period = cand[k]; break; }
+            if (pass == 0) {
+                ncand = st.ncand;
+                if (ncand == 0 || best < 0.1 * r0) break;          /* lpc.c:1530-1537 */
+            }
         }
         if (period < (jp.ltp_order / 2) + 1) period = 0;
     }
@@ -3359,9 +3393,7 @@ extern "C" int srla_launch_pitch_solve(hipStream_t stream, const SrlaJobParams *
                                        const uint32_t *select, uint32_t round, uint32_t *ties, double *tie_data)
 {
     if (jp->num_items == 0) return 0;
-    const uint32_t lds = SRLA_LTP_LAGS * PITCH_ITEMS * 8u;
-    SET_LDS_ATTR(srla_pitch_solve);
-    hipExtLaunchKernelGGL(srla_pitch_solve, dim3((jp->num_items + PITCH_ITEMS - 1) / PITCH_ITEMS), dim3(WAVE), lds, stream, ev_start, ev_stop, 0,
+    hipExtLaunchKernelGGL(srla_pitch_solve, dim3((jp->num_items + WAVE - 1) / WAVE), dim3(WAVE), 0, stream, ev_start, ev_stop, 0,
                           *jp, items, lags_ws, results, select, round, ties, tie_data);
     return (hipGetLastError() == hipSuccess) ? 0 : -2;
 }
