@@ -112,7 +112,7 @@ struct Slot {
     uint32_t out_boost = 1;              /* stream-out workgroup multiplier (the last jobs of a stream drain faster) */
     DevBuf d_pcm;                        /* PCM input: the job's frames as uploaded, de-interleaved into d_input by srla_deinterleave */
     DevBuf d_input16;                    /* host input of at most 16 bits crosses PCIe as int16 and is widened into d_input */
-    DevBuf d_input, d_items, d_cands, d_windows, d_results, d_res_ws, d_blocks, d_block_off, d_scratch, d_dbg, d_lags, d_err, d_class_index, d_stream;
+    DevBuf d_input, d_items, d_cands, d_windows, d_results, d_res_ws, d_blocks, d_block_off, d_scratch, d_dbg, d_lags, d_err, d_gamma, d_class_index, d_stream;
     DevBuf d_segs, d_seg_ctl;            /* SrlaSegDesc per segment; device-side segment records of srla_block_offsets */
     DevBuf d_coef_ws;                    /* SVR refinement: 64 doubles per item, the predictor between solve and quantiser */
     DevBuf d_big_scratch, d_big_items;   /* blocks above 8192 samples: FFT scratch in global memory, indices of the big items */

@@ -38,7 +38,7 @@ Impl::~Impl()
             for (hipEvent_t e : { s.ev_a1, s.ev_p0, s.ev_p, s.ev_a0 }) if (e) (void)hipEventDestroy(e);
             s.d_input16.release(); s.d_pcm.release();
             DevBuf *db[] = { &s.d_input, &s.d_items, &s.d_cands, &s.d_windows, &s.d_results, &s.d_res_ws,
-                             &s.d_blocks, &s.d_block_off, &s.d_scratch, &s.d_dbg, &s.d_lags, &s.d_err, &s.d_class_index, &s.d_stream,
+                             &s.d_blocks, &s.d_block_off, &s.d_scratch, &s.d_dbg, &s.d_lags, &s.d_err, &s.d_gamma, &s.d_class_index, &s.d_stream,
                              &s.d_segs, &s.d_seg_ctl, &s.d_ties, &s.d_tie_data, &s.d_big_scratch, &s.d_big_items, &s.d_coef_ws };
             for (auto *b : db) b->release();
             PinBuf *pb[] = { &s.h_in, &s.h_stream, &s.h_info, &s.h_segs };
@@ -336,6 +336,7 @@ bool Impl::prepare_job(Slot &s, bool want_dbg)
     const uint32_t lag_rows = std::max<uint32_t>(par.ltp_order > 0 ? SRLA_LTP_LAGS : 0u, preset_order() + 1);
     if (!s.d_lags.ensure((size_t)lag_rows * std::max<size_t>(1, n_items) * sizeof(double))) return false;
     if (!s.d_err.ensure((size_t)(preset_order() + 1) * std::max<size_t>(1, n_items) * sizeof(double))) return false;
+    if (!s.d_gamma.ensure((size_t)(preset_order() + 1) * std::max<size_t>(1, n_items) * sizeof(double))) return false;
     s.want_dbg = want_dbg;
     if (!job.uploaded) {
         if (n_items) HIP_OK(hipMemcpyAsync(s.d_items.p, job.items.data(), n_items * sizeof(SrlaItemDesc), hipMemcpyHostToDevice, W));
@@ -445,7 +446,7 @@ bool Impl::run_stage(Slot &s, int st, int part)
                                         s.d_err.as<double>(), d_huff.as<uint8_t>(), s.d_results.as<SrlaItemResult>(), dbg,
                                         s.d_ties.as<uint32_t>(), ev0, s.t1[ST_B], s.in_cur, s.d_coef_ws.as<double>(),
                                         par.num_svr_filter_learning_iteration, std::min<uint32_t>(par.max_num_samples_per_block, 8192u),
-                                        d_svr_scratch.p, kSvrGroups);
+                                        d_svr_scratch.p, kSvrGroups, s.d_gamma.as<double>());
         } else { if (ev0) HIP_OK(hipEventRecord(ev0, N)); HIP_OK(hipEventRecord(s.t1[ST_B], N)); }
         break;
     case ST_C:

@@ -67,7 +67,8 @@ int srla_launch_lpc_solve(hipStream_t stream, const SrlaJobParams *jp, const Srl
                           SrlaItemResult *results, double *dbg, uint32_t *ties, hipEvent_t ev_start, hipEvent_t ev_stop,
                           const int32_t *input, double *coef_ws /* 64 doubles per item (256 for orders above 64) */,
                           uint32_t svr_iterations /* 0: off */, uint32_t svr_n_cap /* longest LDS-resident block of the job */,
-                          void *svr_scratch, uint32_t svr_groups /* srla_svr_refine_big: groups x srla_svr_big_scratch_bytes(max block) */);
+                          void *svr_scratch, uint32_t svr_groups /* srla_svr_refine_big: groups x srla_svr_big_scratch_bytes(max block) */,
+                          double *gamma_ws /* [order][item] like err_ws: reflection coefficients (orders 8 .. 64: the three-launch chain) */);
 size_t srla_svr_big_scratch_bytes(uint32_t n_max);
 int srla_launch_residual_cost(hipStream_t stream, int rclass, const SrlaJobParams *jp, const int32_t *input,
                               const SrlaItemDesc *items, const SrlaGeom *geoms, const SrlaLdsPlan *plan,
@@ -102,6 +103,7 @@ typedef struct {
     uint32_t fused_fft;            /* SRLA_MI355X_FUSED_FFT: fft_complex_lds16 for 2048- and 4096-point items */
     uint32_t pack_lds_cap_words;   /* SRLA_MI355X_PACK_LDS_WORDS: 0 = the default cap (24 Ki words) */
     uint32_t out_wgs;              /* SRLA_MI355X_OUT_WGS: stream-out workgroups, 0 = by sample width */
+    uint32_t solve_onepass;        /* SRLA_MI355X_SOLVE_ONEPASS: srla_lpc_solve_regs instead of errvars + order_select + taps */
 } SrlaLaunchTuning;
 void srla_set_launch_tuning(const SrlaLaunchTuning *t);
 #define SRLA_SEGCTL_WORDS_HOST 8

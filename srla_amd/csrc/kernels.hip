@@ -1153,6 +1153,110 @@ __global__ __launch_bounds__(WAVE) void srla_lpc_solve_regs(
                        [&](uint32_t i) -> int32_t { return q[(size_t)i * L + lane]; }, s_huff, out);
 }
 
+/* The same chain as three launches, each with the parallelism its part has (the default for orders 8 .. 64):
+ *   srla_lpc_errvars<P>   one LANE per item, registers: the recursion alone -- error variance of every order (err_ws) and the
+ *                         reflection coefficient of every step (gamma_ws; row 0 holds a[1] of order 1).
+ *   srla_order_select     one WAVE per item, lane = order: the 64 code-length estimates (a square root, two divisions and two
+ *                         logarithms each -- more than half of the one-pass kernel's instructions, and there on the serial
+ *                         chain of a single lane) side by side.
+ *   srla_lpc_taps<P>      one LANE per item: the predictor of the chosen order rebuilt from the stored reflection coefficients
+ *                         (lpc.c:430-433, the update alone: the same products and sums on the same operands, no dot
+ *                         products), 8-bit quantiser, tap cost.
+ * srla_lpc_solve_regs holds a whole SIMD's registers for 0.11 ms on its own and 0.17-0.24 ms beside the wide kernels (206
+ * wavefronts of 262 VGPRs at -V 1); the three together hold far less for far shorter. */
+template <int P>
+__global__ __launch_bounds__(WAVE) void srla_lpc_errvars(SrlaJobParams jp, const double *__restrict__ lags_ws, double *__restrict__ err_ws,
+                                                         double *__restrict__ gamma_ws)
+{
+    const uint32_t idx = blockIdx.x * WAVE + threadIdx.x;
+    if (idx >= jp.num_items) return;
+    const size_t stride = jp.num_items;
+    double r[P + 1];
+#pragma unroll
+    for (int i = 0; i <= P; i++) r[i] = lags_ws[(size_t)i * stride + idx];
+    const double r0 = r[0] * (1.0 + 1e-5);                   /* ridge, lpc.c:483 */
+    double *err = err_ws + idx, *gam = gamma_ws + idx;
+    err[0] = r0;
+    if (fabs(r0) < (double)FLT_EPSILON) {
+        /* lpc.c:395-405: every error variance is r0, every predictor zero */
+        for (uint32_t o = 1; o <= (uint32_t)P; o++) { err[(size_t)o * stride] = r0; gam[(size_t)(o - 1) * stride] = 0.0; }
+        return;
+    }
+    double a[P + 2];
+    const double a1 = -r[1] / r0;
+    a[0] = 1.0; a[1] = a1; a[2] = 0.0;
+    double e = r0 + r[1] * a1;
+    err[stride] = e;
+    gam[0] = a1;
+#pragma unroll
+    for (int k = 1; k < P; k++) {
+        double gamma = 0.0;
+#pragma unroll
+        for (int i = 0; i <= k; i++) gamma += a[i] * r[k + 1 - i];          /* index order, lpc.c:420-423 */
+        gamma /= -e;
+        e = e * (1.0 - gamma * gamma);
+#pragma unroll
+        for (int i = 0; i <= (k + 1) / 2; i++) {
+            const int j = k + 1 - i;
+            const double ai = a[i], aj = a[j];
+            a[i] = ai + gamma * aj;
+            if (i != j) a[j] = aj + gamma * ai;
+        }
+        a[k + 2] = 0.0;
+        err[(size_t)(k + 1) * stride] = e;
+        gam[(size_t)k * stride] = gamma;
+    }
+}
+
+template <int P>
+__global__ __launch_bounds__(WAVE) void srla_lpc_taps(SrlaJobParams jp, const double *__restrict__ err_ws, const double *__restrict__ gamma_ws,
+                                                      const uint8_t *__restrict__ huff_len, SrlaItemResult *__restrict__ results,
+                                                      double *__restrict__ coef_ws /* SVR refinement follows: the predictor of the chosen order goes here (row of 64 per item), unquantised */)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr int L = WAVE;
+    const uint32_t lane = threadIdx.x;
+    uint8_t *s_huff = lds;                                   /* 512 bytes: plain, pair-summed code lengths */
+    double *snap = (double *)(lds + 512);                    /* snap[i * L + lane], i < P: taps of the chosen order */
+    int32_t *q = (int32_t *)(snap + (size_t)P * L);          /* q[i * L + lane]: quantised taps */
+    for (uint32_t i = lane; i < 128; i += WAVE) ((uint32_t *)s_huff)[i] = ((const uint32_t *)huff_len)[i];
+    __syncthreads();
+    const uint32_t idx = blockIdx.x * WAVE + lane;
+    if (idx >= jp.num_items) return;                         /* no barriers below: lanes are independent */
+    const size_t stride = jp.num_items;
+    SrlaItemResult *out = &results[idx];
+    const uint32_t order = out->lpc_order;
+    const bool silent = fabs(err_ws[idx]) < (double)FLT_EPSILON;
+    const double *gam = gamma_ws + idx;
+    double a[P + 2];
+    a[0] = 1.0; a[1] = gam[0]; a[2] = 0.0;
+#pragma unroll
+    for (int k = 1; k < P; k++) {
+        if ((uint32_t)k < order) {                           /* (a wavefront goes as far as the highest order among its items) */
+            const double gamma = gam[(size_t)k * stride];
+#pragma unroll
+            for (int i = 0; i <= (k + 1) / 2; i++) {
+                const int j = k + 1 - i;
+                const double ai = a[i], aj = a[j];
+                a[i] = ai + gamma * aj;
+                if (i != j) a[j] = aj + gamma * ai;
+            }
+        }
+        a[k + 2] = 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < P; i++) snap[(size_t)i * L + lane] = a[1 + i];
+    if (coef_ws != nullptr) {
+        double *row = coef_ws + (size_t)idx * 64u;             /* SVR_P doubles per item whatever the preset */
+        for (uint32_t i = 0; i < order; i++) row[i] = silent ? 0.0 : snap[(size_t)i * L + lane];
+        return;
+    }
+    quantize_and_price(order, silent,
+                       [&](uint32_t i) -> double { return snap[(size_t)i * L + lane]; },
+                       [&](uint32_t i, int32_t v) { q[(size_t)i * L + lane] = v; },
+                       [&](uint32_t i) -> int32_t { return q[(size_t)i * L + lane]; }, s_huff, out);
+}
+
 template <int L>
 __global__ __launch_bounds__(WAVE) void srla_lpc_quantize(
     SrlaJobParams jp, const double *__restrict__ lags_ws, const uint8_t *__restrict__ huff_len,
@@ -3320,7 +3424,7 @@ extern "C" int srla_launch_chain_commit(hipStream_t stream, double *pool, const 
 }
 
 /* --------------------------------------------------------------------------- launchers ---- */
-static SrlaLaunchTuning g_tune = { 0u, 0u, 0u };
+static SrlaLaunchTuning g_tune = { 0u, 0u, 0u, 0u };
 extern "C" void srla_set_launch_tuning(const SrlaLaunchTuning *t) { if (t) g_tune = *t; }
 
 #define SET_LDS_ATTR(fn)                                                                                     \
@@ -3402,10 +3506,11 @@ extern "C" int srla_launch_lpc_solve(hipStream_t stream, const SrlaJobParams *jp
                                      const SrlaGeom *geoms, const double *lags_ws, double *err_ws, const uint8_t *huff_len,
                                      SrlaItemResult *results, double *dbg, uint32_t *ties, hipEvent_t ev_start, hipEvent_t ev_stop,
                                      const int32_t *input, double *coef_ws, uint32_t svr_iterations, uint32_t svr_n_cap,
-                                     void *svr_scratch, uint32_t svr_groups)
+                                     void *svr_scratch, uint32_t svr_groups, double *gamma_ws)
 {
     if (jp->num_items == 0) return 0;
     const uint32_t p = jp->max_order;
+    const bool three = !g_tune.solve_onepass && gamma_ws != nullptr;   /* orders 8 .. 64: errvars + order_select + taps */
     if (svr_iterations > 0) {
         /* solve (taps left unquantised) -> SVR refinement -> quantiser */
         const dim3 g64s((jp->num_items + 63) / 64), blks(WAVE);
@@ -3413,9 +3518,16 @@ extern "C" int srla_launch_lpc_solve(hipStream_t stream, const SrlaJobParams *jp
 #define SVR_PATH(PP)                                                                                                     \
     do {                                                                                                                 \
         const uint32_t lds = 512 + PP * 8 * 64 + PP * 4 * 64;                                                            \
-        SET_LDS_ATTR(srla_lpc_solve_regs<PP>);                                                                           \
-        hipExtLaunchKernelGGL(srla_lpc_solve_regs<PP>, g64s, blks, lds, stream, ev_start, nullptr, 0, *jp, items, geoms, lags_ws, err_ws, \
-                              huff_len, results, dbg, ties, coef_ws);                                                    \
+        if (three) {                                                                                                     \
+            SET_LDS_ATTR(srla_lpc_taps<PP>);                                                                             \
+            hipExtLaunchKernelGGL(srla_lpc_errvars<PP>, g64s, blks, 0, stream, ev_start, nullptr, 0, *jp, lags_ws, err_ws, gamma_ws); \
+            hipLaunchKernelGGL(srla_order_select, dim3(jp->num_items), blks, 0, stream, *jp, items, geoms, err_ws, results, dbg, ties); \
+            hipLaunchKernelGGL(srla_lpc_taps<PP>, g64s, blks, lds, stream, *jp, err_ws, gamma_ws, huff_len, results, coef_ws); \
+        } else {                                                                                                         \
+            SET_LDS_ATTR(srla_lpc_solve_regs<PP>);                                                                       \
+            hipExtLaunchKernelGGL(srla_lpc_solve_regs<PP>, g64s, blks, lds, stream, ev_start, nullptr, 0, *jp, items, geoms, lags_ws, err_ws, \
+                                  huff_len, results, dbg, ties, coef_ws);                                                \
+        }                                                                                                                \
     } while (0)
         if (p == 8) SVR_PATH(8); else if (p == 16) SVR_PATH(16); else if (p == 32) SVR_PATH(32); else if (p == 64) SVR_PATH(64);
         else if (p <= 128) {
@@ -3460,9 +3572,16 @@ extern "C" int srla_launch_lpc_solve(hipStream_t stream, const SrlaJobParams *jp
 #define REGS_PATH(PP)                                                                                                    \
     do {                                                                                                                 \
         const uint32_t lds = 512 + PP * 8 * 64 + PP * 4 * 64;                                                            \
-        SET_LDS_ATTR(srla_lpc_solve_regs<PP>);                                                                           \
-        hipExtLaunchKernelGGL(srla_lpc_solve_regs<PP>, g64, blk, lds, stream, ev_start, ev_stop, 0, *jp, items, geoms, lags_ws, err_ws, \
-                              huff_len, results, dbg, ties, (double *)nullptr);                                          \
+        if (three) {                                                                                                     \
+            SET_LDS_ATTR(srla_lpc_taps<PP>);                                                                             \
+            hipExtLaunchKernelGGL(srla_lpc_errvars<PP>, g64, blk, 0, stream, ev_start, nullptr, 0, *jp, lags_ws, err_ws, gamma_ws); \
+            hipLaunchKernelGGL(srla_order_select, dim3(jp->num_items), blk, 0, stream, *jp, items, geoms, err_ws, results, dbg, ties); \
+            hipExtLaunchKernelGGL(srla_lpc_taps<PP>, g64, blk, lds, stream, nullptr, ev_stop, 0, *jp, err_ws, gamma_ws, huff_len, results, (double *)nullptr); \
+        } else {                                                                                                         \
+            SET_LDS_ATTR(srla_lpc_solve_regs<PP>);                                                                       \
+            hipExtLaunchKernelGGL(srla_lpc_solve_regs<PP>, g64, blk, lds, stream, ev_start, ev_stop, 0, *jp, items, geoms, lags_ws, err_ws, \
+                                  huff_len, results, dbg, ties, (double *)nullptr);                                      \
+        }                                                                                                                \
     } while (0)
     if (p == 8) REGS_PATH(8);
     else if (p == 16) REGS_PATH(16);
