@@ -3709,9 +3709,13 @@ extern "C" int srla_launch_pack(hipStream_t stream, const SrlaJobParams *jp, uin
     hipLaunchKernelGGL(srla_pack_blocks, dim3(num_slots), dim3(NT), lds, stream,
                        *jp, input, items, blocks, results, res_ws, huff_code, huff_len, block_off, seg_ctl, stage, scratch, info,
                        lds_words, rl_samples);
-    /* one workgroup keeps up with 16-bit streams (~12 GB/s of output at full speed) and leaves the PCIe write path calm
-     * enough for srla_autocorr (measured: more slow it down); 24-bit streams carry twice the bytes and need two */
-    const uint32_t wgs = g_tune.out_wgs ? g_tune.out_wgs : (jp->bits_per_sample > 16 ? 2u : 1u);
+    /* Two workgroups (three for 24-bit streams, which carry more bytes).  One moves a 4 M-sample job's 6.5 MB in 0.45-0.57 ms
+     * beside the other kernels -- longer than the job's wide kernels take (0.46 ms), so the block assembly stream, not stream W,
+     * set the pace of a long stream (kernel trace of round 3); two take 0.25 ms.  More slow srla_autocorr down through the
+     * PCIe write path's back-pressure (4: 0.25 -> 0.30 ms per job) and lose more than they gain.  A stream of its own for this
+     * kernel (so that it runs beside the next job's assembly) was measured again and is worse by 13 %: a fifth compute
+     * queue serialises with the others. */
+    const uint32_t wgs = g_tune.out_wgs ? g_tune.out_wgs : (jp->bits_per_sample > 16 ? 3u : 2u);
     hipExtLaunchKernelGGL(srla_stream_out, dim3(wgs * (out_boost ? out_boost : 1u)), dim3(NT), 0, stream, nullptr, ev_stop, 0,
                           stage, seg_ctl, segs, jp->num_segs, host_stage, 0u);
     return (hipGetLastError() == hipSuccess) ? 0 : -2;
