@@ -100,7 +100,8 @@ struct Job {
 struct Slot {
     hipStream_t own_stream = nullptr;    /* chain-mode jobs: every stage but the block assembly runs here */
     hipEvent_t t0[6] = {}, t1[6] = {};   /* start / end of the stages of the job (see Impl::run_stage) */
-    hipEvent_t ev_a1 = nullptr, ev_p0 = nullptr, ev_p = nullptr, ev_a0 = nullptr;   /* stage A of an LTP job in two parts (run_stage): end of the
+    hipEvent_t ev_a1 = nullptr, ev_p0 = nullptr, ev_p = nullptr, ev_a0 = nullptr;
+    hipEvent_t ev_pk = nullptr;          /* block assembly done (stream N): hand-over to srla_stream_out on stream C */   /* stage A of an LTP job in two parts (run_stage): end of the
                                           * LTP-pass autocorrelation, start / end of the pitch solve, start of the LPC-pass autocorrelation */
     hipEvent_t ev_in = nullptr;          /* the job's samples have arrived in d_input (host-input calls) */
     const int32_t *in_cur = nullptr;     /* device input of the current job */
@@ -176,6 +177,9 @@ struct Impl {
     bool pin_too_slow = false;          /* registration measured slower than staging would be (no huge pages): not tried again */
     bool wave_fft = false;              /* SRLA_MI355X_WAVE_FFT=1: 1024- to 8192-point items on srla_autocorr_w (register-resident transform, autocorr_wave.hip)
                                          * instead of srla_autocorr: bit-identical, measured slower -- an option, not the default */
+    bool pack_on_n = false;             /* SRLA_MI355X_PACK_ON_N=1: block offsets + assembly on stream N behind the pricing, only the stream-out on C (measured: M device-resident -4 %, config 2 +3 %, others equal -- not the default) */
+    uint32_t short_min = 786432;        /* SRLA_MI355X_SHORT_MIN: ... and no piece shorter than this many samples */
+    uint32_t short_div = 4;             /* SRLA_MI355X_SHORT_DIV: a stream shorter than one job is cut into pieces of a job / this */
     bool split_ltp_stage = true;        /* SRLA_MI355X_NO_LTP_SKEW: stage A of LTP jobs in one piece on W, as before */
     bool keep_residuals_always = true;  /* false with SRLA_MI355X_RECOMPUTE_RESIDUALS */
     bool keep_residuals = false;      /* SRLAMI355X_ProbeBlock with a residual buffer: srla_residual_cost stores what it prices */

@@ -35,7 +35,7 @@ Impl::~Impl()
             for (auto &e : s.t0) if (e) (void)hipEventDestroy(e);
             for (auto &e : s.t1) if (e) (void)hipEventDestroy(e);
             if (s.ev_in) (void)hipEventDestroy(s.ev_in);
-            for (hipEvent_t e : { s.ev_a1, s.ev_p0, s.ev_p, s.ev_a0 }) if (e) (void)hipEventDestroy(e);
+            for (hipEvent_t e : { s.ev_a1, s.ev_p0, s.ev_p, s.ev_a0, s.ev_pk }) if (e) (void)hipEventDestroy(e);
             s.d_input16.release(); s.d_pcm.release();
             DevBuf *db[] = { &s.d_input, &s.d_items, &s.d_cands, &s.d_windows, &s.d_results, &s.d_res_ws,
                              &s.d_blocks, &s.d_block_off, &s.d_scratch, &s.d_dbg, &s.d_lags, &s.d_err, &s.d_gamma, &s.d_class_index, &s.d_stream,
@@ -97,6 +97,7 @@ bool Impl::init_device()
         for (auto &e : s.t1) HIP_OK(hipEventCreate(&e));
         HIP_OK(hipEventCreateWithFlags(&s.ev_in, hipEventDisableTiming));
         HIP_OK(hipEventCreate(&s.ev_a1)); HIP_OK(hipEventCreate(&s.ev_p0)); HIP_OK(hipEventCreate(&s.ev_p)); HIP_OK(hipEventCreate(&s.ev_a0));
+        HIP_OK(hipEventCreateWithFlags(&s.ev_pk, hipEventDisableTiming));
     }
     double thr[32];
     srla::build_rice_thresholds(thr);
@@ -474,18 +475,24 @@ bool Impl::run_stage(Slot &s, int st, int part)
     case ST_E:
         /* block offsets + complete blocks + stream-out to where the streams want them (their pinned buffers, or this
          * slot's pinned staging buffer); runs on its own stream and leaves W to autocorr / residual_cost */
-        HIP_OK(hipStreamWaitEvent(C, s.t1[ST_D], 0));
+        /* The offsets and the assembly right behind the pricing on N (high priority: on the low-priority stream they waited
+         * for the tails of the wide kernels, 0.13-0.3 ms per job for 0.05 ms of work), the stream-out on C: the copy of job k
+         * then also runs beside the assembly of job k + 1.  A job on a stream of its own keeps to it. */
+        {
+        hipStream_t P = (pack_on_n && !s.own_stream) ? N : C;
+        if (P == C) HIP_OK(hipStreamWaitEvent(C, s.t1[ST_D], 0));
         if (job.num_slots) {
             SrlaJobInfo *info = s.h_info.as<SrlaJobInfo>();
             uint32_t *wbytes = reinterpret_cast<uint32_t *>(info + 1);
-            rc |= srla_launch_pack(C, &jp, job.num_slots, s.in_cur, s.d_items.as<SrlaItemDesc>(), s.d_windows.as<SrlaWindowDesc>(),
+            rc |= srla_launch_pack(P, &jp, job.num_slots, s.in_cur, s.d_items.as<SrlaItemDesc>(), s.d_windows.as<SrlaWindowDesc>(),
                                    s.d_blocks.as<SrlaBlockRecord>(), s.d_results.as<SrlaItemResult>(), s.d_res_ws.as<int32_t>(),
                                    d_huffcode.as<uint32_t>(), d_huff.as<uint8_t>(), s.d_block_off.as<uint32_t>(),
                                    d_pos.as<uint32_t>(), s.d_segs.as<SrlaSegDesc>(), s.d_seg_ctl.as<uint32_t>(),
                                    s.d_stream.as<uint8_t>(), s.h_stream.as<uint8_t>(), s.d_scratch.as<uint8_t>(), info, wbytes,
                                    reinterpret_cast<SrlaSegInfo *>(wbytes + job.windows.size()), s.d_ties.as<uint32_t>(),
-                                   ev0, s.t1[ST_E], s.out_boost);
-        } else { if (ev0) HIP_OK(hipEventRecord(ev0, C)); HIP_OK(hipEventRecord(s.t1[ST_E], C)); }
+                                   ev0, s.t1[ST_E], s.out_boost, (P == C) ? nullptr : C, s.ev_pk);
+        } else { if (P != C) HIP_OK(hipStreamWaitEvent(C, s.t1[ST_D], 0)); if (ev0) HIP_OK(hipEventRecord(ev0, C)); HIP_OK(hipEventRecord(s.t1[ST_E], C)); }
+        }
         break;
     default: return false;
     }
@@ -938,6 +945,12 @@ SRLAApiResult Impl::encode_streams(bool search)
         if (in_flight(t, 0)) {
             if (!begin(t) || !run_stage(job_slot(t), ST_A, ltp_skew ? 1 : 0)) return fail(SRLA_APIRESULT_NG);
         }
+        /* (the block assembly first: on stream N it must not queue behind this iteration's solve and pricing, which wait for
+         * wide kernels that have only just been enqueued) */
+        if (in_flight(t, 2 + ltp_skew)) {
+            Slot &s = job_slot(t - 2 - ltp_skew);
+            if (!run_stage(s, ST_E)) return fail(SRLA_APIRESULT_NG);
+        }
         if (in_flight(t, ltp_skew)) {
             Slot &s = job_slot(t - ltp_skew);
             if ((ltp_skew && !run_stage(s, ST_A, 2)) || !run_stage(s, ST_B)) return fail(SRLA_APIRESULT_NG);
@@ -945,10 +958,6 @@ SRLAApiResult Impl::encode_streams(bool search)
         if (in_flight(t, 1 + ltp_skew)) {
             Slot &s = job_slot(t - 1 - ltp_skew);
             if (!run_stage(s, ST_C) || !run_stage(s, ST_D)) return fail(SRLA_APIRESULT_NG);
-        }
-        if (in_flight(t, 2 + ltp_skew)) {
-            Slot &s = job_slot(t - 2 - ltp_skew);
-            if (!run_stage(s, ST_E)) return fail(SRLA_APIRESULT_NG);
         }
         if (single && chain.active && chain.early) {
             /* the host prepares the chain jobs while the device works on the first regular job */

@@ -278,10 +278,13 @@ void Impl::plan_jobs(std::vector<JobPlan> &plan, bool search)
             const uint32_t first = (uint32_t)(((rest - small) / window_len) * window_len);
             one(tail0, first, kSlots);
             one(tail0 + first, (uint32_t)(rest - first), kSlots + 1);
-        } else if (nfull == 0 && rest > 3 * (job_len / 8) && job_len >= 8 * (uint64_t)window_len) {
+        } else if (nfull == 0 && rest >= 2 * (uint64_t)short_min && job_len >= 8 * (uint64_t)window_len) {
             /* a stream shorter than one job: as one job its five stages would run one after the other on an otherwise idle
-             * GPU; in pieces of about a quarter job they overlap (60 s of stereo: 1.15 -> 1.03 ms) */
-            const uint64_t pieces = (rest + job_len / 4 - 1) / (job_len / 4);
+             * GPU; in a few pieces they overlap (60 s of stereo: 1.15 -> 1.03 ms).  About three pieces: more cost more host
+             * time per piece than their overlap returns (60 s in 6 pieces: 2 670 instead of 3 100 Msamples/s) */
+            const uint64_t part = job_len / std::max<uint32_t>(2u, short_div);
+            uint64_t pieces = (rest + part - 1) / part;
+            pieces = std::max<uint64_t>(pieces, std::min<uint64_t>(3u, rest / short_min));
             const uint64_t piece = (((rest + pieces - 1) / pieces + window_len - 1) / window_len) * window_len;
             uint32_t k = 0;
             for (uint64_t s0 = 0; s0 < rest; s0 += piece, k++)

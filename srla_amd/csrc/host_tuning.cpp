@@ -37,6 +37,8 @@ void Impl::read_environment()
         else fprintf(stderr, "[srla-mi355x] SRLA_MI355X_SLOTS=%d ignored: %d..%d job buffer sets are supported\n", v, 5, (int)kMaxSlots - 5);
     }
     { const long long v = number("SRLA_MI355X_JOB_SAMPLES", 0); if (v >= 65536) job_samples = (uint64_t)v; }
+    { const long long v = number("SRLA_MI355X_SHORT_MIN", 0); if (v >= 16384) short_min = (uint32_t)v; }
+    { const long long v = number("SRLA_MI355X_SHORT_DIV", 0); if (v >= 2 && v <= 64) short_div = (uint32_t)v; }
     { const long long v = number("SRLA_MI355X_PACK_THREADS", 0); if (v > 0) env_pack_threads = (uint32_t)v; }
     if (const char *e = getenv("SRLA_MI355X_TAIL_BOOST")) {     /* "wgs,jobs": stream-out workgroup multiplier of the last jobs */
         unsigned a = 0, b = 0;
@@ -47,6 +49,7 @@ void Impl::read_environment()
     keep_residuals_always = !is_set("SRLA_MI355X_RECOMPUTE_RESIDUALS");   /* set: no residual scratch, the pack kernel recomputes */
     if (is_set("SRLA_MI355X_WAVE_FFT")) wave_fft = number("SRLA_MI355X_WAVE_FFT", 1) != 0;   /* 1: srla_autocorr_w for 1024..8192-point items */
     split_ltp_stage = !is_set("SRLA_MI355X_NO_LTP_SKEW");                 /* set: the pitch solve back on stream W */
+    if (is_set("SRLA_MI355X_PACK_ON_N")) pack_on_n = number("SRLA_MI355X_PACK_ON_N", 1) != 0;
     SrlaLaunchTuning lt;
     lt.fused_fft = number("SRLA_MI355X_FUSED_FFT", 0) != 0 ? 1u : 0u;     /* two FFT stages per LDS round trip */
     lt.pack_lds_cap_words = (uint32_t)std::max<long long>(0, number("SRLA_MI355X_PACK_LDS_WORDS", 0));   /* tests: reach the global-memory pack path */

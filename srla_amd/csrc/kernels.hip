@@ -3697,7 +3697,7 @@ extern "C" int srla_launch_pack(hipStream_t stream, const SrlaJobParams *jp, uin
                                 uint32_t *stream_pos, const SrlaSegDesc *segs, uint32_t *seg_ctl,
                                 uint8_t *stage, uint8_t *host_stage, uint8_t *scratch, SrlaJobInfo *info,
                                 uint32_t *window_bytes, SrlaSegInfo *seg_info, const uint32_t *ties,
-                                hipEvent_t ev_start, hipEvent_t ev_stop, uint32_t out_boost)
+                                hipEvent_t ev_start, hipEvent_t ev_stop, uint32_t out_boost, hipStream_t out_stream, hipEvent_t ev_packed)
 {
     if (num_slots == 0) return 0;
     hipExtLaunchKernelGGL(srla_block_offsets, dim3(1), dim3(NT), 0, stream, ev_start, nullptr, 0, *jp, windows, blocks, results, num_slots, block_off,
@@ -3716,7 +3716,12 @@ extern "C" int srla_launch_pack(hipStream_t stream, const SrlaJobParams *jp, uin
      * kernel (so that it runs beside the next job's assembly) was measured again and is worse by 13 %: a fifth compute
      * queue serialises with the others. */
     const uint32_t wgs = g_tune.out_wgs ? g_tune.out_wgs : (jp->bits_per_sample > 16 ? 3u : 2u);
-    hipExtLaunchKernelGGL(srla_stream_out, dim3(wgs * (out_boost ? out_boost : 1u)), dim3(NT), 0, stream, nullptr, ev_stop, 0,
+    hipStream_t os = stream;
+    if (out_stream != nullptr && ev_packed != nullptr) {
+        if (hipEventRecord(ev_packed, stream) != hipSuccess || hipStreamWaitEvent(out_stream, ev_packed, 0) != hipSuccess) return -2;
+        os = out_stream;
+    }
+    hipExtLaunchKernelGGL(srla_stream_out, dim3(wgs * (out_boost ? out_boost : 1u)), dim3(NT), 0, os, nullptr, ev_stop, 0,
                           stage, seg_ctl, segs, jp->num_segs, host_stage, 0u);
     return (hipGetLastError() == hipSuccess) ? 0 : -2;
 }
