@@ -142,6 +142,7 @@ struct StreamCtx {
     uint8_t *out_direct = nullptr;             /* device-visible address of `data` (pinned / registered / device memory), or null */
     bool out_in_hbm = false;
     bool in_pinned = false;                    /* the input planes are pinned host memory: DMA reads them without staging */
+    bool in_mixed = false;                     /* ... locked in place by this call while the pool could also stage them: the jobs take turns */
     bool with_header = true;                   /* EncodeWhole / EncodeBatch: header + offset shift; block calls: neither */
     SRLAEncoder_EncodeBlockCallback cb = nullptr;
     /* offset left shift (srla_utility.c:177): the OR of ALL samples decides it.  Host input is encoded while the staging
@@ -177,6 +178,8 @@ struct Impl {
     bool pin_too_slow = false;          /* registration measured slower than staging would be (no huge pages): not tried again */
     bool wave_fft = false;              /* SRLA_MI355X_WAVE_FFT=1: 1024- to 8192-point items on srla_autocorr_w (register-resident transform, autocorr_wave.hip)
                                          * instead of srla_autocorr: bit-identical, measured slower -- an option, not the default */
+    uint32_t mix_num = 0, mix_den = 0;  /* SRLA_MI355X_MIX="a,b": pageable planes are locked in place and of every b jobs a are read by DMA, b - a staged (measured at "1,2": M -5 %, config 2 -7 %: off) */
+    uint32_t mix_count = 0;
     bool pack_on_n = false;             /* SRLA_MI355X_PACK_ON_N=1: block offsets + assembly on stream N behind the pricing, only the stream-out on C (measured: M device-resident -4 %, config 2 +3 %, others equal -- not the default) */
     uint32_t short_min = 786432;        /* SRLA_MI355X_SHORT_MIN: ... and no piece shorter than this many samples */
     uint32_t short_div = 4;             /* SRLA_MI355X_SHORT_DIV: a stream shorter than one job is cut into pieces of a job / this */

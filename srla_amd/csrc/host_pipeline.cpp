@@ -188,6 +188,14 @@ bool Impl::stage_input(Slot &s, const JobPlan &plan)
     if (!s.d_input.ensure((size_t)nch * total * 4)) return false;
     bool all_pinned = true;
     for (const SegPlan &sp : plan.segs) all_pinned = all_pinned && sx[sp.stream].in_pinned;
+    /* Planes that this call locked in place can be read by DMA as they are (4 bytes per sample on the link, no host work) or
+     * staged by the pool threads (2 bytes per 16-bit sample on the link, 6 bytes of host memory traffic per sample).  Neither
+     * resource alone keeps up with the device on a long stream; taking turns job by job uses both. */
+    if (all_pinned && mix_den > 0) {
+        bool ours = true;
+        for (const SegPlan &sp : plan.segs) ours = ours && sx[sp.stream].in_mixed;
+        if (ours && (mix_count++ % mix_den) >= mix_num) all_pinned = false;
+    }
     std::unique_ptr<std::atomic<uint32_t>[]> seg_or(new std::atomic<uint32_t>[nseg]);
     for (uint32_t k = 0; k < nseg; k++) seg_or[k].store(0);
     struct Task { uint32_t seg, ch, off, len; };
@@ -644,7 +652,7 @@ void Impl::classify_buffers(StreamCtx &st, std::vector<const void *> &held)
     /* memory that another handle's call locked in place (the process-wide registry of host_support.cpp) stays locked only as
      * long as somebody holds a reference: take one for this call before enqueueing DMA on it */
     auto keep = [&](const void *p) { if (const void *key = host_pin_addref(p)) held.push_back(key); };
-    st.in_pinned = false;
+    st.in_pinned = false; st.in_mixed = false;
     if (st.host_in && !force_staging) {
         st.in_pinned = true;
         const size_t before = held.size();
@@ -769,7 +777,11 @@ SRLAApiResult Impl::encode_streams(bool search)
         std::vector<const void *> held;
         ~PinGuard() { for (const void *p : held) host_pin_release(p); }
     } pins;
-    const bool want_pins = !force_staging && !pin_too_slow && (pin_inplace == 1 || (pin_inplace < 0 && pool->size() < 6));
+    /* pageable planes are locked in place when the pool is too small to stage them (all jobs by DMA then), and otherwise too
+     * when staging and DMA take turns (mix_den > 0: stage_input) */
+    const bool few_threads = pool->size() < 6;
+    const bool want_pins = !force_staging && !pin_too_slow && (pin_inplace == 1 || (pin_inplace < 0 && (few_threads || mix_den > 0)));
+    mix_count = 0;
     bool need_oracc = false;
     /* parameters under which blocks anywhere in the stream depend on the calls before them: window by window (host_chain.cpp) */
     const bool history = history_regime(search);
@@ -789,7 +801,7 @@ SRLAApiResult Impl::encode_streams(bool search)
                 if (ok && us_per_mb > 40.0) { pin_too_slow = true; ok = false; }
             }
             if (!ok) { while (pins.held.size() > before) { host_pin_release(pins.held.back()); pins.held.pop_back(); } }
-            else st.in_pinned = true;
+            else { st.in_pinned = true; st.in_mixed = pin_inplace != 1 && !few_threads; }
         }
         /* the output buffer always (unless switched off): the blocks then land in it straight from the device, which saves the
          * copy out of the staging buffers that the calling thread would otherwise make job by job (M: +5 %, and steadier) */
