@@ -59,7 +59,15 @@ typedef struct SrlaItemDesc {
     uint32_t lshift;       /* offset left shift of the item's stream (header.offset_lshift, srla_utility.c:177) */
     uint32_t forced_ltp;   /* 0, or the LTP taps the host arbitrated: bit 31 | three 6-bit fields (stream order)  */
     uint32_t seg;          /* segment (stream part) of the job the item belongs to */
+    uint32_t forced_svr;   /* 0, or 1 + row of the job's table of SVR-refined predictors the host arbitrated (host_ties.cpp) */
+    uint32_t pad0;
 } SrlaItemDesc;
+
+/* what the SVR kernels need beyond the solve chain's arguments (all optional) */
+typedef struct SrlaSvrExtra {
+    uint32_t *ties;              /* the job's near-tie list (kind 2 entries) */
+    const double *forced_rows;   /* rows of 256 doubles: predictors the host refined with its own libm (SrlaItemDesc::forced_svr) */
+} SrlaSvrExtra;
 
 /* What srla_autocorr needs to know about an item, in one record (item descriptor + the constants of its block
  * length): one load at the head of the workgroup instead of a chain of three dependent ones.  The host keeps one

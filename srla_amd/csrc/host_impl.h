@@ -92,6 +92,7 @@ struct Job {
     std::vector<SrlaAutocorrItem> class_index; /* the items grouped by FFT-size class (srla_autocorr launches per class) */
     uint32_t class_first[7] = {}, class_count[7] = {};   /* N' < 1024, 2048, 4096, 8192, 16384, 32768; N' = 1024 */
     std::vector<uint32_t> big_items;  /* items of more than 8192 samples (srla_residual_cost_big) */
+    std::vector<double> svr_rows;     /* rows of 256: SVR-refined predictors the host arbitrated (SrlaItemDesc::forced_svr) */
     uint32_t big_max_n = 0;
     uint64_t key = 0;                 /* geometry signature: equal keys => identical descriptor tables */
     bool uploaded = false;            /* the slot's device copies match the tables above */
@@ -117,6 +118,7 @@ struct Slot {
     DevBuf d_segs, d_seg_ctl;            /* SrlaSegDesc per segment; device-side segment records of srla_block_offsets */
     DevBuf d_coef_ws;                    /* SVR refinement: 64 doubles per item, the predictor between solve and quantiser */
     DevBuf d_big_scratch, d_big_items;   /* blocks above 8192 samples: FFT scratch in global memory, indices of the big items */
+    DevBuf d_svr_rows;                   /* Job::svr_rows on the device */
     DevBuf d_ties, d_tie_data;           /* near-tie list of the job (count + entries), 8 doubles per entry for LTP entries */
     PinBuf h_in, h_stream, h_info;       /* h_info: SrlaJobInfo, the per-window byte counts, SrlaSegInfo per segment */
     PinBuf h_segs;                       /* host copy of the segment table (uploaded per job) */
@@ -255,7 +257,7 @@ struct Impl {
     std::vector<StreamCtx> sx;
     /* Decisions of the host libm that differ from the device's (host_ties.cpp), by (job of the call, item): the job is
      * analysed again with them.  Chain-mode jobs use the job numbers kChainJobKey + 0..2. */
-    struct Override { int32_t forced_order = -1; uint32_t forced_ltp = 0; };
+    struct Override { int32_t forced_order = -1; uint32_t forced_ltp = 0; std::vector<double> svr_row; };
     std::map<uint64_t, Override> overrides;
     static constexpr uint32_t kChainJobKey = 0xFFFFFFF0u;
     static uint64_t override_key(uint32_t job, uint32_t item) { return ((uint64_t)job << 32) | item; }
@@ -263,6 +265,9 @@ struct Impl {
     /* Looks at the items the finished job flagged as near-ties, decides them with the host libm and records an override
      * where the device decided otherwise.  Returns the number of new overrides, -1 on error. */
     int arbitrate(Slot &s, uint32_t jobkey);
+    /* the SVR refinement of one flagged item redone with the host libm; 1: the device's predictor differs (override recorded),
+     * 0: confirmed, -1: error */
+    int arbitrate_svr(Slot &s, uint32_t jobkey, uint32_t item);
 
     /* ---- staged execution of one job (host_pipeline.cpp) --------------------------------------------------
      * Three HIP streams: W carries the wide kernels (autocorr, residual_cost), N the narrow ones

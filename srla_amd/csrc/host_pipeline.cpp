@@ -39,7 +39,7 @@ Impl::~Impl()
             s.d_input16.release(); s.d_pcm.release();
             DevBuf *db[] = { &s.d_input, &s.d_items, &s.d_cands, &s.d_windows, &s.d_results, &s.d_res_ws,
                              &s.d_blocks, &s.d_block_off, &s.d_scratch, &s.d_dbg, &s.d_lags, &s.d_err, &s.d_gamma, &s.d_class_index, &s.d_stream,
-                             &s.d_segs, &s.d_seg_ctl, &s.d_ties, &s.d_tie_data, &s.d_big_scratch, &s.d_big_items, &s.d_coef_ws };
+                             &s.d_segs, &s.d_seg_ctl, &s.d_ties, &s.d_tie_data, &s.d_svr_rows, &s.d_big_scratch, &s.d_big_items, &s.d_coef_ws };
             for (auto *b : db) b->release();
             PinBuf *pb[] = { &s.h_in, &s.h_stream, &s.h_info, &s.h_segs };
             for (auto *b : pb) b->release();
@@ -315,7 +315,7 @@ bool Impl::prepare_job(Slot &s, bool want_dbg)
     if (!s.h_info.ensure(sizeof(SrlaJobInfo) + n_win * 4 + nseg * sizeof(SrlaSegInfo))) return false;
     if (!s.d_segs.ensure(nseg * sizeof(SrlaSegDesc)) || !s.h_segs.ensure(nseg * sizeof(SrlaSegDesc))) return false;
     if (!s.d_seg_ctl.ensure(nseg * SRLA_SEGCTL_WORDS_HOST * 4)) return false;
-    if (!s.d_ties.ensure((2 * std::max<size_t>(1, n_items) + 2) * 4)) return false;
+    if (!s.d_ties.ensure((3 * std::max<size_t>(1, n_items) + 2) * 4)) return false;   /* an order, an LTP and an SVR entry per item at most */
     if (par.ltp_order > 0 && !s.d_tie_data.ensure(std::max<size_t>(1, n_items) * 8 * sizeof(double))) return false;
     {
         /* a block is never larger than its raw form (11 + n * nch * bytes): bound of the job's bytes (+ the slack between segments) */
@@ -356,6 +356,11 @@ bool Impl::prepare_job(Slot &s, bool want_dbg)
         job.uploaded = true;
     }
     HIP_OK(hipMemsetAsync(s.d_ties.p, 0, 4, W));
+    if (!job.svr_rows.empty()) {
+        /* predictors the host refined with its own libm (rare: a plain copy) */
+        if (!s.d_svr_rows.ensure(job.svr_rows.size() * sizeof(double))) return false;
+        HIP_OK(hipMemcpy(s.d_svr_rows.p, job.svr_rows.data(), job.svr_rows.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
     /* the segment table: where the blocks of each stream part go */
     {
         SrlaSegDesc *sd = s.h_segs.as<SrlaSegDesc>();
@@ -451,11 +456,12 @@ bool Impl::run_stage(Slot &s, int st, int part)
     case ST_B:
         HIP_OK(hipStreamWaitEvent(N, s.t1[ST_A], 0));
         if (have_items && jp.max_order > 0) {
+            const SrlaSvrExtra ex = { s.d_ties.as<uint32_t>(), job.svr_rows.empty() ? nullptr : s.d_svr_rows.as<double>() };
             rc |= srla_launch_lpc_solve(N, &jp, s.d_items.as<SrlaItemDesc>(), d_geoms.as<SrlaGeom>(), s.d_lags.as<double>(),
                                         s.d_err.as<double>(), d_huff.as<uint8_t>(), s.d_results.as<SrlaItemResult>(), dbg,
                                         s.d_ties.as<uint32_t>(), ev0, s.t1[ST_B], s.in_cur, s.d_coef_ws.as<double>(),
                                         par.num_svr_filter_learning_iteration, std::min<uint32_t>(par.max_num_samples_per_block, 8192u),
-                                        d_svr_scratch.p, kSvrGroups, s.d_gamma.as<double>());
+                                        d_svr_scratch.p, kSvrGroups, s.d_gamma.as<double>(), &ex);
         } else { if (ev0) HIP_OK(hipEventRecord(ev0, N)); HIP_OK(hipEventRecord(s.t1[ST_B], N)); }
         break;
     case ST_C:

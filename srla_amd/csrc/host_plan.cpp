@@ -99,7 +99,7 @@ void Impl::build_job(Job &job, const JobPlan &plan, const std::vector<uint32_t> 
     if (lens) search = false;
     job.key = key; job.uploaded = false;
     job.segs = plan.segs; job.seg_lshift = lshift; job.total = plan.total;
-    job.windows.clear(); job.cands.clear(); job.items.clear(); job.groups.clear(); job.class_index.clear();
+    job.windows.clear(); job.cands.clear(); job.items.clear(); job.groups.clear(); job.class_index.clear(); job.svr_rows.clear();
     job.seg_first_window.clear();
     job.num_slots = 0; job.res_elems = 0; job.analyzed_samples = 0;
     job.keep_residuals = keep_residuals || keep_residuals_always;

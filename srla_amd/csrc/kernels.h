@@ -68,7 +68,8 @@ int srla_launch_lpc_solve(hipStream_t stream, const SrlaJobParams *jp, const Srl
                           const int32_t *input, double *coef_ws /* 64 doubles per item (256 for orders above 64) */,
                           uint32_t svr_iterations /* 0: off */, uint32_t svr_n_cap /* longest LDS-resident block of the job */,
                           void *svr_scratch, uint32_t svr_groups /* srla_svr_refine_big: groups x srla_svr_big_scratch_bytes(max block) */,
-                          double *gamma_ws /* [order][item] like err_ws: reflection coefficients (orders 8 .. 64: the three-launch chain) */);
+                          double *gamma_ws /* [order][item] like err_ws: reflection coefficients (orders 8 .. 64: the three-launch chain) */,
+                          const SrlaSvrExtra *svr_extra /* may be null */);
 size_t srla_svr_big_scratch_bytes(uint32_t n_max);
 int srla_launch_residual_cost(hipStream_t stream, int rclass, const SrlaJobParams *jp, const int32_t *input,
                               const SrlaItemDesc *items, const SrlaGeom *geoms, const SrlaLdsPlan *plan,

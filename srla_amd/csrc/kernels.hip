@@ -695,12 +695,12 @@ __global__ __launch_bounds__(NTK) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
  * K2p: srla_pitch_solve -- one lane per item (lpc.c:1473-1649, srla_encoder.c:1031-1047)
  * ============================================================================================== */
 /* Near-ties (H2): an item whose decision hangs on a libm function the device cannot reproduce bit for bit is appended to
- * the job's tie list -- ties[0] = count, ties[1 + k] = item | kind << 31 (kind 1: LTP taps) -- and, for LTP items, the
+ * the job's tie list -- ties[0] = count, ties[1 + k] = item | kind << 30 (kind 0: LPC order, 1: LTP taps, 2: SVR refinement) -- and, for LTP items, the
  * numbers the host needs to redo the 3x3 solve with its own pow() go to tie_data[8 k ..]. */
 __device__ __forceinline__ uint32_t tie_append(uint32_t *__restrict__ ties, uint32_t item, uint32_t kind)
 {
     const uint32_t k = atomicAdd(&ties[0], 1u);
-    ties[1u + k] = item | (kind << 31);
+    ties[1u + k] = item | (kind << 30);
     return k;
 }
 
@@ -2368,12 +2368,13 @@ __global__ __launch_bounds__(NT) void srla_residual_cost_big(
 #define SVR_P  64           /* orders up to 64 (presets 0..4) */
 #define SVR_PS 65           /* row stride of the matrix in LDS */
 
-__device__ __forceinline__ double svr_rgr_mean_code_length(double mean_abs_error, bool *near_tie)
+/* logscale: 1.0 (exact) in production; the tie tests falsify the device's log with it (SrlaJobParams) */
+__device__ __forceinline__ double svr_rgr_mean_code_length(double mean_abs_error, bool *near_tie, double logscale)
 {
     /* lpc.c:1023-1033 with BITS_PER_SAMPLE = 16 (:1042) */
     const double intmean = mean_abs_error * 65536.0;
     const double rho = 1.0 / (1.0 + intmean);
-    const double l2 = log(log(0.5127629514) / log(1.0 - rho)) * 1.4426950408889634;
+    const double l2 = (log(log(0.5127629514) / log(1.0 - rho)) * logscale) * 1.4426950408889634;
     const double m = (0.0 > l2) ? 0.0 : l2;
     const uint32_t k2 = (uint32_t)m;
     if (m > 0.5 && fabs(m - floor(m + 0.5)) < 1e-9) *near_tie = true;       /* the integer part hangs on log()'s last bits */
@@ -2391,10 +2392,16 @@ template <bool BIG>
 __device__ void svr_refine_item(const SrlaJobParams &jp, const int32_t *__restrict__ input, const SrlaItemDesc &it, SrlaItemResult *out,
                                 double *row, const uint32_t iterations, int32_t *xi, double *rr, double *cov, const uint32_t PS,
                                 double *low, double *r_vec, double *delta, double *coef, double *init_coef, double *best_coef,
-                                double *s_scalar, long long *s_lag, uint32_t *s_flag)
+                                double *s_scalar, long long *s_lag, uint32_t *s_flag, const SrlaSvrExtra ex, const uint32_t item_idx)
 {
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t p = out->lpc_order;
+    if (it.forced_svr != 0 && ex.forced_rows != nullptr) {
+        /* the host has redone the refinement with its libm (host_ties.cpp) */
+        __syncthreads();
+        for (uint32_t i = tid; i < p; i += SVR_NT) row[i] = ex.forced_rows[(size_t)(it.forced_svr - 1u) * 256u + i];
+        return;
+    }
     const InputView iv = input_view(jp, it.lshift);
     const uint32_t n = it.n;
     const int32_t *in = input + it.sample_off;
@@ -2533,7 +2540,7 @@ __device__ void svr_refine_item(const SrlaJobParams &jp, const int32_t *__restri
             __syncthreads();
             if (tid == 0) {
                 bool tie = false;
-                const double obj = svr_rgr_mean_code_length(s_scalar[0] / (double)n, &tie);
+                const double obj = svr_rgr_mean_code_length(s_scalar[0] / (double)n, &tie, jp.tie_logscale);
                 /* cov delta = r_vec by the factor, lpc.c:605-631 */
                 for (uint32_t i = 0; i < p; i++) {
                     double sum = r_vec[i];
@@ -2552,7 +2559,7 @@ __device__ void svr_refine_item(const SrlaJobParams &jp, const int32_t *__restri
             const double obj = s_scalar[1];
             /* comparisons of objective values that differ by less than the device's log / pow can be trusted for */
             if (tid == 0) {
-                const double tol = 1e-9;
+                const double tol = jp.tie_rel;
                 if ((obj != min_obj && fabs(obj - min_obj) <= tol * fabs(obj)) || (obj != prev_obj && fabs(obj - prev_obj) <= tol * fabs(obj))
                     || fabs(fabs(prev_obj - obj) - 1e-8) <= 1e-8 * tol) s_flag[2] = 1;
             }
@@ -2568,13 +2575,16 @@ __device__ void svr_refine_item(const SrlaJobParams &jp, const int32_t *__restri
     }
     __syncthreads();
     for (uint32_t i = tid; i < p; i += SVR_NT) row[i] = best_coef[i];
-    if (tid == 0 && s_flag[2]) out->flags |= SRLA_ITEM_SVR_TIE;
+    if (tid == 0 && s_flag[2]) {
+        out->flags |= SRLA_ITEM_SVR_TIE;
+        if (ex.ties != nullptr) (void)tie_append(ex.ties, item_idx, 2u);
+    }
 }
 
 
 __global__ __launch_bounds__(SVR_NT) void srla_svr_refine(
     SrlaJobParams jp, const int32_t *__restrict__ input, const SrlaItemDesc *__restrict__ items,
-    SrlaItemResult *__restrict__ results, double *__restrict__ coef_ws, uint32_t ws_stride, uint32_t iterations, uint32_t n_cap)
+    SrlaItemResult *__restrict__ results, double *__restrict__ coef_ws, uint32_t ws_stride, uint32_t iterations, uint32_t n_cap, SrlaSvrExtra ex)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     int32_t *xi = (int32_t *)lds;                                        /* the pre-emphasised (+ LTP) block */
@@ -2592,7 +2602,7 @@ __global__ __launch_bounds__(SVR_NT) void srla_svr_refine(
     const SrlaItemDesc it = items[item_idx];
     if (p == 0 || p > SVR_P || it.n > n_cap) return;                     /* the others: srla_svr_refine_big */
     svr_refine_item<false>(jp, input, it, out, coef_ws + (size_t)item_idx * ws_stride, iterations, xi, rr, cov, SVR_PS,
-                           low, r_vec, delta, coef, init_coef, best_coef, s_scalar, s_lag, s_flag);
+                           low, r_vec, delta, coef, init_coef, best_coef, s_scalar, s_lag, s_flag, ex, item_idx);
 }
 
 /* per workgroup in `scratch`: n_max int32, n_max doubles, SVR_PMAX x (SVR_PMAX + 1) doubles */
@@ -2608,7 +2618,7 @@ extern "C" size_t srla_svr_big_scratch_bytes(uint32_t n_max)
 __global__ __launch_bounds__(SVR_NT) void srla_svr_refine_big(
     SrlaJobParams jp, const int32_t *__restrict__ input, const SrlaItemDesc *__restrict__ items,
     SrlaItemResult *__restrict__ results, double *__restrict__ coef_ws, uint32_t ws_stride, uint32_t iterations, uint32_t n_cap,
-    unsigned char *__restrict__ scratch, uint32_t n_max)
+    unsigned char *__restrict__ scratch, uint32_t n_max, SrlaSvrExtra ex)
 {
     __shared__ double vec[6][SVR_PMAX];
     __shared__ double s_scalar[2];
@@ -2624,7 +2634,7 @@ __global__ __launch_bounds__(SVR_NT) void srla_svr_refine_big(
         const SrlaItemDesc it = items[item_idx];
         if (p == 0 || (p <= SVR_P && it.n <= n_cap)) continue;           /* done by srla_svr_refine */
         svr_refine_item<true>(jp, input, it, out, coef_ws + (size_t)item_idx * ws_stride, iterations, xi, rr, cov, SVR_PMAX + 1,
-                              vec[0], vec[1], vec[2], vec[3], vec[4], vec[5], s_scalar, s_lag, s_flag);
+                              vec[0], vec[1], vec[2], vec[3], vec[4], vec[5], s_scalar, s_lag, s_flag, ex, item_idx);
     }
 }
 
@@ -3506,10 +3516,12 @@ extern "C" int srla_launch_lpc_solve(hipStream_t stream, const SrlaJobParams *jp
                                      const SrlaGeom *geoms, const double *lags_ws, double *err_ws, const uint8_t *huff_len,
                                      SrlaItemResult *results, double *dbg, uint32_t *ties, hipEvent_t ev_start, hipEvent_t ev_stop,
                                      const int32_t *input, double *coef_ws, uint32_t svr_iterations, uint32_t svr_n_cap,
-                                     void *svr_scratch, uint32_t svr_groups, double *gamma_ws)
+                                     void *svr_scratch, uint32_t svr_groups, double *gamma_ws, const SrlaSvrExtra *svr_extra)
 {
     if (jp->num_items == 0) return 0;
     const uint32_t p = jp->max_order;
+    SrlaSvrExtra ex = { nullptr, nullptr };
+    if (svr_extra) ex = *svr_extra;
     const bool three = !g_tune.solve_onepass && gamma_ws != nullptr;   /* orders 8 .. 64: errvars + order_select + taps */
     if (svr_iterations > 0) {
         /* solve (taps left unquantised) -> SVR refinement -> quantiser */
@@ -3554,14 +3566,14 @@ extern "C" int srla_launch_lpc_solve(hipStream_t stream, const SrlaJobParams *jp
                 (void)hipGetLastError();
             }
             hipLaunchKernelGGL(srla_svr_refine, dim3(8u * ((jp->num_items + 7u) >> 3)), dim3(SVR_NT), lds_svr, stream, *jp, input, items, results, coef_ws,
-                               ws_stride, svr_iterations, svr_n_cap);
+                               ws_stride, svr_iterations, svr_n_cap, ex);
         }
         if (p > 64 || jp->max_block > svr_n_cap) {
             /* orders 128 / 255, blocks above 8192 samples: persistent workgroups on global scratch */
             if (svr_scratch == nullptr || svr_groups == 0) return -1;
             const uint32_t groups = jp->num_items < svr_groups ? jp->num_items : svr_groups;
             hipLaunchKernelGGL(srla_svr_refine_big, dim3(groups), dim3(SVR_NT), 0, stream, *jp, input, items, results, coef_ws,
-                               ws_stride, svr_iterations, svr_n_cap, (unsigned char *)svr_scratch, jp->max_block);
+                               ws_stride, svr_iterations, svr_n_cap, (unsigned char *)svr_scratch, jp->max_block, ex);
         }
         SET_LDS_ATTR(srla_lpc_quantize_ws);
         hipExtLaunchKernelGGL(srla_lpc_quantize_ws, g64s, blks, 512 + (p < 64 ? 64 : p) * 4 * 64, stream, nullptr, ev_stop, 0, *jp, coef_ws, ws_stride, huff_len, results);

@@ -57,6 +57,22 @@ def test_falsified_device_decisions_are_overruled(product, monkeypatch, name, ho
             assert st.num_tie_overrides > 0 and st.num_restarts > 0, (name, st.num_tie_items, st.num_tie_resolved)
 
 
+def test_falsified_svr_objectives_are_overruled(product, monkeypatch):
+    """--svr-filter-learning-iteration: the refinement's comparisons of objective values (lpc.c:1023-1033, 1112-1121) hang on
+    log() and pow().  With the device's log falsified and the band widened every refined item is flagged, the host redoes the
+    refinement with its libm (host_ties.cpp: arbitrate_svr) and, where a single bit of the predictor differs, its own is used."""
+    monkeypatch.setenv("SRLA_MI355X_TIE_TEST", "0.05,1e-9,1.01,0.0")
+    cli = dict(preset=2, max_block=2048, divisions=1, svr_iterations=3)
+    for kind, n in ((helpers.MUSIC, 100000), (helpers.VARIED, 98304)):
+        pcm = helpers.synth(kind, 33, 48000, 2, n)
+        got, st = _run(product, pcm, **cli)
+        want = helpers.Oracle(2, **cli).encode_whole(pcm)
+        assert np.array_equal(got, want), (kind, n)
+        assert st.num_svr_tie_items > 0 and st.num_tie_resolved > 0, (st.num_svr_tie_items, st.num_tie_resolved)
+        if kind == helpers.MUSIC:
+            assert st.num_tie_overrides > 0 and st.num_restarts > 0, (st.num_tie_items, st.num_tie_overrides)
+
+
 def test_block_calls_arbitrate_too(product, monkeypatch):
     monkeypatch.setenv("SRLA_MI355X_TIE_TEST", "0.05,0.25,1.01,0.1")
     cli = dict(preset=4, max_block=4096, divisions=0, ltp_order=3)
