@@ -395,7 +395,9 @@ def main(argv=None):
         elapsed = float(t.item())
         # every rank's own time inside the library per step and how its buffers reached the device (for the N > 1 line)
         L.SRLAMI355X_GetStats(enc, C.byref(st), 0)
-        mine = torch.tensor([st.total_ms / max(1, args.steps), float(st.num_inplace_pins > 0), float(st.num_inplace_out_pins > 0)],
+        # (every rank checks its own streams: they decode back to its input -- oracle decoder = checker only)
+        mine_ok = all(bool((helpers.oracle_decode(outs[f][:out_sizes[f]].copy()) == pcms[f]).all()) for f in range(files))
+        mine = torch.tensor([st.total_ms / max(1, args.steps), float(st.num_inplace_pins > 0), float(st.num_inplace_out_pins > 0), float(mine_ok)],
                             dtype=torch.float64, device="cpu" if shared_gpu else "cuda")
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
@@ -440,6 +442,7 @@ def main(argv=None):
             "per_rank": None if rank_ms is None else {
                 "encode_ms_per_step_min": round(min(r[0] for r in rank_ms), 3), "encode_ms_per_step_max": round(max(r[0] for r in rank_ms), 3),
                 "ranks_input_locked_in_place": int(sum(r[1] for r in rank_ms)), "ranks_output_locked_in_place": int(sum(r[2] for r in rank_ms)),
+                "ranks_lossless_roundtrip": int(sum(r[3] for r in rank_ms)),
                 "host_pool_threads_per_rank": pack_threads},
             "tie_items": int(st.num_tie_items), "tie_resolved": int(st.num_tie_resolved), "tie_overrides": int(st.num_tie_overrides),
             # how the pageable buffers reached the device: staged through pinned buffers by the pool threads, or -- when the

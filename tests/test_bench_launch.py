@@ -57,3 +57,19 @@ def test_two_ranks_on_one_shared_gpu():
                 env_extra={"SRLA_BENCH_SHARED_GPU": "1"}, timeout=600)
     assert line["n_gpus"] == 2 and line["lossless_roundtrip"] is True and line["value"] > 0
     assert "EncodeWhole" in line["config"]["workload"]
+
+
+@pytest.mark.gpu
+def test_four_ranks_with_the_host_budget_of_an_eight_gpu_node():
+    """8 ranks share 16 CPUs on the pod: one pool thread per rank (--pack-threads 1).  Four ranks on the one GPU of the test box
+    with that budget: every rank's streams decode back to its input, no rank stages its pageable planes (they are locked in
+    place and read by DMA, the output is written in place by the device), and the line says so."""
+    line = _run(["--gpus", "4", "--steps", "2", "--warmup", "1", "--seconds", "120", "--no-cpu-baseline", "--pack-threads", "1"],
+                env_extra={"SRLA_BENCH_SHARED_GPU": "1"}, timeout=900)
+    assert line["n_gpus"] == 4 and line["lossless_roundtrip"] is True and line["value"] > 0
+    pr = line["per_rank"]
+    assert pr["ranks_lossless_roundtrip"] == 4
+    assert pr["ranks_input_locked_in_place"] == 4 and pr["ranks_output_locked_in_place"] == 4
+    assert pr["host_pool_threads_per_rank"] == 1 and line["host_pool_threads"] == 1
+    assert 0 < pr["encode_ms_per_step_min"] <= pr["encode_ms_per_step_max"]
+    assert "page-locked in place" in line["host_buffers"]
