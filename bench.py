@@ -220,6 +220,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-numa-pin", action="store_true", help="do not restrict the process to the GPU-local NUMA node")
     ap.add_argument("--pack-threads", type=int, default=0, help="host pool threads (staging copies; default: min(8, usable CPUs / ranks))")
     ap.add_argument("--pinned-io", action="store_true", help="headline with pinned input planes and a pinned output buffer (reported in config.workload)")
+    ap.add_argument("--no-extras", action="store_true", help="only the timed steps: no device_resident / stream_60s / stream_10s sections (profiler runs)")
     ap.add_argument("--dry-run", action="store_true", help="launch / rendezvous / reduce only, no GPU work (CPU test of the N-rank flow)")
     return ap.parse_args(argv)
 
@@ -452,7 +453,7 @@ def main(argv=None):
                 "staged through pinned buffers by %d host threads" % pack_threads,
                 "page-locked in place per call, written by the device" if st.num_inplace_out_pins else "copied out of pinned staging buffers")),
         })
-        if world == 1 and files == 1:
+        if world == 1 and files == 1 and not args.no_extras:
             # the same encode with the samples resident in HBM and a pinned output buffer (what a caller that already holds
             # the samples on the device gets): reported beside `value`, never as `value`
             d_pcm = torch.from_numpy(pcms[0]).cuda()
@@ -472,7 +473,7 @@ def main(argv=None):
             line["device_resident"] = {"value": round(n / dt / 1e6, 3), "unit": "Msamples/s", "ms_per_call": round(1e3 * dt, 3),
                                        "same_bytes": bool(np.array_equal(out_t.numpy()[:dsz.value], streams[0])),
                                        "note": "SRLAMI355X_EncodeWholeDevice: samples resident in HBM, pinned output buffer; median of %d calls" % reps}
-        if world == 1 and files == 1:
+        if world == 1 and files == 1 and not args.no_extras:
             # SURVEY 8d's own input length (60 s; and 10 s) through the same unchanged SRLAEncoder_EncodeWhole, pageable host
             # memory to pageable host memory: short streams cannot hide the pipeline's fill and drain.  Beside `value`, never it.
             for secs in (60, 10):
