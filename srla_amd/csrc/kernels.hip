@@ -942,7 +942,10 @@ __global__ __launch_bounds__(WAVE) void srla_order_select(
     const double *__restrict__ err_ws, SrlaItemResult *__restrict__ results, double *__restrict__ dbg,
     uint32_t *__restrict__ ties)
 {
-    const uint32_t idx = blockIdx.x, lane = threadIdx.x;
+    /* (neighbouring items share the 64-byte sectors of the [order][item] table: they go to the same XCD, hence the same L2 --
+     * dealt round robin over the XCDs every sector was fetched from HBM eight times, 255 MB per launch at -V 2) */
+    const uint32_t idx = xcd_position(blockIdx.x, jp.num_items), lane = threadIdx.x;
+    if (idx >= jp.num_items) return;
     const SrlaItemDesc it = items[idx];
     const double comp = geoms[it.geom].welch_comp;
     const uint32_t p = jp.max_order, n = it.n, bps = jp.bits_per_sample;
@@ -1228,12 +1231,19 @@ __global__ __launch_bounds__(WAVE) void srla_lpc_taps(SrlaJobParams jp, const do
     const uint32_t order = out->lpc_order;
     const bool silent = fabs(err_ws[idx]) < (double)FLT_EPSILON;
     const double *gam = gamma_ws + idx;
+    /* every reflection coefficient the wavefront can need, fetched at once (one coalesced load per step, all in flight together:
+     * fetched step by step inside the branch below they were 63 dependent round trips, 50 us of the launch) */
+    uint32_t top = order;
+    for (int off = 32; off > 0; off >>= 1) { const uint32_t o2 = (uint32_t)__shfl_xor((int)top, off, WAVE); top = (o2 > top) ? o2 : top; }
+    double g[P];
+#pragma unroll
+    for (int k = 0; k < P; k++) g[k] = ((uint32_t)k < top) ? gam[(size_t)k * stride] : 0.0;
     double a[P + 2];
-    a[0] = 1.0; a[1] = gam[0]; a[2] = 0.0;
+    a[0] = 1.0; a[1] = g[0]; a[2] = 0.0;
 #pragma unroll
     for (int k = 1; k < P; k++) {
         if ((uint32_t)k < order) {                           /* (a wavefront goes as far as the highest order among its items) */
-            const double gamma = gam[(size_t)k * stride];
+            const double gamma = g[k];
 #pragma unroll
             for (int i = 0; i <= (k + 1) / 2; i++) {
                 const int j = k + 1 - i;
@@ -3533,7 +3543,7 @@ extern "C" int srla_launch_lpc_solve(hipStream_t stream, const SrlaJobParams *jp
         if (three) {                                                                                                     \
             SET_LDS_ATTR(srla_lpc_taps<PP>);                                                                             \
             hipExtLaunchKernelGGL(srla_lpc_errvars<PP>, g64s, blks, 0, stream, ev_start, nullptr, 0, *jp, lags_ws, err_ws, gamma_ws); \
-            hipLaunchKernelGGL(srla_order_select, dim3(jp->num_items), blks, 0, stream, *jp, items, geoms, err_ws, results, dbg, ties); \
+            hipLaunchKernelGGL(srla_order_select, dim3(8u * ((jp->num_items + 7u) >> 3)), blks, 0, stream, *jp, items, geoms, err_ws, results, dbg, ties); \
             hipLaunchKernelGGL(srla_lpc_taps<PP>, g64s, blks, lds, stream, *jp, err_ws, gamma_ws, huff_len, results, coef_ws); \
         } else {                                                                                                         \
             SET_LDS_ATTR(srla_lpc_solve_regs<PP>);                                                                       \
@@ -3547,14 +3557,14 @@ extern "C" int srla_launch_lpc_solve(hipStream_t stream, const SrlaJobParams *jp
             SET_LDS_ATTR(srla_lpc_recursion<64>);
             SET_LDS_ATTR(srla_lpc_quantize<64>);
             hipExtLaunchKernelGGL(srla_lpc_recursion<64>, g64s, blks, lds, stream, ev_start, nullptr, 0, *jp, lags_ws, err_ws);
-            hipLaunchKernelGGL(srla_order_select, dim3(jp->num_items), blks, 0, stream, *jp, items, geoms, err_ws, results, dbg, ties);
+            hipLaunchKernelGGL(srla_order_select, dim3(8u * ((jp->num_items + 7u) >> 3)), blks, 0, stream, *jp, items, geoms, err_ws, results, dbg, ties);
             hipLaunchKernelGGL(srla_lpc_quantize<64>, g64s, blks, lds, stream, *jp, lags_ws, huff_len, results, coef_ws);
         } else {
             const uint32_t lds = (2 * p + 3) * 8 * 32;
             SET_LDS_ATTR(srla_lpc_recursion<32>);
             SET_LDS_ATTR(srla_lpc_quantize<32>);
             hipExtLaunchKernelGGL(srla_lpc_recursion<32>, dim3((jp->num_items + 31) / 32), blks, lds, stream, ev_start, nullptr, 0, *jp, lags_ws, err_ws);
-            hipLaunchKernelGGL(srla_order_select, dim3(jp->num_items), blks, 0, stream, *jp, items, geoms, err_ws, results, dbg, ties);
+            hipLaunchKernelGGL(srla_order_select, dim3(8u * ((jp->num_items + 7u) >> 3)), blks, 0, stream, *jp, items, geoms, err_ws, results, dbg, ties);
             hipLaunchKernelGGL(srla_lpc_quantize<32>, dim3((jp->num_items + 31) / 32), blks, lds, stream, *jp, lags_ws, huff_len, results, coef_ws);
         }
 #undef SVR_PATH
@@ -3587,7 +3597,7 @@ extern "C" int srla_launch_lpc_solve(hipStream_t stream, const SrlaJobParams *jp
         if (three) {                                                                                                     \
             SET_LDS_ATTR(srla_lpc_taps<PP>);                                                                             \
             hipExtLaunchKernelGGL(srla_lpc_errvars<PP>, g64, blk, 0, stream, ev_start, nullptr, 0, *jp, lags_ws, err_ws, gamma_ws); \
-            hipLaunchKernelGGL(srla_order_select, dim3(jp->num_items), blk, 0, stream, *jp, items, geoms, err_ws, results, dbg, ties); \
+            hipLaunchKernelGGL(srla_order_select, dim3(8u * ((jp->num_items + 7u) >> 3)), blk, 0, stream, *jp, items, geoms, err_ws, results, dbg, ties); \
             hipExtLaunchKernelGGL(srla_lpc_taps<PP>, g64, blk, lds, stream, nullptr, ev_stop, 0, *jp, err_ws, gamma_ws, huff_len, results, (double *)nullptr); \
         } else {                                                                                                         \
             SET_LDS_ATTR(srla_lpc_solve_regs<PP>);                                                                       \
@@ -3604,14 +3614,14 @@ extern "C" int srla_launch_lpc_solve(hipStream_t stream, const SrlaJobParams *jp
         SET_LDS_ATTR(srla_lpc_recursion<64>);
         SET_LDS_ATTR(srla_lpc_quantize<64>);
         hipExtLaunchKernelGGL(srla_lpc_recursion<64>, g64, blk, lds, stream, ev_start, nullptr, 0, *jp, lags_ws, err_ws);
-        hipLaunchKernelGGL(srla_order_select, dim3(jp->num_items), blk, 0, stream, *jp, items, geoms, err_ws, results, dbg, ties);
+        hipLaunchKernelGGL(srla_order_select, dim3(8u * ((jp->num_items + 7u) >> 3)), blk, 0, stream, *jp, items, geoms, err_ws, results, dbg, ties);
         hipExtLaunchKernelGGL(srla_lpc_quantize<64>, g64, blk, lds, stream, nullptr, ev_stop, 0, *jp, lags_ws, huff_len, results, (double *)nullptr);
     } else {
         const uint32_t lds = (2 * p + 3) * 8 * 32;
         SET_LDS_ATTR(srla_lpc_recursion<32>);
         SET_LDS_ATTR(srla_lpc_quantize<32>);
         hipExtLaunchKernelGGL(srla_lpc_recursion<32>, dim3((jp->num_items + 31) / 32), blk, lds, stream, ev_start, nullptr, 0, *jp, lags_ws, err_ws);
-        hipLaunchKernelGGL(srla_order_select, dim3(jp->num_items), blk, 0, stream, *jp, items, geoms, err_ws, results, dbg, ties);
+        hipLaunchKernelGGL(srla_order_select, dim3(8u * ((jp->num_items + 7u) >> 3)), blk, 0, stream, *jp, items, geoms, err_ws, results, dbg, ties);
         hipExtLaunchKernelGGL(srla_lpc_quantize<32>, dim3((jp->num_items + 31) / 32), blk, lds, stream, nullptr, ev_stop, 0, *jp, lags_ws, huff_len, results, (double *)nullptr);
     }
 #undef REGS_PATH
