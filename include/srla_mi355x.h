@@ -231,9 +231,11 @@ struct SRLAMI355XStats {
     double   pitch_ms;              /* srla_pitch_solve, timed jobs only (jobs whose stage A runs in two parts; otherwise inside autocorr_ms) */
 };
 /* reasons (SRLAMI355XStats::nonidentical_reasons, SRLAMI355X_NonIdenticalReasons) */
-#define SRLAMI355X_NONIDENTICAL_SVR_HISTORY 1u  /* SVR refinement on and blocks whose analysis depends on the call before them (an odd-length
-                                                 * last window, an odd minimum block, the long-term predictor with blocks of at most 256
-                                                 * samples): the refinement's residual is what such a block inherits in the reference (lpc.c:1047) */
+#define SRLAMI355X_NONIDENTICAL_SVR_HISTORY 1u  /* SVR refinement on, in a window whose blocks depend on the calls before them (odd lengths,
+                                                 * short LTP blocks): an item whose objective comparisons the HOST libm decided differently
+                                                 * from the device gets the host's predictor, but leaves the transform's words -- not the
+                                                 * refinement's residual (lpc.c:1047) -- for the blocks after it.  Counted where it happens
+                                                 * (never seen on real input); the parameters alone no longer carry this reason. */
 #define SRLAMI355X_NONIDENTICAL_LTP_TINY_BUFFER 2u  /* long-term predictor on an encoder created for blocks of at most 256 samples: the
                                                      * reference's FFT buffer is then shorter than the 263 lags it copies out of it
                                                      * (lpc.c:371-373 reads beyond the buffer, into the transform's scratch area) */

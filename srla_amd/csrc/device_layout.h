@@ -60,6 +60,11 @@ typedef struct SrlaItemDesc {
     uint32_t forced_ltp;   /* 0, or the LTP taps the host arbitrated: bit 31 | three 6-bit fields (stream order)  */
     uint32_t seg;          /* segment (stream part) of the job the item belongs to */
     uint32_t forced_svr;   /* 0, or 1 + row of the job's table of SVR-refined predictors the host arbitrated (host_ties.cpp) */
+    /* chain / history mode with the SVR refinement on (host_chain.cpp): what the reference's persistent buffer holds in its
+     * first n words once the item's analysis is over -- the refinement's `residual` (lpc.c:1047,1095-1106), or, where the
+     * refinement does not run (order 0, singular matrix), what the LPC-pass autocorrelation left there */
+    uint32_t svr_dump;     /* 1 + pool offset of the n words this item leaves, 0: not kept */
+    uint32_t svr_under;    /* 1 + pool offset of the buffer its LPC-pass call left */
     uint32_t pad0;
 } SrlaItemDesc;
 
@@ -67,6 +72,9 @@ typedef struct SrlaItemDesc {
 typedef struct SrlaSvrExtra {
     uint32_t *ties;              /* the job's near-tie list (kind 2 entries) */
     const double *forced_rows;   /* rows of 256 doubles: predictors the host refined with its own libm (SrlaItemDesc::forced_svr) */
+    double *chain_pool;          /* chain / history mode: where the calls leave their buffers (SrlaItemDesc::svr_dump / svr_under) */
+    const uint32_t *select;      /* chain / history mode with SVR on: the solve chain runs round by round; only the items with */
+    uint32_t round;              /* select[item] == round take part (null: all) */
 } SrlaSvrExtra;
 
 /* What srla_autocorr needs to know about an item, in one record (item descriptor + the constants of its block

@@ -26,7 +26,8 @@ void Impl::chain_append(uint32_t jobidx, const Job &job, const std::function<boo
                     for (int64_t j = (int64_t)chain_calls.size() - 1; j >= 0; j--)
                         if (chain_calls[(size_t)j].nfft > mid) { c.src = (int32_t)j; break; }
                     if (c.src >= 0 && chain_calls[(size_t)c.src].job == jobidx) {
-                        /* inside a round the LTP-lag launches come first, then the pitch solve, then the LPC-lag launches */
+                        /* inside a round the LTP-lag launches come first, then the pitch solve, then the LPC-lag launches
+                         * (and, with SVR on, the solve chain and the refinement: pass 2) */
                         const ChainCall &sc = chain_calls[(size_t)c.src];
                         const uint32_t need = (pass == 0 && sc.pass == 1) ? sc.round : sc.round + 1;
                         round = std::max(round, need);
@@ -51,12 +52,22 @@ void Impl::chain_append(uint32_t jobidx, const Job &job, const std::function<boo
                 c.round = round;
                 if (pass == 1) pass1_round[item] = round;
                 chain_calls.push_back(c);
+                if (pass == 0 && chain_svr()) {
+                    /* LPCCalculator_CalculateLPCCoefficientsSVR keeps its `residual` in the same persistent buffer
+                     * (lpc.c:1047): after the item's analysis the first n words are the refinement's (or, where it does not
+                     * run, still the transform's: the kernel copies them) -- a writer of n words in the sequence of calls */
+                    ChainCall v{};
+                    v.job = jobidx; v.item = item; v.pass = 2; v.n = cd.n; v.nfft = cd.n; v.src = (int32_t)chain_calls.size() - 1;
+                    v.dump = (uint32_t)chain_pool_used; chain_pool_used += (cd.n + 1u) & ~1u;
+                    v.round = round;
+                    chain_calls.push_back(v);
+                }
             }
         }
     }
 }
 
-void Impl::chain_build(uint32_t jobidx, const Job &job, ChainJob &cj)
+void Impl::chain_build(uint32_t jobidx, Job &job, ChainJob &cj)
 {
     struct Entry { uint32_t round, pass, cls; SrlaAutocorrItem ai; };
     std::vector<Entry> entries;
@@ -73,9 +84,18 @@ void Impl::chain_build(uint32_t jobidx, const Job &job, ChainJob &cj)
     };
     auto cls_of = [](uint32_t nfft) { return (nfft <= 1024u) ? 0u : ((nfft <= 2048u) ? 1u : ((nfft <= 4096u) ? 2u : ((nfft <= 8192u) ? 3u : ((nfft <= 16384u) ? 4u : 5u)))); };
     cj.select.assign(std::max<size_t>(1, job.items.size()), 0xFFFFFFFFu);
+    cj.select_b.assign(std::max<size_t>(1, job.items.size()), 0u);
     cj.rounds = 1;
+    for (SrlaItemDesc &it : job.items) { it.svr_dump = 0; it.svr_under = 0; }
     for (const ChainCall &c : chain_calls) {
         if (c.job != jobidx) continue;
+        if (c.pass == 2) {
+            /* the refinement's place in the sequence: where the item leaves its n words, and what lies under them */
+            job.items[c.item].svr_dump = c.dump + 1u;
+            job.items[c.item].svr_under = chain_calls[(size_t)c.src].dump + 1u;
+            cj.select_b[c.item] = c.round;
+            continue;
+        }
         SrlaAutocorrItem ai = make(c.item);
         ai.chain_dump = c.dump + 1u;
         ai.chain_lags = c.lags;
@@ -133,7 +153,13 @@ bool Impl::chain_stage_a(Slot &s, uint32_t jobidx, const ChainJob &cj)
     static const int kClass[4] = { 0, 1, 2, 4 };
     int rc = 0;
     size_t li = 0;
-    for (uint32_t r = 0; r < cj.rounds; r++)
+    const bool svr_rounds = chain_svr() && !s.job.groups.empty() && jp.max_order > 0;
+    if (svr_rounds) {
+        if (!d_chain_select_b[jobidx].ensure(cj.select_b.size() * 4)) return false;
+        HIP_OK(hipMemcpy(d_chain_select_b[jobidx].p, cj.select_b.data(), cj.select_b.size() * 4, hipMemcpyHostToDevice));
+    }
+    s.b_done = false;
+    for (uint32_t r = 0; r < cj.rounds; r++) {
         for (int pass = (par.ltp_order > 0) ? 1 : 0; pass >= 0; pass--) {
             bool any = false;
             for (; li < cj.launches.size() && cj.launches[li].round == r && cj.launches[li].pass == (uint32_t)pass; li++) {
@@ -153,6 +179,18 @@ bool Impl::chain_stage_a(Slot &s, uint32_t jobidx, const ChainJob &cj)
                 rc |= srla_launch_pitch_solve(W, &jp, s.d_items.as<SrlaItemDesc>(), s.d_lags.as<double>(), s.d_results.as<SrlaItemResult>(), nullptr, nullptr,
                                               d_chain_select[jobidx].as<uint32_t>(), r, s.d_ties.as<uint32_t>(), s.d_tie_data.as<double>());
         }
+        if (svr_rounds) {
+            /* SVR on: what a later call inherits may be this round's refinements (lpc.c:1047), so the solve chain of the round's
+             * items runs here, between the rounds of autocorrelations, instead of once for the whole job */
+            const SrlaSvrExtra ex = { s.d_ties.as<uint32_t>(), s.job.svr_rows.empty() ? nullptr : s.d_svr_rows.as<double>(), d_chain_pool.as<double>(),
+                                      d_chain_select_b[jobidx].as<uint32_t>(), r };
+            rc |= srla_launch_lpc_solve(W, &jp, s.d_items.as<SrlaItemDesc>(), d_geoms.as<SrlaGeom>(), s.d_lags.as<double>(), s.d_err.as<double>(),
+                                        d_huff.as<uint8_t>(), s.d_results.as<SrlaItemResult>(), nullptr, s.d_ties.as<uint32_t>(), nullptr, nullptr,
+                                        s.in_cur, s.d_coef_ws.as<double>(), par.num_svr_filter_learning_iteration,
+                                        std::min<uint32_t>(par.max_num_samples_per_block, 8192u), d_svr_scratch.p, kSvrGroups, s.d_gamma.as<double>(), &ex);
+        }
+    }
+    s.b_done = svr_rounds;
     HIP_OK(hipEventRecord(s.t1[ST_A], W));
     if (rc != 0) { fprintf(stderr, "[srla-mi355x] kernel launch failed in a chain stage\n"); return false; }
     return true;
@@ -238,7 +276,7 @@ bool Impl::chain_begin(uint32_t seed_off, uint32_t seed_n)
         /* the encode job's calls are not known yet when searching: its blocks tile the window, an FFT is shorter
          * than twice its block (or the smallest FFT size) */
         const uint32_t max_parts = c.search ? (c.tail_n + par.min_num_samples_per_block - 1) / par.min_num_samples_per_block : 0u;
-        const uint64_t bound = chain_pool_used + (uint64_t)nv * passes * (2ull * c.tail_n + 64ull * max_parts);
+        const uint64_t bound = chain_pool_used + (uint64_t)nv * (passes + (chain_svr() ? 1u : 0u)) * (2ull * c.tail_n + 64ull * max_parts);
         if (!d_chain_pool.ensure(bound * sizeof(double))) return false;
         const size_t tab_bound = chain_tab.size() + (size_t)std::max(1u, max_parts) * nv * SRLA_LTP_LAGS;
         if (!d_chain_tab.ensure(tab_bound * 4)) return false;
@@ -385,16 +423,18 @@ void Impl::history_phase_reset()
 /* folds the calls of job `jobidx` into the buffer: word i <- the last call whose transform was longer than i */
 bool Impl::history_commit(uint32_t jobidx, hipStream_t stream)
 {
-    uint32_t src[17], top = 0;
-    for (uint32_t &v : src) v = 0xFFFFFFFFu;
-    for (size_t j = 1; j < chain_calls.size(); j++) {
+    /* from the last call backwards: a call owns the words between what later calls cover and its own extent (a transform's
+     * length, or -- SVR on -- the n words of a refinement's residual) */
+    uint32_t lo[SRLA_COMMIT_SEGS], hi[SRLA_COMMIT_SEGS], src[SRLA_COMMIT_SEGS], nseg = 0, covered = 0;
+    for (size_t j = chain_calls.size(); j-- > 1;) {
         const ChainCall &c = chain_calls[j];
-        if (c.job != jobidx) continue;
-        for (uint32_t k = 0; k < 17 && (1u << k) <= c.nfft; k++) src[k] = c.dump;
-        top = std::max(top, c.nfft);
+        if (c.job != jobidx || c.nfft <= covered) continue;
+        if (nseg == SRLA_COMMIT_SEGS) { fprintf(stderr, "[srla-mi355x] internal error: too many extents in a history phase\n"); return false; }
+        lo[nseg] = covered; hi[nseg] = c.nfft; src[nseg] = c.dump; nseg++;
+        covered = c.nfft;
     }
-    if (top == 0) return true;                                    /* a silent / RAW window: no call, the buffer stays */
-    return srla_launch_chain_commit(stream, d_chain_pool.as<double>(), src, top) == 0;
+    if (nseg == 0) return true;                                   /* a silent / RAW window: no call, the buffer stays */
+    return srla_launch_chain_commit(stream, d_chain_pool.as<double>(), lo, hi, src, nseg) == 0;
 }
 
 SRLAApiResult Impl::history_window(uint32_t stream, uint32_t pos, uint32_t n, bool search)
@@ -507,7 +547,7 @@ SRLAApiResult Impl::history_encode(bool search)
                 }
         }
         drain();
-        if (!d_chain_pool.ensure((kHistoryWords + (uint64_t)nv * passes * words + 1024u) * sizeof(double))) return SRLA_APIRESULT_NG;
+        if (!d_chain_pool.ensure((kHistoryWords + (uint64_t)nv * (passes + (chain_svr() ? 1u : 0u)) * (words + 2u * calls) + 1024u) * sizeof(double))) return SRLA_APIRESULT_NG;
         if (!d_chain_tab.ensure(((size_t)calls * nv * SRLA_LTP_LAGS + 1024u) * 4)) return SRLA_APIRESULT_NG;
     }
     SRLAApiResult worst = SRLA_APIRESULT_OK;

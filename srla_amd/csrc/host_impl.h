@@ -125,6 +125,7 @@ struct Slot {
     Job job;
     bool busy = false;
     bool used_h2d = false;
+    bool b_done = false;                 /* chain mode with SVR on: the solve chain already ran, round by round, inside stage A */
     bool emits = true;                   /* the job runs the block assembly (chain mode's seed and search jobs do not) */
     bool merge_cb = false;               /* one encode callback for the whole segment (chain mode's encode job: its windows are the partitions of ONE look-ahead window) */
     const uint32_t *window_bytes() const { return reinterpret_cast<const uint32_t *>(h_info.as<SrlaJobInfo>() + 1); }
@@ -319,16 +320,18 @@ struct Impl {
         std::vector<SrlaAutocorrItem> list;
         std::vector<ChainLaunch> launches;
         std::vector<uint32_t> select;     /* per item: the round of its LTP-lag call */
+        std::vector<uint32_t> select_b;   /* SVR on: per item the round of its LPC-lag call = the round its solve chain and refinement run in */
         uint32_t rounds = 0;
     };
     std::vector<ChainCall> chain_calls;
     uint64_t chain_pool_used = 0;
     std::vector<uint32_t> chain_tab;      /* gather table for the LTP lags beyond a short FFT (SrlaAutocorrItem::chain_lags) */
     size_t chain_tab_uploaded = 0;
-    DevBuf d_chain_pool, d_chain_tab, d_chain_list[3], d_chain_select[3];
+    DevBuf d_chain_pool, d_chain_tab, d_chain_list[3], d_chain_select[3], d_chain_select_b[3];
     /* the reference's calls for the candidates of `job`, appended in its order; silent(off, n): the block is all zero */
     void chain_append(uint32_t jobidx, const Job &job, const std::function<bool(uint32_t, uint32_t)> &silent);
-    void chain_build(uint32_t jobidx, const Job &job, ChainJob &cj);
+    void chain_build(uint32_t jobidx, Job &job, ChainJob &cj);
+    bool chain_svr() const { return par.num_svr_filter_learning_iteration > 0; }   /* the refinement writes the reference's buffer too */
     bool chain_stage_a(Slot &s, uint32_t jobidx, const ChainJob &cj);   /* stage A of a chain job: the autocorrelation launches round by round */
     /* The last window [tail_start, tail_start + tail_n) of a stream in chain mode, in three steps so that it overlaps
      * the regular jobs: chain_begin (seed + search job; needs nothing from the jobs before unless the seed does),

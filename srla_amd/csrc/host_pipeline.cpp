@@ -378,7 +378,7 @@ bool Impl::prepare_job(Slot &s, bool want_dbg)
         HIP_OK(hipMemcpyAsync(s.d_segs.p, s.h_segs.p, nseg * sizeof(SrlaSegDesc), hipMemcpyHostToDevice, C));
     }
     s.jp = job_params(job, s.stride_cur, sx[job.segs[0].stream].lshift_on_device);
-    s.busy = true;
+    s.busy = true; s.b_done = false;
     stats.num_windows += n_win; stats.num_candidates += n_cands; stats.num_items += n_items;
     stats.analyzed_samples += job.analyzed_samples;
     stats.analyze_launches++;
@@ -455,7 +455,11 @@ bool Impl::run_stage(Slot &s, int st, int part)
         break; }
     case ST_B:
         HIP_OK(hipStreamWaitEvent(N, s.t1[ST_A], 0));
-        if (have_items && jp.max_order > 0) {
+        if (s.b_done) {
+            /* chain mode with SVR on: the solve chain ran round by round inside stage A (host_chain.cpp) */
+            if (ev0) HIP_OK(hipEventRecord(ev0, N));
+            HIP_OK(hipEventRecord(s.t1[ST_B], N));
+        } else if (have_items && jp.max_order > 0) {
             const SrlaSvrExtra ex = { s.d_ties.as<uint32_t>(), job.svr_rows.empty() ? nullptr : s.d_svr_rows.as<double>() };
             rc |= srla_launch_lpc_solve(N, &jp, s.d_items.as<SrlaItemDesc>(), d_geoms.as<SrlaGeom>(), s.d_lags.as<double>(),
                                         s.d_err.as<double>(), d_huff.as<uint8_t>(), s.d_results.as<SrlaItemResult>(), dbg,
@@ -707,11 +711,9 @@ uint32_t Impl::nonidentical_reasons(uint32_t num_samples) const
 {
     uint32_t r = 0;
     const bool search = search_enabled();
-    if (par.num_svr_filter_learning_iteration > 0) {
-        /* the refinement leaves its residual in the buffer the next history-dependent call inherits from (lpc.c:1047): not modelled */
-        if (history_regime(search)) r |= SRLAMI355X_NONIDENTICAL_SVR_HISTORY;
-        else if (num_samples != 0 && chain_tail(num_samples, search) != 0) r |= SRLAMI355X_NONIDENTICAL_SVR_HISTORY;
-    }
+    /* (SVR refinement together with history-dependent blocks: modelled -- the refinement's residual is one more writer of the
+     * reference's buffer in chain / history mode, host_chain.cpp.  The one exception is counted where it happens: arbitrate_svr) */
+    (void)search; (void)num_samples;
     if (par.ltp_order > 0) {
         /* lpcc->buffer holds RoundUp2Powered(config max block) doubles (lpc.c:211): at most 256 of them => the 263 lags of
          * lpc.c:371-373 end in the transform's scratch buffer behind it */
@@ -740,9 +742,8 @@ std::string Impl::nonidentical_text(uint32_t r)
 {
     std::string t;
     if (r & SRLAMI355X_NONIDENTICAL_SVR_HISTORY)
-        t += "SVR refinement (--svr-filter-learning-iteration) together with blocks whose analysis depends on the call before them "
-             "(odd block lengths, or the long-term predictor with blocks of at most 256 samples): the reference's refinement leaves its "
-             "residual where those blocks look (lpc.c:1047), which this library does not reproduce";
+        t += "an SVR refinement whose objective comparisons the host libm decided differently from the device, in a window whose later "
+             "blocks inherit the refinement's residual (lpc.c:1047): the predictor is the host's, the residual left behind is not";
     if (r & SRLAMI355X_NONIDENTICAL_LTP_TINY_BUFFER) {
         if (!t.empty()) t += "; ";
         t += "long-term predictor on an encoder created for blocks of at most 256 samples: the reference's FFT buffer is shorter than "

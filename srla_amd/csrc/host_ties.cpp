@@ -360,5 +360,16 @@ int Impl::arbitrate_svr(Slot &s, uint32_t jobkey, uint32_t item)
     if (hipMemcpy(dev.data(), s.d_coef_ws.as<double>() + (size_t)item * ws_stride, (size_t)order * 8, hipMemcpyDeviceToHost) != hipSuccess) return -1;
     if (memcmp(dev.data(), coef.data(), (size_t)order * 8) == 0) return 0;
     overrides[override_key(jobkey, item)].svr_row = coef;
+    if (jobkey >= kChainJobKey) {
+        /* chain / history mode: later blocks of the window inherit the refinement's residual (lpc.c:1047), and an item whose
+         * predictor is forced leaves the transform's words instead -- named and counted, not silent */
+        stats.num_nonidentical_calls++;
+        stats.nonidentical_reasons |= SRLAMI355X_NONIDENTICAL_SVR_HISTORY;
+        if (!(warned_reasons & SRLAMI355X_NONIDENTICAL_SVR_HISTORY)) {
+            warned_reasons |= SRLAMI355X_NONIDENTICAL_SVR_HISTORY;
+            fprintf(stderr, "[srla-mi355x] WARNING: output valid and lossless but NOT guaranteed bit-identical to the reference: %s\n",
+                    nonidentical_text(SRLAMI355X_NONIDENTICAL_SVR_HISTORY).c_str());
+        }
+    }
     return 1;
 }

@@ -51,10 +51,12 @@ int srla_launch_autocorr_big(hipStream_t stream, const SrlaJobParams *jp, const 
 int srla_launch_residual_cost_big(hipStream_t stream, const SrlaJobParams *jp, const int32_t *input, const SrlaItemDesc *items,
                                   const SrlaGeom *geoms, const double *rice_thresholds, int32_t *res_ws, SrlaItemResult *results,
                                   const uint32_t *big_items, uint32_t count, uint32_t max_n, hipEvent_t ev_start, hipEvent_t ev_stop);
-/* History mode (host_chain.cpp): folds the buffers the calls of a phase left in the chain pool into the first `top` words of
- * the pool -- the reference's persistent FFT buffer as the next phase finds it.  src17[k]: pool offset of the buffer of the
- * phase's last call with nfft >= 2^k (owner of the words [2^(k-1), 2^k); k = 0: word 0), 0xFFFFFFFF: none. */
-int srla_launch_chain_commit(hipStream_t stream, double *pool, const uint32_t *src17, uint32_t top);
+/* History mode (host_chain.cpp): folds the buffers the calls of a phase left in the chain pool into the first words of the pool
+ * -- the reference's persistent FFT buffer as the next phase finds it.  Word i of [lo[k], hi[k]) comes from pool[src[k] + i]: the
+ * segments say which call was the last to write which words (a transform writes its whole length, an SVR refinement the
+ * block's n words). */
+#define SRLA_COMMIT_SEGS 40
+int srla_launch_chain_commit(hipStream_t stream, double *pool, const uint32_t *lo, const uint32_t *hi, const uint32_t *src, uint32_t nseg);
 /* int16 planes (stride16 elements apart) -> int32 planes (n apart): host input of at most 16 bits per sample */
 int srla_launch_widen16(hipStream_t stream, const int16_t *src, size_t stride16, int32_t *dst, uint32_t n, uint32_t num_channels);
 /* ties / tie_data: the job's near-tie list (device_layout.h: SrlaJobParams::tie_rel), may be null */

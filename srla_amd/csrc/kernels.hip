@@ -916,12 +916,13 @@ __device__ __forceinline__ void levinson_lane(double *a, double *r, uint32_t lan
 
 template <int L>
 __global__ __launch_bounds__(WAVE) void srla_lpc_recursion(SrlaJobParams jp, const double *__restrict__ lags_ws,
-                                                           double *__restrict__ err_ws)
+                                                           double *__restrict__ err_ws, const uint32_t *__restrict__ sel, uint32_t sel_round)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const uint32_t lane = threadIdx.x;
     const uint32_t idx = blockIdx.x * L + lane;
     if (lane >= L || idx >= jp.num_items) return;   /* no barriers below: lanes are independent */
+    if (sel != nullptr && sel[idx] != sel_round) return;   /* chain mode with SVR on: the solve chain round by round */
     const uint32_t p = jp.max_order;
     double *a = (double *)lds;                        /* a[i * L + lane], i < p + 2 */
     double *r = a + (size_t)(p + 2) * L;              /* r[i * L + lane], i < p + 1 */
@@ -940,12 +941,13 @@ __global__ __launch_bounds__(WAVE) void srla_lpc_recursion(SrlaJobParams jp, con
 __global__ __launch_bounds__(WAVE) void srla_order_select(
     SrlaJobParams jp, const SrlaItemDesc *__restrict__ items, const SrlaGeom *__restrict__ geoms,
     const double *__restrict__ err_ws, SrlaItemResult *__restrict__ results, double *__restrict__ dbg,
-    uint32_t *__restrict__ ties)
+    uint32_t *__restrict__ ties, const uint32_t *__restrict__ sel, uint32_t sel_round)
 {
     /* (neighbouring items share the 64-byte sectors of the [order][item] table: they go to the same XCD, hence the same L2 --
      * dealt round robin over the XCDs every sector was fetched from HBM eight times, 255 MB per launch at -V 2) */
     const uint32_t idx = xcd_position(blockIdx.x, jp.num_items), lane = threadIdx.x;
     if (idx >= jp.num_items) return;
+    if (sel != nullptr && sel[idx] != sel_round) return;
     const SrlaItemDesc it = items[idx];
     const double comp = geoms[it.geom].welch_comp;
     const uint32_t p = jp.max_order, n = it.n, bps = jp.bits_per_sample;
@@ -1169,10 +1171,11 @@ __global__ __launch_bounds__(WAVE) void srla_lpc_solve_regs(
  * wavefronts of 262 VGPRs at -V 1); the three together hold far less for far shorter. */
 template <int P>
 __global__ __launch_bounds__(WAVE) void srla_lpc_errvars(SrlaJobParams jp, const double *__restrict__ lags_ws, double *__restrict__ err_ws,
-                                                         double *__restrict__ gamma_ws)
+                                                         double *__restrict__ gamma_ws, const uint32_t *__restrict__ sel, uint32_t sel_round)
 {
     const uint32_t idx = blockIdx.x * WAVE + threadIdx.x;
     if (idx >= jp.num_items) return;
+    if (sel != nullptr && sel[idx] != sel_round) return;
     const size_t stride = jp.num_items;
     double r[P + 1];
 #pragma unroll
@@ -1214,7 +1217,8 @@ __global__ __launch_bounds__(WAVE) void srla_lpc_errvars(SrlaJobParams jp, const
 template <int P>
 __global__ __launch_bounds__(WAVE) void srla_lpc_taps(SrlaJobParams jp, const double *__restrict__ err_ws, const double *__restrict__ gamma_ws,
                                                       const uint8_t *__restrict__ huff_len, SrlaItemResult *__restrict__ results,
-                                                      double *__restrict__ coef_ws /* SVR refinement follows: the predictor of the chosen order goes here (row of 64 per item), unquantised */)
+                                                      double *__restrict__ coef_ws /* SVR refinement follows: the predictor of the chosen order goes here (row of 64 per item), unquantised */,
+                                                      const uint32_t *__restrict__ sel, uint32_t sel_round)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int L = WAVE;
@@ -1226,6 +1230,7 @@ __global__ __launch_bounds__(WAVE) void srla_lpc_taps(SrlaJobParams jp, const do
     __syncthreads();
     const uint32_t idx = blockIdx.x * WAVE + lane;
     if (idx >= jp.num_items) return;                         /* no barriers below: lanes are independent */
+    if (sel != nullptr && sel[idx] != sel_round) return;
     const size_t stride = jp.num_items;
     SrlaItemResult *out = &results[idx];
     const uint32_t order = out->lpc_order;
@@ -1270,12 +1275,14 @@ __global__ __launch_bounds__(WAVE) void srla_lpc_taps(SrlaJobParams jp, const do
 template <int L>
 __global__ __launch_bounds__(WAVE) void srla_lpc_quantize(
     SrlaJobParams jp, const double *__restrict__ lags_ws, const uint8_t *__restrict__ huff_len,
-    SrlaItemResult *__restrict__ results, double *__restrict__ coef_ws /* SVR refinement follows: the taps of the chosen order, unquantised, rows of 256 */)
+    SrlaItemResult *__restrict__ results, double *__restrict__ coef_ws /* SVR refinement follows: the taps of the chosen order, unquantised, rows of 256 */,
+    const uint32_t *__restrict__ sel, uint32_t sel_round)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const uint32_t lane = threadIdx.x;
     const uint32_t idx = blockIdx.x * L + lane;
     if (lane >= L || idx >= jp.num_items) return;
+    if (sel != nullptr && sel[idx] != sel_round) return;
     const uint32_t p = jp.max_order;
     double *a = (double *)lds;
     double *r = a + (size_t)(p + 2) * L;
@@ -2406,10 +2413,15 @@ __device__ void svr_refine_item(const SrlaJobParams &jp, const int32_t *__restri
 {
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t p = out->lpc_order;
+    double *dump = (it.svr_dump != 0 && ex.chain_pool != nullptr) ? ex.chain_pool + (it.svr_dump - 1u) : nullptr;
+    const double *under = (it.svr_under != 0 && ex.chain_pool != nullptr) ? ex.chain_pool + (it.svr_under - 1u) : nullptr;
+    /* where the refinement does not touch the reference's buffer, its first n words stay what the LPC-pass call left */
+    auto leave_untouched = [&]() { if (dump != nullptr && under != nullptr) for (uint32_t i = tid; i < it.n; i += SVR_NT) dump[i] = under[i]; };
     if (it.forced_svr != 0 && ex.forced_rows != nullptr) {
         /* the host has redone the refinement with its libm (host_ties.cpp) */
         __syncthreads();
         for (uint32_t i = tid; i < p; i += SVR_NT) row[i] = ex.forced_rows[(size_t)(it.forced_svr - 1u) * 256u + i];
+        leave_untouched();
         return;
     }
     const InputView iv = input_view(jp, it.lshift);
@@ -2513,6 +2525,7 @@ __device__ void svr_refine_item(const SrlaJobParams &jp, const int32_t *__restri
     }
     if (s_flag[0]) {                                                     /* singular: all-zero input (lpc.c:1071-1077) */
         for (uint32_t i = tid; i < p; i += SVR_NT) row[i] = 0.0;
+        leave_untouched();
         return;
     }
     /* ---- the learning loop, lpc.c:1083-1127 ---- */
@@ -2584,6 +2597,22 @@ __device__ void svr_refine_item(const SrlaJobParams &jp, const int32_t *__restri
         }
     }
     __syncthreads();
+    if (dump != nullptr) {
+        /* What the reference's `residual` = the calculator's persistent buffer holds now (lpc.c:1047,1095-1106): the block itself
+         * below the order, from there on the soft-thresholded residual of the LAST pass that ran (rr[] still holds that pass's
+         * residuals; its margin is the last of the list) -- what an odd-length or a short LTP block analysed later inherits. */
+        const double margin = margins[5];
+        for (uint32_t s0 = tid; s0 < n; s0 += SVR_NT) {
+            double v;
+            if (s0 < p) v = (double)xi[s0] * norm;
+            else {
+                const double r = rr[s0];
+                const double a = (r > 0) ? r : -r;
+                v = (double)((r > 0) - (r < 0)) * (((a - margin) > 0.0) ? (a - margin) : 0.0);
+            }
+            dump[s0] = v;
+        }
+    }
     for (uint32_t i = tid; i < p; i += SVR_NT) row[i] = best_coef[i];
     if (tid == 0 && s_flag[2]) {
         out->flags |= SRLA_ITEM_SVR_TIE;
@@ -2607,9 +2636,12 @@ __global__ __launch_bounds__(SVR_NT) void srla_svr_refine(
     __shared__ uint32_t s_flag[4];                                       /* 0: singular, 1: break, 2: near-tie, 3: |x| max */
     const uint32_t item_idx = xcd_position(blockIdx.x, jp.num_items);
     if (item_idx >= jp.num_items) return;
+    if (ex.select != nullptr && ex.select[item_idx] != ex.round) return;
     SrlaItemResult *out = &results[item_idx];
     const uint32_t p = out->lpc_order;
     const SrlaItemDesc it = items[item_idx];
+    if (p == 0 && it.svr_dump != 0 && it.svr_under != 0 && ex.chain_pool != nullptr)   /* order 0: no refinement (srla_encoder.c:1084) */
+        for (uint32_t i = threadIdx.x; i < it.n; i += SVR_NT) ex.chain_pool[(size_t)(it.svr_dump - 1u) + i] = ex.chain_pool[(size_t)(it.svr_under - 1u) + i];
     if (p == 0 || p > SVR_P || it.n > n_cap) return;                     /* the others: srla_svr_refine_big */
     svr_refine_item<false>(jp, input, it, out, coef_ws + (size_t)item_idx * ws_stride, iterations, xi, rr, cov, SVR_PS,
                            low, r_vec, delta, coef, init_coef, best_coef, s_scalar, s_lag, s_flag, ex, item_idx);
@@ -2639,6 +2671,7 @@ __global__ __launch_bounds__(SVR_NT) void srla_svr_refine_big(
     double *rr = (double *)(mine + (((size_t)n_max * 4 + 15) & ~(size_t)15));
     double *cov = rr + n_max;
     for (uint32_t item_idx = blockIdx.x; item_idx < jp.num_items; item_idx += gridDim.x) {
+        if (ex.select != nullptr && ex.select[item_idx] != ex.round) continue;
         SrlaItemResult *out = &results[item_idx];
         const uint32_t p = out->lpc_order;
         const SrlaItemDesc it = items[item_idx];
@@ -2650,7 +2683,8 @@ __global__ __launch_bounds__(SVR_NT) void srla_svr_refine_big(
 
 /* the quantiser and tap cost (lpc.c:1341-1405, srla_encoder.c:1141-1174) from the refined taps: one lane per item */
 __global__ __launch_bounds__(WAVE) void srla_lpc_quantize_ws(SrlaJobParams jp, const double *__restrict__ coef_ws, uint32_t ws_stride,
-                                                             const uint8_t *__restrict__ huff_len, SrlaItemResult *__restrict__ results)
+                                                             const uint8_t *__restrict__ huff_len, SrlaItemResult *__restrict__ results,
+                                                             const uint32_t *__restrict__ sel, uint32_t sel_round)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int L = WAVE;
@@ -2661,6 +2695,7 @@ __global__ __launch_bounds__(WAVE) void srla_lpc_quantize_ws(SrlaJobParams jp, c
     __syncthreads();
     const uint32_t idx = blockIdx.x * WAVE + lane;
     if (idx >= jp.num_items) return;
+    if (sel != nullptr && sel[idx] != sel_round) return;
     SrlaItemResult *out = &results[idx];
     const uint32_t order = out->lpc_order;
     const double *row = coef_ws + (size_t)idx * ws_stride;
@@ -3422,22 +3457,23 @@ __global__ void srla_mask_to_shift(uint32_t *__restrict__ out)
 /* The reference's persistent FFT buffer (lpc.c:58,211) as it stands after a phase of calls, kept in the first `top` words
  * of the chain pool: word i becomes what the LAST call of the phase whose transform was longer than i left there (every call
  * left its complete buffer at its own place in the pool); words no call of the phase reached keep what they held.
- * src[k]: pool offset of the buffer of the last call with nfft >= 2^k, i.e. of the owner of the words [2^(k-1), 2^k)
- * (k = 0: word 0), or 0xFFFFFFFF. */
-struct SrlaCommitTable { uint32_t src[17]; };
+ * The host says which call owns which words (segments). */
+struct SrlaCommitTable { uint32_t lo[SRLA_COMMIT_SEGS], hi[SRLA_COMMIT_SEGS], src[SRLA_COMMIT_SEGS], n; };
 __global__ __launch_bounds__(256) void srla_chain_commit(double *__restrict__ pool, SrlaCommitTable tab, uint32_t top)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= top) return;
-    const uint32_t k = (i == 0) ? 0u : (32u - (uint32_t)__clz((int)i));
-    const uint32_t src = tab.src[k];
-    if (src != 0xFFFFFFFFu) pool[i] = pool[(size_t)src + i];
+    for (uint32_t k = 0; k < tab.n; k++)
+        if (i >= tab.lo[k] && i < tab.hi[k]) { pool[i] = pool[(size_t)tab.src[k] + i]; return; }
 }
 
-extern "C" int srla_launch_chain_commit(hipStream_t stream, double *pool, const uint32_t *src17, uint32_t top)
+extern "C" int srla_launch_chain_commit(hipStream_t stream, double *pool, const uint32_t *lo, const uint32_t *hi, const uint32_t *src, uint32_t nseg)
 {
     SrlaCommitTable tab;
-    for (int k = 0; k < 17; k++) tab.src[k] = src17[k];
+    uint32_t top = 0;
+    if (nseg > SRLA_COMMIT_SEGS) return -1;
+    for (uint32_t k = 0; k < nseg; k++) { tab.lo[k] = lo[k]; tab.hi[k] = hi[k]; tab.src[k] = src[k]; top = (hi[k] > top) ? hi[k] : top; }
+    tab.n = nseg;
     if (top == 0) return 0;
     hipLaunchKernelGGL(srla_chain_commit, dim3((top + 255u) / 256u), dim3(256), 0, stream, pool, tab, top);
     return hipGetLastError() == hipSuccess ? 0 : -1;
@@ -3530,9 +3566,9 @@ extern "C" int srla_launch_lpc_solve(hipStream_t stream, const SrlaJobParams *jp
 {
     if (jp->num_items == 0) return 0;
     const uint32_t p = jp->max_order;
-    SrlaSvrExtra ex = { nullptr, nullptr };
+    SrlaSvrExtra ex = { nullptr, nullptr, nullptr, nullptr, 0u };
     if (svr_extra) ex = *svr_extra;
-    const bool three = !g_tune.solve_onepass && gamma_ws != nullptr;   /* orders 8 .. 64: errvars + order_select + taps */
+    const bool three = (!g_tune.solve_onepass || ex.select != nullptr) && gamma_ws != nullptr;   /* (the one-pass kernel has no round filter) */   /* orders 8 .. 64: errvars + order_select + taps */
     if (svr_iterations > 0) {
         /* solve (taps left unquantised) -> SVR refinement -> quantiser */
         const dim3 g64s((jp->num_items + 63) / 64), blks(WAVE);
@@ -3542,9 +3578,9 @@ extern "C" int srla_launch_lpc_solve(hipStream_t stream, const SrlaJobParams *jp
         const uint32_t lds = 512 + PP * 8 * 64 + PP * 4 * 64;                                                            \
         if (three) {                                                                                                     \
             SET_LDS_ATTR(srla_lpc_taps<PP>);                                                                             \
-            hipExtLaunchKernelGGL(srla_lpc_errvars<PP>, g64s, blks, 0, stream, ev_start, nullptr, 0, *jp, lags_ws, err_ws, gamma_ws); \
-            hipLaunchKernelGGL(srla_order_select, dim3(8u * ((jp->num_items + 7u) >> 3)), blks, 0, stream, *jp, items, geoms, err_ws, results, dbg, ties); \
-            hipLaunchKernelGGL(srla_lpc_taps<PP>, g64s, blks, lds, stream, *jp, err_ws, gamma_ws, huff_len, results, coef_ws); \
+            hipExtLaunchKernelGGL(srla_lpc_errvars<PP>, g64s, blks, 0, stream, ev_start, nullptr, 0, *jp, lags_ws, err_ws, gamma_ws, ex.select, ex.round); \
+            hipLaunchKernelGGL(srla_order_select, dim3(8u * ((jp->num_items + 7u) >> 3)), blks, 0, stream, *jp, items, geoms, err_ws, results, dbg, ties, ex.select, ex.round); \
+            hipLaunchKernelGGL(srla_lpc_taps<PP>, g64s, blks, lds, stream, *jp, err_ws, gamma_ws, huff_len, results, coef_ws, ex.select, ex.round); \
         } else {                                                                                                         \
             SET_LDS_ATTR(srla_lpc_solve_regs<PP>);                                                                       \
             hipExtLaunchKernelGGL(srla_lpc_solve_regs<PP>, g64s, blks, lds, stream, ev_start, nullptr, 0, *jp, items, geoms, lags_ws, err_ws, \
@@ -3556,16 +3592,16 @@ extern "C" int srla_launch_lpc_solve(hipStream_t stream, const SrlaJobParams *jp
             const uint32_t lds = (2 * p + 3) * 8 * 64;
             SET_LDS_ATTR(srla_lpc_recursion<64>);
             SET_LDS_ATTR(srla_lpc_quantize<64>);
-            hipExtLaunchKernelGGL(srla_lpc_recursion<64>, g64s, blks, lds, stream, ev_start, nullptr, 0, *jp, lags_ws, err_ws);
-            hipLaunchKernelGGL(srla_order_select, dim3(8u * ((jp->num_items + 7u) >> 3)), blks, 0, stream, *jp, items, geoms, err_ws, results, dbg, ties);
-            hipLaunchKernelGGL(srla_lpc_quantize<64>, g64s, blks, lds, stream, *jp, lags_ws, huff_len, results, coef_ws);
+            hipExtLaunchKernelGGL(srla_lpc_recursion<64>, g64s, blks, lds, stream, ev_start, nullptr, 0, *jp, lags_ws, err_ws, ex.select, ex.round);
+            hipLaunchKernelGGL(srla_order_select, dim3(8u * ((jp->num_items + 7u) >> 3)), blks, 0, stream, *jp, items, geoms, err_ws, results, dbg, ties, ex.select, ex.round);
+            hipLaunchKernelGGL(srla_lpc_quantize<64>, g64s, blks, lds, stream, *jp, lags_ws, huff_len, results, coef_ws, ex.select, ex.round);
         } else {
             const uint32_t lds = (2 * p + 3) * 8 * 32;
             SET_LDS_ATTR(srla_lpc_recursion<32>);
             SET_LDS_ATTR(srla_lpc_quantize<32>);
-            hipExtLaunchKernelGGL(srla_lpc_recursion<32>, dim3((jp->num_items + 31) / 32), blks, lds, stream, ev_start, nullptr, 0, *jp, lags_ws, err_ws);
-            hipLaunchKernelGGL(srla_order_select, dim3(8u * ((jp->num_items + 7u) >> 3)), blks, 0, stream, *jp, items, geoms, err_ws, results, dbg, ties);
-            hipLaunchKernelGGL(srla_lpc_quantize<32>, dim3((jp->num_items + 31) / 32), blks, lds, stream, *jp, lags_ws, huff_len, results, coef_ws);
+            hipExtLaunchKernelGGL(srla_lpc_recursion<32>, dim3((jp->num_items + 31) / 32), blks, lds, stream, ev_start, nullptr, 0, *jp, lags_ws, err_ws, ex.select, ex.round);
+            hipLaunchKernelGGL(srla_order_select, dim3(8u * ((jp->num_items + 7u) >> 3)), blks, 0, stream, *jp, items, geoms, err_ws, results, dbg, ties, ex.select, ex.round);
+            hipLaunchKernelGGL(srla_lpc_quantize<32>, dim3((jp->num_items + 31) / 32), blks, lds, stream, *jp, lags_ws, huff_len, results, coef_ws, ex.select, ex.round);
         }
 #undef SVR_PATH
         {   /* items of order <= 64 in blocks that fit LDS, whatever the preset's maximum */
@@ -3586,7 +3622,7 @@ extern "C" int srla_launch_lpc_solve(hipStream_t stream, const SrlaJobParams *jp
                                ws_stride, svr_iterations, svr_n_cap, (unsigned char *)svr_scratch, jp->max_block, ex);
         }
         SET_LDS_ATTR(srla_lpc_quantize_ws);
-        hipExtLaunchKernelGGL(srla_lpc_quantize_ws, g64s, blks, 512 + (p < 64 ? 64 : p) * 4 * 64, stream, nullptr, ev_stop, 0, *jp, coef_ws, ws_stride, huff_len, results);
+        hipExtLaunchKernelGGL(srla_lpc_quantize_ws, g64s, blks, 512 + (p < 64 ? 64 : p) * 4 * 64, stream, nullptr, ev_stop, 0, *jp, coef_ws, ws_stride, huff_len, results, ex.select, ex.round);
         return (hipGetLastError() == hipSuccess) ? 0 : -2;
     }
     const dim3 g64((jp->num_items + 63) / 64), blk(WAVE);
@@ -3596,9 +3632,9 @@ extern "C" int srla_launch_lpc_solve(hipStream_t stream, const SrlaJobParams *jp
         const uint32_t lds = 512 + PP * 8 * 64 + PP * 4 * 64;                                                            \
         if (three) {                                                                                                     \
             SET_LDS_ATTR(srla_lpc_taps<PP>);                                                                             \
-            hipExtLaunchKernelGGL(srla_lpc_errvars<PP>, g64, blk, 0, stream, ev_start, nullptr, 0, *jp, lags_ws, err_ws, gamma_ws); \
-            hipLaunchKernelGGL(srla_order_select, dim3(8u * ((jp->num_items + 7u) >> 3)), blk, 0, stream, *jp, items, geoms, err_ws, results, dbg, ties); \
-            hipExtLaunchKernelGGL(srla_lpc_taps<PP>, g64, blk, lds, stream, nullptr, ev_stop, 0, *jp, err_ws, gamma_ws, huff_len, results, (double *)nullptr); \
+            hipExtLaunchKernelGGL(srla_lpc_errvars<PP>, g64, blk, 0, stream, ev_start, nullptr, 0, *jp, lags_ws, err_ws, gamma_ws, ex.select, ex.round); \
+            hipLaunchKernelGGL(srla_order_select, dim3(8u * ((jp->num_items + 7u) >> 3)), blk, 0, stream, *jp, items, geoms, err_ws, results, dbg, ties, ex.select, ex.round); \
+            hipExtLaunchKernelGGL(srla_lpc_taps<PP>, g64, blk, lds, stream, nullptr, ev_stop, 0, *jp, err_ws, gamma_ws, huff_len, results, (double *)nullptr, ex.select, ex.round); \
         } else {                                                                                                         \
             SET_LDS_ATTR(srla_lpc_solve_regs<PP>);                                                                       \
             hipExtLaunchKernelGGL(srla_lpc_solve_regs<PP>, g64, blk, lds, stream, ev_start, ev_stop, 0, *jp, items, geoms, lags_ws, err_ws, \
@@ -3613,16 +3649,16 @@ extern "C" int srla_launch_lpc_solve(hipStream_t stream, const SrlaJobParams *jp
         const uint32_t lds = (2 * p + 3) * 8 * 64;
         SET_LDS_ATTR(srla_lpc_recursion<64>);
         SET_LDS_ATTR(srla_lpc_quantize<64>);
-        hipExtLaunchKernelGGL(srla_lpc_recursion<64>, g64, blk, lds, stream, ev_start, nullptr, 0, *jp, lags_ws, err_ws);
-        hipLaunchKernelGGL(srla_order_select, dim3(8u * ((jp->num_items + 7u) >> 3)), blk, 0, stream, *jp, items, geoms, err_ws, results, dbg, ties);
-        hipExtLaunchKernelGGL(srla_lpc_quantize<64>, g64, blk, lds, stream, nullptr, ev_stop, 0, *jp, lags_ws, huff_len, results, (double *)nullptr);
+        hipExtLaunchKernelGGL(srla_lpc_recursion<64>, g64, blk, lds, stream, ev_start, nullptr, 0, *jp, lags_ws, err_ws, ex.select, ex.round);
+        hipLaunchKernelGGL(srla_order_select, dim3(8u * ((jp->num_items + 7u) >> 3)), blk, 0, stream, *jp, items, geoms, err_ws, results, dbg, ties, ex.select, ex.round);
+        hipExtLaunchKernelGGL(srla_lpc_quantize<64>, g64, blk, lds, stream, nullptr, ev_stop, 0, *jp, lags_ws, huff_len, results, (double *)nullptr, ex.select, ex.round);
     } else {
         const uint32_t lds = (2 * p + 3) * 8 * 32;
         SET_LDS_ATTR(srla_lpc_recursion<32>);
         SET_LDS_ATTR(srla_lpc_quantize<32>);
-        hipExtLaunchKernelGGL(srla_lpc_recursion<32>, dim3((jp->num_items + 31) / 32), blk, lds, stream, ev_start, nullptr, 0, *jp, lags_ws, err_ws);
-        hipLaunchKernelGGL(srla_order_select, dim3(8u * ((jp->num_items + 7u) >> 3)), blk, 0, stream, *jp, items, geoms, err_ws, results, dbg, ties);
-        hipExtLaunchKernelGGL(srla_lpc_quantize<32>, dim3((jp->num_items + 31) / 32), blk, lds, stream, nullptr, ev_stop, 0, *jp, lags_ws, huff_len, results, (double *)nullptr);
+        hipExtLaunchKernelGGL(srla_lpc_recursion<32>, dim3((jp->num_items + 31) / 32), blk, lds, stream, ev_start, nullptr, 0, *jp, lags_ws, err_ws, ex.select, ex.round);
+        hipLaunchKernelGGL(srla_order_select, dim3(8u * ((jp->num_items + 7u) >> 3)), blk, 0, stream, *jp, items, geoms, err_ws, results, dbg, ties, ex.select, ex.round);
+        hipExtLaunchKernelGGL(srla_lpc_quantize<32>, dim3((jp->num_items + 31) / 32), blk, lds, stream, nullptr, ev_stop, 0, *jp, lags_ws, huff_len, results, (double *)nullptr, ex.select, ex.round);
     }
 #undef REGS_PATH
     return (hipGetLastError() == hipSuccess) ? 0 : -2;

@@ -40,7 +40,16 @@ CLI = {
     "m0_B1000_V3": dict(preset=0, max_block=1000, divisions=3),
     # through the API only (the tool derives min = max >> V): min 375, max 3000, look-ahead 6000
     "m4_min375_max3000_P3": dict(preset=4, max_block=3000, min_block=375, lookahead=6000, ltp_order=3),
+    # --svr-filter-learning-iteration: the refinement leaves its residual in the buffer the next history-dependent call reads
+    # (lpc.c:1047).  In the history regimes, and -- ordinary parameters, odd stream length -- in the last window alone.
+    "m2_B1000_V3_svr1": dict(preset=2, max_block=1000, divisions=3, svr_iterations=1),
+    "m4_B1024_V2_P3_svr1": dict(preset=4, max_block=1024, divisions=2, ltp_order=3, svr_iterations=1),
+    "m4_B4095_V0_svr2": dict(preset=4, max_block=4095, divisions=0, svr_iterations=2),
+    "m4_B4096_V1_svr2": dict(preset=4, max_block=4096, divisions=1, svr_iterations=2),
+    "m2_B4096_V2_P3_svr1": dict(preset=2, max_block=4096, divisions=2, ltp_order=3, svr_iterations=1),
+    "m3_B2048_V0_svr3": dict(preset=3, max_block=2048, divisions=0, svr_iterations=3),
 }
+SVR_ONLY_ODD = ("m4_B4096_V1_svr2", "m2_B4096_V2_P3_svr1", "m3_B2048_V0_svr3")   # not history regimes: only an odd-length stream's tail
 
 cases = []
 
@@ -50,6 +59,12 @@ def add(name, spec, cli_name, store=False):
 
 
 for c in CLI:
+    if "svr" in c:
+        # (the refinement is slow in the reference too: shorter inputs)
+        if c not in SVR_ONLY_ODD: add("hist_music_" + c, dict(kind=MUSIC, seed=81, rate=48000, nch=2, n=24000, bps=16), c)
+        add("hist_varied_odd_" + c, dict(kind=VARIED, seed=82, rate=48000, nch=2, n=30003, bps=16), c)
+        add("hist_music_odd_" + c, dict(kind=MUSIC, seed=87, rate=44100, nch=1, n=20001, bps=16), c)
+        continue
     add("hist_music_" + c, dict(kind=MUSIC, seed=81, rate=48000, nch=2, n=60000, bps=16), c)
     add("hist_varied_odd_" + c, dict(kind=VARIED, seed=82, rate=48000, nch=2, n=48003, bps=16), c)
 for c in ("m4_B1024_V2_P3", "m2_B512_V1_P1", "m4_B2048_V3_P3", "m4_B4095_V0", "m2_B1000_V3_P1"):
