@@ -18,15 +18,23 @@ Every rank encodes its own streams (windows and files are independent units: no 
 scaling is weak.
 
 Extra objects on the JSON line:
-  roofline         dominant kernel (srla_residual_cost): algorithmic bytes = 16 B per stereo sample instant
-                   x instants per launch, over the average launch duration measured with HIP events attached to the
-                   dispatches inside the timed region; peak = 8000 GB/s HBM3E; traffic, valu_util and fp64_inst_frac from
-                   the committed rocprofv3 PMC summary (profiles/pmc_summary.json).
+  roofline         every stage of a job (`stages`: srla_autocorr, srla_pitch_solve, srla_lpc_solve, srla_residual_cost,
+                   srla_price_windows, srla_pack_blocks) priced against the same contract -- algorithmic bytes = 16 B per
+                   stereo sample instant x instants per launch, over the stage's average duration per job measured
+                   with HIP events attached to the dispatches inside the timed region; peak = 8000 GB/s HBM3E; `kernel` (and
+                   achieved / frac / traffic at the top level) = the analysis stage with the LONGEST measured duration;
+                   `end_to_end` = the whole path (algorithmic bytes of everything a rank encoded / its wall time); traffic,
+                   valu_util, lds_util, lds_bank_conflict_frac, wait_frac, fp64_inst_frac per stage from the committed
+                   rocprofv3 PMC summary (profiles/pmc_summary.json).
   cpu_baseline     the compiled reference (oracle/_ref, "reference") or the oracle ("port") timed on ONE host core on
                    a bounded sample of the same workload (rank 0, N = 1 only); `all_cores`: for context, the same on
                    every usable core at once (one handle per thread).
   device_resident  the same encode with the samples already in HBM and a pinned output buffer
-                   (SRLAMI355X_EncodeWholeDevice), mean of a few calls outside the timed region -- never `value`.
+                   (SRLAMI355X_EncodeWholeDevice), median of a few calls outside the timed region -- never `value`.
+  stream_60s, stream_10s   one 60 s (SURVEY 8d's own input length) / 10 s stream per SRLAEncoder_EncodeWhole call, pageable
+                   host memory to pageable host memory, median of 20 calls outside the timed region -- never `value`.
+  per_rank         (N > 1) every rank's own time inside the library per step (min / max), how many ranks locked their input /
+                   output in place instead of staging, how many ranks' streams decoded back to their input, pool threads.
 """
 import argparse
 import ctypes as C
