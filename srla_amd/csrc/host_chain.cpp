@@ -172,7 +172,7 @@ bool Impl::chain_stage_a(Slot &s, uint32_t jobidx, const ChainJob &cj)
                 rc |= srla_launch_autocorr(W, kClass[l.cls], &jp, s.in_cur, s.d_items.as<SrlaItemDesc>(), d_geoms.as<SrlaGeom>(), d_tw.p,
                                            (uint32_t)pass, s.d_results.as<SrlaItemResult>(), s.d_lags.as<double>(), nullptr,
                                            d_chain_list[jobidx].as<SrlaAutocorrItem>() + l.first, l.count, nullptr, nullptr,
-                                           d_chain_pool.as<double>(), d_chain_tab.as<uint32_t>());
+                                           d_chain_pool.as<double>(), d_chain_tab.as<uint32_t>(), 0);
                 any = true;
             }
             if (pass == 1 && any)

@@ -442,7 +442,7 @@ bool Impl::run_stage(Slot &s, int st, int part)
                 else
                 rc |= srla_launch_autocorr(W, kClass[c], &jp, s.in_cur, s.d_items.as<SrlaItemDesc>(), d_geoms.as<SrlaGeom>(), d_tw.p,
                                            (uint32_t)seq[i].pass, s.d_results.as<SrlaItemResult>(), s.d_lags.as<double>(), dbg,
-                                           s.d_class_index.as<SrlaAutocorrItem>() + job.class_first[c], job.class_count[c], e0, e1, nullptr, nullptr);
+                                           s.d_class_index.as<SrlaAutocorrItem>() + job.class_first[c], job.class_count[c], e0, e1, nullptr, nullptr, c == 6 ? 1 : 0);
             } else {
                 hipStream_t ps = W;
                 if (split) { ps = N; HIP_OK(hipStreamWaitEvent(N, s.ev_a1, 0)); }

@@ -35,7 +35,8 @@ int srla_launch_autocorr(hipStream_t stream, int rclass, const SrlaJobParams *jp
                          uint32_t pass, SrlaItemResult *results, double *lags_ws, double *dbg,
                          const SrlaAutocorrItem *class_items, uint32_t count, hipEvent_t ev_start, hipEvent_t ev_stop,
                          double *chain_pool /* null outside chain mode (device_layout.h: chain_src / chain_dump) */,
-                         const uint32_t *chain_tab /* gather table of chain_lags */);
+                         const uint32_t *chain_tab /* gather table of chain_lags */,
+                         int exact_nfft /* rclass 0 only: every item has exactly 1024 points */);
 /* The same for the items of ONE transform size nfft = 1024, 2048 or 4096 outside chain mode: nfft / 64 lanes of one wavefront per
  * item, the transform in registers, no barriers (autocorr_wave.hip). */
 int srla_launch_autocorr_wave(hipStream_t stream, uint32_t nfft, const SrlaJobParams *jp, const int32_t *input, const void *twiddles,
@@ -107,6 +108,7 @@ typedef struct {
     uint32_t fused_fft;            /* SRLA_MI355X_FUSED_FFT: fft_complex_lds16 for 2048- and 4096-point items */
     uint32_t pack_lds_cap_words;   /* SRLA_MI355X_PACK_LDS_WORDS: 0 = the default cap (24 Ki words) */
     uint32_t out_wgs;              /* SRLA_MI355X_OUT_WGS: stream-out workgroups, 0 = by sample width */
+    uint32_t generic_fft;          /* SRLA_MI355X_GENERIC_FFT: srla_autocorr without the FFT size compiled in, as in round 2 */
     uint32_t solve_onepass;        /* SRLA_MI355X_SOLVE_ONEPASS: srla_lpc_solve_regs instead of errvars + order_select + taps */
 } SrlaLaunchTuning;
 void srla_set_launch_tuning(const SrlaLaunchTuning *t);

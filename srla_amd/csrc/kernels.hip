@@ -134,6 +134,80 @@ __device__ void fft_complex_lds(cplx *x, uint32_t m, int flag, const cplx *__res
     }
 }
 
+/* The same transform with the length M and the direction FLAG known at compile time: the stage loop unrolls, so every stage's
+ * sub-size, stride and table offset are constants -- p and q of a butterfly are a shift and a mask by immediates, the four inputs
+ * and four outputs stand at one computed LDS address plus immediate offsets, the three table entries at one computed address
+ * plus immediates, and the direction costs no selects.  (Half of srla_autocorr's VALU instructions were this bookkeeping, not
+ * fp64 arithmetic: SQ_INSTS_VALU_*_F64 / SQ_INSTS_VALU = 0.49.)  Same butterflies, same operands, same bits. */
+template <int R, int NTK, bool PRUNE, int M, int FLAG>
+__device__ __forceinline__ void fft_complex_lds_ct(cplx *x, const cplx *__restrict__ tw, const uint32_t need)
+{
+    const uint32_t tid = threadIdx.x;
+    constexpr uint32_t nb = M >> 2, m4 = M >> 2;
+    constexpr int NST = (M >= 4096) ? 6 : ((M >= 1024) ? 5 : ((M >= 256) ? 4 : ((M >= 64) ? 3 : ((M >= 16) ? 2 : 1))));   /* radix-4 stages: n = M, M/4, ... > 2 */
+    uint32_t twoff = 0;
+#pragma unroll
+    for (int st = 0; st < NST; st++) {
+        const uint32_t n = (uint32_t)M >> (2 * st), s = 1u << (2 * st), log2s = 2u * (uint32_t)st;
+        if (n <= 2) break;
+        const uint32_t n1 = n >> 2;
+        const bool k1 = !PRUNE || s < need, k2 = !PRUNE || 2 * s < need, k3 = !PRUNE || 3 * s < need;
+        cplx a[R], b[R], c[R], d[R], w1[R], w2[R], w3[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const uint32_t bf = tid + (uint32_t)r * NTK;
+            const uint32_t q = bf & (s - 1);
+            if (bf < nb && (!PRUNE || q < need)) {
+                const uint32_t p = bf >> log2s;
+                const cplx *t = tw + twoff + p;
+                if (k1) w1[r] = t[0];
+                if (k2) w2[r] = t[n1];
+                if (k3) w3[r] = t[2 * n1];
+                const cplx *xi = x + bf;
+                a[r] = xi[0]; b[r] = xi[m4]; c[r] = xi[2 * m4]; d[r] = xi[3 * m4];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const uint32_t bf = tid + (uint32_t)r * NTK;
+            const uint32_t q = bf & (s - 1);
+            if (bf < nb && (!PRUNE || q < need)) {
+                const cplx apc = c_add(a[r], c[r]), amc = c_sub(a[r], c[r]), bpd = c_add(b[r], d[r]);
+                const cplx bmd = c_sub(b[r], d[r]);
+                const cplx jbmd = (FLAG < 0) ? make_double2(-bmd.y, bmd.x) : make_double2(bmd.y, -bmd.x);
+                cplx *xo = x + (4u * bf - 3u * q);
+                xo[0] = c_add(apc, bpd);
+                if (k1) xo[s] = c_mul(w1[r], c_sub(amc, jbmd));
+                if (k2) xo[2 * s] = c_mul(w2[r], c_sub(apc, bpd));
+                if (k3) xo[3 * s] = c_mul(w3[r], c_add(amc, jbmd));
+            }
+        }
+        __syncthreads();
+        twoff += 3 * n1;
+    }
+    constexpr uint32_t last_n = (uint32_t)M >> (2 * NST);       /* 2 when log2 M is odd, else 1 */
+    if (last_n == 2) {
+        constexpr uint32_t s = (uint32_t)M >> 1;
+        cplx a[2 * R], b[2 * R];
+#pragma unroll
+        for (int r = 0; r < 2 * R; r++) {
+            const uint32_t q = tid + (uint32_t)r * NTK;
+            if (q < s && (!PRUNE || q < need)) { a[r] = x[q]; b[r] = x[q + s]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 2 * R; r++) {
+            const uint32_t q = tid + (uint32_t)r * NTK;
+            if (q < s && (!PRUNE || q < need)) {
+                x[q] = c_add(a[r], b[r]);
+                if (!PRUNE || q + s < need) x[q + s] = c_sub(a[r], b[r]);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 __device__ __forceinline__ uint32_t complex_table_len(uint32_t m)
 {
     uint32_t t = 0;
@@ -380,7 +454,7 @@ __device__ void spectrum_power_pass(cplx *x, uint32_t nfft, const cplx *__restri
 
 /* circular autocorrelation of the (already windowed, zero padded) signal in buf (lpc.c:330-376): on return
  * complex slot cidx<F16>(i/2) component i&1 holds the unscaled lag i, for i < num_lags */
-template <int R, int NTK, bool F16>
+template <int R, int NTK, bool F16, int NFFT = 0>
 __device__ void autocorr_in_place(cplx *buf, uint32_t nfft, const cplx *__restrict__ twbase, uint32_t num_lags)
 {
     const uint32_t m = nfft >> 1;
@@ -389,7 +463,12 @@ __device__ void autocorr_in_place(cplx *buf, uint32_t nfft, const cplx *__restri
     const cplx *tw_inv = twbase + ct;
     const cplx *rtw_fwd = twbase + 2 * ct;
     const cplx *rtw_inv = rtw_fwd + quarter;
-    if (F16) {
+    if constexpr (NFFT != 0 && !F16) {
+        /* the transform's length known at compile time (a launch of one FFT-size class outside chain mode) */
+        fft_complex_lds_ct<R, NTK, false, NFFT / 2, -1>(buf, tw_fwd, m);
+        spectrum_power_pass<NTK, false>(buf, nfft, rtw_fwd, rtw_inv);
+        fft_complex_lds_ct<R, NTK, true, NFFT / 2, 1>(buf, tw_inv, (num_lags + 1) >> 1);
+    } else if (F16) {
         fft_complex_lds16<NTK, false>(buf, m, -1, tw_fwd, m);
         spectrum_power_pass<NTK, true>(buf, nfft, rtw_fwd, rtw_inv);
         fft_complex_lds16<NTK, true>(buf, m, 1, tw_inv, (num_lags + 1) >> 1);
@@ -438,7 +517,7 @@ extern "C" uint32_t srla_kernel_small_a_bytes(void) { return (uint32_t)((sizeof(
 
 /* R: chunks of 8 samples per thread (8 R NTK >= nfft).  F16: the fused-pass transform (NTK = nfft / 32), else one stage
  * per round trip (R butterflies per thread and stage) */
-template <int R, int NTK, bool F16>
+template <int R, int NTK, bool F16, int NFFT = 0 /* every item of the launch has this FFT size (0: they say themselves) */>
 __global__ __launch_bounds__(NTK) __attribute__((amdgpu_waves_per_eu(4, 8))) void srla_autocorr(
     SrlaJobParams jp, const int32_t *__restrict__ input, const SrlaItemDesc *__restrict__ items,
     const SrlaGeom *__restrict__ geoms, const cplx *__restrict__ twiddles, uint32_t fft_bytes, uint32_t pass,
@@ -458,7 +537,7 @@ __global__ __launch_bounds__(NTK) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     const InputView iv = input_view(jp, it.lshift);
     const uint32_t item_idx = it.item;
     const struct { uint32_t nfft, tw_off; double welch_divisor, acorr_norm; } g = { it.nfft, it.tw_off, it.welch_divisor, it.acorr_norm };
-    const uint32_t n = it.n, nfft = g.nfft, bps = jp.bits_per_sample;
+    const uint32_t n = it.n, nfft = NFFT ? (uint32_t)NFFT : g.nfft, bps = jp.bits_per_sample;
     const int32_t *in = input + it.sample_off;
     const bool aligned = input_aligned(in, iv);
     const bool first_pass = (pass == 1) || (jp.ltp_order == 0);   /* the pass that owns the pre-emphasis tap */
@@ -671,7 +750,7 @@ __global__ __launch_bounds__(NTK) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         return;
     }
 #endif
-    autocorr_in_place<R, NTK, F16>(buf, nfft, twiddles + g.tw_off, (num_lags < nfft && !dump) ? num_lags : nfft);
+    autocorr_in_place<R, NTK, F16, NFFT>(buf, nfft, twiddles + g.tw_off, (num_lags < nfft && !dump) ? num_lags : nfft);
     if (dump) {
         double *dst = chain_pool + (it.chain_dump - 1u);
         for (uint32_t i = tid; i < nfft; i += NTK) { const cplx z = buf[cidx<F16>(i >> 1)]; dst[i] = (i & 1u) ? z.y : z.x; }
@@ -3480,7 +3559,7 @@ extern "C" int srla_launch_chain_commit(hipStream_t stream, double *pool, const 
 }
 
 /* --------------------------------------------------------------------------- launchers ---- */
-static SrlaLaunchTuning g_tune = { 0u, 0u, 0u, 0u };
+static SrlaLaunchTuning g_tune = { 0u, 0u, 0u, 0u, 0u };
 extern "C" void srla_set_launch_tuning(const SrlaLaunchTuning *t) { if (t) g_tune = *t; }
 
 #define SET_LDS_ATTR(fn)                                                                                     \
@@ -3493,7 +3572,7 @@ extern "C" int srla_launch_autocorr(hipStream_t stream, int rclass, const SrlaJo
                                     const SrlaItemDesc *items, const SrlaGeom *geoms, const void *twiddles,
                                     uint32_t pass, SrlaItemResult *results, double *lags_ws, double *dbg,
                                     const SrlaAutocorrItem *class_items, uint32_t count, hipEvent_t ev_start, hipEvent_t ev_stop,
-                                    double *chain_pool, const uint32_t *chain_tab)
+                                    double *chain_pool, const uint32_t *chain_tab, int exact_nfft)
 {
     if (count == 0) return 0;
     /* rclass = largest FFT size of the launch / 2048 (0: <= 1024 points).  LDS: nfft / 2 complex slots */
@@ -3511,6 +3590,25 @@ extern "C" int srla_launch_autocorr(hipStream_t stream, int rclass, const SrlaJo
      * and half the LDS cycles, but 21 % more VALU instructions and, for 2048 points, half the wavefronts per item: measured
      * 163 vs 159 us (4096) and 80 vs 61 us (2048) per launch at the metric configuration -- an option, not the default. */
     const int fused = g_tune.fused_fft ? 1 : 0;
+    /* outside chain mode the items of a launch (classes of more than 1024 points; `exact_nfft`: also the 1024-point class) all
+     * have the class's FFT size: the kernel with the transform's length compiled in */
+    if (chain_pool == nullptr && !fused && !g_tune.generic_fft && (rclass != 0 || exact_nfft)) {
+#define LAUNCH_CT(RR, TT, NF)                                                                                \
+    do {                                                                                                     \
+        SET_LDS_ATTR((srla_autocorr<RR, TT, false, NF>));                                                    \
+        hipExtLaunchKernelGGL((srla_autocorr<RR, TT, false, NF>), grid, dim3(TT), lds, stream, ev_start, ev_stop, 0, *jp, input, items, geoms, \
+                           (const cplx *)twiddles, fft_bytes, pass, results, lags_ws, dbg, class_items, count, chain_pool, chain_tab); \
+    } while (0)
+        switch (rclass) {
+        case 0: LAUNCH_CT(1, 128, 1024); break;
+        case 1: LAUNCH_CT(1, 256, 2048); break;
+        case 2: LAUNCH_CT(2, 256, 4096); break;
+        case 4: LAUNCH_CT(2, 512, 8192); break;
+        default: return -1;
+        }
+#undef LAUNCH_CT
+        return (hipGetLastError() == hipSuccess) ? 0 : -2;
+    }
     switch (rclass * 10 + fused) {
     case 0: case 1: LAUNCH(1, 128, false); break;     /* <= 1024 points: 128 threads (one butterfly each and stage), 8 KB of LDS */
     case 10: LAUNCH(1, 256, false); break;
