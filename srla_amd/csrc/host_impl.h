@@ -181,6 +181,7 @@ struct Impl {
     bool pin_too_slow = false;          /* registration measured slower than staging would be (no huge pages): not tried again */
     bool wave_fft = false;              /* SRLA_MI355X_WAVE_FFT=1: 1024- to 8192-point items on srla_autocorr_w (register-resident transform, autocorr_wave.hip)
                                          * instead of srla_autocorr: bit-identical, measured slower -- an option, not the default */
+    uint32_t run_ahead = 8;             /* SRLA_MI355X_RUN_AHEAD: jobs the host may be ahead of the stage skew (bounded by the buffer sets) */
     uint32_t mix_num = 0, mix_den = 0;  /* SRLA_MI355X_MIX="a,b": pageable planes are locked in place and of every b jobs a are read by DMA, b - a staged (measured at "1,2": M -5 %, config 2 -7 %: off) */
     uint32_t mix_count = 0;
     bool pack_on_n = false;             /* SRLA_MI355X_PACK_ON_N=1: block offsets + assembly on stream N behind the pricing, only the stream-out on C (measured: M device-resident -4 %, config 2 +3 %, others equal -- not the default) */
@@ -194,7 +195,7 @@ struct Impl {
 
     int device = 0;                   /* HIP device of this handle (SRLAMI355X_SetDevice at the time of Create) */
     bool dev_ready = false, dev_failed = false;
-    static constexpr uint32_t kMaxSlots = 11;         /* rotating + 2 tail + 3 chain-mode job buffer sets */
+    static constexpr uint32_t kMaxSlots = 14;         /* up to 9 rotating + 2 tail + 3 chain-mode job buffer sets */
     static constexpr uint32_t kStreams = 3;   /* more streams than HW queues serialise badly (measured) */
     hipStream_t streams[kStreams] = {};
     hipStream_t chain_stream = nullptr; /* autocorrelation rounds of chain mode */

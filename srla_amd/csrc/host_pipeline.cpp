@@ -957,9 +957,14 @@ SRLAApiResult Impl::encode_streams(bool search)
      * (arbitrate) sends the loop back to it. */
     const uint32_t ltp_skew = (par.ltp_order > 0 && split_ltp_stage) ? 1u : 0u;
     const uint32_t depth = 3 + ltp_skew;
+    /* The host may run further ahead than the stages' skew asks for: a job is collected `lag` iterations after it was begun, and
+     * every buffer set beyond depth + 1 is one more job staged and uploaded while the device still works on older ones (host
+     * input: staging 0.28 ms + upload 0.3 ms per 4 M-sample job on top of the 1.5 ms a job takes from its first kernel to its
+     * last byte; with lag = depth the device waited for input about a tenth of the time). */
+    const uint32_t lag = depth + std::min<uint32_t>(run_ahead, (kSlots > depth + 1u) ? kSlots - 1u - depth : 0u);
     uint32_t base = 0, restarts = 0;
     auto in_flight = [&](uint32_t t, uint32_t back) { return t >= back && t - back < njobs && t - back >= base; };
-    for (uint32_t t = 0; t < njobs + depth;) {
+    for (uint32_t t = 0; t < njobs + lag;) {
         const auto t_enq = Clock::now();
         if (in_flight(t, 0)) {
             if (!begin(t) || !run_stage(job_slot(t), ST_A, ltp_skew ? 1 : 0)) return fail(SRLA_APIRESULT_NG);
@@ -994,8 +999,8 @@ SRLAApiResult Impl::encode_streams(bool search)
         }
         stats.h2d_ms += ms_since(t_enq);       /* host time spent staging and enqueueing */
         if (timeline) tl_printf("[timeline] host: iteration %u enqueued at %.3f ms\n", t, ms_since(t0));
-        if (t < depth || t - depth < base) { t++; continue; }
-        const uint32_t k = t - depth;
+        if (t < lag || t - lag < base) { t++; continue; }
+        const uint32_t k = t - lag;
         Slot &s = job_slot(k);
         if (!wait_job(s)) return fail(SRLA_APIRESULT_NG);
         if (timeline) tl_printf("[timeline] host: job %u collected at %.3f ms\n", k, ms_since(t0));
