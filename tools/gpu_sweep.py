@@ -60,14 +60,14 @@ def cases(count, seed, max_samples=6_000_000):
         kind = rnd.choice([helpers.MUSIC, helpers.VARIED, helpers.VARIED, helpers.NOISE, helpers.SINE])
         cli = dict(preset=preset, max_block=max_block, divisions=divisions, ltp_order=ltp, lookahead_factor=lookahead_factor)
         shifted = rnd.random() < 0.15
-        # SVR refinement in one case out of eight (a generator of its own: the other cases stay what they were); even
-        # lengths only, and short ones: the oracle's covariance matrices take their time
+        # SVR refinement in one case out of eight (a generator of its own: the other cases stay what they were), any length and
+        # any regime (its residual is a writer of the reference's buffer in chain / history mode); short streams:
+        # the oracle's covariance matrices take their time
         rnd2 = random.Random(seed * 7919 + case)
         history = (min_block & 1) or (ltp and min_block <= 256)
-        if rnd2.random() < 0.125 and preset > 0 and not history:
+        if rnd2.random() < 0.125 and preset > 0:
             cli["svr_iterations"] = rnd2.choice([1, 2, 3, 5])
-            n = min(n, 200_000 // nch)
-            n -= n % 2
+            n = min(n, (60_000 if history else 200_000) // nch)
             if n == 0:
                 continue
         yield case, nch, bps, n, kind, cli, shifted
