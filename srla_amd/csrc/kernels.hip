@@ -1447,13 +1447,17 @@ extern "C" uint32_t srla_kernel_small_c_bytes(void) { return (uint32_t)((sizeof(
  * neighbouring threads) and the 2047-byte parameter table do.  LDS layout of the signal: four words of
  * padding after every S samples so that the 16-byte window loads of a wavefront are conflict free. */
 struct SmallF {
-    int32_t  coefq[FIR_PAD + 8];
+    union {
+        int32_t  coefq[FIR_PAD + 8];          /* FIR_MAD24 / FIR_WIDE: taps, front padded with zeros to a multiple of four */
+        uint32_t cpack[2][FIR_PAD + 4];       /* FIR_DOT: per group of four taps the four coefficient words of the low plane
+                                               * ([0]: int16 pairs) and of the high plane ([1]: int8 quads), then the closing words */
+    };
     uint32_t level_bits[16];
     uint8_t  ktab[2048];
     double   wave_mean[NWAVES];
     double   thr[32];                 /* Rice parameter thresholds (copy of the host table) */
     uint32_t wave_max[NWAVES];
-    uint32_t pad[4];
+    uint32_t wave_high[NWAVES];       /* FIR_DOT: does any sample of the wavefront leave 16 bits? */
 };
 
 /* LDS layout of the fast path's signal: every thread owns S = 4 FL consecutive samples.  For even FL a pad of four
@@ -1513,10 +1517,41 @@ __device__ __forceinline__ uint32_t mad24(int32_t a, int32_t b, uint32_t acc)
     return r;
 }
 
-/* WIDE: samples beyond 24 bits (24-bit input: M/S, pre-emphasis and the LTP widen it to 28): every tap multiplies
- * the two 16-bit halves of the sample separately on the 24-bit multiplier (x c = (x >> 16) c 2^16 + (x & 0xffff) c
- * modulo 2^32), which is still twice as fast as 32-bit multiplies */
-template <int FL, bool WIDE>
+/* The FIR of the fast path, three ways (all the reference's wrap-around int32 sum, srla_lpc_predict.c:118-265):
+ * FIR_DOT   (input of at most 18 bits, the default): the signal x -- within 24 bits after M/S, pre-emphasis and the LTP -- is split
+ *           exactly as x = 2^16 h + l with l = the sign-extended low half and h = (x - l) >> 16 (8 bits), and kept in LDS as an int16
+ *           plane and an int8 plane.  sum c x = sum c l + 2^16 sum c h modulo 2^32, with the taps (8-bit) packed to match: the low
+ *           plane costs one v_dot2_i32_i16 per TWO taps and sample, the high plane one v_dot4_i32_i8 per FOUR -- and h is zero
+ *           wherever the signal stays within 16 bits (ordinary 16-bit audio below full scale), which the workgroup finds out while it
+ *           packs the planes and then skips the high pass.  A thread's four outputs of a chunk lie at the four byte phases of the
+ *           packed words, so the TAPS are packed in four phases (even / odd for the low plane) and the sample words are used as they
+ *           lie; a tap pair that straddles two groups of four taps is closed by one more word after the loop.
+ * FIR_MAD24 (what FIR_DOT replaced; -DSRLA_FIR_MAD24): one v_mad_i32_i24 per tap and sample on int32 words.
+ * FIR_WIDE  samples beyond 24 bits (24-bit input: M/S, pre-emphasis and the LTP widen it to 28): every tap multiplies
+ *           the two 16-bit halves of the sample separately on the 24-bit multiplier (x c = (x >> 16) c 2^16 + (x & 0xffff) c
+ *           modulo 2^32), which is still twice as fast as 32-bit multiplies */
+#define FIR_MAD24 0
+#define FIR_WIDE  1
+#define FIR_DOT   2
+typedef short srla_short2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t dot2_i16(uint32_t a, uint32_t b, uint32_t acc)
+{
+    return (uint32_t)__builtin_amdgcn_sdot2(__builtin_bit_cast(srla_short2, a), __builtin_bit_cast(srla_short2, b), (int)acc, false);
+}
+__device__ __forceinline__ uint32_t dot4_i8(uint32_t a, uint32_t b, uint32_t acc)
+{
+    return (uint32_t)__builtin_amdgcn_sdot4((int)a, (int)b, (int)acc, false);
+}
+/* distance, in padded groups of four samples, from a thread's first own group to the group d groups away (d < FL): going
+ * back, a pad group lies behind every FL groups (even FL only, see sig_index); d is the same in every lane */
+template <int FL>
+__device__ __forceinline__ int group_offset(int d)
+{
+    if constexpr (FL & 1) return d;
+    else return (d < 0) ? d - ((FL - 1 - d) / FL) : d;
+}
+
+template <int FL, int MODE>
 __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, const InputView &iv, const int32_t *__restrict__ in, const SrlaItemDesc &it,
                                    unsigned char *lds, const double *__restrict__ rice_thresholds,
                                    int32_t *__restrict__ res_ws, SrlaItemResult *__restrict__ out)
@@ -1526,6 +1561,13 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
     constexpr int PADS = ((PADMIN + S - 1) / S) * S;            /* front padding, a multiple of S: covers the FIR's reach back and the LTP's */
     constexpr int PADW = (FL & 1) ? 0 : 4;                      /* see sig_index */
     constexpr uint32_t SIG_WORDS = (uint32_t)((PADS + 1024 * FL) / S) * (S + PADW) + 8;
+    constexpr bool WIDE = MODE == FIR_WIDE, DOT = MODE == FIR_DOT;
+    /* FIR_DOT: the two planes lie over the int32 signal (which then only the LTP uses, before them): PADF zeros + the block, in
+     * the same padded element order as the int32 layout */
+    constexpr int PADF = ((FIR_PAD + S - 1) / S) * S;
+    constexpr uint32_t PLANE_ELEMS = (uint32_t)((PADF + 1024 * FL) / S) * (S + PADW);
+    constexpr uint32_t HIGH_OFF = (PLANE_ELEMS * 2 + 15) & ~15u;
+    static_assert(HIGH_OFF + PLANE_ELEMS <= SIG_WORDS * 4, "the planes fit the int32 signal's LDS");
     int32_t *sig = (int32_t *)lds;
     SmallF *sm = (SmallF *)(lds + ((SIG_WORDS * 4 + 15) & ~15u));
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1561,9 +1603,52 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
 #define PUBLISH_Y()                                                                                              \
     _Pragma("unroll") for (int c = 0; c < FL; c++)                                                               \
         *reinterpret_cast<int4 *>(sig + sig_index<FL>(PADS + (int)s_base + 4 * c)) = make_int4(y[4 * c], y[4 * c + 1], y[4 * c + 2], y[4 * c + 3]);
-    PUBLISH_Y();
-    for (uint32_t i = tid; i < (uint32_t)(PADS / S) * (S + PADW); i += NT) sig[i] = 0;    /* front padding */
-    for (uint32_t k = tid; k < o4; k += NT) sm->coefq[k] = (k < o4 - order) ? 0 : (int32_t)out->lpc_coef[k - (o4 - order)];
+    /* FIR_DOT: the block as two planes, x = 2^16 h + l (the wavefront notes whether any of its h is not zero) */
+    auto publish_planes = [&]() {
+        uint32_t hq[S], high_any = 0;
+#pragma unroll
+        for (int i = 0; i < S; i++) { hq[i] = (uint32_t)((y[i] + 0x8000) >> 16); high_any |= hq[i]; }
+        const bool wave_high = __any((int)(high_any != 0));
+#pragma unroll
+        for (int c = 0; c < FL; c++) {
+            const uint32_t e = sig_index<FL>(PADF + (int)s_base + 4 * c);
+            *reinterpret_cast<uint2 *>(lds + 2 * e) = make_uint2(((uint32_t)y[4 * c] & 0xFFFFu) | ((uint32_t)y[4 * c + 1] << 16),
+                                                                 ((uint32_t)y[4 * c + 2] & 0xFFFFu) | ((uint32_t)y[4 * c + 3] << 16));
+            uint32_t hw = 0;
+            if (wave_high) hw = (hq[4 * c] & 0xFFu) | ((hq[4 * c + 1] & 0xFFu) << 8) | ((hq[4 * c + 2] & 0xFFu) << 16) | (hq[4 * c + 3] << 24);
+            *reinterpret_cast<uint32_t *>(lds + HIGH_OFF + e) = hw;
+        }
+        if (lane == 0) sm->wave_high[wave] = wave_high ? 1u : 0u;
+        constexpr uint32_t FRONT = (uint32_t)(PADF / S) * (S + PADW);     /* front padding, elements */
+        for (uint32_t i = tid; i < FRONT / 2; i += NT) reinterpret_cast<uint32_t *>(lds)[i] = 0;
+        for (uint32_t i = tid; i < FRONT / 4; i += NT) reinterpret_cast<uint32_t *>(lds + HIGH_OFF)[i] = 0;
+    };
+    if (DOT && period == 0) publish_planes();
+    else {
+        PUBLISH_Y();
+        for (uint32_t i = tid; i < (uint32_t)(PADS / S) * (S + PADW); i += NT) sig[i] = 0;    /* front padding */
+    }
+    if constexpr (DOT) {
+        /* tap k of the zero-padded, reversed filter (k outside [0, o4): zero) */
+        auto cq = [&](int k) -> uint32_t {
+            return (k < (int)(o4 - order) || k >= (int)o4) ? 0u : (uint32_t)(int32_t)out->lpc_coef[k - (int)(o4 - order)];
+        };
+        for (uint32_t g = tid; g <= (o4 >> 2); g += NT) {
+            const int b = 4 * (int)g;
+            const uint32_t c[7] = { cq(b - 3), cq(b - 2), cq(b - 1), cq(b), cq(b + 1), cq(b + 2), cq(b + 3) };   /* c[3 + d] = tap b + d */
+            /* low plane: outputs 0 and 2 of a chunk use (b, b+1) (b+2, b+3), outputs 1 and 3 (b-1, b) (b+1, b+2) */
+            sm->cpack[0][b + 0] = (c[3] & 0xFFFFu) | (c[4] << 16);
+            sm->cpack[0][b + 1] = (c[5] & 0xFFFFu) | (c[6] << 16);
+            sm->cpack[0][b + 2] = (c[2] & 0xFFFFu) | (c[3] << 16);
+            sm->cpack[0][b + 3] = (c[4] & 0xFFFFu) | (c[5] << 16);
+            /* high plane: output r of a chunk uses taps b - r .. b - r + 3 */
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                sm->cpack[1][b + r] = (c[3 - r] & 0xFFu) | ((c[4 - r] & 0xFFu) << 8) | ((c[5 - r] & 0xFFu) << 16) | (c[6 - r] << 24);
+        }
+    } else {
+        for (uint32_t k = tid; k < o4; k += NT) sm->coefq[k] = (k < o4 - order) ? 0 : (int32_t)out->lpc_coef[k - (o4 - order)];
+    }
     if (tid < 16) sm->level_bits[tid] = 0;
     if (tid >= 32 && tid < 64) sm->thr[tid - 32] = rice_thresholds[tid - 32];
     __syncthreads();
@@ -1603,7 +1688,7 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
             }
         }
         __syncthreads();
-        PUBLISH_Y();
+        if constexpr (DOT) publish_planes(); else PUBLISH_Y();
         __syncthreads();
     }
 #undef PUBLISH_Y
@@ -1614,15 +1699,70 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
     {
         const int32_t half = (int32_t)(1u << ((rshift - 1u) & 31u));
         uint32_t acc[S];
-        int4 cur[FL];
 #pragma unroll
         for (int i = 0; i < S; i++) acc[i] = (uint32_t)half;
+        int32_t yprev = 0;
+        if constexpr (DOT) {
+            const int ng = (int)__builtin_amdgcn_readfirstlane(o4 >> 2);          /* groups of four taps */
+            const uint2 *lgrp = reinterpret_cast<const uint2 *>(lds);               /* low plane: a group = four int16 */
+            const uint32_t *hgrp = reinterpret_cast<const uint32_t *>(lds + HIGH_OFF);   /* high plane: a group = four int8 */
+            const int own = (int)(sig_index<FL>(PADF + (int)s_base) >> 2);           /* the thread's first own group */
+            uint2 cur[FL];
+#pragma unroll
+            for (int c = 0; c < FL; c++) cur[c] = lgrp[own + group_offset<FL>(c - ng)];
+            for (int j = 0; j < ng; j++) {
+                const uint4 cf = *reinterpret_cast<const uint4 *>(&sm->cpack[0][4 * j]);
+#pragma unroll
+                for (int c = 0; c < FL; c++) {
+                    const uint2 nxt = lgrp[own + group_offset<FL>(c + j + 1 - ng)];
+                    acc[4 * c + 0] = dot2_i16(cf.y, cur[c].y, dot2_i16(cf.x, cur[c].x, acc[4 * c + 0]));
+                    acc[4 * c + 1] = dot2_i16(cf.w, cur[c].y, dot2_i16(cf.z, cur[c].x, acc[4 * c + 1]));
+                    acc[4 * c + 2] = dot2_i16(cf.y, nxt.x, dot2_i16(cf.x, cur[c].y, acc[4 * c + 2]));
+                    acc[4 * c + 3] = dot2_i16(cf.w, nxt.x, dot2_i16(cf.z, cur[c].y, acc[4 * c + 3]));
+                    cur[c] = nxt;
+                }
+            }
+            {
+                /* the last tap of the odd outputs: its partner in the pair is the output's own sample, times zero */
+                const uint32_t cl = sm->cpack[0][4 * ng + 2];
+#pragma unroll
+                for (int c = 0; c < FL; c++) {
+                    acc[4 * c + 1] = dot2_i16(cl, cur[c].x, acc[4 * c + 1]);
+                    acc[4 * c + 3] = dot2_i16(cl, cur[c].y, acc[4 * c + 3]);
+                }
+            }
+            const uint4 wh = *reinterpret_cast<const uint4 *>(sm->wave_high);
+            if (__builtin_amdgcn_readfirstlane(wh.x | wh.y | wh.z | wh.w)) {
+                uint32_t ah[S];
+#pragma unroll
+                for (int i = 0; i < S; i++) ah[i] = 0;
+                for (int j = 0; j <= ng; j++) {
+                    /* group ng closes the pass: the taps that are left for outputs 1..3 meet the chunk's own samples */
+                    const uint4 cf = *reinterpret_cast<const uint4 *>(&sm->cpack[1][4 * j]);
+#pragma unroll
+                    for (int c = 0; c < FL; c++) {
+                        const uint32_t a = hgrp[own + group_offset<FL>(c + j - ng)];
+                        ah[4 * c + 0] = dot4_i8(cf.x, a, ah[4 * c + 0]);
+                        ah[4 * c + 1] = dot4_i8(cf.y, a, ah[4 * c + 1]);
+                        ah[4 * c + 2] = dot4_i8(cf.z, a, ah[4 * c + 2]);
+                        ah[4 * c + 3] = dot4_i8(cf.w, a, ah[4 * c + 3]);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < S; i++) acc[i] += ah[i] << 16;
+            }
+            if (tid != 0 && s_base < order) {
+                const uint32_t e = sig_index<FL>(PADF + (int)s_base - 1);
+                yprev = (int32_t)*reinterpret_cast<const int16_t *>(lds + 2 * e) + ((int32_t)*reinterpret_cast<const int8_t *>(lds + HIGH_OFF + e)) * 65536;
+            }
+        } else {
+        int4 cur[FL];
 #pragma unroll
         for (int c = 0; c < FL; c++) cur[c] = *reinterpret_cast<const int4 *>(sig + sig_index<FL>(PADS + (int)s_base + 4 * c - (int)o4));
         /* !WIDE: every sample fits in 24 bits (bps <= 18: |x| < 2^(bps-1) per channel, S = R - L doubles it,
          * pre-emphasis doubles again, the LTP at most quadruples) and the taps are 8-bit, so the full-rate 24-bit
          * multiply gives the same low 32 bits as the wrap-around 32-bit product */
-        if constexpr (!WIDE) {
+        if constexpr (MODE == FIR_MAD24) {
         for (uint32_t kb = 0; kb < o4; kb += 4) {
             const int4 cf = *reinterpret_cast<const int4 *>(&sm->coefq[kb]);
 #pragma unroll
@@ -1669,7 +1809,8 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
             }
         }
         }
-        const int32_t yprev = (tid == 0) ? 0 : sig[sig_index<FL>(PADS + (int)s_base - 1)];
+        yprev = (tid == 0) ? 0 : sig[sig_index<FL>(PADS + (int)s_base - 1)];
+        }
         int32_t *res_out = res_ws + it.res_off + s_base;
         int32_t rr[S];
 #pragma unroll
@@ -1985,6 +2126,11 @@ __device__ __forceinline__ void rice_search_finish(const uint32_t *u, const Srla
     }
 }
 
+#ifdef SRLA_FIR_MAD24
+#define SRLA_FIR_NARROW FIR_MAD24
+#else
+#define SRLA_FIR_NARROW FIR_DOT
+#endif
 template <int R>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(R >= 4 ? 2 : 5, 8))) void srla_residual_cost(
     SrlaJobParams jp, const int32_t *__restrict__ input, const SrlaItemDesc *__restrict__ items,
@@ -2008,8 +2154,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(R >= 4 ? 2 :
             SrlaItemResult *outf = &results[block];
 #define FAST(FLV)                                                                                                   \
             do {                                                                                                    \
-                if (jp.bits_per_sample <= 18) residual_cost_fast<FLV, false>(jp, iv, inf, itf, lds, rice_thresholds, res_ws, outf); \
-                else residual_cost_fast<FLV, true>(jp, iv, inf, itf, lds, rice_thresholds, res_ws, outf);          \
+                if (jp.bits_per_sample <= 18) residual_cost_fast<FLV, SRLA_FIR_NARROW>(jp, iv, inf, itf, lds, rice_thresholds, res_ws, outf); \
+                else residual_cost_fast<FLV, FIR_WIDE>(jp, iv, inf, itf, lds, rice_thresholds, res_ws, outf);       \
                 return;                                                                                             \
             } while (0)
             switch (fl) {
