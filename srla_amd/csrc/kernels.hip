@@ -145,6 +145,11 @@ __device__ __forceinline__ void fft_complex_lds_ct(cplx *x, const cplx *__restri
     const uint32_t tid = threadIdx.x;
     constexpr uint32_t nb = M >> 2, m4 = M >> 2;
     constexpr int NST = (M >= 4096) ? 6 : ((M >= 1024) ? 5 : ((M >= 256) ? 4 : ((M >= 64) ? 3 : ((M >= 16) ? 2 : 1))));   /* radix-4 stages: n = M, M/4, ... > 2 */
+#ifdef SRLA_FFT_NO_SWZ12
+    constexpr bool SWZ12 = false;
+#else
+    constexpr bool SWZ12 = M >= 128;      /* the first stage's outputs permuted in LDS, see below */
+#endif
     uint32_t twoff = 0;
 #pragma unroll
     for (int st = 0; st < NST; st++) {
@@ -163,7 +168,8 @@ __device__ __forceinline__ void fft_complex_lds_ct(cplx *x, const cplx *__restri
                 if (k1) w1[r] = t[0];
                 if (k2) w2[r] = t[n1];
                 if (k3) w3[r] = t[2 * n1];
-                const cplx *xi = x + bf;
+                /* SWZ12, second stage: the first stage left its outputs in the permuted order (below) */
+                const cplx *xi = x + ((SWZ12 && st == 1) ? (bf ^ ((bf >> 3) & 3u)) : bf);
                 a[r] = xi[0]; b[r] = xi[m4]; c[r] = xi[2 * m4]; d[r] = xi[3 * m4];
             }
         }
@@ -176,11 +182,27 @@ __device__ __forceinline__ void fft_complex_lds_ct(cplx *x, const cplx *__restri
                 const cplx apc = c_add(a[r], c[r]), amc = c_sub(a[r], c[r]), bpd = c_add(b[r], d[r]);
                 const cplx bmd = c_sub(b[r], d[r]);
                 const cplx jbmd = (FLAG < 0) ? make_double2(-bmd.y, bmd.x) : make_double2(bmd.y, -bmd.x);
+                if (SWZ12 && st == 0) {
+                    /* First stage: a thread's four outputs are the consecutive elements 4 bf .. 4 bf + 3, so the eight lanes a
+                     * ds_write_b128 is served in store 64 bytes apart: output k of every second lane lands in the same 16-byte
+                     * column of the eight (4-way conflicts on all four stores).  Element e therefore goes to e ^ ((e >> 3) & 3):
+                     * the four elements of a thread are permuted among themselves, differently in the four lanes that share a
+                     * column, and the eight stores land in eight columns.  The second stage reads elements bf + k m/4, lanes of a
+                     * quad permuted within the quad -- a ds_read_b128 is served in groups made of whole quads, so it stays
+                     * conflict-free. */
+                    const uint32_t kx = (bf >> 1) & 3u;
+                    cplx *xo = x + 4u * bf;
+                    xo[kx] = c_add(apc, bpd);
+                    if (k1) xo[1u ^ kx] = c_mul(w1[r], c_sub(amc, jbmd));
+                    if (k2) xo[2u ^ kx] = c_mul(w2[r], c_sub(apc, bpd));
+                    if (k3) xo[3u ^ kx] = c_mul(w3[r], c_add(amc, jbmd));
+                } else {
                 cplx *xo = x + (4u * bf - 3u * q);
                 xo[0] = c_add(apc, bpd);
                 if (k1) xo[s] = c_mul(w1[r], c_sub(amc, jbmd));
                 if (k2) xo[2 * s] = c_mul(w2[r], c_sub(apc, bpd));
                 if (k3) xo[3 * s] = c_mul(w3[r], c_add(amc, jbmd));
+                }
             }
         }
         __syncthreads();
@@ -642,14 +664,28 @@ __global__ __launch_bounds__(NTK) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     if (pass == 0 && jp.max_order == 0 && !chain) return;   /* preset 0: fixed order 0, no LPC analysis needed */
 
     /* pre-emphasis in registers: y[i] = x[i] - ((x[i-1] * coef) >> 4), x[-1] = x[0] (srla_utility.c:342) */
+    if (jp.bits_per_sample <= 18) {
+        /* narrow input: sample (at most 19 bits) times 5-bit tap on the full-rate 24-bit multiplier */
 #pragma unroll
-    for (int c = 0; c < CH; c++) {
-        int32_t prev = pv[c];
+        for (int c = 0; c < CH; c++) {
+            int32_t prev = pv[c];
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int32_t cur = v[c][i];
-            v[c][i] = (int32_t)((uint32_t)cur - (uint32_t)((int32_t)((uint32_t)prev * (uint32_t)coef) >> 4));
-            prev = cur;
+            for (int i = 0; i < 4; i++) {
+                const int32_t cur = v[c][i];
+                v[c][i] = (int32_t)((uint32_t)cur - (uint32_t)(__mul24(prev, coef) >> 4));
+                prev = cur;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+            int32_t prev = pv[c];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int32_t cur = v[c][i];
+                v[c][i] = (int32_t)((uint32_t)cur - (uint32_t)((int32_t)((uint32_t)prev * (uint32_t)coef) >> 4));
+                prev = cur;
+            }
         }
     }
 
@@ -1596,7 +1632,10 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
 #pragma unroll
         for (int i = 0; i < S; i++) {
             const int32_t cur = y[i];
-            y[i] = (int32_t)((uint32_t)cur - (uint32_t)((int32_t)((uint32_t)prev * (uint32_t)coef) >> 4));
+            /* narrow input: the sample (at most 19 bits: S = R - L of 18-bit input) times the 5-bit tap on the full-rate 24-bit
+             * multiplier (v_mul_lo_u32 issues at a quarter of the rate) */
+            const int32_t prod = WIDE ? (int32_t)((uint32_t)prev * (uint32_t)coef) : __mul24(prev, coef);
+            y[i] = (int32_t)((uint32_t)cur - (uint32_t)(prod >> 4));
             prev = cur;
         }
     }
@@ -1813,15 +1852,25 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
         }
         int32_t *res_out = res_ws + it.res_off + s_base;
         int32_t rr[S];
+        /* the first `order` samples of the block are differenced, not predicted (srla_lpc_predict.c:118-265): only the first
+         * threads of the first wavefront hold any, every other wavefront takes the plain form without per-sample selects */
+        if (__any((int)(order == 0 || s_base < order))) {
+#pragma unroll
+            for (int i = 0; i < S; i++) {
+                const uint32_t s = s_base + i;
+                int32_t rv;
+                if (order == 0 || s == 0) rv = y[i];
+                else if (s < order) rv = (int32_t)((uint32_t)y[i] - (uint32_t)((i == 0) ? yprev : y[i - 1]));
+                else rv = (int32_t)((uint32_t)y[i] + (uint32_t)((int32_t)acc[i] >> rshift));
+                rr[i] = rv;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < S; i++) rr[i] = (int32_t)((uint32_t)y[i] + (uint32_t)((int32_t)acc[i] >> rshift));
+        }
 #pragma unroll
         for (int i = 0; i < S; i++) {
-            const uint32_t s = s_base + i;
-            int32_t rv;
-            if (order == 0 || s == 0) rv = y[i];
-            else if (s < order) rv = (int32_t)((uint32_t)y[i] - (uint32_t)((i == 0) ? yprev : y[i - 1]));
-            else rv = (int32_t)((uint32_t)y[i] + (uint32_t)((int32_t)acc[i] >> rshift));
-            rr[i] = rv;
-            u[i] = zigzag32(rv);
+            u[i] = zigzag32(rr[i]);
             max_u = (u[i] > max_u) ? u[i] : max_u;
         }
         if (jp.keep_residuals)
@@ -1834,12 +1883,23 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
 
     /* partition means: exact integer sums at the finest level, pairwise averages above */
     double m10[4];
+    if (__all((int)(max_u < (1u << 28)))) {
+        /* the sum of a finest partition (at most 8 values) stays within 32 bits: one add per sample and an exact conversion */
 #pragma unroll
-    for (int p = 0; p < 4; p++) {
-        unsigned long long sum = 0;
+        for (int p = 0; p < 4; p++) {
+            uint32_t sum = 0;
 #pragma unroll
-        for (int i = 0; i < FL; i++) sum += u[p * FL + i];
-        m10[p] = (double)sum / (double)FL;
+            for (int i = 0; i < FL; i++) sum += u[p * FL + i];
+            m10[p] = (double)sum / (double)FL;
+        }
+    } else {
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            unsigned long long sum = 0;
+#pragma unroll
+            for (int i = 0; i < FL; i++) sum += u[p * FL + i];
+            m10[p] = (double)sum / (double)FL;
+        }
     }
     double m[11];                                   /* m[l]: mean of the level-l partition this thread lies in */
     const double m9a = (m10[0] + m10[1]) / 2.0, m9b = (m10[2] + m10[3]) / 2.0;

@@ -245,6 +245,55 @@ def test_item_records_residuals_and_lags(product, n, cli_name, kind):
         assert np.allclose(dbg[v, 513:513 + pmax], lens[1:], rtol=1e-12, atol=1e-9)
 
 
+def _full_scale(n, seed, partial=False):
+    """16-bit stereo that leaves 16 bits after S = R - L, the pre-emphasis and the LTP: tones at full scale in anti-phase plus
+    clipped noise.  `partial`: only the second half is loud (some wavefronts of a workgroup see wide samples, others none)."""
+    rng = np.random.default_rng(seed)
+    t = np.arange(n)
+    tone = 32767.0 * np.sign(np.sin(2 * np.pi * t * 0.013)) * (0.55 + 0.45 * np.sin(2 * np.pi * t / 977.0))
+    left = np.clip(tone + rng.normal(0, 6000, n), -32768, 32767)
+    right = np.clip(-tone + rng.normal(0, 6000, n), -32768, 32767)
+    pcm = np.stack([left, right]).astype(np.int32)
+    if partial:
+        pcm[:, :n // 2] >>= 4
+    return pcm
+
+
+@pytest.mark.parametrize("n,cli_name,partial", [(4096, "m4_B4096", False), (4096, "m4_B4096", True), (2048, "m4_B4096", False),
+                                                (1024, "m4_B4096_V2", True), (3072, "m4_B4096_V2_P3", False),
+                                                (4096, "m4_B4096_V2_P3", True), (8192, "m4_B8192_V2_P3", False),
+                                                (5120, "m4_B8192_V2_P3", True), (1000, "m6_B1024_V1_P1", False)])
+def test_full_scale_input_item_records_and_residuals(product, n, cli_name, partial):
+    """srla_residual_cost keeps 16-bit input as an int16 plane plus an int8 plane that is only filtered where the signal leaves 16
+    bits (kernels.hip FIR_DOT); ordinary test signals never do, these always do.  Residuals and parameters per variant."""
+    cli = CLIS[cli_name]
+    pcm = _full_scale(n, 300 + n, partial)
+    assert np.abs(pcm[1] - pcm[0]).max() > 40000
+    recs, res, dbg = _probe(product, pcm, **cli)
+    o = helpers.Oracle(2, **cli)
+    left, right = pcm[0].copy(), pcm[1].copy()
+    side = right - left
+    mid = left + (side >> 1)
+    for v, samples in enumerate((left, right, mid, side)):
+        want, want_res, filtered = o.analyze_channel(samples)
+        got = _fields(recs[v])
+        w = want.as_dict()
+        for key in ("preemph_coef", "lpc_order", "lpc_rshift", "ltp_period", "code_length", "res_code_type", "res_porder", "res_bits",
+                    "lpc_coef"):
+            assert got[key] == w[key], (v, key)
+        assert np.array_equal(res[v], want_res), v
+
+
+@pytest.mark.parametrize("cli_name", ["m4_B4096", "m4_B4096_V2_P3", "m4_B8192_V2_P3", "m2_B4096_V0"])
+def test_full_scale_stream_bytes_equal_oracle(product, cli_name):
+    cli = CLIS[cli_name]
+    pcm = np.concatenate([_full_scale(40000, 7), _full_scale(33000, 8, True)], axis=1)
+    got = product.encode(pcm, **cli)
+    want = helpers.Oracle(2, **cli).encode_whole(pcm)
+    assert np.array_equal(got, want)
+    assert np.array_equal(helpers.oracle_decode(got), pcm)
+
+
 # ------------------------------------------------------------------------------ block API ------
 def test_block_calls(product):
     cli = dict(preset=4, max_block=4096, divisions=2)
