@@ -34,6 +34,7 @@ enum { SRLA_CODE_RICE = 0, SRLA_CODE_RECURSIVE_RICE = 1, SRLA_CODE_ALLZERO = 2 }
 #define SRLA_ITEM_LTP_FAIL     8u   /* 3x3 Cholesky failed: the reference returns NG           */
 #define SRLA_ITEM_ODD_LENGTH   16u  /* odd block length: reference result is history dependent */
 #define SRLA_ITEM_SVR_TIE      32u  /* SVR refinement: a comparison of objective values within the libm tolerance */
+#define SRLA_ITEM_RES_U16      64u  /* the item's residual stands in the scratch zig-zag mapped, as uint16 (srla_residual_cost) */
 
 /* Per block-length constants the host prepares with the host libm. */
 typedef struct SrlaGeom {
@@ -194,8 +195,9 @@ typedef struct SrlaJobParams {
     uint32_t num_items;
     uint32_t num_cands;
     uint32_t num_windows;
-    uint32_t keep_residuals;  /* srla_residual_cost stores every item's residual and srla_pack_blocks reads the chosen ones (the
-                               * default, and what SRLAMI355X_ProbeBlock returns); 0 (SRLA_MI355X_RECOMPUTE_RESIDUALS): none are
+    uint32_t keep_residuals;  /* srla_residual_cost stores every item's residual and srla_pack_blocks reads the chosen ones (1: the
+                               * default, zig-zag mapped uint16 where a block's values fit, SRLA_ITEM_RES_U16; 2: always the int32
+                               * residual -- what SRLAMI355X_ProbeBlock returns, SRLA_MI355X_RES32); 0 (SRLA_MI355X_RECOMPUTE_RESIDUALS): none are
                                * stored and srla_pack_blocks recomputes the chosen blocks' (blocks > 8192 samples always keep) */
     uint32_t out_stride;      /* SRLA_DIAG_STOP builds only: where srla_residual_cost stops (kernel timing experiments) */
     const uint32_t *lshift_dev; /* when non-null the offset left shift is read from here (device memory) instead of the

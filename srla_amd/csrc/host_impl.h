@@ -189,6 +189,7 @@ struct Impl {
     uint32_t short_div = 4;             /* SRLA_MI355X_SHORT_DIV: a stream shorter than one job is cut into pieces of a job / this */
     bool split_ltp_stage = true;        /* SRLA_MI355X_NO_LTP_SKEW: stage A of LTP jobs in one piece on W, as before */
     bool keep_residuals_always = true;  /* false with SRLA_MI355X_RECOMPUTE_RESIDUALS */
+    bool res32 = false;                 /* SRLA_MI355X_RES32: the residual scratch always holds int32 (no uint16 form) */
     bool keep_residuals = false;      /* SRLAMI355X_ProbeBlock with a residual buffer: srla_residual_cost stores what it prices */
     uint32_t offset_lshift = 0;       /* encoder->header.offset_lshift of the reference: set by EncodeWhole, used by the block calls */
     uint32_t pack_threads = 0;

@@ -1850,7 +1850,6 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
         }
         yprev = (tid == 0) ? 0 : sig[sig_index<FL>(PADS + (int)s_base - 1)];
         }
-        int32_t *res_out = res_ws + it.res_off + s_base;
         int32_t rr[S];
         /* the first `order` samples of the block are differenced, not predicted (srla_lpc_predict.c:118-265): only the first
          * threads of the first wavefront hold any, every other wavefront takes the plain form without per-sample selects */
@@ -1873,9 +1872,6 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
             u[i] = zigzag32(rr[i]);
             max_u = (u[i] > max_u) ? u[i] : max_u;
         }
-        if (jp.keep_residuals)
-#pragma unroll
-            for (int c = 0; c < FL; c++) *reinterpret_cast<int4 *>(res_out + 4 * c) = make_int4(rr[4 * c], rr[4 * c + 1], rr[4 * c + 2], rr[4 * c + 3]);
     }
 #ifdef SRLA_DIAG_STOP
     if (jp.out_stride == 2) { if (max_u == 0x7fffffff) out->pad[1] = 1; return; }   /* kernel timing experiments (make EXTRA=-DSRLA_DIAG_STOP): never in the shipped library */
@@ -1921,6 +1917,36 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
         m[0] = (m1a + m1b) / 2.0;
         max_u = sm->wave_max[0];
         for (int w = 1; w < NWAVES; w++) max_u = (sm->wave_max[w] > max_u) ? sm->wave_max[w] : max_u;
+    }
+    /* The residual goes to the scratch in HBM for srla_pack_blocks -- of EVERY item, chosen or not, which made these stores most
+     * of the launch's memory traffic.  What the pack kernel codes is the zig-zag mapped value, and where the block's largest one
+     * fits 16 bits (ordinary 16-bit audio) that is what is stored, two bytes per sample, in the first half of the item's region
+     * (SRLA_ITEM_RES_U16); else, and for SRLAMI355X_ProbeBlock (keep_residuals == 2), the int32 residual. */
+    if (jp.keep_residuals) {
+        if (jp.keep_residuals == 1u && max_u < 65536u) {
+            uint32_t *r16 = reinterpret_cast<uint32_t *>(res_ws + it.res_off) + (s_base >> 1);
+            if constexpr ((FL & 1) == 0) {
+#pragma unroll
+                for (int c = 0; c < FL / 2; c++)
+                    *reinterpret_cast<uint4 *>(r16 + 4 * c) = make_uint4(u[8 * c] | (u[8 * c + 1] << 16), u[8 * c + 2] | (u[8 * c + 3] << 16),
+                                                                       u[8 * c + 4] | (u[8 * c + 5] << 16), u[8 * c + 6] | (u[8 * c + 7] << 16));
+            } else {
+#pragma unroll
+                for (int c = 0; c < FL; c++)
+                    *reinterpret_cast<uint2 *>(r16 + 2 * c) = make_uint2(u[4 * c] | (u[4 * c + 1] << 16), u[4 * c + 2] | (u[4 * c + 3] << 16));
+            }
+            if (tid == 0) out->flags |= SRLA_ITEM_RES_U16;
+        } else {
+            if (tid == 0) out->flags &= ~SRLA_ITEM_RES_U16;
+            int32_t *res_out = res_ws + it.res_off + s_base;
+#pragma unroll
+            for (int c = 0; c < FL; c++) {
+                int32_t r4[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) r4[i] = (int32_t)((u[4 * c + i] >> 1) ^ (0u - (u[4 * c + i] & 1u)));
+                *reinterpret_cast<int4 *>(res_out + 4 * c) = make_int4(r4[0], r4[1], r4[2], r4[3]);
+            }
+        }
     }
     uint32_t code_type;
     if (max_u == 0) code_type = SRLA_CODE_ALLZERO;
@@ -3483,13 +3509,21 @@ __device__ __forceinline__ void pack_block_body(
                 const uint32_t s0 = (tid * per < n) ? tid * per : n, s1 = (s0 + per < n) ? (s0 + per) : n;
                 const uint32_t part0 = (s0 < n) ? s0 / plen : 0;
                 const bool cached = per <= CACHE && (per & 3u) == 0 && s0 + per <= n;   /* s0 is a multiple of 4: aligned */
+                /* srla_residual_cost left the zig-zag mapped residual as uint16 where the block's values fit (see there) */
+                const bool res_u16 = (ir->flags & SRLA_ITEM_RES_U16) != 0u;
+                const uint16_t *res16 = reinterpret_cast<const uint16_t *>(res);
                 uint32_t uc[CACHE];
                 if (cached) {
 #pragma unroll
                     for (uint32_t c = 0; c < CACHE / 4; c++) {
                         if (4 * c < per) {
-                            const int4 q = *reinterpret_cast<const int4 *>(res + s0 + 4 * c);
-                            uc[4 * c] = zigzag32(q.x); uc[4 * c + 1] = zigzag32(q.y); uc[4 * c + 2] = zigzag32(q.z); uc[4 * c + 3] = zigzag32(q.w);
+                            if (res_u16) {
+                                const uint2 q = *reinterpret_cast<const uint2 *>(res16 + s0 + 4 * c);
+                                uc[4 * c] = q.x & 0xFFFFu; uc[4 * c + 1] = q.x >> 16; uc[4 * c + 2] = q.y & 0xFFFFu; uc[4 * c + 3] = q.y >> 16;
+                            } else {
+                                const int4 q = *reinterpret_cast<const int4 *>(res + s0 + 4 * c);
+                                uc[4 * c] = zigzag32(q.x); uc[4 * c + 1] = zigzag32(q.y); uc[4 * c + 2] = zigzag32(q.z); uc[4 * c + 3] = zigzag32(q.w);
+                            }
                         }
                     }
                 }
@@ -3512,7 +3546,7 @@ __device__ __forceinline__ void pack_block_body(
 #pragma unroll
                         for (uint32_t i = 0; i < CACHE; i++) if (i < per) count(s0 + i, uc[i]);
                     } else {
-                        for (uint32_t s = s0; s < s1; s++) count(s, zigzag32(res[s]));
+                        for (uint32_t s = s0; s < s1; s++) count(s, res_u16 ? (uint32_t)res16[s] : zigzag32(res[s]));
                     }
                 }
                 /* exclusive prefix sum over the workgroup */
@@ -3556,7 +3590,7 @@ __device__ __forceinline__ void pack_block_body(
 #pragma unroll
                         for (uint32_t i = 0; i < CACHE; i++) if (i < per) emit(s0 + i, uc[i]);
                     } else {
-                        for (uint32_t s = s0; s < s1; s++) emit(s, zigzag32(res[s]));
+                        for (uint32_t s = s0; s < s1; s++) emit(s, res_u16 ? (uint32_t)res16[s] : zigzag32(res[s]));
                     }
                 }
             }
