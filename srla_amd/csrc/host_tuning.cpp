@@ -53,12 +53,14 @@ void Impl::read_environment()
     if (is_set("SRLA_MI355X_PACK_ON_N")) pack_on_n = number("SRLA_MI355X_PACK_ON_N", 1) != 0;
     if (const char *e = getenv("SRLA_MI355X_MIX")) { unsigned a = 0, b = 0; if (sscanf(e, "%u,%u", &a, &b) == 2 && a <= b) { mix_num = a; mix_den = b; } }
     { const long long v = number("SRLA_MI355X_RUN_AHEAD", -1); if (v >= 0 && v <= 8) run_ahead = (uint32_t)v; }
-    SrlaLaunchTuning lt;
+    SrlaLaunchTuning lt = {};
     lt.fused_fft = number("SRLA_MI355X_FUSED_FFT", 0) != 0 ? 1u : 0u;     /* two FFT stages per LDS round trip */
     lt.pack_lds_cap_words = (uint32_t)std::max<long long>(0, number("SRLA_MI355X_PACK_LDS_WORDS", 0));   /* tests: reach the global-memory pack path */
     lt.out_wgs = (uint32_t)std::max<long long>(0, number("SRLA_MI355X_OUT_WGS", 0));
     lt.generic_fft = number("SRLA_MI355X_GENERIC_FFT", 0) != 0 ? 1u : 0u;
     lt.solve_onepass = number("SRLA_MI355X_SOLVE_ONEPASS", 0) != 0 ? 1u : 0u;   /* the solve chain as one launch (round 2's default) */
+    lt.solve_lds = (uint32_t)std::max<long long>(0, number("SRLA_MI355X_SOLVE_LDS", 0));
+    lt.errvars_regs = number("SRLA_MI355X_ERRVARS_REGS", 0) != 0 ? 1u : 0u;
     srla_set_launch_tuning(&lt);
 
     /* ---- diagnostics ------------------------------------------------------------------------------------------------ */

@@ -110,6 +110,8 @@ typedef struct {
     uint32_t out_wgs;              /* SRLA_MI355X_OUT_WGS: stream-out workgroups, 0 = by sample width */
     uint32_t generic_fft;          /* SRLA_MI355X_GENERIC_FFT: srla_autocorr without the FFT size compiled in, as in round 2 */
     uint32_t solve_onepass;        /* SRLA_MI355X_SOLVE_ONEPASS: srla_lpc_solve_regs instead of errvars + order_select + taps */
+    uint32_t solve_lds;            /* SRLA_MI355X_SOLVE_LDS=8|16|32: orders up to 64 on the LDS chain with that many items per wavefront */
+    uint32_t errvars_regs;         /* SRLA_MI355X_ERRVARS_REGS: srla_lpc_errvars<64> entirely in registers (348 per lane) instead of the lean form */
 } SrlaLaunchTuning;
 void srla_set_launch_tuning(const SrlaLaunchTuning *t);
 #define SRLA_SEGCTL_WORDS_HOST 8

@@ -40,6 +40,17 @@
 
 #pragma clang fp contract(off)
 
+/* The narrow kernels of stream N (a few hundred latency-bound wavefronts: serial fp64 recursions, the window pricing) share their
+ * SIMDs with the wide kernels' wavefronts, which issue VALU instructions back to back: at the default priority a recursion's
+ * next instruction waits its turn behind them and the solve stage of a job took 0.35-0.53 ms beside them against 0.1 ms alone --
+ * longer than the wide stream had work for, so srla_residual_cost of the job waited for it (timeline).  Raised
+ * wave priority lets the few instructions they have go first; they are too few to slow the wide kernels down. */
+#ifdef SRLA_NO_NARROW_PRIORITY
+#define NARROW_KERNEL_PRIORITY() do { } while (0)
+#else
+#define NARROW_KERNEL_PRIORITY() __builtin_amdgcn_s_setprio(3)
+#endif
+
 #include "device_common.h"
 
 /* ------------------------------------------------------------------------------ FFT ------ */
@@ -857,6 +868,7 @@ __global__ __launch_bounds__(WAVE) void srla_pitch_solve(SrlaJobParams jp, const
                                                          const uint32_t *__restrict__ select, uint32_t round,
                                                          uint32_t *__restrict__ ties, double *__restrict__ tie_data)
 {
+    NARROW_KERNEL_PRIORITY();
     /* One LANE per item, 64 items per wavefront.  The lag table is [lag][item], so the lanes of a wavefront read one lag of
      * their 64 items with one coalesced load, and because the scan visits the lags in a fixed order (pitch_scan_step) the
      * loads run ahead of the arithmetic instead of forming a chain of data-dependent round trips (round 2: the lags of 8 items
@@ -1058,6 +1070,7 @@ __global__ __launch_bounds__(WAVE) void srla_order_select(
     const double *__restrict__ err_ws, SrlaItemResult *__restrict__ results, double *__restrict__ dbg,
     uint32_t *__restrict__ ties, const uint32_t *__restrict__ sel, uint32_t sel_round)
 {
+    NARROW_KERNEL_PRIORITY();
     /* (neighbouring items share the 64-byte sectors of the [order][item] table: they go to the same XCD, hence the same L2 --
      * dealt round robin over the XCDs every sector was fetched from HBM eight times, 255 MB per launch at -V 2) */
     const uint32_t idx = xcd_position(blockIdx.x, jp.num_items), lane = threadIdx.x;
@@ -1288,6 +1301,7 @@ template <int P>
 __global__ __launch_bounds__(WAVE) void srla_lpc_errvars(SrlaJobParams jp, const double *__restrict__ lags_ws, double *__restrict__ err_ws,
                                                          double *__restrict__ gamma_ws, const uint32_t *__restrict__ sel, uint32_t sel_round)
 {
+    NARROW_KERNEL_PRIORITY();
     const uint32_t idx = blockIdx.x * WAVE + threadIdx.x;
     if (idx >= jp.num_items) return;
     if (sel != nullptr && sel[idx] != sel_round) return;
@@ -1329,12 +1343,83 @@ __global__ __launch_bounds__(WAVE) void srla_lpc_errvars(SrlaJobParams jp, const
     }
 }
 
+/* srla_lpc_errvars with a footprint that fits beside the wide kernels.  The register form of order 64 holds 348 registers per
+ * lane -- two thirds of a SIMD's file.  Beside srla_residual_cost (five wavefronts of 96 registers per SIMD, a fresh workgroup
+ * taking every slot that frees up) such a wavefront finds no room until the wide launch drains: in a kernel trace of a 600 s
+ * encode srla_lpc_errvars<64> took 31 us when it started just ahead of a wide kernel and 230-470 us otherwise, it ended exactly
+ * where a wide kernel ended, stream N was busy back to back and srla_residual_cost of the job waited for it (0.5 ms of gaps on
+ * stream W per call).  Here the lags r[] and the upper part of the predictor a[] stand in LDS ([index][lane]: conflict-free,
+ * addresses are immediates because everything stays unrolled), AREG entries of a[] in registers and L = 32 items share a
+ * wavefront: about 120 registers and 23 KB of LDS -- what ONE retiring workgroup of a wide kernel leaves behind.  The same
+ * operations in the same order on the same operands (lpc.c:417-438): identical bits. */
+template <int P, int L, int AREG>
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4, 8))) /* at most 128 registers */ void srla_lpc_errvars_lean(SrlaJobParams jp, const double *__restrict__ lags_ws, double *__restrict__ err_ws,
+                                                              double *__restrict__ gamma_ws, const uint32_t *__restrict__ sel, uint32_t sel_round)
+{
+    NARROW_KERNEL_PRIORITY();
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t idx = blockIdx.x * L + lane;
+    if (lane >= (uint32_t)L || idx >= jp.num_items) return;   /* no barriers below: lanes are independent */
+    if (sel != nullptr && sel[idx] != sel_round) return;
+    const size_t stride = jp.num_items;
+    double *rl = reinterpret_cast<double *>(lds) + lane;      /* r[k] at rl[k * L] */
+    double *al = rl + (size_t)(P + 1) * L;                    /* a[i], i >= AREG, at al[(i - AREG) * L] */
+#pragma unroll
+    for (int i = 0; i <= P; i++) rl[i * L] = lags_ws[(size_t)i * stride + idx];
+    const double r0 = rl[0] * (1.0 + 1e-5);                   /* ridge, lpc.c:483 */
+    double *err = err_ws + idx, *gam = gamma_ws + idx;
+    err[0] = r0;
+    if (fabs(r0) < (double)FLT_EPSILON) {
+        /* lpc.c:395-405: every error variance is r0, every predictor zero */
+        for (uint32_t o = 1; o <= (uint32_t)P; o++) { err[(size_t)o * stride] = r0; gam[(size_t)(o - 1) * stride] = 0.0; }
+        return;
+    }
+    double areg[AREG];
+    /* i is a constant wherever these are called (the loops below are fully unrolled), so the choice folds away */
+    auto A = [&](int i) -> double { return (i < AREG) ? areg[i < AREG ? i : 0] : al[(i - AREG) * L]; };
+    auto setA = [&](int i, double v) { if (i < AREG) areg[i < AREG ? i : 0] = v; else al[(i - AREG) * L] = v; };
+    const double r1 = rl[L];
+    const double a1 = -r1 / r0;
+    setA(0, 1.0); setA(1, a1); setA(2, 0.0);
+    double e = r0 + r1 * a1;
+    err[stride] = e;
+    gam[0] = a1;
+#pragma unroll
+    for (int k = 1; k < P; k++) {
+        /* (the fences keep the scheduler from hoisting a whole step's LDS loads to its top: chunks of eight terms, whose loads
+         * are in flight together, stay within the register budget) */
+        double gamma = 0.0;
+#pragma unroll
+        for (int i = 0; i <= k; i++) {
+            gamma += A(i) * rl[(k + 1 - i) * L];                               /* index order, lpc.c:420-423 */
+            if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        gamma /= -e;
+        e = e * (1.0 - gamma * gamma);
+#pragma unroll
+        for (int i = 0; i <= (k + 1) / 2; i++) {
+            const int j = k + 1 - i;
+            const double ai = A(i), aj = A(j);
+            setA(i, ai + gamma * aj);
+            if (i != j) setA(j, aj + gamma * ai);
+            if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        setA(k + 2, 0.0);
+        __builtin_amdgcn_sched_barrier(0);
+        err[(size_t)(k + 1) * stride] = e;
+        gam[(size_t)k * stride] = gamma;
+    }
+}
+
 template <int P>
 __global__ __launch_bounds__(WAVE) void srla_lpc_taps(SrlaJobParams jp, const double *__restrict__ err_ws, const double *__restrict__ gamma_ws,
                                                       const uint8_t *__restrict__ huff_len, SrlaItemResult *__restrict__ results,
                                                       double *__restrict__ coef_ws /* SVR refinement follows: the predictor of the chosen order goes here (row of 64 per item), unquantised */,
                                                       const uint32_t *__restrict__ sel, uint32_t sel_round)
 {
+    NARROW_KERNEL_PRIORITY();
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int L = WAVE;
     const uint32_t lane = threadIdx.x;
@@ -3039,6 +3124,7 @@ __global__ __launch_bounds__(WAVE) void srla_price_windows(SrlaJobParams jp, con
                                                            const SrlaItemResult *__restrict__ results,
                                                            SrlaBlockRecord *__restrict__ blocks)
 {
+    NARROW_KERNEL_PRIORITY();
     __shared__ uint32_t s_packed[SRLA_MAX_WINDOW_CANDS];
     __shared__ uint8_t s_ni[SRLA_MAX_WINDOW_CANDS], s_nj[SRLA_MAX_WINDOW_CANDS];
     __shared__ uint32_t s_cost[SRLA_MAX_NODES], s_path[SRLA_MAX_NODES], s_via[SRLA_MAX_NODES], s_used[SRLA_MAX_NODES];
@@ -3799,7 +3885,7 @@ extern "C" int srla_launch_chain_commit(hipStream_t stream, double *pool, const 
 }
 
 /* --------------------------------------------------------------------------- launchers ---- */
-static SrlaLaunchTuning g_tune = { 0u, 0u, 0u, 0u, 0u };
+static SrlaLaunchTuning g_tune = {};
 extern "C" void srla_set_launch_tuning(const SrlaLaunchTuning *t) { if (t) g_tune = *t; }
 
 #define SET_LDS_ATTR(fn)                                                                                     \
@@ -3896,6 +3982,27 @@ extern "C" int srla_launch_pitch_solve(hipStream_t stream, const SrlaJobParams *
     return (hipGetLastError() == hipSuccess) ? 0 : -2;
 }
 
+/* the recursion of the three-launch solve chain: order 64 in the lean form (srla_lpc_errvars_lean), smaller orders in registers */
+#define ERRVARS_LEAN_L 32
+#define ERRVARS_LEAN_AREG 36
+template <int PP>
+static void launch_errvars(hipStream_t stream, hipEvent_t ev_start, const SrlaJobParams *jp, const double *lags_ws, double *err_ws,
+                           double *gamma_ws, const SrlaSvrExtra &ex)
+{
+    if constexpr (PP == 64) {
+        /* a small job (a short stream, a piece of one) does not fill the chip: nothing to be starved by, and the register form is
+         * twice as fast on its own (31 against 65 us) */
+        if (!g_tune.errvars_regs && jp->num_items >= 6144u) {
+            const uint32_t lds = ((PP + 1) + (PP + 2 - ERRVARS_LEAN_AREG)) * 8 * ERRVARS_LEAN_L;
+            hipExtLaunchKernelGGL((srla_lpc_errvars_lean<PP, ERRVARS_LEAN_L, ERRVARS_LEAN_AREG>), dim3((jp->num_items + ERRVARS_LEAN_L - 1) / ERRVARS_LEAN_L),
+                                  dim3(WAVE), lds, stream, ev_start, nullptr, 0, *jp, lags_ws, err_ws, gamma_ws, ex.select, ex.round);
+            return;
+        }
+    }
+    hipExtLaunchKernelGGL(srla_lpc_errvars<PP>, dim3((jp->num_items + 63) / 64), dim3(WAVE), 0, stream, ev_start, nullptr, 0, *jp, lags_ws, err_ws,
+                          gamma_ws, ex.select, ex.round);
+}
+
 extern "C" int srla_launch_lpc_solve(hipStream_t stream, const SrlaJobParams *jp, const SrlaItemDesc *items,
                                      const SrlaGeom *geoms, const double *lags_ws, double *err_ws, const uint8_t *huff_len,
                                      SrlaItemResult *results, double *dbg, uint32_t *ties, hipEvent_t ev_start, hipEvent_t ev_stop,
@@ -3916,7 +4023,7 @@ extern "C" int srla_launch_lpc_solve(hipStream_t stream, const SrlaJobParams *jp
         const uint32_t lds = 512 + PP * 8 * 64 + PP * 4 * 64;                                                            \
         if (three) {                                                                                                     \
             SET_LDS_ATTR(srla_lpc_taps<PP>);                                                                             \
-            hipExtLaunchKernelGGL(srla_lpc_errvars<PP>, g64s, blks, 0, stream, ev_start, nullptr, 0, *jp, lags_ws, err_ws, gamma_ws, ex.select, ex.round); \
+            launch_errvars<PP>(stream, ev_start, jp, lags_ws, err_ws, gamma_ws, ex);                                     \
             hipLaunchKernelGGL(srla_order_select, dim3(8u * ((jp->num_items + 7u) >> 3)), blks, 0, stream, *jp, items, geoms, err_ws, results, dbg, ties, ex.select, ex.round); \
             hipLaunchKernelGGL(srla_lpc_taps<PP>, g64s, blks, lds, stream, *jp, err_ws, gamma_ws, huff_len, results, coef_ws, ex.select, ex.round); \
         } else {                                                                                                         \
@@ -3970,7 +4077,7 @@ extern "C" int srla_launch_lpc_solve(hipStream_t stream, const SrlaJobParams *jp
         const uint32_t lds = 512 + PP * 8 * 64 + PP * 4 * 64;                                                            \
         if (three) {                                                                                                     \
             SET_LDS_ATTR(srla_lpc_taps<PP>);                                                                             \
-            hipExtLaunchKernelGGL(srla_lpc_errvars<PP>, g64, blk, 0, stream, ev_start, nullptr, 0, *jp, lags_ws, err_ws, gamma_ws, ex.select, ex.round); \
+            launch_errvars<PP>(stream, ev_start, jp, lags_ws, err_ws, gamma_ws, ex);                                     \
             hipLaunchKernelGGL(srla_order_select, dim3(8u * ((jp->num_items + 7u) >> 3)), blk, 0, stream, *jp, items, geoms, err_ws, results, dbg, ties, ex.select, ex.round); \
             hipExtLaunchKernelGGL(srla_lpc_taps<PP>, g64, blk, lds, stream, nullptr, ev_stop, 0, *jp, err_ws, gamma_ws, huff_len, results, (double *)nullptr, ex.select, ex.round); \
         } else {                                                                                                         \
@@ -3979,7 +4086,20 @@ extern "C" int srla_launch_lpc_solve(hipStream_t stream, const SrlaJobParams *jp
                                   huff_len, results, dbg, ties, (double *)nullptr);                                      \
         }                                                                                                                \
     } while (0)
-    if (p == 8) REGS_PATH(8);
+#define LDS_PATH(LL)                                                                                                     \
+    do {                                                                                                                 \
+        const uint32_t lds = (2 * p + 3) * 8 * LL;                                                                       \
+        const dim3 gl((jp->num_items + LL - 1) / LL);                                                                    \
+        SET_LDS_ATTR(srla_lpc_recursion<LL>);                                                                            \
+        SET_LDS_ATTR(srla_lpc_quantize<LL>);                                                                             \
+        hipExtLaunchKernelGGL(srla_lpc_recursion<LL>, gl, blk, lds, stream, ev_start, nullptr, 0, *jp, lags_ws, err_ws, ex.select, ex.round); \
+        hipLaunchKernelGGL(srla_order_select, dim3(8u * ((jp->num_items + 7u) >> 3)), blk, 0, stream, *jp, items, geoms, err_ws, results, dbg, ties, ex.select, ex.round); \
+        hipExtLaunchKernelGGL(srla_lpc_quantize<LL>, gl, blk, lds, stream, nullptr, ev_stop, 0, *jp, lags_ws, huff_len, results, (double *)nullptr, ex.select, ex.round); \
+    } while (0)
+    if (g_tune.solve_lds == 8 && p <= 64) LDS_PATH(8);
+    else if (g_tune.solve_lds == 16 && p <= 64) LDS_PATH(16);
+    else if (g_tune.solve_lds == 32 && p <= 64) LDS_PATH(32);
+    else if (p == 8) REGS_PATH(8);
     else if (p == 16) REGS_PATH(16);
     else if (p == 32) REGS_PATH(32);
     else if (p == 64) REGS_PATH(64);
@@ -3999,6 +4119,7 @@ extern "C" int srla_launch_lpc_solve(hipStream_t stream, const SrlaJobParams *jp
         hipExtLaunchKernelGGL(srla_lpc_quantize<32>, dim3((jp->num_items + 31) / 32), blk, lds, stream, nullptr, ev_stop, 0, *jp, lags_ws, huff_len, results, (double *)nullptr, ex.select, ex.round);
     }
 #undef REGS_PATH
+#undef LDS_PATH
     return (hipGetLastError() == hipSuccess) ? 0 : -2;
 }
 
