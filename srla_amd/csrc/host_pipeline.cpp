@@ -46,6 +46,8 @@ Impl::~Impl()
         }
         for (auto &st : streams) if (st) (void)hipStreamDestroy(st);
         if (upload) (void)hipStreamDestroy(upload);
+        if (out_stream) (void)hipStreamDestroy(out_stream);
+        if (dma_stream) { (void)hipStreamSynchronize(dma_stream); (void)hipStreamDestroy(dma_stream); }
         if (chain_stream) { (void)hipStreamSynchronize(chain_stream); (void)hipStreamDestroy(chain_stream); }
         if (ev_or) (void)hipEventDestroy(ev_or);
         if (ev_ref) (void)hipEventDestroy(ev_ref);
@@ -81,6 +83,7 @@ bool Impl::init_device()
         HIP_OK(hipStreamCreateWithPriority(&streams[0], hipStreamNonBlocking, pr[0]));
         HIP_OK(hipStreamCreateWithPriority(&streams[1], hipStreamNonBlocking, pr[1]));
         HIP_OK(hipStreamCreateWithPriority(&streams[2], hipStreamNonBlocking, pr[2]));
+        if (out_stream_on) HIP_OK(hipStreamCreateWithPriority(&out_stream, hipStreamNonBlocking, lo));
     }
     HIP_OK(hipEventCreate(&ev_or));
     HIP_OK(hipEventCreate(&ev_ref));
@@ -90,6 +93,9 @@ bool Impl::init_device()
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
         HIP_OK(hipStreamCreateWithPriority(&chain_stream, hipStreamNonBlocking, hi));   /* a few workgroups per launch, latency bound */
     }
+    /* (created last: the runtime hands out its hardware queues in the order the streams are made, and a stream made before
+     * `upload` moved that one onto a queue it shares with a compute stream -- host input -12 %, measured) */
+    if (dma_out) HIP_OK(hipStreamCreateWithFlags(&dma_stream, hipStreamNonBlocking));
     if (!h_or.ensure(64)) return false;
     for (uint32_t si = 0; si < kMaxSlots; si++) {
         Slot &s = slot[si];
@@ -98,6 +104,7 @@ bool Impl::init_device()
         HIP_OK(hipEventCreateWithFlags(&s.ev_in, hipEventDisableTiming));
         HIP_OK(hipEventCreate(&s.ev_a1)); HIP_OK(hipEventCreate(&s.ev_p0)); HIP_OK(hipEventCreate(&s.ev_p)); HIP_OK(hipEventCreate(&s.ev_a0));
         HIP_OK(hipEventCreateWithFlags(&s.ev_pk, hipEventDisableTiming));
+        HIP_OK(hipEventCreateWithFlags(&s.ev_dma, hipEventDisableTiming));
     }
     double thr[32];
     srla::build_rice_thresholds(thr);
@@ -499,6 +506,8 @@ bool Impl::run_stage(Slot &s, int st, int part)
         {
         hipStream_t P = (pack_on_n && !s.own_stream) ? N : C;
         if (P == C) HIP_OK(hipStreamWaitEvent(C, s.t1[ST_D], 0));
+        s.use_dma = call_dma && !s.own_stream && s.emits && !s.last_job;   /* (the call's last job: the copy-out kernel follows its assembly without a host round trip) */
+        if (s.dma_pending) { HIP_OK(hipStreamWaitEvent(P, s.ev_dma, 0)); s.dma_pending = false; }   /* the staging buffer's last job has left it */
         if (job.num_slots) {
             SrlaJobInfo *info = s.h_info.as<SrlaJobInfo>();
             uint32_t *wbytes = reinterpret_cast<uint32_t *>(info + 1);
@@ -508,7 +517,8 @@ bool Impl::run_stage(Slot &s, int st, int part)
                                    d_pos.as<uint32_t>(), s.d_segs.as<SrlaSegDesc>(), s.d_seg_ctl.as<uint32_t>(),
                                    s.d_stream.as<uint8_t>(), s.h_stream.as<uint8_t>(), s.d_scratch.as<uint8_t>(), info, wbytes,
                                    reinterpret_cast<SrlaSegInfo *>(wbytes + job.windows.size()), s.d_ties.as<uint32_t>(),
-                                   ev0, s.t1[ST_E], s.out_boost, (P == C) ? nullptr : C, s.ev_pk);
+                                   ev0, s.t1[ST_E], s.out_boost, (P == C) ? ((out_stream && !s.own_stream) ? out_stream : nullptr) : C, s.ev_pk,
+                                   s.use_dma ? 1u : 0u);
         } else { if (P != C) HIP_OK(hipStreamWaitEvent(C, s.t1[ST_D], 0)); if (ev0) HIP_OK(hipEventRecord(ev0, C)); HIP_OK(hipEventRecord(s.t1[ST_E], C)); }
         }
         break;
@@ -561,7 +571,7 @@ bool Impl::run_job_sync(Slot &s, const JobPlan &plan, bool search, bool want_dbg
         settle_lshift(plan, lsh);
         build_job(s.job, plan, lsh, search);
         if (apply_overrides(s.job, jobkey)) { s.job.uploaded = false; s.job.key = 0; }
-        s.own_stream = nullptr; s.timed = timing; s.out_boost = 1;
+        s.own_stream = nullptr; s.timed = timing; s.out_boost = 1; s.last_job = true;   /* (no DMA output: the copy-out kernel) */
         for (const SegPlan &sp : plan.segs) sx[sp.stream].pass_started = false;
         if (!prepare_job(s, want_dbg)) return false;
         for (int st = 0; st < NUM_ST; st++) if (!run_stage(s, st)) return false;
@@ -601,6 +611,12 @@ SRLAApiResult Impl::finish_job(Slot &s)
             fprintf(stderr, "[srla-mi355x] internal error: stream %u continues at %u, the host expected %u\n", sp.stream, si[k].pos, st.write_off);
             return SRLA_APIRESULT_NG;
         }
+        if (s.use_dma && si[k].bytes != 0) {
+            /* (the segment stands in the job's staging buffer at stage_off, srla_block_offsets) */
+            if (hipMemcpyAsync(st.data + si[k].pos, s.d_stream.as<uint8_t>() + si[k].stage_off, si[k].bytes, hipMemcpyDefault, dma_stream) != hipSuccess)
+                return SRLA_APIRESULT_NG;
+            dma_used = true; s.dma_pending = true;
+        }
         if (!st.out_direct && st.data != nullptr) {
             const uint8_t *src = s.h_stream.as<uint8_t>() + si[k].stage_off;
             uint8_t *dst = st.data + si[k].pos;
@@ -625,6 +641,7 @@ SRLAApiResult Impl::finish_job(Slot &s)
         st.write_off += si[k].bytes;
         st.progress = progress;
     }
+    if (s.dma_pending && hipEventRecord(s.ev_dma, dma_stream) != hipSuccess) return SRLA_APIRESULT_NG;
     stats.num_blocks += info.num_blocks; stats.num_raw_blocks += info.num_raw; stats.num_silent_blocks += info.num_silent;
     stats.num_tie_items += info.num_tie_items; stats.num_odd_items += info.num_odd_items;
     stats.pack_ms += ms_since(t0);
@@ -776,6 +793,7 @@ SRLAApiResult Impl::encode_streams(bool search)
         for (auto &st : streams) if (st) (void)hipStreamSynchronize(st);
         if (upload) (void)hipStreamSynchronize(upload);
         if (chain_stream) (void)hipStreamSynchronize(chain_stream);
+        if (dma_stream && dma_used) { (void)hipStreamSynchronize(dma_stream); dma_used = false; }
     };
     if (timeline) (void)hipEventRecord(ev_ref, streams[0]);
     if ((size_t)8 * nst > d_pos.cap) { drain(); if (!d_pos.ensure((size_t)8 * nst)) return SRLA_APIRESULT_NG; }
@@ -784,6 +802,12 @@ SRLAApiResult Impl::encode_streams(bool search)
         std::vector<const void *> held;
         ~PinGuard() { for (const void *p : held) host_pin_release(p); }
     } pins;
+    /* copies of finished jobs by the DMA engines (Impl::dma_out) end before the call leaves -- and before `pins` lets go of the
+     * buffers they write to (destroyed first: declared last) */
+    struct DmaGuard {
+        Impl *im;
+        ~DmaGuard() { if (im->dma_stream && im->dma_used) { (void)hipStreamSynchronize(im->dma_stream); im->dma_used = false; } }
+    } dma_guard{ this };
     /* pageable planes are locked in place when the pool is too small to stage them (all jobs by DMA then), and otherwise too
      * when staging and DMA take turns (mix_den > 0: stage_input) */
     const bool few_threads = pool->size() < 6;
@@ -894,6 +918,9 @@ SRLAApiResult Impl::encode_streams(bool search)
     plan_jobs(plan, search);
     const uint32_t njobs = (uint32_t)plan.size();
     overrides.clear();
+    /* (a stream of a few pieces is a latency chain: its copies would start only when the host has collected each piece) */
+    call_dma = dma_out && dma_stream != nullptr && njobs > 3;
+    for (const StreamCtx &st : sx) call_dma = call_dma && st.out_direct != nullptr && st.data != nullptr && st.cb == nullptr;
     if (timeline) tl_printf("[timeline] %u stream(s), %u jobs; host %.3f ms into the call\n", nst, njobs, ms_since(t0));
 
     auto fail = [&](SRLAApiResult rc) {
@@ -916,6 +943,7 @@ SRLAApiResult Impl::encode_streams(bool search)
         s.emits = true; s.merge_cb = false;
         s.timed = timing && (k % timing_stride == 0);
         s.out_boost = (k + tail_boost_jobs >= njobs) ? tail_boost : 1u;
+        s.last_job = k + 1 == njobs;
         return prepare_job(s, false);
     };
     /* chain mode of the (single) stream, overlapped with the regular jobs */

@@ -50,6 +50,8 @@ void Impl::read_environment()
     res32 = is_set("SRLA_MI355X_RES32");                                  /* set: every residual kept as int32 (round 3's first form) */
     if (is_set("SRLA_MI355X_WAVE_FFT")) wave_fft = number("SRLA_MI355X_WAVE_FFT", 1) != 0;   /* 1: srla_autocorr_w for 1024..8192-point items */
     split_ltp_stage = !is_set("SRLA_MI355X_NO_LTP_SKEW");                 /* set: the pitch solve back on stream W */
+    if (is_set("SRLA_MI355X_DMA_OUT")) dma_out = number("SRLA_MI355X_DMA_OUT", 1) != 0;
+    if (is_set("SRLA_MI355X_OUT_STREAM")) out_stream_on = number("SRLA_MI355X_OUT_STREAM", 1) != 0;
     if (is_set("SRLA_MI355X_PACK_ON_N")) pack_on_n = number("SRLA_MI355X_PACK_ON_N", 1) != 0;
     if (const char *e = getenv("SRLA_MI355X_MIX")) { unsigned a = 0, b = 0; if (sscanf(e, "%u,%u", &a, &b) == 2 && a <= b) { mix_num = a; mix_den = b; } }
     { const long long v = number("SRLA_MI355X_RUN_AHEAD", -1); if (v >= 0 && v <= 8) run_ahead = (uint32_t)v; }

@@ -4214,7 +4214,8 @@ extern "C" int srla_launch_pack(hipStream_t stream, const SrlaJobParams *jp, uin
                                 uint32_t *stream_pos, const SrlaSegDesc *segs, uint32_t *seg_ctl,
                                 uint8_t *stage, uint8_t *host_stage, uint8_t *scratch, SrlaJobInfo *info,
                                 uint32_t *window_bytes, SrlaSegInfo *seg_info, const uint32_t *ties,
-                                hipEvent_t ev_start, hipEvent_t ev_stop, uint32_t out_boost, hipStream_t out_stream, hipEvent_t ev_packed)
+                                hipEvent_t ev_start, hipEvent_t ev_stop, uint32_t out_boost, hipStream_t out_stream, hipEvent_t ev_packed,
+                                uint32_t no_stream_out)
 {
     if (num_slots == 0) return 0;
     hipExtLaunchKernelGGL(srla_block_offsets, dim3(1), dim3(NT), 0, stream, ev_start, nullptr, 0, *jp, windows, blocks, results, num_slots, block_off,
@@ -4223,9 +4224,10 @@ extern "C" int srla_launch_pack(hipStream_t stream, const SrlaJobParams *jp, uin
     const uint32_t rl_samples = jp->keep_residuals ? 0u : ((jp->max_block < 8192u ? jp->max_block : 8192u) + 3u) & ~3u;
     const uint32_t lds = (lds_words + 32 + 512 + (FIR_PAD + rl_samples + 8) + (FIR_PAD + 8)) * 4;
     SET_LDS_ATTR(srla_pack_blocks);
-    hipLaunchKernelGGL(srla_pack_blocks, dim3(num_slots), dim3(NT), lds, stream,
-                       *jp, input, items, blocks, results, res_ws, huff_code, huff_len, block_off, seg_ctl, stage, scratch, info,
-                       lds_words, rl_samples);
+    hipExtLaunchKernelGGL(srla_pack_blocks, dim3(num_slots), dim3(NT), lds, stream, nullptr, no_stream_out ? ev_stop : nullptr, 0,
+                          *jp, input, items, blocks, results, res_ws, huff_code, huff_len, block_off, seg_ctl, stage, scratch, info,
+                          lds_words, rl_samples);
+    if (no_stream_out) return (hipGetLastError() == hipSuccess) ? 0 : -2;
     /* Two workgroups (three for 24-bit streams, which carry more bytes).  One moves a 4 M-sample job's 6.5 MB in 0.45-0.57 ms
      * beside the other kernels -- longer than the job's wide kernels take (0.46 ms), so the block assembly stream, not stream W,
      * set the pace of a long stream (kernel trace of round 3); two take 0.25 ms.  More slow srla_autocorr down through the
