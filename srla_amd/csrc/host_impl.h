@@ -112,7 +112,7 @@ struct Slot {
     bool split_a = false;                /* stage A was enqueued in two parts (run_stage) */
     bool timed = false;                  /* this job records start events for every stage (one job in four) */
     bool last_job = false;               /* the last job of the call's plan */
-    bool use_dma = false;                /* this job's bytes leave by DMA when it is collected (Impl::dma_out) */
+    bool use_dma = false;                /* this job's bytes leave by a host-issued copy when it is collected (Impl::dma_out) */
     bool dma_pending = false;            /* ev_dma marks the end of the last copies out of this slot's staging buffer */
     hipEvent_t ev_dma = nullptr;
     uint32_t out_boost = 1;              /* stream-out workgroup multiplier (the last jobs of a stream drain faster) */
@@ -188,13 +188,14 @@ struct Impl {
     uint32_t run_ahead = 8;             /* SRLA_MI355X_RUN_AHEAD: jobs the host may be ahead of the stage skew (bounded by the buffer sets) */
     uint32_t mix_num = 0, mix_den = 0;  /* SRLA_MI355X_MIX="a,b": pageable planes are locked in place and of every b jobs a are read by DMA, b - a staged (measured at "1,2": M -5 %, config 2 -7 %: off) */
     uint32_t mix_count = 0;
-    /* Output by DMA (the default where it applies: a call of several jobs whose streams' buffers the device can reach -- pinned,
-     * registered or locked in place for the call, or device memory -- and that has no encode callback): the assembly stage of a
-     * job ends with srla_pack_blocks, and when the host collects the job it has the segments' bytes copied from the job's staging
-     * buffer in HBM to their place by the DMA engines (hipMemcpyAsync on a stream that carries nothing else).  With
-     * srla_stream_out behind it the assembly stream took 0.5 ms per 4 M-sample job -- 0.3 ms of them two workgroups pacing
-     * themselves on PCIe stores -- against the 0.45 ms of wide kernels, and set the pace of a long stream (kernel trace).
-     * SRLA_MI355X_DMA_OUT=0: the copy-out kernel everywhere. */
+    /* Output by host-issued copies (the default where it applies: a call of more than three jobs whose streams' buffers the
+     * device can reach -- pinned, registered or locked in place for the call, or device memory -- and that has no encode
+     * callback): the assembly stage of a job ends with srla_pack_blocks, and when the host collects the job it has the segments'
+     * bytes copied from the job's staging buffer in HBM to their place with hipMemcpyAsync on a stream that carries nothing
+     * else (on this system the runtime's own copy kernel, 256 workgroups, 6.5 MB in 0.12-0.19 ms beside the other kernels).
+     * With srla_stream_out behind it the assembly stream took 0.5 ms per 4 M-sample job -- 0.3 ms of them two workgroups
+     * pacing themselves on PCIe stores -- against the 0.45 ms of wide kernels, and set the pace of a long stream (kernel
+     * trace: stream C back to back).  SRLA_MI355X_DMA_OUT=0: the copy-out kernel everywhere. */
     bool dma_out = true;
     hipStream_t dma_stream = nullptr;
     bool call_dma = false;              /* this call: see above */

@@ -83,7 +83,6 @@ bool Impl::init_device()
         HIP_OK(hipStreamCreateWithPriority(&streams[0], hipStreamNonBlocking, pr[0]));
         HIP_OK(hipStreamCreateWithPriority(&streams[1], hipStreamNonBlocking, pr[1]));
         HIP_OK(hipStreamCreateWithPriority(&streams[2], hipStreamNonBlocking, pr[2]));
-        if (out_stream_on) HIP_OK(hipStreamCreateWithPriority(&out_stream, hipStreamNonBlocking, lo));
     }
     HIP_OK(hipEventCreate(&ev_or));
     HIP_OK(hipEventCreate(&ev_ref));
@@ -96,6 +95,11 @@ bool Impl::init_device()
     /* (created last: the runtime hands out its hardware queues in the order the streams are made, and a stream made before
      * `upload` moved that one onto a queue it shares with a compute stream -- host input -12 %, measured) */
     if (dma_out) HIP_OK(hipStreamCreateWithFlags(&dma_stream, hipStreamNonBlocking));
+    if (out_stream_on) {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        HIP_OK(hipStreamCreateWithPriority(&out_stream, hipStreamNonBlocking, lo));
+    }
     if (!h_or.ensure(64)) return false;
     for (uint32_t si = 0; si < kMaxSlots; si++) {
         Slot &s = slot[si];
@@ -802,7 +806,7 @@ SRLAApiResult Impl::encode_streams(bool search)
         std::vector<const void *> held;
         ~PinGuard() { for (const void *p : held) host_pin_release(p); }
     } pins;
-    /* copies of finished jobs by the DMA engines (Impl::dma_out) end before the call leaves -- and before `pins` lets go of the
+    /* the host-issued copies of finished jobs (Impl::dma_out) end before the call leaves -- and before `pins` lets go of the
      * buffers they write to (destroyed first: declared last) */
     struct DmaGuard {
         Impl *im;
