@@ -199,6 +199,8 @@ typedef struct SrlaJobParams {
                                * default, zig-zag mapped uint16 where a block's values fit, SRLA_ITEM_RES_U16; 2: always the int32
                                * residual -- what SRLAMI355X_ProbeBlock returns, SRLA_MI355X_RES32); 0 (SRLA_MI355X_RECOMPUTE_RESIDUALS): none are
                                * stored and srla_pack_blocks recomputes the chosen blocks' (blocks > 8192 samples always keep) */
+    uint32_t crowded;         /* the job runs beside other jobs' wide kernels (a call of several jobs): kernels that only fit an
+                               * empty SIMD take their lean form whatever the job's size (srla_lpc_errvars_lean) */
     uint32_t out_stride;      /* SRLA_DIAG_STOP builds only: where srla_residual_cost stops (kernel timing experiments) */
     const uint32_t *lshift_dev; /* when non-null the offset left shift is read from here (device memory) instead of the
                                * item's: lets a whole device-resident stream be enqueued before its OR-reduction has finished */

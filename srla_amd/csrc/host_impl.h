@@ -198,6 +198,7 @@ struct Impl {
      * trace: stream C back to back).  SRLA_MI355X_DMA_OUT=0: the copy-out kernel everywhere. */
     bool dma_out = true;
     hipStream_t dma_stream = nullptr;
+    bool call_crowded = false;          /* this call: more than three jobs, so a job's narrow kernels run beside other jobs' wide ones (SrlaJobParams::crowded) */
     bool call_dma = false;              /* this call: see above */
     bool dma_used = false;              /* copies may be in flight on dma_stream */
     bool out_stream_on = false;         /* SRLA_MI355X_OUT_STREAM=1: srla_stream_out on a (low-priority) stream of its own, so that the copy-out of job k runs beside the assembly of job k + 1 */

@@ -575,7 +575,7 @@ bool Impl::run_job_sync(Slot &s, const JobPlan &plan, bool search, bool want_dbg
         settle_lshift(plan, lsh);
         build_job(s.job, plan, lsh, search);
         if (apply_overrides(s.job, jobkey)) { s.job.uploaded = false; s.job.key = 0; }
-        s.own_stream = nullptr; s.timed = timing; s.out_boost = 1; s.last_job = true;   /* (no DMA output: the copy-out kernel) */
+        s.own_stream = nullptr; s.timed = timing; s.out_boost = 1; s.last_job = true; call_crowded = false;   /* (no DMA output: the copy-out kernel) */
         for (const SegPlan &sp : plan.segs) sx[sp.stream].pass_started = false;
         if (!prepare_job(s, want_dbg)) return false;
         for (int st = 0; st < NUM_ST; st++) if (!run_stage(s, st)) return false;
@@ -922,6 +922,7 @@ SRLAApiResult Impl::encode_streams(bool search)
     plan_jobs(plan, search);
     const uint32_t njobs = (uint32_t)plan.size();
     overrides.clear();
+    call_crowded = njobs > 3;
     /* (a stream of a few pieces is a latency chain: its copies would start only when the host has collected each piece) */
     call_dma = dma_out && dma_stream != nullptr && njobs > 3;
     for (const StreamCtx &st : sx) call_dma = call_dma && st.out_direct != nullptr && st.data != nullptr && st.cb == nullptr;

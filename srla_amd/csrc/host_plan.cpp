@@ -231,6 +231,7 @@ SrlaJobParams Impl::job_params(const Job &job, uint32_t channel_stride, bool lsh
     jp.out_stride = diag_stop;                               /* kernel timing experiments only */
 #endif
     jp.lshift_dev = lshift_on_device ? (d_or.as<uint32_t>() + 1) : nullptr;
+    jp.crowded = call_crowded ? 1u : 0u;
     jp.keep_residuals = job.keep_residuals ? ((keep_residuals || res32) ? 2u : 1u) : 0u;
     jp.tie_rel = tie_rel; jp.tie_ltp = tie_ltp; jp.tie_logscale = tie_logscale; jp.tie_ltpbias = tie_ltpbias;
     return jp;

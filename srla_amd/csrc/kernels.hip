@@ -3992,7 +3992,7 @@ static void launch_errvars(hipStream_t stream, hipEvent_t ev_start, const SrlaJo
     if constexpr (PP == 64) {
         /* a small job (a short stream, a piece of one) does not fill the chip: nothing to be starved by, and the register form is
          * twice as fast on its own (31 against 65 us) */
-        if (!g_tune.errvars_regs && jp->num_items >= 6144u) {
+        if (!g_tune.errvars_regs && (jp->num_items >= 6144u || jp->crowded)) {
             const uint32_t lds = ((PP + 1) + (PP + 2 - ERRVARS_LEAN_AREG)) * 8 * ERRVARS_LEAN_L;
             hipExtLaunchKernelGGL((srla_lpc_errvars_lean<PP, ERRVARS_LEAN_L, ERRVARS_LEAN_AREG>), dim3((jp->num_items + ERRVARS_LEAN_L - 1) / ERRVARS_LEAN_L),
                                   dim3(WAVE), lds, stream, ev_start, nullptr, 0, *jp, lags_ws, err_ws, gamma_ws, ex.select, ex.round);
