@@ -2007,18 +2007,21 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
      * of the launch's memory traffic.  What the pack kernel codes is the zig-zag mapped value, and where the block's largest one
      * fits 16 bits (ordinary 16-bit audio) that is what is stored, two bytes per sample, in the first half of the item's region
      * (SRLA_ITEM_RES_U16); else, and for SRLAMI355X_ProbeBlock (keep_residuals == 2), the int32 residual. */
+    /* every zig-zag value of the block within 16 bits (the whole workgroup agrees): pairs of them in one register serve the store
+     * below and the code-bit pass further down */
+    const bool narrow16 = max_u < 65536u;
+    uint32_t pk[S / 2];
+#pragma unroll
+    for (int j = 0; j < S / 2; j++) pk[j] = u[2 * j] | (u[2 * j + 1] << 16);
     if (jp.keep_residuals) {
-        if (jp.keep_residuals == 1u && max_u < 65536u) {
+        if (jp.keep_residuals == 1u && narrow16) {
             uint32_t *r16 = reinterpret_cast<uint32_t *>(res_ws + it.res_off) + (s_base >> 1);
             if constexpr ((FL & 1) == 0) {
 #pragma unroll
-                for (int c = 0; c < FL / 2; c++)
-                    *reinterpret_cast<uint4 *>(r16 + 4 * c) = make_uint4(u[8 * c] | (u[8 * c + 1] << 16), u[8 * c + 2] | (u[8 * c + 3] << 16),
-                                                                       u[8 * c + 4] | (u[8 * c + 5] << 16), u[8 * c + 6] | (u[8 * c + 7] << 16));
+                for (int c = 0; c < FL / 2; c++) *reinterpret_cast<uint4 *>(r16 + 4 * c) = make_uint4(pk[4 * c], pk[4 * c + 1], pk[4 * c + 2], pk[4 * c + 3]);
             } else {
 #pragma unroll
-                for (int c = 0; c < FL; c++)
-                    *reinterpret_cast<uint2 *>(r16 + 2 * c) = make_uint2(u[4 * c] | (u[4 * c + 1] << 16), u[4 * c + 2] | (u[4 * c + 3] << 16));
+                for (int c = 0; c < FL; c++) *reinterpret_cast<uint2 *>(r16 + 2 * c) = make_uint2(pk[2 * c], pk[2 * c + 1]);
             }
             if (tid == 0) out->flags |= SRLA_ITEM_RES_U16;
         } else {
@@ -2093,6 +2096,55 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
             (void)fixed8;
             /* neighbouring coarse levels very often have the same parameter in every lane of the wavefront: then the
              * thread's sum is the one just computed (wave-uniform test, so no lane diverges) */
+            if (narrow16) {
+                /* two samples per instruction: saturating subtract, shift and a dot product with (1, 1) that adds both halves
+                 * to a 32-bit sum (v_pk_sub_u16 clamp, v_pk_lshrrev_b16, v_dot2_u32_u16) -- three instructions per PAIR and
+                 * level instead of three per sample.  A parameter's threshold 2 << k leaves 16 bits at k = 15: every value
+                 * is below it then, as below 65535; k >= 16 prices every value at zero quotient bits likewise. */
+                typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+                const us2 ones = { 1, 1 };
+                auto thr16 = [&](uint32_t k) -> uint32_t {
+                    const uint32_t t2 = (code_type == SRLA_CODE_RICE) ? 0u : (2u << (k & 15u));
+                    return (k >= 16u) ? 0xFFFFu : ((t2 > 0xFFFFu) ? 0xFFFFu : t2);
+                };
+                auto pair_cost = [&](uint32_t w, uint32_t thr2, uint32_t sh2, uint32_t sum) -> uint32_t {
+                    const us2 d = __builtin_elementwise_sub_sat(__builtin_bit_cast(us2, w), __builtin_bit_cast(us2, thr2));
+                    return __builtin_amdgcn_udot2(d >> __builtin_bit_cast(us2, sh2), ones, sum, false);
+                };
+                uint32_t t = 0;
+#pragma unroll
+                for (int l = 0; l <= 8; l++) {
+                    const bool same = (l > 0) && __all((int)(kl[l] == kl[l > 0 ? l - 1 : 0]));
+                    if (!same) {
+                        const uint32_t thr2 = thr16(kl[l]) * 0x10001u, sh2 = (kl[l] & 15u) * 0x10001u;
+                        t = (uint32_t)S * code_cost_fixed(kl[l], code_type);
+#pragma unroll
+                        for (int j = 0; j < S / 2; j++) t = pair_cost(pk[j], thr2, sh2, t);
+                    }
+                    acc[l] += t;
+                }
+                {
+                    uint32_t t9 = (uint32_t)(2 * FL) * (code_cost_fixed(k9[0], code_type) + code_cost_fixed(k9[1], code_type));
+                    const uint32_t th[2] = { thr16(k9[0]) * 0x10001u, thr16(k9[1]) * 0x10001u };
+                    const uint32_t sh[2] = { (k9[0] & 15u) * 0x10001u, (k9[1] & 15u) * 0x10001u };
+#pragma unroll
+                    for (int j = 0; j < S / 2; j++) t9 = pair_cost(pk[j], th[(2 * j) / (2 * FL)], sh[(2 * j) / (2 * FL)], t9);
+                    acc[9] += t9;
+                }
+                {
+                    uint32_t t10 = (uint32_t)FL * (code_cost_fixed(k10[0], code_type) + code_cost_fixed(k10[1], code_type)
+                                                   + code_cost_fixed(k10[2], code_type) + code_cost_fixed(k10[3], code_type));
+                    uint32_t th[4], sh[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) { th[q] = thr16(k10[q]); sh[q] = k10[q] & 15u; }
+#pragma unroll
+                    for (int j = 0; j < S / 2; j++) {
+                        const int q0 = (2 * j) / FL, q1 = (2 * j + 1) / FL;      /* the quarters of the pair's two samples */
+                        t10 = pair_cost(pk[j], th[q0] | (th[q1] << 16), sh[q0] | (sh[q1] << 16), t10);
+                    }
+                    acc[10] += t10;
+                }
+            } else {
             uint32_t t = 0;
 #pragma unroll
             for (int l = 0; l <= 8; l++) {
@@ -2116,6 +2168,7 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
 #pragma unroll
                 for (int i = 0; i < S; i++) t += code_cost_var(u[i], k10[i / FL], code_type);
                 acc[10] += t;
+            }
             }
         }
 #ifdef SRLA_DIAG_STOP
