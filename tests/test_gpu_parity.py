@@ -413,6 +413,65 @@ def test_pinned_output_is_written_by_the_device(product, misalign):
     product.destroy(enc)
 
 
+@pytest.mark.parametrize("misalign", [0, 5])
+@pytest.mark.parametrize("cli_name", ["m4_B4096", "m4_B4096_V2_P3"])
+def test_pinned_output_of_a_call_of_many_jobs_is_copied_by_the_host(product, misalign, cli_name, monkeypatch):
+    """A call of more than three jobs without a callback ends every job's assembly stage with the pack kernel, and the host has
+    the job's bytes copied from its staging buffer in HBM to their place when it collects the job (host_pipeline.cpp,
+    Impl::dma_out); the last job and the chain-mode tail (odd length) leave through the copy-out kernel.  Same bytes at any
+    alignment, nothing outside the stream, overflow detected, and a callback (which keeps the kernel path) changes nothing."""
+    import torch
+    monkeypatch.setenv("SRLA_MI355X_JOB_SAMPLES", "65536")
+    cli = CLIS[cli_name]
+    pcm = helpers.synth(helpers.VARIED, 195, 48000, 2, 700_001)
+    want = helpers.Oracle(2, **cli).encode_whole(pcm)
+    cfg, par = capi.cli_setup(2, 16, 48000, **cli)
+    enc = product.create(cfg)
+    assert product.set_parameter(enc, par) == capi.OK
+    pinned = torch.full((pcm.size * 4 + 64,), 0xAA, dtype=torch.uint8).pin_memory()
+    view = pinned.numpy()
+    rc, size = _encode_into(product, enc, pcm, pinned.data_ptr() + misalign, want.size)       # exactly large enough
+    assert rc == capi.OK and size == want.size
+    assert np.array_equal(view[misalign:misalign + size], want)
+    assert (view[:misalign] == 0xAA).all() and (view[misalign + size:] == 0xAA).all()
+    view[:] = 0x55
+    rc, _ = _encode_into(product, enc, pcm, pinned.data_ptr() + misalign, want.size - 1)
+    assert rc == capi.INSUFFICIENT_BUFFER
+    assert (view[misalign + want.size - 1:] == 0x55).all() and (view[:misalign] == 0x55).all()
+    seen = []
+    view[:] = 0
+    rc, size = _encode_into(product, enc, pcm, pinned.data_ptr() + misalign, view.size - misalign,
+                            callback=lambda total, progress, ptr, sz: seen.append(sz))
+    assert rc == capi.OK and np.array_equal(view[misalign:misalign + size], want) and sum(seen) == size - 30
+    # the option that keeps the copy-out kernel everywhere gives the same stream
+    monkeypatch.setenv("SRLA_MI355X_DMA_OUT", "0")
+    enc2 = product.create(cfg)
+    assert product.set_parameter(enc2, par) == capi.OK
+    view[:] = 0
+    rc, size = _encode_into(product, enc2, pcm, pinned.data_ptr(), view.size)
+    assert rc == capi.OK and np.array_equal(view[:size], want)
+    product.destroy(enc2)
+    product.destroy(enc)
+
+
+def test_pageable_output_locked_in_place_of_a_call_of_many_jobs(product, monkeypatch):
+    """The same with the caller's pageable buffer registered for the call (SRLA_MI355X_PIN_INPLACE=1): the host-issued copies
+    must have landed before the registration is dropped.  A stream whose shift guess is wrong is encoded again behind them."""
+    monkeypatch.setenv("SRLA_MI355X_PIN_INPLACE", "1")
+    monkeypatch.setenv("SRLA_MI355X_JOB_SAMPLES", "262144")
+    cli = dict(preset=4, max_block=4096, divisions=1)
+    pcm = helpers.synth(helpers.MUSIC, 196, 48000, 2, 3_000_000)
+    want = helpers.Oracle(2, **cli).encode_whole(pcm)
+    lib2 = capi.EncoderLib(helpers.PRODUCT_SO)
+    for _ in range(2):
+        assert np.array_equal(lib2.encode(pcm, **cli), want)
+    odd = pcm.copy()
+    odd[:, :600_000] = (odd[:, :600_000] >> 4) << 4
+    want = helpers.Oracle(2, **cli).encode_whole(odd)
+    assert want[24] == 0
+    assert np.array_equal(lib2.encode(odd, **cli), want)
+
+
 @pytest.mark.parametrize("nch,bps,cli_name,kind", [(8, 24, "m4_B8192_V2_P3", helpers.NOISE), (8, 24, "m4_B8192_V2_P3", helpers.MUSIC),
                                                     (2, 16, "m4_B4096_V2", helpers.VARIED)])
 def test_blocks_assembled_in_global_scratch(product, nch, bps, cli_name, kind, monkeypatch):
