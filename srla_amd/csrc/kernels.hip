@@ -1672,15 +1672,22 @@ __device__ __forceinline__ int group_offset(int d)
     else return (d < 0) ? d - ((FL - 1 - d) / FL) : d;
 }
 
-template <int FL, int MODE>
+/* LG: log2 of the items that share the workgroup (0, 1, 2).  A thread's fixed work in the Rice search -- a dozen parameters, eleven
+ * wave reductions, the parameter table -- does not shrink with its samples, so at four or eight samples per thread (1024- and
+ * 2048-sample blocks on 256 threads) it outweighs the per-sample work (cut-short timing: 45 % of a -V 2 launch).  With 2^LG items
+ * per workgroup an item has T = 256 >> LG threads of 4 FL << LG samples each; `lds`, `in`, `it`, `out` are the thread's own item's,
+ * barriers are the workgroup's (the items run in lock step: every barrier below is reached by all of them). */
+template <int FL, int MODE, int LG = 0>
 __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, const InputView &iv, const int32_t *__restrict__ in, const SrlaItemDesc &it,
                                    unsigned char *lds, const double *__restrict__ rice_thresholds,
                                    int32_t *__restrict__ res_ws, SrlaItemResult *__restrict__ out)
 {
-    constexpr int S = 4 * FL;                                   /* samples per thread */
+    constexpr int T = NT >> LG, WPI = T / WAVE;                  /* threads, wavefronts per item */
+    constexpr int CH = FL << LG;                                /* chunks of four samples per thread */
+    constexpr int S = 4 * CH;                                   /* samples per thread */
     constexpr int PADMIN = (FIR_PAD > SRLA_LTP_MAX_PERIOD + 2) ? FIR_PAD : (SRLA_LTP_MAX_PERIOD + 2);
     constexpr int PADS = ((PADMIN + S - 1) / S) * S;            /* front padding, a multiple of S: covers the FIR's reach back and the LTP's */
-    constexpr int PADW = (FL & 1) ? 0 : 4;                      /* see sig_index */
+    constexpr int PADW = (CH & 1) ? 0 : 4;                      /* see sig_index */
     constexpr uint32_t SIG_WORDS = (uint32_t)((PADS + 1024 * FL) / S) * (S + PADW) + 8;
     constexpr bool WIDE = MODE == FIR_WIDE, DOT = MODE == FIR_DOT;
     /* FIR_DOT: the two planes lie over the int32 signal (which then only the LTP uses, before them): PADF zeros + the block, in
@@ -1691,7 +1698,7 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
     static_assert(HIGH_OFF + PLANE_ELEMS <= SIG_WORDS * 4, "the planes fit the int32 signal's LDS");
     int32_t *sig = (int32_t *)lds;
     SmallF *sm = (SmallF *)(lds + ((SIG_WORDS * 4 + 15) & ~15u));
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t tid = threadIdx.x & (uint32_t)(T - 1), lane = tid & 63, wave = tid >> 6;   /* thread, wavefront within the item */
     const uint32_t n = 1024u * FL, bps = jp.bits_per_sample;
     const bool aligned = input_aligned(in, iv);
     const int32_t coef = out->preemph_coef;
@@ -1707,7 +1714,7 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
     const uint32_t load_variant_as = it.variant;
 #endif
 #pragma unroll
-    for (int c = 0; c < FL; c++) {
+    for (int c = 0; c < CH; c++) {
         int32_t t4[4];
         load_chunk(in, iv, load_variant_as, s_base + 4 * c, n, aligned, t4);
         y[4 * c] = t4[0]; y[4 * c + 1] = t4[1]; y[4 * c + 2] = t4[2]; y[4 * c + 3] = t4[3];
@@ -1725,8 +1732,8 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
         }
     }
 #define PUBLISH_Y()                                                                                              \
-    _Pragma("unroll") for (int c = 0; c < FL; c++)                                                               \
-        *reinterpret_cast<int4 *>(sig + sig_index<FL>(PADS + (int)s_base + 4 * c)) = make_int4(y[4 * c], y[4 * c + 1], y[4 * c + 2], y[4 * c + 3]);
+    _Pragma("unroll") for (int c = 0; c < CH; c++)                                                               \
+        *reinterpret_cast<int4 *>(sig + sig_index<CH>(PADS + (int)s_base + 4 * c)) = make_int4(y[4 * c], y[4 * c + 1], y[4 * c + 2], y[4 * c + 3]);
     /* FIR_DOT: the block as two planes, x = 2^16 h + l (the wavefront notes whether any of its h is not zero) */
     auto publish_planes = [&]() {
         uint32_t hq[S], high_any = 0;
@@ -1734,30 +1741,35 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
         for (int i = 0; i < S; i++) { hq[i] = (uint32_t)((y[i] + 0x8000) >> 16); high_any |= hq[i]; }
         const bool wave_high = __any((int)(high_any != 0));
 #pragma unroll
-        for (int c = 0; c < FL; c++) {
-            const uint32_t e = sig_index<FL>(PADF + (int)s_base + 4 * c);
+        for (int c = 0; c < CH; c++) {
+            const uint32_t e = sig_index<CH>(PADF + (int)s_base + 4 * c);
             *reinterpret_cast<uint2 *>(lds + 2 * e) = make_uint2(((uint32_t)y[4 * c] & 0xFFFFu) | ((uint32_t)y[4 * c + 1] << 16),
                                                                  ((uint32_t)y[4 * c + 2] & 0xFFFFu) | ((uint32_t)y[4 * c + 3] << 16));
             uint32_t hw = 0;
             if (wave_high) hw = (hq[4 * c] & 0xFFu) | ((hq[4 * c + 1] & 0xFFu) << 8) | ((hq[4 * c + 2] & 0xFFu) << 16) | (hq[4 * c + 3] << 24);
             *reinterpret_cast<uint32_t *>(lds + HIGH_OFF + e) = hw;
         }
-        if (lane == 0) sm->wave_high[wave] = wave_high ? 1u : 0u;
+        if (lane == 0) {
+            sm->wave_high[wave] = wave_high ? 1u : 0u;
+            if (WPI < NWAVES && wave == 0) for (int w = WPI; w < NWAVES; w++) sm->wave_high[w] = 0u;   /* (read four at a time below) */
+        }
         constexpr uint32_t FRONT = (uint32_t)(PADF / S) * (S + PADW);     /* front padding, elements */
-        for (uint32_t i = tid; i < FRONT / 2; i += NT) reinterpret_cast<uint32_t *>(lds)[i] = 0;
-        for (uint32_t i = tid; i < FRONT / 4; i += NT) reinterpret_cast<uint32_t *>(lds + HIGH_OFF)[i] = 0;
+        for (uint32_t i = tid; i < FRONT / 2; i += T) reinterpret_cast<uint32_t *>(lds)[i] = 0;
+        for (uint32_t i = tid; i < FRONT / 4; i += T) reinterpret_cast<uint32_t *>(lds + HIGH_OFF)[i] = 0;
     };
-    if (DOT && period == 0) publish_planes();
+    /* the LTP's two barriers are taken by every item of the workgroup or by none */
+    const bool ltp_block = (LG == 0) ? (period > 0) : (jp.ltp_order > 0);
+    if (DOT && !ltp_block) publish_planes();
     else {
         PUBLISH_Y();
-        for (uint32_t i = tid; i < (uint32_t)(PADS / S) * (S + PADW); i += NT) sig[i] = 0;    /* front padding */
+        for (uint32_t i = tid; i < (uint32_t)(PADS / S) * (S + PADW); i += T) sig[i] = 0;    /* front padding */
     }
     if constexpr (DOT) {
         /* tap k of the zero-padded, reversed filter (k outside [0, o4): zero) */
         auto cq = [&](int k) -> uint32_t {
             return (k < (int)(o4 - order) || k >= (int)o4) ? 0u : (uint32_t)(int32_t)out->lpc_coef[k - (int)(o4 - order)];
         };
-        for (uint32_t g = tid; g <= (o4 >> 2); g += NT) {
+        for (uint32_t g = tid; g <= (o4 >> 2); g += T) {
             const int b = 4 * (int)g;
             const uint32_t c[7] = { cq(b - 3), cq(b - 2), cq(b - 1), cq(b), cq(b + 1), cq(b + 2), cq(b + 3) };   /* c[3 + d] = tap b + d */
             /* low plane: outputs 0 and 2 of a chunk use (b, b+1) (b+2, b+3), outputs 1 and 3 (b-1, b) (b+1, b+2) */
@@ -1771,7 +1783,7 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
                 sm->cpack[1][b + r] = (c[3 - r] & 0xFFu) | ((c[4 - r] & 0xFFu) << 8) | ((c[5 - r] & 0xFFu) << 16) | (c[6 - r] << 24);
         }
     } else {
-        for (uint32_t k = tid; k < o4; k += NT) sm->coefq[k] = (k < o4 - order) ? 0 : (int32_t)out->lpc_coef[k - (o4 - order)];
+        for (uint32_t k = tid; k < o4; k += T) sm->coefq[k] = (k < o4 - order) ? 0 : (int32_t)out->lpc_coef[k - (o4 - order)];
     }
     if (tid < 16) sm->level_bits[tid] = 0;
     if (tid >= 32 && tid < 64) sm->thr[tid - 32] = rice_thresholds[tid - 32];
@@ -1780,7 +1792,8 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
     if (jp.out_stride == 1 || jp.out_stride == 22) { if (y[0] == 0x7fffffff) out->pad[1] = 1; return; }   /* kernel timing experiments (make EXTRA=-DSRLA_DIAG_STOP): never in the shipped library */
 #endif
 
-    if (period > 0) {
+    if (ltp_block) {
+        if (period > 0) {
         /* long-term predictor, srla_lpc_predict.c:267-294 (in place: read everything, barrier, rewrite) */
         const uint32_t taps = jp.ltp_order, half_order = taps >> 1;
         const int32_t c0 = out->ltp_coef[0], c1 = out->ltp_coef[1], c2 = out->ltp_coef[2];
@@ -1811,6 +1824,7 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
                 y[i] = (int32_t)((uint32_t)y[i] - (uint32_t)((int32_t)acc >> 5));
             }
         }
+        }
         __syncthreads();
         if constexpr (DOT) publish_planes(); else PUBLISH_Y();
         __syncthreads();
@@ -1830,15 +1844,15 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
             const int ng = (int)__builtin_amdgcn_readfirstlane(o4 >> 2);          /* groups of four taps */
             const uint2 *lgrp = reinterpret_cast<const uint2 *>(lds);               /* low plane: a group = four int16 */
             const uint32_t *hgrp = reinterpret_cast<const uint32_t *>(lds + HIGH_OFF);   /* high plane: a group = four int8 */
-            const int own = (int)(sig_index<FL>(PADF + (int)s_base) >> 2);           /* the thread's first own group */
-            uint2 cur[FL];
+            const int own = (int)(sig_index<CH>(PADF + (int)s_base) >> 2);           /* the thread's first own group */
+            uint2 cur[CH];
 #pragma unroll
-            for (int c = 0; c < FL; c++) cur[c] = lgrp[own + group_offset<FL>(c - ng)];
+            for (int c = 0; c < CH; c++) cur[c] = lgrp[own + group_offset<CH>(c - ng)];
             for (int j = 0; j < ng; j++) {
                 const uint4 cf = *reinterpret_cast<const uint4 *>(&sm->cpack[0][4 * j]);
 #pragma unroll
-                for (int c = 0; c < FL; c++) {
-                    const uint2 nxt = lgrp[own + group_offset<FL>(c + j + 1 - ng)];
+                for (int c = 0; c < CH; c++) {
+                    const uint2 nxt = lgrp[own + group_offset<CH>(c + j + 1 - ng)];
                     acc[4 * c + 0] = dot2_i16(cf.y, cur[c].y, dot2_i16(cf.x, cur[c].x, acc[4 * c + 0]));
                     acc[4 * c + 1] = dot2_i16(cf.w, cur[c].y, dot2_i16(cf.z, cur[c].x, acc[4 * c + 1]));
                     acc[4 * c + 2] = dot2_i16(cf.y, nxt.x, dot2_i16(cf.x, cur[c].y, acc[4 * c + 2]));
@@ -1850,7 +1864,7 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
                 /* the last tap of the odd outputs: its partner in the pair is the output's own sample, times zero */
                 const uint32_t cl = sm->cpack[0][4 * ng + 2];
 #pragma unroll
-                for (int c = 0; c < FL; c++) {
+                for (int c = 0; c < CH; c++) {
                     acc[4 * c + 1] = dot2_i16(cl, cur[c].x, acc[4 * c + 1]);
                     acc[4 * c + 3] = dot2_i16(cl, cur[c].y, acc[4 * c + 3]);
                 }
@@ -1864,8 +1878,8 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
                     /* group ng closes the pass: the taps that are left for outputs 1..3 meet the chunk's own samples */
                     const uint4 cf = *reinterpret_cast<const uint4 *>(&sm->cpack[1][4 * j]);
 #pragma unroll
-                    for (int c = 0; c < FL; c++) {
-                        const uint32_t a = hgrp[own + group_offset<FL>(c + j - ng)];
+                    for (int c = 0; c < CH; c++) {
+                        const uint32_t a = hgrp[own + group_offset<CH>(c + j - ng)];
                         ah[4 * c + 0] = dot4_i8(cf.x, a, ah[4 * c + 0]);
                         ah[4 * c + 1] = dot4_i8(cf.y, a, ah[4 * c + 1]);
                         ah[4 * c + 2] = dot4_i8(cf.z, a, ah[4 * c + 2]);
@@ -1876,13 +1890,13 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
                 for (int i = 0; i < S; i++) acc[i] += ah[i] << 16;
             }
             if (tid != 0 && s_base < order) {
-                const uint32_t e = sig_index<FL>(PADF + (int)s_base - 1);
+                const uint32_t e = sig_index<CH>(PADF + (int)s_base - 1);
                 yprev = (int32_t)*reinterpret_cast<const int16_t *>(lds + 2 * e) + ((int32_t)*reinterpret_cast<const int8_t *>(lds + HIGH_OFF + e)) * 65536;
             }
         } else {
-        int4 cur[FL];
+        int4 cur[CH];
 #pragma unroll
-        for (int c = 0; c < FL; c++) cur[c] = *reinterpret_cast<const int4 *>(sig + sig_index<FL>(PADS + (int)s_base + 4 * c - (int)o4));
+        for (int c = 0; c < CH; c++) cur[c] = *reinterpret_cast<const int4 *>(sig + sig_index<CH>(PADS + (int)s_base + 4 * c - (int)o4));
         /* !WIDE: every sample fits in 24 bits (bps <= 18: |x| < 2^(bps-1) per channel, S = R - L doubles it,
          * pre-emphasis doubles again, the LTP at most quadruples) and the taps are 8-bit, so the full-rate 24-bit
          * multiply gives the same low 32 bits as the wrap-around 32-bit product */
@@ -1890,8 +1904,8 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
         for (uint32_t kb = 0; kb < o4; kb += 4) {
             const int4 cf = *reinterpret_cast<const int4 *>(&sm->coefq[kb]);
 #pragma unroll
-            for (int c = 0; c < FL; c++) {
-                const int4 nxt = *reinterpret_cast<const int4 *>(sig + sig_index<FL>(PADS + (int)s_base + 4 * c - (int)o4 + (int)kb + 4));
+            for (int c = 0; c < CH; c++) {
+                const int4 nxt = *reinterpret_cast<const int4 *>(sig + sig_index<CH>(PADS + (int)s_base + 4 * c - (int)o4 + (int)kb + 4));
                 const int w0 = cur[c].x, w1 = cur[c].y, w2 = cur[c].z, w3 = cur[c].w, w4 = nxt.x, w5 = nxt.y, w6 = nxt.z;
                 acc[4 * c + 0] = mad24(cf.w, w3, mad24(cf.z, w2, mad24(cf.y, w1, mad24(cf.x, w0, acc[4 * c + 0]))));
                 acc[4 * c + 1] = mad24(cf.w, w4, mad24(cf.z, w3, mad24(cf.y, w2, mad24(cf.x, w1, acc[4 * c + 1]))));
@@ -1901,17 +1915,17 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
             }
         }
         } else {
-        int4 curh[FL];
+        int4 curh[CH];
 #pragma unroll
-        for (int c = 0; c < FL; c++) {
+        for (int c = 0; c < CH; c++) {
             curh[c] = make_int4(cur[c].x >> 16, cur[c].y >> 16, cur[c].z >> 16, cur[c].w >> 16);
             cur[c] = make_int4(cur[c].x & 0xFFFF, cur[c].y & 0xFFFF, cur[c].z & 0xFFFF, cur[c].w & 0xFFFF);
         }
         for (uint32_t kb = 0; kb < o4; kb += 4) {
             const int4 cf = *reinterpret_cast<const int4 *>(&sm->coefq[kb]);
 #pragma unroll
-            for (int c = 0; c < FL; c++) {
-                const int4 nx = *reinterpret_cast<const int4 *>(sig + sig_index<FL>(PADS + (int)s_base + 4 * c - (int)o4 + (int)kb + 4));
+            for (int c = 0; c < CH; c++) {
+                const int4 nx = *reinterpret_cast<const int4 *>(sig + sig_index<CH>(PADS + (int)s_base + 4 * c - (int)o4 + (int)kb + 4));
                 const int4 nl = make_int4(nx.x & 0xFFFF, nx.y & 0xFFFF, nx.z & 0xFFFF, nx.w & 0xFFFF);
                 const int4 nh = make_int4(nx.x >> 16, nx.y >> 16, nx.z >> 16, nx.w >> 16);
                 {
@@ -1933,7 +1947,7 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
             }
         }
         }
-        yprev = (tid == 0) ? 0 : sig[sig_index<FL>(PADS + (int)s_base - 1)];
+        yprev = (tid == 0) ? 0 : sig[sig_index<CH>(PADS + (int)s_base - 1)];
         }
         int32_t rr[S];
         /* the first `order` samples of the block are differenced, not predicted (srla_lpc_predict.c:118-265): only the first
@@ -1962,52 +1976,61 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
     if (jp.out_stride == 2) { if (max_u == 0x7fffffff) out->pad[1] = 1; return; }   /* kernel timing experiments (make EXTRA=-DSRLA_DIAG_STOP): never in the shipped library */
 #endif
 
-    /* partition means: exact integer sums at the finest level, pairwise averages above */
-    double m10[4];
+    /* Partition means: exact integer sums at the finest level, pairwise averages above (srla_coder.c:366-389).  A thread holds
+     * Q = 4 << LG finest partitions of FL samples; its levels 10 .. TL = 8 - LG form a heap in registers (node 1: the partition
+     * that is the thread, nodes Q .. 2Q-1: level 10), levels TL-1 .. TL-6 come by wave shuffles, and what is left above the
+     * wavefront (LS = TL - 6 levels) through LDS across the item's wavefronts. */
+    constexpr int Q = 4 << LG, LOGQ = 2 + LG, TL = 8 - LG, LS = TL - 6;
+    double mth[2 * Q];
     if (__all((int)(max_u < (1u << 28)))) {
         /* the sum of a finest partition (at most 8 values) stays within 32 bits: one add per sample and an exact conversion */
 #pragma unroll
-        for (int p = 0; p < 4; p++) {
+        for (int p = 0; p < Q; p++) {
             uint32_t sum = 0;
 #pragma unroll
             for (int i = 0; i < FL; i++) sum += u[p * FL + i];
-            m10[p] = (double)sum / (double)FL;
+            mth[Q + p] = (double)sum / (double)FL;
         }
     } else {
 #pragma unroll
-        for (int p = 0; p < 4; p++) {
+        for (int p = 0; p < Q; p++) {
             unsigned long long sum = 0;
 #pragma unroll
             for (int i = 0; i < FL; i++) sum += u[p * FL + i];
-            m10[p] = (double)sum / (double)FL;
+            mth[Q + p] = (double)sum / (double)FL;
         }
     }
-    double m[11];                                   /* m[l]: mean of the level-l partition this thread lies in */
-    const double m9a = (m10[0] + m10[1]) / 2.0, m9b = (m10[2] + m10[3]) / 2.0;
-    m[8] = (m9a + m9b) / 2.0;
 #pragma unroll
-    for (int l = 7; l >= 2; l--) {
-        const double other = __shfl_xor(m[l + 1], 1 << (7 - l), WAVE);
+    for (int i = Q - 1; i >= 1; i--) mth[i] = (mth[2 * i] + mth[2 * i + 1]) / 2.0;
+    double m[TL + 1];                               /* m[l]: mean of the level-l partition this thread lies in, l <= TL */
+    m[TL] = mth[1];
+#pragma unroll
+    for (int l = TL - 1; l >= LS; l--) {
+        const double other = __shfl_xor(m[l + 1], 1 << (TL - 1 - l), WAVE);
         /* (mean[2p] + mean[2p+1]) / 2: the lane holding the even child adds in that order */
-        const bool even = ((lane >> (7 - l)) & 1u) == 0;
+        const bool even = ((lane >> (TL - 1 - l)) & 1u) == 0;
         m[l] = even ? (m[l + 1] + other) / 2.0 : (other + m[l + 1]) / 2.0;
     }
     max_u = wave_max_u32(max_u);
-    if (lane == 0) { sm->wave_mean[wave] = m[2]; sm->wave_max[wave] = max_u; }
+    if (lane == 0) { sm->wave_mean[wave] = m[LS]; sm->wave_max[wave] = max_u; }
     __syncthreads();
     {
-        const double a = sm->wave_mean[0], b = sm->wave_mean[1], c = sm->wave_mean[2], d = sm->wave_mean[3];
-        const double m1a = (a + b) / 2.0, m1b = (c + d) / 2.0;
-        m[1] = (wave < 2) ? m1a : m1b;
-        m[0] = (m1a + m1b) / 2.0;
+        if constexpr (LS == 2) {
+            const double a = sm->wave_mean[0], b = sm->wave_mean[1], c = sm->wave_mean[2], d = sm->wave_mean[3];
+            const double m1a = (a + b) / 2.0, m1b = (c + d) / 2.0;
+            m[1] = (wave < 2) ? m1a : m1b;
+            m[0] = (m1a + m1b) / 2.0;
+        } else if constexpr (LS == 1) {
+            m[0] = (sm->wave_mean[0] + sm->wave_mean[1]) / 2.0;
+        }
         max_u = sm->wave_max[0];
-        for (int w = 1; w < NWAVES; w++) max_u = (sm->wave_max[w] > max_u) ? sm->wave_max[w] : max_u;
+        for (int w = 1; w < WPI; w++) max_u = (sm->wave_max[w] > max_u) ? sm->wave_max[w] : max_u;
     }
     /* The residual goes to the scratch in HBM for srla_pack_blocks -- of EVERY item, chosen or not, which made these stores most
      * of the launch's memory traffic.  What the pack kernel codes is the zig-zag mapped value, and where the block's largest one
      * fits 16 bits (ordinary 16-bit audio) that is what is stored, two bytes per sample, in the first half of the item's region
      * (SRLA_ITEM_RES_U16); else, and for SRLAMI355X_ProbeBlock (keep_residuals == 2), the int32 residual. */
-    /* every zig-zag value of the block within 16 bits (the whole workgroup agrees): pairs of them in one register serve the store
+    /* every zig-zag value of the block within 16 bits (the whole item agrees): pairs of them in one register serve the store
      * below and the code-bit pass further down */
     const bool narrow16 = max_u < 65536u;
     uint32_t pk[S / 2];
@@ -2016,19 +2039,19 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
     if (jp.keep_residuals) {
         if (jp.keep_residuals == 1u && narrow16) {
             uint32_t *r16 = reinterpret_cast<uint32_t *>(res_ws + it.res_off) + (s_base >> 1);
-            if constexpr ((FL & 1) == 0) {
+            if constexpr ((CH & 1) == 0) {
 #pragma unroll
-                for (int c = 0; c < FL / 2; c++) *reinterpret_cast<uint4 *>(r16 + 4 * c) = make_uint4(pk[4 * c], pk[4 * c + 1], pk[4 * c + 2], pk[4 * c + 3]);
+                for (int c = 0; c < CH / 2; c++) *reinterpret_cast<uint4 *>(r16 + 4 * c) = make_uint4(pk[4 * c], pk[4 * c + 1], pk[4 * c + 2], pk[4 * c + 3]);
             } else {
 #pragma unroll
-                for (int c = 0; c < FL; c++) *reinterpret_cast<uint2 *>(r16 + 2 * c) = make_uint2(pk[2 * c], pk[2 * c + 1]);
+                for (int c = 0; c < CH; c++) *reinterpret_cast<uint2 *>(r16 + 2 * c) = make_uint2(pk[2 * c], pk[2 * c + 1]);
             }
             if (tid == 0) out->flags |= SRLA_ITEM_RES_U16;
         } else {
             if (tid == 0) out->flags &= ~SRLA_ITEM_RES_U16;
             int32_t *res_out = res_ws + it.res_off + s_base;
 #pragma unroll
-            for (int c = 0; c < FL; c++) {
+            for (int c = 0; c < CH; c++) {
                 int32_t r4[4];
 #pragma unroll
                 for (int i = 0; i < 4; i++) r4[i] = (int32_t)((u[4 * c + i] >> 1) ^ (0u - (u[4 * c + i] & 1u)));
@@ -2044,110 +2067,106 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
     if (jp.out_stride == 3) { if (m[0] == 1.2345) out->pad[1] = 1; return; }   /* kernel timing experiments (make EXTRA=-DSRLA_DIAG_STOP): never in the shipped library */
 #endif
 
-    uint32_t best_porder = 0, best_bits = 0;
-    if (code_type != SRLA_CODE_ALLZERO) {
-        uint32_t k10[4], k9[2], kl[9];
+    /* (the barriers below are outside the `coded` branches: with several items per workgroup an all-zero item meets them too) */
+    const bool coded = code_type != SRLA_CODE_ALLZERO;
+    uint32_t kth[2 * Q];       /* parameters of the thread's heap: kth[(1 << d) + j], partition j of level TL + d */
+    uint32_t kl[TL + 1];       /* kl[l]: parameter of the level-l partition the thread lies in (kl[TL] = kth[1]) */
+    if (coded) {
 #pragma unroll
-        for (int p = 0; p < 4; p++) k10[p] = rice_param(m10[p], code_type, sm->thr);
-        k9[0] = rice_param(m9a, code_type, sm->thr);
-        k9[1] = rice_param(m9b, code_type, sm->thr);
+        for (int i = 1; i < 2 * Q; i++) kth[i] = rice_param(mth[i], code_type, sm->thr);
 #pragma unroll
-        for (int l = 0; l <= 8; l++) kl[l] = rice_param(m[l], code_type, sm->thr);
-        /* publish the table (leaders only), heap layout */
+        for (int l = 0; l < TL; l++) kl[l] = rice_param(m[l], code_type, sm->thr);
+        kl[TL] = kth[1];
+        /* publish the table (leaders only), heap layout: level l at [2^l - 1, 2^(l+1) - 1) */
 #pragma unroll
-        for (int p = 0; p < 4; p++) sm->ktab[1023 + 4 * tid + p] = (uint8_t)k10[p];
-        sm->ktab[511 + 2 * tid] = (uint8_t)k9[0];
-        sm->ktab[511 + 2 * tid + 1] = (uint8_t)k9[1];
+        for (int d = 0; d <= LOGQ; d++)
 #pragma unroll
-        for (int l = 0; l <= 8; l++)
-            if ((tid & ((1u << (8 - l)) - 1u)) == 0) sm->ktab[((1u << l) - 1) + (tid >> (8 - l))] = (uint8_t)kl[l];
-        __syncthreads();
+            for (int j = 0; j < (1 << d); j++) sm->ktab[((1u << (TL + d)) - 1u) + (tid << d) + (uint32_t)j] = (uint8_t)kth[(1 << d) + j];
+#pragma unroll
+        for (int l = 0; l < TL; l++)
+            if ((tid & ((1u << (TL - l)) - 1u)) == 0) sm->ktab[((1u << l) - 1) + (tid >> (TL - l))] = (uint8_t)kl[l];
+    }
+    __syncthreads();
 #ifdef SRLA_DIAG_STOP
-        if (jp.out_stride == 4) { if (kl[0] + k10[3] == 0x7fffffff) out->pad[1] = 1; return; }   /* kernel timing experiments (make EXTRA=-DSRLA_DIAG_STOP): never in the shipped library */
+    if (jp.out_stride == 4) { if (coded && kl[0] + kth[2 * Q - 1] == 0x7fffffff) out->pad[1] = 1; return; }   /* kernel timing experiments (make EXTRA=-DSRLA_DIAG_STOP): never in the shipped library */
 #endif
+    uint32_t best_porder = 0, best_bits = 0;
+    if (coded) {
         uint32_t acc[11];
         /* side information (srla_coder.c:415-427) booked by the first thread of each partition */
-        {
-            uint32_t side10 = 0;
 #pragma unroll
-            for (int p = 0; p < 4; p++) {
-                const uint32_t part = 4 * tid + p;
-                const uint32_t prevk = (p == 0) ? ((part == 0) ? 0u : sm->ktab[1023 + part - 1]) : k10[p - 1];
-                side10 += (part == 0) ? 15u : (zigzag32((int32_t)k10[p] - (int32_t)prevk) + 1u);
-            }
-            acc[10] = side10;
-            const uint32_t prev9 = (tid == 0) ? 0u : sm->ktab[511 + 2 * tid - 1];
-            acc[9] = ((tid == 0) ? 15u : (zigzag32((int32_t)k9[0] - (int32_t)prev9) + 1u)) + (zigzag32((int32_t)k9[1] - (int32_t)k9[0]) + 1u);
+        for (int d = 0; d <= LOGQ; d++) {
+            const uint32_t lbase = (1u << (TL + d)) - 1u;
+            uint32_t side = 0;
 #pragma unroll
-            for (int l = 0; l <= 8; l++) {
-                uint32_t side = 0;
-                if ((tid & ((1u << (8 - l)) - 1u)) == 0) {
-                    const uint32_t part = tid >> (8 - l);
-                    side = (part == 0) ? 15u : (zigzag32((int32_t)kl[l] - (int32_t)sm->ktab[((1u << l) - 1) + part - 1]) + 1u);
-                }
-                acc[l] = side;
+            for (int j = 0; j < (1 << d); j++) {
+                const uint32_t part = (tid << d) + (uint32_t)j;
+                const uint32_t prevk = (j == 0) ? ((part == 0) ? 0u : sm->ktab[lbase + part - 1]) : kth[(1 << d) + (j > 0 ? j - 1 : 0)];
+                side += (part == 0) ? 15u : (zigzag32((int32_t)kth[(1 << d) + j] - (int32_t)prevk) + 1u);
             }
+            acc[TL + d] = side;
         }
-        /* Code bits of this thread's samples under every level's parameters.  Levels 0..8 price all of the thread's
-         * samples with one parameter, level 9 each half, level 10 each quarter: 11 evaluations per sample, no tables,
-         * no lane divergence (the variable part is a saturating subtract + shift, srla_coder.c:327-347). */
-        {
-            uint32_t fixed8 = 0;                                  /* sum over levels is not needed: per level below */
-            (void)fixed8;
-            /* neighbouring coarse levels very often have the same parameter in every lane of the wavefront: then the
-             * thread's sum is the one just computed (wave-uniform test, so no lane diverges) */
-            if (narrow16) {
-                /* two samples per instruction: saturating subtract, shift and a dot product with (1, 1) that adds both halves
-                 * to a 32-bit sum (v_pk_sub_u16 clamp, v_pk_lshrrev_b16, v_dot2_u32_u16) -- three instructions per PAIR and
-                 * level instead of three per sample.  A parameter's threshold 2 << k leaves 16 bits at k = 15: every value
-                 * is below it then, as below 65535; k >= 16 prices every value at zero quotient bits likewise. */
-                typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-                const us2 ones = { 1, 1 };
-                auto thr16 = [&](uint32_t k) -> uint32_t {
-                    const uint32_t t2 = (code_type == SRLA_CODE_RICE) ? 0u : (2u << (k & 15u));
-                    return (k >= 16u) ? 0xFFFFu : ((t2 > 0xFFFFu) ? 0xFFFFu : t2);
-                };
-                auto pair_cost = [&](uint32_t w, uint32_t thr2, uint32_t sh2, uint32_t sum) -> uint32_t {
-                    const us2 d = __builtin_elementwise_sub_sat(__builtin_bit_cast(us2, w), __builtin_bit_cast(us2, thr2));
-                    return __builtin_amdgcn_udot2(d >> __builtin_bit_cast(us2, sh2), ones, sum, false);
-                };
-                uint32_t t = 0;
 #pragma unroll
-                for (int l = 0; l <= 8; l++) {
-                    const bool same = (l > 0) && __all((int)(kl[l] == kl[l > 0 ? l - 1 : 0]));
-                    if (!same) {
-                        const uint32_t thr2 = thr16(kl[l]) * 0x10001u, sh2 = (kl[l] & 15u) * 0x10001u;
-                        t = (uint32_t)S * code_cost_fixed(kl[l], code_type);
-#pragma unroll
-                        for (int j = 0; j < S / 2; j++) t = pair_cost(pk[j], thr2, sh2, t);
-                    }
-                    acc[l] += t;
-                }
-                {
-                    uint32_t t9 = (uint32_t)(2 * FL) * (code_cost_fixed(k9[0], code_type) + code_cost_fixed(k9[1], code_type));
-                    const uint32_t th[2] = { thr16(k9[0]) * 0x10001u, thr16(k9[1]) * 0x10001u };
-                    const uint32_t sh[2] = { (k9[0] & 15u) * 0x10001u, (k9[1] & 15u) * 0x10001u };
-#pragma unroll
-                    for (int j = 0; j < S / 2; j++) t9 = pair_cost(pk[j], th[(2 * j) / (2 * FL)], sh[(2 * j) / (2 * FL)], t9);
-                    acc[9] += t9;
-                }
-                {
-                    uint32_t t10 = (uint32_t)FL * (code_cost_fixed(k10[0], code_type) + code_cost_fixed(k10[1], code_type)
-                                                   + code_cost_fixed(k10[2], code_type) + code_cost_fixed(k10[3], code_type));
-                    uint32_t th[4], sh[4];
-#pragma unroll
-                    for (int q = 0; q < 4; q++) { th[q] = thr16(k10[q]); sh[q] = k10[q] & 15u; }
-#pragma unroll
-                    for (int j = 0; j < S / 2; j++) {
-                        const int q0 = (2 * j) / FL, q1 = (2 * j + 1) / FL;      /* the quarters of the pair's two samples */
-                        t10 = pair_cost(pk[j], th[q0] | (th[q1] << 16), sh[q0] | (sh[q1] << 16), t10);
-                    }
-                    acc[10] += t10;
-                }
-            } else {
+        for (int l = 0; l < TL; l++) {
+            uint32_t side = 0;
+            if ((tid & ((1u << (TL - l)) - 1u)) == 0) {
+                const uint32_t part = tid >> (TL - l);
+                side = (part == 0) ? 15u : (zigzag32((int32_t)kl[l] - (int32_t)sm->ktab[((1u << l) - 1) + part - 1]) + 1u);
+            }
+            acc[l] = side;
+        }
+        /* Code bits of this thread's samples under every level's parameters.  Levels 0 .. TL price all of the thread's samples
+         * with one parameter, level TL + d each of its 2^d parts: 11 evaluations per sample, no tables, no lane divergence (the
+         * variable part is a saturating subtract + shift, srla_coder.c:327-347).  Neighbouring coarse levels very often have the
+         * same parameter in every lane of the wavefront: then the thread's sum is the one just computed (wave-uniform test). */
+        if (narrow16) {
+            /* two samples per instruction: saturating subtract, shift and a dot product with (1, 1) that adds both halves
+             * to a 32-bit sum (v_pk_sub_u16 clamp, v_pk_lshrrev_b16, v_dot2_u32_u16) -- three instructions per PAIR and
+             * level instead of three per sample.  A parameter's threshold 2 << k leaves 16 bits at k = 15: every value
+             * is below it then, as below 65535; k >= 16 prices every value at zero quotient bits likewise. */
+            typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+            const us2 ones = { 1, 1 };
+            auto thr16 = [&](uint32_t k) -> uint32_t {
+                const uint32_t t2 = (code_type == SRLA_CODE_RICE) ? 0u : (2u << (k & 15u));
+                return (k >= 16u) ? 0xFFFFu : ((t2 > 0xFFFFu) ? 0xFFFFu : t2);
+            };
+            auto pair_cost = [&](uint32_t w, uint32_t thr2, uint32_t sh2, uint32_t sum) -> uint32_t {
+                const us2 dd = __builtin_elementwise_sub_sat(__builtin_bit_cast(us2, w), __builtin_bit_cast(us2, thr2));
+                return __builtin_amdgcn_udot2(dd >> __builtin_bit_cast(us2, sh2), ones, sum, false);
+            };
             uint32_t t = 0;
 #pragma unroll
-            for (int l = 0; l <= 8; l++) {
+            for (int l = 0; l <= TL; l++) {
+                const bool same = (l > 0) && __all((int)(kl[l] == kl[l > 0 ? l - 1 : 0]));
+                if (!same) {
+                    const uint32_t thr2 = thr16(kl[l]) * 0x10001u, sh2 = (kl[l] & 15u) * 0x10001u;
+                    t = (uint32_t)S * code_cost_fixed(kl[l], code_type);
+#pragma unroll
+                    for (int j = 0; j < S / 2; j++) t = pair_cost(pk[j], thr2, sh2, t);
+                }
+                acc[l] += t;
+            }
+#pragma unroll
+            for (int d = 1; d <= LOGQ; d++) {
+                constexpr int dummy = 0; (void)dummy;
+                const int plen = S >> d;                                   /* samples of a part */
+                uint32_t td = 0, th[1 << LOGQ], sh[1 << LOGQ];
+#pragma unroll
+                for (int j = 0; j < (1 << d); j++) {
+                    td += (uint32_t)plen * code_cost_fixed(kth[(1 << d) + j], code_type);
+                    th[j] = thr16(kth[(1 << d) + j]); sh[j] = kth[(1 << d) + j] & 15u;
+                }
+#pragma unroll
+                for (int j = 0; j < S / 2; j++) {
+                    const int q0 = (2 * j) / plen, q1 = (2 * j + 1) / plen;   /* the parts of the pair's two samples */
+                    td = pair_cost(pk[j], th[q0] | (th[q1] << 16), sh[q0] | (sh[q1] << 16), td);
+                }
+                acc[TL + d] += td;
+            }
+        } else {
+            uint32_t t = 0;
+#pragma unroll
+            for (int l = 0; l <= TL; l++) {
                 const bool same = (l > 0) && __all((int)(kl[l] == kl[l > 0 ? l - 1 : 0]));
                 if (!same) {
                     t = (uint32_t)S * code_cost_fixed(kl[l], code_type);
@@ -2156,36 +2175,37 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
                 }
                 acc[l] += t;
             }
-            {
-                uint32_t t = (uint32_t)(2 * FL) * (code_cost_fixed(k9[0], code_type) + code_cost_fixed(k9[1], code_type));
 #pragma unroll
-                for (int i = 0; i < S; i++) t += code_cost_var(u[i], k9[i / (2 * FL)], code_type);
-                acc[9] += t;
-            }
-            {
-                uint32_t t = (uint32_t)FL * (code_cost_fixed(k10[0], code_type) + code_cost_fixed(k10[1], code_type)
-                                             + code_cost_fixed(k10[2], code_type) + code_cost_fixed(k10[3], code_type));
+            for (int d = 1; d <= LOGQ; d++) {
+                const int plen = S >> d;
+                uint32_t td = 0;
 #pragma unroll
-                for (int i = 0; i < S; i++) t += code_cost_var(u[i], k10[i / FL], code_type);
-                acc[10] += t;
-            }
+                for (int j = 0; j < (1 << d); j++) td += (uint32_t)plen * code_cost_fixed(kth[(1 << d) + j], code_type);
+#pragma unroll
+                for (int i = 0; i < S; i++) td += code_cost_var(u[i], kth[(1 << d) + i / plen], code_type);
+                acc[TL + d] += td;
             }
         }
 #ifdef SRLA_DIAG_STOP
-        if (jp.out_stride == 5) { uint32_t t = 0; for (int l = 0; l <= 10; l++) t += acc[l]; if (t == 0x7fffffff) out->pad[1] = 1; return; }   /* kernel timing experiments (make EXTRA=-DSRLA_DIAG_STOP): never in the shipped library */
+        if (jp.out_stride == 5) { uint32_t tt = 0; for (int l = 0; l <= 10; l++) tt += acc[l]; if (tt == 0x7fffffff) out->pad[1] = 1; }
 #endif
 #pragma unroll
         for (int l = 0; l <= 10; l++) {
             const uint32_t sum = wave_sum_u32(acc[l]);
             if (lane == 0) atomicAdd(&sm->level_bits[l], sum);
         }
-        __syncthreads();
+    }
+#ifdef SRLA_DIAG_STOP
+    if (jp.out_stride == 5) return;   /* kernel timing experiments (make EXTRA=-DSRLA_DIAG_STOP): never in the shipped library */
+#endif
+    __syncthreads();
+    if (coded) {
         best_bits = 0xFFFFFFFFu;
         for (uint32_t l = 0; l <= 10; l++) {
             const uint32_t b = sm->level_bits[l];
             if (b < best_bits) { best_bits = b; best_porder = l; }
         }
-        for (uint32_t p = tid; p < (1u << best_porder); p += NT) out->kparam[p] = sm->ktab[((1u << best_porder) - 1) + p];
+        for (uint32_t p = tid; p < (1u << best_porder); p += T) out->kparam[p] = sm->ktab[((1u << best_porder) - 1) + p];
     }
     if (tid == 0) {
         const uint32_t res_bits = best_bits + 2u;
