@@ -66,7 +66,7 @@ SrlaLdsPlan Impl::lds_plan(uint32_t nfft) const
     p.small_off = off; off += srla_kernel_small_c_bytes();
     p.total = off;
     /* the fast path of the same kernel carves the block differently: make sure it fits too */
-    for (uint32_t fl = 1; fl <= 8 && 1024u * fl <= nfft; fl++) p.total = std::max(p.total, srla_kernel_fast_lds_bytes(fl));
+    for (uint32_t fl = 1; fl <= 8 && 1024u * fl <= nfft; fl++) p.total = std::max(p.total, srla_kernel_fast_lds_bytes(fl, par.ltp_order, par.bits_per_sample));
     return p;
 }
 
@@ -181,7 +181,7 @@ void Impl::build_job(Job &job, const JobPlan &plan, const std::vector<uint32_t> 
             for (const SrlaItemDesc &it : job.items) {
                 const uint32_t fl = it.n >> 10;
                 if ((it.n & 1023u) != 0 || fl < 1 || fl > 8 || fl > 2u * (uint32_t)g.rclass) { all_fast = false; break; }
-                fast_bytes = std::max(fast_bytes, srla_kernel_fast_lds_bytes(fl));
+                fast_bytes = std::max(fast_bytes, srla_kernel_fast_lds_bytes(fl, par.ltp_order, par.bits_per_sample));
             }
             if (all_fast) g.plan.total = fast_bytes;
         }

@@ -24,7 +24,7 @@ extern "C" {
 
 uint32_t srla_kernel_small_a_bytes(void);
 uint32_t srla_kernel_small_c_bytes(void);
-uint32_t srla_kernel_fast_lds_bytes(uint32_t fl);   /* LDS of the 1024*fl-sample fast path of srla_residual_cost */
+uint32_t srla_kernel_fast_lds_bytes(uint32_t fl, uint32_t ltp_order, uint32_t bits_per_sample);   /* LDS of a workgroup of the 1024*fl-sample fast path of srla_residual_cost (one item, or the items that share it) */
 #define SRLA_FIR_PAD 256
 
 /* pass 0: LPC lags (initialises the item record unless an LTP pass ran first), pass 1: LTP lags.

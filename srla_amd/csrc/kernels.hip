@@ -1654,6 +1654,38 @@ __device__ __forceinline__ uint32_t mad24(int32_t a, int32_t b, uint32_t acc)
 #define FIR_MAD24 0
 #define FIR_WIDE  1
 #define FIR_DOT   2
+#ifdef SRLA_FIR_MAD24
+#define SRLA_FIR_NARROW FIR_MAD24
+#else
+#define SRLA_FIR_NARROW FIR_DOT
+#endif
+/* LDS of ONE item of the fast path, by block length (fl = n / 1024) and the log2 of the items that share its workgroup: the
+ * int32 signal (front padding for the FIR's and the LTP's reach back, pads between the threads' runs: sig_index), or only the
+ * two planes that lie over it when neither the long-term predictor nor a FIR form other than FIR_DOT needs the int32 words;
+ * then the small structure.  One definition for the kernel and for the host's launch size. */
+__host__ __device__ constexpr uint32_t fast_sig_bytes(int fl, int lg, bool planes_only)
+{
+    const int ch = fl << lg, s = 4 * ch, padw = (ch & 1) ? 0 : 4;
+    const int padmin = (FIR_PAD > SRLA_LTP_MAX_PERIOD + 2) ? FIR_PAD : (SRLA_LTP_MAX_PERIOD + 2);
+    const int pads = ((padmin + s - 1) / s) * s, padf = ((FIR_PAD + s - 1) / s) * s;
+    const uint32_t sig_words = (uint32_t)((pads + 1024 * fl) / s) * (uint32_t)(s + padw) + 8u;
+    const uint32_t plane_elems = (uint32_t)((padf + 1024 * fl) / s) * (uint32_t)(s + padw);
+    const uint32_t planes = ((plane_elems * 2u + 15u) & ~15u) + plane_elems;
+    return ((planes_only ? planes : sig_words * 4u) + 15u) & ~15u;
+}
+/* Items per workgroup (log2).  -DSRLA_ITEM_GROUPS: blocks of 1024 and (without the long-term predictor) 2048 samples share a
+ * workgroup two by two, so that a thread holds 8 or 16 samples instead of 4 or 8 and its fixed work in the Rice search is spread
+ * over more of them.  Bit-identical (all GPU tests), and measured SLOWER: srla_residual_cost 0.196 -> 0.218 ms per job at M,
+ * 0.503 -> 0.578 at -V 2, 0.725 -> 0.771 at -V 2 -P 3 (the neighbour's workgroup that leaves at once still takes a slot and
+ * three dependent loads, and two items in lock step wait for the slower one at every barrier).  Not the default. */
+__host__ __device__ constexpr int fast_group_log2(uint32_t fl, uint32_t ltp_order)
+{
+#ifdef SRLA_ITEM_GROUPS
+    return (fl == 1u) ? 1 : ((fl == 2u && ltp_order == 0u) ? 1 : 0);
+#else
+    return (void)fl, (void)ltp_order, 0;
+#endif
+}
 typedef short srla_short2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t dot2_i16(uint32_t a, uint32_t b, uint32_t acc)
 {
@@ -1697,7 +1729,8 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
     constexpr uint32_t HIGH_OFF = (PLANE_ELEMS * 2 + 15) & ~15u;
     static_assert(HIGH_OFF + PLANE_ELEMS <= SIG_WORDS * 4, "the planes fit the int32 signal's LDS");
     int32_t *sig = (int32_t *)lds;
-    SmallF *sm = (SmallF *)(lds + ((SIG_WORDS * 4 + 15) & ~15u));
+    static_assert(fast_sig_bytes(FL, LG, false) == ((SIG_WORDS * 4 + 15) & ~15u) && fast_sig_bytes(FL, LG, true) == ((HIGH_OFF + PLANE_ELEMS + 15) & ~15u), "one layout");
+    SmallF *sm = (SmallF *)(lds + fast_sig_bytes(FL, LG, DOT && jp.ltp_order == 0));
     const uint32_t tid = threadIdx.x & (uint32_t)(T - 1), lane = tid & 63, wave = tid >> 6;   /* thread, wavefront within the item */
     const uint32_t n = 1024u * FL, bps = jp.bits_per_sample;
     const bool aligned = input_aligned(in, iv);
@@ -1981,29 +2014,38 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
      * that is the thread, nodes Q .. 2Q-1: level 10), levels TL-1 .. TL-6 come by wave shuffles, and what is left above the
      * wavefront (LS = TL - 6 levels) through LDS across the item's wavefronts. */
     constexpr int Q = 4 << LG, LOGQ = 2 + LG, TL = 8 - LG, LS = TL - 6;
-    double mth[2 * Q];
-    if (__all((int)(max_u < (1u << 28)))) {
-        /* the sum of a finest partition (at most 8 values) stays within 32 bits: one add per sample and an exact conversion */
+    const bool sums32 = __all((int)(max_u < (1u << 28)));
+    /* the means of the thread's finest partitions; then level by level in place: lv[i] = (lv[2i] + lv[2i+1]) / 2 */
+    auto finest_means = [&](double *lv) {
+        if (sums32) {
+            /* the sum of a finest partition (at most 8 values) stays within 32 bits: one add per sample and an exact conversion */
 #pragma unroll
-        for (int p = 0; p < Q; p++) {
-            uint32_t sum = 0;
+            for (int p = 0; p < Q; p++) {
+                uint32_t sum = 0;
 #pragma unroll
-            for (int i = 0; i < FL; i++) sum += u[p * FL + i];
-            mth[Q + p] = (double)sum / (double)FL;
+                for (int i = 0; i < FL; i++) sum += u[p * FL + i];
+                lv[p] = (double)sum / (double)FL;
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < Q; p++) {
+                unsigned long long sum = 0;
+#pragma unroll
+                for (int i = 0; i < FL; i++) sum += u[p * FL + i];
+                lv[p] = (double)sum / (double)FL;
+            }
         }
-    } else {
-#pragma unroll
-        for (int p = 0; p < Q; p++) {
-            unsigned long long sum = 0;
-#pragma unroll
-            for (int i = 0; i < FL; i++) sum += u[p * FL + i];
-            mth[Q + p] = (double)sum / (double)FL;
-        }
-    }
-#pragma unroll
-    for (int i = Q - 1; i >= 1; i--) mth[i] = (mth[2 * i] + mth[2 * i + 1]) / 2.0;
+    };
     double m[TL + 1];                               /* m[l]: mean of the level-l partition this thread lies in, l <= TL */
-    m[TL] = mth[1];
+    {
+        double lv[Q];
+        finest_means(lv);
+#pragma unroll
+        for (int w = Q / 2; w >= 1; w >>= 1)
+#pragma unroll
+            for (int i = 0; i < w; i++) lv[i] = (lv[2 * i] + lv[2 * i + 1]) / 2.0;
+        m[TL] = lv[0];
+    }
 #pragma unroll
     for (int l = TL - 1; l >= LS; l--) {
         const double other = __shfl_xor(m[l + 1], 1 << (TL - 1 - l), WAVE);
@@ -2072,8 +2114,24 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
     uint32_t kth[2 * Q];       /* parameters of the thread's heap: kth[(1 << d) + j], partition j of level TL + d */
     uint32_t kl[TL + 1];       /* kl[l]: parameter of the level-l partition the thread lies in (kl[TL] = kth[1]) */
     if (coded) {
+        /* The thread's heap of means once more, every mean turned into its parameter at once: keeping the 2Q - 1 doubles across
+         * the barrier above instead cost the launch its occupancy (spills under the 96-register cap).  The empty asm keeps the
+         * compiler from recognising the earlier computation and keeping its values alive after all. */
+        {
 #pragma unroll
-        for (int i = 1; i < 2 * Q; i++) kth[i] = rice_param(mth[i], code_type, sm->thr);
+            for (int i = 0; i < S; i++) asm volatile("" : "+v"(u[i]));
+            double lv[Q];
+            finest_means(lv);
+#pragma unroll
+            for (int p = 0; p < Q; p++) kth[Q + p] = rice_param(lv[p], code_type, sm->thr);
+#pragma unroll
+            for (int w = Q / 2; w >= 1; w >>= 1)
+#pragma unroll
+                for (int i = 0; i < w; i++) {
+                    lv[i] = (lv[2 * i] + lv[2 * i + 1]) / 2.0;
+                    kth[w + i] = rice_param(lv[i], code_type, sm->thr);
+                }
+        }
 #pragma unroll
         for (int l = 0; l < TL; l++) kl[l] = rice_param(m[l], code_type, sm->thr);
         kl[TL] = kth[1];
@@ -2218,12 +2276,12 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
     }
 }
 
-extern "C" uint32_t srla_kernel_fast_lds_bytes(uint32_t fl)
+extern "C" uint32_t srla_kernel_fast_lds_bytes(uint32_t fl, uint32_t ltp_order, uint32_t bits_per_sample)
 {
-    const uint32_t padmin = (FIR_PAD > SRLA_LTP_MAX_PERIOD + 2) ? FIR_PAD : (SRLA_LTP_MAX_PERIOD + 2);
-    const uint32_t S = 4 * fl, pads = ((padmin + S - 1) / S) * S;
-    const uint32_t sig_words = ((pads + 1024 * fl) / S) * (S + ((fl & 1u) ? 0u : 4u)) + 8;
-    return ((sig_words * 4 + 15) & ~15u) + (uint32_t)((sizeof(SmallF) + 15) & ~15u);
+    const bool dot = SRLA_FIR_NARROW == FIR_DOT && bits_per_sample <= 18;
+    const int lg = dot ? fast_group_log2(fl, ltp_order) : 0;
+    const uint32_t item = fast_sig_bytes((int)fl, lg, dot && ltp_order == 0) + (uint32_t)((sizeof(SmallF) + 15) & ~15u);
+    return item << lg;
 }
 
 /* The partitioned (recursive) Rice parameter search of SRLACoder_ComputeCodeLength (srla_coder.c:349-484) over the zig-zag
@@ -2370,11 +2428,6 @@ __device__ __forceinline__ void rice_search_finish(const uint32_t *u, const Srla
     }
 }
 
-#ifdef SRLA_FIR_MAD24
-#define SRLA_FIR_NARROW FIR_MAD24
-#else
-#define SRLA_FIR_NARROW FIR_DOT
-#endif
 template <int R>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(R >= 4 ? 2 : 5, 8))) void srla_residual_cost(
     SrlaJobParams jp, const int32_t *__restrict__ input, const SrlaItemDesc *__restrict__ items,
@@ -2394,6 +2447,30 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(R >= 4 ? 2 :
         /* blocks of 1024 * FL samples take the register / shuffle fast path */
         const uint32_t fl = itf.n >> 10;
         if ((itf.n & 1023u) == 0 && fl >= 1 && fl <= 8 && fl <= (uint32_t)(2 * R)) {
+            if (SRLA_FIR_NARROW == FIR_DOT && jp.bits_per_sample <= 18) {
+                /* Blocks of 1024 and (without the LTP) 2048 samples share a workgroup two by two: the item with the even index
+                 * leads, its neighbour's workgroup leaves at once.  Neighbours are nearly always the variants of one candidate,
+                 * hence of one length; where they are not (odd item counts, mono candidates of different lengths) each item
+                 * keeps its own workgroup. */
+                const int lg = fast_group_log2(fl, jp.ltp_order);
+                if (lg > 0) {
+                    const uint32_t leader = block & ~((1u << lg) - 1u);
+                    bool grouped = leader + (1u << lg) <= jp.num_items;
+                    for (uint32_t g = 0; grouped && g < (1u << lg); g++) grouped = items[leader + g].n == itf.n;
+                    if (grouped) {
+                        if (block != leader) return;
+                        /* (lg is 0 or 1.  The item is the wavefront's: a scalar, so that everything read through it -- order,
+                         * shift, taps, pointers -- stays in scalar registers and scalar branches as with one item per workgroup) */
+                        const uint32_t g = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / (uint32_t)(NT >> 1)));
+                        const SrlaItemDesc itg = items[leader + g];
+                        const InputView ivg = input_view(jp, itg.lshift);
+                        unsigned char *ldsg = lds + g * (fast_sig_bytes((int)fl, 1, jp.ltp_order == 0) + (uint32_t)((sizeof(SmallF) + 15) & ~15u));
+                        if (fl == 1) residual_cost_fast<1, FIR_DOT, 1>(jp, ivg, input + itg.sample_off, itg, ldsg, rice_thresholds, res_ws, &results[leader + g]);
+                        else residual_cost_fast<2, FIR_DOT, 1>(jp, ivg, input + itg.sample_off, itg, ldsg, rice_thresholds, res_ws, &results[leader + g]);
+                        return;
+                    }
+                }
+            }
             const int32_t *inf = input + itf.sample_off;
             SrlaItemResult *outf = &results[block];
 #define FAST(FLV)                                                                                                   \
