@@ -45,6 +45,8 @@ def main():
     ap.add_argument("--ranks", type=int, default=1)
     ap.add_argument("--dir", default="/dev/shm/srla_corpus")
     ap.add_argument("--repeat", type=int, default=2)
+    ap.add_argument("--batch-samples", type=int, default=0, help="passed on to srla_corpus (0: its default)")
+    ap.add_argument("--tool-args", default="", help="more arguments for srla_corpus, e.g. '--readers 10 --writers 4'")
     ap.add_argument("--host-deinterleave", action="store_true", help="the tool de-interleaves on the host (SRLAMI355X_EncodeBatchEx) instead of the device")
     a = ap.parse_args()
     shutil.rmtree(a.dir, ignore_errors=True)
@@ -55,7 +57,8 @@ def main():
     for i in range(a.files):
         write_wav16(os.path.join(ind, "track%03d.wav" % i), helpers.synth(helpers.MUSIC, 7000 + i, 48000, 2, n), 48000)
     print("synthesised %d files x %.0f s (%.2f GB of WAV) in %.1f s" % (a.files, a.seconds, a.files * n * 4 / 1e9, time.perf_counter() - t0), flush=True)
-    flags = ["-e", "-m", str(a.m), "-B", str(a.B), "-V", str(a.V), "-P", str(a.P)] + (["--host-deinterleave"] if a.host_deinterleave else [])
+    flags = ["-e", "-m", str(a.m), "-B", str(a.B), "-V", str(a.V), "-P", str(a.P)] + (["--host-deinterleave"] if a.host_deinterleave else []) \
+        + (["--batch-samples", str(a.batch_samples)] if a.batch_samples else []) + a.tool_args.split()
     result = None
     for rep in range(a.repeat):
         shutil.rmtree(outd, ignore_errors=True)
