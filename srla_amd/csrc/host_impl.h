@@ -205,6 +205,7 @@ struct Impl {
     hipStream_t out_stream = nullptr;
     bool pack_on_n = false;             /* SRLA_MI355X_PACK_ON_N=1: block offsets + assembly on stream N behind the pricing, only the stream-out on C (measured: M device-resident -4 %, config 2 +3 %, others equal -- not the default) */
     uint32_t short_min = 786432;        /* SRLA_MI355X_SHORT_MIN: ... and no piece shorter than this many samples */
+    uint32_t mid_jobs = 1;              /* SRLA_MI355X_MID_JOBS: a stream of up to this many whole jobs (and a rest) is cut into pieces like a short one (0: only streams shorter than a job) */
     uint32_t short_div = 4;             /* SRLA_MI355X_SHORT_DIV: a stream shorter than one job is cut into pieces of a job / this */
     bool split_ltp_stage = true;        /* SRLA_MI355X_NO_LTP_SKEW: stage A of LTP jobs in one piece on W, as before */
     bool keep_residuals_always = true;  /* false with SRLA_MI355X_RECOMPUTE_RESIDUALS */

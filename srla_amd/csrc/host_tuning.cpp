@@ -38,6 +38,7 @@ void Impl::read_environment()
     }
     { const long long v = number("SRLA_MI355X_JOB_SAMPLES", 0); if (v >= 65536) job_samples = (uint64_t)v; }
     { const long long v = number("SRLA_MI355X_SHORT_MIN", 0); if (v >= 16384) short_min = (uint32_t)v; }
+    { const long long v = number("SRLA_MI355X_MID_JOBS", -1); if (v >= 0 && v <= 16) mid_jobs = (uint32_t)v; }
     { const long long v = number("SRLA_MI355X_SHORT_DIV", 0); if (v >= 2 && v <= 64) short_div = (uint32_t)v; }
     { const long long v = number("SRLA_MI355X_PACK_THREADS", 0); if (v > 0) env_pack_threads = (uint32_t)v; }
     if (const char *e = getenv("SRLA_MI355X_TAIL_BOOST")) {     /* "wgs,jobs": stream-out workgroup multiplier of the last jobs */
