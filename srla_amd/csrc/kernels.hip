@@ -2206,7 +2206,6 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
             }
 #pragma unroll
             for (int d = 1; d <= LOGQ; d++) {
-                constexpr int dummy = 0; (void)dummy;
                 const int plen = S >> d;                                   /* samples of a part */
                 uint32_t td = 0, th[1 << LOGQ], sh[1 << LOGQ];
 #pragma unroll
