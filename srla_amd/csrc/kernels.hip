@@ -150,7 +150,7 @@ __device__ void fft_complex_lds(cplx *x, uint32_t m, int flag, const cplx *__res
  * and four outputs stand at one computed LDS address plus immediate offsets, the three table entries at one computed address
  * plus immediates, and the direction costs no selects.  (Half of srla_autocorr's VALU instructions were this bookkeeping, not
  * fp64 arithmetic: SQ_INSTS_VALU_*_F64 / SQ_INSTS_VALU = 0.49.)  Same butterflies, same operands, same bits. */
-template <int R, int NTK, bool PRUNE, int M, int FLAG>
+template <int R, int NTK, bool PRUNE, int M, int FLAG, bool FIRSTREG = false /* the first stage has been done from registers (fft_first_stage_regs): start at the second */>
 __device__ __forceinline__ void fft_complex_lds_ct(cplx *x, const cplx *__restrict__ tw, const uint32_t need)
 {
     const uint32_t tid = threadIdx.x;
@@ -167,6 +167,7 @@ __device__ __forceinline__ void fft_complex_lds_ct(cplx *x, const cplx *__restri
         const uint32_t n = (uint32_t)M >> (2 * st), s = 1u << (2 * st), log2s = 2u * (uint32_t)st;
         if (n <= 2) break;
         const uint32_t n1 = n >> 2;
+        if (FIRSTREG && st == 0) { twoff += 3 * n1; continue; }
         const bool k1 = !PRUNE || s < need, k2 = !PRUNE || 2 * s < need, k3 = !PRUNE || 3 * s < need;
         cplx a[R], b[R], c[R], d[R], w1[R], w2[R], w3[R];
 #pragma unroll
@@ -180,7 +181,7 @@ __device__ __forceinline__ void fft_complex_lds_ct(cplx *x, const cplx *__restri
                 if (k2) w2[r] = t[n1];
                 if (k3) w3[r] = t[2 * n1];
                 /* SWZ12, second stage: the first stage left its outputs in the permuted order (below) */
-                const cplx *xi = x + ((SWZ12 && st == 1) ? (bf ^ ((bf >> 3) & 3u)) : bf);
+                const cplx *xi = x + ((FIRSTREG && st == 1) ? (bf ^ ((bf >> 3) & 7u)) : ((SWZ12 && st == 1) ? (bf ^ ((bf >> 3) & 3u)) : bf));
                 a[r] = xi[0]; b[r] = xi[m4]; c[r] = xi[2 * m4]; d[r] = xi[3 * m4];
             }
         }
@@ -193,7 +194,7 @@ __device__ __forceinline__ void fft_complex_lds_ct(cplx *x, const cplx *__restri
                 const cplx apc = c_add(a[r], c[r]), amc = c_sub(a[r], c[r]), bpd = c_add(b[r], d[r]);
                 const cplx bmd = c_sub(b[r], d[r]);
                 const cplx jbmd = (FLAG < 0) ? make_double2(-bmd.y, bmd.x) : make_double2(bmd.y, -bmd.x);
-                if (SWZ12 && st == 0) {
+                if (SWZ12 && !FIRSTREG && st == 0) {
                     /* First stage: a thread's four outputs are the consecutive elements 4 bf .. 4 bf + 3, so the eight lanes a
                      * ds_write_b128 is served in store 64 bytes apart: output k of every second lane lands in the same 16-byte
                      * column of the eight (4-way conflicts on all four stores).  Element e therefore goes to e ^ ((e >> 3) & 3):
@@ -239,6 +240,38 @@ __device__ __forceinline__ void fft_complex_lds_ct(cplx *x, const cplx *__restri
         }
         __syncthreads();
     }
+}
+
+/* The first radix-4 stage of the forward transform fed from registers.  A thread of the 4096- and 8192-point classes loads the
+ * sample chunks 4 tid + c nfft/4, c = 0..3 -- complex elements 2 tid + c m/4 and 2 tid + 1 + c m/4: exactly the four inputs of
+ * butterflies 2 tid and 2 tid + 1 (inputs bf + k m/4).  With that assignment the windowed signal never passes through LDS (a
+ * store and a load of the whole buffer and one barrier less per item).  The butterflies are fft_complex_lds_ct's (the same
+ * operands in the same order); their eight consecutive outputs 8 tid .. 8 tid + 7 go to e ^ ((e >> 3) & 7) -- the eight lanes a
+ * 16-byte store is served in land in eight columns -- and the second stage reads bf + k m/4 at bf ^ ((bf >> 3) & 7): lanes
+ * permuted within their block of eight by at most their block's index, which leaves every lane group of a 16-byte load (whole
+ * quads of four blocks) on sixteen columns (checked in tests/test_kernel_models.py). */
+template <int M>
+__device__ __forceinline__ void fft_first_stage_regs(cplx *x, const double (&w)[4][4], const cplx *__restrict__ tw)
+{
+    const uint32_t tid = threadIdx.x;
+    constexpr uint32_t n1 = (uint32_t)M >> 2;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const uint32_t bf = 2u * tid + (uint32_t)h;
+        const cplx *t = tw + bf;
+        const cplx w1 = t[0], w2 = t[n1], w3 = t[2 * n1];
+        const cplx a = make_double2(w[0][2 * h], w[0][2 * h + 1]), b = make_double2(w[1][2 * h], w[1][2 * h + 1]);
+        const cplx c = make_double2(w[2][2 * h], w[2][2 * h + 1]), d = make_double2(w[3][2 * h], w[3][2 * h + 1]);
+        const cplx apc = c_add(a, c), amc = c_sub(a, c), bpd = c_add(b, d), bmd = c_sub(b, d);
+        const cplx jbmd = make_double2(-bmd.y, bmd.x);                                /* forward: flag = -1 */
+        cplx *xo = x + 8u * tid;
+        const uint32_t sw = tid & 7u, j0 = 4u * (uint32_t)h;
+        xo[(j0 + 0u) ^ sw] = c_add(apc, bpd);
+        xo[(j0 + 1u) ^ sw] = c_mul(w1, c_sub(amc, jbmd));
+        xo[(j0 + 2u) ^ sw] = c_mul(w2, c_sub(apc, bpd));
+        xo[(j0 + 3u) ^ sw] = c_mul(w3, c_add(amc, jbmd));
+    }
+    __syncthreads();
 }
 
 __device__ __forceinline__ uint32_t complex_table_len(uint32_t m)
@@ -487,7 +520,7 @@ __device__ void spectrum_power_pass(cplx *x, uint32_t nfft, const cplx *__restri
 
 /* circular autocorrelation of the (already windowed, zero padded) signal in buf (lpc.c:330-376): on return
  * complex slot cidx<F16>(i/2) component i&1 holds the unscaled lag i, for i < num_lags */
-template <int R, int NTK, bool F16, int NFFT = 0>
+template <int R, int NTK, bool F16, int NFFT = 0, bool FIRSTREG = false>
 __device__ void autocorr_in_place(cplx *buf, uint32_t nfft, const cplx *__restrict__ twbase, uint32_t num_lags)
 {
     const uint32_t m = nfft >> 1;
@@ -498,7 +531,7 @@ __device__ void autocorr_in_place(cplx *buf, uint32_t nfft, const cplx *__restri
     const cplx *rtw_inv = rtw_fwd + quarter;
     if constexpr (NFFT != 0 && !F16) {
         /* the transform's length known at compile time (a launch of one FFT-size class outside chain mode) */
-        fft_complex_lds_ct<R, NTK, false, NFFT / 2, -1>(buf, tw_fwd, m);
+        fft_complex_lds_ct<R, NTK, false, NFFT / 2, -1, FIRSTREG>(buf, tw_fwd, m);
         spectrum_power_pass<NTK, false>(buf, nfft, rtw_fwd, rtw_inv);
         fft_complex_lds_ct<R, NTK, true, NFFT / 2, 1>(buf, tw_inv, (num_lags + 1) >> 1);
     } else if (F16) {
@@ -732,6 +765,12 @@ __global__ __launch_bounds__(NTK) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     }
 
     /* Welch window (lpc.c:256-266) on the [-1,1) normalised signal, zero padded to nfft */
+#if defined(SRLA_DIAG_STOP) || defined(SRLA_FFT_NO_FIRSTREG)
+    constexpr bool FIRSTREG = false;
+#else
+    constexpr bool FIRSTREG = NFFT != 0 && !F16 && R == 2 && 8 * R * NTK == NFFT;   /* fft_first_stage_regs: the windowed chunks stay in registers */
+#endif
+    double wreg[FIRSTREG ? 4 : 1][4];
     {
         const double norm_bps = __builtin_ldexp(1.0, -(int)(bps - 1));
         const uint32_t half = n >> 1;
@@ -776,11 +815,15 @@ __global__ __launch_bounds__(NTK) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                         w[i] = val;
                     }
                 }
-                buf[cidx<F16>(i4 >> 1)] = make_double2(w[0], w[1]);
-                buf[cidx<F16>((i4 >> 1) + 1u)] = make_double2(w[2], w[3]);
+                if constexpr (FIRSTREG) {
+                    wreg[c][0] = w[0]; wreg[c][1] = w[1]; wreg[c][2] = w[2]; wreg[c][3] = w[3];
+                } else {
+                    buf[cidx<F16>(i4 >> 1)] = make_double2(w[0], w[1]);
+                    buf[cidx<F16>((i4 >> 1) + 1u)] = make_double2(w[2], w[3]);
+                }
             }
         }
-        __syncthreads();
+        if constexpr (!FIRSTREG) __syncthreads();
     }
 
     const uint32_t num_lags = (pass == 1) ? SRLA_LTP_LAGS : (jp.max_order + 1);
@@ -797,7 +840,8 @@ __global__ __launch_bounds__(NTK) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         return;
     }
 #endif
-    autocorr_in_place<R, NTK, F16, NFFT>(buf, nfft, twiddles + g.tw_off, (num_lags < nfft && !dump) ? num_lags : nfft);
+    if constexpr (FIRSTREG) fft_first_stage_regs<NFFT / 2>(buf, wreg, twiddles + g.tw_off);
+    autocorr_in_place<R, NTK, F16, NFFT, FIRSTREG>(buf, nfft, twiddles + g.tw_off, (num_lags < nfft && !dump) ? num_lags : nfft);
     if (dump) {
         double *dst = chain_pool + (it.chain_dump - 1u);
         for (uint32_t i = tid; i < nfft; i += NTK) { const cplx z = buf[cidx<F16>(i >> 1)]; dst[i] = (i & 1u) ? z.y : z.x; }
