@@ -11,18 +11,20 @@
  *                           symmetry pass fused -> inverse FFT pruned to the lags that are read -> lags.
  *   srla_pitch_solve        (LTP only) ONE LANE per item: the sequential pitch scan of lpc.c:1473-1555 (lags staged
  *                           in LDS) and the 3x3 Cholesky solve.
- *   srla_lpc_recursion(_regs)  ONE LANE per item: Levinson-Durbin with the gamma dot product summed in index
+ *   srla_lpc_errvars(_lean) / srla_lpc_recursion  ONE LANE per item: Levinson-Durbin with the gamma dot product summed in index
  *                           order (lpc.c:417-438) -- inherently serial per item, so 64 recursions run side by
  *                           side in a wavefront (coefficients in registers for the preset orders, LDS otherwise).
  *   srla_order_select       one wave per item, lane = order: code-length estimate and its first strict minimum.
  *   srla_lpc_quantize(_regs)   one lane per item: predictor of the chosen order, 8-bit quantiser, tap cost.
- *   srla_residual_cost<R>   one workgroup per item: pre-emphasis (+LTP), register-blocked int32 FIR on the 24-bit
- *                           multiplier, residual to HBM, partitioned (recursive) Rice code-length search.
+ *   srla_residual_cost<R>   one workgroup per item: pre-emphasis (+LTP), the wrap-around int32 FIR on packed int16 / int8
+ *                           planes (v_dot2_i32_i16 / v_dot4_i32_i8), residual to HBM (uint16 where it fits), partitioned
+ *                           (recursive) Rice code-length search.
  *   srla_price_windows      stereo decision + block sizes + shortest path, one wave per window.
  *   srla_block_offsets      byte offset of every chosen block, the job's place in the stream, per-window sizes.
  *   srla_pack_blocks        one workgroup per chosen block: the COMPLETE block (header, payload fields, Huffman
  *                           coded taps, Rice coded residuals, Fletcher-16) assembled in LDS.
- *   srla_stream_out         the job's finished bytes, device buffer -> host memory (one workgroup, PCIe paced).
+ *   srla_stream_out         the job's finished bytes, device buffer -> host memory (a few workgroups, PCIe paced) where the
+ *                           host does not copy them itself when it collects the job (host_pipeline.cpp, Impl::dma_out).
  *   srla_or_reduce          whole-stream OR for the offset left shift.
  *
  * No MFMA: integer/fp64 butterflies and reductions, not a dense contraction.  All fp64 arithmetic
