@@ -149,16 +149,70 @@ def cpu_baseline(pcm, cli, seconds, rate, bps=16):
             "bytes": int(out.size), "all_cores": all_cores}
 
 
-# stage of a job -> (Stats field with its HIP-event time, "timed jobs only"?, kernels of the stage as rocprofv3 names them)
+# stage of a job -> (Stats field with its HIP-event time or None, "timed jobs only"?, every kernel the library can launch in the
+# stage, as rocprofv3 names them).  Which of them a configuration really launches is read from the committed profile of the same
+# command (profiles/pmc_summary.json[config]): a stage is priced with the kernels that ran, never with a list kept by hand.
+# tests/test_bench_stages.py fails when a kernel of the library or of a committed profile belongs to no stage.
 STAGES = (
-    ("srla_autocorr",      "autocorr_ms", True,  ("srla_autocorr",), sum),
-    ("srla_pitch_solve",   "pitch_ms",    True,  ("srla_pitch_solve",), sum),
-    ("srla_lpc_solve",     "solve_ms",    True,  ("srla_lpc_solve_regs", "srla_lpc_recursion", "srla_order_select", "srla_lpc_quantize", "srla_svr_refine"), sum),
-    ("srla_residual_cost", "residual_ms", False, ("srla_residual_cost<", "srla_residual_cost_big"), max),   # one block-length class per job
-    ("srla_price_windows", "price_ms",    True,  ("srla_price_windows",), sum),
-    ("srla_pack_blocks",   "gather_ms",   True,  ("srla_block_offsets", "srla_pack_blocks", "srla_stream_out"), sum),
+    ("srla_stage_in",      None,          True,  ("srla_widen16", "srla_deinterleave", "srla_or_reduce", "srla_mask_to_shift", "srla_chain_commit",
+                                                  "__amd_rocclr_fillBuffer")),
+    ("srla_autocorr",      "autocorr_ms", True,  ("srla_autocorr<", "srla_autocorr_big", "srla_autocorr_w")),
+    ("srla_pitch_solve",   "pitch_ms",    True,  ("srla_pitch_solve",)),
+    ("srla_lpc_solve",     "solve_ms",    True,  ("srla_lpc_errvars", "srla_order_select", "srla_lpc_taps", "srla_lpc_solve_regs", "srla_lpc_recursion",
+                                                  "srla_lpc_quantize", "srla_svr_refine")),
+    ("srla_residual_cost", "residual_ms", False, ("srla_residual_cost<", "srla_residual_cost_big")),
+    ("srla_price_windows", "price_ms",    True,  ("srla_price_windows",)),
+    # block offsets + assembly + the way out: srla_stream_out where the device stores into the caller's buffer, the runtime's
+    # copy kernel where the host issues the copies (it also carries the uploads of pageable input: they are the same dispatches
+    # to the profiler)
+    ("srla_pack_blocks",   "gather_ms",   True,  ("srla_block_offsets", "srla_pack_blocks", "srla_stream_out", "__amd_rocclr_copyBuffer")),
 )
-PMC_JOB_INSTANTS = 4194304.0      # a full job of the PMC command (tools/collect_profiles_r03.sh: two jobs of 4 Mi sample instants)
+
+
+def kernel_stage(name):
+    """stage of a kernel as rocprofv3 names it (None: unknown to this table)"""
+    bare = name.split("(")[0].replace("void ", "")
+    if bare == "srla_residual_cost":              # (alias entry of older summaries)
+        return "srla_residual_cost"
+    for stage, _, _, prefixes in STAGES:
+        if any(bare.startswith(p) for p in prefixes):
+            return stage
+    return None
+
+
+def committed_profile(config):
+    """(pmc summary entry of the config, path of the committed kernel_stats.csv of the same command or None): newest round first"""
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_summary.json"))).get(config, {})
+    except Exception:
+        pmc = {}
+    stats = None
+    for rnd in sorted((d for d in os.listdir(os.path.join(ROOT, "profiles")) if d.startswith("r") and d[1:].isdigit()), reverse=True):
+        cand = os.path.join(ROOT, "profiles", rnd, config, "kernel_stats.csv")
+        if os.path.exists(cand):
+            stats = cand
+            break
+    return pmc, stats
+
+
+def dominant_kernel(stats_csv, algo_bytes_per_job, peak):
+    """the single kernel with the largest total time in the committed rocprofv3 --kernel-trace --stats summary of this command,
+    priced like a stage: algorithmic bytes of one job / its average duration (what the review recomputes by hand)"""
+    import csv
+    try:
+        rows = list(csv.DictReader(open(stats_csv)))
+    except Exception:
+        return None
+    rows = [r for r in rows if kernel_stage(r["Name"]) is not None]
+    if not rows:
+        return None
+    r = max(rows, key=lambda r: float(r["TotalDurationNs"]))
+    avg_ms = float(r["AverageNs"]) / 1e6
+    gbs = algo_bytes_per_job / (avg_ms * 1e-3) / 1e9
+    return {"name": r["Name"].split("(")[0].replace("void ", ""), "stage": kernel_stage(r["Name"]), "calls": int(r["Calls"]),
+            "avg_launch_ms": round(avg_ms, 4), "share_of_kernel_time": round(float(r["Percentage"]) / 100.0, 4),
+            "achieved": round(gbs, 2), "frac": round(gbs / peak, 6),
+            "source": os.path.relpath(stats_csv, ROOT) + " (average over full and tail jobs of that run)"}
 
 
 def roofline_object(st, config, launches, instants_per_launch, algo_bytes, end_to_end_gbs, peak=8000.0):
@@ -166,43 +220,54 @@ def roofline_object(st, config, launches, instants_per_launch, algo_bytes, end_t
     stereo sample instant x the instants one job (= one launch of every analysis kernel) covers, over the stage's average
     duration per job measured with HIP events attached to the dispatches inside the timed region (srla_residual_cost on every
     job, the other stages on one job in four: each start event costs stream time).  `kernel` is the stage with the LONGEST
-    measured duration per job; counters (HBM traffic, VALU / LDS utilisation) come from the committed rocprofv3 PMC passes
-    (profiles/pmc_summary.json), summed over the kernels of the stage and scaled to this run's instants per launch."""
+    measured duration per job among ALL stages; `dominant_kernel` the single kernel with the largest total time in the committed
+    rocprofv3 summary of the same command.  Counters (HBM traffic, VALU / LDS utilisation) come from the committed rocprofv3 PMC
+    passes (profiles/pmc_summary.json): the traffic of a stage is the HBM bytes of ALL dispatches of the stage's kernels that ran
+    in the PMC command, per sample instant of that command, times this run's instants per launch."""
     timed = max(1, st.timed_jobs)
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_summary.json"))).get(config, {})
-    except Exception:
-        pmc = {}
+    pmc, stats_csv = committed_profile(config)
+    pmc_instants = pmc.get("_pmc_instants") or 2.0 * 4194304.0
+    kernels_seen = {k: v for k, v in pmc.items() if not k.startswith("_") and isinstance(v, dict)}
     stages = {}
-    for name, field, timed_only, kernels, combine in STAGES:
-        ms = getattr(st, field) / (timed if timed_only else launches)
-        if ms <= 0:
+    for name, field, timed_only, _ in STAGES:
+        ents = [(k, v) for k, v in kernels_seen.items() if kernel_stage(k) == name and k != "srla_residual_cost"]
+        ms = (getattr(st, field) / (timed if timed_only else launches)) if field else 0.0
+        if ms <= 0 and not ents:
             continue
-        gbs = algo_bytes / (ms * 1e-3) / 1e9
-        e = {"ms_per_job": round(ms, 4), "achieved": round(gbs, 2), "frac": round(gbs / peak, 6), "traffic": None}
-        ents = [(k, v) for k, v in pmc.items() if any(k.startswith(p) for p in kernels)]
-        # one launch per FFT-size class / pack kernel and job: the stage's traffic is the sum over its kernels' full-job launches
-        # (srla_residual_cost: one block-length class per job, so the largest)
-        if ents and all("hbm_bytes_per_launch" in v for _, v in ents):
-            e["traffic"] = int(combine([v["hbm_bytes_per_launch"] for _, v in ents]) * instants_per_launch / PMC_JOB_INSTANTS)
+        e = {"ms_per_job": round(ms, 4) if ms > 0 else None, "achieved": None, "frac": None, "traffic": None}
+        if ms > 0:
+            gbs = algo_bytes / (ms * 1e-3) / 1e9
+            e.update(achieved=round(gbs, 2), frac=round(gbs / peak, 6))
+        if ents:
+            e["kernels"] = sorted(k for k, _ in ents)
+        if ents and all("hbm_bytes_total" in v for _, v in ents):
+            e["traffic"] = int(sum(v["hbm_bytes_total"] for _, v in ents) / pmc_instants * instants_per_launch)
+        elif ents and all("hbm_bytes_per_launch" in v for _, v in ents):
+            # (summaries of round 3 and before: the largest dispatch of every kernel = its full-job launch of 4 Mi instants)
+            per = [v["hbm_bytes_per_launch"] for _, v in ents]
+            e["traffic"] = int((max(per) if name == "srla_residual_cost" else sum(per)) * instants_per_launch / 4194304.0)
+        if e["traffic"] is not None:
             e["traffic_over_algorithmic"] = round(e["traffic"] / algo_bytes, 2)
         if ents:
-            big = max(ents, key=lambda kv: kv[1].get("avg_duration_us", 0.0))[1]
-            for key in ("valu_util", "lds_util", "lds_bank_conflict_frac", "wait_frac", "fp64_inst_frac"):
+            big = max(ents, key=lambda kv: kv[1].get("full_job_duration_us", kv[1].get("avg_duration_us", 0.0)))[1]
+            for key in ("valu_util", "lds_util", "lds_bank_conflict_frac", "wait_frac", "waves_per_simd", "fp64_inst_frac"):
                 if big.get(key) is not None:
                     e[key] = big[key]
         stages[name] = e
-    analysis = [k for k in ("srla_autocorr", "srla_pitch_solve", "srla_lpc_solve", "srla_residual_cost") if k in stages]
-    dominant = max(analysis, key=lambda k: stages[k]["ms_per_job"]) if analysis else None
-    d = stages.get(dominant, {"ms_per_job": 0.0, "achieved": 0.0, "frac": 0.0, "traffic": None})
+    measured = [k for k in stages if stages[k]["ms_per_job"]]
+    longest = max(measured, key=lambda k: stages[k]["ms_per_job"]) if measured else None
+    d = stages.get(longest, {"ms_per_job": 0.0, "achieved": 0.0, "frac": 0.0, "traffic": None})
+    all_traffic = [e["traffic"] for e in stages.values() if e.get("traffic") is not None]
     roof = {"bound": "hbm", "achieved": d["achieved"], "peak": peak, "unit": "GB/s", "frac": d["frac"], "traffic": d["traffic"],
-            "kernel": dominant, "avg_launch_ms": d["ms_per_job"],
+            "kernel": longest, "avg_launch_ms": d["ms_per_job"],
+            "dominant_kernel": dominant_kernel(stats_csv, algo_bytes, peak) if stats_csv else None,
             "launches": int(st.analyze_launches), "algorithmic_bytes_per_launch": int(algo_bytes),
             "items_per_launch": int(st.num_items / launches),
             "stages": stages,
+            "traffic_all_stages": int(sum(all_traffic)) if all_traffic else None,
             # the whole path against the same contract: algorithmic bytes of everything one rank encoded / its wall time
             "end_to_end": {"achieved": round(end_to_end_gbs, 2), "frac": round(end_to_end_gbs / peak, 6)},
-            "pmc_source": "profiles/pmc_summary.json[%s] (rocprofv3 --pmc, separate passes)" % config if pmc else None}
+            "pmc_source": pmc.get("_source", "profiles/pmc_summary.json[%s] (rocprofv3 --pmc, separate passes)" % config) if pmc else None}
     for key in ("valu_util", "fp64_inst_frac"):
         if key in d:
             roof[key] = d[key]
@@ -212,9 +277,12 @@ def roofline_object(st, config, launches, instants_per_launch, algo_bytes, end_t
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=None, help="ranks (one GPU each); default: WORLD_SIZE of the launcher, else 1")
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="M", choices=sorted(CONFIGS), help="M: the metric configuration; C1..C5: BASELINE.json's configs")
+    ap.add_argument("--calls-per-step", type=int, default=0,
+                    help="encode calls per step, back to back (default: as many as make a step about 0.1 s of device work -- 24 x 600 s "
+                         "at the metric configuration --, so that 20 steps keep the GPU busy for 2 s and an outside sampler sees it)")
     ap.add_argument("--seconds", type=float, default=None, help="audio per stream (default: the configuration's)")
     ap.add_argument("--files", type=int, default=None, help="streams per GPU per step (> 1: one SRLAMI355X_EncodeBatch call per step)")
     ap.add_argument("--cpu-seconds", type=float, default=0.0,
@@ -281,6 +349,9 @@ def main(argv=None):
     files = args.files if args.files is not None else conf.get("files", 1)
     n = int(seconds * rate)
     n -= n % 2
+    # a step of about 0.1 s: calls of the same unchanged API, back to back (nominal pace of the configurations on one MI355X)
+    nominal = {"M": 6400.0, "C1": 300.0, "C2": 7000.0, "C3": 2300.0, "C4": 1300.0, "C5": 1800.0}[args.config]
+    calls = args.calls_per_step or max(1, int(round(0.1 * nominal * 1e6 / max(1.0, float(n) * files))))
     metric = "encode Msamples/s (-m %d -B %d -V %d -P %d, %s %g kHz %d-bit)" % (
         cli["preset"], cli["max_block"], cli["divisions"], cli["ltp_order"], "stereo" if nch == 2 else "%d ch" % nch, rate / 1000.0, bps)
 
@@ -368,17 +439,21 @@ def main(argv=None):
     planes = [capi.planar_ptrs(p) for p in pcms]
 
     if files == 1:
-        def step():
+        def call():
             rc = L.SRLAEncoder_EncodeWhole(enc, planes[0], n, outs[0].ctypes.data_as(C.c_void_p), cap, C.cast(out_sizes, C.POINTER(C.c_uint32)), None)
             if rc != capi.OK:
                 raise SystemExit("SRLAEncoder_EncodeWhole -> %d" % rc)
     else:
         batch = capi.BatchCall(lib, pcms, outs)
 
-        def step():
+        def call():
             rc = batch.run(enc, out_sizes)
             if rc != capi.OK:
                 raise SystemExit("SRLAMI355X_EncodeBatch -> %d" % rc)
+
+    def step():
+        for _ in range(calls):
+            call()
 
     for _ in range(args.warmup):
         step()
@@ -418,11 +493,11 @@ def main(argv=None):
     if rank == 0:
         # sanity inside the bench: the streams decode back to the input (oracle decoder = checker only)
         lossless = all(bool((helpers.oracle_decode(streams[f]) == pcms[f]).all()) for f in range(files))
-        total_instants = float(n) * files * args.steps * world
+        total_instants = float(n) * files * calls * args.steps * world
         value = total_instants / elapsed / 1e6
         launches = max(1, st.analyze_launches)          # one launch of srla_residual_cost per job
         timed = max(1, st.timed_jobs)
-        instants_per_launch = float(n) * files * args.steps / launches
+        instants_per_launch = float(n) * files * calls * args.steps / launches
         algo_bytes = 8.0 * nch * instants_per_launch            # 8 B per channel-sample
         roof = roofline_object(st, args.config, launches, instants_per_launch, algo_bytes,
                                8.0 * nch * total_instants / world / elapsed / 1e9)
@@ -430,12 +505,14 @@ def main(argv=None):
         line = dict(base_line)
         line.update({
             "value": round(value, 3), "ms_per_step": round(1e3 * elapsed / args.steps, 3),
-            "config": {"workload": "%s: srla -e -m %d -B %d -V %d -L 4 -P %d; %d x %.0f s synthetic %d-ch %g kHz/%d-bit (%s) per GPU per step; "
+            "config": {"workload": "%s: srla -e -m %d -B %d -V %d -L 4 -P %d; %d x %.0f s synthetic %d-ch %g kHz/%d-bit (%s) per call, "
+                                   "%d call(s) back to back per GPU per step; "
                                    "%s: planar int32 in %s host memory -> complete .srl stream(s) in %s host memory" %
                                    (args.config, cli["preset"], cli["max_block"], cli["divisions"], cli["ltp_order"], files, n / rate, nch,
-                                    rate / 1000.0, bps, conf["kind"], "SRLAEncoder_EncodeWhole" if files == 1 else "SRLAMI355X_EncodeBatch",
+                                    rate / 1000.0, bps, conf["kind"], calls, "SRLAEncoder_EncodeWhole" if files == 1 else "SRLAMI355X_EncodeBatch",
                                     "pinned" if args.pinned_io else "pageable", "pinned" if args.pinned_io else "pageable"),
-                       "samples_per_channel_per_step": n * files, "streams_per_step": files,
+                       "samples_per_channel_per_step": n * files * calls, "samples_per_channel_per_call": n * files,
+                       "calls_per_step": calls, "streams_per_step": files * calls,
                        "parallelism": "windows / files sharded per GPU, no collective"},
             "compression_ratio": round(total_out / float(sum(p.size for p in pcms) * (bps // 8)), 6),
             "lossless_roundtrip": lossless,

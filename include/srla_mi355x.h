@@ -259,6 +259,19 @@ SRLAApiResult SRLAMI355X_ProbeBlock(
 /* Library identification string ("srla-mi355x <version> gfx950 ..."). */
 const char *SRLAMI355X_Version(void);
 
+/* ---- test hooks -------------------------------------------------------------------------------------------------------------
+ * The host-libm arbitration arithmetic of the library (srla_amd/csrc/host_ties.cpp) on its own: no handle, no device.  Not part
+ * of the drop-in surface; exported so that a CPU-only test can compare it bit for bit with the oracle on the oracle's inputs.
+ *   TestSelectOrder  srla_encoder.c:934-957 on error_vars[0..max_order] * compensation -> the chosen order
+ *   TestLtpTaps      lpc.c:1620-1645 + srla_encoder.c:1031-1047 from R(0), R(1), R(2), R(p-1), R(p), R(p+1) -> the three 6-bit
+ *                    taps packed 6 bits each in stream order, or 0xFFFFFFFF (singular)
+ *   TestSvrRefine    lpc.c:1036-1136 on the normalised block, predictor refined in place
+ *   TestLevinson     lpc.c:379-441 -> the predictor of `order` from ridge-regularised lags */
+uint32_t SRLAMI355X_TestSelectOrder(const double *error_vars, uint32_t max_order, double compensation, uint32_t num_samples, uint32_t bits_per_sample);
+uint32_t SRLAMI355X_TestLtpTaps(const double *lags6, uint32_t ltp_order);
+void SRLAMI355X_TestSvrRefine(const double *data, uint32_t num_samples, double *coef, uint32_t order, uint32_t max_iter);
+void SRLAMI355X_TestLevinson(const double *lags_ridged, uint32_t order, double *coef);
+
 #ifdef __cplusplus
 }
 #endif

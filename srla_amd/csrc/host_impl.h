@@ -353,7 +353,9 @@ struct Impl {
     /* the reference's calls for the candidates of `job`, appended in its order; silent(off, n): the block is all zero */
     void chain_append(uint32_t jobidx, const Job &job, const std::function<bool(uint32_t, uint32_t)> &silent);
     void chain_build(uint32_t jobidx, Job &job, ChainJob &cj);
-    bool chain_svr() const { return par.num_svr_filter_learning_iteration > 0; }   /* the refinement writes the reference's buffer too */
+    /* the refinement writes the reference's buffer too -- where it runs at all: with preset 0 the chosen order is 0 and
+     * srla_encoder.c:1084 never calls it, so there is no such writer in the sequence of calls */
+    bool chain_svr() const { return par.num_svr_filter_learning_iteration > 0 && preset_order() > 0; }
     bool chain_stage_a(Slot &s, uint32_t jobidx, const ChainJob &cj);   /* stage A of a chain job: the autocorrelation launches round by round */
     /* The last window [tail_start, tail_start + tail_n) of a stream in chain mode, in three steps so that it overlaps
      * the regular jobs: chain_begin (seed + search job; needs nothing from the jobs before unless the seed does),

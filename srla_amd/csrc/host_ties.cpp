@@ -201,6 +201,28 @@ void levinson(const double *r, uint32_t order, std::vector<double> &coef)
 
 }  // namespace
 
+/* Test hooks (include/srla_mi355x.h, "test hooks"): the arbitration arithmetic above on its own, no device involved, so that a
+ * CPU-only test can feed it the oracle's inputs and compare bit for bit (tests/test_host_ties.py). */
+extern "C" {
+uint32_t SRLAMI355X_TestSelectOrder(const double *error_vars, uint32_t max_order, double compensation, uint32_t num_samples, uint32_t bits_per_sample)
+{
+    return select_order(error_vars, max_order, compensation, num_samples, bits_per_sample);
+}
+uint32_t SRLAMI355X_TestLtpTaps(const double *lags6, uint32_t ltp_order) { return ltp_taps(lags6, ltp_order); }
+void SRLAMI355X_TestSvrRefine(const double *data, uint32_t num_samples, double *coef, uint32_t order, uint32_t max_iter)
+{
+    std::vector<double> d(data, data + num_samples), c(coef, coef + order);
+    svr_refine(d, c, max_iter);
+    std::copy(c.begin(), c.end(), coef);
+}
+void SRLAMI355X_TestLevinson(const double *lags_ridged, uint32_t order, double *coef)
+{
+    std::vector<double> c;
+    levinson(lags_ridged, order, c);
+    std::copy(c.begin(), c.end(), coef);
+}
+}
+
 bool Impl::apply_overrides(Job &job, uint32_t jobkey)
 {
     if (overrides.empty()) return false;

@@ -1,0 +1,65 @@
+"""bench.py's roofline book-keeping: every kernel the library can launch, and every kernel a committed profile saw, belongs to a
+stage of bench.STAGES -- a stage is priced with what ran (profiles/pmc_summary.json), never with a list that went stale."""
+import csv
+import glob
+import json
+import os
+import re
+
+import bench
+import helpers
+
+
+def _library_kernels():
+    names = set()
+    for src in ("kernels.hip", "autocorr_wave.hip"):
+        text = open(os.path.join(helpers.ROOT, "srla_amd", "csrc", src)).read()
+        for m in re.finditer(r"__global__[^;{]*?\b(srla_[a-z0-9_]+)\s*\(", text, re.S):
+            names.add(m.group(1))
+    return names
+
+
+def test_every_kernel_of_the_library_has_a_stage():
+    kernels = _library_kernels()
+    assert len(kernels) >= 20 and "srla_residual_cost" in kernels and "srla_lpc_errvars_lean" in kernels
+    for k in sorted(kernels):
+        # templates appear as name<...> to the profiler
+        assert bench.kernel_stage(k) or bench.kernel_stage(k + "<1>"), "kernel %s belongs to no stage of bench.STAGES" % k
+
+
+def test_every_kernel_of_the_committed_profiles_has_a_stage():
+    pmc = json.load(open(os.path.join(helpers.ROOT, "profiles", "pmc_summary.json")))
+    seen = 0
+    for cfg, entry in pmc.items():
+        for k in entry:
+            if k.startswith("_"):
+                continue
+            seen += 1
+            assert bench.kernel_stage(k), "profiles/pmc_summary.json[%s]: kernel %s belongs to no stage" % (cfg, k)
+    for path in glob.glob(os.path.join(helpers.ROOT, "profiles", "r0[3-9]", "*", "kernel_stats.csv")):
+        for r in csv.DictReader(open(path)):
+            seen += 1
+            assert bench.kernel_stage(r["Name"]), "%s: kernel %s belongs to no stage" % (path, r["Name"])
+    assert seen > 50
+
+
+def test_no_kernel_belongs_to_two_stages():
+    for k in sorted(_library_kernels()) + ["__amd_rocclr_copyBuffer", "__amd_rocclr_fillBufferAligned"]:
+        hits = [s for s, _, _, prefixes in bench.STAGES if any(k.startswith(p) or (k + "<").startswith(p) for p in prefixes)]
+        assert len(hits) == 1, (k, hits)
+
+
+def test_the_solve_stage_is_priced_with_the_kernels_that_ran():
+    """the default chain is srla_lpc_errvars(_lean) + srla_order_select + srla_lpc_taps"""
+    class St:                                           # the fields roofline_object reads
+        timed_jobs = 4; analyze_launches = 8; num_items = 8 * 15360
+        autocorr_ms = 0.8; pitch_ms = 0.0; solve_ms = 0.4; residual_ms = 1.6; price_ms = 0.04; gather_ms = 1.0
+    roof = bench.roofline_object(St, "M", 8, 3.6e6, 16.0 * 3.6e6, 100.0)
+    solve = roof["stages"]["srla_lpc_solve"]
+    assert any(k.startswith("srla_lpc_errvars") for k in solve["kernels"]) and any(k.startswith("srla_lpc_taps") for k in solve["kernels"])
+    assert not any(k.startswith("srla_lpc_solve_regs") for k in solve["kernels"])
+    assert solve["traffic_over_algorithmic"] > 0.4
+    # the longest stage of ALL stages names the line; the single dominant kernel of the committed profile stands beside it
+    assert roof["kernel"] == "srla_pack_blocks"
+    assert roof["dominant_kernel"]["name"].startswith("srla_")
+    assert roof["dominant_kernel"]["stage"] in roof["stages"]

@@ -49,6 +49,20 @@ def cases(count, seed, max_samples=6_000_000):
         lookahead_factor = rnd.choice([1, 2, 4, 8, 16]) if divisions else 4
         if (max_block * lookahead_factor) // min_block + 1 > 129:
             continue
+        # explicit (minimum, maximum, look-ahead) triples in one case out of four (a generator of its own: the other cases stay
+        # what they were): what the API accepts beyond the tool's max >> V and L x max (srla_encoder.c:727-741) -- maximum /
+        # minimum not a power of two, look-ahead = k x minimum with k not a multiple of maximum / minimum
+        rnd4 = random.Random(seed * 15485863 + case)
+        triple = None
+        if rnd4.random() < 0.25:
+            tmin = rnd4.choice([64, 125, 128, 192, 256, 300, 333, 384, 500, 512, 640, 1000, 1024, 1536, 2048, 4096])
+            ratio = rnd4.choice([1, 2, 3, 3, 4, 5, 6, 7, 8])
+            k = rnd4.randint(ratio, min(128, max(ratio + 1, 4 * ratio)))
+            if ratio > 1 and k % ratio == 0 and rnd4.random() < 0.8:
+                k += 1
+            if tmin * ratio <= 32768 and k <= 128 and order <= tmin and not (ltp and tmin * ratio <= 256):
+                triple = (tmin, tmin * ratio, tmin * k)
+                min_block, max_block = triple[0], triple[1]
         # length: whole min blocks plus any tail
         nblocks = rnd.randint(0, max(2, min(600000 // min_block, 3 * (2 << 20) // min_block // 4)))
         tail = rnd.choice([0, rnd.randint(1, min_block - 1), rnd.randint(1, min_block - 1)])
@@ -59,6 +73,8 @@ def cases(count, seed, max_samples=6_000_000):
             continue
         kind = rnd.choice([helpers.MUSIC, helpers.VARIED, helpers.VARIED, helpers.NOISE, helpers.SINE])
         cli = dict(preset=preset, max_block=max_block, divisions=divisions, ltp_order=ltp, lookahead_factor=lookahead_factor)
+        if triple:
+            cli = dict(preset=preset, max_block=triple[1], min_block=triple[0], lookahead=triple[2], ltp_order=ltp)
         shifted = rnd.random() < 0.15
         # SVR refinement in one case out of eight (a generator of its own: the other cases stay what they were), any length and
         # any regime (its residual is a writer of the reference's buffer in chain / history mode); short streams:
