@@ -155,6 +155,11 @@ SRLAApiResult SRLAMI355X_EncodeWholeDevice(
  * (SRLAEncoder_EncodeHeader) -- srla_amd/multigpu.py does exactly that with one rank per GPU.  input points at the
  * first sample of the range.  is_stream_end: the range ends the stream (only then may it hold a partial window; give it
  * the stream's last two windows at least, the reference's analysis of an odd-length last window looks back one block). */
+/* The OR of every sample of `input` (planar, the handle's channel count, num_samples per channel), computed by the handle's
+ * host threads: what a rank contributes to the stream's offset left shift before SRLAMI355X_EncodeWindows (the shift is the
+ * number of trailing zeros of the OR over ALL ranks' ranges, srla_utility.c:177-203). */
+SRLAApiResult SRLAMI355X_OrMask(struct SRLAEncoder *encoder, const int32_t *const *input, uint32_t num_samples, uint32_t *mask);
+
 SRLAApiResult SRLAMI355X_EncodeWindows(
     struct SRLAEncoder *encoder, const int32_t *const *input, uint32_t num_samples, uint32_t offset_lshift, int is_stream_end,
     uint8_t *data, uint32_t data_size, uint32_t *output_size);

@@ -466,7 +466,10 @@ int main(int argc, char **argv)
         std::vector<SRLAApiResult> res(ns, SRLA_APIRESULT_NG);
         for (uint32_t i = 0; i < ns; i++) {
             outs[i].reset(new Encoded());
-            outs[i]->cap = (size_t)files[i]->file_size + (size_t)files[i]->file_size / 32 + 65536;
+            /* the true bound: stream header + an 11-byte header per block (a RAW block carries its samples as they are,
+             * srla_encoder.c:823-852) + the PCM itself; the reference's tool allocates twice the file (srla_codec.c:125-129) */
+            const uint64_t min_block = std::max<uint32_t>(1u, o.max_block >> o.divisions);
+            outs[i]->cap = (size_t)((uint64_t)files[i]->file_size + ((uint64_t)files[i]->n / min_block + 2u) * 16u + 65536u);
             outs[i]->data = static_cast<uint8_t *>(g_pinned.take(outs[i]->cap, &outs[i]->pool_cap));
             if (outs[i]->data == nullptr) outs[i]->cap = 0;                    /* out of pinned memory: the call refuses the batch */
             inputs[i] = files[i]->planes.data(); nsmp[i] = files[i]->n; ors[i] = files[i]->sample_or;

@@ -201,6 +201,9 @@ typedef struct SrlaJobParams {
                                * stored and srla_pack_blocks recomputes the chosen blocks' (blocks > 8192 samples always keep) */
     uint32_t crowded;         /* the job runs beside other jobs' wide kernels (a call of several jobs): kernels that only fit an
                                * empty SIMD take their lean form whatever the job's size (srla_lpc_errvars_lean) */
+    uint32_t rc_lo, rc_hi;    /* srla_residual_cost: when rc_hi != 0 the launch takes the items with rc_lo < n <= rc_hi only (a job with blocks
+                               * above 4096 samples is analysed by two launches: the register budget of the 8192-sample form, two
+                               * wavefronts per SIMD, would otherwise be every item's) */
     uint32_t out_stride;      /* SRLA_DIAG_STOP builds only: where srla_residual_cost stops (kernel timing experiments) */
     const uint32_t *lshift_dev; /* when non-null the offset left shift is read from here (device memory) instead of the
                                * item's: lets a whole device-resident stream be enqueued before its OR-reduction has finished */

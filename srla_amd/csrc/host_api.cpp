@@ -5,6 +5,7 @@
 #include "host_impl.h"
 
 #include <algorithm>
+#include <atomic>
 #include <stdlib.h>
 #include <string.h>
 
@@ -143,6 +144,23 @@ uint32_t SRLAMI355X_NonIdenticalReasons(struct SRLAEncoder *encoder, uint32_t nu
 {
     Impl *im = impl_of(encoder);
     return (im && im->set_parameter) ? im->nonidentical_reasons(num_samples) : 0u;
+}
+
+/* OR of every sample of planar host input: the one whole-stream quantity (srla_utility.c:177-203), by the handle's pool threads */
+SRLAApiResult SRLAMI355X_OrMask(struct SRLAEncoder *encoder, const int32_t *const *input, uint32_t num_samples, uint32_t *mask)
+{
+    Impl *im = impl_of(encoder);
+    if (im == nullptr || input == NULL || mask == NULL) return SRLA_APIRESULT_INVALID_ARGUMENT;
+    if (!im->set_parameter) return SRLA_APIRESULT_PARAMETER_NOT_SET;
+    if (!im->init_device()) return SRLA_APIRESULT_NG;
+    const uint32_t nch = im->par.num_channels, chunk = 1u << 20, per_ch = (num_samples + chunk - 1) / chunk;
+    std::atomic<uint32_t> acc{ 0 };
+    im->pool->parallel_for(per_ch * nch, [&](uint32_t i) {
+        const uint32_t ch = i / per_ch, o = (i % per_ch) * chunk, len = std::min(chunk, num_samples - o);
+        acc.fetch_or(srla::or_reduce(input[ch] + o, len), std::memory_order_relaxed);
+    });
+    *mask = acc.load();
+    return SRLA_APIRESULT_OK;
 }
 
 /* one stream of host samples through encode_streams */

@@ -64,6 +64,10 @@ struct Group {
     uint32_t nfft, first, count;
     int rclass;
     SrlaLdsPlan plan;
+    /* rclass 4 (blocks above 4096 samples in the job): srla_residual_cost in two launches -- the items of at most 4096 samples with
+     * the 92-register form (plan_small), the others with the 8192-sample form (plan) */
+    bool split = false;
+    SrlaLdsPlan plan_small;
 };
 
 /* samples [s0, s0 + ns) of stream `stream` of the call, standing at sample `base` of the job's input planes */
@@ -183,6 +187,7 @@ struct Impl {
      * 0 / 1: never / always (SRLA_MI355X_PIN_INPLACE) */
     int pin_inplace = -1;
     bool pin_too_slow = false;          /* registration measured slower than staging would be (no huge pages): not tried again */
+    bool split_residual_cost = true;    /* SRLA_MI355X_SPLIT_RC=0: one srla_residual_cost launch per job whatever its block sizes (as before round 4) */
     bool wave_fft = false;              /* SRLA_MI355X_WAVE_FFT=1: 1024- to 8192-point items on srla_autocorr_w (register-resident transform, autocorr_wave.hip)
                                          * instead of srla_autocorr: bit-identical, measured slower -- an option, not the default */
     uint32_t run_ahead = 8;             /* SRLA_MI355X_RUN_AHEAD: jobs the host may be ahead of the stage skew (bounded by the buffer sets) */

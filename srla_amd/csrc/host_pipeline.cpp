@@ -35,7 +35,7 @@ Impl::~Impl()
             for (auto &e : s.t0) if (e) (void)hipEventDestroy(e);
             for (auto &e : s.t1) if (e) (void)hipEventDestroy(e);
             if (s.ev_in) (void)hipEventDestroy(s.ev_in);
-            for (hipEvent_t e : { s.ev_a1, s.ev_p0, s.ev_p, s.ev_a0, s.ev_pk }) if (e) (void)hipEventDestroy(e);
+            for (hipEvent_t e : { s.ev_a1, s.ev_p0, s.ev_p, s.ev_a0, s.ev_pk, s.ev_dma }) if (e) (void)hipEventDestroy(e);
             s.d_input16.release(); s.d_pcm.release();
             DevBuf *db[] = { &s.d_input, &s.d_items, &s.d_cands, &s.d_windows, &s.d_results, &s.d_res_ws,
                              &s.d_blocks, &s.d_block_off, &s.d_scratch, &s.d_dbg, &s.d_lags, &s.d_err, &s.d_gamma, &s.d_class_index, &s.d_stream,
@@ -485,6 +485,18 @@ bool Impl::run_stage(Slot &s, int st, int part)
             const Group &g = job.groups[0];
             /* the roofline kernel: start event on every job */
             const bool big = !job.big_items.empty();
+            if (g.split) {
+                /* the large items first: they are what the launch waits for, the small ones fill in behind them */
+                SrlaJobParams jl = jp, js = jp;
+                jl.rc_lo = 4096u; jl.rc_hi = 8192u;
+                js.rc_lo = 0u; js.rc_hi = 4096u;
+                rc |= srla_launch_residual_cost(W, 4, &jl, s.in_cur, s.d_items.as<SrlaItemDesc>(), d_geoms.as<SrlaGeom>(), &g.plan,
+                                                d_thr.as<double>(), s.d_res_ws.as<int32_t>(), s.d_results.as<SrlaItemResult>(),
+                                                timing ? s.t0[ST_C] : nullptr, nullptr);
+                rc |= srla_launch_residual_cost(W, 2, &js, s.in_cur, s.d_items.as<SrlaItemDesc>(), d_geoms.as<SrlaGeom>(), &g.plan_small,
+                                                d_thr.as<double>(), s.d_res_ws.as<int32_t>(), s.d_results.as<SrlaItemResult>(),
+                                                nullptr, big ? nullptr : s.t1[ST_C]);
+            } else
             rc |= srla_launch_residual_cost(W, g.rclass, &jp, s.in_cur, s.d_items.as<SrlaItemDesc>(), d_geoms.as<SrlaGeom>(), &g.plan,
                                             d_thr.as<double>(), s.d_res_ws.as<int32_t>(), s.d_results.as<SrlaItemResult>(),
                                             timing ? s.t0[ST_C] : nullptr, big ? nullptr : s.t1[ST_C]);
@@ -604,6 +616,12 @@ SRLAApiResult Impl::finish_job(Slot &s)
                 (info.error & SRLA_JOBERR_COVER) ? "a window's blocks do not cover it" : "");
         return SRLA_APIRESULT_NG;
     }
+    /* every way out once a copy has been enqueued: ev_dma marks the end of the copies, or the next job in this slot would wait
+     * on a stale (or never recorded) event instead of on them */
+    auto leave = [&](SRLAApiResult rc) {
+        if (s.dma_pending && hipEventRecord(s.ev_dma, dma_stream) != hipSuccess) { (void)hipGetLastError(); s.dma_pending = false; (void)hipStreamSynchronize(dma_stream); }
+        return rc;
+    };
     const SrlaSegInfo *si = s.seg_info();
     const uint32_t *wb = s.window_bytes();
     SRLAApiResult worst = SRLA_APIRESULT_OK;
@@ -613,12 +631,12 @@ SRLAApiResult Impl::finish_job(Slot &s)
         if (si[k].skip) { st.rc = SRLA_APIRESULT_INSUFFICIENT_BUFFER; worst = st.rc; continue; }
         if (si[k].pos != st.write_off) {
             fprintf(stderr, "[srla-mi355x] internal error: stream %u continues at %u, the host expected %u\n", sp.stream, si[k].pos, st.write_off);
-            return SRLA_APIRESULT_NG;
+            return leave(SRLA_APIRESULT_NG);
         }
         if (s.use_dma && si[k].bytes != 0) {
             /* (the segment stands in the job's staging buffer at stage_off, srla_block_offsets) */
             if (hipMemcpyAsync(st.data + si[k].pos, s.d_stream.as<uint8_t>() + si[k].stage_off, si[k].bytes, hipMemcpyDefault, dma_stream) != hipSuccess)
-                return SRLA_APIRESULT_NG;
+                return leave(SRLA_APIRESULT_NG);
             dma_used = true; s.dma_pending = true;
         }
         if (!st.out_direct && st.data != nullptr) {
@@ -645,7 +663,7 @@ SRLAApiResult Impl::finish_job(Slot &s)
         st.write_off += si[k].bytes;
         st.progress = progress;
     }
-    if (s.dma_pending && hipEventRecord(s.ev_dma, dma_stream) != hipSuccess) return SRLA_APIRESULT_NG;
+    if (s.dma_pending && hipEventRecord(s.ev_dma, dma_stream) != hipSuccess) { s.dma_pending = false; (void)hipStreamSynchronize(dma_stream); return SRLA_APIRESULT_NG; }
     stats.num_blocks += info.num_blocks; stats.num_raw_blocks += info.num_raw; stats.num_silent_blocks += info.num_silent;
     stats.num_tie_items += info.num_tie_items; stats.num_odd_items += info.num_odd_items;
     stats.pack_ms += ms_since(t0);

@@ -184,6 +184,23 @@ void Impl::build_job(Job &job, const JobPlan &plan, const std::vector<uint32_t> 
                 fast_bytes = std::max(fast_bytes, srla_kernel_fast_lds_bytes(fl, par.ltp_order, par.bits_per_sample));
             }
             if (all_fast) g.plan.total = fast_bytes;
+            /* a job with blocks above 4096 samples: the smaller items in a launch of their own (srla_residual_cost<2>: 92 registers, five
+             * wavefronts per SIMD, against 228 and two for the 8192-sample form), with their own LDS size */
+            bool any_small = false, any_large = false;
+            for (const SrlaItemDesc &it : job.items) { if (it.n <= 4096u) any_small = true; else if (it.n <= 8192u) any_large = true; }
+            g.split = split_residual_cost && g.rclass == 4 && any_small && any_large;
+            if (g.split) {
+                g.plan_small = lds_plan(4096u);
+                bool small_fast = true;
+                uint32_t small_bytes = 0;
+                for (const SrlaItemDesc &it : job.items) {
+                    if (it.n > 4096u) continue;
+                    const uint32_t fl = it.n >> 10;
+                    if ((it.n & 1023u) != 0 || fl < 1) { small_fast = false; break; }
+                    small_bytes = std::max(small_bytes, srla_kernel_fast_lds_bytes(fl, par.ltp_order, par.bits_per_sample));
+                }
+                if (small_fast) g.plan_small.total = small_bytes;
+            }
         }
         job.groups.push_back(g);
     }
@@ -273,7 +290,9 @@ void Impl::plan_jobs(std::vector<JobPlan> &plan, bool search)
          * upload and ends with a full job's chain of stages; in pieces like a short stream the device starts after one piece's
          * staging and the last chain is a piece's.  Measured: 120 s of stereo 3 300 -> 3 560 Msamples/s; with TWO whole jobs
          * (200 s) the pieces lose (4 500 -> 4 040: the host's staging of piece after piece sets the pace), hence 1. */
-        if (nfull > 0 && nfull <= mid_jobs && job_len >= 8 * (uint64_t)window_len) { nfull = 0; rest = body; }
+        /* (only where the pieces branch below takes the stream: otherwise it would fall through to ONE job of up to twice the
+         * planned job length, which the buffer and LDS planning do not assume) */
+        if (nfull > 0 && nfull <= mid_jobs && job_len >= 8 * (uint64_t)window_len && body >= 2 * (uint64_t)short_min) { nfull = 0; rest = body; }
         auto one = [&](uint32_t s0, uint32_t ns, uint32_t slot_index) {
             JobPlan jp; jp.segs.push_back({ 0u, s0, ns, 0u }); jp.total = al16(ns); jp.slot = slot_index; plan.push_back(jp);
         };

@@ -49,6 +49,7 @@ void Impl::read_environment()
     /* ---- measured alternatives kept as options -------------------------------------------------------- */
     keep_residuals_always = !is_set("SRLA_MI355X_RECOMPUTE_RESIDUALS");   /* set: no residual scratch, the pack kernel recomputes */
     res32 = is_set("SRLA_MI355X_RES32");                                  /* set: every residual kept as int32 (round 3's first form) */
+    if (is_set("SRLA_MI355X_SPLIT_RC")) split_residual_cost = number("SRLA_MI355X_SPLIT_RC", 1) != 0;
     if (is_set("SRLA_MI355X_WAVE_FFT")) wave_fft = number("SRLA_MI355X_WAVE_FFT", 1) != 0;   /* 1: srla_autocorr_w for 1024..8192-point items */
     split_ltp_stage = !is_set("SRLA_MI355X_NO_LTP_SKEW");                 /* set: the pitch solve back on stream W */
     if (is_set("SRLA_MI355X_DMA_OUT")) dma_out = number("SRLA_MI355X_DMA_OUT", 1) != 0;

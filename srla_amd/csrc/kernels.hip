@@ -2474,7 +2474,10 @@ __device__ __forceinline__ void rice_search_finish(const uint32_t *u, const Srla
 }
 
 template <int R>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(R >= 4 ? 2 : 5, 8))) void srla_residual_cost(
+#ifndef SRLA_RC4_WAVES
+#define SRLA_RC4_WAVES 3      /* wavefronts per SIMD the 8192-sample form is compiled for: 168 registers and 17 spilled dwords per lane; 2 (228 registers, no spills) was 9 % slower at -B 8192 -V 2 -P 3, profiles/r04/ab_residual_cost_split.txt */
+#endif
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(R >= 4 ? SRLA_RC4_WAVES : 5, 8))) void srla_residual_cost(
     SrlaJobParams jp, const int32_t *__restrict__ input, const SrlaItemDesc *__restrict__ items,
     const SrlaGeom *__restrict__ geoms, SrlaLdsPlan plan, const double *__restrict__ rice_thresholds,
     int32_t *__restrict__ res_ws, SrlaItemResult *__restrict__ results)
@@ -2487,6 +2490,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(R >= 4 ? 2 :
     if (block >= jp.num_items) return;
     const SrlaItemDesc itf = items[block];
     if (itf.n > 8192u) return;                       /* srla_residual_cost_big takes these */
+    if (jp.rc_hi != 0u && (itf.n <= jp.rc_lo || itf.n > jp.rc_hi)) return;   /* the other launch of the job takes these */
     const InputView iv = input_view(jp, itf.lshift);
     {
         /* blocks of 1024 * FL samples take the register / shuffle fast path */

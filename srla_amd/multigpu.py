@@ -70,7 +70,15 @@ def encode_stream_sharded(encode_range, pcm, header_fn, window_len, rank=0, worl
     n = pcm.shape[1]
     first, count = shard_ranges(n, window_len, world)[rank]
     mine = np.ascontiguousarray(pcm[:, first:first + count])
-    mask = int(np.bitwise_or.reduce(mine.astype(np.int64).ravel() & 0xFFFFFFFF)) if count else 0
+    # the range's OR: from the library where the encoder object offers it (SRLAMI355X_OrMask: the handle's host threads, no
+    # temporaries), else one pass over an unsigned view of the range
+    or_mask = getattr(getattr(encode_range, "__self__", None), "or_mask", None)
+    if not count:
+        mask = 0
+    elif or_mask is not None:
+        mask = or_mask(mine)
+    else:
+        mask = int(np.bitwise_or.reduce(mine.view(np.uint32), axis=None))
     if world > 1:
         import torch.distributed as dist
         group = host_group(group)
@@ -112,15 +120,30 @@ class WindowEncoder:
         same = self.par.min_num_samples_per_block == self.par.max_num_samples_per_block
         self.window_len = self.par.max_num_samples_per_block if same else self.par.num_lookahead_samples
         self.num_samples = 0
+        orfn = lib.lib.SRLAMI355X_OrMask
+        orfn.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_int32)), C.c_uint32, C.POINTER(C.c_uint32)]
+        orfn.restype = C.c_int
+        self.orfn = orfn
+        self.buf = np.zeros(0, dtype=np.uint8)          # one output buffer per encoder, grown on demand (np.empty: never zeroed again)
+
+    def or_mask(self, pcm):
+        m = C.c_uint32(0)
+        rc = self.orfn(self.enc, capi.planar_ptrs(pcm), pcm.shape[1], C.byref(m))
+        if rc != capi.OK:
+            raise RuntimeError("SRLAMI355X_OrMask -> %d" % rc)
+        return int(m.value)
 
     def encode_range(self, pcm, shift, is_end):
-        cap = 4 * pcm.size + 4096
-        buf = np.zeros(cap, dtype=np.uint8)
+        # bound of a range's blocks: the raw PCM + an 11-byte header per minimum block (RAW is the fallback, srla_encoder.c:1323-1327)
+        bps = self.par.bits_per_sample
+        cap = pcm.size * (bps // 8) + 16 * (pcm.shape[1] // max(1, self.par.min_num_samples_per_block) + 2) + 4096
+        if self.buf.size < cap:
+            self.buf = np.empty(cap, dtype=np.uint8)
         out = C.c_uint32(0)
-        rc = self.fn(self.enc, capi.planar_ptrs(pcm), pcm.shape[1], shift, 1 if is_end else 0, buf.ctypes.data_as(C.c_void_p), cap, C.byref(out))
+        rc = self.fn(self.enc, capi.planar_ptrs(pcm), pcm.shape[1], shift, 1 if is_end else 0, self.buf.ctypes.data_as(C.c_void_p), self.buf.size, C.byref(out))
         if rc != capi.OK:
             raise RuntimeError("SRLAMI355X_EncodeWindows -> %d" % rc)
-        return buf[:out.value].copy()
+        return self.buf[:out.value].copy()
 
     def header(self, shift, num_samples=None):
         """The 30 header bytes of a stream of `num_samples` samples per channel (default: self.num_samples)."""

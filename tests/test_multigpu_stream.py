@@ -85,7 +85,12 @@ def test_window_ranges_concatenate_to_the_whole_stream(product, cli, n, shift):
         try:
             parts = []
             ranges = multigpu.shard_ranges(n, we.window_len, world)
-            mask = int(np.bitwise_or.reduce(pcm.astype(np.int64).ravel() & 0xFFFFFFFF))
+            # every rank's share of the OR from the library (SRLAMI355X_OrMask), combined as the all-reduce would
+            mask = 0
+            for first, count in ranges:
+                if count:
+                    mask |= we.or_mask(np.ascontiguousarray(pcm[:, first:first + count]))
+            assert mask == int(np.bitwise_or.reduce(pcm.view(np.uint32), axis=None))
             s = multigpu.offset_lshift_of(mask)
             for first, count in ranges:
                 if count:
@@ -94,3 +99,25 @@ def test_window_ranges_concatenate_to_the_whole_stream(product, cli, n, shift):
             assert np.array_equal(got, want), (cli, n, shift, world)
         finally:
             we.close()
+
+
+@pytest.mark.gpu
+def test_sharded_encode_takes_the_or_from_the_library_and_reuses_its_buffer(product):
+    """encode_stream_sharded with a WindowEncoder (world 1 here; the 2-rank flow above): the range's OR comes from
+    SRLAMI355X_OrMask, the output buffer is allocated once per encoder"""
+    cli = dict(preset=4, max_block=4096, divisions=1)
+    pcm = helpers.synth(helpers.MUSIC, 89, 48000, 2, 9 * 16384 + 77)
+    pcm = np.ascontiguousarray((pcm >> 2) << 2)
+    we = multigpu.WindowEncoder(product, 2, 16, 48000, **cli)
+    try:
+        calls = []
+        orig = we.or_mask
+        we.or_mask = lambda a: calls.append(1) or orig(a)
+        got = multigpu.encode_stream_sharded(we.encode_range, pcm, we.header, we.window_len)
+        assert calls == [1]
+        assert np.array_equal(got, product.encode(pcm, **cli))
+        buf = we.buf
+        got2 = multigpu.encode_stream_sharded(we.encode_range, pcm, we.header, we.window_len)
+        assert we.buf is buf and np.array_equal(got2, got)
+    finally:
+        we.close()

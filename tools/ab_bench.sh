@@ -14,7 +14,7 @@ try:
     d = json.loads(line)
     st = d["roofline"]["stages"]
     print("%-3s %-28s value %8.1f resident %8s  stages(ms/job): %s  60s %s 10s %s" % (c, env, d["value"], d.get("device_resident", {}).get("value"),
-          " ".join("%s=%.3f" % (k.replace("srla_", ""), v["ms_per_job"]) for k, v in st.items()),
+          " ".join("%s=%.3f" % (k.replace("srla_", ""), v["ms_per_job"]) for k, v in st.items() if v.get("ms_per_job")),
           d.get("stream_60s", {}).get("value"), d.get("stream_10s", {}).get("value")), flush=True)
 except Exception as e:
     print(c, env, "FAILED", e, line[:300], flush=True)
