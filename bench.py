@@ -154,7 +154,7 @@ def cpu_baseline(pcm, cli, seconds, rate, bps=16):
 # command (profiles/pmc_summary.json[config]): a stage is priced with the kernels that ran, never with a list kept by hand.
 # tests/test_bench_stages.py fails when a kernel of the library or of a committed profile belongs to no stage.
 STAGES = (
-    ("srla_stage_in",      None,          True,  ("srla_widen16", "srla_deinterleave", "srla_or_reduce", "srla_mask_to_shift", "srla_chain_commit",
+    ("srla_stage_in",      None,          True,  ("srla_widen16", "srla_deinterleave", "srla_make_variants", "srla_or_reduce", "srla_mask_to_shift", "srla_chain_commit",
                                                   "__amd_rocclr_fillBuffer")),
     ("srla_autocorr",      "autocorr_ms", True,  ("srla_autocorr<", "srla_autocorr_big", "srla_autocorr_w")),
     ("srla_pitch_solve",   "pitch_ms",    True,  ("srla_pitch_solve",)),

@@ -133,6 +133,7 @@ bool Impl::chain_stage_a(Slot &s, uint32_t jobidx, const ChainJob &cj)
     /* many small dependent launches: on a stream of their own, so that the regular jobs' wide kernels do not queue
      * behind them */
     hipStream_t W = s.own_stream;
+    s.var_ready = false;                 /* (chain-mode launches read the channel planes) */
     const SrlaJobParams &jp = s.jp;
     if (!d_chain_list[jobidx].ensure(std::max<size_t>(1, cj.list.size()) * sizeof(SrlaAutocorrItem))) return false;
     if (!d_chain_select[jobidx].ensure(cj.select.size() * 4)) return false;

@@ -115,13 +115,16 @@ struct Slot {
     bool want_dbg = false;
     bool split_a = false;                /* stage A was enqueued in two parts (run_stage) */
     bool timed = false;                  /* this job records start events for every stage (one job in four) */
-    bool last_job = false;               /* the last job of the call's plan */
+    bool last_job = false;               /* one of the last jobs of the call's plan (Impl::dma_tail_jobs) */
     bool use_dma = false;                /* this job's bytes leave by a host-issued copy when it is collected (Impl::dma_out) */
     bool dma_pending = false;            /* ev_dma marks the end of the last copies out of this slot's staging buffer */
     hipEvent_t ev_dma = nullptr;
     uint32_t out_boost = 1;              /* stream-out workgroup multiplier (the last jobs of a stream drain faster) */
     DevBuf d_pcm;                        /* PCM input: the job's frames as uploaded, de-interleaved into d_input by srla_deinterleave */
     DevBuf d_input16;                    /* host input of at most 16 bits crosses PCIe as int16 and is widened into d_input */
+    DevBuf d_var16, d_var32, d_var_flag; /* the job's variant planes (srla_make_variants, SrlaJobParams::var16 / var32 / var_flag) */
+    hipEvent_t ev_var = nullptr;         /* ... are complete */
+    bool var_ready = false;              /* ... exist for the job in this slot (stage A of run_stage made them) */
     DevBuf d_input, d_items, d_cands, d_windows, d_results, d_res_ws, d_blocks, d_block_off, d_scratch, d_dbg, d_lags, d_err, d_gamma, d_class_index, d_stream;
     DevBuf d_segs, d_seg_ctl;            /* SrlaSegDesc per segment; device-side segment records of srla_block_offsets */
     DevBuf d_coef_ws;                    /* SVR refinement: 64 doubles per item, the predictor between solve and quantiser */
@@ -239,6 +242,13 @@ struct Impl {
     DevBuf d_svr_scratch;              /* srla_svr_refine_big (orders above 64, blocks above 8192 samples): kSvrGroups regions */
     static constexpr uint32_t kSvrGroups = 256;
     bool timing = true;               /* stage timing events (SRLA_MI355X_NO_TIMING drops them) */
+    bool variant_planes = false;        /* SRLA_MI355X_VARIANTS=0: srla_autocorr / srla_residual_cost combine and shift the channel planes themselves, item by item */
+    uint32_t pin_min_mb = 32;           /* SRLA_MI355X_PIN_MIN_MB: streams of fewer MB of samples are never page-locked in place (staging them costs less than the registration) */
+    bool pair_small_jobs = true;        /* SRLA_MI355X_PAIR=0: never merge a small job's 2048- and 4096-point autocorrelation launches */
+    uint32_t pair_max_items = 6144;     /* SRLA_MI355X_PAIR_MAX: ... jobs of at most this many items in the two classes */
+    bool spin_short_calls = true;       /* SRLA_MI355X_SPIN=0: never poll a job's last event, always sleep on it */
+    bool spin_collect = false;          /* this call: at most three jobs */
+    uint32_t dma_tail_jobs = 1;         /* SRLA_MI355X_DMA_TAIL: the call's last n jobs leave by srla_stream_out even where the others leave by host-issued copies */
     uint32_t tail_boost = 4, tail_boost_jobs = 3;   /* SRLA_MI355X_TAIL_BOOST="wgs,jobs" */
     uint32_t timing_stride = 4;       /* every n-th job carries start events on all stages (SRLA_MI355X_TIMING_STRIDE) */
     void read_environment();          /* host_tuning.cpp: the one place that reads the environment */

@@ -35,6 +35,8 @@ Impl::~Impl()
             for (auto &e : s.t0) if (e) (void)hipEventDestroy(e);
             for (auto &e : s.t1) if (e) (void)hipEventDestroy(e);
             if (s.ev_in) (void)hipEventDestroy(s.ev_in);
+            if (s.ev_var) (void)hipEventDestroy(s.ev_var);
+            s.d_var16.release(); s.d_var32.release(); s.d_var_flag.release();
             for (hipEvent_t e : { s.ev_a1, s.ev_p0, s.ev_p, s.ev_a0, s.ev_pk, s.ev_dma }) if (e) (void)hipEventDestroy(e);
             s.d_input16.release(); s.d_pcm.release();
             DevBuf *db[] = { &s.d_input, &s.d_items, &s.d_cands, &s.d_windows, &s.d_results, &s.d_res_ws,
@@ -106,6 +108,7 @@ bool Impl::init_device()
         for (auto &e : s.t0) HIP_OK(hipEventCreate(&e));
         for (auto &e : s.t1) HIP_OK(hipEventCreate(&e));
         HIP_OK(hipEventCreateWithFlags(&s.ev_in, hipEventDisableTiming));
+        HIP_OK(hipEventCreateWithFlags(&s.ev_var, hipEventDisableTiming));
         HIP_OK(hipEventCreate(&s.ev_a1)); HIP_OK(hipEventCreate(&s.ev_p0)); HIP_OK(hipEventCreate(&s.ev_p)); HIP_OK(hipEventCreate(&s.ev_a0));
         HIP_OK(hipEventCreateWithFlags(&s.ev_pk, hipEventDisableTiming));
         HIP_OK(hipEventCreateWithFlags(&s.ev_dma, hipEventDisableTiming));
@@ -211,7 +214,10 @@ bool Impl::stage_input(Slot &s, const JobPlan &plan)
     for (uint32_t k = 0; k < nseg; k++) seg_or[k].store(0);
     struct Task { uint32_t seg, ch, off, len; };
     std::vector<Task> tasks;
-    const uint32_t chunk = 256u << 10;
+    /* tasks of 256 Ki samples; a small job (a short stream, a piece of one) in smaller ones, so that every pool thread gets a few:
+     * a 10 s stereo stream was four tasks for eight threads (staging 0.1 ms of a 0.44 ms call) */
+    uint32_t chunk = 256u << 10;
+    while (chunk > (16u << 10) && (uint64_t)total * nch < (uint64_t)chunk * 3u * pool->size()) chunk >>= 1;
     auto list_tasks = [&](bool only_open) {
         tasks.clear();
         for (uint32_t k = 0; k < nseg; k++) {
@@ -416,6 +422,33 @@ bool Impl::run_stage(Slot &s, int st, int part)
         if (part != 2) {
             if (on_device) HIP_OK(hipStreamWaitEvent(W, ev_or, 0));
             if (s.used_h2d) HIP_OK(hipStreamWaitEvent(W, s.ev_in, 0));
+            s.var_ready = false;
+            if (variant_planes && have_items && !job.seg_lshift.empty() && job.seg_lshift.size() == job.segs.size()) {
+                /* the job's variant planes, once, on the upload stream (behind the job's own upload; beside the other jobs' wide
+                 * kernels): the items of srla_autocorr and srla_residual_cost then load one plane each */
+                const uint32_t nch = par.num_channels, nv = num_variants(), vstride = job.total;
+                const bool narrow = par.bits_per_sample <= 16;
+                const size_t planes16 = narrow ? (size_t)(nch >= 2 ? nch + 1 : nch) : 0, planes32 = narrow ? (nch >= 2 ? 1u : 0u) : nv;
+                if (!s.d_var16.ensure(std::max<size_t>(16, planes16 * vstride * 2)) || !s.d_var32.ensure(std::max<size_t>(16, planes32 * vstride * 4)) ||
+                    !s.d_var_flag.ensure(16)) return false;
+                if (on_device) HIP_OK(hipStreamWaitEvent(upload, ev_or, 0));
+                HIP_OK(hipMemsetAsync(s.d_var_flag.p, 0, 4, upload));
+                for (size_t g0 = 0; g0 < job.segs.size(); g0 += SRLA_VAR_SEGS) {
+                    SrlaVarSegs vs{};
+                    vs.count = (uint32_t)std::min<size_t>(SRLA_VAR_SEGS, job.segs.size() - g0);
+                    for (uint32_t g = 0; g < vs.count; g++) { vs.base[g] = job.segs[g0 + g].base; vs.ns[g] = job.segs[g0 + g].ns; vs.sh[g] = job.seg_lshift[g0 + g]; }
+                    rc |= srla_launch_make_variants(upload, s.in_cur, s.stride_cur, nch, jp.lshift_dev, &vs, narrow ? s.d_var16.as<int16_t>() : nullptr,
+                                                    s.d_var32.as<int32_t>(), vstride, s.d_var_flag.as<uint32_t>());
+                }
+                HIP_OK(hipEventRecord(s.ev_var, upload));
+                HIP_OK(hipStreamWaitEvent(W, s.ev_var, 0));
+                s.var_ready = true;
+            }
+        }
+        SrlaJobParams jv = jp;                                    /* what srla_autocorr sees: with the variant planes when the job has them */
+        if (s.var_ready) {
+            jv.var16 = (par.bits_per_sample <= 16) ? s.d_var16.as<int16_t>() : nullptr;
+            jv.var32 = s.d_var32.as<int32_t>(); jv.var_flag = s.d_var_flag.as<uint32_t>(); jv.var_stride = job.total;
         }
         struct L { int kind, cls, pass; };                       /* kind 0: autocorr class launch, 1: pitch solve */
         L seq[20]; int nl = 0;
@@ -434,12 +467,28 @@ bool Impl::run_stage(Slot &s, int st, int part)
         if (split && part == 2) { first = pitch_at + 1; HIP_OK(hipStreamWaitEvent(W, s.ev_p, 0)); }
         static const int kClass[7] = { 0, 1, 2, 4, 0, 0, 0 };     /* FFT size / 2048 (0: at most 1024 points) */
         static const uint32_t kWaveFft[7] = { 0u, 2048u, 4096u, 8192u, 0u, 0u, 1024u };   /* classes of ONE size that srla_autocorr_w takes */
+        auto start_event = [&](int i) -> hipEvent_t {
+            hipEvent_t e = (i == 0) ? ev0 : nullptr;
+            if (split) { if (i == pitch_at) e = s.ev_p0; if (i == pitch_at + 1 && s.timed) e = s.ev_a0; }
+            return e;
+        };
+        auto stop_event = [&](int i) -> hipEvent_t {
+            hipEvent_t e = (i == nl - 1) ? s.t1[ST_A] : nullptr;
+            if (split) { if (i == pitch_at - 1) e = s.ev_a1; /* the last launch of the LTP pass */ if (i == pitch_at) e = s.ev_p; }
+            return e;
+        };
+        /* a small job's 2048- and 4096-point classes in ONE launch (srla_autocorr_pair): a short stream is a latency chain */
+        const bool pair_ok = pair_small_jobs && !wave_fft && !srla_autocorr_pair_excluded() &&
+                             job.class_count[1] != 0 && job.class_count[2] != 0 && job.class_count[1] + job.class_count[2] <= pair_max_items;
         for (int i = first; i <= last; i++) {
-            hipEvent_t e0 = (i == 0) ? ev0 : nullptr, e1 = (i == nl - 1) ? s.t1[ST_A] : nullptr;
-            if (split) {
-                if (i == pitch_at - 1) e1 = s.ev_a1;             /* the last launch of the LTP pass */
-                if (i == pitch_at) { e0 = s.ev_p0; e1 = s.ev_p; }
-                if (i == pitch_at + 1 && s.timed) e0 = s.ev_a0;
+            hipEvent_t e0 = start_event(i), e1 = stop_event(i);
+            if (pair_ok && seq[i].kind == 0 && seq[i].cls == 1 && i + 1 <= last && seq[i + 1].kind == 0 && seq[i + 1].cls == 2 && seq[i + 1].pass == seq[i].pass) {
+                rc |= srla_launch_autocorr_pair(W, &jv, s.in_cur, s.d_items.as<SrlaItemDesc>(), d_geoms.as<SrlaGeom>(), d_tw.p, (uint32_t)seq[i].pass,
+                                                s.d_results.as<SrlaItemResult>(), s.d_lags.as<double>(), dbg,
+                                                s.d_class_index.as<SrlaAutocorrItem>() + job.class_first[2], job.class_count[2],
+                                                s.d_class_index.as<SrlaAutocorrItem>() + job.class_first[1], job.class_count[1], e0, stop_event(i + 1));
+                i++;
+                continue;
             }
             if (seq[i].kind == 0) {
                 const int c = seq[i].cls;
@@ -451,7 +500,7 @@ bool Impl::run_stage(Slot &s, int st, int part)
                     rc |= srla_launch_autocorr_wave(W, kWaveFft[c], &jp, s.in_cur, d_tw.p, (uint32_t)seq[i].pass, s.d_results.as<SrlaItemResult>(),
                                                     s.d_lags.as<double>(), dbg, s.d_class_index.as<SrlaAutocorrItem>() + job.class_first[c], job.class_count[c], e0, e1);
                 else
-                rc |= srla_launch_autocorr(W, kClass[c], &jp, s.in_cur, s.d_items.as<SrlaItemDesc>(), d_geoms.as<SrlaGeom>(), d_tw.p,
+                rc |= srla_launch_autocorr(W, kClass[c], &jv, s.in_cur, s.d_items.as<SrlaItemDesc>(), d_geoms.as<SrlaGeom>(), d_tw.p,
                                            (uint32_t)seq[i].pass, s.d_results.as<SrlaItemResult>(), s.d_lags.as<double>(), dbg,
                                            s.d_class_index.as<SrlaAutocorrItem>() + job.class_first[c], job.class_count[c], e0, e1, nullptr, nullptr, c == 6 ? 1 : 0);
             } else {
@@ -485,9 +534,14 @@ bool Impl::run_stage(Slot &s, int st, int part)
             const Group &g = job.groups[0];
             /* the roofline kernel: start event on every job */
             const bool big = !job.big_items.empty();
+            SrlaJobParams jv = jp;                                /* with the variant planes when stage A made them */
+            if (s.var_ready) {
+                jv.var16 = (par.bits_per_sample <= 16) ? s.d_var16.as<int16_t>() : nullptr;
+                jv.var32 = s.d_var32.as<int32_t>(); jv.var_flag = s.d_var_flag.as<uint32_t>(); jv.var_stride = job.total;
+            }
             if (g.split) {
                 /* the large items first: they are what the launch waits for, the small ones fill in behind them */
-                SrlaJobParams jl = jp, js = jp;
+                SrlaJobParams jl = jv, js = jv;
                 jl.rc_lo = 4096u; jl.rc_hi = 8192u;
                 js.rc_lo = 0u; js.rc_hi = 4096u;
                 rc |= srla_launch_residual_cost(W, 4, &jl, s.in_cur, s.d_items.as<SrlaItemDesc>(), d_geoms.as<SrlaGeom>(), &g.plan,
@@ -497,7 +551,7 @@ bool Impl::run_stage(Slot &s, int st, int part)
                                                 d_thr.as<double>(), s.d_res_ws.as<int32_t>(), s.d_results.as<SrlaItemResult>(),
                                                 nullptr, big ? nullptr : s.t1[ST_C]);
             } else
-            rc |= srla_launch_residual_cost(W, g.rclass, &jp, s.in_cur, s.d_items.as<SrlaItemDesc>(), d_geoms.as<SrlaGeom>(), &g.plan,
+            rc |= srla_launch_residual_cost(W, g.rclass, &jv, s.in_cur, s.d_items.as<SrlaItemDesc>(), d_geoms.as<SrlaGeom>(), &g.plan,
                                             d_thr.as<double>(), s.d_res_ws.as<int32_t>(), s.d_results.as<SrlaItemResult>(),
                                             timing ? s.t0[ST_C] : nullptr, big ? nullptr : s.t1[ST_C]);
             if (big)
@@ -546,6 +600,17 @@ bool Impl::run_stage(Slot &s, int st, int part)
 
 bool Impl::wait_job(Slot &s)
 {
+    if (spin_collect) {
+        /* a call of a few jobs is a latency chain: poll the event (a load of its signal) for a while instead of sleeping on it */
+        const auto t0 = Clock::now();
+        hipError_t q;
+        while ((q = hipEventQuery(s.t1[ST_E])) == hipErrorNotReady && ms_since(t0) < 2.0) {
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
+        if (q != hipSuccess) (void)hipGetLastError();
+    }
     HIP_OK(hipEventSynchronize(s.t1[ST_E]));
     float t = 0;
     double *acc[NUM_ST] = { &stats.autocorr_ms, &stats.solve_ms, &stats.residual_ms, &stats.price_ms, &stats.gather_ms };
@@ -642,7 +707,9 @@ SRLAApiResult Impl::finish_job(Slot &s)
         if (!st.out_direct && st.data != nullptr) {
             const uint8_t *src = s.h_stream.as<uint8_t>() + si[k].stage_off;
             uint8_t *dst = st.data + si[k].pos;
-            const uint32_t chunk = 256u << 10, total = si[k].bytes;
+            const uint32_t total = si[k].bytes;
+            uint32_t chunk = 256u << 10;
+            while (chunk > (16u << 10) && total < chunk * 3u * pool->size()) chunk >>= 1;      /* (a short stream's bytes: a few tasks per thread) */
             pool->parallel_for((total + chunk - 1) / chunk, [&](uint32_t i) {
                 const uint32_t o = i * chunk;
                 memcpy(dst + o, src + o, std::min(chunk, total - o));
@@ -842,7 +909,7 @@ SRLAApiResult Impl::encode_streams(bool search)
         StreamCtx &st = sx[si];
         classify_buffers(st, pins.held);
         /* (streams of less than a few MB are not worth a registration: staging them costs microseconds) */
-        const bool worth_pinning = (uint64_t)st.num_samples * nch * 4u >= (4u << 20);
+        const bool worth_pinning = (uint64_t)st.num_samples * nch * 4u >= ((uint64_t)pin_min_mb << 20);
         if (want_pins && worth_pinning && st.host_in && !st.in_pinned) {
             const size_t before = pins.held.size();
             bool ok = true;
@@ -941,6 +1008,7 @@ SRLAApiResult Impl::encode_streams(bool search)
     const uint32_t njobs = (uint32_t)plan.size();
     overrides.clear();
     call_crowded = njobs > 3;
+    spin_collect = spin_short_calls && njobs <= 3;
     /* (a stream of a few pieces is a latency chain: its copies would start only when the host has collected each piece) */
     call_dma = dma_out && dma_stream != nullptr && njobs > 3;
     for (const StreamCtx &st : sx) call_dma = call_dma && st.out_direct != nullptr && st.data != nullptr && st.cb == nullptr;
@@ -966,7 +1034,7 @@ SRLAApiResult Impl::encode_streams(bool search)
         s.emits = true; s.merge_cb = false;
         s.timed = timing && (k % timing_stride == 0);
         s.out_boost = (k + tail_boost_jobs >= njobs) ? tail_boost : 1u;
-        s.last_job = k + 1 == njobs;
+        s.last_job = k + dma_tail_jobs >= njobs;              /* (the last jobs of the call: the copy-out kernel, no host round trip) */
         return prepare_job(s, false);
     };
     /* chain mode of the (single) stream, overlapped with the regular jobs */
@@ -1070,6 +1138,7 @@ SRLAApiResult Impl::encode_streams(bool search)
             }
         }
         const SRLAApiResult rc = finish_job(s);
+        if (timeline) tl_printf("[timeline] host: job %u finished at %.3f ms\n", k, ms_since(t0));
         if (rc != SRLA_APIRESULT_OK && (single || rc != SRLA_APIRESULT_INSUFFICIENT_BUFFER)) {
             if (rc == SRLA_APIRESULT_INSUFFICIENT_BUFFER && sx[0].lshift_spec) { drain(); sx[0].or_dev_end = 0; /* not every job was staged: the device's OR is partial, the host looks at the whole stream */ break; }   /* perhaps only because the shift was guessed wrong: see below */
             return fail(rc);
@@ -1161,6 +1230,14 @@ SRLAApiResult Impl::encode_streams(bool search)
         if (!write_header(st)) return fail(SRLA_APIRESULT_NG);
     }
     if (single && sx[0].with_header && sx[0].rc == SRLA_APIRESULT_OK) offset_lshift = sx[0].lshift;   /* encoder->header of the reference */
+    if (timeline) {
+        /* (what the guards above do when the call leaves, here under the clock) */
+        tl_printf("[timeline] host: streams complete at %.3f ms\n", ms_since(t0));
+        if (dma_stream && dma_used) { (void)hipStreamSynchronize(dma_stream); dma_used = false; }
+        tl_printf("[timeline] host: copies complete at %.3f ms\n", ms_since(t0));
+        for (const void *p : pins.held) host_pin_release(p);
+        pins.held.clear();
+    }
     stats.total_ms += ms_since(t0);
     if (timeline) { tl_printf("[timeline] call returned at %.3f ms\n", ms_since(t0)); fputs(tl_log.c_str(), stderr); tl_log.clear(); }
     return worst;

@@ -41,6 +41,12 @@ void Impl::read_environment()
     { const long long v = number("SRLA_MI355X_MID_JOBS", -1); if (v >= 0 && v <= 16) mid_jobs = (uint32_t)v; }
     { const long long v = number("SRLA_MI355X_SHORT_DIV", 0); if (v >= 2 && v <= 64) short_div = (uint32_t)v; }
     { const long long v = number("SRLA_MI355X_PACK_THREADS", 0); if (v > 0) env_pack_threads = (uint32_t)v; }
+    { const long long v = number("SRLA_MI355X_PIN_MIN_MB", -1); if (v >= 0 && v <= 65536) pin_min_mb = (uint32_t)v; }
+    if (is_set("SRLA_MI355X_VARIANTS")) variant_planes = number("SRLA_MI355X_VARIANTS", 1) != 0;
+    if (is_set("SRLA_MI355X_PAIR")) pair_small_jobs = number("SRLA_MI355X_PAIR", 1) != 0;
+    { const long long v = number("SRLA_MI355X_PAIR_MAX", -1); if (v >= 0) pair_max_items = (uint32_t)v; }
+    if (is_set("SRLA_MI355X_SPIN")) spin_short_calls = number("SRLA_MI355X_SPIN", 1) != 0;
+    { const long long v = number("SRLA_MI355X_DMA_TAIL", -1); if (v >= 1 && v <= 16) dma_tail_jobs = (uint32_t)v; }
     if (const char *e = getenv("SRLA_MI355X_TAIL_BOOST")) {     /* "wgs,jobs": stream-out workgroup multiplier of the last jobs */
         unsigned a = 0, b = 0;
         if (sscanf(e, "%u,%u", &a, &b) == 2 && a >= 1) { tail_boost = a; tail_boost_jobs = b; }

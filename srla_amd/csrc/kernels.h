@@ -30,6 +30,16 @@ uint32_t srla_kernel_fast_lds_bytes(uint32_t fl, uint32_t ltp_order, uint32_t bi
 /* pass 0: LPC lags (initialises the item record unless an LTP pass ran first), pass 1: LTP lags.
  * One launch per FFT-size class (rclass = 0, 1, 2, 4 for N' <= 1024, 2048, 4096, 8192): class_items holds the `count`
  * items of the class. */
+/* the job's variant planes (SrlaJobParams::var16 / var32; v16 null: every variant as int32) from its channel planes, segment by segment */
+int srla_launch_make_variants(hipStream_t stream, const int32_t *src, uint32_t src_stride, uint32_t nch, const uint32_t *lshift_dev,
+                              const SrlaVarSegs *segs, int16_t *v16, int32_t *v32, uint32_t vstride, uint32_t *flag /* zeroed by the caller */);
+/* a small job's 4096- and 2048-point classes in one launch (not in chain mode); srla_autocorr_pair_excluded: a launch tuning
+ * (fused / generic transform) asks for kernels the pair does not have */
+int srla_launch_autocorr_pair(hipStream_t stream, const SrlaJobParams *jp, const int32_t *input, const SrlaItemDesc *items,
+                              const SrlaGeom *geoms, const void *twiddles, uint32_t pass, SrlaItemResult *results, double *lags_ws,
+                              double *dbg, const SrlaAutocorrItem *items_4096, uint32_t count_4096,
+                              const SrlaAutocorrItem *items_2048, uint32_t count_2048, hipEvent_t ev_start, hipEvent_t ev_stop);
+int srla_autocorr_pair_excluded(void);
 int srla_launch_autocorr(hipStream_t stream, int rclass, const SrlaJobParams *jp, const int32_t *input,
                          const SrlaItemDesc *items, const SrlaGeom *geoms, const void *twiddles,
                          uint32_t pass, SrlaItemResult *results, double *lags_ws, double *dbg,

@@ -581,17 +581,21 @@ struct SmallA {
     uint32_t pad[2];
 };
 
+/* (Laid OVER the FFT buffer instead of behind it -- a 4096-point item is then 32 768 bytes instead of 32 944 -- it changes nothing:
+ * measured in round 4, srla_autocorr 0.212 ms per job either way; LDS is handed out in granules that leave four workgroups per CU.) */
 extern "C" uint32_t srla_kernel_small_a_bytes(void) { return (uint32_t)((sizeof(SmallA) + 15) & ~15u); }
 
 /* R: chunks of 8 samples per thread (8 R NTK >= nfft).  F16: the fused-pass transform (NTK = nfft / 32), else one stage
  * per round trip (R butterflies per thread and stage) */
+/* the analysis of one item: the body of srla_autocorr (one FFT-size class per launch) and of srla_autocorr_pair (two classes in
+ * one launch); `bid`: the workgroup's index within its class */
 template <int R, int NTK, bool F16, int NFFT = 0 /* every item of the launch has this FFT size (0: they say themselves) */>
-__global__ __launch_bounds__(NTK) __attribute__((amdgpu_waves_per_eu(4, 8))) void srla_autocorr(
-    SrlaJobParams jp, const int32_t *__restrict__ input, const SrlaItemDesc *__restrict__ items,
+__device__ __forceinline__ void autocorr_item(
+    const SrlaJobParams &jp, const int32_t *__restrict__ input, const SrlaItemDesc *__restrict__ items,
     const SrlaGeom *__restrict__ geoms, const cplx *__restrict__ twiddles, uint32_t fft_bytes, uint32_t pass,
     SrlaItemResult *__restrict__ results, double *__restrict__ lags_ws, double *__restrict__ dbg,
     const SrlaAutocorrItem *__restrict__ class_items, uint32_t count, double *__restrict__ chain_pool,
-    const uint32_t *__restrict__ chain_tab)
+    const uint32_t *__restrict__ chain_tab, const uint32_t bid)
 {
     constexpr int CH = 2 * R;   /* chunks of four samples per thread: covers 8 * R * NTK >= nfft */
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -599,10 +603,10 @@ __global__ __launch_bounds__(NTK) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     SmallA *sm = (SmallA *)(lds + fft_bytes);
 
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t pos = xcd_position(blockIdx.x, count);
+    const uint32_t pos = xcd_position(bid, count);
     if (pos >= count) return;
     const SrlaAutocorrItem it = class_items[pos];                    /* items of one FFT-size class */
-    const InputView iv = input_view(jp, it.lshift);
+    const InputView iv = input_view(jp, it.lshift, input);
     const uint32_t item_idx = it.item;
     const struct { uint32_t nfft, tw_off; double welch_divisor, acorr_norm; } g = { it.nfft, it.tw_off, it.welch_divisor, it.acorr_norm };
     const uint32_t n = it.n, nfft = NFFT ? (uint32_t)NFFT : g.nfft, bps = jp.bits_per_sample;
@@ -861,6 +865,34 @@ __global__ __launch_bounds__(NTK) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         lags_ws[(size_t)i * stride + item_idx] = lag;
         if (dbg) dbg[(size_t)item_idx * SRLA_DBG_STRIDE + ((pass == 1) ? SRLA_DBG_LTPLAGS : SRLA_DBG_LAGS) + i] = lag;
     }
+}
+
+template <int R, int NTK, bool F16, int NFFT = 0>
+__global__ __launch_bounds__(NTK) __attribute__((amdgpu_waves_per_eu(4, 8))) void srla_autocorr(
+    SrlaJobParams jp, const int32_t *__restrict__ input, const SrlaItemDesc *__restrict__ items,
+    const SrlaGeom *__restrict__ geoms, const cplx *__restrict__ twiddles, uint32_t fft_bytes, uint32_t pass,
+    SrlaItemResult *__restrict__ results, double *__restrict__ lags_ws, double *__restrict__ dbg,
+    const SrlaAutocorrItem *__restrict__ class_items, uint32_t count, double *__restrict__ chain_pool,
+    const uint32_t *__restrict__ chain_tab)
+{
+    autocorr_item<R, NTK, F16, NFFT>(jp, input, items, geoms, twiddles, fft_bytes, pass, results, lags_ws, dbg, class_items, count, chain_pool, chain_tab, blockIdx.x);
+}
+
+/* The 4096-point and the 2048-point class of a SMALL job in one launch (both run on 256 threads): a short stream's chain of
+ * launches is a latency chain on a mostly idle device, and two class launches one after the other cost two launch floors where the
+ * items of both fit the device together.  The workgroups of the larger class come first.  Registers and LDS are the larger class's
+ * for every workgroup, which would halve the 2048-point items' occupancy in a full job: small jobs only (srla_launch_autocorr_pair). */
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void srla_autocorr_pair(
+    SrlaJobParams jp, const int32_t *__restrict__ input, const SrlaItemDesc *__restrict__ items,
+    const SrlaGeom *__restrict__ geoms, const cplx *__restrict__ twiddles, uint32_t fft_bytes, uint32_t pass,
+    SrlaItemResult *__restrict__ results, double *__restrict__ lags_ws, double *__restrict__ dbg,
+    const SrlaAutocorrItem *__restrict__ items_4096, uint32_t count_4096, const SrlaAutocorrItem *__restrict__ items_2048, uint32_t count_2048)
+{
+    const uint32_t g4 = 8u * ((count_4096 + 7u) >> 3);
+    if (blockIdx.x < g4)
+        autocorr_item<2, 256, false, 4096>(jp, input, items, geoms, twiddles, fft_bytes, pass, results, lags_ws, dbg, items_4096, count_4096, nullptr, nullptr, blockIdx.x);
+    else
+        autocorr_item<1, 256, false, 2048>(jp, input, items, geoms, twiddles, fft_bytes, pass, results, lags_ws, dbg, items_2048, count_2048, nullptr, nullptr, blockIdx.x - g4);
 }
 
 /* ================================================================================================
@@ -1176,8 +1208,11 @@ __global__ __launch_bounds__(WAVE) void srla_order_select(
 /* shared tail of the quantiser kernels: cf(i) = tap i of the chosen predictor */
 template <typename CF, typename QS, typename QL>
 __device__ __forceinline__ void quantize_and_price(uint32_t order, bool silent, CF cf, QS qstore, QL qload,
-                                                   const uint8_t *__restrict__ huff_len, SrlaItemResult *out)
+                                                   const uint8_t *__restrict__ huff_len, SrlaItemResult *out,
+                                                   const double band = 0.0, bool *near_boundary = nullptr)
 {
+    /* band > 0: *near_boundary is set when the outcome hangs on the last bits of a tap -- the largest tap within `band` (relative) of a
+     * power of two (the shared shift), or a scaled tap plus the error fed back within `band` of a rounding boundary */
     uint32_t rshift = 0, use_sum = 0, coef_bits = 0;
     if (order > 0) {
         /* 8-bit quantisation with error feedback from the last tap (lpc.c:1341-1405) */
@@ -1188,18 +1223,21 @@ __device__ __forceinline__ void quantize_and_price(uint32_t order, bool silent, 
             for (uint32_t i = 0; i < order; i++) qstore(i, 0);
         } else {
             int ndigit;
-            (void)frexp(maxabs, &ndigit);
+            const double mant = frexp(maxabs, &ndigit);
             rshift = (uint32_t)(7 - ndigit);
             if (rshift >= 16u) rshift = 15u;
             const double scale = __builtin_ldexp(1.0, (int)rshift);
+            bool near = band > 0.0 && (mant - 0.5 < band || 1.0 - mant < band);
             double qerr = 0.0;
             for (int i = (int)order - 1; i >= 0; i--) {
                 qerr += cf((uint32_t)i) * scale;
+                if (band > 0.0) { const double a = fabs(qerr), fr = a - floor(a); if (fabs(fr - 0.5) < band) near = true; }
                 int32_t qq = (int32_t)round_half_away(qerr);
                 if (qq >= 128) qq = 127; else if (qq < -128) qq = -128;
                 qerr -= (double)qq;
                 qstore(order - 1 - (uint32_t)i, qq);        /* reversed: oldest sample first (srla_encoder.c:1104) */
             }
+            if (near_boundary != nullptr && near) *near_boundary = true;
         }
         /* Huffman cost plain vs pair-summed (srla_encoder.c:1141-1174) */
         uint32_t plain = 0, summed = 0, overflow = 0;
@@ -2491,7 +2529,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(R >= 4 ? SRL
     const SrlaItemDesc itf = items[block];
     if (itf.n > 8192u) return;                       /* srla_residual_cost_big takes these */
     if (jp.rc_hi != 0u && (itf.n <= jp.rc_lo || itf.n > jp.rc_hi)) return;   /* the other launch of the job takes these */
-    const InputView iv = input_view(jp, itf.lshift);
+    const InputView iv = input_view(jp, itf.lshift, input);
     {
         /* blocks of 1024 * FL samples take the register / shuffle fast path */
         const uint32_t fl = itf.n >> 10;
@@ -2512,7 +2550,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(R >= 4 ? SRL
                          * shift, taps, pointers -- stays in scalar registers and scalar branches as with one item per workgroup) */
                         const uint32_t g = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / (uint32_t)(NT >> 1)));
                         const SrlaItemDesc itg = items[leader + g];
-                        const InputView ivg = input_view(jp, itg.lshift);
+                        const InputView ivg = input_view(jp, itg.lshift, input);
                         unsigned char *ldsg = lds + g * (fast_sig_bytes((int)fl, 1, jp.ltp_order == 0) + (uint32_t)((sizeof(SmallF) + 15) & ~15u));
                         if (fl == 1) residual_cost_fast<1, FIR_DOT, 1>(jp, ivg, input + itg.sample_off, itg, ldsg, rice_thresholds, res_ws, &results[leader + g]);
                         else residual_cost_fast<2, FIR_DOT, 1>(jp, ivg, input + itg.sample_off, itg, ldsg, rice_thresholds, res_ws, &results[leader + g]);
@@ -3279,7 +3317,7 @@ __global__ __launch_bounds__(SVR_NT) void srla_svr_refine_big(
 /* the quantiser and tap cost (lpc.c:1341-1405, srla_encoder.c:1141-1174) from the refined taps: one lane per item */
 __global__ __launch_bounds__(WAVE) void srla_lpc_quantize_ws(SrlaJobParams jp, const double *__restrict__ coef_ws, uint32_t ws_stride,
                                                              const uint8_t *__restrict__ huff_len, SrlaItemResult *__restrict__ results,
-                                                             const uint32_t *__restrict__ sel, uint32_t sel_round)
+                                                             const uint32_t *__restrict__ sel, uint32_t sel_round, uint32_t *__restrict__ ties)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int L = WAVE;
@@ -3294,10 +3332,19 @@ __global__ __launch_bounds__(WAVE) void srla_lpc_quantize_ws(SrlaJobParams jp, c
     SrlaItemResult *out = &results[idx];
     const uint32_t order = out->lpc_order;
     const double *row = coef_ws + (size_t)idx * ws_stride;
+    /* The refined taps carry the last bits of the refinement's pow(x, -0.5) (lpc.c:591 via :1071; the device's is the correctly
+     * rounded value, glibc's within an ulp of it): where the quantiser's outcome hangs on such bits the item is flagged like an
+     * objective near-tie and the host redoes the refinement with its own libm (host_ties.cpp: arbitrate_svr).  The band is the
+     * near-tie threshold of the comparisons (1e-9 in production): eight orders of magnitude above what an ulp of a tap moves. */
+    bool near = false;
     quantize_and_price(order, false,
                        [&](uint32_t i) -> double { return row[i]; },
                        [&](uint32_t i, int32_t v) { q[(size_t)i * L + lane] = v; },
-                       [&](uint32_t i) -> int32_t { return q[(size_t)i * L + lane]; }, s_huff, out);
+                       [&](uint32_t i) -> int32_t { return q[(size_t)i * L + lane]; }, s_huff, out, jp.tie_rel, &near);
+    if (near && order > 0 && !(out->flags & SRLA_ITEM_SVR_TIE)) {
+        out->flags |= SRLA_ITEM_SVR_TIE;
+        if (ties != nullptr) (void)tie_append(ties, idx, 2u);
+    }
 }
 
 /* ------------------------------------------------------------------------- pricing -------- */
@@ -4149,6 +4196,87 @@ extern "C" int srla_launch_autocorr(hipStream_t stream, int rclass, const SrlaJo
     return (hipGetLastError() == hipSuccess) ? 0 : -2;
 }
 
+extern "C" int srla_autocorr_pair_excluded(void) { return (g_tune.fused_fft || g_tune.generic_fft) ? 1 : 0; }
+
+extern "C" int srla_launch_autocorr_pair(hipStream_t stream, const SrlaJobParams *jp, const int32_t *input, const SrlaItemDesc *items,
+                                         const SrlaGeom *geoms, const void *twiddles, uint32_t pass, SrlaItemResult *results, double *lags_ws,
+                                         double *dbg, const SrlaAutocorrItem *items_4096, uint32_t count_4096,
+                                         const SrlaAutocorrItem *items_2048, uint32_t count_2048, hipEvent_t ev_start, hipEvent_t ev_stop)
+{
+    if (count_4096 == 0 || count_2048 == 0) return -1;
+    const uint32_t fft_bytes = 2048u * 16u, lds = fft_bytes + srla_kernel_small_a_bytes();
+    dim3 grid(8u * ((count_4096 + 7u) >> 3) + 8u * ((count_2048 + 7u) >> 3));
+    SET_LDS_ATTR(srla_autocorr_pair);
+    hipExtLaunchKernelGGL(srla_autocorr_pair, grid, dim3(256), lds, stream, ev_start, ev_stop, 0, *jp, input, items, geoms, (const cplx *)twiddles,
+                          fft_bytes, pass, results, lags_ws, dbg, items_4096, count_4096, items_2048, count_2048);
+    return (hipGetLastError() == hipSuccess) ? 0 : -2;
+}
+
+/* The job's variant planes (SrlaJobParams::var16 / var32): every analysed variant of every sample with the offset shift applied,
+ * once per job.  Four samples per thread; blockIdx.y = segment (segments of different streams may have different shifts). */
+__global__ __launch_bounds__(NT) void srla_make_variants(const int32_t *__restrict__ src, uint32_t src_stride, uint32_t nch,
+                                                         const uint32_t *__restrict__ lshift_dev, SrlaVarSegs segs,
+                                                         int16_t *__restrict__ v16, int32_t *__restrict__ v32, uint32_t vstride,
+                                                         uint32_t *__restrict__ flag)
+{
+    const uint32_t g = blockIdx.y;
+    const uint32_t base = segs.base[g], ns = segs.ns[g], sh = lshift_dev ? *lshift_dev : segs.sh[g];
+    const uint32_t i4 = 4u * (blockIdx.x * NT + threadIdx.x);
+    if (i4 >= ns) return;
+    const uint32_t o = base + i4, cnt = (ns - i4 < 4u) ? ns - i4 : 4u;
+    const bool vec = cnt == 4u && ((reinterpret_cast<uintptr_t>(src) & 15u) == 0) && ((src_stride & 3u) == 0) && ((o & 3u) == 0);
+    int32_t l[4] = { 0, 0, 0, 0 }, r[4] = { 0, 0, 0, 0 };
+    auto load4 = [&](uint32_t ch, int32_t out[4]) {
+        const int32_t *p = src + (size_t)ch * src_stride + o;
+        if (vec) { const int4 a = *reinterpret_cast<const int4 *>(p); out[0] = a.x >> sh; out[1] = a.y >> sh; out[2] = a.z >> sh; out[3] = a.w >> sh; }
+        else for (uint32_t i = 0; i < cnt; i++) out[i] = p[i] >> sh;
+    };
+    auto store4 = [&](uint32_t plane, const int32_t x[4], bool as32) {
+        if (as32) {
+            int32_t *q = v32 + (size_t)plane * vstride + o;
+            if (cnt == 4u) *reinterpret_cast<int4 *>(q) = make_int4(x[0], x[1], x[2], x[3]);
+            else for (uint32_t i = 0; i < cnt; i++) q[i] = x[i];
+        } else {
+            int16_t *q = v16 + (size_t)plane * vstride + o;
+            if (cnt == 4u) *reinterpret_cast<short4 *>(q) = make_short4((short)x[0], (short)x[1], (short)x[2], (short)x[3]);
+            else for (uint32_t i = 0; i < cnt; i++) q[i] = (int16_t)x[i];
+        }
+    };
+    const bool narrow = v16 != nullptr;
+    uint32_t wide = 0;
+    for (uint32_t ch = 0; ch < nch; ch++) {
+        int32_t x[4] = { 0, 0, 0, 0 };
+        load4(ch, x);
+        if (narrow) for (int i = 0; i < 4; i++) wide |= ((uint32_t)x[i] + 32768u) & 0xFFFF0000u;   /* (M of two int16 values is one) */
+        store4(ch, x, !narrow);
+        if (ch == 0) { l[0] = x[0]; l[1] = x[1]; l[2] = x[2]; l[3] = x[3]; }
+        if (ch == 1) { r[0] = x[0]; r[1] = x[1]; r[2] = x[2]; r[3] = x[3]; }
+    }
+    if (nch >= 2) {
+        int32_t m[4], d[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            d[i] = (int32_t)((uint32_t)r[i] - (uint32_t)l[i]);                  /* S = R - L,  M = L + (S >> 1)  (srla_utility.c:91-103) */
+            m[i] = (int32_t)((uint32_t)l[i] + (uint32_t)(d[i] >> 1));
+        }
+        store4(nch, m, !narrow);
+        store4(narrow ? 0u : nch + 1u, d, true);
+    }
+    if (__any((int)(wide != 0u)) && (threadIdx.x & 63u) == 0u) atomicOr(flag, 1u);
+}
+
+extern "C" int srla_launch_make_variants(hipStream_t stream, const int32_t *src, uint32_t src_stride, uint32_t nch, const uint32_t *lshift_dev,
+                                         const SrlaVarSegs *segs, int16_t *v16, int32_t *v32, uint32_t vstride, uint32_t *flag)
+{
+    if (segs->count == 0) return 0;
+    uint32_t longest = 0;
+    for (uint32_t g = 0; g < segs->count; g++) longest = std::max(longest, segs->ns[g]);
+    if (longest == 0) return 0;
+    const uint32_t per = NT * 4u;
+    hipLaunchKernelGGL(srla_make_variants, dim3((longest + per - 1) / per, segs->count), dim3(NT), 0, stream, src, src_stride, nch, lshift_dev, *segs, v16, v32, vstride, flag);
+    return (hipGetLastError() == hipSuccess) ? 0 : -2;
+}
+
 __global__ __launch_bounds__(NT) void srla_widen16(const int16_t *__restrict__ src, size_t stride16, int32_t *__restrict__ dst, uint32_t n)
 {
     /* four samples per thread: one 8-byte load, four consecutive stores (the int32 planes need not be 16-byte aligned) */
@@ -4266,7 +4394,7 @@ extern "C" int srla_launch_lpc_solve(hipStream_t stream, const SrlaJobParams *jp
                                ws_stride, svr_iterations, svr_n_cap, (unsigned char *)svr_scratch, jp->max_block, ex);
         }
         SET_LDS_ATTR(srla_lpc_quantize_ws);
-        hipExtLaunchKernelGGL(srla_lpc_quantize_ws, g64s, blks, 512 + (p < 64 ? 64 : p) * 4 * 64, stream, nullptr, ev_stop, 0, *jp, coef_ws, ws_stride, huff_len, results, ex.select, ex.round);
+        hipExtLaunchKernelGGL(srla_lpc_quantize_ws, g64s, blks, 512 + (p < 64 ? 64 : p) * 4 * 64, stream, nullptr, ev_stop, 0, *jp, coef_ws, ws_stride, huff_len, results, ex.select, ex.round, ex.ties);
         return (hipGetLastError() == hipSuccess) ? 0 : -2;
     }
     const dim3 g64((jp->num_items + 63) / 64), blk(WAVE);
