@@ -13,19 +13,22 @@ encoded by one SRLAMI355X_EncodeBatch call per step).
 
 Timed region of `value`: SRLAEncoder_EncodeWhole -- planar int32 samples in ordinary (pageable) host
 memory in, the complete .srl stream in ordinary host memory out; staging, H2D, every kernel and the way back are
-inside.  K steps between barriers, max over ranks; value = sample instants encoded by all ranks / that time.
+inside.  K steps between barriers, max over ranks; value = sample instants encoded by all ranks / that time.  A step is
+`--calls-per-step` back-to-back calls (default: about 0.1 s of device work, 22 x 600 s at the metric configuration).
 Every rank encodes its own streams (windows and files are independent units: no collective on the data path), so
 scaling is weak.
 
 Extra objects on the JSON line:
-  roofline         every stage of a job (`stages`: srla_autocorr, srla_pitch_solve, srla_lpc_solve, srla_residual_cost,
+  roofline         every stage of a job (`stages`: srla_stage_in, srla_autocorr, srla_pitch_solve, srla_lpc_solve, srla_residual_cost,
                    srla_price_windows, srla_pack_blocks) priced against the same contract -- algorithmic bytes = 16 B per
                    stereo sample instant x instants per launch, over the stage's average duration per job measured
-                   with HIP events attached to the dispatches inside the timed region; peak = 8000 GB/s HBM3E; `kernel` (and
-                   achieved / frac / traffic at the top level) = the analysis stage with the LONGEST measured duration;
-                   `end_to_end` = the whole path (algorithmic bytes of everything a rank encoded / its wall time); traffic,
-                   valu_util, lds_util, lds_bank_conflict_frac, wait_frac, fp64_inst_frac per stage from the committed
-                   rocprofv3 PMC summary (profiles/pmc_summary.json).
+                   with HIP events attached to the dispatches inside the timed region; peak = 8000 GB/s HBM3E.  `kernel` (and
+                   achieved / frac / traffic at the top level) = the stage with the LONGEST measured duration among ALL stages;
+                   `dominant_kernel` = the single kernel with the largest total time in the committed rocprofv3 --kernel-trace
+                   --stats summary of the same command (profiles/rNN/<config>/kernel_stats.csv), priced the same way;
+                   `end_to_end` = the whole path (algorithmic bytes of everything a rank encoded / its wall time).  A stage's
+                   `kernels`, traffic, valu_util, lds_util, lds_bank_conflict_frac, wait_frac, fp64_inst_frac come from the committed
+                   rocprofv3 PMC summary (profiles/pmc_summary.json): the kernels that RAN in that command, never a hand-kept list.
   cpu_baseline     the compiled reference (oracle/_ref, "reference") or the oracle ("port") timed on ONE host core on
                    a bounded sample of the same workload (rank 0, N = 1 only); `all_cores`: for context, the same on
                    every usable core at once (one handle per thread).
@@ -156,7 +159,7 @@ def cpu_baseline(pcm, cli, seconds, rate, bps=16):
 STAGES = (
     ("srla_stage_in",      None,          True,  ("srla_widen16", "srla_deinterleave", "srla_make_variants", "srla_or_reduce", "srla_mask_to_shift", "srla_chain_commit",
                                                   "__amd_rocclr_fillBuffer")),
-    ("srla_autocorr",      "autocorr_ms", True,  ("srla_autocorr<", "srla_autocorr_big", "srla_autocorr_w")),
+    ("srla_autocorr",      "autocorr_ms", True,  ("srla_autocorr<", "srla_autocorr_big", "srla_autocorr_w", "srla_autocorr_pair")),
     ("srla_pitch_solve",   "pitch_ms",    True,  ("srla_pitch_solve",)),
     ("srla_lpc_solve",     "solve_ms",    True,  ("srla_lpc_errvars", "srla_order_select", "srla_lpc_taps", "srla_lpc_solve_regs", "srla_lpc_recursion",
                                                   "srla_lpc_quantize", "srla_svr_refine")),

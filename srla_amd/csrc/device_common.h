@@ -31,6 +31,17 @@ __device__ __forceinline__ cplx c_mul(cplx a, cplx b)
     return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
 
+/* (int32_t)d as the reference's build computes it: cvttsd2si yields the "integer indefinite" 0x80000000 for every value outside
+ * int32 and for NaN, where the device's conversion saturates (INT_MAX for large positive values).  The reference converts unbounded
+ * doubles in one place that matters -- the long-term predictor's taps, (int32_t)Round(coef * 32) before the clip to [-32, 31]
+ * (srla_encoder.c:1031-1037): a block whose lag 0 is rounding noise (an all-zero variant of an odd-length block, whose only input is
+ * the word the Welch window leaves untouched, lpc.c:260-264) gets taps of 1e30 and more, and the reference's stream then carries -32
+ * for the POSITIVE ones too. */
+__device__ __forceinline__ int32_t cvt_i32_as_x86(double d)
+{
+    return (d >= -2147483648.0 && d < 2147483648.0) ? (int32_t)d : (int32_t)0x80000000;
+}
+
 __device__ __forceinline__ double round_half_away(double d)
 {
     /* srla_utility.c:22-25 */

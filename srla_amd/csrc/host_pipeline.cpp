@@ -909,7 +909,10 @@ SRLAApiResult Impl::encode_streams(bool search)
         StreamCtx &st = sx[si];
         classify_buffers(st, pins.held);
         /* (streams of less than a few MB are not worth a registration: staging them costs microseconds) */
-        const bool worth_pinning = (uint64_t)st.num_samples * nch * 4u >= ((uint64_t)pin_min_mb << 20);
+        /* ... when the pool is too small to stage (want_pins); where the threads could stage it as well, the OUTPUT buffer of a stream
+         * below pin_min_mb MB of samples is not worth its registration either (releasing it cost 0.07 ms of a 60 s stream's 0.94 ms) */
+        const uint64_t sample_bytes = (uint64_t)st.num_samples * nch * 4u;
+        const bool worth_pinning = sample_bytes >= (want_pins ? (uint64_t)(4u << 20) : ((uint64_t)pin_min_mb << 20));
         if (want_pins && worth_pinning && st.host_in && !st.in_pinned) {
             const size_t before = pins.held.size();
             bool ok = true;

@@ -1035,7 +1035,7 @@ __global__ __launch_bounds__(WAVE) void srla_pitch_solve(SrlaJobParams jp, const
                 const double scaled = xs[i2] * 32.0 + jp.tie_ltpbias;   /* bias: 0.0 in production (tie tests) */
                 const double fr = fabs(scaled) + 0.5;
                 if (fabs(fr - floor(fr + 0.5)) < jp.tie_ltp && fabs(scaled) < 40.0) flags |= SRLA_ITEM_LTP_TIE;
-                int32_t c = (int32_t)round_half_away(scaled);
+                int32_t c = cvt_i32_as_x86(round_half_away(scaled));
                 c = (c < -32) ? -32 : ((c > 31) ? 31 : c);
                 q[i2] = c;
             }
@@ -1232,7 +1232,7 @@ __device__ __forceinline__ void quantize_and_price(uint32_t order, bool silent, 
             for (int i = (int)order - 1; i >= 0; i--) {
                 qerr += cf((uint32_t)i) * scale;
                 if (band > 0.0) { const double a = fabs(qerr), fr = a - floor(a); if (fabs(fr - 0.5) < band) near = true; }
-                int32_t qq = (int32_t)round_half_away(qerr);
+                int32_t qq = cvt_i32_as_x86(round_half_away(qerr));
                 if (qq >= 128) qq = 127; else if (qq < -128) qq = -128;
                 qerr -= (double)qq;
                 qstore(order - 1 - (uint32_t)i, qq);        /* reversed: oldest sample first (srla_encoder.c:1104) */
@@ -1601,7 +1601,7 @@ __global__ __launch_bounds__(WAVE) void srla_lpc_quantize(
             double qerr = 0.0;
             for (int i = (int)order - 1; i >= 0; i--) {
                 qerr += A_(1 + i) * scale;
-                int32_t qq = (int32_t)round_half_away(qerr);
+                int32_t qq = cvt_i32_as_x86(round_half_away(qerr));
                 if (qq >= 128) qq = 127; else if (qq < -128) qq = -128;
                 qerr -= (double)qq;
                 Q_(order - 1 - i) = qq;          /* reversed: oldest sample first (srla_encoder.c:1104) */
@@ -2512,10 +2512,13 @@ __device__ __forceinline__ void rice_search_finish(const uint32_t *u, const Srla
 }
 
 template <int R>
+#ifndef SRLA_RC_WAVES
+#define SRLA_RC_WAVES 5       /* wavefronts per SIMD the forms for blocks of at most 4096 samples are compiled for (92 registers) */
+#endif
 #ifndef SRLA_RC4_WAVES
 #define SRLA_RC4_WAVES 3      /* wavefronts per SIMD the 8192-sample form is compiled for: 168 registers and 17 spilled dwords per lane; 2 (228 registers, no spills) was 9 % slower at -B 8192 -V 2 -P 3, profiles/r04/ab_residual_cost_split.txt */
 #endif
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(R >= 4 ? SRLA_RC4_WAVES : 5, 8))) void srla_residual_cost(
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(R >= 4 ? SRLA_RC4_WAVES : SRLA_RC_WAVES, 8))) void srla_residual_cost(
     SrlaJobParams jp, const int32_t *__restrict__ input, const SrlaItemDesc *__restrict__ items,
     const SrlaGeom *__restrict__ geoms, SrlaLdsPlan plan, const double *__restrict__ rice_thresholds,
     int32_t *__restrict__ res_ws, SrlaItemResult *__restrict__ results)

@@ -150,6 +150,16 @@ def synth(kind, seed, rate, nch, n, bps=16):
 SINE, MUSIC, VARIED, NOISE = 0, 1, 2, 3
 
 
+def synth_spec(sp):
+    """input of a golden entry: {kind, seed, rate, nch, n, bps} [+ first, count: a slice of the n samples; + lshift: low bits cleared]"""
+    a = synth(sp["kind"], sp["seed"], sp["rate"], sp["nch"], sp["n"], sp["bps"])
+    if "first" in sp:
+        a = np.ascontiguousarray(a[:, sp["first"]:sp["first"] + sp["count"]])
+    if sp.get("lshift"):
+        a = np.ascontiguousarray((a >> sp["lshift"]) << sp["lshift"])
+    return a
+
+
 def sha256(arr):
     return hashlib.sha256(np.ascontiguousarray(arr).tobytes()).hexdigest()
 

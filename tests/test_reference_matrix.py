@@ -30,7 +30,7 @@ def matrix_inputs():
 
 def _triple_input(t):
     sp = t["input"]
-    pcm = helpers.synth(sp["kind"], sp["seed"], sp["rate"], sp["nch"], sp["n"], sp["bps"])
+    pcm = helpers.synth_spec(sp)
     assert helpers.sha256(pcm) == t["input_sha256"]
     return pcm
 
@@ -56,7 +56,7 @@ def test_oracle_reproduces_the_reference_matrix(matrix_inputs):
         assert data.size == gold["srl_size"] and helpers.sha256(data) == gold["srl_sha256"], gold["name"]
 
 
-@pytest.mark.parametrize("t", [t for t in TRIPLES if t["input"]["n"] * t["input"]["nch"] <= 130000 and not (t["cli"].get("svr_iterations") and t["cli"]["preset"] > 0)],
+@pytest.mark.parametrize("t", [t for t in TRIPLES if t["input"].get("count", t["input"]["n"]) * t["input"]["nch"] <= 130000 and not (t["cli"].get("svr_iterations") and t["cli"]["preset"] > 0)],
                          ids=lambda t: t["name"])
 def test_oracle_reproduces_the_reference_on_explicit_triples(t):
     pcm = _triple_input(t)

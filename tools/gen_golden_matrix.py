@@ -68,6 +68,20 @@ TRIPLE_INPUTS = [
 ]
 
 
+# Inputs of their own.  "impulses": identical impulse trains in both channels between silent stretches, behind a busy block (a slice of
+# the "varied" generator, low three bits cleared) -- S = R - L is ALL ZERO in blocks that are not silent, so with an odd block length the
+# analysis of S sees nothing but the word the Welch window leaves untouched (lpc.c:260-264): rounding noise of the call before.  The
+# long-term predictor then finds its "pitch" among the stale words beyond the FFT buffer and solves for taps of 1e30 and more, which
+# the reference converts to int32 out of range (srla_encoder.c:1031-1037) -- found by tools/gpu_sweep.py, seed 42 case 37, round 4.
+IMPULSES = dict(kind=VARIED, seed=5037, rate=48000, nch=2, n=160000, bps=16, first=143000, count=11000, lshift=3)
+EXTRA = [
+    ("impulses", IMPULSES, "min125_max1000_L1375_m4_P3", dict(preset=4, min_block=125, max_block=1000, lookahead=1375, ltp_order=3)),
+    ("impulses", IMPULSES, "min125_max1000_L1000_m0_P1", dict(preset=0, min_block=125, max_block=1000, lookahead=1000, ltp_order=1)),
+    ("impulses", IMPULSES, "B999_V0_m2_P3", dict(preset=2, min_block=999, max_block=999, lookahead=3996, ltp_order=3)),
+    ("impulses", IMPULSES, "B4096_V2_m4_P3", dict(preset=4, max_block=4096, divisions=2, ltp_order=3)),
+]
+
+
 def run_fresh(job):
     with tempfile.TemporaryDirectory() as d:
         src, dst = os.path.join(d, "job.pkl"), os.path.join(d, "out.pkl")
@@ -105,8 +119,10 @@ def main():
         for iname, sp in TRIPLE_INPUTS:
             if cli.get("svr_iterations") and cli["preset"] > 0:
                 sp = dict(sp, n=min(sp["n"], 20001 if sp["n"] & 1 else 20000))     # the refinement is slow in the reference too
-            pcm = helpers.synth(sp["kind"], sp["seed"], sp["rate"], sp["nch"], sp["n"], sp["bps"])
+            pcm = helpers.synth_spec(sp)
             jobs.append(("triple_%s_%s" % (iname, cname), sp, cli, pcm))
+    for iname, sp, cname, cli in EXTRA:
+        jobs.append(("triple_%s_%s" % (iname, cname), sp, cli, helpers.synth_spec(sp)))
     outs = list(pool.map(lambda j: run_fresh(dict(kind="triple", pcm=j[3], bps=j[1]["bps"], rate=j[1]["rate"], cli=j[2])), jobs))
     triples = []
     for (name, sp, cli, pcm), (data,) in zip(jobs, outs):
