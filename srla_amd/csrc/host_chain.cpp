@@ -188,7 +188,7 @@ bool Impl::chain_stage_a(Slot &s, uint32_t jobidx, const ChainJob &cj)
             rc |= srla_launch_lpc_solve(W, &jp, s.d_items.as<SrlaItemDesc>(), d_geoms.as<SrlaGeom>(), s.d_lags.as<double>(), s.d_err.as<double>(),
                                         d_huff.as<uint8_t>(), s.d_results.as<SrlaItemResult>(), nullptr, s.d_ties.as<uint32_t>(), nullptr, nullptr,
                                         s.in_cur, s.d_coef_ws.as<double>(), par.num_svr_filter_learning_iteration,
-                                        std::min<uint32_t>(par.max_num_samples_per_block, 8192u), d_svr_scratch.p, kSvrGroups, s.d_gamma.as<double>(), &ex);
+                                        std::min<uint32_t>(par.max_num_samples_per_block, 8192u), d_svr_scratch_chain.p, kSvrGroups, s.d_gamma.as<double>(), &ex);
         }
     }
     s.b_done = svr_rounds;

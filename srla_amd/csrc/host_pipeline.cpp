@@ -54,7 +54,7 @@ Impl::~Impl()
         if (ev_or) (void)hipEventDestroy(ev_or);
         if (ev_ref) (void)hipEventDestroy(ev_ref);
         h_or.release();
-        d_tw.release(); d_geoms.release(); d_thr.release(); d_huff.release(); d_huffcode.release(); d_pos.release(); d_or.release(); d_oracc.release(); d_svr_scratch.release();
+        d_tw.release(); d_geoms.release(); d_thr.release(); d_huff.release(); d_huffcode.release(); d_pos.release(); d_or.release(); d_oracc.release(); d_svr_scratch.release(); d_svr_scratch_chain.release();
         d_chain_pool.release(); d_chain_tab.release();
         for (auto &b : d_chain_list) b.release();
         for (auto &b : d_chain_select) b.release();
@@ -356,7 +356,8 @@ bool Impl::prepare_job(Slot &s, bool want_dbg)
         const uint32_t max_order = preset_order();
         if (!s.d_coef_ws.ensure(std::max<size_t>(1, n_items) * (max_order <= 64 ? 64 : 256) * sizeof(double))) return false;
         if ((max_order > 64 || par.max_num_samples_per_block > 8192u) &&
-            !d_svr_scratch.ensure((size_t)kSvrGroups * srla_svr_big_scratch_bytes(par.max_num_samples_per_block))) return false;
+            (!d_svr_scratch.ensure((size_t)kSvrGroups * srla_svr_big_scratch_bytes(par.max_num_samples_per_block)) ||
+             !d_svr_scratch_chain.ensure((size_t)kSvrGroups * srla_svr_big_scratch_bytes(par.max_num_samples_per_block)))) return false;
     }
     if (want_dbg && !s.d_dbg.ensure(std::max<size_t>(1, n_items) * SRLA_DBG_STRIDE * sizeof(double))) return false;
     const uint32_t lag_rows = std::max<uint32_t>(par.ltp_order > 0 ? SRLA_LTP_LAGS : 0u, preset_order() + 1);

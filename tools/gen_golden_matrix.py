@@ -79,6 +79,12 @@ EXTRA = [
     ("impulses", IMPULSES, "min125_max1000_L1000_m0_P1", dict(preset=0, min_block=125, max_block=1000, lookahead=1000, ltp_order=1)),
     ("impulses", IMPULSES, "B999_V0_m2_P3", dict(preset=2, min_block=999, max_block=999, lookahead=3996, ltp_order=3)),
     ("impulses", IMPULSES, "B4096_V2_m4_P3", dict(preset=4, max_block=4096, divisions=2, ltp_order=3)),
+    # one look-ahead window and a tail whose last block (160 samples) is shorter than the LTP's 263 lags: ONE regular job beside the chain-mode
+    # window, both with the SVR refinement of order 255 in global scratch (tools/gpu_sweep.py, seed 48 case 60, round 4: a shared scratch region)
+    ("sine_window_and_tail", dict(kind=0, seed=5060, rate=48000, nch=2, n=32416, bps=16), "min1536_max4608_L16896_m6_P1_svr1",
+     dict(preset=6, min_block=1536, max_block=4608, lookahead=16896, ltp_order=1, svr_iterations=1)),
+    ("sine_window_and_tail", dict(kind=0, seed=5060, rate=48000, nch=2, n=32416, bps=16), "min1536_max4608_L16896_m5_P1_svr2",
+     dict(preset=5, min_block=1536, max_block=4608, lookahead=16896, ltp_order=1, svr_iterations=2)),
 ]
 
 

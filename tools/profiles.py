@@ -58,16 +58,21 @@ def sh(cmd, log, timeout):
             return -1
 
 
-def collect(tag, configs, passes):
+def collect(tag, configs, passes, bench_only=False):
     out = os.path.join(ROOT, "gpurun_out", tag)
     os.makedirs(out, exist_ok=True)
     bench = "python %s/bench.py" % ROOT
     for cfg in configs:
         d = os.path.join(out, cfg)
         os.makedirs(d, exist_ok=True)
-        sh("rocprofv3 --kernel-trace --stats --output-format csv -d %s/stats -o run -- %s --config %s --steps 3 --warmup 1 --no-cpu-baseline --no-extras"
-           % (d, bench, cfg), d + "/bench_under_rocprof.log", 900)
+        if not bench_only:
+            sh("rocprofv3 --kernel-trace --stats --output-format csv -d %s/stats -o run -- %s --config %s --steps 3 --warmup 1 --no-cpu-baseline --no-extras"
+               % (d, bench, cfg), d + "/bench_under_rocprof.log", 900)
+        # (--bench-only: the line again once the summary of THIS round is in profiles/, so that its stage table and dominant_kernel
+        # are priced with this round's counters and kernel_stats.csv)
         sh("%s --config %s --steps 20 --warmup 3 --no-cpu-baseline" % (bench, cfg), d + "/bench.log", 900)
+        if bench_only:
+            continue
         pmc = "%s --config %s --steps 1 --warmup 0 --calls-per-step 1 --seconds %s --files 1 --no-cpu-baseline --no-extras" % (bench, cfg, PMC_SECONDS)
         for p in passes:
             sh("rocprofv3 --kernel-trace --pmc %s --output-format csv -d %s/%s -o run -- %s" % (PASSES[p], d, p, pmc), "%s/%s.log" % (d, p), 600)
@@ -227,8 +232,9 @@ def main():
         ap.add_argument("--tag", default="r04")
         ap.add_argument("--configs", default="M,C2,C3,C4,C5")
         ap.add_argument("--passes", default=",".join(PASSES))
+        ap.add_argument("--bench-only", action="store_true")
         a = ap.parse_args()
-        collect(a.tag, a.configs.split(","), a.passes.split(","))
+        collect(a.tag, a.configs.split(","), a.passes.split(","), a.bench_only)
     elif len(sys.argv) == 4 and sys.argv[1] == "summarize":
         summarize(sys.argv[2], sys.argv[3])
     else:
