@@ -22,7 +22,7 @@ extern "C" {
 #endif
 
 #define ORACLE_MAX_CHANNELS 8
-#define ORACLE_MAX_NODES    132   /* look-ahead / minimum block + 1 */
+#define ORACLE_MAX_NODES    1025  /* look-ahead / minimum block + 1 */
 #define ORACLE_MAX_ORDER    255
 #define ORACLE_LTP_TAPS     3
 

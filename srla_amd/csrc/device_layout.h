@@ -17,7 +17,7 @@
 
 #define SRLA_MAX_CH          8
 #define SRLA_MAX_ORDER       255
-#define SRLA_MAX_NODES       129     /* lookahead / min block + 1 */
+#define SRLA_MAX_NODES       1025    /* lookahead / min block + 1 (`srla -e -V 8` at the default look-ahead factor 4; 129 until round 4) */
 #define SRLA_MAX_PORDER      10      /* srla_coder.c:18 */
 #define SRLA_LTP_MIN_PERIOD  8
 #define SRLA_LTP_MAX_PERIOD  262

@@ -90,6 +90,7 @@ struct Job {
     std::vector<Group> groups;
     std::vector<uint32_t> seg_first_window;   /* per segment (+ one past the end) */
     uint32_t num_slots = 0;
+    uint32_t max_nodes = 2, max_window_cands = 1;   /* of a window of the job (srla_price_windows: LDS size, global fallback) */
     uint64_t res_elems = 0;
     bool keep_residuals = false;
     uint64_t analyzed_samples = 0;
@@ -122,6 +123,7 @@ struct Slot {
     uint32_t out_boost = 1;              /* stream-out workgroup multiplier (the last jobs of a stream drain faster) */
     DevBuf d_pcm;                        /* PCM input: the job's frames as uploaded, de-interleaved into d_input by srla_deinterleave */
     DevBuf d_input16;                    /* host input of at most 16 bits crosses PCIe as int16 and is widened into d_input */
+    DevBuf d_price_ws;                   /* srla_price_windows: two words per candidate, for windows whose candidates do not fit LDS */
     DevBuf d_var16, d_var32, d_var_flag; /* the job's variant planes (srla_make_variants, SrlaJobParams::var16 / var32 / var_flag) */
     hipEvent_t ev_var = nullptr;         /* ... are complete */
     bool var_ready = false;              /* ... exist for the job in this slot (stage A of run_stage made them) */

@@ -36,7 +36,7 @@ Impl::~Impl()
             for (auto &e : s.t1) if (e) (void)hipEventDestroy(e);
             if (s.ev_in) (void)hipEventDestroy(s.ev_in);
             if (s.ev_var) (void)hipEventDestroy(s.ev_var);
-            s.d_var16.release(); s.d_var32.release(); s.d_var_flag.release();
+            s.d_var16.release(); s.d_var32.release(); s.d_var_flag.release(); s.d_price_ws.release();
             for (hipEvent_t e : { s.ev_a1, s.ev_p0, s.ev_p, s.ev_a0, s.ev_pk, s.ev_dma }) if (e) (void)hipEventDestroy(e);
             s.d_input16.release(); s.d_pcm.release();
             DevBuf *db[] = { &s.d_input, &s.d_items, &s.d_cands, &s.d_windows, &s.d_results, &s.d_res_ws,
@@ -564,8 +564,14 @@ bool Impl::run_stage(Slot &s, int st, int part)
     case ST_D:
         HIP_OK(hipStreamWaitEvent(N, s.t1[ST_C], 0));
         if (jp.num_windows) {
+            uint32_t *price_ws = nullptr;
+            if (job.max_window_cands > srla_price_lds_cands()) {
+                if (!s.d_price_ws.ensure(std::max<size_t>(16, job.cands.size() * 8))) return false;
+                price_ws = s.d_price_ws.as<uint32_t>();
+            }
             rc |= srla_launch_price(N, &jp, s.d_windows.as<SrlaWindowDesc>(), s.d_cands.as<SrlaCandDesc>(),
-                                    s.d_results.as<SrlaItemResult>(), s.d_blocks.as<SrlaBlockRecord>(), ev0, s.t1[ST_D]);
+                                    s.d_results.as<SrlaItemResult>(), s.d_blocks.as<SrlaBlockRecord>(), ev0, s.t1[ST_D],
+                                    job.max_nodes, job.max_window_cands, price_ws);
         } else { if (ev0) HIP_OK(hipEventRecord(ev0, N)); HIP_OK(hipEventRecord(s.t1[ST_D], N)); }
         break;
     case ST_E:

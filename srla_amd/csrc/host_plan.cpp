@@ -101,7 +101,7 @@ void Impl::build_job(Job &job, const JobPlan &plan, const std::vector<uint32_t> 
     job.segs = plan.segs; job.seg_lshift = lshift; job.total = plan.total;
     job.windows.clear(); job.cands.clear(); job.items.clear(); job.groups.clear(); job.class_index.clear(); job.svr_rows.clear();
     job.seg_first_window.clear();
-    job.num_slots = 0; job.res_elems = 0; job.analyzed_samples = 0;
+    job.num_slots = 0; job.res_elems = 0; job.analyzed_samples = 0; job.max_nodes = 2; job.max_window_cands = 1;
     job.keep_residuals = keep_residuals || keep_residuals_always;
 
     struct Pending { uint32_t cand; uint32_t nfft; uint32_t seg; };
@@ -118,6 +118,7 @@ void Impl::build_job(Job &job, const JobPlan &plan, const std::vector<uint32_t> 
             wd.block_base = job.num_slots;
             wd.seg = sg;
             job.num_slots += wd.num_nodes - 1;
+            job.max_nodes = std::max(job.max_nodes, wd.num_nodes);
             const uint32_t w = (uint32_t)job.windows.size();
             auto add_cand = [&](uint32_t i, uint32_t j, uint32_t off, uint32_t n) {
                 SrlaCandDesc cd{};
@@ -138,6 +139,7 @@ void Impl::build_job(Job &job, const JobPlan &plan, const std::vector<uint32_t> 
                     }
             }
             wd.num_cands = (uint32_t)job.cands.size() - wd.cand_base;
+            job.max_window_cands = std::max(job.max_window_cands, wd.num_cands);
             job.windows.push_back(wd);
             pos += wn;
         }
@@ -264,6 +266,13 @@ uint32_t Impl::windows_per_job(bool search) const
         per_window *= ratio;
     }
     uint64_t w = (1536ull << 20) / std::max<uint64_t>(per_window, 1);
+    if (search) {
+        /* ... and by the item tables (1.4 KB of result record and up to 2 KB of lags per item): about a million items per job -- only
+         * parameters with hundreds of minimum blocks per window get there (`-V 6`: 57 000 items per window) */
+        const uint64_t nodes = par.num_lookahead_samples / par.min_num_samples_per_block;
+        const uint64_t ratio = par.max_num_samples_per_block / par.min_num_samples_per_block;
+        w = std::min<uint64_t>(w, std::max<uint64_t>(1, (1ull << 20) / std::max<uint64_t>(1, nodes * ratio * num_variants())));
+    }
     const uint64_t cap_samples = job_samples;  /* several jobs per stream so that the GPU and the host pack overlap */
     w = std::min<uint64_t>(w, std::max<uint64_t>(1, cap_samples / window_len));
     return (uint32_t)std::max<uint64_t>(1, w);

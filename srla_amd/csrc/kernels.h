@@ -90,8 +90,11 @@ int srla_launch_residual_cost(hipStream_t stream, int rclass, const SrlaJobParam
                               hipEvent_t ev_start, hipEvent_t ev_stop);
 
 int srla_launch_price(hipStream_t stream, const SrlaJobParams *jp, const SrlaWindowDesc *windows,
-                      const SrlaCandDesc *cands, const SrlaItemResult *results, SrlaBlockRecord *blocks,
-                      hipEvent_t ev_start, hipEvent_t ev_stop);
+                      const SrlaCandDesc *cands, const SrlaItemResult *results,
+                      SrlaBlockRecord *blocks, hipEvent_t ev_start, hipEvent_t ev_stop,
+                      uint32_t max_nodes /* of a window of the job */, uint32_t max_window_cands,
+                      uint32_t *price_ws /* two words per candidate of the job; needed when max_window_cands > srla_price_lds_cands() */);
+uint32_t srla_price_lds_cands(void);
 
 /* srla_block_offsets + srla_pack_blocks + srla_stream_out: the job's blocks, complete, assembled in the device
  * buffer `stage` and then moved, segment by segment (device_layout.h: SrlaSegDesc), to their byte offsets of their

@@ -3356,7 +3356,10 @@ __global__ __launch_bounds__(WAVE) void srla_lpc_quantize_ws(SrlaJobParams jp, c
  * ApplyDijkstraMethod (:249-307) with its exact tie behaviour (lowest-index minimum, strict
  * improvement), the node scan and the edge relaxation spread over the lanes; partition read-back
  * (:397-421), one block record per lane. */
-#define SRLA_MAX_WINDOW_CANDS (SRLA_MAX_NODES * (SRLA_MAX_NODES - 1) / 2)
+/* candidates of a window whose prices and end nodes are kept in LDS (8 bytes each); a window with more keeps them in a global
+ * workspace (look-ahead / minimum block above 128 with a large maximum / minimum: slow, and so is everything else about such
+ * parameters -- a window of `srla -e -V 7` has 57 000 candidates) */
+#define SRLA_PRICE_LDS_CANDS 14400u
 
 __device__ __forceinline__ uint64_t wave_min_u64(uint64_t v)
 {
@@ -3371,16 +3374,21 @@ __device__ __forceinline__ uint64_t wave_min_u64(uint64_t v)
 __global__ __launch_bounds__(WAVE) void srla_price_windows(SrlaJobParams jp, const SrlaWindowDesc *__restrict__ windows,
                                                            const SrlaCandDesc *__restrict__ cands,
                                                            const SrlaItemResult *__restrict__ results,
-                                                           SrlaBlockRecord *__restrict__ blocks)
+                                                           SrlaBlockRecord *__restrict__ blocks, uint32_t lds_nodes, uint32_t lds_cands,
+                                                           uint32_t *__restrict__ price_ws)
 {
     NARROW_KERNEL_PRIORITY();
-    __shared__ uint32_t s_packed[SRLA_MAX_WINDOW_CANDS];
-    __shared__ uint8_t s_ni[SRLA_MAX_WINDOW_CANDS], s_nj[SRLA_MAX_WINDOW_CANDS];
-    __shared__ uint32_t s_cost[SRLA_MAX_NODES], s_path[SRLA_MAX_NODES], s_via[SRLA_MAX_NODES], s_used[SRLA_MAX_NODES];
-    __shared__ uint32_t s_order[SRLA_MAX_NODES];
+    /* dynamic LDS: five words per node (+ one: s_first has nodes + 1 entries), then the candidates' prices and end nodes -- of a
+     * window of at most lds_cands candidates; a larger one keeps them in price_ws (two words per candidate of the job) */
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    uint32_t *s_cost = (uint32_t *)lds, *s_path = s_cost + lds_nodes, *s_via = s_path + lds_nodes, *s_used = s_via + lds_nodes;
+    uint32_t *s_order = s_used + lds_nodes, *s_first = s_order + lds_nodes;
     const uint32_t w = blockIdx.x, lane = threadIdx.x;
     const SrlaWindowDesc wd = windows[w];
     const uint32_t nch = jp.num_channels, bps = jp.bits_per_sample, nodes = wd.num_nodes;
+    const bool in_lds = wd.num_cands <= lds_cands;
+    uint32_t *s_packed = in_lds ? (s_first + lds_nodes + 1u) : (price_ws + 2u * (size_t)wd.cand_base);
+    uint32_t *s_nij = s_packed + (in_lds ? lds_cands : wd.num_cands);          /* node_i | node_j << 16 */
 
     for (uint32_t c = lane; c < wd.num_cands; c += WAVE) {
         const SrlaCandDesc cd = cands[wd.cand_base + c];
@@ -3408,10 +3416,21 @@ __global__ __launch_bounds__(WAVE) void srla_price_windows(SrlaJobParams jp, con
             }
         }
         s_packed[c] = bytes | (type << 28) | (method << 30);
-        s_ni[c] = (uint8_t)cd.node_i; s_nj[c] = (uint8_t)cd.node_j;
+        s_nij[c] = cd.node_i | (cd.node_j << 16);
     }
     for (uint32_t i = lane; i < nodes; i += WAVE) {
         s_cost[i] = (i == 0) ? 0u : SRLA_BIG_WEIGHT; s_path[i] = 0xFFFFFFFFu; s_via[i] = 0xFFFFFFFFu; s_used[i] = 0;
+        s_first[i] = wd.num_cands;
+    }
+    if (lane == 0) s_first[nodes] = wd.num_cands;
+    __threadfence();                 /* (the candidates' words may stand in global memory: price_ws) */
+    __syncthreads();
+    /* the candidates stand in the order of their start node (host_plan.cpp: i outer, j inner): s_first[i] = the first one leaving
+     * node i, so that a step of the search looks at the edges of ITS node only (all of a window's candidates per step cost
+     * nodes x candidates: 15 million visits for a window of 257 nodes) */
+    for (uint32_t c = lane; c < wd.num_cands; c += WAVE) {
+        const uint32_t ni = s_nij[c] & 0xFFFFu;
+        if (c == 0 || (s_nij[c - 1] & 0xFFFFu) != ni) s_first[ni] = c;
     }
     __syncthreads();
     /* shortest path 0 -> nodes-1 over candidate edges */
@@ -3420,15 +3439,16 @@ __global__ __launch_bounds__(WAVE) void srla_price_windows(SrlaJobParams jp, con
         /* first unused node whose cost is below BIG and minimal (`mn > cost[i]`, ascending i) */
         uint64_t key = ~0ull;
         for (uint32_t i = lane; i < nodes; i += WAVE)
-            if (!s_used[i] && s_cost[i] < SRLA_BIG_WEIGHT) { const uint64_t k = ((uint64_t)s_cost[i] << 8) | i; key = (k < key) ? k : key; }
+            if (!s_used[i] && s_cost[i] < SRLA_BIG_WEIGHT) { const uint64_t k = ((uint64_t)s_cost[i] << 11) | i; key = (k < key) ? k : key; }
         key = wave_min_u64(key);
-        if (key != ~0ull) target = (uint32_t)(key & 0xFFu);
+        if (key != ~0ull) target = (uint32_t)(key & 0x7FFu);
         if (target == nodes - 1) break;
         const uint32_t base_cost = s_cost[target];
         /* relax every edge leaving `target`; its edges end on distinct nodes, so the lanes never collide */
-        for (uint32_t c = lane; c < wd.num_cands; c += WAVE) {
-            if (s_ni[c] != target) continue;
-            const uint32_t j = s_nj[c];
+        /* (every node but the last has the candidate (i, i + 1), so node i's run ends where node i + 1's starts) */
+        for (uint32_t c = s_first[target] + lane; c < s_first[target + 1]; c += WAVE) {
+            if ((s_nij[c] & 0xFFFFu) != target) continue;
+            const uint32_t j = s_nij[c] >> 16;
             const uint32_t via = (s_packed[c] & 0x0FFFFFFFu) + base_cost;
             if (s_cost[j] > via) { s_cost[j] = via; s_path[j] = target; s_via[j] = c; }
         }
@@ -4507,13 +4527,22 @@ extern "C" int srla_launch_residual_cost_big(hipStream_t stream, const SrlaJobPa
     return (hipGetLastError() == hipSuccess) ? 0 : -2;
 }
 
+extern "C" uint32_t srla_price_lds_cands(void) { return SRLA_PRICE_LDS_CANDS; }
+
 extern "C" int srla_launch_price(hipStream_t stream, const SrlaJobParams *jp, const SrlaWindowDesc *windows,
                                  const SrlaCandDesc *cands, const SrlaItemResult *results,
-                                 SrlaBlockRecord *blocks, hipEvent_t ev_start, hipEvent_t ev_stop)
+                                 SrlaBlockRecord *blocks, hipEvent_t ev_start, hipEvent_t ev_stop,
+                                 uint32_t max_nodes, uint32_t max_window_cands, uint32_t *price_ws)
 {
     if (jp->num_windows == 0) return 0;
-    hipExtLaunchKernelGGL(srla_price_windows, dim3(jp->num_windows), dim3(WAVE), 0, stream, ev_start, ev_stop, 0,
-                       *jp, windows, cands, results, blocks);
+    /* LDS for the largest window of the job: its nodes, and its candidates where they fit (else price_ws, which the caller sized
+     * for two words per candidate of the job) */
+    const uint32_t lds_nodes = max_nodes, lds_cands = (max_window_cands <= SRLA_PRICE_LDS_CANDS) ? max_window_cands : 0u;
+    if (max_window_cands > SRLA_PRICE_LDS_CANDS && price_ws == nullptr) return -1;
+    const uint32_t lds = (6u * lds_nodes + 1u + 2u * lds_cands) * 4u + 16u;
+    SET_LDS_ATTR(srla_price_windows);
+    hipExtLaunchKernelGGL(srla_price_windows, dim3(jp->num_windows), dim3(WAVE), lds, stream, ev_start, ev_stop, 0,
+                       *jp, windows, cands, results, blocks, lds_nodes, lds_cands, price_ws);
     return (hipGetLastError() == hipSuccess) ? 0 : -2;
 }
 

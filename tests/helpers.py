@@ -217,7 +217,7 @@ class Oracle:
         return out.value
 
     def search_partitions(self, pcm):
-        parts = (C.c_uint32 * 132)()
+        parts = (C.c_uint32 * 1100)()
         n = C.c_uint32(0)
         rc = self.lib.oracle_search_partitions(self.h, capi.planar_ptrs(pcm), pcm.shape[1], C.byref(n), parts)
         if rc != 0:

@@ -81,6 +81,11 @@ EXTRA = [
     ("impulses", IMPULSES, "B4096_V2_m4_P3", dict(preset=4, max_block=4096, divisions=2, ltp_order=3)),
     # one look-ahead window and a tail whose last block (160 samples) is shorter than the LTP's 263 lags: ONE regular job beside the chain-mode
     # window, both with the SVR refinement of order 255 in global scratch (tools/gpu_sweep.py, seed 48 case 60, round 4: a shared scratch region)
+    # more than 128 minimum blocks per look-ahead window (the library's limit until round 4): `srla -e -B 4096 -V 6` (257 search nodes,
+    # 14 368 candidates per window), 513 nodes with the candidates beyond the pricing kernel's LDS, 513 nodes in history mode
+    ("music_40000", dict(kind=MUSIC, seed=95, rate=48000, nch=2, n=40000, bps=16), "B4096_V6_m2", dict(preset=2, max_block=4096, divisions=6)),
+    ("music_40000", dict(kind=MUSIC, seed=95, rate=48000, nch=2, n=40000, bps=16), "B2048_V6_L8_m1", dict(preset=1, max_block=2048, divisions=6, lookahead_factor=8)),
+    ("varied_40001", dict(kind=VARIED, seed=96, rate=48000, nch=2, n=40001, bps=16), "B1024_V4_L32_m2_P3", dict(preset=2, max_block=1024, divisions=4, lookahead_factor=32, ltp_order=3)),
     ("sine_window_and_tail", dict(kind=0, seed=5060, rate=48000, nch=2, n=32416, bps=16), "min1536_max4608_L16896_m6_P1_svr1",
      dict(preset=6, min_block=1536, max_block=4608, lookahead=16896, ltp_order=1, svr_iterations=1)),
     ("sine_window_and_tail", dict(kind=0, seed=5060, rate=48000, nch=2, n=32416, bps=16), "min1536_max4608_L16896_m5_P1_svr2",

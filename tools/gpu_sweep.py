@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity sweep on an MI355X: library bytes vs oracle bytes over random configurations and lengths.
 
-    python tools/gpu_sweep.py [cases] [seed]
+    python tools/gpu_sweep.py [cases] [seed] [--mutate]
 
 Any length, odd ones included (the last window of such a stream is history dependent in the reference and goes
 through the library's chain mode); LTP with any minimum block and odd block sizes (history mode: every
@@ -89,19 +89,58 @@ def cases(count, seed, max_samples=6_000_000):
         yield case, nch, bps, n, kind, cli, shifted
 
 
-def make_pcm(case, nch, bps, n, kind, shifted):
+MUTATIONS = ("none", "identical_channels", "one_silent_channel", "sign_flipped", "sparse_impulses", "silent_stretches", "dc_offset", "full_scale_square")
+
+
+def mutation_of(case, seed):
+    """with `--mutate`: one case in three gets a degenerate relation between or inside its channels (a generator of its own: the cases
+    stay what they were) -- all-zero variants, impulses between silence, constants: the inputs whose analysis hangs on history and on
+    out-of-range arithmetic (round 4's two finds were of this kind)"""
+    r = random.Random(seed * 2654435761 + case)
+    return r.choice(MUTATIONS[1:]) if r.random() < 1.0 / 3.0 else "none"
+
+
+def mutate(pcm, how, bps, case):
+    full = (1 << (bps - 1)) - 1
+    a = pcm.copy()
+    r = np.random.RandomState(1000 + case)
+    if how == "identical_channels":
+        a[1:] = a[0]
+    elif how == "one_silent_channel":
+        a[-1] = 0
+    elif how == "sign_flipped" and a.shape[0] > 1:
+        a[1] = np.clip(-a[0].astype(np.int64), -full - 1, full).astype(np.int32)
+    elif how == "sparse_impulses":
+        keep = np.zeros(a.shape[1], dtype=bool)
+        keep[::int(r.randint(40, 900))] = True
+        a[:, ~keep] = 0
+    elif how == "silent_stretches":
+        for _ in range(max(1, a.shape[1] // 20000)):
+            o = int(r.randint(0, max(1, a.shape[1] - 1)))
+            a[:, o:o + int(r.randint(100, 12000))] = 0
+    elif how == "dc_offset":
+        a[:] = np.clip(a // 64 + full // 2, -full - 1, full)
+    elif how == "full_scale_square":
+        a[:] = np.where((np.arange(a.shape[1]) // int(r.randint(3, 200))) % 2 == 0, full, -full - 1).astype(np.int32)
+    return np.ascontiguousarray(a)
+
+
+def make_pcm(case, nch, bps, n, kind, shifted, mutation="none"):
     pcm = helpers.synth(kind, 5000 + case, 48000, nch, n, bps)
+    if mutation != "none":
+        pcm = mutate(pcm, mutation, bps, case)
     if shifted:
         pcm = (pcm >> 3) << 3                           # exercises the offset left shift
     return pcm
 
 
-def sweep(count, seed, max_samples=6_000_000):
+def sweep(count, seed, max_samples=6_000_000, with_mutations=False):
     lib = capi.EncoderLib(helpers.PRODUCT_SO)
     bad = 0
     done = 0
     for case, nch, bps, n, kind, cli, shifted in cases(count, seed, max_samples):
-        pcm = make_pcm(case, nch, bps, n, kind, shifted)
+        mutation = mutation_of(case, seed) if with_mutations else "none"
+        pcm = make_pcm(case, nch, bps, n, kind, shifted, mutation)
         try:
             got = lib.encode(pcm, bits_per_sample=bps, **cli)
         except RuntimeError as e:                        # limits of the implementation are refused loudly
@@ -111,12 +150,13 @@ def sweep(count, seed, max_samples=6_000_000):
         done += 1
         if not np.array_equal(got, want):
             bad += 1
-            print("MISMATCH case %d (seed %d): nch=%d bps=%d n=%d kind=%d %s sizes %d vs %d" % (case, seed, nch, bps, n, kind, cli, got.size, want.size), flush=True)
+            print("MISMATCH case %d (seed %d): nch=%d bps=%d n=%d kind=%d mutation=%s %s sizes %d vs %d" % (case, seed, nch, bps, n, kind, mutation, cli, got.size, want.size), flush=True)
     return done, bad
 
 
 def main():
-    done, bad = sweep(int(sys.argv[1]) if len(sys.argv) > 1 else 150, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    done, bad = sweep(int(args[0]) if len(args) > 0 else 150, int(args[1]) if len(args) > 1 else 1, with_mutations="--mutate" in sys.argv)
     print("sweep: %d compared, %d mismatches" % (done, bad))
     sys.exit(1 if bad else 0)
 
