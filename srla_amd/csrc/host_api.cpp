@@ -112,9 +112,10 @@ SRLAApiResult SRLAEncoder_SetEncodeParameter(struct SRLAEncoder *encoder, const 
         || im->cfg.max_num_channels < p->num_channels) return SRLA_APIRESULT_INSUFFICIENT_BUFFER;
     /* limits of this implementation (documented in DESIGN.md) */
     if (p->num_channels > SRLA_MAX_CH) return SRLA_APIRESULT_INSUFFICIENT_BUFFER;
-    if (p->max_num_samples_per_block > SRLA_MAX_FFT) {
-        fprintf(stderr, "[srla-mi355x] max block size %u exceeds this implementation's limit of %u samples\n",
-                p->max_num_samples_per_block, SRLA_MAX_FFT);
+    if (p->max_num_samples_per_block > 65535u) {
+        /* (a block header holds its sample count in 16 bits, srla_encoder.c:1583-1595: larger blocks cannot be written by the reference either) */
+        fprintf(stderr, "[srla-mi355x] max block size %u exceeds the limit of %u samples\n",
+                p->max_num_samples_per_block, 65535u);
         return SRLA_APIRESULT_INSUFFICIENT_BUFFER;
     }
     if (p->num_lookahead_samples / p->min_num_samples_per_block + 1 > SRLA_MAX_NODES) {

@@ -82,7 +82,7 @@ void Impl::chain_build(uint32_t jobidx, Job &job, ChainJob &cj)
         ai.lshift = it.lshift;
         return ai;
     };
-    auto cls_of = [](uint32_t nfft) { return (nfft <= 1024u) ? 0u : ((nfft <= 2048u) ? 1u : ((nfft <= 4096u) ? 2u : ((nfft <= 8192u) ? 3u : ((nfft <= 16384u) ? 4u : 5u)))); };
+    auto cls_of = [](uint32_t nfft) { return (nfft <= 1024u) ? 0u : ((nfft <= 2048u) ? 1u : ((nfft <= 4096u) ? 2u : ((nfft <= 8192u) ? 3u : ((nfft <= 16384u) ? 4u : ((nfft <= 32768u) ? 5u : 6u))))); };
     cj.select.assign(std::max<size_t>(1, job.items.size()), 0xFFFFFFFFu);
     cj.select_b.assign(std::max<size_t>(1, job.items.size()), 0u);
     cj.rounds = 1;
@@ -167,7 +167,7 @@ bool Impl::chain_stage_a(Slot &s, uint32_t jobidx, const ChainJob &cj)
                 const ChainLaunch &l = cj.launches[li];
                 if (l.cls >= 4)
                     rc |= srla_launch_autocorr_big(W, &jp, s.in_cur, d_tw.p, (uint32_t)pass, s.d_results.as<SrlaItemResult>(), s.d_lags.as<double>(), nullptr,
-                                                   d_chain_list[jobidx].as<SrlaAutocorrItem>() + l.first, l.count, l.cls == 4 ? 16384u : 32768u, nullptr, nullptr,
+                                                   d_chain_list[jobidx].as<SrlaAutocorrItem>() + l.first, l.count, l.cls == 4 ? 16384u : (l.cls == 5 ? 32768u : 65536u), nullptr, nullptr,
                                                    d_chain_pool.as<double>(), d_chain_tab.as<uint32_t>(), s.d_big_scratch.p, SRLA_BIG_GROUPS);
                 else
                 rc |= srla_launch_autocorr(W, kClass[l.cls], &jp, s.in_cur, s.d_items.as<SrlaItemDesc>(), d_geoms.as<SrlaGeom>(), d_tw.p,

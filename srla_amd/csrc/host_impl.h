@@ -43,7 +43,8 @@
 #include "kernels.h"
 
 #define SRLA_HANDLE_MAGIC 0x53524C41u /* 'SRLA' */
-#define SRLA_MAX_FFT      32768u      /* largest block (above 8192 samples: the global-memory slow paths of kernels.hip) */
+#define SRLA_MAX_FFT      65536u      /* largest transform: blocks of up to 65 535 samples, what a block header can say (srla_encoder.c:1583-1595);
+                                       * above 8192 samples: the global-memory slow paths of kernels.hip */
 #define SRLA_BIG_GROUPS   384u        /* persistent workgroups (scratch regions) of srla_autocorr_big */
 
 struct SRLAEncoder {
@@ -95,7 +96,7 @@ struct Job {
     bool keep_residuals = false;
     uint64_t analyzed_samples = 0;
     std::vector<SrlaAutocorrItem> class_index; /* the items grouped by FFT-size class (srla_autocorr launches per class) */
-    uint32_t class_first[7] = {}, class_count[7] = {};   /* N' < 1024, 2048, 4096, 8192, 16384, 32768; N' = 1024 */
+    uint32_t class_first[8] = {}, class_count[8] = {};   /* N' < 1024, 2048, 4096, 8192, 16384, 32768; N' = 1024; N' = 65536 */
     std::vector<uint32_t> big_items;  /* items of more than 8192 samples (srla_residual_cost_big) */
     std::vector<double> svr_rows;     /* rows of 256: SVR-refined predictors the host arbitrated (SrlaItemDesc::forced_svr) */
     uint32_t big_max_n = 0;
@@ -130,6 +131,7 @@ struct Slot {
     DevBuf d_input, d_items, d_cands, d_windows, d_results, d_res_ws, d_blocks, d_block_off, d_scratch, d_dbg, d_lags, d_err, d_gamma, d_class_index, d_stream;
     DevBuf d_segs, d_seg_ctl;            /* SrlaSegDesc per segment; device-side segment records of srla_block_offsets */
     DevBuf d_coef_ws;                    /* SVR refinement: 64 doubles per item, the predictor between solve and quantiser */
+    DevBuf d_big_sig;                    /* srla_residual_cost_big: the signal of blocks above 32768 samples (it no longer fits LDS) */
     DevBuf d_big_scratch, d_big_items;   /* blocks above 8192 samples: FFT scratch in global memory, indices of the big items */
     DevBuf d_svr_rows;                   /* Job::svr_rows on the device */
     DevBuf d_ties, d_tie_data;           /* near-tie list of the job (count + entries), 8 doubles per entry for LTP entries */

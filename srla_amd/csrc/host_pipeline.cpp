@@ -36,7 +36,7 @@ Impl::~Impl()
             for (auto &e : s.t1) if (e) (void)hipEventDestroy(e);
             if (s.ev_in) (void)hipEventDestroy(s.ev_in);
             if (s.ev_var) (void)hipEventDestroy(s.ev_var);
-            s.d_var16.release(); s.d_var32.release(); s.d_var_flag.release(); s.d_price_ws.release();
+            s.d_var16.release(); s.d_var32.release(); s.d_var_flag.release(); s.d_price_ws.release(); s.d_big_sig.release();
             for (hipEvent_t e : { s.ev_a1, s.ev_p0, s.ev_p, s.ev_a0, s.ev_pk, s.ev_dma }) if (e) (void)hipEventDestroy(e);
             s.d_input16.release(); s.d_pcm.release();
             DevBuf *db[] = { &s.d_input, &s.d_items, &s.d_cands, &s.d_windows, &s.d_results, &s.d_res_ws,
@@ -346,8 +346,10 @@ bool Impl::prepare_job(Slot &s, bool want_dbg)
         if (srla_pack_needs_scratch(&probe) && !s.d_scratch.ensure(bound)) return false;
     }
     if (!job.big_items.empty()) {
-        const uint32_t nfft_max = job.big_max_n > 16384u ? 32768u : 16384u;
-        if (!s.d_big_scratch.ensure((size_t)SRLA_BIG_GROUPS * nfft_max * 16u)) return false;
+        const uint32_t nfft_max = job.big_max_n > 32768u ? 65536u : (job.big_max_n > 16384u ? 32768u : 16384u);
+        /* (two transform buffers per workgroup; for 65536 points also the signal, which no longer fits LDS: srla_launch_autocorr_big) */
+        if (!s.d_big_scratch.ensure((size_t)SRLA_BIG_GROUPS * nfft_max * (16u + (nfft_max > 32768u ? 4u : 0u)))) return false;
+        if (job.big_max_n > 32768u && !s.d_big_sig.ensure(job.big_items.size() * (size_t)srla_residual_big_sig_words(job.big_max_n) * 4u)) return false;
         const void *pb = s.d_big_items.p;
         if (!s.d_big_items.ensure(job.big_items.size() * 4)) return false;
         if (pb != s.d_big_items.p) job.uploaded = false;
@@ -452,10 +454,10 @@ bool Impl::run_stage(Slot &s, int st, int part)
             jv.var32 = s.d_var32.as<int32_t>(); jv.var_flag = s.d_var_flag.as<uint32_t>(); jv.var_stride = job.total;
         }
         struct L { int kind, cls, pass; };                       /* kind 0: autocorr class launch, 1: pitch solve */
-        L seq[20]; int nl = 0;
+        L seq[24]; int nl = 0;
         if (have_items) {
             for (int pass = (par.ltp_order > 0) ? 1 : 0; pass >= 0; pass--) {
-                for (int c = 0; c < 7; c++) if (job.class_count[c]) seq[nl++] = { 0, c, pass };
+                for (int c = 0; c < 8; c++) if (job.class_count[c]) seq[nl++] = { 0, c, pass };
                 if (pass == 1) seq[nl++] = { 1, 0, 1 };
             }
         }
@@ -466,8 +468,9 @@ bool Impl::run_stage(Slot &s, int st, int part)
         for (int i = 0; i < nl; i++) if (seq[i].kind == 1) pitch_at = i;
         if (split && part == 1) last = pitch_at;
         if (split && part == 2) { first = pitch_at + 1; HIP_OK(hipStreamWaitEvent(W, s.ev_p, 0)); }
-        static const int kClass[7] = { 0, 1, 2, 4, 0, 0, 0 };     /* FFT size / 2048 (0: at most 1024 points) */
-        static const uint32_t kWaveFft[7] = { 0u, 2048u, 4096u, 8192u, 0u, 0u, 1024u };   /* classes of ONE size that srla_autocorr_w takes */
+        static const int kClass[8] = { 0, 1, 2, 4, 0, 0, 0, 0 };     /* FFT size / 2048 (0: at most 1024 points) */
+        static const uint32_t kWaveFft[8] = { 0u, 2048u, 4096u, 8192u, 0u, 0u, 1024u, 0u };   /* classes of ONE size that srla_autocorr_w takes */
+        static const uint32_t kBigFft[8] = { 0u, 0u, 0u, 0u, 16384u, 32768u, 0u, 65536u };   /* classes of srla_autocorr_big */
         auto start_event = [&](int i) -> hipEvent_t {
             hipEvent_t e = (i == 0) ? ev0 : nullptr;
             if (split) { if (i == pitch_at) e = s.ev_p0; if (i == pitch_at + 1 && s.timed) e = s.ev_a0; }
@@ -493,9 +496,9 @@ bool Impl::run_stage(Slot &s, int st, int part)
             }
             if (seq[i].kind == 0) {
                 const int c = seq[i].cls;
-                if (c == 4 || c == 5)
+                if (kBigFft[c])
                     rc |= srla_launch_autocorr_big(W, &jp, s.in_cur, d_tw.p, (uint32_t)seq[i].pass, s.d_results.as<SrlaItemResult>(), s.d_lags.as<double>(), dbg,
-                                                   s.d_class_index.as<SrlaAutocorrItem>() + job.class_first[c], job.class_count[c], c == 4 ? 16384u : 32768u,
+                                                   s.d_class_index.as<SrlaAutocorrItem>() + job.class_first[c], job.class_count[c], kBigFft[c],
                                                    e0, e1, nullptr, nullptr, s.d_big_scratch.p, SRLA_BIG_GROUPS);
                 else if (wave_fft && kWaveFft[c])
                     rc |= srla_launch_autocorr_wave(W, kWaveFft[c], &jp, s.in_cur, d_tw.p, (uint32_t)seq[i].pass, s.d_results.as<SrlaItemResult>(),
@@ -558,7 +561,8 @@ bool Impl::run_stage(Slot &s, int st, int part)
             if (big)
                 rc |= srla_launch_residual_cost_big(W, &jp, s.in_cur, s.d_items.as<SrlaItemDesc>(), d_geoms.as<SrlaGeom>(), d_thr.as<double>(),
                                                     s.d_res_ws.as<int32_t>(), s.d_results.as<SrlaItemResult>(), s.d_big_items.as<uint32_t>(),
-                                                    (uint32_t)job.big_items.size(), job.big_max_n, nullptr, s.t1[ST_C]);
+                                                    (uint32_t)job.big_items.size(), job.big_max_n, nullptr, s.t1[ST_C],
+                                                    job.big_max_n > 32768u ? s.d_big_sig.as<int32_t>() : nullptr);
         } else { if (timing) HIP_OK(hipEventRecord(s.t0[ST_C], W)); HIP_OK(hipEventRecord(s.t1[ST_C], W)); }
         break;
     case ST_D:

@@ -211,13 +211,13 @@ void Impl::build_job(Job &job, const JobPlan &plan, const std::vector<uint32_t> 
         if (job.items[i].n > 8192u) { job.big_items.push_back(i); job.big_max_n = std::max(job.big_max_n, job.items[i].n); }
     job.class_index.clear();
     job.class_index.reserve(job.items.size());
-    for (int c = 0; c < 7; c++) {
+    for (int c = 0; c < 8; c++) {
         job.class_first[c] = (uint32_t)job.class_index.size();
         for (uint32_t i = 0; i < job.items.size(); i++) {
             const SrlaItemDesc &it = job.items[i];
             const SrlaGeom &gm = geoms[it.geom];
             const uint32_t nfft = gm.nfft;
-            const int cls = (nfft < 1024u) ? 0 : (nfft == 1024u) ? 6 : ((nfft <= 2048u) ? 1 : ((nfft <= 4096u) ? 2 : ((nfft <= 8192u) ? 3 : ((nfft <= 16384u) ? 4 : 5))));
+            const int cls = (nfft < 1024u) ? 0 : (nfft == 1024u) ? 6 : ((nfft <= 2048u) ? 1 : ((nfft <= 4096u) ? 2 : ((nfft <= 8192u) ? 3 : ((nfft <= 16384u) ? 4 : ((nfft <= 32768u) ? 5 : 7)))));
             if (cls == c) {
                 SrlaAutocorrItem ai{};
                 ai.item = i; ai.sample_off = it.sample_off; ai.n = it.n; ai.variant = it.variant;

@@ -59,9 +59,11 @@ int srla_launch_autocorr_big(hipStream_t stream, const SrlaJobParams *jp, const 
                              uint32_t count, uint32_t nfft, hipEvent_t ev_start, hipEvent_t ev_stop, double *chain_pool,
                              const uint32_t *chain_tab, void *scratch, uint32_t scratch_groups);
 /* the items of more than 8192 samples (big_items: their indices), which srla_residual_cost leaves alone */
+uint32_t srla_residual_big_sig_words(uint32_t max_n);
 int srla_launch_residual_cost_big(hipStream_t stream, const SrlaJobParams *jp, const int32_t *input, const SrlaItemDesc *items,
                                   const SrlaGeom *geoms, const double *rice_thresholds, int32_t *res_ws, SrlaItemResult *results,
-                                  const uint32_t *big_items, uint32_t count, uint32_t max_n, hipEvent_t ev_start, hipEvent_t ev_stop);
+                                  const uint32_t *big_items, uint32_t count, uint32_t max_n, hipEvent_t ev_start, hipEvent_t ev_stop,
+                                  int32_t *sig_ws /* blocks above 32768 samples: count x srla_residual_big_sig_words(max_n) words */);
 /* History mode (host_chain.cpp): folds the buffers the calls of a phase left in the chain pool into the first words of the pool
  * -- the reference's persistent FFT buffer as the next phase finds it.  Word i of [lo[k], hi[k]) comes from pool[src[k] + i]: the
  * segments say which call was the last to write which words (a transform writes its whole length, an SVR refinement the

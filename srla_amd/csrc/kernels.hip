@@ -2774,14 +2774,19 @@ __device__ cplx *fft_complex_global(cplx *src, cplx *dst, uint32_t m, int flag, 
 }
 
 /* srla_autocorr for items of more than 8192 points: persistent workgroups (each owns 2 x nfft / 2 complex of scratch) */
+/* YGLOBAL: the 65536-point class -- the pre-emphasised signal in global memory (ywork) instead of LDS.  Two instantiations, so that
+ * either form addresses ONE address space (a pointer that may be LDS or global makes every access a flat one). */
+template <bool YGLOBAL>
 __global__ __launch_bounds__(NTB) void srla_autocorr_big(
     SrlaJobParams jp, const int32_t *__restrict__ input, const cplx *__restrict__ twiddles, uint32_t pass,
     SrlaItemResult *__restrict__ results, double *__restrict__ lags_ws, double *__restrict__ dbg,
     const SrlaAutocorrItem *__restrict__ class_items, uint32_t count, double *__restrict__ chain_pool,
-    const uint32_t *__restrict__ chain_tab, cplx *__restrict__ scratch, uint32_t scratch_stride /* cplx per workgroup */)
+    const uint32_t *__restrict__ chain_tab, cplx *__restrict__ scratch, uint32_t scratch_stride /* cplx per workgroup */,
+    int32_t *__restrict__ ywork /* 65536-point items: nfft words per workgroup in global memory instead of LDS (256 KB), else null */)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    int32_t *ylds = (int32_t *)lds;                               /* nfft words: the pre-emphasised signal (LTP filter) */
+    int32_t *ylds;                                                /* nfft words: the pre-emphasised signal (LTP filter) */
+    if constexpr (YGLOBAL) ylds = ywork + (size_t)blockIdx.x * scratch_stride; else ylds = (int32_t *)lds;
     __shared__ long long s_l[2 * (NTB / WAVE)];
     __shared__ uint32_t s_u[NTB / WAVE];
     __shared__ int32_t s_coef;
@@ -2919,15 +2924,19 @@ __global__ __launch_bounds__(NTB) void srla_autocorr_big(
 /* srla_residual_cost for blocks of more than 8192 samples: ONE int32 buffer in LDS (pre-emphasised signal -> long-term
  * predictor -> FIR residual -> zig-zag residual, each rewritten in place from the top of the block down: every output reads
  * only lower indices), then the shared Rice search. */
+template <bool SIG_GLOBAL /* blocks above 32768 samples: the signal in sig_ws (global) instead of LDS */>
 __global__ __launch_bounds__(NT) void srla_residual_cost_big(
     SrlaJobParams jp, const int32_t *__restrict__ input, const SrlaItemDesc *__restrict__ items,
     const SrlaGeom *__restrict__ geoms, const double *__restrict__ rice_thresholds, int32_t *__restrict__ res_ws,
-    SrlaItemResult *__restrict__ results, const uint32_t *__restrict__ big_items, uint32_t count, uint32_t sig_words)
+    SrlaItemResult *__restrict__ results, const uint32_t *__restrict__ big_items, uint32_t count, uint32_t sig_words,
+    int32_t *__restrict__ sig_ws /* blocks above 32768 samples: sig_words words per workgroup in global memory (the signal no longer fits LDS), else null */)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    int32_t *sig = (int32_t *)lds;                                  /* FIR_PAD zeros, then the block */
-    double *means = (double *)(lds + (size_t)sig_words * 4);
-    SmallC *sm = (SmallC *)(lds + (size_t)sig_words * 4 + 8u * 2048u);
+    const size_t sig_lds = SIG_GLOBAL ? 0 : (size_t)sig_words * 4;
+    int32_t *sig;                                                   /* FIR_PAD zeros, then the block */
+    if constexpr (SIG_GLOBAL) sig = sig_ws + (size_t)blockIdx.x * sig_words; else sig = (int32_t *)lds;
+    double *means = (double *)(lds + sig_lds);
+    SmallC *sm = (SmallC *)(lds + sig_lds + 8u * 2048u);
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     if (blockIdx.x >= count) return;
     const uint32_t item_idx = big_items[blockIdx.x];
@@ -4506,24 +4515,40 @@ extern "C" int srla_launch_autocorr_big(hipStream_t stream, const SrlaJobParams 
     {
         /* the kernel also has a few hundred bytes of static LDS: ask for what is left of the 160 KB */
         static bool done_ = false;
-        if (!done_) { (void)hipFuncSetAttribute((const void *)srla_autocorr_big, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); done_ = true; }
+        if (!done_) { (void)hipFuncSetAttribute((const void *)srla_autocorr_big<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); done_ = true; }
         (void)hipGetLastError();
     }
-    hipExtLaunchKernelGGL(srla_autocorr_big, dim3(groups), dim3(NTB), nfft * 4u, stream, ev_start, ev_stop, 0, *jp, input, (const cplx *)twiddles, pass,
-                          results, lags_ws, dbg, class_items, count, chain_pool, chain_tab, (cplx *)scratch, nfft);
+    /* (scratch: scratch_groups regions of nfft complex words -- the two transform buffers --, then, for 65536 points, scratch_groups
+     * regions of nfft int32 words for the signal that no longer fits LDS) */
+    int32_t *ywork = (nfft > 32768u) ? (int32_t *)((cplx *)scratch + (size_t)scratch_groups * nfft) : nullptr;
+    if (ywork)
+        hipExtLaunchKernelGGL(srla_autocorr_big<true>, dim3(groups), dim3(NTB), 16u, stream, ev_start, ev_stop, 0, *jp, input, (const cplx *)twiddles, pass,
+                              results, lags_ws, dbg, class_items, count, chain_pool, chain_tab, (cplx *)scratch, nfft, ywork);
+    else
+        hipExtLaunchKernelGGL(srla_autocorr_big<false>, dim3(groups), dim3(NTB), nfft * 4u, stream, ev_start, ev_stop, 0, *jp, input, (const cplx *)twiddles, pass,
+                              results, lags_ws, dbg, class_items, count, chain_pool, chain_tab, (cplx *)scratch, nfft, ywork);
     return (hipGetLastError() == hipSuccess) ? 0 : -2;
 }
 
+extern "C" uint32_t srla_residual_big_sig_words(uint32_t max_n) { return FIR_PAD + ((max_n + 3u) & ~3u) + 8u; }
+
 extern "C" int srla_launch_residual_cost_big(hipStream_t stream, const SrlaJobParams *jp, const int32_t *input, const SrlaItemDesc *items,
                                               const SrlaGeom *geoms, const double *rice_thresholds, int32_t *res_ws, SrlaItemResult *results,
-                                              const uint32_t *big_items, uint32_t count, uint32_t max_n, hipEvent_t ev_start, hipEvent_t ev_stop)
+                                              const uint32_t *big_items, uint32_t count, uint32_t max_n, hipEvent_t ev_start, hipEvent_t ev_stop,
+                                              int32_t *sig_ws)
 {
     if (count == 0) return 0;
-    const uint32_t sig_words = FIR_PAD + ((max_n + 3u) & ~3u) + 8u;
-    const uint32_t lds = sig_words * 4u + 8u * 2048u + srla_kernel_small_c_bytes();
-    SET_LDS_ATTR(srla_residual_cost_big);
-    hipExtLaunchKernelGGL(srla_residual_cost_big, dim3(count), dim3(NT), lds, stream, ev_start, ev_stop, 0, *jp, input, items, geoms, rice_thresholds,
-                          res_ws, results, big_items, count, sig_words);
+    const uint32_t sig_words = srla_residual_big_sig_words(max_n);
+    if (max_n > 32768u && sig_ws == nullptr) return -1;
+    if (max_n <= 32768u) sig_ws = nullptr;
+    const uint32_t lds = (sig_ws ? 0u : sig_words * 4u) + 8u * 2048u + srla_kernel_small_c_bytes();
+    SET_LDS_ATTR(srla_residual_cost_big<false>);
+    if (sig_ws)
+        hipExtLaunchKernelGGL(srla_residual_cost_big<true>, dim3(count), dim3(NT), lds, stream, ev_start, ev_stop, 0, *jp, input, items, geoms, rice_thresholds,
+                              res_ws, results, big_items, count, sig_words, sig_ws);
+    else
+        hipExtLaunchKernelGGL(srla_residual_cost_big<false>, dim3(count), dim3(NT), lds, stream, ev_start, ev_stop, 0, *jp, input, items, geoms, rice_thresholds,
+                              res_ws, results, big_items, count, sig_words, sig_ws);
     return (hipGetLastError() == hipSuccess) ? 0 : -2;
 }
 

@@ -86,6 +86,12 @@ EXTRA = [
     ("music_40000", dict(kind=MUSIC, seed=95, rate=48000, nch=2, n=40000, bps=16), "B4096_V6_m2", dict(preset=2, max_block=4096, divisions=6)),
     ("music_40000", dict(kind=MUSIC, seed=95, rate=48000, nch=2, n=40000, bps=16), "B2048_V6_L8_m1", dict(preset=1, max_block=2048, divisions=6, lookahead_factor=8)),
     ("varied_40001", dict(kind=VARIED, seed=96, rate=48000, nch=2, n=40001, bps=16), "B1024_V4_L32_m2_P3", dict(preset=2, max_block=1024, divisions=4, lookahead_factor=32, ltp_order=3)),
+    # blocks above 32 768 samples (the library's limit until round 4; a block header holds 65 535 at most): the 65 536-point transform,
+    # signal staging in global memory
+    ("music_150001", dict(kind=MUSIC, seed=97, rate=48000, nch=2, n=150001, bps=16), "B65535_V0_m4", dict(preset=4, max_block=65535, divisions=0)),
+    ("music_150001", dict(kind=MUSIC, seed=97, rate=48000, nch=2, n=150001, bps=16), "B50000_V1_m2_P3", dict(preset=2, max_block=50000, divisions=1, lookahead_factor=2, ltp_order=3)),
+    ("varied_3ch24_140000", dict(kind=VARIED, seed=98, rate=96000, nch=3, n=140000, bps=24), "B40000_V2_m5_P1", dict(preset=5, max_block=40000, divisions=2, lookahead_factor=1, ltp_order=1)),
+    ("music_150001", dict(kind=MUSIC, seed=97, rate=48000, nch=2, n=150001, bps=16), "B65535_V0_m3_svr1", dict(preset=3, max_block=65535, divisions=0, svr_iterations=1)),
     ("sine_window_and_tail", dict(kind=0, seed=5060, rate=48000, nch=2, n=32416, bps=16), "min1536_max4608_L16896_m6_P1_svr1",
      dict(preset=6, min_block=1536, max_block=4608, lookahead=16896, ltp_order=1, svr_iterations=1)),
     ("sine_window_and_tail", dict(kind=0, seed=5060, rate=48000, nch=2, n=32416, bps=16), "min1536_max4608_L16896_m5_P1_svr2",

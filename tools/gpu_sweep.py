@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity sweep on an MI355X: library bytes vs oracle bytes over random configurations and lengths.
 
-    python tools/gpu_sweep.py [cases] [seed] [--mutate]
+    python tools/gpu_sweep.py [cases] [seed] [--mutate] [--history]
 
 Any length, odd ones included (the last window of such a stream is history dependent in the reference and goes
 through the library's chain mode); LTP with any minimum block and odd block sizes (history mode: every
@@ -134,11 +134,22 @@ def make_pcm(case, nch, bps, n, kind, shifted, mutation="none"):
     return pcm
 
 
-def sweep(count, seed, max_samples=6_000_000, with_mutations=False):
+def is_history_regime(cli):
+    """blocks anywhere in the stream depend on the calls before them: odd minimum block, or the LTP with a minimum block <= 256"""
+    minb = cli.get("min_block", cli["max_block"] >> cli.get("divisions", 0))
+    return bool(minb & 1) or (cli.get("ltp_order", 0) > 0 and minb <= 256)
+
+
+def sweep(count, seed, max_samples=6_000_000, with_mutations=False, only_history=False):
     lib = capi.EncoderLib(helpers.PRODUCT_SO)
     bad = 0
     done = 0
     for case, nch, bps, n, kind, cli, shifted in cases(count, seed, max_samples):
+        if only_history:
+            # `--history`: only the regimes that go through history / chain mode, shortened (the oracle walks them call by call)
+            if not (is_history_regime(cli) or (n & 1) or cli.get("svr_iterations")):
+                continue
+            n = min(n, 120_000 // nch) | (n & 1)
         mutation = mutation_of(case, seed) if with_mutations else "none"
         pcm = make_pcm(case, nch, bps, n, kind, shifted, mutation)
         try:
@@ -146,7 +157,16 @@ def sweep(count, seed, max_samples=6_000_000, with_mutations=False):
         except RuntimeError as e:                        # limits of the implementation are refused loudly
             print("refused", cli, nch, bps, n, e)
             continue
-        want = helpers.Oracle(nch, bits_per_sample=bps, **cli).encode_whole(pcm)
+        try:
+            want = helpers.Oracle(nch, bits_per_sample=bps, **cli).encode_whole(pcm)
+        except RuntimeError as e:
+            # the oracle fails where the reference has no defined output (it returns an error or crashes: e.g. the LTP's 3 x 3 solve on
+            # the rounding noise of an all-zero variant, seed 61 case 544); the library's stream must still decode to the input
+            ok = np.array_equal(helpers.oracle_decode(got), pcm)
+            print("oracle fails (%s): case %d (seed %d) nch=%d n=%d kind=%d mutation=%s %s; the library's stream %s" %
+                  (e, case, seed, nch, n, kind, mutation, cli, "decodes to the input" if ok else "DOES NOT DECODE"), flush=True)
+            bad += 0 if ok else 1
+            continue
         done += 1
         if not np.array_equal(got, want):
             bad += 1
@@ -156,7 +176,8 @@ def sweep(count, seed, max_samples=6_000_000, with_mutations=False):
 
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
-    done, bad = sweep(int(args[0]) if len(args) > 0 else 150, int(args[1]) if len(args) > 1 else 1, with_mutations="--mutate" in sys.argv)
+    done, bad = sweep(int(args[0]) if len(args) > 0 else 150, int(args[1]) if len(args) > 1 else 1, with_mutations="--mutate" in sys.argv,
+                      only_history="--history" in sys.argv)
     print("sweep: %d compared, %d mismatches" % (done, bad))
     sys.exit(1 if bad else 0)
 
