@@ -77,3 +77,21 @@ def test_bad_files_are_reported_not_fatal(tmp_path):
     assert p.returncode == 1 and "bad.wav" in p.stderr
     want = helpers.Oracle(2, preset=4, max_block=4096, divisions=1).encode_whole(pcm)
     assert np.array_equal(np.fromfile(str(tmp_path / "out" / "good.srl"), dtype=np.uint8), want)
+
+
+@pytest.mark.gpu
+def test_incompressible_input_with_small_blocks_fits_the_output_buffer(tmp_path):
+    """full-scale 8-bit mono white noise in blocks of 256 samples (the smallest the reference's tool can create an encoder for: it asks
+    for 255 parameters, srla_codec.c:95): every block is RAW, an 11-byte header per 256 bytes of samples -- 4.3 % more than the file,
+    which the tool's output buffers once (file + 1/32 + 64 KiB) did not hold.  They are sized from the true bound now, PCM + a header
+    per minimum block; the reference's tool allocates twice the file (srla_codec.c:125-129)."""
+    root = tmp_path / "in"
+    root.mkdir()
+    pcm = np.random.RandomState(7).randint(-128, 128, size=(1, 6_000_000)).astype(np.int32)
+    _write_wav(str(root / "noise.wav"), pcm, 22050, 8)
+    p = subprocess.run([TOOL, "-e", "-m", "2", "-B", "256", "-V", "0", str(root), str(tmp_path / "out")], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    got = np.fromfile(str(tmp_path / "out" / "noise.srl"), dtype=np.uint8)
+    assert got.size > pcm.size + pcm.size // 32 + 65536              # beyond what the old bound allowed
+    want = helpers.Oracle(1, bits_per_sample=8, sampling_rate=22050, preset=2, max_block=256, divisions=0).encode_whole(pcm)
+    assert np.array_equal(got, want)

@@ -675,6 +675,31 @@ def test_fused_fft_option_gives_the_same_bytes(product, monkeypatch, cli):
     assert np.array_equal(product.encode(pcm, **cli), want)
 
 
+ROUND4_OPTIONS = {
+    "variant_planes": {"SRLA_MI355X_VARIANTS": "1"},
+    "one_residual_cost_launch": {"SRLA_MI355X_SPLIT_RC": "0"},
+    "no_pair_no_spin": {"SRLA_MI355X_PAIR": "0", "SRLA_MI355X_SPIN": "0"},
+    "dma_tail_3_small_jobs": {"SRLA_MI355X_DMA_TAIL": "3", "SRLA_MI355X_JOB_SAMPLES": "131072"},
+    "pin_everything": {"SRLA_MI355X_PIN_MIN_MB": "0"},
+}
+
+
+@pytest.mark.parametrize("option", sorted(ROUND4_OPTIONS))
+def test_round_4_options_give_the_same_bytes(product, monkeypatch, option):
+    """the measured alternatives of round 4 are options, not dead code: each gives the oracle's bytes --
+    on 16-bit stereo with every block size class (-B 8192 -V 2 -P 3: both srla_residual_cost launches), on 24-bit 3-channel input
+    (variant planes as int32), on mono, and on a stream DECLARED 16 bits wide whose samples are not (the variant planes' fall-back)"""
+    for k, v in ROUND4_OPTIONS[option].items():
+        monkeypatch.setenv(k, v)
+    cases = [(helpers.synth(helpers.MUSIC, 81, 48000, 2, 300_001), 16, dict(preset=4, max_block=8192, divisions=2, ltp_order=3)),
+             (helpers.synth(helpers.VARIED, 82, 48000, 3, 120_000, 24), 24, dict(preset=4, max_block=4096, divisions=1)),
+             (helpers.synth(helpers.MUSIC, 83, 44100, 1, 100_000), 16, dict(preset=2, max_block=4096, divisions=1)),
+             (helpers.synth(helpers.NOISE, 84, 48000, 2, 90_000, 24), 16, dict(preset=4, max_block=4096, divisions=1))]
+    for pcm, bps, cli in cases:
+        want = helpers.Oracle(pcm.shape[0], bits_per_sample=bps, **cli).encode_whole(pcm)
+        assert np.array_equal(product.encode(pcm, bits_per_sample=bps, **cli), want), (option, pcm.shape, bps, cli)
+
+
 def test_wrong_shift_guess_that_overflows_the_buffer_is_retried(product, monkeypatch):
     """Host input without callback is encoded with the offset shift of its FIRST job while the OR of the rest is still being
     gathered.  16-bit audio in a 24-bit container behind leading digital silence: the guess (0) makes the stream much larger
