@@ -8,8 +8,8 @@
   stats/   rocprofv3 --kernel-trace --stats -- python bench.py --config X --steps 3 --warmup 1 --no-cpu-baseline --no-extras
   bench.log   python bench.py --config X --steps 20 --warmup 3 --no-cpu-baseline   (no profiler)
   fetch/ write/ sq1/ .. sq4/   one rocprofv3 --kernel-trace --pmc <counters> pass each (never together with other trace
-           domains) over the PMC command: bench.py --config X --steps 1 --warmup 0 --calls-per-step 1 --seconds 174.8
-           --files 1 --no-cpu-baseline --no-extras  (two full jobs of 4 Mi sample instants)
+           domains) over the PMC command: bench.py --config X --steps 1 --warmup 0 --calls-per-step 1 --seconds 524.3
+           --files 1 --no-cpu-baseline --no-extras  (six jobs of 4 Mi sample instants)
 
 `summarize` turns that into what is committed: profiles/<round>/<config>/{kernel_stats.csv, bench_line.json,
 bench_line_under_rocprof.json, pmc_<pass>.csv} and profiles/pmc_summary.json (read by bench.py for roofline.traffic / valu_util).
@@ -36,7 +36,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLOCK_GHZ = 2.4
 SIMDS, CUS = 1024, 256
-PMC_SECONDS = 174.8                       # two jobs of 4 Mi sample instants at 48 kHz
+PMC_SECONDS = 524.3                       # six jobs of 4 Mi sample instants at 48 kHz: more than three, so that the bytes leave by host-issued
+                                          # copies as in the headline run (a call of at most three jobs uses srla_stream_out throughout)
 PASSES = {
     "fetch": "FETCH_SIZE",
     "write": "WRITE_SIZE",
