@@ -244,6 +244,14 @@ struct SRLAMI355XStats {
 #define SRLAMI355X_NONIDENTICAL_LTP_TINY_BUFFER 2u  /* long-term predictor on an encoder created for blocks of at most 256 samples: the
                                                      * reference's FFT buffer is then shorter than the 263 lags it copies out of it
                                                      * (lpc.c:371-373 reads beyond the buffer, into the transform's scratch area) */
+#define SRLAMI355X_NONIDENTICAL_HANDLE_HISTORY 4u  /* a block of this call inherits a word of the reference's persistent FFT buffer
+                                                    * (encoder->lpcc: one calculator per handle, lpc.c:58,211) that an EARLIER call on
+                                                    * the same handle left, and the library does not know that word.  The calls of the
+                                                    * reference's entry points read and leave the handle's buffer as the reference's do
+                                                    * (history-mode calls exactly; a regular call of several windows through its last two
+                                                    * windows, encoded once more when a later call is about to read the buffer); what stays
+                                                    * unknown are words those two windows did not rewrite (a stream ending in digital
+                                                    * silence) and the buffer after a call that failed.  Counted where it happens. */
 /* The reasons for which a stream of `num_samples` samples per channel encoded under the handle's current parameters would not be
  * guaranteed bit-identical to the reference (0: it is); num_samples = 0 asks about the parameters alone. */
 uint32_t SRLAMI355X_NonIdenticalReasons(struct SRLAEncoder *encoder, uint32_t num_samples);

@@ -173,6 +173,7 @@ static SRLAApiResult one_stream(Impl *im, const int32_t *const *input, const int
     StreamCtx st;
     st.host_in = input; st.d_in = d_input; st.d_stride = d_stride; st.num_samples = num_samples;
     st.data = data; st.data_size = data_size; st.with_header = with_header; st.cb = cb;
+    st.reference_call = true;
     im->sx.clear();
     im->sx.push_back(st);
     const SRLAApiResult rc = im->encode_streams(search);

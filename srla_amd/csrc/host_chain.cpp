@@ -11,6 +11,7 @@ void Impl::chain_append(uint32_t jobidx, const Job &job, const std::function<boo
 {
     const uint32_t nch = par.num_channels, nv = num_variants();
     std::vector<uint32_t> pass1_round(job.items.size(), 0);
+    std::vector<uint8_t> pass1_tainted(job.items.size(), 0);
     for (const SrlaCandDesc &cd : job.cands) {
         if (cd.item_base == 0xFFFFFFFFu || silent(cd.sample_off, cd.n)) continue;   /* RAW by length / SILENT: no analysis (srla_encoder.c:766-796) */
         for (uint32_t k = 0; k < nv; k++) {
@@ -21,10 +22,17 @@ void Impl::chain_append(uint32_t jobidx, const Job &job, const std::function<boo
                 c.job = jobidx; c.item = item; c.pass = (uint32_t)pass; c.n = cd.n; c.nfft = geoms[job.items[item].geom].nfft;
                 c.src = -1; c.dump = (uint32_t)chain_pool_used; chain_pool_used += c.nfft;
                 uint32_t round = (pass == 0 && par.ltp_order > 0) ? pass1_round[item] : 0;
+                /* (the item's LPC-lag call analyses what its long-term predictor left: it is no better known than that) */
+                c.tainted = (pass == 0 && par.ltp_order > 0) ? (pass1_tainted[item] != 0) : false;
+                /* a word read from the buffer itself (chain_calls[0] in history mode) is known as far as buf_exact reaches */
+                auto unknown = [&](const ChainCall &sc, uint32_t upto) {
+                    return sc.job == 0xFFFFFFFFu ? (upto > buf_exact) : sc.tainted;
+                };
                 if (c.n & 1u) {
                     const uint32_t mid = c.n >> 1;
                     for (int64_t j = (int64_t)chain_calls.size() - 1; j >= 0; j--)
                         if (chain_calls[(size_t)j].nfft > mid) { c.src = (int32_t)j; break; }
+                    if (c.src >= 0 && unknown(chain_calls[(size_t)c.src], mid + 1u)) c.tainted = true;
                     if (c.src >= 0 && chain_calls[(size_t)c.src].job == jobidx) {
                         /* inside a round the LTP-lag launches come first, then the pitch solve, then the LPC-lag launches
                          * (and, with SVR on, the solve chain and the refinement: pass 2) */
@@ -45,12 +53,14 @@ void Impl::chain_append(uint32_t jobidx, const Job &job, const std::function<boo
                         if (sc.nfft <= lo) continue;
                         const uint32_t hi = std::min<uint32_t>(sc.nfft, SRLA_LTP_LAGS);
                         for (uint32_t i = lo; i < hi; i++) chain_tab[base + (i - c.nfft)] = sc.dump + i + 1u;
+                        if (unknown(sc, hi)) c.tainted = true;
                         lo = hi;
                         if (sc.job == jobidx) round = std::max(round, sc.round + 1);
                     }
                 }
                 c.round = round;
-                if (pass == 1) pass1_round[item] = round;
+                if (pass == 1) { pass1_round[item] = round; pass1_tainted[item] = c.tainted ? 1 : 0; }
+                if (c.tainted) call_tainted = true;
                 chain_calls.push_back(c);
                 if (pass == 0 && chain_svr()) {
                     /* LPCCalculator_CalculateLPCCoefficientsSVR keeps its `residual` in the same persistent buffer
@@ -59,7 +69,7 @@ void Impl::chain_append(uint32_t jobidx, const Job &job, const std::function<boo
                     ChainCall v{};
                     v.job = jobidx; v.item = item; v.pass = 2; v.n = cd.n; v.nfft = cd.n; v.src = (int32_t)chain_calls.size() - 1;
                     v.dump = (uint32_t)chain_pool_used; chain_pool_used += (cd.n + 1u) & ~1u;
-                    v.round = round;
+                    v.round = round; v.tainted = c.tainted;
                     chain_calls.push_back(v);
                 }
             }
@@ -427,14 +437,20 @@ bool Impl::history_commit(uint32_t jobidx, hipStream_t stream)
     /* from the last call backwards: a call owns the words between what later calls cover and its own extent (a transform's
      * length, or -- SVR on -- the n words of a refinement's residual) */
     uint32_t lo[SRLA_COMMIT_SEGS], hi[SRLA_COMMIT_SEGS], src[SRLA_COMMIT_SEGS], nseg = 0, covered = 0;
+    /* the leading words that are known afterwards: the extents of known calls, from word 0 up to the first extent of a call that
+     * read an unknown word; beyond all extents the buffer is what it was */
+    uint32_t exact = 0;
+    bool all_known = true;
     for (size_t j = chain_calls.size(); j-- > 1;) {
         const ChainCall &c = chain_calls[j];
         if (c.job != jobidx || c.nfft <= covered) continue;
         if (nseg == SRLA_COMMIT_SEGS) { fprintf(stderr, "[srla-mi355x] internal error: too many extents in a history phase\n"); return false; }
         lo[nseg] = covered; hi[nseg] = c.nfft; src[nseg] = c.dump; nseg++;
+        if (all_known && !c.tainted) exact = c.nfft; else all_known = false;
         covered = c.nfft;
     }
     if (nseg == 0) return true;                                   /* a silent / RAW window: no call, the buffer stays */
+    buf_exact = all_known ? std::max(covered, buf_exact) : exact;
     return srla_launch_chain_commit(stream, d_chain_pool.as<double>(), lo, hi, src, nseg) == 0;
 }
 
@@ -555,8 +571,15 @@ SRLAApiResult Impl::history_encode(bool search)
     chain.active = false;
     for (uint32_t i = 0; i < sx.size(); i++) {
         StreamCtx &st = sx[i];
-        /* a fresh handle: the reference's buffer starts as zero pages (the `srla` tool creates its encoder per file) */
-        if (hipMemsetAsync(d_chain_pool.p, 0, (size_t)kHistoryWords * sizeof(double), streams[1]) != hipSuccess) return SRLA_APIRESULT_NG;
+        /* the buffer as this handle's calls left it (one of the reference's entry points: host_impl.h, d_hist); a fresh handle's --
+         * and, for the streams of a batch, each stream's -- starts as zero pages (the `srla` tool creates its encoder per file) */
+        const bool tracked = sx.size() == 1 && st.reference_call;
+        if (tracked && !hist_fresh && d_hist.p != nullptr) {
+            if (hipMemcpyAsync(d_chain_pool.p, d_hist.p, (size_t)kHistoryWords * sizeof(double), hipMemcpyDeviceToDevice, streams[1]) != hipSuccess) return SRLA_APIRESULT_NG;
+        } else {
+            if (hipMemsetAsync(d_chain_pool.p, 0, (size_t)kHistoryWords * sizeof(double), streams[1]) != hipSuccess) return SRLA_APIRESULT_NG;
+        }
+        buf_exact = (tracked && !hist_fresh) ? hist_exact : kHistoryWords;
         chain_calls.clear();
         ChainCall buffer{};
         buffer.job = 0xFFFFFFFFu; buffer.nfft = kHistoryWords; buffer.src = -1; buffer.dump = 0;
@@ -567,6 +590,13 @@ SRLAApiResult Impl::history_encode(bool search)
             else if (rc != SRLA_APIRESULT_OK) { drain(); for (auto &sl : slot) sl.busy = false; chain.active = false; return rc; }
         }
         chain.active = false;
+        if (tracked) {
+            /* what the next call on this handle finds */
+            if (!d_hist.ensure((size_t)kHistoryWords * sizeof(double))) return SRLA_APIRESULT_NG;
+            if (hipMemcpyAsync(d_hist.p, d_chain_pool.p, (size_t)kHistoryWords * sizeof(double), hipMemcpyDeviceToDevice, streams[1]) != hipSuccess) return SRLA_APIRESULT_NG;
+            hist_fresh = false;
+            hist_exact = (st.rc == SRLA_APIRESULT_OK) ? buf_exact : 0u;       /* (a call that ran out of room stopped somewhere inside a window) */
+        }
         if (st.rc != SRLA_APIRESULT_OK) { worst = st.rc; continue; }
         if (!write_header(st)) return SRLA_APIRESULT_NG;
     }

@@ -162,6 +162,8 @@ struct StreamCtx {
     bool in_pinned = false;                    /* the input planes are pinned host memory: DMA reads them without staging */
     bool in_mixed = false;                     /* ... locked in place by this call while the pool could also stage them: the jobs take turns */
     bool with_header = true;                   /* EncodeWhole / EncodeBatch: header + offset shift; block calls: neither */
+    bool reference_call = false;               /* one of the reference's own entry points on this handle: the call reads and leaves the
+                                                * handle's persistent FFT buffer as the reference's would (Impl::d_hist) */
     SRLAEncoder_EncodeBlockCallback cb = nullptr;
     /* offset left shift (srla_utility.c:177): the OR of ALL samples decides it.  Host input is encoded while the staging
      * copies are still gathering that OR: a stream whose first job does not hold all of it starts with the shift of what
@@ -358,7 +360,7 @@ struct Impl {
      * call runs after its source; even calls need no source and all run in round 0.  The calls before the window
      * matter only through the last block encoded before it (the "seed" job).  A fresh handle starts from zeros,
      * as the `srla` tool's freshly mapped buffer does. */
-    struct ChainCall { uint32_t job, item, pass, n, nfft, round; int32_t src; uint32_t dump, lags; };
+    struct ChainCall { uint32_t job, item, pass, n, nfft, round; int32_t src; uint32_t dump, lags; bool tainted; };
     struct ChainLaunch { uint32_t round, pass, cls, first, count; };
     struct ChainJob {
         std::vector<SrlaAutocorrItem> list;
@@ -421,9 +423,41 @@ struct Impl {
     /* bit-identity that cannot be promised (SRLAMI355X_NONIDENTICAL_*): said on stderr, counted in the statistics */
     uint32_t nonidentical_reasons(uint32_t num_samples) const;
     void note_nonidentical(uint32_t num_samples);
+    void note_reasons(uint32_t reasons);
     static std::string nonidentical_text(uint32_t reasons);
     uint32_t warned_reasons = 0;
     static constexpr uint32_t kHistoryWords = 65536;
+    /* ---- the buffer from call to call ------------------------------------------------------------------------------
+     * The reference keeps ONE calculator per encoder (srla_encoder.c: encoder->lpcc), so the buffer outlives a call: what a
+     * handle encoded before can decide a later call's history-dependent blocks (the same stream behind another one under
+     * `-B 4095 -V 0` differs from a fresh handle's in 5 of 7 cases: profiles/r04/handle_reuse_probe.txt).  d_hist is that
+     * buffer as the last call of one of the reference's entry points left it; hist_exact counts the leading words of it that are
+     * known to equal the reference's.  Calls that run in history mode (every call of the history regimes, and every call of at
+     * most one window) start from it and leave it exactly; a regular call of several windows does not track it (hist_exact = 0
+     * afterwards: its stream's own blocks never reach back beyond their own window and the one before).  A call whose
+     * history-dependent read lands in words that are not known is counted (SRLAMI355X_NONIDENTICAL_HANDLE_HISTORY). */
+    DevBuf d_hist;
+    bool hist_fresh = true;               /* nothing has been encoded on this handle: the buffer is all zero (not even allocated) */
+    uint32_t hist_exact = kHistoryWords;  /* words [0, hist_exact) of d_hist are the reference's */
+    uint32_t buf_exact = kHistoryWords;   /* the same for the pool's head while a history-mode call runs */
+    bool call_tainted = false;            /* a call of the running API call read a word that is not known */
+    /* ... and behind a regular call of several windows: the words below the longest transform of a full window are what the
+     * stream's LAST TWO windows leave (every full window's search analyses a candidate of the maximum block, whose transform
+     * covers them; nothing in a regular regime reaches back further).  The call keeps those windows' samples (pinned host
+     * memory, copied while it waits for its last job); when a later call on the handle is about to read the buffer -- a
+     * history-mode call -- the two windows are first encoded once more in history mode under the parameters they were encoded
+     * with, output discarded (replay_tail), which leaves the buffer as the reference's call left it.  Calls that never read the
+     * buffer pay the copy (two windows) and nothing else. */
+    struct TailCapture {
+        bool valid = false, copied = false;
+        SRLAEncodeParameter par{};
+        uint32_t lshift = 0, n = 0, nch = 0;
+        PinBuf smp;                       /* nch planes of n samples */
+    } tail;
+    bool replaying = false;
+    std::vector<uint8_t> replay_out;
+    bool keep_tail(const StreamCtx &st, bool search);   /* the samples of the last two windows (before the call's last wait) */
+    bool replay_tail();
     bool history_regime(bool search) const;
     void history_phase_reset();
     bool history_commit(uint32_t jobidx, hipStream_t stream);

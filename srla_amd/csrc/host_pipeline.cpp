@@ -55,7 +55,7 @@ Impl::~Impl()
         if (ev_ref) (void)hipEventDestroy(ev_ref);
         h_or.release();
         d_tw.release(); d_geoms.release(); d_thr.release(); d_huff.release(); d_huffcode.release(); d_pos.release(); d_or.release(); d_oracc.release(); d_svr_scratch.release(); d_svr_scratch_chain.release();
-        d_chain_pool.release(); d_chain_tab.release();
+        d_chain_pool.release(); d_chain_tab.release(); d_hist.release(); tail.smp.release();
         for (auto &b : d_chain_list) b.release();
         for (auto &b : d_chain_select) b.release();
     }
@@ -842,9 +842,10 @@ uint32_t Impl::nonidentical_reasons(uint32_t num_samples) const
 }
 
 /* counts a call made under such parameters and says so once per handle and reason */
-void Impl::note_nonidentical(uint32_t num_samples)
+void Impl::note_nonidentical(uint32_t num_samples) { note_reasons(nonidentical_reasons(num_samples)); }
+
+void Impl::note_reasons(uint32_t r)
 {
-    const uint32_t r = nonidentical_reasons(num_samples);
     if (r == 0) return;
     stats.num_nonidentical_calls++;
     stats.nonidentical_reasons |= r;
@@ -861,6 +862,13 @@ std::string Impl::nonidentical_text(uint32_t r)
     if (r & SRLAMI355X_NONIDENTICAL_SVR_HISTORY)
         t += "an SVR refinement whose objective comparisons the host libm decided differently from the device, in a window whose later "
              "blocks inherit the refinement's residual (lpc.c:1047): the predictor is the host's, the residual left behind is not";
+    if (r & SRLAMI355X_NONIDENTICAL_HANDLE_HISTORY) {
+        if (!t.empty()) t += "; ";
+        t += "a block of this call inherits a word of the reference's FFT buffer (lpc.c:260-264, 371-373) that an EARLIER call on this "
+             "handle left there and that the library does not know: the last two windows of the stream before did not rewrite it (a "
+             "stream that ends in digital silence, a call that failed) -- a fresh handle per stream (what the `srla` tool does) keeps the "
+             "output bit-identical";
+    }
     if (r & SRLAMI355X_NONIDENTICAL_LTP_TINY_BUFFER) {
         if (!t.empty()) t += "; ";
         t += "long-term predictor on an encoder created for blocks of at most 256 samples: the reference's FFT buffer is shorter than "
@@ -915,7 +923,21 @@ SRLAApiResult Impl::encode_streams(bool search)
     mix_count = 0;
     bool need_oracc = false;
     /* parameters under which blocks anywhere in the stream depend on the calls before them: window by window (host_chain.cpp) */
-    const bool history = history_regime(search);
+    /* ... and, for the reference's own entry points, calls of at most one window: they are where a handle's earlier calls can
+     * reach into this one, and in history mode they leave the handle's buffer exactly as the reference's (host_impl.h, d_hist) */
+    const bool tracked = single && sx[0].reference_call && !no_chain;
+    const bool history = replaying || history_regime(search) ||
+                         (tracked && sx[0].num_samples <= (search ? par.num_lookahead_samples : par.max_num_samples_per_block));
+    if (history && tracked && tail.valid && !replaying) {
+        /* this call may read the buffer: first what the last regular call on the handle left in it */
+        std::vector<StreamCtx> mine;
+        mine.swap(sx);
+        const bool ok = replay_tail();
+        sx.swap(mine);
+        if (!ok) return SRLA_APIRESULT_NG;
+    }
+    call_tainted = false;
+    tail.copied = false;
     for (uint32_t si = 0; si < nst; si++) {
         StreamCtx &st = sx[si];
         classify_buffers(st, pins.held);
@@ -1010,9 +1032,13 @@ SRLAApiResult Impl::encode_streams(bool search)
     if (history) {
         overrides.clear();
         const SRLAApiResult rc = history_encode(search);
+        if (call_tainted) note_reasons(SRLAMI355X_NONIDENTICAL_HANDLE_HISTORY);
         stats.total_ms += ms_since(t0);
         return rc;
     }
+    /* a regular call of several windows: none of its blocks reaches back beyond its own stream, and what it leaves in the
+     * reference's buffer is not tracked */
+    if (tracked) { hist_fresh = false; hist_exact = 0; tail.valid = false; }
     if (need_oracc) {
         if ((size_t)8 * nst > d_oracc.cap) { drain(); if (!d_oracc.ensure((size_t)8 * nst)) return SRLA_APIRESULT_NG; }
         if (hipMemsetAsync(d_oracc.p, 0, (size_t)8 * nst, upload) != hipSuccess) return SRLA_APIRESULT_NG;
@@ -1135,6 +1161,7 @@ SRLAApiResult Impl::encode_streams(bool search)
         if (t < lag || t - lag < base) { t++; continue; }
         const uint32_t k = t - lag;
         Slot &s = job_slot(k);
+        if (tracked && k + 1 == njobs && !tail.copied && !keep_tail(sx[0], search)) return fail(SRLA_APIRESULT_NG);   /* (everything is enqueued: the host would only wait) */
         if (!wait_job(s)) return fail(SRLA_APIRESULT_NG);
         if (timeline) tl_printf("[timeline] host: job %u collected at %.3f ms\n", k, ms_since(t0));
         if (s.h_info.as<SrlaJobInfo>()->num_tie_items != 0) {
@@ -1252,7 +1279,63 @@ SRLAApiResult Impl::encode_streams(bool search)
         for (const void *p : pins.held) host_pin_release(p);
         pins.held.clear();
     }
+    if (tracked && tail.copied && worst == SRLA_APIRESULT_OK) {
+        /* what a later call on this handle may have to know (host_impl.h, TailCapture); the shift is final only now */
+        if (sx[0].d_in && hipStreamSynchronize(upload) != hipSuccess) return fail(SRLA_APIRESULT_NG);
+        tail.par = par; tail.lshift = sx[0].lshift; tail.valid = true;
+    }
     stats.total_ms += ms_since(t0);
     if (timeline) { tl_printf("[timeline] call returned at %.3f ms\n", ms_since(t0)); fputs(tl_log.c_str(), stderr); tl_log.clear(); }
     return worst;
+}
+
+/* the samples of the stream's last two windows, where the call that encoded them can be repeated from */
+bool Impl::keep_tail(const StreamCtx &st, bool search)
+{
+    const uint32_t window_len = search ? par.num_lookahead_samples : par.max_num_samples_per_block, nch = par.num_channels;
+    const uint32_t nwin = (st.num_samples + window_len - 1) / window_len;
+    const uint32_t start = (nwin >= 2 ? nwin - 2 : 0) * window_len, n = st.num_samples - start;
+    tail.copied = false;
+    if (st.host_in == nullptr && st.d_in == nullptr) return true;
+    if (!tail.smp.ensure((size_t)nch * n * 4)) return false;
+    for (uint32_t ch = 0; ch < nch; ch++) {
+        int32_t *dst = tail.smp.as<int32_t>() + (size_t)ch * n;
+        if (st.host_in) memcpy(dst, st.host_in[ch] + start, (size_t)n * 4);
+        else if (hipMemcpyAsync(dst, st.d_in + (size_t)ch * st.d_stride + start, (size_t)n * 4, hipMemcpyDeviceToHost, upload) != hipSuccess) return false;
+    }
+    tail.n = n; tail.nch = nch; tail.copied = true;
+    return true;
+}
+
+/* The last two windows of the handle's last regular call once more, in history mode, under the parameters of that call, the bytes
+ * discarded: afterwards d_hist holds what the reference's buffer held when that call returned (as far as hist_exact says). */
+bool Impl::replay_tail()
+{
+    if (!tail.valid) return true;
+    tail.valid = false;
+    const auto t0 = Clock::now();
+    const SRLAEncodeParameter keep_par = par;
+    const uint32_t keep_shift = offset_lshift, keep_warned = warned_reasons;
+    const SRLAMI355XStats keep_stats = stats;
+    par = tail.par; param_generation++;
+    const uint32_t nch = tail.nch, n = tail.n;
+    std::vector<const int32_t *> planes(nch);
+    for (uint32_t ch = 0; ch < nch; ch++) planes[ch] = tail.smp.as<int32_t>() + (size_t)ch * n;
+    replay_out.resize((size_t)nch * n * 4 + 64u * (n / std::max<uint32_t>(1u, par.min_num_samples_per_block) + 2u) + 4096u);
+    StreamCtx st;
+    st.host_in = planes.data(); st.num_samples = n;
+    st.data = replay_out.data(); st.data_size = (uint32_t)std::min<size_t>(replay_out.size(), 0xFFFFFFFFu);
+    st.with_header = false; st.reference_call = true;
+    st.lshift = tail.lshift; st.lshift_final = true;
+    sx.clear();
+    sx.push_back(st);
+    replaying = true;
+    const SRLAApiResult rc = encode_streams(search_enabled());
+    replaying = false;
+    par = keep_par; param_generation++;
+    offset_lshift = keep_shift; warned_reasons = keep_warned;
+    stats = keep_stats;
+    stats.history_ms += ms_since(t0);
+    if (rc != SRLA_APIRESULT_OK) { hist_exact = 0; fprintf(stderr, "[srla-mi355x] internal error: the replay of the last call's windows failed (%d)\n", (int)rc); return false; }
+    return true;
 }

@@ -1,0 +1,171 @@
+"""Sequences of calls on ONE encoder handle (the reference keeps one LPC calculator per encoder, so its FFT buffer --
+lpc.c:58,211 -- outlives a call, and the middle word of an odd-length block, lpc.c:260-264, or the lags beyond a short transform,
+lpc.c:371-373, of a LATER call can be what an EARLIER call left).  The sequences, the runner shared by the golden generator
+(tools/gen_golden_reuse.py: the compiled reference, one fresh process per sequence), the oracle and the library.  Test infrastructure."""
+import numpy as np
+
+import helpers
+from helpers import MUSIC, VARIED, NOISE
+from srla_amd import capi
+
+
+def _inp(kind, seed, n, nch=2, bps=16, **more):
+    return dict(kind=kind, seed=seed, rate=48000, nch=nch, n=n, bps=bps, **more)
+
+
+def _blocks(kind, seed, total, block, nch=2):
+    """a stream handed over block by block, each block's size asked for first: ComputeBlockSize + EncodeBlock per block"""
+    steps = []
+    for first in range(0, total, block):
+        sp = _inp(kind, seed, total, nch, first=first, count=min(block, total - first))
+        steps += [dict(api="size", input=sp), dict(api="block", input=sp)]
+    return steps
+
+
+def _windows(kind, seed, total, window, nch=2):
+    """... window by window through EncodeOptimalPartitionedBlock (what EncodeWhole does, srla_encoder.c:1746-1771)"""
+    return [dict(api="partitioned", input=_inp(kind, seed, total, nch, first=first, count=min(window, total - first)))
+            for first in range(0, total, window)]
+
+
+# name -> (the `srla` tool's knobs for Create + the first SetEncodeParameter, steps).  A step: {"api": whole | block | size |
+# partitioned, "input": spec of helpers.synth_spec}  or  {"api": "set", "cli": knobs} (SetEncodeParameter on the same handle).
+SEQUENCES = {
+    # history regimes: the same stream behind another one differs from a fresh handle's in most cases (profiles/r04/handle_reuse_probe.txt)
+    "B4095_V0_odd_streams": (dict(preset=4, max_block=4095, divisions=0), [
+        dict(api="whole", input=_inp(MUSIC, 301, 9001)), dict(api="whole", input=_inp(VARIED, 302, 1869)),
+        dict(api="whole", input=_inp(NOISE, 303, 5017)), dict(api="whole", input=_inp(MUSIC, 304, 2681)),
+        dict(api="whole", input=_inp(VARIED, 302, 1869)), dict(api="whole", input=_inp(MUSIC, 305, 12288))]),
+    "B1000_V3_odd_minimum": (dict(preset=4, max_block=1000, divisions=3), [
+        dict(api="whole", input=_inp(VARIED, 311, 4321)), dict(api="whole", input=_inp(MUSIC, 312, 777)),
+        dict(api="whole", input=_inp(MUSIC, 313, 6000)), dict(api="whole", input=_inp(NOISE, 314, 1251))]),
+    "B1024_V2_P3_short_ltp_blocks": (dict(preset=4, max_block=1024, divisions=2, ltp_order=3), [
+        dict(api="whole", input=_inp(MUSIC, 321, 5000)), dict(api="whole", input=_inp(VARIED, 322, 3333)),
+        dict(api="whole", input=_inp(MUSIC, 323, 300)), dict(api="whole", input=_inp(VARIED, 322, 3333))]),
+    "B2047_V0_m2_svr2_odd_streams": (dict(preset=2, max_block=2047, divisions=0, svr_iterations=2), [
+        dict(api="whole", input=_inp(MUSIC, 331, 5001)), dict(api="whole", input=_inp(VARIED, 332, 2047)),
+        dict(api="whole", input=_inp(MUSIC, 331, 5001))]),
+    # regular regime: clips of less than a window behind one another
+    "B4096_V1_short_clips": (dict(preset=4, max_block=4096, divisions=1), [
+        dict(api="whole", input=_inp(MUSIC, 341, 3001)), dict(api="whole", input=_inp(VARIED, 342, 2500)),
+        dict(api="whole", input=_inp(MUSIC, 343, 1001)), dict(api="whole", input=_inp(NOISE, 344, 16383)),
+        dict(api="whole", input=_inp(MUSIC, 345, 77)), dict(api="whole", input=_inp(MUSIC, 341, 3001))]),
+    "B4096_V2_P3_short_clips_identical_channels": (dict(preset=4, max_block=4096, divisions=2, ltp_order=3), [
+        dict(api="whole", input=_inp(NOISE, 351, 8000)), dict(api="whole", input=_inp(MUSIC, 352, 1251, nch=2, same=True)),
+        dict(api="whole", input=_inp(MUSIC, 353, 12001)), dict(api="whole", input=_inp(VARIED, 354, 255, same=True))]),
+    # the block API as a caller streams with it
+    "B4096_V0_blocks": (dict(preset=4, max_block=4096, divisions=0), _blocks(MUSIC, 361, 20001, 4096) + _blocks(VARIED, 362, 9999, 4096)),
+    "B1000_V0_P3_blocks_mono": (dict(preset=3, max_block=1000, divisions=0, ltp_order=3), _blocks(MUSIC, 371, 4501, 1000, nch=1)),
+    "B2048_V2_windows": (dict(preset=4, max_block=2048, divisions=2), _windows(VARIED, 381, 20481, 8192)),
+    # the parameters change on the way (the calculator, and with it the buffer, stays: srla_encoder.c:745-746).  The maximum block is
+    # the one the encoder was created for throughout: the reference searches partitions up to the CONFIG's maximum
+    # (srla_encoder.c:598, 1669) and fails with SRLA_APIRESULT_NG as soon as a candidate exceeds the parameters' (:1499).
+    "parameters_change": (dict(preset=4, max_block=4000, divisions=0, config=dict(min_block=125, max_block=4000, lookahead=16000)), [
+        dict(api="whole", input=_inp(MUSIC, 391, 6001)),
+        dict(api="set", cli=dict(preset=2, max_block=4000, divisions=5)),
+        dict(api="whole", input=_inp(VARIED, 392, 2345)),
+        dict(api="set", cli=dict(preset=4, max_block=4000, divisions=1, ltp_order=3)),
+        dict(api="whole", input=_inp(MUSIC, 393, 4097)),
+        dict(api="set", cli=dict(preset=4, max_block=4000, divisions=0)),
+        dict(api="whole", input=_inp(MUSIC, 391, 6001))]),
+    # a stream of several windows (regular pipeline), then clips whose first blocks reach back into what it left
+    "B4096_V1_long_then_clips": (dict(preset=4, max_block=4096, divisions=1), [
+        dict(api="whole", input=_inp(MUSIC, 401, 70001)), dict(api="whole", input=_inp(VARIED, 402, 2049)),
+        dict(api="whole", input=_inp(MUSIC, 403, 5000)), dict(api="whole", input=_inp(VARIED, 404, 1001))]),
+    "B4096_V0_long_then_odd_blocks": (dict(preset=4, max_block=4096, divisions=0), [
+        dict(api="whole", input=_inp(MUSIC, 411, 30000)), dict(api="block", input=_inp(VARIED, 412, 4095)),
+        dict(api="whole", input=_inp(NOISE, 413, 12289)), dict(api="size", input=_inp(VARIED, 414, 3001)),
+        dict(api="block", input=_inp(VARIED, 414, 3001))]),
+    "B2048_V2_P3_long_then_short_ltp_block": (dict(preset=4, max_block=2048, divisions=2, ltp_order=3), [
+        dict(api="whole", input=_inp(MUSIC, 421, 40961)), dict(api="whole", input=_inp(VARIED, 422, 199)),
+        dict(api="whole", input=_inp(MUSIC, 423, 24576)), dict(api="partitioned", input=_inp(VARIED, 424, 2049 + 100))]),
+    "B4095_V0_long_regular_interleaved": (dict(preset=4, max_block=4095, divisions=0, config=dict(min_block=4095, max_block=4095, lookahead=16380)), [
+        dict(api="whole", input=_inp(MUSIC, 431, 9001)),
+        dict(api="set", cli=dict(preset=4, max_block=4095, min_block=4095, lookahead=4095, ltp_order=1)),
+        dict(api="whole", input=_inp(VARIED, 432, 5017)),
+        dict(api="whole", input=_inp(MUSIC, 431, 9001))]),
+}
+# The one case the library cannot follow (counted, SRLAMI355X_NONIDENTICAL_HANDLE_HISTORY): the stream before ended in more than two
+# windows of digital silence, whose blocks the reference does not analyse (srla_encoder.c:766-796) -- what the buffer holds then is
+# what the stream's LAST AUDIBLE window left, which the library does not keep.
+SILENT_END = (dict(preset=4, max_block=4096, divisions=1), [
+    dict(api="whole", input=_inp(MUSIC, 441, 90000, zero_from=40000)), dict(api="whole", input=_inp(VARIED, 442, 2047)),
+    dict(api="whole", input=_inp(VARIED, 443, 1001))])
+
+
+def make_input(sp):
+    sp = dict(sp)
+    same = sp.pop("same", False)
+    zero_from = sp.pop("zero_from", None)
+    if same:                                   # identical channels: S = R - L is all zero
+        one = dict(sp, nch=1)
+        m = helpers.synth_spec(one)
+        a = np.ascontiguousarray(np.vstack([m] * sp["nch"]))
+    else:
+        a = helpers.synth_spec(sp)
+    if zero_from is not None:                  # digital silence from there on
+        a[:, zero_from:] = 0
+    return a
+
+
+def channels_of(steps):
+    return next(s["input"]["nch"] for s in steps if "input" in s)
+
+
+def run_on_library(lib, cli, steps):
+    """lib: capi.EncoderLib (the compiled reference, or the product) -> list of outputs (bytes as uint8 arrays; an int for "size"; None for "set")"""
+    nch = channels_of(steps)
+    cli = dict(cli)
+    wide = cli.pop("config", None)             # Create for more than the first parameters need (sequences that change them)
+    cfg, par = capi.cli_setup(nch, 16, 48000, **cli)
+    if wide:
+        cfg = capi.cli_setup(nch, 16, 48000, **wide)[0]
+    enc = lib.create(cfg)
+    if not enc:
+        raise RuntimeError("SRLAEncoder_Create failed")
+    outs = []
+    try:
+        if lib.set_parameter(enc, par) != capi.OK:
+            raise RuntimeError("SRLAEncoder_SetEncodeParameter failed")
+        for st in steps:
+            if st["api"] == "set":
+                _, p2 = capi.cli_setup(nch, 16, 48000, **st["cli"])
+                if lib.set_parameter(enc, p2) != capi.OK:
+                    raise RuntimeError("SRLAEncoder_SetEncodeParameter failed on the way")
+                outs.append(None)
+                continue
+            pcm = make_input(st["input"])
+            if st["api"] == "size":
+                rc, v = lib.compute_block_size(enc, pcm)
+            elif st["api"] == "block":
+                rc, v = lib.encode_block(enc, pcm)
+            elif st["api"] == "partitioned":
+                rc, v = lib.encode_partitioned(enc, pcm)
+            else:
+                rc, v = lib.encode_whole(enc, pcm)
+            if rc != capi.OK:
+                raise RuntimeError("%s -> %d" % (st["api"], rc))
+            outs.append(v)
+        return outs, enc
+    except Exception:
+        lib.destroy(enc)
+        raise
+
+
+def run_on_oracle(cli, steps):
+    """the oracle keeps the calculator's buffer per handle as the reference does; no SetEncodeParameter on the way, no partitioned call"""
+    nch = channels_of(steps)
+    o = helpers.Oracle(nch, **{k: v for k, v in cli.items() if k != "config"})
+    outs = []
+    for st in steps:
+        pcm = make_input(st["input"])
+        outs.append(o.compute_block_size(pcm) if st["api"] == "size" else o.encode_block(pcm) if st["api"] == "block" else o.encode_whole(pcm))
+    return outs
+
+
+def digest(v):
+    if v is None:
+        return None
+    if isinstance(v, (int, np.integer)):
+        return dict(size=int(v))
+    return dict(size=int(v.size), sha256=helpers.sha256(v))

@@ -156,25 +156,26 @@ def test_chain_tail_with_silence_raw_blocks_callback_and_device_input(product):
         assert np.array_equal(product.encode(x, **cli), helpers.Oracle(2, **cli).encode_whole(x)), m
 
 
-def test_odd_block_calls_on_a_fresh_handle(product):
-    """EncodeBlock / ComputeBlockSize / EncodeOptimalPartitionedBlock of odd-length input: a fresh handle starts from
-    a zeroed FFT buffer, as a fresh oracle does (calls on a used handle of the reference depend on all earlier calls)."""
+def test_odd_block_calls_follow_the_handles_history(product):
+    """EncodeBlock / ComputeBlockSize / EncodeOptimalPartitionedBlock of odd-length input: a fresh handle starts from a zeroed FFT
+    buffer, and every later call on the handle from what the calls before it left there -- as on ONE oracle handle, which keeps the
+    calculator's buffer like the reference (tests/test_handle_reuse.py pins that against the compiled reference)."""
     cli = dict(preset=4, max_block=4096, divisions=2, ltp_order=3)
     sig = helpers.synth(helpers.VARIED, 71, 48000, 2, 48000 * 2)
     cfg, par = capi.cli_setup(2, 16, 48000, **cli)
     enc = product.create(cfg)
     assert product.set_parameter(enc, par) == capi.OK
+    o = helpers.Oracle(2, **cli)
     for start, n in ((0, 4095), (48000, 1001), (30000, 301), (100, 99)):
         blk = np.ascontiguousarray(sig[:, start:start + n])
         rc, size = product.compute_block_size(enc, blk)
         rc2, data = product.encode_block(enc, blk)
         assert rc == rc2 == capi.OK
-        assert size == data.size
-        assert np.array_equal(data, helpers.Oracle(2, **cli).encode_block(blk)), (start, n)
+        assert size == o.compute_block_size(blk), (start, n)
+        assert np.array_equal(data, o.encode_block(blk)), (start, n)
     win = np.ascontiguousarray(sig[:, 20000:20000 + 16384 - 1027])
     rc, data = product.encode_partitioned(enc, win)
     assert rc == capi.OK
-    o = helpers.Oracle(2, **cli)
     parts = o.search_partitions(win)
     pos, chunks = 0, []
     for p in parts:
@@ -182,6 +183,14 @@ def test_odd_block_calls_on_a_fresh_handle(product):
         pos += p
     assert np.array_equal(data, np.concatenate(chunks))
     product.destroy(enc)
+    # a fresh handle per call gives what a fresh oracle gives
+    for start, n in ((48000, 1001), (100, 99)):
+        blk = np.ascontiguousarray(sig[:, start:start + n])
+        enc = product.create(cfg)
+        assert product.set_parameter(enc, par) == capi.OK
+        rc, data = product.encode_block(enc, blk)
+        product.destroy(enc)
+        assert rc == capi.OK and np.array_equal(data, helpers.Oracle(2, **cli).encode_block(blk)), (start, n)
 
 
 def test_round_trip_and_idempotence_at_full_size(product):
