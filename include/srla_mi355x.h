@@ -106,7 +106,10 @@ void SRLAEncoder_Destroy(struct SRLAEncoder *encoder);
 /* include/srla_encoder.h:54-55 (srla_encoder.c:710) */
 SRLAApiResult SRLAEncoder_SetEncodeParameter(struct SRLAEncoder *encoder, const struct SRLAEncodeParameter *parameter);
 
-/* include/srla_encoder.h:58-60 (srla_encoder.c:1477) */
+/* include/srla_encoder.h:58-60 (srla_encoder.c:1477).  As in the reference: with one or two channels the size SRLAEncoder_EncodeBlock
+ * writes; with more, the price of the block's first two channels (srla_encoder.c:1287-1301 adds up only those, :1519-1532 returns the
+ * sum) -- the number the block division search works with.  Like every entry point below it reads and leaves the handle's persistent
+ * analysis buffer as the reference's call does (DESIGN.md 4 "the buffer from call to call"). */
 SRLAApiResult SRLAEncoder_ComputeBlockSize(
     struct SRLAEncoder *encoder, const int32_t *const *input, uint32_t num_samples, uint32_t *output_size);
 

@@ -178,7 +178,8 @@ typedef struct SrlaBlockRecord {
     uint32_t bytes;         /* total block size incl. the 11-byte header */
     uint32_t item[SRLA_MAX_CH];  /* item index per output channel (compress blocks) */
     uint32_t seg;           /* segment of the job the block belongs to */
-    uint32_t pad;
+    uint32_t price;         /* what the block division search paid for the block = what SRLAEncoder_ComputeBlockSize returns: with more
+                             * than two channels the reference prices only the first two (srla_encoder.c:1287-1301, :1519-1532) */
 } SrlaBlockRecord;          /* 64 bytes */
 
 /* segments of a job for srla_make_variants (by value: no table upload) */

@@ -190,7 +190,15 @@ SRLAApiResult SRLAEncoder_ComputeBlockSize(struct SRLAEncoder *encoder, const in
     if (im == nullptr || input == NULL || num_samples == 0 || output_size == NULL) return SRLA_APIRESULT_INVALID_ARGUMENT;
     if (!im->set_parameter) return SRLA_APIRESULT_PARAMETER_NOT_SET;
     if (num_samples > im->par.max_num_samples_per_block) return SRLA_APIRESULT_INSUFFICIENT_BUFFER;
-    return one_stream(im, input, nullptr, 0, num_samples, nullptr, 0, output_size, nullptr, false, false);
+    /* With more than two channels the reference's answer is NOT the size EncodeBlock writes: ComputeCoefficients adds up the code
+     * lengths of the first two channels only (srla_encoder.c:1287-1301), and that sum is what ComputeBlockSize returns and what its
+     * RAW fall-back compares (:1519-1532) -- the price the block division search works with.  The same number here. */
+    im->want_block_price = im->par.num_channels > 2 && !im->no_chain;
+    im->block_price = 0;
+    const SRLAApiResult rc = one_stream(im, input, nullptr, 0, num_samples, nullptr, 0, output_size, nullptr, false, false);
+    if (rc == SRLA_APIRESULT_OK && im->want_block_price) *output_size = im->block_price;
+    im->want_block_price = false;
+    return rc;
 }
 
 SRLAApiResult SRLAEncoder_EncodeBlock(struct SRLAEncoder *encoder, const int32_t *const *input, uint32_t num_samples,

@@ -538,6 +538,14 @@ SRLAApiResult Impl::history_window(uint32_t stream, uint32_t pos, uint32_t n, bo
     }
     if (!history_commit(2, hs)) return SRLA_APIRESULT_NG;
     stats.num_history_windows++;
+    if (want_block_price) {
+        /* SRLAEncoder_ComputeBlockSize: what the SEARCH pays for the block (with more than two channels the reference prices the
+         * first two only, srla_encoder.c:1287-1301), which the pricing kernel left in the block's record */
+        SrlaBlockRecord rec;
+        if (hipMemcpy(&rec, e.d_blocks.as<SrlaBlockRecord>() + e.job.windows[0].block_base, sizeof(rec), hipMemcpyDeviceToHost) != hipSuccess || !rec.valid)
+            return SRLA_APIRESULT_NG;
+        block_price = rec.price;
+    }
     return finish_job(e);
 }
 

@@ -449,11 +449,13 @@ struct Impl {
      * with, output discarded (replay_tail), which leaves the buffer as the reference's call left it.  Calls that never read the
      * buffer pay the copy (two windows) and nothing else. */
     struct TailCapture {
-        bool valid = false, copied = false;
+        bool valid = false, copied = false, silent_stream = false;
         SRLAEncodeParameter par{};
         uint32_t lshift = 0, n = 0, nch = 0;
         PinBuf smp;                       /* nch planes of n samples */
     } tail;
+    bool want_block_price = false;        /* SRLAEncoder_ComputeBlockSize with more than two channels: the search's price of the block */
+    uint32_t block_price = 0;
     bool replaying = false;
     std::vector<uint8_t> replay_out;
     bool keep_tail(const StreamCtx &st, bool search);   /* the samples of the last two windows (before the call's last wait) */

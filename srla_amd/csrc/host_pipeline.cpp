@@ -1038,7 +1038,9 @@ SRLAApiResult Impl::encode_streams(bool search)
     }
     /* a regular call of several windows: none of its blocks reaches back beyond its own stream, and what it leaves in the
      * reference's buffer is not tracked */
-    if (tracked) { hist_fresh = false; hist_exact = 0; tail.valid = false; }
+    const bool fresh_before = hist_fresh;
+    const uint32_t exact_before = hist_exact;
+    if (tracked) { hist_fresh = false; hist_exact = 0; tail.silent_stream = false; }      /* (tail: keep_tail, once the stream has been looked at) */
     if (need_oracc) {
         if ((size_t)8 * nst > d_oracc.cap) { drain(); if (!d_oracc.ensure((size_t)8 * nst)) return SRLA_APIRESULT_NG; }
         if (hipMemsetAsync(d_oracc.p, 0, (size_t)8 * nst, upload) != hipSuccess) return SRLA_APIRESULT_NG;
@@ -1058,6 +1060,7 @@ SRLAApiResult Impl::encode_streams(bool search)
         drain();
         for (auto &sl : slot) sl.busy = false;
         chain.active = false;
+        if (tracked) { tail.valid = false; hist_exact = 0; }     /* (the reference's call stopped somewhere, too) */
         return rc;
     };
     auto job_slot = [&](uint32_t k) -> Slot & { return slot[plan[k].slot]; };
@@ -1279,6 +1282,8 @@ SRLAApiResult Impl::encode_streams(bool search)
         for (const void *p : pins.held) host_pin_release(p);
         pins.held.clear();
     }
+    if (tracked && tail.silent_stream && worst == SRLA_APIRESULT_OK) { hist_fresh = fresh_before; hist_exact = exact_before; }   /* a silent stream: no call of the reference's calculator */
+    else if (tracked && !tail.copied) tail.valid = false;                                       /* (a call that failed on the way) */
     if (tracked && tail.copied && worst == SRLA_APIRESULT_OK) {
         /* what a later call on this handle may have to know (host_impl.h, TailCapture); the shift is final only now */
         if (sx[0].d_in && hipStreamSynchronize(upload) != hipSuccess) return fail(SRLA_APIRESULT_NG);
@@ -1294,9 +1299,28 @@ bool Impl::keep_tail(const StreamCtx &st, bool search)
 {
     const uint32_t window_len = search ? par.num_lookahead_samples : par.max_num_samples_per_block, nch = par.num_channels;
     const uint32_t nwin = (st.num_samples + window_len - 1) / window_len;
-    const uint32_t start = (nwin >= 2 ? nwin - 2 : 0) * window_len, n = st.num_samples - start;
-    tail.copied = false;
+    uint32_t start = (nwin >= 2 ? nwin - 2 : 0) * window_len, n = st.num_samples - start;
+    tail.copied = false; tail.silent_stream = false;
     if (st.host_in == nullptr && st.d_in == nullptr) return true;
+    if (st.host_in) {
+        /* digital silence at the end: its blocks are not analysed (srla_encoder.c:766-796), so what the buffer holds is what the
+         * last AUDIBLE window and the one before it left -- those two are kept (looking back over at most 64 windows) */
+        const uint32_t lo = (nwin > 64u) ? (nwin - 64u) * window_len : 0u;
+        uint32_t audible = lo;                                  /* one past the last non-zero sample */
+        for (uint32_t ch = 0; ch < nch; ch++) {
+            const int32_t *p = st.host_in[ch];
+            uint32_t i = st.num_samples;
+            while (i > audible && p[i - 1] == 0) i--;
+            audible = std::max(audible, i);
+        }
+        if (audible == 0) { tail.silent_stream = true; return true; }      /* nothing was analysed: the buffer, and what is kept of the call before, stay */
+        if (audible > lo) {
+            const uint32_t wa = (audible - 1) / window_len;
+            start = (wa >= 1 ? wa - 1 : 0) * window_len;
+            n = std::min<uint64_t>(st.num_samples, (uint64_t)(wa + 1) * window_len) - start;
+        }
+    }
+    tail.valid = false;
     if (!tail.smp.ensure((size_t)nch * n * 4)) return false;
     for (uint32_t ch = 0; ch < nch; ch++) {
         int32_t *dst = tail.smp.as<int32_t>() + (size_t)ch * n;

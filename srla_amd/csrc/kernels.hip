@@ -3512,7 +3512,7 @@ __global__ __launch_bounds__(WAVE) void srla_price_windows(SrlaJobParams jp, con
             }
             rec->item[ch] = it;
         }
-        rec->seg = wd.seg; rec->pad = 0;
+        rec->seg = wd.seg; rec->price = packed & 0x0FFFFFFFu;
     }
 }
 

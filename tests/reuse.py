@@ -79,24 +79,33 @@ SEQUENCES = {
     "B2048_V2_P3_long_then_short_ltp_block": (dict(preset=4, max_block=2048, divisions=2, ltp_order=3), [
         dict(api="whole", input=_inp(MUSIC, 421, 40961)), dict(api="whole", input=_inp(VARIED, 422, 199)),
         dict(api="whole", input=_inp(MUSIC, 423, 24576)), dict(api="partitioned", input=_inp(VARIED, 424, 2049 + 100))]),
+    # digital silence at the end of a stream of several windows (its blocks are not analysed, srla_encoder.c:766-796): the buffer holds
+    # what the last AUDIBLE windows left; an all-silent stream leaves it alone
+    "B4096_V1_silent_end_then_clips": (dict(preset=4, max_block=4096, divisions=1), [
+        dict(api="whole", input=_inp(MUSIC, 441, 90000, zero_from=40000)), dict(api="whole", input=_inp(VARIED, 442, 2047)),
+        dict(api="whole", input=_inp(MUSIC, 446, 50000, zero_from=0)), dict(api="whole", input=_inp(VARIED, 443, 1001)),
+        dict(api="whole", input=_inp(MUSIC, 447, 70000)), dict(api="whole", input=_inp(MUSIC, 446, 50000, zero_from=0)),
+        dict(api="whole", input=_inp(VARIED, 448, 4095))]),
     "B4095_V0_long_regular_interleaved": (dict(preset=4, max_block=4095, divisions=0, config=dict(min_block=4095, max_block=4095, lookahead=16380)), [
         dict(api="whole", input=_inp(MUSIC, 431, 9001)),
         dict(api="set", cli=dict(preset=4, max_block=4095, min_block=4095, lookahead=4095, ltp_order=1)),
         dict(api="whole", input=_inp(VARIED, 432, 5017)),
         dict(api="whole", input=_inp(MUSIC, 431, 9001))]),
 }
-# The one case the library cannot follow (counted, SRLAMI355X_NONIDENTICAL_HANDLE_HISTORY): the stream before ended in more than two
-# windows of digital silence, whose blocks the reference does not analyse (srla_encoder.c:766-796) -- what the buffer holds then is
-# what the stream's LAST AUDIBLE window left, which the library does not keep.
-SILENT_END = (dict(preset=4, max_block=4096, divisions=1), [
-    dict(api="whole", input=_inp(MUSIC, 441, 90000, zero_from=40000)), dict(api="whole", input=_inp(VARIED, 442, 2047)),
-    dict(api="whole", input=_inp(VARIED, 443, 1001))])
+# What the library cannot follow (counted, SRLAMI355X_NONIDENTICAL_HANDLE_HISTORY): of a regular call it keeps the last audible window
+# and the one before it; here those are a silent window and 100 samples, whose transform rewrites 256 words -- the words above are
+# what the stream BEFORE left, which is no longer kept.
+UNKNOWN_WORDS = (dict(preset=4, max_block=4096, divisions=1), [
+    dict(api="whole", input=_inp(MUSIC, 441, 90000)),
+    dict(api="whole", input=_inp(MUSIC, 445, 2 * 16384 + 100, zero_to=2 * 16384)),
+    dict(api="whole", input=_inp(VARIED, 442, 2047)), dict(api="whole", input=_inp(VARIED, 443, 1001))])
 
 
 def make_input(sp):
     sp = dict(sp)
     same = sp.pop("same", False)
     zero_from = sp.pop("zero_from", None)
+    zero_to = sp.pop("zero_to", None)
     if same:                                   # identical channels: S = R - L is all zero
         one = dict(sp, nch=1)
         m = helpers.synth_spec(one)
@@ -105,6 +114,8 @@ def make_input(sp):
         a = helpers.synth_spec(sp)
     if zero_from is not None:                  # digital silence from there on
         a[:, zero_from:] = 0
+    if zero_to is not None:                    # ... up to there
+        a[:, :zero_to] = 0
     return a
 
 

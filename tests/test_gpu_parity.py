@@ -304,6 +304,28 @@ def test_full_scale_stream_bytes_equal_oracle(product, cli_name):
 
 
 # ------------------------------------------------------------------------------ block API ------
+@pytest.mark.parametrize("nch,bps", [(3, 16), (5, 24), (8, 8)])
+def test_compute_block_size_of_more_than_two_channels(product, nch, bps):
+    """with 3+ channels the reference's ComputeBlockSize is the SEARCH's price of the block -- the first two channels only
+    (srla_encoder.c:1287-1301, :1519-1532; pinned by tests/test_oracle_vs_reference.py) --, not the size EncodeBlock writes"""
+    cli = dict(preset=4, max_block=2048, divisions=1, ltp_order=3 if nch == 5 else 0)
+    cfg, par = capi.cli_setup(nch, bps, 48000, **cli)
+    enc = product.create(cfg)
+    assert product.set_parameter(enc, par) == capi.OK
+    o = helpers.Oracle(nch, bits_per_sample=bps, **cli)
+    sig = helpers.synth(helpers.VARIED, 170 + nch, 48000, nch, 30000, bps)
+    noise = helpers.synth(helpers.NOISE, 171, 48000, nch, 2048, bps)
+    blocks = [np.ascontiguousarray(sig[:, s:s + n]) for s, n in ((0, 2048), (9000, 2047), (20000, 700), (100, 20))]
+    blocks += [noise, np.zeros((nch, 1500), dtype=np.int32)]                    # RAW by size, SILENT
+    for blk in blocks:
+        rc, size = product.compute_block_size(enc, blk)
+        rc2, data = product.encode_block(enc, blk)
+        assert rc == rc2 == capi.OK
+        assert size == o.compute_block_size(blk), blk.shape
+        assert np.array_equal(data, o.encode_block(blk)), blk.shape
+    product.destroy(enc)
+
+
 def test_block_calls(product):
     cli = dict(preset=4, max_block=4096, divisions=2)
     cfg, par = capi.cli_setup(2, 16, 48000, **cli)

@@ -24,7 +24,7 @@ def _same(got, gold):
 
 
 def test_goldens_cover_the_sequences_and_some_calls_show_the_carry():
-    assert sorted(GOLD) == sorted(NAMES + ["silent_end"])
+    assert sorted(GOLD) == sorted(NAMES + ["unknown_words"])
     for name in NAMES:
         steps = reuse.SEQUENCES[name][1]
         assert [c["api"] for c in GOLD[name]] == [s["api"] for s in steps]
@@ -66,9 +66,9 @@ def test_library_reproduces_the_reference_call_after_call(product, name, capfd):
 
 @pytest.mark.gpu
 def test_a_word_the_library_does_not_know_is_counted(product, capfd):
-    """behind a stream that ends in more than two windows of digital silence the buffer holds what the last AUDIBLE window left; a
-    clip whose first block reaches back into it is counted and named, and still decodes to its input"""
-    cli, steps = reuse.SILENT_END
+    """of a regular call the library keeps the last audible window and the one before; when those rewrite only the buffer's first words
+    (a silent window and 100 samples), a clip that reaches beyond them is counted and named, and still decodes to its input"""
+    cli, steps = reuse.UNKNOWN_WORDS
     outs, enc = reuse.run_on_library(product, cli, steps)
     try:
         st = _stats(product, enc)
@@ -76,7 +76,7 @@ def test_a_word_the_library_does_not_know_is_counted(product, capfd):
         product.destroy(enc)
     assert st.num_nonidentical_calls >= 1 and st.nonidentical_reasons == HANDLE_HISTORY
     assert "NOT guaranteed bit-identical" in capfd.readouterr().err
-    assert _same(outs[0], GOLD["silent_end"][0])
+    assert _same(outs[0], GOLD["unknown_words"][0]) and _same(outs[1], GOLD["unknown_words"][1])
     for stp, o in zip(steps, outs):
         assert np.array_equal(helpers.oracle_decode(o), reuse.make_input(stp["input"]))
 

@@ -76,6 +76,26 @@ def test_block_level_api_matches():
     assert np.array_equal(o.encode_block(pcm), data)
 
 
+def test_compute_block_size_of_more_than_two_channels_prices_the_first_two():
+    """srla_encoder.c:1287-1301 adds up the code lengths of channels 0 and 1 only, and :1519-1532 returns that sum: with 3+ channels
+    ComputeBlockSize is NOT the size EncodeBlock writes -- it is the price the block division search works with"""
+    ref = helpers.reference_encoder()
+    from srla_amd import capi
+    for nch, kind in ((3, helpers.MUSIC), (5, helpers.VARIED), (8, helpers.NOISE)):
+        cli = dict(preset=4, max_block=2048, divisions=1)
+        pcm = helpers.synth(kind, 3080 + nch, 48000, nch, 2048)
+        cfg, par = capi.cli_setup(nch, 16, 48000, **cli)
+        enc = ref.create(cfg)
+        assert ref.set_parameter(enc, par) == capi.OK
+        rc, size = ref.compute_block_size(enc, pcm)
+        rc2, data = ref.encode_block(enc, pcm)
+        ref.destroy(enc)
+        o = helpers.Oracle(nch, **cli)
+        assert rc == rc2 == capi.OK
+        assert o.compute_block_size(pcm) == size and size < data.size
+        assert np.array_equal(o.encode_block(pcm), data)
+
+
 SVR = [dict(preset=2, max_block=4096, divisions=1, svr_iterations=1), dict(preset=4, max_block=4096, divisions=1, svr_iterations=5),
        dict(preset=4, max_block=4096, divisions=2, ltp_order=3, svr_iterations=2), dict(preset=6, max_block=2048, divisions=0, svr_iterations=3),
        dict(preset=3, max_block=8192, divisions=1, svr_iterations=10)]
