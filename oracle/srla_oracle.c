@@ -826,6 +826,18 @@ void oracle_destroy(struct Oracle *o)
     free(o);
 }
 
+int oracle_set_parameter(struct Oracle *o, const OracleConfig *cfg)
+{
+    if (!o || !cfg || cfg->num_channels != o->cfg.num_channels || cfg->max_block != o->cfg.max_block
+        || cfg->min_block == 0 || cfg->min_block > cfg->max_block || cfg->lookahead < cfg->max_block
+        || (cfg->lookahead % cfg->min_block) != 0 || cfg->preset > 6
+        || (cfg->ltp_order > 0 && (cfg->ltp_order % 2) == 0) || cfg->ltp_order > ORACLE_LTP_TAPS)
+        return -1;
+    o->cfg = *cfg;
+    o->offset_lshift = 0;          /* srla_encoder.c:743-750: a new header */
+    return 0;
+}
+
 void oracle_set_offset_lshift(struct Oracle *o, uint32_t lshift) { o->offset_lshift = lshift; }
 void oracle_set_svr_iterations(struct Oracle *o, uint32_t iterations) { o->svr_iterations = iterations; }
 

@@ -65,6 +65,10 @@ struct Oracle;
 
 struct Oracle *oracle_create(const OracleConfig *cfg);
 void oracle_destroy(struct Oracle *o);
+/* SRLAEncoder_SetEncodeParameter on a used handle (srla_encoder.c:710-763): the parameters change -- within what the handle was
+ * created for; this restatement allocates by the maximum block, so that has to stay --, the header starts over (offset shift 0), the
+ * calculator and with it the persistent FFT buffer STAY.  0 on success. */
+int oracle_set_parameter(struct Oracle *o, const OracleConfig *cfg);
 void oracle_set_offset_lshift(struct Oracle *o, uint32_t lshift);
 void oracle_set_svr_iterations(struct Oracle *o, uint32_t iterations);   /* --svr-filter-learning-iteration (lpc.c:1036-1136) */
 int oracle_svr_refine(const double *data, uint32_t num_samples, double *coef, uint32_t order, uint32_t max_iter);

@@ -65,6 +65,8 @@ def oracle_lib():
         lib.oracle_create.restype = C.c_void_p
         lib.oracle_create.argtypes = [C.POINTER(OracleConfig)]
         lib.oracle_destroy.argtypes = [C.c_void_p]
+        lib.oracle_set_parameter.argtypes = [C.c_void_p, C.POINTER(OracleConfig)]
+        lib.oracle_set_parameter.restype = C.c_int
         lib.oracle_set_offset_lshift.argtypes = [C.c_void_p, C.c_uint32]
         lib.oracle_set_svr_iterations.argtypes = [C.c_void_p, C.c_uint32]
         lib.oracle_svr_refine.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32]
@@ -185,6 +187,17 @@ class Oracle:
             self.h = None
 
     __del__ = close
+
+    def set_parameter(self, preset=4, max_block=4096, divisions=1, lookahead_factor=4, ltp_order=0, min_block=None, lookahead=None,
+                      svr_iterations=0):
+        """SetEncodeParameter on the used handle: the persistent buffer stays (same maximum block and channels)"""
+        minb = (max_block >> divisions) if min_block is None else min_block
+        look = lookahead_factor * max_block if lookahead is None else lookahead
+        cfg = OracleConfig(self.cfg.num_channels, self.cfg.bits_per_sample, self.cfg.sampling_rate, minb, max_block, look, ltp_order, preset)
+        if self.lib.oracle_set_parameter(self.h, C.byref(cfg)) != 0:
+            raise ValueError("oracle_set_parameter rejected the parameters")
+        self.cfg = cfg
+        self.lib.oracle_set_svr_iterations(self.h, svr_iterations)
 
     def set_offset_lshift(self, s):
         self.lib.oracle_set_offset_lshift(self.h, s)

@@ -164,13 +164,29 @@ def run_on_library(lib, cli, steps):
 
 
 def run_on_oracle(cli, steps):
-    """the oracle keeps the calculator's buffer per handle as the reference does; no SetEncodeParameter on the way, no partitioned call"""
+    """the oracle keeps the calculator's buffer per handle as the reference does (a partitioned call = the search, then EncodeBlock per
+    partition, srla_encoder.c:1646-1698)"""
     nch = channels_of(steps)
     o = helpers.Oracle(nch, **{k: v for k, v in cli.items() if k != "config"})
     outs = []
     for st in steps:
+        if st["api"] == "set":
+            o.set_parameter(**st["cli"])
+            outs.append(None)
+            continue
         pcm = make_input(st["input"])
-        outs.append(o.compute_block_size(pcm) if st["api"] == "size" else o.encode_block(pcm) if st["api"] == "block" else o.encode_whole(pcm))
+        if st["api"] == "size":
+            outs.append(o.compute_block_size(pcm))
+        elif st["api"] == "block":
+            outs.append(o.encode_block(pcm))
+        elif st["api"] == "partitioned":
+            pos, chunks = 0, []
+            for p in o.search_partitions(pcm):
+                chunks.append(o.encode_block(np.ascontiguousarray(pcm[:, pos:pos + p])))
+                pos += p
+            outs.append(np.concatenate(chunks))
+        else:
+            outs.append(o.encode_whole(pcm))
     return outs
 
 

@@ -5,9 +5,10 @@ tests/test_handle_reuse.py).
 
     python tools/gpu_reuse_sweep.py [sequences] [seed]
 
-Every sequence: random parameters (regular and history regimes, LTP, now and then SVR), 3-9 calls of EncodeWhole /
+Every sequence: random parameters (regular and history regimes, LTP, now and then SVR; 8 / 16 / 24 bit), 3-9 calls of EncodeWhole /
 ComputeBlockSize / EncodeBlock / EncodeOptimalPartitionedBlock with lengths around the block and window sizes (odd and even, clips
-of less than a window, streams of several windows), inputs of every kind incl. identical channels and digital silence at the end.
+of less than a window, streams of several windows), now and then SetEncodeParameter in between, inputs of every kind incl.
+identical channels, digital silence at the end and an offset left shift.
 A call the library counts as SRLAMI355X_NONIDENTICAL_HANDLE_HISTORY may differ (reported separately); any other difference is a
 mismatch (exit status 1)."""
 import ctypes as C
@@ -55,8 +56,29 @@ def sequences(count, seed):
         if rnd.random() < 0.12:
             cli["svr_iterations"] = rnd.choice([1, 2])
         window = look if divisions else max_block
+        bps = rnd.choice([16, 16, 16, 8, 24])
         steps = []
         for k in range(rnd.randint(3, 9)):
+            if k > 0 and rnd.random() < 0.15:
+                # SetEncodeParameter on the way: everything but the maximum block (the reference searches up to the one the encoder was
+                # created for) and the channels
+                d2 = rnd.choice([0, 1, 2, 3])
+                if max_block % (1 << d2) != 0 or (max_block >> d2) < 32:
+                    d2 = 0
+                p2 = rnd.choice([1, 2, 3, 4, 4, 5])
+                if [0, 8, 16, 32, 64, 128, 255][p2] > (max_block >> d2):
+                    p2 = 2
+                l2 = rnd.choice([0, 0, 1, 3])
+                if l2 and max_block <= 256:
+                    l2 = 0
+                divisions, min_block = d2, max_block >> d2
+                look = rnd.choice([2, 4]) * max_block if divisions else 4 * max_block
+                window = look if divisions else max_block
+                new = dict(preset=p2, max_block=max_block, divisions=d2, ltp_order=l2, lookahead_factor=look // max_block)
+                if rnd.random() < 0.1:
+                    new["svr_iterations"] = 1
+                steps.append(dict(api="set", cli=new))
+                cli_now = new
             api = rnd.choice(["whole", "whole", "whole", "block", "size", "partitioned"])
             if api in ("block", "size"):
                 n = rnd.choice([max_block, max_block - 1, rnd.randint(1, max_block), rnd.randint(1, max_block) | 1, min_block + 1])
@@ -67,17 +89,17 @@ def sequences(count, seed):
             else:
                 n = rnd.choice([rnd.randint(1, window), rnd.randint(1, window) | 1, window + rnd.randint(1, window), rnd.randint(2, 6) * window + rnd.randint(0, window),
                                 (rnd.randint(2, 5) * window + rnd.randint(0, window)) | 1, rnd.randint(1, min_block) | 1])
-            n = max(2, min(n, 60000 if "svr_iterations" in cli else 200000))
+            n = max(2, min(n, 60000 if ("svr_iterations" in cli or any("svr_iterations" in x.get("cli", {}) for x in steps)) else 200000))
             if api in ("block", "size"):
                 n = min(n, max_block)
             kind = rnd.choice([helpers.MUSIC, helpers.VARIED, helpers.VARIED, helpers.NOISE, helpers.SINE])
-            twist = rnd.choice(["none", "none", "none", "identical", "silent_end", "silent_all", "impulses"])
+            twist = rnd.choice(["none", "none", "none", "identical", "silent_end", "silent_all", "impulses", "shifted"])
             steps.append(dict(api=api, n=n, kind=kind, seed=seed * 1000 + case * 16 + k, twist=twist))
-        yield case, nch, cli, steps
+        yield case, nch, bps, cli, steps
 
 
-def make_input(st, nch):
-    a = helpers.synth(st["kind"], st["seed"], 48000, nch, st["n"], 16)
+def make_input(st, nch, bps=16):
+    a = helpers.synth(st["kind"], st["seed"], 48000, nch, st["n"], bps)
     r = np.random.RandomState(st["seed"] % (1 << 31))
     t = st["twist"]
     if t == "identical":
@@ -86,6 +108,8 @@ def make_input(st, nch):
         a[:, int(r.randint(0, a.shape[1])):] = 0
     elif t == "silent_all":
         a[:] = 0
+    elif t == "shifted":
+        a[:] = (a >> 3) << 3                       # an offset left shift: EncodeWhole leaves it in the handle's header for the block calls
     elif t == "impulses":
         keep = np.zeros(a.shape[1], dtype=bool)
         keep[::int(r.randint(40, 900))] = True
@@ -114,14 +138,21 @@ def main():
     lib = capi.EncoderLib(helpers.PRODUCT_SO)
     lib.lib.SRLAMI355X_GetStats.argtypes = [C.c_void_p, C.POINTER(bench.Stats), C.c_int]
     calls = mismatches = flagged_calls = flagged_differ = seqs = 0
-    for case, nch, cli, steps in sequences(count, seed):
-        cfg, par = capi.cli_setup(nch, 16, 48000, **cli)
+    for case, nch, bps, cli, steps in sequences(count, seed):
+        cfg, par = capi.cli_setup(nch, bps, 48000, **cli)
+        # created for everything the sequence's parameter changes may ask for (same maximum block)
+        cfg.min_num_samples_per_block = min([par.min_num_samples_per_block] + [cli["max_block"] >> x["cli"]["divisions"] for x in steps if x["api"] == "set"])
+        cfg.max_num_lookahead_samples = 4 * cli["max_block"]
         enc = lib.create(cfg)
         assert enc and lib.set_parameter(enc, par) == capi.OK
-        o = helpers.Oracle(nch, **cli)
+        o = helpers.Oracle(nch, bits_per_sample=bps, **cli)
         seqs += 1
         for k, st in enumerate(steps):
-            pcm = make_input(st, nch)
+            if st["api"] == "set":
+                assert lib.set_parameter(enc, capi.cli_setup(nch, bps, 48000, **st["cli"])[1]) == capi.OK
+                o.set_parameter(**st["cli"])
+                continue
+            pcm = make_input(st, nch, bps)
             before = bench.Stats(); lib.lib.SRLAMI355X_GetStats(enc, C.byref(before), 0)
             if st["api"] == "size":
                 rc, got = lib.compute_block_size(enc, pcm)
