@@ -100,3 +100,36 @@ def test_a_batch_neither_reads_nor_changes_the_handles_buffer(product):
                 assert rc == capi.OK and all(np.array_equal(o, fresh) for o in outs)
     finally:
         product.destroy(enc)
+
+
+@pytest.mark.gpu
+def test_streams_from_device_memory_leave_the_buffer_too(product):
+    """SRLAMI355X_EncodeWholeDevice counts as EncodeWhole: its kept windows come out of device memory"""
+    import torch
+    from srla_amd import capi
+    name = "B4096_V0_long_then_odd_blocks"
+    cli, steps = reuse.SEQUENCES[name]
+    cfg, par = capi.cli_setup(2, 16, 48000, **cli)
+    enc = product.create(cfg)
+    fn = product.lib.SRLAMI355X_EncodeWholeDevice
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.c_void_p]
+    try:
+        assert product.set_parameter(enc, par) == capi.OK
+        for i, (stp, gold) in enumerate(zip(steps, GOLD[name])):
+            pcm = reuse.make_input(stp["input"])
+            if stp["api"] == "whole":
+                d = torch.from_numpy(pcm).cuda()
+                torch.cuda.synchronize()
+                buf = np.zeros(pcm.size * 4 + 4096, np.uint8)
+                out = C.c_uint32(0)
+                rc = fn(enc, C.c_void_p(d.data_ptr()), pcm.shape[1], pcm.shape[1], buf.ctypes.data_as(C.c_void_p), buf.size, C.byref(out), None)
+                got = buf[:out.value]
+                del d
+            elif stp["api"] == "size":
+                rc, got = product.compute_block_size(enc, pcm)
+            else:
+                rc, got = product.encode_block(enc, pcm)
+            assert rc == capi.OK and _same(got, gold), i
+        assert _stats(product, enc).num_nonidentical_calls == 0
+    finally:
+        product.destroy(enc)
