@@ -456,6 +456,8 @@ bool Impl::history_commit(uint32_t jobidx, hipStream_t stream)
 
 SRLAApiResult Impl::history_window(uint32_t stream, uint32_t pos, uint32_t n, bool search)
 {
+    const auto tw0 = Clock::now();
+    double t_prep1 = 0, t_dev1 = 0, t_read = 0, t_prep2 = 0, t_dev2 = 0;
     ChainRun &c = chain;
     StreamCtx &st = sx[stream];
     const uint32_t nch = par.num_channels;
@@ -493,7 +495,9 @@ SRLAApiResult Impl::history_window(uint32_t stream, uint32_t pos, uint32_t n, bo
             chain_tab_uploaded = 0;
             if (!prepare_job(sj, false) || !chain_stage_a(sj, 1, c.cs)) return SRLA_APIRESULT_NG;
             for (int st2 = ST_B; st2 <= ST_D; st2++) if (!run_stage(sj, st2)) return SRLA_APIRESULT_NG;
+            t_prep1 = ms_since(tw0);
             if (hipEventSynchronize(sj.t1[ST_D]) != hipSuccess) return SRLA_APIRESULT_NG;
+            t_dev1 = ms_since(tw0);
             const int m = arbitrate(sj, kChainJobKey + 1);
             if (m < 0) return SRLA_APIRESULT_NG;
             if (m == 0) break;
@@ -509,6 +513,7 @@ SRLAApiResult Impl::history_window(uint32_t stream, uint32_t pos, uint32_t n, bo
         uint32_t covered = 0;
         for (const SrlaBlockRecord &r : recs) if (r.valid) { lens.push_back(r.n); covered += r.n; }
         if (covered != n) { fprintf(stderr, "[srla-mi355x] internal error: a window's partitions cover %u of %u samples\n", covered, n); return SRLA_APIRESULT_NG; }
+        t_read = ms_since(tw0);
     } else lens.push_back(n);
 
     /* SRLAEncoder_EncodeBlock for every block of the partition (srla_encoder.c:1676-1692): analysed again, where they now stand */
@@ -528,7 +533,9 @@ SRLAApiResult Impl::history_window(uint32_t stream, uint32_t pos, uint32_t n, bo
         st.pass_started = false;                                 /* the window goes where the host knows the stream has reached */
         if (!prepare_job(e, false) || !chain_stage_a(e, 2, c.ce)) return SRLA_APIRESULT_NG;
         for (int st2 = ST_B; st2 <= ST_E; st2++) if (!run_stage(e, st2)) return SRLA_APIRESULT_NG;
+        t_prep2 = ms_since(tw0);
         if (!wait_job(e)) return SRLA_APIRESULT_NG;
+        t_dev2 = ms_since(tw0);
         if (e.h_info.as<SrlaJobInfo>()->num_tie_items == 0) break;
         const int m = arbitrate(e, kChainJobKey + 2);
         if (m < 0) return SRLA_APIRESULT_NG;
@@ -538,6 +545,9 @@ SRLAApiResult Impl::history_window(uint32_t stream, uint32_t pos, uint32_t n, bo
     }
     if (!history_commit(2, hs)) return SRLA_APIRESULT_NG;
     stats.num_history_windows++;
+    if (chain_trace)
+        fprintf(stderr, "[history] window of %u: search enqueued %.3f, priced %.3f, partition read %.3f, encode enqueued %.3f, collected %.3f ms (%u + %u rounds)\n",
+                n, t_prep1, t_dev1, t_read, t_prep2, t_dev2, search ? c.cs.rounds : 0u, c.ce.rounds);
     if (want_block_price) {
         /* SRLAEncoder_ComputeBlockSize: what the SEARCH pays for the block (with more than two channels the reference prices the
          * first two only, srla_encoder.c:1287-1301), which the pricing kernel left in the block's record */
