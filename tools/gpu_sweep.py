@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity sweep on an MI355X: library bytes vs oracle bytes over random configurations and lengths.
 
-    python tools/gpu_sweep.py [cases] [seed] [--mutate] [--history]
+    python tools/gpu_sweep.py [cases] [seed] [--mutate] [--history] [--paths]
 
 Any length, odd ones included (the last window of such a stream is history dependent in the reference and goes
 through the library's chain mode); LTP with any minimum block and odd block sizes (history mode: every
@@ -140,7 +140,78 @@ def is_history_regime(cli):
     return bool(minb & 1) or (cli.get("ltp_order", 0) > 0 and minb <= 256)
 
 
-def sweep(count, seed, max_samples=6_000_000, with_mutations=False, only_history=False):
+PATHS = ("pageable", "pinned_planes", "device_memory", "callback", "pinned_output", "few_threads")
+
+
+def encode_by_path(lib, pcm, bps, cli, path):
+    """with `--paths`: the same stream through the other ways into and out of SRLAEncoder_EncodeWhole -- planes in
+    SRLAMI355X_AllocHost memory (read by DMA where they lie, the offset shift guessed from the first samples and checked on the
+    device), planes in device memory (SRLAMI355X_EncodeWholeDevice), a block callback (the OR pass first, the bytes delivered window by
+    window), the output buffer in pinned memory (written by the device), a pool of two host threads (planes locked in place)"""
+    import ctypes as C
+    L = lib.lib
+    if path == "pageable":
+        return lib.encode(pcm, bits_per_sample=bps, **cli)
+    cfg, par = capi.cli_setup(pcm.shape[0], bps, 48000, **cli)
+    enc = lib.create(cfg)
+    if not enc:
+        raise RuntimeError("SRLAEncoder_Create failed")
+    L.SRLAMI355X_AllocHost.restype = C.c_void_p
+    L.SRLAMI355X_AllocHost.argtypes = [C.c_size_t]
+    L.SRLAMI355X_FreeHost.argtypes = [C.c_void_p]
+    held = []
+    try:
+        rc = lib.set_parameter(enc, par)
+        if rc != capi.OK:
+            raise RuntimeError("SRLAEncoder_SetEncodeParameter -> %d" % rc)
+        cap = 2 * pcm.size * 4 + 1024
+        if path == "pinned_planes":
+            ptr = L.SRLAMI355X_AllocHost(pcm.nbytes)
+            held.append(ptr)
+            pin = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_int32)), shape=pcm.shape)
+            pin[:] = pcm
+            rc, data = lib.encode_whole(enc, pin)
+        elif path == "device_memory":
+            import torch
+            d = torch.from_numpy(pcm).cuda()
+            torch.cuda.synchronize()
+            fn = L.SRLAMI355X_EncodeWholeDevice
+            fn.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.c_void_p]
+            buf = np.zeros(cap, np.uint8)
+            out = C.c_uint32(0)
+            rc = fn(enc, C.c_void_p(d.data_ptr()), pcm.shape[1], pcm.shape[1], buf.ctypes.data_as(C.c_void_p), buf.size, C.byref(out), None)
+            data = buf[:out.value].copy()
+            del d
+        elif path == "callback":
+            seen = []
+
+            def cb(num_samples, progress, ptr, size):
+                seen.append((num_samples, progress, size))
+            rc, data = lib.encode_whole(enc, pcm, callback=cb)
+            if rc == capi.OK:
+                assert seen and seen[-1][1] == pcm.shape[1] and all(x[0] == pcm.shape[1] for x in seen), "callback progress"
+                assert sum(x[2] for x in seen) == data.size - capi.HEADER_SIZE, "callback sizes"
+                assert all(a[1] < b[1] for a, b in zip(seen, seen[1:])), "callback order"
+        elif path == "pinned_output":
+            ptr = L.SRLAMI355X_AllocHost(cap)
+            held.append(ptr)
+            out = C.c_uint32(0)
+            rc = L.SRLAEncoder_EncodeWhole(enc, capi.planar_ptrs(pcm), pcm.shape[1], C.c_void_p(ptr), cap, C.byref(out), None)
+            data = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(cap,))[:out.value].copy()
+        else:
+            L.SRLAMI355X_SetPackThreads.argtypes = [C.c_void_p, C.c_uint32]
+            L.SRLAMI355X_SetPackThreads(enc, 2)
+            rc, data = lib.encode_whole(enc, pcm)
+        if rc != capi.OK:
+            raise RuntimeError("SRLAEncoder_EncodeWhole -> %d" % rc)
+        return data
+    finally:
+        lib.destroy(enc)
+        for ptr in held:
+            L.SRLAMI355X_FreeHost(ptr)
+
+
+def sweep(count, seed, max_samples=6_000_000, with_mutations=False, only_history=False, with_paths=False):
     lib = capi.EncoderLib(helpers.PRODUCT_SO)
     bad = 0
     done = 0
@@ -152,8 +223,9 @@ def sweep(count, seed, max_samples=6_000_000, with_mutations=False, only_history
             n = min(n, 120_000 // nch) | (n & 1)
         mutation = mutation_of(case, seed) if with_mutations else "none"
         pcm = make_pcm(case, nch, bps, n, kind, shifted, mutation)
+        path = random.Random(seed * 6700417 + case).choice(PATHS) if with_paths else "pageable"
         try:
-            got = lib.encode(pcm, bits_per_sample=bps, **cli)
+            got = encode_by_path(lib, pcm, bps, cli, path)
         except RuntimeError as e:                        # limits of the implementation are refused loudly
             print("refused", cli, nch, bps, n, e)
             continue
@@ -170,14 +242,14 @@ def sweep(count, seed, max_samples=6_000_000, with_mutations=False, only_history
         done += 1
         if not np.array_equal(got, want):
             bad += 1
-            print("MISMATCH case %d (seed %d): nch=%d bps=%d n=%d kind=%d mutation=%s %s sizes %d vs %d" % (case, seed, nch, bps, n, kind, mutation, cli, got.size, want.size), flush=True)
+            print("MISMATCH case %d (seed %d): nch=%d bps=%d n=%d kind=%d mutation=%s path=%s %s sizes %d vs %d" % (case, seed, nch, bps, n, kind, mutation, path, cli, got.size, want.size), flush=True)
     return done, bad
 
 
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     done, bad = sweep(int(args[0]) if len(args) > 0 else 150, int(args[1]) if len(args) > 1 else 1, with_mutations="--mutate" in sys.argv,
-                      only_history="--history" in sys.argv)
+                      only_history="--history" in sys.argv, with_paths="--paths" in sys.argv)
     print("sweep: %d compared, %d mismatches" % (done, bad))
     sys.exit(1 if bad else 0)
 
