@@ -257,6 +257,7 @@ struct Impl {
     uint32_t pair_max_items = 6144;     /* SRLA_MI355X_PAIR_MAX: ... jobs of at most this many items in the two classes */
     bool spin_short_calls = true;       /* SRLA_MI355X_SPIN=0: never poll a job's last event, always sleep on it */
     bool spin_collect = false;          /* this call: at most three jobs */
+    uint32_t pool_linger_us = 600;      /* SRLA_MI355X_POOL_LINGER_US: how long the pool's workers keep looking for the next round of such a call before they sleep */
     uint32_t dma_tail_jobs = 1;         /* SRLA_MI355X_DMA_TAIL: the call's last n jobs leave by srla_stream_out even where the others leave by host-issued copies */
     uint32_t tail_boost = 4, tail_boost_jobs = 3;   /* SRLA_MI355X_TAIL_BOOST="wgs,jobs" */
     uint32_t timing_stride = 4;       /* every n-th job carries start events on all stages (SRLA_MI355X_TIMING_STRIDE) */

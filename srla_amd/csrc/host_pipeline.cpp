@@ -1051,6 +1051,7 @@ SRLAApiResult Impl::encode_streams(bool search)
     overrides.clear();
     call_crowded = njobs > 3;
     spin_collect = spin_short_calls && njobs <= 3;
+    pool->set_linger_us(spin_collect ? pool_linger_us : 0u);      /* (a short call's two rounds -- staging, copy-out -- are 0.3 ms apart) */
     /* (a stream of a few pieces is a latency chain: its copies would start only when the host has collected each piece) */
     call_dma = dma_out && dma_stream != nullptr && njobs > 3;
     for (const StreamCtx &st : sx) call_dma = call_dma && st.out_direct != nullptr && st.data != nullptr && st.cb == nullptr;

@@ -108,18 +108,33 @@ public:
         if (workers_.empty() || count == 1) { for (uint32_t i = 0; i < count; i++) fn(i); return; }
         {
             std::lock_guard<std::mutex> l(m_);
-            fn_ = &fn; next_.store(0); count_ = count; pending_ = (unsigned)workers_.size(); gen_++;
+            fn_ = &fn; next_.store(0); count_ = count; pending_.store((unsigned)workers_.size(), std::memory_order_relaxed); gen_++;
             gen_atomic_.store(gen_, std::memory_order_release);
         }
         cv_.notify_all();
         run_chunk();
-        std::unique_lock<std::mutex> l(m_);
-        done_cv_.wait(l, [this] { return pending_ == 0; });
+        /* the stragglers are microseconds away: look before sleeping (a futex wake-up is 10-20 us) */
+        for (int spin = 0; spin < 4000 && pending_.load(std::memory_order_acquire) != 0; spin++) cpu_pause();
+        if (pending_.load(std::memory_order_acquire) != 0) {
+            std::unique_lock<std::mutex> l(m_);
+            done_cv_.wait(l, [this] { return pending_.load(std::memory_order_acquire) == 0; });
+        }
         fn_ = nullptr;
     }
     unsigned size() const { return (unsigned)workers_.size() + 1; }
+    /* How long a worker keeps looking for the next round before it sleeps.  Rounds of a long call arrive every few hundred
+     * microseconds and a sleeping worker is fine for them (0: a few microseconds of looking); a call of one job has two rounds --
+     * staging at its start, the copy-out at its end, 0.3 ms apart -- and a worker that has to be woken for the second one costs a
+     * tenth of the call's time. */
+    void set_linger_us(uint32_t us) { linger_us_.store(us, std::memory_order_relaxed); }
 
 private:
+    static void cpu_pause()
+    {
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
     void run_chunk()
     {
         for (;;) {
@@ -133,11 +148,15 @@ private:
         uint64_t seen = 0;
         for (;;) {
             {
-                /* spin briefly before sleeping: pack rounds arrive every few hundred microseconds */
-                for (int spin = 0; spin < 200 && gen_atomic_.load(std::memory_order_acquire) == seen && !stop_; spin++) {
-#if defined(__x86_64__)
-                    __builtin_ia32_pause();
-#endif
+                /* look briefly before sleeping: pack rounds arrive every few hundred microseconds */
+                for (int spin = 0; spin < 200 && gen_atomic_.load(std::memory_order_acquire) == seen && !stop_; spin++) cpu_pause();
+                const uint32_t linger = linger_us_.load(std::memory_order_relaxed);
+                if (linger != 0 && gen_atomic_.load(std::memory_order_acquire) == seen) {
+                    const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(linger);
+                    while (gen_atomic_.load(std::memory_order_acquire) == seen && !stop_) {
+                        for (int k = 0; k < 32; k++) cpu_pause();
+                        if (std::chrono::steady_clock::now() >= until) break;
+                    }
                 }
                 std::unique_lock<std::mutex> l(m_);
                 cv_.wait(l, [&] { return stop_ || gen_ != seen; });
@@ -145,9 +164,9 @@ private:
                 seen = gen_;
             }
             run_chunk();
-            {
+            if (pending_.fetch_sub(1, std::memory_order_acq_rel) == 1) {
                 std::lock_guard<std::mutex> l(m_);
-                if (--pending_ == 0) done_cv_.notify_all();
+                done_cv_.notify_all();
             }
         }
     }
@@ -158,7 +177,8 @@ private:
     const std::function<void(uint32_t)> *fn_ = nullptr;
     std::atomic<uint32_t> next_{ 0 };
     uint32_t count_ = 0;
-    unsigned pending_;
+    std::atomic<unsigned> pending_;
+    std::atomic<uint32_t> linger_us_{ 0 };
     uint64_t gen_ = 0;
     std::atomic<uint64_t> gen_atomic_{ 0 };
 };
