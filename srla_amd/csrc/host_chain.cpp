@@ -147,14 +147,31 @@ bool Impl::chain_stage_a(Slot &s, uint32_t jobidx, const ChainJob &cj)
     const SrlaJobParams &jp = s.jp;
     if (!d_chain_list[jobidx].ensure(std::max<size_t>(1, cj.list.size()) * sizeof(SrlaAutocorrItem))) return false;
     if (!d_chain_select[jobidx].ensure(cj.select.size() * 4)) return false;
-    if (!cj.list.empty()) HIP_OK(hipMemcpy(d_chain_list[jobidx].p, cj.list.data(), cj.list.size() * sizeof(SrlaAutocorrItem), hipMemcpyHostToDevice));
-    HIP_OK(hipMemcpy(d_chain_select[jobidx].p, cj.select.data(), cj.select.size() * 4, hipMemcpyHostToDevice));
-    if (chain_tab.size() > chain_tab_uploaded) {
-        /* only the new entries: kernels of the jobs before may still be reading theirs */
+    const bool svr_rounds = chain_svr() && !s.job.groups.empty() && jp.max_order > 0;
+    if (svr_rounds && !d_chain_select_b[jobidx].ensure(cj.select_b.size() * 4)) return false;
+    {
+        /* the job's tables go up in ONE asynchronous copy each, out of a pinned staging area of the job's own, on the stream their
+         * readers run on (four blocking copies out of pageable memory cost 0.11 ms per stage -- a third of a block call).  The area
+         * is written again only after the job's events have been waited for (a phase ends with a host round trip). */
+        const size_t list_b = cj.list.size() * sizeof(SrlaAutocorrItem), sel_b = cj.select.size() * 4, selb_b = svr_rounds ? cj.select_b.size() * 4 : 0;
+        const size_t tab_new = chain_tab.size() - std::min(chain_tab.size(), chain_tab_uploaded), tab_b = tab_new * 4;
         if (chain_tab.size() * 4 > d_chain_tab.cap) return false;
-        HIP_OK(hipMemcpy(d_chain_tab.as<uint32_t>() + chain_tab_uploaded, chain_tab.data() + chain_tab_uploaded,
-                         (chain_tab.size() - chain_tab_uploaded) * 4, hipMemcpyHostToDevice));
-        chain_tab_uploaded = chain_tab.size();
+        PinBuf &h = h_chain_up[jobidx];
+        if (!h.ensure(list_b + sel_b + selb_b + tab_b + 64)) return false;
+        uint8_t *hp = h.as<uint8_t>();
+        if (list_b) { memcpy(hp, cj.list.data(), list_b); HIP_OK(hipMemcpyAsync(d_chain_list[jobidx].p, hp, list_b, hipMemcpyHostToDevice, W)); }
+        hp += list_b;
+        memcpy(hp, cj.select.data(), sel_b);
+        HIP_OK(hipMemcpyAsync(d_chain_select[jobidx].p, hp, sel_b, hipMemcpyHostToDevice, W));
+        hp += sel_b;
+        if (selb_b) { memcpy(hp, cj.select_b.data(), selb_b); HIP_OK(hipMemcpyAsync(d_chain_select_b[jobidx].p, hp, selb_b, hipMemcpyHostToDevice, W)); }
+        hp += selb_b;
+        if (tab_b) {
+            /* only the new entries: kernels of the jobs before may still be reading theirs */
+            memcpy(hp, chain_tab.data() + chain_tab_uploaded, tab_b);
+            HIP_OK(hipMemcpyAsync(d_chain_tab.as<uint32_t>() + chain_tab_uploaded, hp, tab_b, hipMemcpyHostToDevice, W));
+            chain_tab_uploaded = chain_tab.size();
+        }
     }
     /* prepare_job put the descriptor uploads on the wide stream: everything after this stage must see them */
     HIP_OK(hipEventRecord(s.t0[ST_A], streams[0]));
@@ -164,11 +181,6 @@ bool Impl::chain_stage_a(Slot &s, uint32_t jobidx, const ChainJob &cj)
     static const int kClass[4] = { 0, 1, 2, 4 };
     int rc = 0;
     size_t li = 0;
-    const bool svr_rounds = chain_svr() && !s.job.groups.empty() && jp.max_order > 0;
-    if (svr_rounds) {
-        if (!d_chain_select_b[jobidx].ensure(cj.select_b.size() * 4)) return false;
-        HIP_OK(hipMemcpy(d_chain_select_b[jobidx].p, cj.select_b.data(), cj.select_b.size() * 4, hipMemcpyHostToDevice));
-    }
     s.b_done = false;
     for (uint32_t r = 0; r < cj.rounds; r++) {
         for (int pass = (par.ltp_order > 0) ? 1 : 0; pass >= 0; pass--) {
@@ -241,9 +253,21 @@ bool Impl::chain_make_job(Slot &s, uint32_t s0, uint32_t ns, bool search, const 
     return true;
 }
 
+/* The pool's head IS the handle's buffer after a tracked history-mode call (no copy per call); whoever is about to write there --
+ * chain mode lays its calls out from word 0, a batch's streams start from zeros, a growing pool moves -- puts it into d_hist first. */
+bool Impl::hist_leave_pool()
+{
+    if (!pool_holds_hist) return true;
+    pool_holds_hist = false;
+    if (!d_hist.ensure((size_t)kHistoryWords * sizeof(double))) return false;
+    if (hipMemcpyAsync(d_hist.p, d_chain_pool.p, (size_t)kHistoryWords * sizeof(double), hipMemcpyDeviceToDevice, streams[1]) != hipSuccess) return false;
+    return hipStreamSynchronize(streams[1]) == hipSuccess;     /* (rare: the writers that follow are on other streams or free the pool) */
+}
+
 bool Impl::chain_begin(uint32_t seed_off, uint32_t seed_n)
 {
     ChainRun &c = chain;
+    if (!hist_leave_pool()) return false;
     const StreamCtx &st = sx[c.stream];
     const uint32_t nch = par.num_channels, nv = num_variants(), passes = par.ltp_order > 0 ? 2u : 1u;
     /* which blocks are all zero decides which calls exist: look at the samples */
@@ -482,6 +506,7 @@ SRLAApiResult Impl::history_window(uint32_t stream, uint32_t pos, uint32_t n, bo
         /* SRLAEncoder_SearchOptimalBlockPartitions (srla_encoder.c:310-424): every candidate, then Dijkstra */
         history_phase_reset();
         if (!chain_make_job(sj, pos, n, true, nullptr)) return SRLA_APIRESULT_NG;
+        const double t_made = ms_since(tw0);
         sj.job.key = 0;
         chain_append(1, sj.job, silent);
         if (chain_pool_used * sizeof(double) > d_chain_pool.cap || chain_tab.size() * 4 > d_chain_tab.cap) {
@@ -489,14 +514,27 @@ SRLAApiResult Impl::history_window(uint32_t stream, uint32_t pos, uint32_t n, bo
             return SRLA_APIRESULT_NG;
         }
         chain_build(1, sj.job, c.cs);
+        const double t_built = ms_since(tw0);
         for (int attempt = 0;; attempt++) {
             (void)apply_overrides(sj.job, kChainJobKey + 1);
             sj.job.uploaded = false;
             chain_tab_uploaded = 0;
-            if (!prepare_job(sj, false) || !chain_stage_a(sj, 1, c.cs)) return SRLA_APIRESULT_NG;
+            if (!prepare_job(sj, false)) return SRLA_APIRESULT_NG;
+            const double t_prepared = ms_since(tw0);
+            if (!chain_stage_a(sj, 1, c.cs)) return SRLA_APIRESULT_NG;
+            const double t_a = ms_since(tw0);
             for (int st2 = ST_B; st2 <= ST_D; st2++) if (!run_stage(sj, st2)) return SRLA_APIRESULT_NG;
+            {
+                /* the partition comes back behind the pricing, on its stream: one wait for both */
+                const SrlaWindowDesc &wd0 = sj.job.windows[0];
+                const size_t bytes = (size_t)(wd0.num_nodes - 1) * sizeof(SrlaBlockRecord);
+                if (!h_chain_recs.ensure(bytes)) return SRLA_APIRESULT_NG;
+                if (hipMemcpyAsync(h_chain_recs.p, sj.d_blocks.as<SrlaBlockRecord>() + wd0.block_base, bytes, hipMemcpyDeviceToHost, hs) != hipSuccess) return SRLA_APIRESULT_NG;
+            }
             t_prep1 = ms_since(tw0);
-            if (hipEventSynchronize(sj.t1[ST_D]) != hipSuccess) return SRLA_APIRESULT_NG;
+            if (chain_trace) fprintf(stderr, "[history]   search prep: samples + tables %.3f, call list %.3f, uploads %.3f, stage A enqueued %.3f, B-D enqueued %.3f ms\n",
+                                     t_made, t_built, t_prepared, t_a, t_prep1);
+            if (hipStreamSynchronize(hs) != hipSuccess) return SRLA_APIRESULT_NG;
             t_dev1 = ms_since(tw0);
             const int m = arbitrate(sj, kChainJobKey + 1);
             if (m < 0) return SRLA_APIRESULT_NG;
@@ -507,11 +545,9 @@ SRLAApiResult Impl::history_window(uint32_t stream, uint32_t pos, uint32_t n, bo
         sj.busy = false;
         if (!history_commit(1, hs)) return SRLA_APIRESULT_NG;
         const SrlaWindowDesc &wd = sj.job.windows[0];
-        std::vector<SrlaBlockRecord> recs(wd.num_nodes - 1);
-        if (hipMemcpy(recs.data(), sj.d_blocks.as<SrlaBlockRecord>() + wd.block_base, recs.size() * sizeof(SrlaBlockRecord), hipMemcpyDeviceToHost) != hipSuccess)
-            return SRLA_APIRESULT_NG;
+        const SrlaBlockRecord *recs = h_chain_recs.as<SrlaBlockRecord>();
         uint32_t covered = 0;
-        for (const SrlaBlockRecord &r : recs) if (r.valid) { lens.push_back(r.n); covered += r.n; }
+        for (uint32_t k = 0; k + 1 < wd.num_nodes; k++) if (recs[k].valid) { lens.push_back(recs[k].n); covered += recs[k].n; }
         if (covered != n) { fprintf(stderr, "[srla-mi355x] internal error: a window's partitions cover %u of %u samples\n", covered, n); return SRLA_APIRESULT_NG; }
         t_read = ms_since(tw0);
     } else lens.push_back(n);
@@ -581,8 +617,9 @@ SRLAApiResult Impl::history_encode(bool search)
                     words += pow2(std::min(len, window_len - i * minb)); calls++;
                 }
         }
+        const size_t want = (kHistoryWords + (uint64_t)nv * (passes + (chain_svr() ? 1u : 0u)) * (words + 2u * calls) + 1024u) * sizeof(double);
         drain();
-        if (!d_chain_pool.ensure((kHistoryWords + (uint64_t)nv * (passes + (chain_svr() ? 1u : 0u)) * (words + 2u * calls) + 1024u) * sizeof(double))) return SRLA_APIRESULT_NG;
+        if (want > d_chain_pool.cap && (!hist_leave_pool() || !d_chain_pool.ensure(want))) return SRLA_APIRESULT_NG;
         if (!d_chain_tab.ensure(((size_t)calls * nv * SRLA_LTP_LAGS + 1024u) * 4)) return SRLA_APIRESULT_NG;
     }
     SRLAApiResult worst = SRLA_APIRESULT_OK;
@@ -592,12 +629,17 @@ SRLAApiResult Impl::history_encode(bool search)
         /* the buffer as this handle's calls left it (one of the reference's entry points: host_impl.h, d_hist); a fresh handle's --
          * and, for the streams of a batch, each stream's -- starts as zero pages (the `srla` tool creates its encoder per file) */
         const bool tracked = sx.size() == 1 && st.reference_call;
-        if (tracked && !hist_fresh && d_hist.p != nullptr) {
+        if (tracked && !hist_fresh && pool_holds_hist) {
+            /* the pool's head is the buffer as the handle's last call left it */
+        } else if (tracked && !hist_fresh && d_hist.p != nullptr) {
             if (hipMemcpyAsync(d_chain_pool.p, d_hist.p, (size_t)kHistoryWords * sizeof(double), hipMemcpyDeviceToDevice, streams[1]) != hipSuccess) return SRLA_APIRESULT_NG;
         } else {
+            if (!hist_leave_pool()) return SRLA_APIRESULT_NG;
             if (hipMemsetAsync(d_chain_pool.p, 0, (size_t)kHistoryWords * sizeof(double), streams[1]) != hipSuccess) return SRLA_APIRESULT_NG;
         }
+        pool_holds_hist = false;
         buf_exact = (tracked && !hist_fresh) ? hist_exact : kHistoryWords;
+        if (tracked) hist_exact = 0;                              /* (until the call has come through: the ways out below) */
         chain_calls.clear();
         ChainCall buffer{};
         buffer.job = 0xFFFFFFFFu; buffer.nfft = kHistoryWords; buffer.src = -1; buffer.dump = 0;
@@ -609,9 +651,8 @@ SRLAApiResult Impl::history_encode(bool search)
         }
         chain.active = false;
         if (tracked) {
-            /* what the next call on this handle finds */
-            if (!d_hist.ensure((size_t)kHistoryWords * sizeof(double))) return SRLA_APIRESULT_NG;
-            if (hipMemcpyAsync(d_hist.p, d_chain_pool.p, (size_t)kHistoryWords * sizeof(double), hipMemcpyDeviceToDevice, streams[1]) != hipSuccess) return SRLA_APIRESULT_NG;
+            /* what the next call on this handle finds: the pool's head, where it stands */
+            pool_holds_hist = true;
             hist_fresh = false;
             hist_exact = (st.rc == SRLA_APIRESULT_OK) ? buf_exact : 0u;       /* (a call that ran out of room stopped somewhere inside a window) */
         }

@@ -375,6 +375,8 @@ struct Impl {
     std::vector<uint32_t> chain_tab;      /* gather table for the LTP lags beyond a short FFT (SrlaAutocorrItem::chain_lags) */
     size_t chain_tab_uploaded = 0;
     DevBuf d_chain_pool, d_chain_tab, d_chain_list[3], d_chain_select[3], d_chain_select_b[3];
+    PinBuf h_chain_up[3];                 /* staging of a chain job's tables (chain_stage_a) */
+    PinBuf h_chain_recs;                  /* a history-mode window's partition on its way back */
     /* the reference's calls for the candidates of `job`, appended in its order; silent(off, n): the block is all zero */
     void chain_append(uint32_t jobidx, const Job &job, const std::function<bool(uint32_t, uint32_t)> &silent);
     void chain_build(uint32_t jobidx, Job &job, ChainJob &cj);
@@ -438,6 +440,8 @@ struct Impl {
      * afterwards: its stream's own blocks never reach back beyond their own window and the one before).  A call whose
      * history-dependent read lands in words that are not known is counted (SRLAMI355X_NONIDENTICAL_HANDLE_HISTORY). */
     DevBuf d_hist;
+    bool pool_holds_hist = false;         /* the buffer stands in the chain pool's head (after a tracked history-mode call) instead of in d_hist */
+    bool hist_leave_pool();
     bool hist_fresh = true;               /* nothing has been encoded on this handle: the buffer is all zero (not even allocated) */
     uint32_t hist_exact = kHistoryWords;  /* words [0, hist_exact) of d_hist are the reference's */
     uint32_t buf_exact = kHistoryWords;   /* the same for the pool's head while a history-mode call runs */

@@ -55,7 +55,7 @@ Impl::~Impl()
         if (ev_ref) (void)hipEventDestroy(ev_ref);
         h_or.release();
         d_tw.release(); d_geoms.release(); d_thr.release(); d_huff.release(); d_huffcode.release(); d_pos.release(); d_or.release(); d_oracc.release(); d_svr_scratch.release(); d_svr_scratch_chain.release();
-        d_chain_pool.release(); d_chain_tab.release(); d_hist.release(); tail.smp.release();
+        d_chain_pool.release(); d_chain_tab.release(); d_hist.release(); tail.smp.release(); for (auto &h : h_chain_up) h.release(); h_chain_recs.release();
         for (auto &b : d_chain_list) b.release();
         for (auto &b : d_chain_select) b.release();
     }
