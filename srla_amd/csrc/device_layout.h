@@ -126,6 +126,18 @@ typedef struct SrlaJobInfo {
     uint32_t num_tie_items, num_odd_items;   /* flagged items of the job (any candidate) / odd-length items among the chosen blocks */
     uint32_t error;          /* SRLA_JOBERR_* bits (OVERFLOW: in at least one segment) */
 } SrlaJobInfo;
+/* What the host needs to arbitrate a job's near-ties (host_ties.cpp), gathered by srla_block_offsets into pinned host memory so that
+ * the host reads it where it stands instead of fetching it with a dozen blocking copies after the call's last job (0.16 ms of a
+ * 600 s call).  out: `cap` doubles -- the list entries (item | kind << 30) -- then per entry max(P + 2, 8) doubles: an order tie's
+ * error variances of orders 0..P and the order the device chose; an LTP tie's eight numbers (tie_data).  Jobs with more than `cap`
+ * entries (the tests' widened thresholds) are fetched as before. */
+#define SRLA_TIE_GATHER_CAP 16u
+typedef struct SrlaTieGather {
+    const double *err;       /* [order][item] */
+    const double *tie_data;  /* [entry][8], may be null */
+    double *out;
+    uint32_t cap, num_items;
+} SrlaTieGather;
 /* per segment, behind SrlaJobInfo and the per-window byte counts */
 typedef struct SrlaSegInfo {
     uint32_t bytes;          /* bytes of the segment's blocks                                           */

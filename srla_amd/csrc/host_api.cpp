@@ -443,14 +443,12 @@ SRLAApiResult SRLAMI355X_ProbeBlock(struct SRLAEncoder *encoder, const int32_t *
     im->keep_residuals = false;
     if (!ran) return SRLA_APIRESULT_NG;
     const uint32_t nv = im->num_variants();
-    if (records && hipMemcpy(records, s.d_results.p, (size_t)nv * sizeof(SrlaItemResult), hipMemcpyDeviceToHost) != hipSuccess)
-        return SRLA_APIRESULT_NG;
-    if (debug && hipMemcpy(debug, s.d_dbg.p, (size_t)nv * SRLA_DBG_STRIDE * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
-        return SRLA_APIRESULT_NG;
+    if (records && !im->d2h(records, s.d_results.p, (size_t)nv * sizeof(SrlaItemResult))) return SRLA_APIRESULT_NG;
+    if (debug && !im->d2h(debug, s.d_dbg.p, (size_t)nv * SRLA_DBG_STRIDE * sizeof(double))) return SRLA_APIRESULT_NG;
     if (residuals) {
         for (uint32_t v = 0; v < nv; v++)
-            if (hipMemcpy(residuals + (size_t)v * num_samples, s.d_res_ws.as<int32_t>() + s.job.items[v].res_off,
-                          (size_t)num_samples * 4, hipMemcpyDeviceToHost) != hipSuccess) return SRLA_APIRESULT_NG;
+            if (!im->d2h(residuals + (size_t)v * num_samples, s.d_res_ws.as<int32_t>() + s.job.items[v].res_off, (size_t)num_samples * 4))
+                return SRLA_APIRESULT_NG;
     }
     return SRLA_APIRESULT_OK;
 }

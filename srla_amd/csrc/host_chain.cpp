@@ -144,6 +144,7 @@ bool Impl::chain_stage_a(Slot &s, uint32_t jobidx, const ChainJob &cj)
      * behind them */
     hipStream_t W = s.own_stream;
     s.var_ready = false;                 /* (chain-mode launches read the channel planes) */
+    s.ties_gathered = false;
     const SrlaJobParams &jp = s.jp;
     if (!d_chain_list[jobidx].ensure(std::max<size_t>(1, cj.list.size()) * sizeof(SrlaAutocorrItem))) return false;
     if (!d_chain_select[jobidx].ensure(cj.select.size() * 4)) return false;
@@ -276,7 +277,7 @@ bool Impl::chain_begin(uint32_t seed_off, uint32_t seed_n)
         for (uint32_t ch = 0; ch < nch; ch++) {
             if (st.pcm) (void)pcm_channel(st.pcm, st.pcm_bytes, nch, ch, off, n, dst.data() + (size_t)ch * n);
             else if (st.host_in) memcpy(dst.data() + (size_t)ch * n, st.host_in[ch] + off, (size_t)n * 4);
-            else if (hipMemcpy(dst.data() + (size_t)ch * n, st.d_in + (size_t)ch * st.d_stride + off, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) return false;
+            else if (!d2h(dst.data() + (size_t)ch * n, st.d_in + (size_t)ch * st.d_stride + off, (size_t)n * 4)) return false;
         }
         return true;
     };
@@ -376,7 +377,7 @@ bool Impl::chain_encode_ad()
     if (c.search) {
         const SrlaWindowDesc &wd = sj.job.windows[0];
         std::vector<SrlaBlockRecord> recs(wd.num_nodes - 1);
-        if (hipMemcpy(recs.data(), sj.d_blocks.as<SrlaBlockRecord>() + wd.block_base, recs.size() * sizeof(SrlaBlockRecord), hipMemcpyDeviceToHost) != hipSuccess)
+        if (!d2h(recs.data(), sj.d_blocks.as<SrlaBlockRecord>() + wd.block_base, recs.size() * sizeof(SrlaBlockRecord)))
             return false;
         std::vector<uint32_t> lens;
         uint32_t covered = 0;
@@ -492,7 +493,7 @@ SRLAApiResult Impl::history_window(uint32_t stream, uint32_t pos, uint32_t n, bo
         int32_t *dst = c.tail_smp.data() + (size_t)ch * n;
         if (st.pcm) (void)pcm_channel(st.pcm, st.pcm_bytes, nch, ch, pos, n, dst);
         else if (st.host_in) memcpy(dst, st.host_in[ch] + pos, (size_t)n * 4);
-        else if (hipMemcpy(dst, st.d_in + (size_t)ch * st.d_stride + pos, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) return SRLA_APIRESULT_NG;
+        else if (!d2h(dst, st.d_in + (size_t)ch * st.d_stride + pos, (size_t)n * 4)) return SRLA_APIRESULT_NG;
     }
     const std::function<bool(uint32_t, uint32_t)> silent = [&](uint32_t off, uint32_t len) { return chain_silent(c.tail_smp, c.tail_n, off, len); };
     Slot &sj = slot[kChainSlot + 1], &e = slot[kChainSlot + 2];
@@ -588,7 +589,7 @@ SRLAApiResult Impl::history_window(uint32_t stream, uint32_t pos, uint32_t n, bo
         /* SRLAEncoder_ComputeBlockSize: what the SEARCH pays for the block (with more than two channels the reference prices the
          * first two only, srla_encoder.c:1287-1301), which the pricing kernel left in the block's record */
         SrlaBlockRecord rec;
-        if (hipMemcpy(&rec, e.d_blocks.as<SrlaBlockRecord>() + e.job.windows[0].block_base, sizeof(rec), hipMemcpyDeviceToHost) != hipSuccess || !rec.valid)
+        if (!d2h(&rec, e.d_blocks.as<SrlaBlockRecord>() + e.job.windows[0].block_base, sizeof(rec)) || !rec.valid)
             return SRLA_APIRESULT_NG;
         block_price = rec.price;
     }

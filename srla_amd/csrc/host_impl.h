@@ -137,6 +137,8 @@ struct Slot {
     DevBuf d_ties, d_tie_data;           /* near-tie list of the job (count + entries), 8 doubles per entry for LTP entries */
     PinBuf h_in, h_stream, h_info;       /* h_info: SrlaJobInfo, the per-window byte counts, SrlaSegInfo per segment */
     PinBuf h_segs;                       /* host copy of the segment table (uploaded per job) */
+    PinBuf h_ties;                       /* SrlaTieGather::out */
+    bool ties_gathered = false;          /* the job went through the block assembly: its near-ties' numbers stand in h_ties */
     Job job;
     bool busy = false;
     bool used_h2d = false;
@@ -257,6 +259,7 @@ struct Impl {
     uint32_t pair_max_items = 6144;     /* SRLA_MI355X_PAIR_MAX: ... jobs of at most this many items in the two classes */
     bool spin_short_calls = true;       /* SRLA_MI355X_SPIN=0: never poll a job's last event, always sleep on it */
     bool spin_collect = false;          /* this call: at most three jobs */
+    bool tie_gather = true;             /* SRLA_MI355X_TIE_GATHER=0: fetch a job's near-tie numbers with blocking copies, as before round 4 */
     uint32_t pool_linger_us = 600;      /* SRLA_MI355X_POOL_LINGER_US: how long the pool's workers keep looking for the next round of such a call before they sleep */
     uint32_t dma_tail_jobs = 1;         /* SRLA_MI355X_DMA_TAIL: the call's last n jobs leave by srla_stream_out even where the others leave by host-issued copies */
     uint32_t tail_boost = 4, tail_boost_jobs = 3;   /* SRLA_MI355X_TAIL_BOOST="wgs,jobs" */
@@ -459,6 +462,13 @@ struct Impl {
         uint32_t lshift = 0, n = 0, nch = 0;
         PinBuf smp;                       /* nch planes of n samples */
     } tail;
+    /* Device -> host read-backs of a few bytes to a few MB (near-tie numbers, partitions, probe records) go through a page-locked
+     * bounce buffer: a copy straight into pageable memory is, on this platform, a GPU write into the caller's pages, and the test
+     * process saw it fail ("Memory access fault ... Write access to a read-only page", a heap page still marked copy-on-write after
+     * an earlier fork of the process) once in several runs of the whole suite. */
+    PinBuf h_bounce;
+    bool d2h(void *dst, const void *src, size_t bytes);
+    bool d2h_2d(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t height);
     bool want_block_price = false;        /* SRLAEncoder_ComputeBlockSize with more than two channels: the search's price of the block */
     uint32_t block_price = 0;
     bool replaying = false;

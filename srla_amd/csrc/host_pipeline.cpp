@@ -43,7 +43,7 @@ Impl::~Impl()
                              &s.d_blocks, &s.d_block_off, &s.d_scratch, &s.d_dbg, &s.d_lags, &s.d_err, &s.d_gamma, &s.d_class_index, &s.d_stream,
                              &s.d_segs, &s.d_seg_ctl, &s.d_ties, &s.d_tie_data, &s.d_svr_rows, &s.d_big_scratch, &s.d_big_items, &s.d_coef_ws };
             for (auto *b : db) b->release();
-            PinBuf *pb[] = { &s.h_in, &s.h_stream, &s.h_info, &s.h_segs };
+            PinBuf *pb[] = { &s.h_in, &s.h_stream, &s.h_info, &s.h_segs, &s.h_ties };
             for (auto *b : pb) b->release();
         }
         for (auto &st : streams) if (st) (void)hipStreamDestroy(st);
@@ -55,7 +55,7 @@ Impl::~Impl()
         if (ev_ref) (void)hipEventDestroy(ev_ref);
         h_or.release();
         d_tw.release(); d_geoms.release(); d_thr.release(); d_huff.release(); d_huffcode.release(); d_pos.release(); d_or.release(); d_oracc.release(); d_svr_scratch.release(); d_svr_scratch_chain.release();
-        d_chain_pool.release(); d_chain_tab.release(); d_hist.release(); tail.smp.release(); for (auto &h : h_chain_up) h.release(); h_chain_recs.release();
+        d_chain_pool.release(); d_chain_tab.release(); d_hist.release(); tail.smp.release(); for (auto &h : h_chain_up) h.release(); h_chain_recs.release(); h_bounce.release();
         for (auto &b : d_chain_list) b.release();
         for (auto &b : d_chain_select) b.release();
     }
@@ -330,6 +330,7 @@ bool Impl::prepare_job(Slot &s, bool want_dbg)
     if (!s.d_blocks.ensure((size_t)job.num_slots * sizeof(SrlaBlockRecord))) return false;
     if (!s.d_block_off.ensure((size_t)job.num_slots * 4 + 16)) return false;
     if (!s.h_info.ensure(sizeof(SrlaJobInfo) + n_win * 4 + nseg * sizeof(SrlaSegInfo))) return false;
+    if (!s.h_ties.ensure((size_t)SRLA_TIE_GATHER_CAP * (1u + std::max<uint32_t>(preset_order() + 2u, 8u)) * sizeof(double))) return false;
     if (!s.d_segs.ensure(nseg * sizeof(SrlaSegDesc)) || !s.h_segs.ensure(nseg * sizeof(SrlaSegDesc))) return false;
     if (!s.d_seg_ctl.ensure(nseg * SRLA_SEGCTL_WORDS_HOST * 4)) return false;
     if (!s.d_ties.ensure((3 * std::max<size_t>(1, n_items) + 2) * 4)) return false;   /* an order, an LTP and an SVR entry per item at most */
@@ -422,6 +423,7 @@ bool Impl::run_stage(Slot &s, int st, int part)
     hipEvent_t ev0 = s.timed ? s.t0[st] : nullptr;
     switch (st) {
     case ST_A: {
+        s.ties_gathered = false;
         if (part != 2) {
             if (on_device) HIP_OK(hipStreamWaitEvent(W, ev_or, 0));
             if (s.used_h2d) HIP_OK(hipStreamWaitEvent(W, s.ev_in, 0));
@@ -592,6 +594,8 @@ bool Impl::run_stage(Slot &s, int st, int part)
         if (job.num_slots) {
             SrlaJobInfo *info = s.h_info.as<SrlaJobInfo>();
             uint32_t *wbytes = reinterpret_cast<uint32_t *>(info + 1);
+            const SrlaTieGather tg = { s.d_err.as<double>(), par.ltp_order > 0 ? s.d_tie_data.as<double>() : nullptr, s.h_ties.as<double>(),
+                                       SRLA_TIE_GATHER_CAP, (uint32_t)job.items.size() };
             rc |= srla_launch_pack(P, &jp, job.num_slots, s.in_cur, s.d_items.as<SrlaItemDesc>(), s.d_windows.as<SrlaWindowDesc>(),
                                    s.d_blocks.as<SrlaBlockRecord>(), s.d_results.as<SrlaItemResult>(), s.d_res_ws.as<int32_t>(),
                                    d_huffcode.as<uint32_t>(), d_huff.as<uint8_t>(), s.d_block_off.as<uint32_t>(),
@@ -599,7 +603,8 @@ bool Impl::run_stage(Slot &s, int st, int part)
                                    s.d_stream.as<uint8_t>(), s.h_stream.as<uint8_t>(), s.d_scratch.as<uint8_t>(), info, wbytes,
                                    reinterpret_cast<SrlaSegInfo *>(wbytes + job.windows.size()), s.d_ties.as<uint32_t>(),
                                    ev0, s.t1[ST_E], s.out_boost, (P == C) ? ((out_stream && !s.own_stream) ? out_stream : nullptr) : C, s.ev_pk,
-                                   s.use_dma ? 1u : 0u);
+                                   s.use_dma ? 1u : 0u, &tg);
+            s.ties_gathered = tie_gather;
         } else { if (P != C) HIP_OK(hipStreamWaitEvent(C, s.t1[ST_D], 0)); if (ev0) HIP_OK(hipEventRecord(ev0, C)); HIP_OK(hipEventRecord(s.t1[ST_E], C)); }
         }
         break;
@@ -879,12 +884,12 @@ std::string Impl::nonidentical_text(uint32_t r)
 }
 
 /* The last valid block of segment k's last window of a priced job: (offset inside the stream, length). */
-static bool last_block_of(Slot &ls, size_t k, uint32_t *off, uint32_t *n)
+static bool last_block_of(Impl *im, Slot &ls, size_t k, uint32_t *off, uint32_t *n)
 {
     const SegPlan &sp = ls.job.segs[k];
     const SrlaWindowDesc &wd = ls.job.windows[ls.job.seg_first_window[k + 1] - 1];
     std::vector<SrlaBlockRecord> recs(wd.num_nodes - 1);
-    if (hipMemcpy(recs.data(), ls.d_blocks.as<SrlaBlockRecord>() + wd.block_base, recs.size() * sizeof(SrlaBlockRecord), hipMemcpyDeviceToHost) != hipSuccess)
+    if (!im->d2h(recs.data(), ls.d_blocks.as<SrlaBlockRecord>() + wd.block_base, recs.size() * sizeof(SrlaBlockRecord)))
         return false;
     *off = 0; *n = 0;
     for (const SrlaBlockRecord &r : recs) if (r.valid) { *off = sp.s0 + (r.sample_off - sp.base); *n = r.n; }
@@ -1105,7 +1110,7 @@ SRLAApiResult Impl::encode_streams(bool search)
         const uint32_t nodes = search ? (st.chain_n + par.min_num_samples_per_block - 1) / par.min_num_samples_per_block + 1 : 2u;
         if (st.body == 0 || (search && nodes >= 3)) { /* nothing before the window matters */ }
         else if (!search) { seed_off = st.body - par.max_num_samples_per_block; seed_n = par.max_num_samples_per_block; }
-        else if (ls == nullptr || !last_block_of(*ls, k, &seed_off, &seed_n)) return SRLA_APIRESULT_NG;
+        else if (ls == nullptr || !last_block_of(this, *ls, k, &seed_off, &seed_n)) return SRLA_APIRESULT_NG;
         if (!chain_begin(seed_off, seed_n) || !chain_encode_ad() || !chain_encode_e()) return SRLA_APIRESULT_NG;
         const SRLAApiResult rc = chain_collect();
         chain.active = false;
@@ -1205,7 +1210,7 @@ SRLAApiResult Impl::encode_streams(bool search)
             /* the last block encoded before the window: its final call is what the window's only candidate inherits from */
             uint32_t seed_off = 0, seed_n = 0;
             Slot &ls = job_slot(njobs - 1);
-            if (!last_block_of(ls, ls.job.segs.size() - 1, &seed_off, &seed_n)) return fail(SRLA_APIRESULT_NG);
+            if (!last_block_of(this, ls, ls.job.segs.size() - 1, &seed_off, &seed_n)) return fail(SRLA_APIRESULT_NG);
             if (!chain_begin(seed_off, seed_n) || !chain_encode_ad() || !chain_encode_e()) return fail(SRLA_APIRESULT_NG);
         }
         const SRLAApiResult rc = chain_collect();
@@ -1228,7 +1233,7 @@ SRLAApiResult Impl::encode_streams(bool search)
             if (st.or_on_device && st.or_dev_end >= st.num_samples) {
                 /* every job has been collected, so every reduction launch on the upload stream is complete */
                 uint32_t m = 0;
-                if (hipStreamSynchronize(upload) != hipSuccess || hipMemcpy(&m, d_oracc.as<uint32_t>() + 2u * i, 4, hipMemcpyDeviceToHost) != hipSuccess)
+                if (hipStreamSynchronize(upload) != hipSuccess || !d2h(&m, d_oracc.as<uint32_t>() + 2u * i, 4))
                     return fail(SRLA_APIRESULT_NG);
                 st.or_mask |= m;
                 st.or_covered = st.num_samples;
@@ -1293,6 +1298,24 @@ SRLAApiResult Impl::encode_streams(bool search)
     stats.total_ms += ms_since(t0);
     if (timeline) { tl_printf("[timeline] call returned at %.3f ms\n", ms_since(t0)); fputs(tl_log.c_str(), stderr); tl_log.clear(); }
     return worst;
+}
+
+bool Impl::d2h(void *dst, const void *src, size_t bytes)
+{
+    if (bytes == 0) return true;
+    if (!h_bounce.ensure(bytes)) return false;
+    if (hipMemcpy(h_bounce.p, src, bytes, hipMemcpyDeviceToHost) != hipSuccess) return false;
+    memcpy(dst, h_bounce.p, bytes);
+    return true;
+}
+
+bool Impl::d2h_2d(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t height)
+{
+    if (width == 0 || height == 0) return true;
+    if (!h_bounce.ensure(width * height)) return false;
+    if (hipMemcpy2D(h_bounce.p, width, src, spitch, width, height, hipMemcpyDeviceToHost) != hipSuccess) return false;
+    for (size_t r = 0; r < height; r++) memcpy(static_cast<uint8_t *>(dst) + r * dpitch, h_bounce.as<uint8_t>() + r * width, width);
+    return true;
 }
 
 /* the samples of the stream's last two windows, where the call that encoded them can be repeated from */

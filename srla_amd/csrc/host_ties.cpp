@@ -249,13 +249,21 @@ bool Impl::apply_overrides(Job &job, uint32_t jobkey)
 int Impl::arbitrate(Slot &s, uint32_t jobkey)
 {
     uint32_t count = 0;
-    if (hipMemcpy(&count, s.d_ties.p, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    if (count == 0) return 0;
     const size_t n_items = s.job.items.size();
+    const uint32_t P = preset_order();
+    /* a job that went through the block assembly left a few near-ties' numbers in pinned host memory (SrlaTieGather): no copies */
+    const double *gathered = nullptr;
+    const uint32_t gstride = std::max<uint32_t>(P + 2u, 8u);
+    if (s.ties_gathered && s.h_info.p != nullptr) {
+        const uint32_t c = s.h_info.as<SrlaJobInfo>()->num_tie_items;
+        if (c != 0 && c <= SRLA_TIE_GATHER_CAP) { count = c; gathered = s.h_ties.as<double>(); }
+    }
+    if (gathered == nullptr && !d2h(&count, s.d_ties.p, 4)) return -1;
+    if (count == 0) return 0;
     if (count > 3 * n_items) return -1;
     std::vector<uint32_t> list(count);
-    if (hipMemcpy(list.data(), s.d_ties.as<uint32_t>() + 1, (size_t)count * 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    const uint32_t P = preset_order();
+    if (gathered != nullptr) { for (uint32_t k = 0; k < count; k++) list[k] = (uint32_t)gathered[k]; }
+    else if (!d2h(list.data(), s.d_ties.as<uint32_t>() + 1, (size_t)count * 4)) return -1;
     /* few flagged items: fetch their columns one by one; many (the tests' widened thresholds): everything at once */
     const bool bulk = count > 24;
     std::vector<double> err;
@@ -263,9 +271,8 @@ int Impl::arbitrate(Slot &s, uint32_t jobkey)
     if (bulk) {
         err.resize((size_t)(P + 1) * n_items);
         orders.resize(n_items);
-        if (hipMemcpy(err.data(), s.d_err.p, err.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-        if (hipMemcpy2D(orders.data(), 4, reinterpret_cast<const uint8_t *>(s.d_results.p) + offsetof(SrlaItemResult, lpc_order), sizeof(SrlaItemResult),
-                        4, n_items, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        if (!d2h(err.data(), s.d_err.p, err.size() * sizeof(double))) return -1;
+        if (!d2h_2d(orders.data(), 4, reinterpret_cast<const uint8_t *>(s.d_results.p) + offsetof(SrlaItemResult, lpc_order), sizeof(SrlaItemResult), 4, n_items)) return -1;
     }
     int mismatches = 0;
     std::vector<double> col(P + 1);
@@ -277,7 +284,8 @@ int Impl::arbitrate(Slot &s, uint32_t jobkey)
         if (item >= n_items) return -1;
         if (kind != 1) continue;
         double td[8];
-        if (hipMemcpy(td, s.d_tie_data.as<double>() + 8 * (size_t)k, sizeof(td), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        if (gathered != nullptr) memcpy(td, gathered + SRLA_TIE_GATHER_CAP + (size_t)k * gstride, sizeof(td));
+        else if (!d2h(td, s.d_tie_data.as<double>() + 8 * (size_t)k, sizeof(td))) return -1;
         const uint32_t host_q = ltp_taps(td, par.ltp_order), dev_q = (uint32_t)td[7];
         if (host_q == 0xFFFFFFFFu || host_q == dev_q) stats.num_tie_resolved++;
         else {
@@ -292,13 +300,16 @@ int Impl::arbitrate(Slot &s, uint32_t jobkey)
         const uint32_t item = list[k] & 0x3FFFFFFFu, kind = list[k] >> 30;
         if (kind != 0 || retaken[item]) continue;
         uint32_t dev_order = 0;
-        if (bulk) {
+        if (gathered != nullptr) {
+            const double *g = gathered + SRLA_TIE_GATHER_CAP + (size_t)k * gstride;
+            for (uint32_t o = 0; o <= P; o++) col[o] = g[o];
+            dev_order = (uint32_t)g[P + 1];
+        } else if (bulk) {
             for (uint32_t o = 0; o <= P; o++) col[o] = err[(size_t)o * n_items + item];
             dev_order = orders[item];
         } else {
-            if (hipMemcpy2D(col.data(), 8, s.d_err.as<double>() + item, n_items * 8, 8, P + 1, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-            if (hipMemcpy(&dev_order, reinterpret_cast<const uint8_t *>(s.d_results.as<SrlaItemResult>() + item) + offsetof(SrlaItemResult, lpc_order), 4,
-                          hipMemcpyDeviceToHost) != hipSuccess) return -1;
+            if (!d2h_2d(col.data(), 8, s.d_err.as<double>() + item, n_items * 8, 8, P + 1)) return -1;
+            if (!d2h(&dev_order, reinterpret_cast<const uint8_t *>(s.d_results.as<SrlaItemResult>() + item) + offsetof(SrlaItemResult, lpc_order), 4)) return -1;
         }
         const SrlaItemDesc &it = s.job.items[item];
         const uint32_t host_order = select_order(col.data(), P, geoms[it.geom].welch_comp, it.n, par.bits_per_sample);
@@ -324,7 +335,7 @@ int Impl::arbitrate_svr(Slot &s, uint32_t jobkey, uint32_t item)
     const SrlaItemDesc &it = s.job.items[item];
     const uint32_t nch = par.num_channels, n = it.n, P = preset_order();
     SrlaItemResult head;
-    if (hipMemcpy(&head, s.d_results.as<SrlaItemResult>() + item, offsetof(SrlaItemResult, lpc_coef), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (!d2h(&head, s.d_results.as<SrlaItemResult>() + item, offsetof(SrlaItemResult, lpc_coef))) return -1;
     const uint32_t order = head.lpc_order;
     if (order == 0 || order > P) return 0;
     /* the block as the analysis saw it: variant (srla_utility.c:91-103), offset shift, pre-emphasis (srla_utility.c:342),
@@ -336,7 +347,7 @@ int Impl::arbitrate_svr(Slot &s, uint32_t jobkey, uint32_t item)
     }
     std::vector<int32_t> a(n), b;
     auto plane = [&](uint32_t ch, std::vector<int32_t> &dst) {
-        return hipMemcpy(dst.data(), s.in_cur + (size_t)ch * s.stride_cur + it.sample_off, (size_t)n * 4, hipMemcpyDeviceToHost) == hipSuccess;
+        return d2h(dst.data(), s.in_cur + (size_t)ch * s.stride_cur + it.sample_off, (size_t)n * 4);
     };
     if (it.variant < nch) { if (!plane(it.variant, a)) return -1; for (auto &v : a) v >>= lsh; }
     else {
@@ -371,7 +382,7 @@ int Impl::arbitrate_svr(Slot &s, uint32_t jobkey, uint32_t item)
     for (uint32_t i = 0; i < n; i++) data[i] = (double)a[i] * norm;
     /* the predictor the refinement started from: the recursion on the item's lags */
     std::vector<double> lags(order + 1);
-    if (hipMemcpy2D(lags.data(), 8, s.d_lags.as<double>() + item, n_items * 8, 8, order + 1, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (!d2h_2d(lags.data(), 8, s.d_lags.as<double>() + item, n_items * 8, 8, order + 1)) return -1;
     lags[0] *= (1.0 + 1e-5);                                              /* ridge, lpc.c:483 */
     std::vector<double> coef;
     if (fabs(lags[0]) < (double)FLT_EPSILON) coef.assign(order, 0.0);     /* lpc.c:395-405 */
@@ -379,7 +390,7 @@ int Impl::arbitrate_svr(Slot &s, uint32_t jobkey, uint32_t item)
     svr_refine(data, coef, par.num_svr_filter_learning_iteration);
     const uint32_t ws_stride = (P <= 64) ? 64u : 256u;
     std::vector<double> dev(order);
-    if (hipMemcpy(dev.data(), s.d_coef_ws.as<double>() + (size_t)item * ws_stride, (size_t)order * 8, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (!d2h(dev.data(), s.d_coef_ws.as<double>() + (size_t)item * ws_stride, (size_t)order * 8)) return -1;
     if (memcmp(dev.data(), coef.data(), (size_t)order * 8) == 0) return 0;
     overrides[override_key(jobkey, item)].svr_row = coef;
     if (jobkey >= kChainJobKey) {

@@ -3531,7 +3531,7 @@ __global__ __launch_bounds__(NT) void srla_block_offsets(
     uint32_t *__restrict__ stream_pos /* per stream: [0] running offset, [1] sticky skip flag */,
     const SrlaSegDesc *__restrict__ segs, uint32_t *__restrict__ seg_ctl, uint64_t stage_addr,
     SrlaJobInfo *__restrict__ info, uint32_t *__restrict__ window_bytes, SrlaSegInfo *__restrict__ seg_info,
-    const uint32_t *__restrict__ ties)
+    const uint32_t *__restrict__ ties, SrlaTieGather tg)
 {
     __shared__ uint32_t s_wave[NWAVES];
     __shared__ uint32_t s_cnt[6];
@@ -3624,6 +3624,24 @@ __global__ __launch_bounds__(NT) void srla_block_offsets(
         info->num_tie_items = ties ? ties[0] : 0u;
         info->num_odd_items = s_cnt[3];
         info->error = s_cnt[5] | (cover_bad ? SRLA_JOBERR_COVER : 0u);
+    }
+    /* the near-ties' numbers for the host (SrlaTieGather) */
+    if (tg.out != nullptr && ties != nullptr) {
+        const uint32_t count = ties[0];
+        if (count != 0 && count <= tg.cap) {
+            const uint32_t P = jp.max_order, stride = (P + 2u > 8u) ? P + 2u : 8u;
+            for (uint32_t k = 0; k < count; k++) {
+                const uint32_t e = ties[1 + k], item = e & 0x3FFFFFFFu, kind = e >> 30;
+                double *dst = tg.out + tg.cap + (size_t)k * stride;
+                if (tid == 0) tg.out[k] = (double)e;
+                if (kind == 0 && item < tg.num_items && tg.err != nullptr) {
+                    for (uint32_t o = tid; o <= P; o += NT) dst[o] = tg.err[(size_t)o * tg.num_items + item];
+                    if (tid == 0) dst[P + 1] = (double)results[item].lpc_order;
+                } else if (kind == 1 && tg.tie_data != nullptr) {
+                    if (tid < 8) dst[tid] = tg.tie_data[8 * (size_t)k + tid];
+                }
+            }
+        }
     }
 }
 
@@ -4599,11 +4617,13 @@ extern "C" int srla_launch_pack(hipStream_t stream, const SrlaJobParams *jp, uin
                                 uint8_t *stage, uint8_t *host_stage, uint8_t *scratch, SrlaJobInfo *info,
                                 uint32_t *window_bytes, SrlaSegInfo *seg_info, const uint32_t *ties,
                                 hipEvent_t ev_start, hipEvent_t ev_stop, uint32_t out_boost, hipStream_t out_stream, hipEvent_t ev_packed,
-                                uint32_t no_stream_out)
+                                uint32_t no_stream_out, const SrlaTieGather *gather)
 {
     if (num_slots == 0) return 0;
+    SrlaTieGather tg{};
+    if (gather != nullptr) tg = *gather;
     hipExtLaunchKernelGGL(srla_block_offsets, dim3(1), dim3(NT), 0, stream, ev_start, nullptr, 0, *jp, windows, blocks, results, num_slots, block_off,
-                       stream_pos, segs, seg_ctl, (uint64_t)reinterpret_cast<uintptr_t>(stage), info, window_bytes, seg_info, ties);
+                       stream_pos, segs, seg_ctl, (uint64_t)reinterpret_cast<uintptr_t>(stage), info, window_bytes, seg_info, ties, tg);
     const uint32_t lds_words = srla_pack_lds_words(jp);
     const uint32_t rl_samples = jp->keep_residuals ? 0u : ((jp->max_block < 8192u ? jp->max_block : 8192u) + 3u) & ~3u;
     const uint32_t lds = (lds_words + 32 + 512 + (FIR_PAD + rl_samples + 8) + (FIR_PAD + 8)) * 4;
