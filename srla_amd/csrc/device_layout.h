@@ -155,7 +155,11 @@ typedef struct SrlaCandDesc {
     uint32_t sample_off;
     uint32_t n;
     uint32_t item_base;     /* first item (variant 0) or 0xFFFFFFFF when not analysed (RAW by length) */
-    uint32_t pad0, pad1;
+    uint32_t raw_silence;   /* 0: the items' own flags say whether the block is silent (every stream whose samples obey its offset
+                             * shift); 1 / 2: the host looked at the RAW samples -- silent / not.  The reference decides silence before
+                             * the shift (srla_encoder.c:783-791); a block call under a shift left by an earlier EncodeWhole can hold
+                             * samples that are zero only after it */
+    uint32_t pad1;
 } SrlaCandDesc;
 
 typedef struct SrlaWindowDesc {

@@ -251,6 +251,7 @@ bool Impl::chain_make_job(Slot &s, uint32_t s0, uint32_t ns, bool search, const 
     std::vector<uint32_t> lsh;
     settle_lshift(p, lsh);
     build_job(s.job, p, lsh, search, lens);
+    if (sx[chain.stream].raw_below_shift) mark_raw_silence(s.job);
     return true;
 }
 

@@ -164,6 +164,7 @@ struct StreamCtx {
     bool in_pinned = false;                    /* the input planes are pinned host memory: DMA reads them without staging */
     bool in_mixed = false;                     /* ... locked in place by this call while the pool could also stage them: the jobs take turns */
     bool with_header = true;                   /* EncodeWhole / EncodeBatch: header + offset shift; block calls: neither */
+    bool raw_below_shift = false;              /* a block call whose samples have bits below the handle's offset shift: silence is decided on the raw samples (SrlaCandDesc::raw_silence) */
     bool reference_call = false;               /* one of the reference's own entry points on this handle: the call reads and leaves the
                                                 * handle's persistent FFT buffer as the reference's would (Impl::d_hist) */
     SRLAEncoder_EncodeBlockCallback cb = nullptr;
@@ -259,6 +260,7 @@ struct Impl {
     uint32_t pair_max_items = 6144;     /* SRLA_MI355X_PAIR_MAX: ... jobs of at most this many items in the two classes */
     bool spin_short_calls = true;       /* SRLA_MI355X_SPIN=0: never poll a job's last event, always sleep on it */
     bool spin_collect = false;          /* this call: at most three jobs */
+    bool lazy_captures = true;          /* SRLA_MI355X_LAZY_CAPTURES=0: every call of at most one window runs in history mode (no captures of such calls) */
     bool tie_gather = true;             /* SRLA_MI355X_TIE_GATHER=0: fetch a job's near-tie numbers with blocking copies, as before round 4 */
     uint32_t pool_linger_us = 600;      /* SRLA_MI355X_POOL_LINGER_US: how long the pool's workers keep looking for the next round of such a call before they sleep */
     uint32_t dma_tail_jobs = 1;         /* SRLA_MI355X_DMA_TAIL: the call's last n jobs leave by srla_stream_out even where the others leave by host-issued copies */
@@ -449,19 +451,30 @@ struct Impl {
     uint32_t hist_exact = kHistoryWords;  /* words [0, hist_exact) of d_hist are the reference's */
     uint32_t buf_exact = kHistoryWords;   /* the same for the pool's head while a history-mode call runs */
     bool call_tainted = false;            /* a call of the running API call read a word that is not known */
-    /* ... and behind a regular call of several windows: the words below the longest transform of a full window are what the
-     * stream's LAST TWO windows leave (every full window's search analyses a candidate of the maximum block, whose transform
-     * covers them; nothing in a regular regime reaches back further).  The call keeps those windows' samples (pinned host
-     * memory, copied while it waits for its last job); when a later call on the handle is about to read the buffer -- a
-     * history-mode call -- the two windows are first encoded once more in history mode under the parameters they were encoded
-     * with, output discarded (replay_tail), which leaves the buffer as the reference's call left it.  Calls that never read the
-     * buffer pay the copy (two windows) and nothing else. */
-    struct TailCapture {
-        bool valid = false, copied = false, silent_stream = false;
+    /* ... and behind calls that ran through the regular pipeline (which keeps no buffer): a call that no earlier call can reach
+     * into -- a stream of several windows; a call of at most one window without an odd-length or short long-term-predictor block --
+     * is encoded by the regular pipeline and leaves a CAPTURE: its samples (of a stream of several windows the last audible window
+     * and the one before it: every full window's search analyses a candidate of the maximum block, whose transform rewrites every
+     * word a later call can read; nothing in a regular regime reaches back further), its parameters, its shift, copied into pinned
+     * host memory while the call waits for its last job.  When a later call on the handle is about to READ the buffer -- a
+     * history-mode call -- the pending captures are first encoded once more, oldest first, in history mode under their own
+     * parameters, bytes discarded (replay_pending), which leaves the buffer as the reference's calls left it.  A capture whose
+     * largest transform is certain to run (`rewrites`) drops the older captures that cannot write beyond it (`extent`): a stream
+     * handed over block by block keeps ONE pending capture.  Calls that never read the buffer pay a copy of at most two windows. */
+    struct Capture {
         SRLAEncodeParameter par{};
         uint32_t lshift = 0, n = 0, nch = 0;
+        uint32_t extent = 0;              /* no word at or beyond it is written by the call */
+        uint32_t rewrites = 0;            /* every word below it is (0: not certain) */
+        bool search = false;              /* EncodeOptimalPartitionedBlock / EncodeWhole with a block division search; else EncodeBlock's way */
+        bool multi = false;               /* the tail of a stream of several windows: what its earlier windows left below `extent` is not kept */
         PinBuf smp;                       /* nch planes of n samples */
-    } tail;
+    };
+    struct TailState { bool copied = false, silent_stream = false; Capture c; } tail;    /* the running call's */
+    std::vector<Capture *> pending, spare;
+    static constexpr size_t kMaxPending = 8;
+    bool push_capture();                  /* tail.c -> pending */
+    void drop_pending();
     /* Device -> host read-backs of a few bytes to a few MB (near-tie numbers, partitions, probe records) go through a page-locked
      * bounce buffer: a copy straight into pageable memory is, on this platform, a GPU write into the caller's pages, and the test
      * process saw it fail ("Memory access fault ... Write access to a read-only page", a heap page still marked copy-on-write after
@@ -473,8 +486,10 @@ struct Impl {
     uint32_t block_price = 0;
     bool replaying = false;
     std::vector<uint8_t> replay_out;
-    bool keep_tail(const StreamCtx &st, bool search);   /* the samples of the last two windows (before the call's last wait) */
-    bool replay_tail();
+    void mark_raw_silence(Job &job);      /* SrlaCandDesc::raw_silence of a job of one stream whose samples do not obey its shift */
+    bool keep_tail(const StreamCtx &st, bool search);   /* the samples a capture needs (before the call's last wait) */
+    bool replay_pending();
+    bool replay_one(Capture &c);
     bool history_regime(bool search) const;
     void history_phase_reset();
     bool history_commit(uint32_t jobidx, hipStream_t stream);

@@ -55,7 +55,7 @@ Impl::~Impl()
         if (ev_ref) (void)hipEventDestroy(ev_ref);
         h_or.release();
         d_tw.release(); d_geoms.release(); d_thr.release(); d_huff.release(); d_huffcode.release(); d_pos.release(); d_or.release(); d_oracc.release(); d_svr_scratch.release(); d_svr_scratch_chain.release();
-        d_chain_pool.release(); d_chain_tab.release(); d_hist.release(); tail.smp.release(); for (auto &h : h_chain_up) h.release(); h_chain_recs.release(); h_bounce.release();
+        d_chain_pool.release(); d_chain_tab.release(); d_hist.release(); tail.c.smp.release(); drop_pending(); for (Capture *c : spare) { c->smp.release(); delete c; } spare.clear(); for (auto &h : h_chain_up) h.release(); h_chain_recs.release(); h_bounce.release();
         for (auto &b : d_chain_list) b.release();
         for (auto &b : d_chain_select) b.release();
     }
@@ -931,18 +931,19 @@ SRLAApiResult Impl::encode_streams(bool search)
     /* ... and, for the reference's own entry points, calls of at most one window: they are where a handle's earlier calls can
      * reach into this one, and in history mode they leave the handle's buffer exactly as the reference's (host_impl.h, d_hist) */
     const bool tracked = single && sx[0].reference_call && !no_chain;
-    const bool history = replaying || history_regime(search) ||
-                         (tracked && sx[0].num_samples <= (search ? par.num_lookahead_samples : par.max_num_samples_per_block));
-    if (history && tracked && tail.valid && !replaying) {
-        /* this call may read the buffer: first what the last regular call on the handle left in it */
+    /* (a call of at most one window reads the buffer only through an odd-length or short long-term-predictor block: chain_tail) */
+    const bool one_window = tracked && sx[0].num_samples <= (search ? par.num_lookahead_samples : par.max_num_samples_per_block);
+    const bool history = replaying || history_regime(search) || (one_window && (!lazy_captures || chain_tail(sx[0].num_samples, search) != 0));
+    if (history && tracked && !pending.empty() && !replaying) {
+        /* this call may read the buffer: first what the regular calls on the handle left in it */
         std::vector<StreamCtx> mine;
         mine.swap(sx);
-        const bool ok = replay_tail();
+        const bool ok = replay_pending();
         sx.swap(mine);
         if (!ok) return SRLA_APIRESULT_NG;
     }
     call_tainted = false;
-    tail.copied = false;
+    tail.copied = false; tail.silent_stream = false;
     for (uint32_t si = 0; si < nst; si++) {
         StreamCtx &st = sx[si];
         classify_buffers(st, pins.held);
@@ -987,7 +988,16 @@ SRLAApiResult Impl::encode_streams(bool search)
         st.or_mask = 0; st.or_covered = 0; st.lshift_spec = false; st.lshift_on_device = false;
         st.or_on_device = false; st.or_dev_end = 0;
         if (st.lshift_final) { /* known: given by the caller (EncodeWindows), or the second attempt after a failed speculation */ }
-        else if (!st.with_header) { st.lshift = offset_lshift; st.lshift_final = true; }   /* block calls: encoder->header.offset_lshift */
+        else if (!st.with_header) {
+            /* block calls: encoder->header.offset_lshift, whatever the samples are */
+            st.lshift = offset_lshift; st.lshift_final = true;
+            st.raw_below_shift = false;
+            if (st.lshift > 0 && st.host_in) {
+                uint32_t m = 0;
+                for (uint32_t ch = 0; ch < nch; ch++) m |= or_reduce(st.host_in[ch], st.num_samples);
+                st.raw_below_shift = (m & ((1u << st.lshift) - 1u)) != 0;
+            }
+        }
         else if (st.d_in) {
             /* offset left shift: OR of every sample (srla_utility.c:177-203) on the device, without a host round trip: the
              * jobs read the shift from device memory */
@@ -1043,9 +1053,7 @@ SRLAApiResult Impl::encode_streams(bool search)
     }
     /* a regular call of several windows: none of its blocks reaches back beyond its own stream, and what it leaves in the
      * reference's buffer is not tracked */
-    const bool fresh_before = hist_fresh;
-    const uint32_t exact_before = hist_exact;
-    if (tracked) { hist_fresh = false; hist_exact = 0; tail.silent_stream = false; }      /* (tail: keep_tail, once the stream has been looked at) */
+    /* (tracked: what the call leaves in the reference's buffer becomes a capture, keep_tail / push_capture) */
     if (need_oracc) {
         if ((size_t)8 * nst > d_oracc.cap) { drain(); if (!d_oracc.ensure((size_t)8 * nst)) return SRLA_APIRESULT_NG; }
         if (hipMemsetAsync(d_oracc.p, 0, (size_t)8 * nst, upload) != hipSuccess) return SRLA_APIRESULT_NG;
@@ -1066,7 +1074,7 @@ SRLAApiResult Impl::encode_streams(bool search)
         drain();
         for (auto &sl : slot) sl.busy = false;
         chain.active = false;
-        if (tracked) { tail.valid = false; hist_exact = 0; }     /* (the reference's call stopped somewhere, too) */
+        if (tracked) { drop_pending(); hist_exact = 0; }         /* (the reference's call stopped somewhere, too) */
         return rc;
     };
     auto job_slot = [&](uint32_t k) -> Slot & { return slot[plan[k].slot]; };
@@ -1077,6 +1085,7 @@ SRLAApiResult Impl::encode_streams(bool search)
         settle_lshift(plan[k], lsh);
         build_job(s.job, plan[k], lsh, search);
         if (apply_overrides(s.job, k)) { s.job.uploaded = false; s.job.key = 0; }
+        if (single && sx[0].raw_below_shift) mark_raw_silence(s.job);
         /* a call of one job has nothing to overlap: its stages run on ONE stream, without the cross-stream hand-overs
          * (about 13 us each; a 10 s stream: 0.49 -> 0.465 ms) */
         s.own_stream = (njobs == 1) ? streams[0] : nullptr;
@@ -1288,16 +1297,42 @@ SRLAApiResult Impl::encode_streams(bool search)
         for (const void *p : pins.held) host_pin_release(p);
         pins.held.clear();
     }
-    if (tracked && tail.silent_stream && worst == SRLA_APIRESULT_OK) { hist_fresh = fresh_before; hist_exact = exact_before; }   /* a silent stream: no call of the reference's calculator */
-    else if (tracked && !tail.copied) tail.valid = false;                                       /* (a call that failed on the way) */
-    if (tracked && tail.copied && worst == SRLA_APIRESULT_OK) {
-        /* what a later call on this handle may have to know (host_impl.h, TailCapture); the shift is final only now */
+    if (tracked && worst != SRLA_APIRESULT_OK) { drop_pending(); hist_exact = 0; }             /* (a call that failed on the way) */
+    else if (tracked && tail.copied) {
+        /* what a later call on this handle may have to know (host_impl.h, Capture); the shift is final only now */
         if (sx[0].d_in && hipStreamSynchronize(upload) != hipSuccess) return fail(SRLA_APIRESULT_NG);
-        tail.par = par; tail.lshift = sx[0].lshift; tail.valid = true;
+        tail.c.par = par; tail.c.lshift = sx[0].lshift; tail.c.search = search;
+        if (!push_capture()) return fail(SRLA_APIRESULT_NG);
+    }   /* (a silent stream: no call of the reference's calculator, nothing to keep) */
+    if (want_block_price && tracked && worst == SRLA_APIRESULT_OK && njobs > 0) {
+        /* SRLAEncoder_ComputeBlockSize through the regular pipeline: the search's price of the block (host_chain.cpp: history_window) */
+        Slot &ps = job_slot(njobs - 1);
+        SrlaBlockRecord rec;
+        if (ps.job.windows.empty() || !d2h(&rec, ps.d_blocks.as<SrlaBlockRecord>() + ps.job.windows[0].block_base, sizeof(rec)) || !rec.valid) return fail(SRLA_APIRESULT_NG);
+        block_price = rec.price;
     }
     stats.total_ms += ms_since(t0);
     if (timeline) { tl_printf("[timeline] call returned at %.3f ms\n", ms_since(t0)); fputs(tl_log.c_str(), stderr); tl_log.clear(); }
     return worst;
+}
+
+/* The reference decides "silent" on the samples as they come (srla_encoder.c:783-791), the items' flags on the samples after the
+ * offset shift: the same thing unless a block call's samples have bits below a shift that an earlier EncodeWhole left in the handle. */
+void Impl::mark_raw_silence(Job &job)
+{
+    const StreamCtx &st = sx[job.segs[0].stream];
+    if (st.host_in == nullptr) return;
+    const SegPlan &sp = job.segs[0];
+    for (SrlaCandDesc &cd : job.cands) {
+        const uint32_t off = sp.s0 + (cd.sample_off - sp.base);
+        bool silent = true;
+        for (uint32_t ch = 0; ch < par.num_channels && silent; ch++) {
+            const int32_t *p = st.host_in[ch] + off;
+            for (uint32_t i = 0; i < cd.n; i++) if (p[i] != 0) { silent = false; break; }
+        }
+        cd.raw_silence = silent ? 1u : 2u;
+    }
+    job.uploaded = false; job.key = 0;          /* (the table holds what the samples are: not one to be found again by shape) */
 }
 
 bool Impl::d2h(void *dst, const void *src, size_t bytes)
@@ -1318,10 +1353,12 @@ bool Impl::d2h_2d(void *dst, size_t dpitch, const void *src, size_t spitch, size
     return true;
 }
 
-/* the samples of the stream's last two windows, where the call that encoded them can be repeated from */
+/* The samples a capture of the running call needs: the whole call when it is one window; of a stream of several windows the last
+ * audible window and the one before it.  Also what the capture is certain to rewrite and cannot write beyond (host_impl.h). */
 bool Impl::keep_tail(const StreamCtx &st, bool search)
 {
     const uint32_t window_len = search ? par.num_lookahead_samples : par.max_num_samples_per_block, nch = par.num_channels;
+    const uint32_t minb = par.min_num_samples_per_block, maxb = par.max_num_samples_per_block;
     const uint32_t nwin = (st.num_samples + window_len - 1) / window_len;
     uint32_t start = (nwin >= 2 ? nwin - 2 : 0) * window_len, n = st.num_samples - start;
     tail.copied = false; tail.silent_stream = false;
@@ -1337,53 +1374,112 @@ bool Impl::keep_tail(const StreamCtx &st, bool search)
             while (i > audible && p[i - 1] == 0) i--;
             audible = std::max(audible, i);
         }
-        if (audible == 0) { tail.silent_stream = true; return true; }      /* nothing was analysed: the buffer, and what is kept of the call before, stay */
+        if (audible == 0) { tail.silent_stream = true; return true; }      /* nothing was analysed: the buffer, and what is kept of the calls before, stay */
         if (audible > lo) {
             const uint32_t wa = (audible - 1) / window_len;
             start = (wa >= 1 ? wa - 1 : 0) * window_len;
             n = std::min<uint64_t>(st.num_samples, (uint64_t)(wa + 1) * window_len) - start;
         }
     }
-    tail.valid = false;
-    if (!tail.smp.ensure((size_t)nch * n * 4)) return false;
+    Capture &c = tail.c;
+    if (!c.smp.ensure((size_t)nch * n * 4)) return false;
     for (uint32_t ch = 0; ch < nch; ch++) {
-        int32_t *dst = tail.smp.as<int32_t>() + (size_t)ch * n;
+        int32_t *dst = c.smp.as<int32_t>() + (size_t)ch * n;
         if (st.host_in) memcpy(dst, st.host_in[ch] + start, (size_t)n * 4);
         else if (hipMemcpyAsync(dst, st.d_in + (size_t)ch * st.d_stride + start, (size_t)n * 4, hipMemcpyDeviceToHost, upload) != hipSuccess) return false;
     }
-    tail.n = n; tail.nch = nch; tail.copied = true;
+    c.n = n; c.nch = nch; c.multi = nwin >= 2;
+    /* the longest candidate a window of the call holds, and whether one of that length is certain to be analysed (longer than the
+     * predictor order, srla_encoder.c:766-796, and not silent) -- looked at in the FIRST kept window, whose transforms every later
+     * one of the call can only overwrite from word 0 up */
+    const uint32_t w0 = std::min(window_len, n);
+    const uint32_t cap_len = search ? std::max(minb, (maxb / minb) * minb) : maxb;       /* candidates are whole minimum blocks, clipped at the window's end */
+    const uint32_t longest = std::min(cap_len, w0);
+    c.extent = geoms[geom_for(c.multi ? std::min(cap_len, window_len) : longest)].nfft;
+    c.rewrites = 0;
+    if (st.host_in && longest > preset_order()) {
+        bool audible = false;
+        for (uint32_t ch = 0; ch < nch && !audible; ch++) {
+            const int32_t *p = st.host_in[ch] + start;
+            for (uint32_t i = 0; i < longest; i++) if (p[i] != 0) { audible = true; break; }
+        }
+        if (audible) c.rewrites = geoms[geom_for(longest)].nfft;
+    }
+    tail.copied = true;
     return true;
 }
 
-/* The last two windows of the handle's last regular call once more, in history mode, under the parameters of that call, the bytes
- * discarded: afterwards d_hist holds what the reference's buffer held when that call returned (as far as hist_exact says). */
-bool Impl::replay_tail()
+void Impl::drop_pending()
 {
-    if (!tail.valid) return true;
-    tail.valid = false;
+    for (Capture *c : pending) spare.push_back(c);
+    pending.clear();
+}
+
+/* the running call's capture joins the pending ones; older ones that cannot write beyond what it is certain to rewrite go */
+bool Impl::push_capture()
+{
+    Capture *c = nullptr;
+    if (!spare.empty()) { c = spare.back(); spare.pop_back(); } else c = new Capture();
+    std::swap(c->smp, tail.c.smp);
+    c->par = tail.c.par; c->lshift = tail.c.lshift; c->n = tail.c.n; c->nch = tail.c.nch;
+    c->extent = tail.c.extent; c->rewrites = tail.c.rewrites; c->search = tail.c.search; c->multi = tail.c.multi;
+    if (c->rewrites != 0)
+        for (size_t k = pending.size(); k-- > 0;)
+            if (pending[k]->extent <= c->rewrites) { spare.push_back(pending[k]); pending.erase(pending.begin() + (long)k); }
+    pending.push_back(c);
+    tail.copied = false;
+    if (pending.size() >= kMaxPending) {
+        /* (captures that hide nothing of each other pile up -- calls of growing silence, say: settle them now) */
+        std::vector<StreamCtx> mine;
+        mine.swap(sx);
+        const bool ok = replay_pending();
+        sx.swap(mine);
+        return ok;
+    }
+    return true;
+}
+
+bool Impl::replay_pending()
+{
+    std::vector<Capture *> todo;
+    todo.swap(pending);
+    bool ok = true;
+    for (Capture *c : todo) { if (ok) ok = replay_one(*c); spare.push_back(c); }
+    if (!ok) hist_exact = 0;
+    return ok;
+}
+
+/* One captured call once more, in history mode, under the parameters of that call, the bytes discarded: afterwards the handle's
+ * buffer holds what the reference's held when that call returned (as far as hist_exact says). */
+bool Impl::replay_one(Capture &c)
+{
     const auto t0 = Clock::now();
     const SRLAEncodeParameter keep_par = par;
     const uint32_t keep_shift = offset_lshift, keep_warned = warned_reasons;
     const SRLAMI355XStats keep_stats = stats;
-    par = tail.par; param_generation++;
-    const uint32_t nch = tail.nch, n = tail.n;
+    const bool keep_price = want_block_price;
+    want_block_price = false;
+    par = c.par; param_generation++;
+    if (c.multi) hist_exact = 0;                /* (what the stream's earlier windows left below the kept windows' reach is not known) */
+    const uint32_t nch = c.nch, n = c.n;
     std::vector<const int32_t *> planes(nch);
-    for (uint32_t ch = 0; ch < nch; ch++) planes[ch] = tail.smp.as<int32_t>() + (size_t)ch * n;
+    for (uint32_t ch = 0; ch < nch; ch++) planes[ch] = c.smp.as<int32_t>() + (size_t)ch * n;
     replay_out.resize((size_t)nch * n * 4 + 64u * (n / std::max<uint32_t>(1u, par.min_num_samples_per_block) + 2u) + 4096u);
     StreamCtx st;
     st.host_in = planes.data(); st.num_samples = n;
     st.data = replay_out.data(); st.data_size = (uint32_t)std::min<size_t>(replay_out.size(), 0xFFFFFFFFu);
     st.with_header = false; st.reference_call = true;
-    st.lshift = tail.lshift; st.lshift_final = true;
+    st.lshift = c.lshift; st.lshift_final = true;
     sx.clear();
     sx.push_back(st);
     replaying = true;
-    const SRLAApiResult rc = encode_streams(search_enabled());
+    const SRLAApiResult rc = encode_streams(c.search);
     replaying = false;
     par = keep_par; param_generation++;
     offset_lshift = keep_shift; warned_reasons = keep_warned;
+    want_block_price = keep_price;
     stats = keep_stats;
     stats.history_ms += ms_since(t0);
-    if (rc != SRLA_APIRESULT_OK) { hist_exact = 0; fprintf(stderr, "[srla-mi355x] internal error: the replay of the last call's windows failed (%d)\n", (int)rc); return false; }
+    if (rc != SRLA_APIRESULT_OK) { hist_exact = 0; fprintf(stderr, "[srla-mi355x] internal error: the replay of a captured call failed (%d)\n", (int)rc); return false; }
     return true;
 }

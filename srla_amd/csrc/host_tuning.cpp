@@ -46,6 +46,7 @@ void Impl::read_environment()
     if (is_set("SRLA_MI355X_PAIR")) pair_small_jobs = number("SRLA_MI355X_PAIR", 1) != 0;
     { const long long v = number("SRLA_MI355X_PAIR_MAX", -1); if (v >= 0) pair_max_items = (uint32_t)v; }
     if (is_set("SRLA_MI355X_SPIN")) spin_short_calls = number("SRLA_MI355X_SPIN", 1) != 0;
+    if (is_set("SRLA_MI355X_LAZY_CAPTURES")) lazy_captures = number("SRLA_MI355X_LAZY_CAPTURES", 1) != 0;
     if (is_set("SRLA_MI355X_TIE_GATHER")) tie_gather = number("SRLA_MI355X_TIE_GATHER", 1) != 0;
     if (is_set("SRLA_MI355X_POOL_LINGER_US")) pool_linger_us = (uint32_t)number("SRLA_MI355X_POOL_LINGER_US", 600);
     { const long long v = number("SRLA_MI355X_DMA_TAIL", -1); if (v >= 1 && v <= 16) dma_tail_jobs = (uint32_t)v; }

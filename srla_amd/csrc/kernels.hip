@@ -3405,6 +3405,8 @@ __global__ __launch_bounds__(WAVE) void srla_price_windows(SrlaJobParams jp, con
         uint32_t bytes = raw_bytes, type = SRLA_BLOCK_RAW, method = 0;
         if (cd.item_base != 0xFFFFFFFFu) {
             bool silent = true;
+            if (cd.raw_silence != 0) silent = cd.raw_silence == 1u;
+            else
             for (uint32_t ch = 0; ch < nch; ch++)
                 if (!(results[cd.item_base + ch].flags & SRLA_ITEM_INPUT_ZERO)) { silent = false; break; }
             if (silent) { type = SRLA_BLOCK_SILENT; bytes = 11u; }

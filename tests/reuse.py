@@ -86,6 +86,13 @@ SEQUENCES = {
         dict(api="whole", input=_inp(MUSIC, 446, 50000, zero_from=0)), dict(api="whole", input=_inp(VARIED, 443, 1001)),
         dict(api="whole", input=_inp(MUSIC, 447, 70000)), dict(api="whole", input=_inp(MUSIC, 446, 50000, zero_from=0)),
         dict(api="whole", input=_inp(VARIED, 448, 4095))]),
+    # block calls under an offset shift that an earlier EncodeWhole left in the handle, on samples that do not obey it: the reference
+    # decides "silent" on the samples as they come (srla_encoder.c:783-791), then analyses what the shift leaves of them -- zeros
+    "block_calls_under_a_foreign_shift": (dict(preset=3, max_block=1024, divisions=2), [
+        dict(api="whole", input=_inp(MUSIC, 451, 5000, lshift=3)),
+        dict(api="size", input=_inp(VARIED, 452, 1024, rshift=13)), dict(api="block", input=_inp(VARIED, 452, 1024, rshift=13)),
+        dict(api="partitioned", input=_inp(VARIED, 453, 4096, rshift=12)), dict(api="block", input=_inp(MUSIC, 454, 1023, rshift=13)),
+        dict(api="block", input=_inp(MUSIC, 455, 1024))]),
     "B4095_V0_long_regular_interleaved": (dict(preset=4, max_block=4095, divisions=0, config=dict(min_block=4095, max_block=4095, lookahead=16380)), [
         dict(api="whole", input=_inp(MUSIC, 431, 9001)),
         dict(api="set", cli=dict(preset=4, max_block=4095, min_block=4095, lookahead=4095, ltp_order=1)),
@@ -106,12 +113,15 @@ def make_input(sp):
     same = sp.pop("same", False)
     zero_from = sp.pop("zero_from", None)
     zero_to = sp.pop("zero_to", None)
+    rshift = sp.pop("rshift", None)
     if same:                                   # identical channels: S = R - L is all zero
         one = dict(sp, nch=1)
         m = helpers.synth_spec(one)
         a = np.ascontiguousarray(np.vstack([m] * sp["nch"]))
     else:
         a = helpers.synth_spec(sp)
+    if rshift:                                 # a few low bits of signal
+        a >>= rshift
     if zero_from is not None:                  # digital silence from there on
         a[:, zero_from:] = 0
     if zero_to is not None:                    # ... up to there
