@@ -251,10 +251,10 @@ struct SRLAMI355XStats {
                                                     * (encoder->lpcc: one calculator per handle, lpc.c:58,211) that an EARLIER call on
                                                     * the same handle left, and the library does not know that word.  The calls of the
                                                     * reference's entry points read and leave the handle's buffer as the reference's do
-                                                    * (history-mode calls exactly; a regular call of several windows through its last two
-                                                    * windows, encoded once more when a later call is about to read the buffer); what stays
-                                                    * unknown are words those two windows did not rewrite (a stream ending in digital
-                                                    * silence) and the buffer after a call that failed.  Counted where it happens. */
+                                                    * (history-mode calls exactly; calls of the regular pipeline through a capture of their
+                                                    * samples, encoded once more when a later call is about to read the buffer); what stays
+                                                    * unknown are words a stream's kept windows did not rewrite and the buffer after a call
+                                                    * that failed.  Counted where it happens. */
 /* The reasons for which a stream of `num_samples` samples per channel encoded under the handle's current parameters would not be
  * guaranteed bit-identical to the reference (0: it is); num_samples = 0 asks about the parameters alone. */
 uint32_t SRLAMI355X_NonIdenticalReasons(struct SRLAEncoder *encoder, uint32_t num_samples);
