@@ -6,7 +6,8 @@ tests/test_handle_reuse.py).
     python tools/gpu_reuse_sweep.py [sequences] [seed]
 
 Every sequence: random parameters (regular and history regimes, LTP, now and then SVR; 8 / 16 / 24 bit), 3-9 calls of EncodeWhole /
-ComputeBlockSize / EncodeBlock / EncodeOptimalPartitionedBlock with lengths around the block and window sizes (odd and even, clips
+SRLAMI355X_EncodeWholeDevice / ComputeBlockSize / EncodeBlock / EncodeOptimalPartitionedBlock (and SRLAMI355X_EncodeBatch, which must
+neither read nor change the handle's buffer) with lengths around the block and window sizes (odd and even, clips
 of less than a window, streams of several windows), now and then SetEncodeParameter in between, inputs of every kind incl.
 identical channels, digital silence at the end and an offset left shift.
 A call the library counts as SRLAMI355X_NONIDENTICAL_HANDLE_HISTORY may differ (reported separately); any other difference is a
@@ -79,7 +80,7 @@ def sequences(count, seed):
                     new["svr_iterations"] = 1
                 steps.append(dict(api="set", cli=new))
                 cli_now = new
-            api = rnd.choice(["whole", "whole", "whole", "block", "size", "partitioned"])
+            api = rnd.choice(["whole", "whole", "whole", "block", "size", "partitioned", "whole_device", "batch"])
             if api in ("block", "size"):
                 n = rnd.choice([max_block, max_block - 1, rnd.randint(1, max_block), rnd.randint(1, max_block) | 1, min_block + 1])
             elif api == "partitioned":
@@ -119,6 +120,8 @@ def make_input(st, nch, bps=16):
 
 
 def oracle_call(o, api, pcm):
+    if api == "whole_device":
+        return o.encode_whole(pcm)
     if api == "size":
         return o.compute_block_size(pcm)
     if api == "block":
@@ -137,6 +140,7 @@ def main():
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     lib = capi.EncoderLib(helpers.PRODUCT_SO)
     lib.lib.SRLAMI355X_GetStats.argtypes = [C.c_void_p, C.POINTER(bench.Stats), C.c_int]
+    lib.lib.SRLAMI355X_EncodeWholeDevice.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.c_void_p]
     calls = mismatches = flagged_calls = flagged_differ = seqs = 0
     for case, nch, bps, cli, steps in sequences(count, seed):
         cfg, par = capi.cli_setup(nch, bps, 48000, **cli)
@@ -154,7 +158,32 @@ def main():
                 continue
             pcm = make_input(st, nch, bps)
             before = bench.Stats(); lib.lib.SRLAMI355X_GetStats(enc, C.byref(before), 0)
-            if st["api"] == "size":
+            if st["api"] == "batch":
+                # EncodeBatch models one fresh handle per stream: the oracle's bytes of a fresh handle, and the handle's buffer untouched
+                other = np.ascontiguousarray(pcm[:, :max(2, pcm.shape[1] // 2)])
+                rc, outs, res = capi.encode_batch(lib, enc, [pcm, other])
+                cur = dict(cli)
+                for x in steps[:k]:
+                    if x["api"] == "set":
+                        cur = dict(x["cli"])
+                ok = rc == capi.OK
+                for a, got in zip((pcm, other), outs):
+                    want = helpers.Oracle(nch, bits_per_sample=bps, **cur).encode_whole(a)
+                    ok = ok and got is not None and got.size == want.size and np.array_equal(got, want)
+                calls += 1
+                if not ok:
+                    mismatches += 1
+                    print("MISMATCH sequence %d call %d (batch): %s  %s  nch %d" % (case, k, cur, st, nch), flush=True)
+                    break
+                continue
+            if st["api"] == "whole_device":
+                import torch
+                d = torch.from_numpy(pcm).cuda(); torch.cuda.synchronize()
+                buf = np.zeros(2 * pcm.size * 4 + 4096, np.uint8); out = C.c_uint32(0)
+                rc = lib.lib.SRLAMI355X_EncodeWholeDevice(enc, C.c_void_p(d.data_ptr()), pcm.shape[1], pcm.shape[1], buf.ctypes.data_as(C.c_void_p), buf.size, C.byref(out), None)
+                got = buf[:out.value].copy()
+                del d
+            elif st["api"] == "size":
                 rc, got = lib.compute_block_size(enc, pcm)
             elif st["api"] == "block":
                 rc, got = lib.encode_block(enc, pcm)
