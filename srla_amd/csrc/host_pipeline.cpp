@@ -1397,14 +1397,7 @@ bool Impl::keep_tail(const StreamCtx &st, bool search)
     const uint32_t longest = std::min(cap_len, w0);
     c.extent = geoms[geom_for(c.multi ? std::min(cap_len, window_len) : longest)].nfft;
     c.rewrites = 0;
-    if (st.host_in && longest > preset_order()) {
-        bool audible = false;
-        for (uint32_t ch = 0; ch < nch && !audible; ch++) {
-            const int32_t *p = st.host_in[ch] + start;
-            for (uint32_t i = 0; i < longest; i++) if (p[i] != 0) { audible = true; break; }
-        }
-        if (audible) c.rewrites = geoms[geom_for(longest)].nfft;
-    }
+    tail.longest = longest;                     /* (push_capture looks at the kept samples once they are all there) */
     tail.copied = true;
     return true;
 }
@@ -1422,7 +1415,17 @@ bool Impl::push_capture()
     if (!spare.empty()) { c = spare.back(); spare.pop_back(); } else c = new Capture();
     std::swap(c->smp, tail.c.smp);
     c->par = tail.c.par; c->lshift = tail.c.lshift; c->n = tail.c.n; c->nch = tail.c.nch;
-    c->extent = tail.c.extent; c->rewrites = tail.c.rewrites; c->search = tail.c.search; c->multi = tail.c.multi;
+    c->extent = tail.c.extent; c->rewrites = 0; c->search = tail.c.search; c->multi = tail.c.multi;
+    /* is a candidate of the longest kind certain to be analysed -- longer than the predictor order (srla_encoder.c:777-779) and not
+     * silent (:783-791)?  The first one of the first kept window: its transform rewrites every word below its length */
+    if (tail.longest > srla::kPresetOrder[c->par.preset] && tail.longest <= c->n) {
+        bool audible = false;
+        for (uint32_t ch = 0; ch < c->nch && !audible; ch++) {
+            const int32_t *p = c->smp.as<int32_t>() + (size_t)ch * c->n;
+            for (uint32_t i = 0; i < tail.longest; i++) if (p[i] != 0) { audible = true; break; }
+        }
+        if (audible) c->rewrites = geoms[geom_for(tail.longest)].nfft;
+    }
     if (c->rewrites != 0)
         for (size_t k = pending.size(); k-- > 0;)
             if (pending[k]->extent <= c->rewrites) { spare.push_back(pending[k]); pending.erase(pending.begin() + (long)k); }
