@@ -1297,13 +1297,6 @@ SRLAApiResult Impl::encode_streams(bool search)
         for (const void *p : pins.held) host_pin_release(p);
         pins.held.clear();
     }
-    if (tracked && worst != SRLA_APIRESULT_OK) { drop_pending(); hist_exact = 0; }             /* (a call that failed on the way) */
-    else if (tracked && tail.copied) {
-        /* what a later call on this handle may have to know (host_impl.h, Capture); the shift is final only now */
-        if (sx[0].d_in && hipStreamSynchronize(upload) != hipSuccess) return fail(SRLA_APIRESULT_NG);
-        tail.c.par = par; tail.c.lshift = sx[0].lshift; tail.c.search = search;
-        if (!push_capture()) return fail(SRLA_APIRESULT_NG);
-    }   /* (a silent stream: no call of the reference's calculator, nothing to keep) */
     if (want_block_price && tracked && worst == SRLA_APIRESULT_OK && njobs > 0) {
         /* SRLAEncoder_ComputeBlockSize through the regular pipeline: the search's price of the block (host_chain.cpp: history_window) */
         Slot &ps = job_slot(njobs - 1);
@@ -1311,6 +1304,13 @@ SRLAApiResult Impl::encode_streams(bool search)
         if (ps.job.windows.empty() || !d2h(&rec, ps.d_blocks.as<SrlaBlockRecord>() + ps.job.windows[0].block_base, sizeof(rec)) || !rec.valid) return fail(SRLA_APIRESULT_NG);
         block_price = rec.price;
     }
+    if (tracked && worst != SRLA_APIRESULT_OK) { drop_pending(); hist_exact = 0; }             /* (a call that failed on the way) */
+    else if (tracked && tail.copied) {
+        /* what a later call on this handle may have to know (host_impl.h, Capture); the shift is final only now */
+        if (sx[0].d_in && hipStreamSynchronize(upload) != hipSuccess) return fail(SRLA_APIRESULT_NG);
+        tail.c.par = par; tail.c.lshift = sx[0].lshift; tail.c.search = search;
+        if (!push_capture()) return fail(SRLA_APIRESULT_NG);
+    }   /* (a silent stream: no call of the reference's calculator, nothing to keep) */
     stats.total_ms += ms_since(t0);
     if (timeline) { tl_printf("[timeline] call returned at %.3f ms\n", ms_since(t0)); fputs(tl_log.c_str(), stderr); tl_log.clear(); }
     return worst;
