@@ -23,7 +23,8 @@ Derived per kernel in pmc_summary.json:
   lds_util              = SQ_LDS_IDX_ACTIVE / (256 CUs * duration * 2.4 GHz)
   fp64_inst_frac        = (ADD_F64 + MUL_F64 + FMA_F64) / SQ_INSTS_VALU
   wait_frac             = SQ_WAIT_ANY / SQ_WAVE_CYCLES   (wave cycles parked in s_waitcnt / barrier)
-the utilisation figures being those of the kernel's LONGEST dispatch (a full job), not an average over full and tail jobs."""
+the utilisation figures being those of ONE full job's dispatch -- among the kernel's dispatches with its largest grid the one of
+median duration (the first one runs cold) --, not an average over full and tail jobs."""
 import collections
 import csv
 import glob
