@@ -470,7 +470,7 @@ struct Impl {
         bool multi = false;               /* the tail of a stream of several windows: what its earlier windows left below `extent` is not kept */
         PinBuf smp;                       /* nch planes of n samples */
     };
-    struct TailState { bool copied = false, silent_stream = false; uint32_t longest = 0; Capture c; } tail;    /* the running call's */
+    struct TailState { bool copied = false, silent_stream = false, from_device = false, whole_stream = false; uint32_t longest = 0, window_len = 0; Capture c; } tail;    /* the running call's */
     std::vector<Capture *> pending, spare;
     static constexpr size_t kMaxPending = 8;
     bool push_capture();                  /* tail.c -> pending */

@@ -1363,6 +1363,11 @@ bool Impl::keep_tail(const StreamCtx &st, bool search)
     uint32_t start = (nwin >= 2 ? nwin - 2 : 0) * window_len, n = st.num_samples - start;
     tail.copied = false; tail.silent_stream = false;
     if (st.host_in == nullptr && st.d_in == nullptr) return true;
+    /* (planes in device memory: the last eight windows come over, and push_capture looks back over their digital silence) */
+    tail.from_device = st.host_in == nullptr;
+    tail.window_len = window_len;
+    if (tail.from_device) { start = (nwin > 8u ? nwin - 8u : 0u) * window_len; n = st.num_samples - start; }
+    tail.whole_stream = start == 0;
     if (st.host_in) {
         /* digital silence at the end: its blocks are not analysed (srla_encoder.c:766-796), so what the buffer holds is what the
          * last AUDIBLE window and the one before it left -- those two are kept (looking back over at most 64 windows) */
@@ -1416,6 +1421,27 @@ bool Impl::push_capture()
     std::swap(c->smp, tail.c.smp);
     c->par = tail.c.par; c->lshift = tail.c.lshift; c->n = tail.c.n; c->nch = tail.c.nch;
     c->extent = tail.c.extent; c->rewrites = 0; c->search = tail.c.search; c->multi = tail.c.multi;
+    if (tail.from_device) {
+        /* digital silence at the end, as keep_tail does it for host planes: the last audible window and the one before it stay */
+        const uint32_t wl = tail.window_len, n0 = c->n;
+        uint32_t audible = 0;
+        for (uint32_t ch = 0; ch < c->nch; ch++) {
+            const int32_t *p = c->smp.as<int32_t>() + (size_t)ch * n0;
+            uint32_t i = n0;
+            while (i > audible && p[i - 1] == 0) i--;
+            audible = std::max(audible, i);
+        }
+        if (audible == 0 && tail.whole_stream) { spare.push_back(c); tail.copied = false; return true; }     /* a silent stream: nothing to keep */
+        if (audible != 0) {
+            const uint32_t wa = (audible - 1) / wl, ns = (wa >= 1 ? wa - 1 : 0) * wl;
+            const uint32_t nn = (uint32_t)std::min<uint64_t>(n0, (uint64_t)(wa + 1) * wl) - ns;
+            if (ns != 0 || nn != n0) {
+                for (uint32_t ch = 0; ch < c->nch; ch++)
+                    memmove(c->smp.as<int32_t>() + (size_t)ch * nn, c->smp.as<int32_t>() + (size_t)ch * n0 + ns, (size_t)nn * 4);
+                c->n = nn;
+            }
+        }
+    }
     /* is a candidate of the longest kind certain to be analysed -- longer than the predictor order (srla_encoder.c:777-779) and not
      * silent (:783-791)?  The first one of the first kept window: its transform rewrites every word below its length */
     if (tail.longest > srla::kPresetOrder[c->par.preset] && tail.longest <= c->n) {
