@@ -162,3 +162,14 @@ def test_product_does_not_link_the_oracle():
     import subprocess
     out = subprocess.run(["nm", "-D", helpers.PRODUCT_SO], capture_output=True, text=True).stdout
     assert "oracle_" not in out
+
+
+def test_every_environment_variable_the_library_reads_is_documented():
+    """srla_amd/csrc/host_tuning.cpp is the one place that reads the environment; INTEGRATION.md section 8 lists what it reads"""
+    import re
+    src = open(os.path.join(helpers.ROOT, "srla_amd", "csrc", "host_tuning.cpp")).read()
+    doc = open(os.path.join(helpers.ROOT, "INTEGRATION.md")).read()
+    names = sorted(set(re.findall(r'"(SRLA_MI355X_[A-Z0-9_]+)"', src)))
+    assert len(names) > 20
+    missing = [n for n in names if n not in doc]
+    assert not missing, missing
