@@ -34,6 +34,7 @@
 #include <hip/hip_ext.h>
 #include <stdlib.h>
 #include <stdint.h>
+#include <string.h>
 #include <float.h>
 #include <algorithm>
 
@@ -54,6 +55,30 @@
 #endif
 
 #include "device_common.h"
+
+/* -DSRLA_DIAG_PHASES (tools/r05_phases.sh; never in the shipped library): where the wavefronts of the two wide kernels spend their
+ * time IN FLIGHT -- every wavefront stamps the shader clock at phase boundaries and adds the differences to a per-workgroup row of
+ * srla_diag_phase[kernel][row][phase]; SRLAMI355X_DiagPhases copies the table out and clears it. */
+#ifdef SRLA_DIAG_PHASES
+__device__ unsigned long long srla_diag_phase[2][1024][16];
+#define PHASE_INIT() unsigned long long ph_t_ = __builtin_amdgcn_s_memtime()
+#define PHASE_PARAM , unsigned long long &ph_t_
+#define PHASE_ARG , ph_t_
+#define PHASE(KERNEL, K) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if ((threadIdx.x & 63u) == 0) atomicAdd(&srla_diag_phase[KERNEL][blockIdx.x & 1023u][K], t_ - ph_t_); ph_t_ = t_; } while (0)
+extern "C" int SRLAMI355X_DiagPhases(unsigned long long *out /* [2][16] */)
+{
+    static unsigned long long host[2][1024][16];
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(srla_diag_phase), sizeof host) != hipSuccess) return -1;
+    for (int k = 0; k < 2; k++) for (int p = 0; p < 16; p++) { unsigned long long t = 0; for (int r = 0; r < 1024; r++) t += host[k][r][p]; out[16 * k + p] = t; }
+    memset(host, 0, sizeof host);
+    return hipMemcpyToSymbol(HIP_SYMBOL(srla_diag_phase), host, sizeof host) == hipSuccess ? 0 : -1;
+}
+#else
+#define PHASE_INIT() do { } while (0)
+#define PHASE(KERNEL, K) do { } while (0)
+#define PHASE_PARAM
+#define PHASE_ARG
+#endif
 
 /* ------------------------------------------------------------------------------ FFT ------ */
 /* complex FFT of m points held interleaved in LDS: radix-4 decimation in frequency with the
@@ -281,6 +306,166 @@ __device__ __forceinline__ uint32_t complex_table_len(uint32_t m)
     uint32_t t = 0;
     for (uint32_t n = m; n > 2; n >>= 2) t += 3 * (n >> 2);
     return t;
+}
+
+/* ---- The transform with wave-private stages (round 5; M <= 2048 complex points on at most four wavefronts) ------------------
+ * After the first radix-4 stage the Stockham data splits into four independent sub-transforms by index mod 4: a later stage
+ * with stride s (a multiple of 4) reads q + s (p + k n/4) and writes q + s (4 p + k) (fft.c:71-128), so q mod 4 never changes.
+ * The four residues are therefore kept as four contiguous REGIONS of the LDS buffer -- element e stands at region e & 3,
+ * position e >> 2 -- and every wavefront owns whole regions: inside a region, butterfly bf = 4 j + rho of the stage with
+ * stride s = 4 s' is butterfly j of an ordinary stage with stride s' on M / 4 points (inputs j + k M/16, outputs
+ * 4 j - 3 (j & (s' - 1)) + k s', table entry j >> log2 s' of the SAME table: p is the same number).  A wavefront's LDS
+ * operations execute in order, so stages 2 .. last of either direction need no workgroup barrier at all: each wavefront
+ * runs through its regions at its own pace.  What is left of the barriers: one behind the first stage (which is in place:
+ * butterfly bf reads the elements bf + k M/4 and leaves output k = element 4 bf + k at position bf of region k -- the same
+ * four slots), one in front of the spectrum pass, one inside it (it reads the regions and writes the inverse's input order),
+ * one behind it, one behind the inverse's first stage, one in front of the lag stores.
+ * Same butterflies, same operands, same operation order: the same bits.
+ *
+ * fft_regions: stages 2 .. last (and the closing radix-2 stage) of the M-point transform on the region layout.
+ *   INSWZ: the regions' positions come permuted by fft_swz (the inverse: its first stage ran in place on the spectrum pass's
+ *          permuted output, see spectrum_power_pass_regions).
+ * Lane -> butterfly: local index u = lane + 64 r; the wavefront's RPW = 4 / (NTK / 64) regions have BPR = M / 16 butterflies
+ * each per stage: region = wave RPW + u / BPR, j = u % BPR. */
+__device__ __forceinline__ uint32_t fft_swz(uint32_t e) { return e ^ ((e >> 3) & 3u); }
+
+template <int R, int NTK, int M, int FLAG, bool PRUNE, bool INSWZ>
+__device__ __forceinline__ void fft_regions(cplx *x, const cplx *__restrict__ tw, const uint32_t need)
+{
+    constexpr int NW = NTK / 64, RPW = 4 / NW;
+    constexpr uint32_t BPR = (uint32_t)M >> 4, QM = (uint32_t)M >> 2, SUB4 = (uint32_t)M >> 4;   /* butterflies per region and stage; region size; quarter of a region */
+    static_assert(NW >= 1 && NW <= 4 && RPW * (int)BPR == 64 * R, "every wavefront owns whole regions");
+    constexpr int NST = (M >= 4096) ? 6 : ((M >= 1024) ? 5 : ((M >= 256) ? 4 : ((M >= 64) ? 3 : ((M >= 16) ? 2 : 1))));
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t twoff = 3u * ((uint32_t)M >> 2);                 /* behind the first stage's tables */
+#pragma unroll
+    for (int st = 1; st < NST; st++) {
+        const uint32_t n = (uint32_t)M >> (2 * st), s = 1u << (2 * st), sp = s >> 2, log2sp = 2u * (uint32_t)(st - 1);
+        if (n <= 2) break;
+        const uint32_t n1 = n >> 2;
+        const bool k1 = !PRUNE || s < need, k2 = !PRUNE || 2 * s < need, k3 = !PRUNE || 3 * s < need;
+        cplx a[R], b[R], c[R], d[R], w1[R], w2[R], w3[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const uint32_t u = lane + 64u * (uint32_t)r;
+            const uint32_t rho = wave * (uint32_t)RPW + u / BPR, j = u % BPR;
+            const uint32_t qp = j & (sp - 1);
+            if (!PRUNE || 4u * qp + rho < need) {
+                const uint32_t p = j >> log2sp;
+                const cplx *t = tw + twoff + p;
+                if (k1) w1[r] = t[0];
+                if (k2) w2[r] = t[n1];
+                if (k3) w3[r] = t[2 * n1];
+                const cplx *xi = x + rho * QM + (((INSWZ && st == 1) || st == 2) ? fft_swz(j) : j);
+                a[r] = xi[0]; b[r] = xi[SUB4]; c[r] = xi[2 * SUB4]; d[r] = xi[3 * SUB4];
+            }
+        }
+        /* (no barrier: the wavefront's own loads above are executed before its stores below) */
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const uint32_t u = lane + 64u * (uint32_t)r;
+            const uint32_t rho = wave * (uint32_t)RPW + u / BPR, j = u % BPR;
+            const uint32_t qp = j & (sp - 1);
+            if (!PRUNE || 4u * qp + rho < need) {
+                const cplx apc = c_add(a[r], c[r]), amc = c_sub(a[r], c[r]), bpd = c_add(b[r], d[r]);
+                const cplx bmd = c_sub(b[r], d[r]);
+                const cplx jbmd = (FLAG < 0) ? make_double2(-bmd.y, bmd.x) : make_double2(bmd.y, -bmd.x);
+                if (st == 1) {
+                    /* the region's first stage: a thread's four outputs are the consecutive positions 4 j .. 4 j + 3; permuted
+                     * among themselves as in fft_complex_lds_ct (position e goes to fft_swz(e)), the next stage reads at fft_swz */
+                    const uint32_t kx = (j >> 1) & 3u;
+                    cplx *xo = x + rho * QM + 4u * j;
+                    xo[kx] = c_add(apc, bpd);
+                    if (k1) xo[1u ^ kx] = c_mul(w1[r], c_sub(amc, jbmd));
+                    if (k2) xo[2u ^ kx] = c_mul(w2[r], c_sub(apc, bpd));
+                    if (k3) xo[3u ^ kx] = c_mul(w3[r], c_add(amc, jbmd));
+                } else {
+                    cplx *xo = x + rho * QM + (4u * j - 3u * qp);
+                    xo[0] = c_add(apc, bpd);
+                    if (k1) xo[sp] = c_mul(w1[r], c_sub(amc, jbmd));
+                    if (k2) xo[2 * sp] = c_mul(w2[r], c_sub(apc, bpd));
+                    if (k3) xo[3 * sp] = c_mul(w3[r], c_add(amc, jbmd));
+                }
+            }
+        }
+        asm volatile("" ::: "memory");
+        twoff += 3 * n1;
+    }
+    constexpr uint32_t last_n = (uint32_t)M >> (2 * NST);       /* 2 when log2 M is odd, else 1 */
+    if (last_n == 2) {
+        /* the radix-2 stage (stride M / 2): the pairs (q', q' + M / 8) of every region */
+        constexpr uint32_t HP = (uint32_t)M >> 3, s = (uint32_t)M >> 1;
+        cplx a[2 * R], b[2 * R];
+#pragma unroll
+        for (int r = 0; r < 2 * R; r++) {
+            const uint32_t u = lane + 64u * (uint32_t)r;
+            const uint32_t rho = wave * (uint32_t)RPW + u / HP, qp = u % HP;
+            if (!PRUNE || 4u * qp + rho < need) { a[r] = x[rho * QM + qp]; b[r] = x[rho * QM + qp + HP]; }
+        }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int r = 0; r < 2 * R; r++) {
+            const uint32_t u = lane + 64u * (uint32_t)r;
+            const uint32_t rho = wave * (uint32_t)RPW + u / HP, qp = u % HP;
+            if (!PRUNE || 4u * qp + rho < need) {
+                x[rho * QM + qp] = c_add(a[r], b[r]);
+                if (!PRUNE || 4u * qp + rho + s < need) x[rho * QM + qp + HP] = c_sub(a[r], b[r]);
+            }
+        }
+        asm volatile("" ::: "memory");
+    }
+}
+
+/* The first radix-4 stage on the region layout, in place: butterfly bf reads the elements bf + k M/4 (natural order, or -- SWZ,
+ * the inverse -- at fft_swz of their index: what spectrum_power_pass_regions leaves) and puts output k where input k stood,
+ * which is position bf (or fft_swz(bf)) of region k.  No thread touches another's slots, so there is no barrier between its loads
+ * and stores; one barrier behind. */
+template <int R, int NTK, int M, int FLAG, bool SWZ>
+__device__ __forceinline__ void fft_first_stage_regions(cplx *x, const cplx *__restrict__ tw)
+{
+    constexpr uint32_t QM = (uint32_t)M >> 2;
+    static_assert(R * NTK == (int)QM, "one first-stage butterfly per thread and r");
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const uint32_t bf = threadIdx.x + (uint32_t)r * NTK;
+        const cplx *t = tw + bf;
+        const cplx w1 = t[0], w2 = t[QM], w3 = t[2 * QM];
+        cplx *xi = x + (SWZ ? fft_swz(bf) : bf);
+        const cplx a = xi[0], b = xi[QM], c = xi[2 * QM], d = xi[3 * QM];
+        const cplx apc = c_add(a, c), amc = c_sub(a, c), bpd = c_add(b, d), bmd = c_sub(b, d);
+        const cplx jbmd = (FLAG < 0) ? make_double2(-bmd.y, bmd.x) : make_double2(bmd.y, -bmd.x);
+        xi[0] = c_add(apc, bpd);
+        xi[QM] = c_mul(w1, c_sub(amc, jbmd));
+        xi[2 * QM] = c_mul(w2, c_sub(apc, bpd));
+        xi[3 * QM] = c_mul(w3, c_add(amc, jbmd));
+    }
+    __syncthreads();
+}
+
+/* The same fed from registers (fft_first_stage_regs' assignment: thread tid holds the inputs of butterflies 2 tid and 2 tid + 1 of
+ * the forward transform): the two outputs k go to positions 2 tid, 2 tid + 1 of region k -- 32 consecutive bytes per lane. */
+template <int M>
+__device__ __forceinline__ void fft_first_stage_regs_regions(cplx *x, const double (&w)[4][4], const cplx *__restrict__ tw)
+{
+    const uint32_t tid = threadIdx.x;
+    constexpr uint32_t QM = (uint32_t)M >> 2;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const uint32_t bf = 2u * tid + (uint32_t)h;
+        const cplx *t = tw + bf;
+        const cplx w1 = t[0], w2 = t[QM], w3 = t[2 * QM];
+        const cplx a = make_double2(w[0][2 * h], w[0][2 * h + 1]), b = make_double2(w[1][2 * h], w[1][2 * h + 1]);
+        const cplx c = make_double2(w[2][2 * h], w[2][2 * h + 1]), d = make_double2(w[3][2 * h], w[3][2 * h + 1]);
+        const cplx apc = c_add(a, c), amc = c_sub(a, c), bpd = c_add(b, d), bmd = c_sub(b, d);
+        const cplx jbmd = make_double2(-bmd.y, bmd.x);                                /* forward: flag = -1 */
+        cplx *xo = x + bf;
+        xo[0] = c_add(apc, bpd);
+        xo[QM] = c_mul(w1, c_sub(amc, jbmd));
+        xo[2 * QM] = c_mul(w2, c_sub(apc, bpd));
+        xo[3 * QM] = c_mul(w3, c_add(amc, jbmd));
+    }
+    __syncthreads();
 }
 
 /* One radix-4 butterfly with the reference's arithmetic (fft.c:98-110), as in fft_complex_lds.  y1..y3 are only formed
@@ -520,10 +705,88 @@ __device__ void spectrum_power_pass(cplx *x, uint32_t nfft, const cplx *__restri
     __syncthreads();
 }
 
+/* The same pass between the two halves of the region-layout transform (fft_regions): reads the forward transform's output where
+ * it stands -- bin e at position e >> 2 of region e & 3 -- and leaves the inverse's input in natural order permuted by fft_swz,
+ * which fft_first_stage_regions<SWZ> reads in place.  Pair P = tid + it NTK: residue rho = P / (M/8), j' = P % (M/8) stand for bin
+ * i = rho + 4 (j' + (rho == 0)) and its partner M - i = region (4 - rho) & 3, position M/4 - 1 - j': both runs are contiguous over
+ * the lanes (no bank conflicts on the loads), and the stores at fft_swz(i) = i ^ ((i >> 3) & 3), i = rho + 4 j', put the eight lanes
+ * of a store group on eight 16-byte columns.  The bins a thread writes are not the slots it read: every pair is loaded first, one
+ * barrier, then arithmetic and stores (the arithmetic itself is spectrum_power_pass's, operation for operation). */
+template <int NTK, int M>
+__device__ __forceinline__ void spectrum_power_pass_regions(cplx *x, const cplx *__restrict__ rtw_fwd, const cplx *__restrict__ rtw_inv)
+{
+    constexpr uint32_t QM = (uint32_t)M >> 2, EIGHTH = (uint32_t)M >> 3;
+    constexpr int ITS = (M / 2) / NTK;
+    static_assert(ITS * NTK == M / 2, "whole rounds");
+    const uint32_t tid = threadIdx.x;
+    cplx za[ITS], zb[ITS], wf[ITS], wi_[ITS];
+    cplx z0 = make_double2(0.0, 0.0);
+    if (tid == 0) z0 = x[0];
+#pragma unroll
+    for (int it = 0; it < ITS; it++) {
+        const uint32_t P = tid + (uint32_t)it * NTK;
+        const uint32_t rho = P / EIGHTH, jp = P % EIGHTH;
+        const uint32_t i = rho + 4u * (jp + (rho == 0u ? 1u : 0u));
+        wf[it] = rtw_fwd[i - 1]; wi_[it] = rtw_inv[i - 1];
+        za[it] = x[rho * QM + jp + (rho == 0u ? 1u : 0u)];
+        zb[it] = x[((4u - rho) & 3u) * QM + (QM - 1u - jp)];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        /* DC / Nyquist bin: x0 = re + im, x1 = re - im, squared (fft.c:187-191, lpc.c:358-359); then the inverse's
+         * 0.5 (x0 + x1), 0.5 (x0 - x1) */
+        const double a = z0.x + z0.y, b = z0.x - z0.y;
+        const double pa = a * a, pb = b * b;
+        x[0] = make_double2(0.5 * (pa + pb), 0.5 * (pa - pb));
+    }
+#pragma unroll
+    for (int it = 0; it < ITS; it++) {
+        const uint32_t P = tid + (uint32_t)it * NTK;
+        const uint32_t rho = P / EIGHTH, jp = P % EIGHTH;
+        const uint32_t i = rho + 4u * (jp + (rho == 0u ? 1u : 0u));
+        const bool self = (i == (uint32_t)M - i);                       /* the middle bin pairs with itself */
+        double p1, p3;
+        {
+            const double c2 = -0.5;                           /* flag = -1 */
+            const cplx w = wf[it];
+            const double x1 = za[it].x, x2 = za[it].y, x3 = zb[it].x, x4 = zb[it].y;
+            const double wr = w.x, wi = w.y;
+            const double h1r = 0.5 * (x1 + x3);
+            const double h1i = 0.5 * (x2 - x4);
+            const double h2r = -c2 * (x2 + x4);
+            const double h2i = c2 * (x1 - x3);
+            const double y1 = h1r + (wr * h2r) - (wi * h2i);
+            const double y2 = h1i + (wr * h2i) + (wi * h2r);
+            const double y3 = h1r - (wr * h2r) + (wi * h2i);
+            const double y4 = -h1i + (wr * h2i) + (wi * h2r);
+            p1 = y1 * y1 + y2 * y2;
+            p3 = y3 * y3 + y4 * y4;
+            if (self) p1 = p3;
+        }
+        {
+            const double c2 = 0.5;                            /* flag = +1 */
+            const cplx w = wi_[it];
+            const double x1 = p1, x2 = 0.0, x3 = p3, x4 = 0.0;
+            const double wr = w.x, wi = w.y;
+            const double h1r = 0.5 * (x1 + x3);
+            const double h1i = 0.5 * (x2 - x4);
+            const double h2r = -c2 * (x2 + x4);
+            const double h2i = c2 * (x1 - x3);
+            const double y1 = h1r + (wr * h2r) - (wi * h2i);
+            const double y2 = h1i + (wr * h2i) + (wi * h2r);
+            const double y3 = h1r - (wr * h2r) + (wi * h2i);
+            const double y4 = -h1i + (wr * h2i) + (wi * h2r);
+            if (!self) x[fft_swz(i)] = make_double2(y1, y2);
+            x[fft_swz((uint32_t)M - i)] = make_double2(y3, y4);
+        }
+    }
+    __syncthreads();
+}
+
 /* circular autocorrelation of the (already windowed, zero padded) signal in buf (lpc.c:330-376): on return
  * complex slot cidx<F16>(i/2) component i&1 holds the unscaled lag i, for i < num_lags */
-template <int R, int NTK, bool F16, int NFFT = 0, bool FIRSTREG = false>
-__device__ void autocorr_in_place(cplx *buf, uint32_t nfft, const cplx *__restrict__ twbase, uint32_t num_lags)
+template <int R, int NTK, bool F16, int NFFT = 0, bool FIRSTREG = false, bool WP = false /* the region layout with wave-private stages: fft_regions */>
+__device__ void autocorr_in_place(cplx *buf, uint32_t nfft, const cplx *__restrict__ twbase, uint32_t num_lags PHASE_PARAM)
 {
     const uint32_t m = nfft >> 1;
     const uint32_t ct = complex_table_len(m), quarter = nfft >> 2;
@@ -531,7 +794,18 @@ __device__ void autocorr_in_place(cplx *buf, uint32_t nfft, const cplx *__restri
     const cplx *tw_inv = twbase + ct;
     const cplx *rtw_fwd = twbase + 2 * ct;
     const cplx *rtw_inv = rtw_fwd + quarter;
-    if constexpr (NFFT != 0 && !F16) {
+    if constexpr (WP) {
+        /* the first forward stage has been done (from LDS in place, or from registers): the regions are complete behind its barrier */
+        fft_regions<R, NTK, NFFT / 2, -1, false, false>(buf, tw_fwd, m);
+        __syncthreads();
+        PHASE(0, 4);                                                  /* forward stages 2.. + barrier */
+        spectrum_power_pass_regions<NTK, NFFT / 2>(buf, rtw_fwd, rtw_inv);
+        PHASE(0, 5);                                                  /* spectrum pass (two barriers) */
+        fft_first_stage_regions<R, NTK, NFFT / 2, 1, true>(buf, tw_inv);
+        PHASE(0, 6);                                                  /* first inverse stage + barrier */
+        fft_regions<R, NTK, NFFT / 2, 1, true, true>(buf, tw_inv, (num_lags + 1) >> 1);
+        __syncthreads();
+    } else if constexpr (NFFT != 0 && !F16) {
         /* the transform's length known at compile time (a launch of one FFT-size class outside chain mode) */
         fft_complex_lds_ct<R, NTK, false, NFFT / 2, -1, FIRSTREG>(buf, tw_fwd, m);
         spectrum_power_pass<NTK, false>(buf, nfft, rtw_fwd, rtw_inv);
@@ -589,7 +863,7 @@ extern "C" uint32_t srla_kernel_small_a_bytes(void) { return (uint32_t)((sizeof(
  * per round trip (R butterflies per thread and stage) */
 /* the analysis of one item: the body of srla_autocorr (one FFT-size class per launch) and of srla_autocorr_pair (two classes in
  * one launch); `bid`: the workgroup's index within its class */
-template <int R, int NTK, bool F16, int NFFT = 0 /* every item of the launch has this FFT size (0: they say themselves) */>
+template <int R, int NTK, bool F16, int NFFT = 0 /* every item of the launch has this FFT size (0: they say themselves) */, bool WP = false /* fft_regions */>
 __device__ __forceinline__ void autocorr_item(
     const SrlaJobParams &jp, const int32_t *__restrict__ input, const SrlaItemDesc *__restrict__ items,
     const SrlaGeom *__restrict__ geoms, const cplx *__restrict__ twiddles, uint32_t fft_bytes, uint32_t pass,
@@ -605,6 +879,7 @@ __device__ __forceinline__ void autocorr_item(
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t pos = xcd_position(bid, count);
     if (pos >= count) return;
+    PHASE_INIT();
     const SrlaAutocorrItem it = class_items[pos];                    /* items of one FFT-size class */
     const InputView iv = input_view(jp, it.lshift, input);
     const uint32_t item_idx = it.item;
@@ -614,22 +889,40 @@ __device__ __forceinline__ void autocorr_item(
     const bool aligned = input_aligned(in, iv);
     const bool first_pass = (pass == 1) || (jp.ltp_order == 0);   /* the pass that owns the pre-emphasis tap */
     SrlaItemResult *out = &results[item_idx];
+#ifdef SRLA_DIAG_PHASES
+    asm volatile("" :: "s"(n), "s"(iv.sh), "s"(it.sample_off));
+    PHASE(0, 9);                                                      /* item record + shift fetched */
+#endif
 
     int32_t v[CH][4];
     int32_t pv[CH], nxv[CH];
+    /* The sample before the chunk (pre-emphasis) and the one after it (r1) are the neighbouring lanes' -- lane l - 1 holds samples
+     * i4 - 4 .. i4 - 1 of the same chunk round, lane l + 1 samples i4 + 4 .. (zeros beyond n, which is what nxv wants there) -- so
+     * they come by DPP wave shifts; only the wavefront's first and last lane fetch theirs, in ONE load that touches two cache lines.
+     * (Round 4 issued two single-sample loads per chunk and channel from every lane: 16-byte lane stride, so each of them walked the
+     * same sixteen cache lines as the chunk's own 16-byte load -- two thirds of the kernel's L1 work, and the wavefronts spent a
+     * quarter of their lifetime waiting for their samples: profiles/r05/phases_*.txt.) */
+    int32_t edge[CH];
 #pragma unroll
     for (int c = 0; c < CH; c++) {
         const uint32_t i4 = 4u * (tid + (uint32_t)c * NTK);
         load_chunk(in, iv, it.variant, i4, n, aligned, v[c]);
-        pv[c] = (i4 == 0 || i4 >= n) ? v[c][0] : load_variant(in, iv, it.variant, i4 - 1);
-        /* the sample after the chunk (for r1), fetched together with the chunk so that no memory round trip is left
-         * for the reduction phase */
-        nxv[c] = (first_pass && i4 + 4 < n) ? load_variant(in, iv, it.variant, i4 + 4) : 0;
+        const bool need_prev = lane == 0 && i4 != 0 && i4 < n, need_next = lane == 63 && first_pass && i4 + 4 < n;
+        edge[c] = (need_prev || need_next) ? load_variant(in, iv, it.variant, need_prev ? i4 - 1 : i4 + 4) : 0;
+    }
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+        const uint32_t i4 = 4u * (tid + (uint32_t)c * NTK);
+        const int32_t from_below = __builtin_amdgcn_update_dpp(edge[c], v[c][3], 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+        pv[c] = (i4 == 0 || i4 >= n) ? v[c][0] : from_below;
+        nxv[c] = __builtin_amdgcn_update_dpp(edge[c], v[c][0], 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
     }
 
 #ifdef SRLA_DIAG_STOP
     if (jp.out_stride == 11) { int32_t t = 0; for (int c = 0; c < CH; c++) t ^= v[c][0] ^ v[c][3] ^ pv[c] ^ nxv[c]; if (t == 0x7fffffff) out->pad[1] = 1; return; }
 #endif
+    asm volatile("" :: "v"(v[0][0]), "v"(v[CH - 1][3]), "v"(pv[CH - 1]), "v"(nxv[CH - 1]));
+    PHASE(0, 0);                                                      /* item record fetched, sample loads landed */
     int32_t coef;
     if (first_pass) {
         /* exact integer correlations r0 = sum x^2, r1 = sum x[i] x[i+1] (srla_utility.c:226-240) */
@@ -712,6 +1005,7 @@ __device__ __forceinline__ void autocorr_item(
      * call leaves the complete buffer (all nfft words of the inverse transform) for the calls after it. */
     const bool chain = chain_pool != nullptr;
     if (pass == 0 && jp.max_order == 0 && !chain) return;   /* preset 0: fixed order 0, no LPC analysis needed */
+    PHASE(0, 1);                                                      /* tap sums, reduction, pre-emphasis tap */
 
     /* pre-emphasis in registers: y[i] = x[i] - ((x[i-1] * coef) >> 4), x[-1] = x[0] (srla_utility.c:342) */
     if (jp.bits_per_sample <= 18) {
@@ -832,6 +1126,7 @@ __device__ __forceinline__ void autocorr_item(
         if constexpr (!FIRSTREG) __syncthreads();
     }
 
+    PHASE(0, 2);                                                      /* pre-emphasis, (LTP), window */
     const uint32_t num_lags = (pass == 1) ? SRLA_LTP_LAGS : (jp.max_order + 1);
     const bool dump = chain && it.chain_dump;
 #ifdef SRLA_DIAG_STOP
@@ -846,17 +1141,27 @@ __device__ __forceinline__ void autocorr_item(
         return;
     }
 #endif
-    if constexpr (FIRSTREG) fft_first_stage_regs<NFFT / 2>(buf, wreg, twiddles + g.tw_off);
-    autocorr_in_place<R, NTK, F16, NFFT, FIRSTREG>(buf, nfft, twiddles + g.tw_off, (num_lags < nfft && !dump) ? num_lags : nfft);
+    static_assert(!WP || (NFFT != 0 && !F16), "the region layout needs the transform's length at compile time");
+    if constexpr (WP) {
+        if constexpr (FIRSTREG) fft_first_stage_regs_regions<NFFT / 2>(buf, wreg, twiddles + g.tw_off);
+        else fft_first_stage_regions<R, NTK, NFFT / 2, -1, false>(buf, twiddles + g.tw_off);
+    } else {
+        if constexpr (FIRSTREG) fft_first_stage_regs<NFFT / 2>(buf, wreg, twiddles + g.tw_off);
+    }
+    PHASE(0, 3);                                                      /* first forward stage + its barrier */
+    autocorr_in_place<R, NTK, F16, NFFT, FIRSTREG, WP>(buf, nfft, twiddles + g.tw_off, (num_lags < nfft && !dump) ? num_lags : nfft PHASE_ARG);
+    PHASE(0, 7);                                                      /* inverse stages 2.. + barrier (4-6: inside autocorr_in_place) */
+    /* where complex element e of the result stands */
+    auto slot = [&](uint32_t e) -> uint32_t { return WP ? ((e & 3u) * (uint32_t)(NFFT / 8) + (e >> 2)) : cidx<F16>(e); };
     if (dump) {
         double *dst = chain_pool + (it.chain_dump - 1u);
-        for (uint32_t i = tid; i < nfft; i += NTK) { const cplx z = buf[cidx<F16>(i >> 1)]; dst[i] = (i & 1u) ? z.y : z.x; }
+        for (uint32_t i = tid; i < nfft; i += NTK) { const cplx z = buf[slot(i >> 1)]; dst[i] = (i & 1u) ? z.y : z.x; }
     }
 
     const size_t stride = jp.num_items;
     for (uint32_t i = tid; i < num_lags; i += NTK) {
         double lag = 0.0;
-        if (i < nfft) { const cplx z = buf[cidx<F16>(i >> 1)]; lag = ((i & 1u) ? z.y : z.x) * g.acorr_norm; }
+        if (i < nfft) { const cplx z = buf[slot(i >> 1)]; lag = ((i & 1u) ? z.y : z.x) * g.acorr_norm; }
         else if (chain && it.chain_lags) {
             /* the reference copies 263 lags out of a shorter FFT buffer: what earlier calls left there */
             const uint32_t o = chain_tab[it.chain_lags - 1u + (i - nfft)];
@@ -865,9 +1170,10 @@ __device__ __forceinline__ void autocorr_item(
         lags_ws[(size_t)i * stride + item_idx] = lag;
         if (dbg) dbg[(size_t)item_idx * SRLA_DBG_STRIDE + ((pass == 1) ? SRLA_DBG_LTPLAGS : SRLA_DBG_LAGS) + i] = lag;
     }
+    PHASE(0, 8);                                                      /* lag stores */
 }
 
-template <int R, int NTK, bool F16, int NFFT = 0>
+template <int R, int NTK, bool F16, int NFFT = 0, bool WP = false>
 __global__ __launch_bounds__(NTK) __attribute__((amdgpu_waves_per_eu(4, 8))) void srla_autocorr(
     SrlaJobParams jp, const int32_t *__restrict__ input, const SrlaItemDesc *__restrict__ items,
     const SrlaGeom *__restrict__ geoms, const cplx *__restrict__ twiddles, uint32_t fft_bytes, uint32_t pass,
@@ -875,13 +1181,14 @@ __global__ __launch_bounds__(NTK) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     const SrlaAutocorrItem *__restrict__ class_items, uint32_t count, double *__restrict__ chain_pool,
     const uint32_t *__restrict__ chain_tab)
 {
-    autocorr_item<R, NTK, F16, NFFT>(jp, input, items, geoms, twiddles, fft_bytes, pass, results, lags_ws, dbg, class_items, count, chain_pool, chain_tab, blockIdx.x);
+    autocorr_item<R, NTK, F16, NFFT, WP>(jp, input, items, geoms, twiddles, fft_bytes, pass, results, lags_ws, dbg, class_items, count, chain_pool, chain_tab, blockIdx.x);
 }
 
 /* The 4096-point and the 2048-point class of a SMALL job in one launch (both run on 256 threads): a short stream's chain of
  * launches is a latency chain on a mostly idle device, and two class launches one after the other cost two launch floors where the
  * items of both fit the device together.  The workgroups of the larger class come first.  Registers and LDS are the larger class's
  * for every workgroup, which would halve the 2048-point items' occupancy in a full job: small jobs only (srla_launch_autocorr_pair). */
+template <bool WP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void srla_autocorr_pair(
     SrlaJobParams jp, const int32_t *__restrict__ input, const SrlaItemDesc *__restrict__ items,
     const SrlaGeom *__restrict__ geoms, const cplx *__restrict__ twiddles, uint32_t fft_bytes, uint32_t pass,
@@ -890,9 +1197,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
 {
     const uint32_t g4 = 8u * ((count_4096 + 7u) >> 3);
     if (blockIdx.x < g4)
-        autocorr_item<2, 256, false, 4096>(jp, input, items, geoms, twiddles, fft_bytes, pass, results, lags_ws, dbg, items_4096, count_4096, nullptr, nullptr, blockIdx.x);
+        autocorr_item<2, 256, false, 4096, WP>(jp, input, items, geoms, twiddles, fft_bytes, pass, results, lags_ws, dbg, items_4096, count_4096, nullptr, nullptr, blockIdx.x);
     else
-        autocorr_item<1, 256, false, 2048>(jp, input, items, geoms, twiddles, fft_bytes, pass, results, lags_ws, dbg, items_2048, count_2048, nullptr, nullptr, blockIdx.x - g4);
+        autocorr_item<1, 256, false, 2048, WP>(jp, input, items, geoms, twiddles, fft_bytes, pass, results, lags_ws, dbg, items_2048, count_2048, nullptr, nullptr, blockIdx.x - g4);
 }
 
 /* ================================================================================================
@@ -1822,6 +2129,7 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
     const uint32_t order = out->lpc_order, rshift = out->lpc_rshift, period = out->ltp_period;
     const uint32_t o4 = (order + 3u) & ~3u;
     const uint32_t s_base = (uint32_t)S * tid;
+    PHASE_INIT();
 
     /* load + pre-emphasis (srla_utility.c:342) */
     int32_t y[S];
@@ -1836,8 +2144,12 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
         load_chunk(in, iv, load_variant_as, s_base + 4 * c, n, aligned, t4);
         y[4 * c] = t4[0]; y[4 * c + 1] = t4[1]; y[4 * c + 2] = t4[2]; y[4 * c + 3] = t4[3];
     }
+    asm volatile("" :: "v"(y[0]), "v"(y[S - 1]));
+    PHASE(1, 0);                                                      /* sample loads landed */
     {
-        int32_t prev = (tid == 0) ? y[0] : load_variant(in, iv, it.variant, s_base - 1);
+        /* the sample before the thread's first is the lane below's last (DPP); the wavefront's first lane fetches its own */
+        const int32_t edge = (lane == 0 && tid != 0) ? load_variant(in, iv, it.variant, s_base - 1) : y[0];
+        int32_t prev = __builtin_amdgcn_update_dpp(edge, y[S - 1], 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
 #pragma unroll
         for (int i = 0; i < S; i++) {
             const int32_t cur = y[i];
@@ -1905,6 +2217,7 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
     if (tid < 16) sm->level_bits[tid] = 0;
     if (tid >= 32 && tid < 64) sm->thr[tid - 32] = rice_thresholds[tid - 32];
     __syncthreads();
+    PHASE(1, 1);                                                      /* pre-emphasis, planes + taps published, barrier */
 #ifdef SRLA_DIAG_STOP
     if (jp.out_stride == 1 || jp.out_stride == 22) { if (y[0] == 0x7fffffff) out->pad[1] = 1; return; }   /* kernel timing experiments (make EXTRA=-DSRLA_DIAG_STOP): never in the shipped library */
 #endif
@@ -1948,6 +2261,7 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
     }
 #undef PUBLISH_Y
 
+    PHASE(1, 2);                                                      /* LTP */
     /* int32 wrap-around FIR (srla_lpc_predict.c:118-265) */
     uint32_t u[S];
     uint32_t max_u = 0;
@@ -2093,6 +2407,8 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
     if (jp.out_stride == 2) { if (max_u == 0x7fffffff) out->pad[1] = 1; return; }   /* kernel timing experiments (make EXTRA=-DSRLA_DIAG_STOP): never in the shipped library */
 #endif
 
+    asm volatile("" :: "v"(u[0]), "v"(u[S - 1]), "v"(max_u));
+    PHASE(1, 3);                                                      /* FIR, residual, zig-zag */
     /* Partition means: exact integer sums at the finest level, pairwise averages above (srla_coder.c:366-389).  A thread holds
      * Q = 4 << LG finest partitions of FL samples; its levels 10 .. TL = 8 - LG form a heap in registers (node 1: the partition
      * that is the thread, nodes Q .. 2Q-1: level 10), levels TL-1 .. TL-6 come by wave shuffles, and what is left above the
@@ -2140,6 +2456,7 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
     max_u = wave_max_u32(max_u);
     if (lane == 0) { sm->wave_mean[wave] = m[LS]; sm->wave_max[wave] = max_u; }
     __syncthreads();
+    PHASE(1, 4);                                                      /* partition means, barrier */
     {
         if constexpr (LS == 2) {
             const double a = sm->wave_mean[0], b = sm->wave_mean[1], c = sm->wave_mean[2], d = sm->wave_mean[3];
@@ -2189,6 +2506,7 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
     if (max_u == 0) code_type = SRLA_CODE_ALLZERO;
     else if (m[0] < 2) code_type = SRLA_CODE_RICE;
     else code_type = SRLA_CODE_RECURSIVE_RICE;
+    PHASE(1, 5);                                                      /* residual store */
 #ifdef SRLA_DIAG_STOP
     if (jp.out_stride == 3) { if (m[0] == 1.2345) out->pad[1] = 1; return; }   /* kernel timing experiments (make EXTRA=-DSRLA_DIAG_STOP): never in the shipped library */
 #endif
@@ -2229,6 +2547,7 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
             if ((tid & ((1u << (TL - l)) - 1u)) == 0) sm->ktab[((1u << l) - 1) + (tid >> (TL - l))] = (uint8_t)kl[l];
     }
     __syncthreads();
+    PHASE(1, 6);                                                      /* Rice parameters, table, barrier */
 #ifdef SRLA_DIAG_STOP
     if (jp.out_stride == 4) { if (coded && kl[0] + kth[2 * Q - 1] == 0x7fffffff) out->pad[1] = 1; return; }   /* kernel timing experiments (make EXTRA=-DSRLA_DIAG_STOP): never in the shipped library */
 #endif
@@ -2340,6 +2659,7 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
     if (jp.out_stride == 5) return;   /* kernel timing experiments (make EXTRA=-DSRLA_DIAG_STOP): never in the shipped library */
 #endif
     __syncthreads();
+    PHASE(1, 7);                                                      /* side information, code bits of 11 levels, reductions, barrier */
     if (coded) {
         best_bits = 0xFFFFFFFFu;
         for (uint32_t l = 0; l <= 10; l++) {
@@ -2357,6 +2677,7 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
         out->res_porder = best_porder;
         out->res_bits = res_bits;
     }
+    PHASE(1, 8);                                                      /* arg-min, record */
 }
 
 extern "C" uint32_t srla_kernel_fast_lds_bytes(uint32_t fl, uint32_t ltp_order, uint32_t bits_per_sample)
@@ -4217,17 +4538,19 @@ extern "C" int srla_launch_autocorr(hipStream_t stream, int rclass, const SrlaJo
     /* outside chain mode the items of a launch (classes of more than 1024 points; `exact_nfft`: also the 1024-point class) all
      * have the class's FFT size: the kernel with the transform's length compiled in */
     if (chain_pool == nullptr && !fused && !g_tune.generic_fft && (rclass != 0 || exact_nfft)) {
-#define LAUNCH_CT(RR, TT, NF)                                                                                \
+#define LAUNCH_CT(RR, TT, NF, WPV)                                                                           \
     do {                                                                                                     \
-        SET_LDS_ATTR((srla_autocorr<RR, TT, false, NF>));                                                    \
-        hipExtLaunchKernelGGL((srla_autocorr<RR, TT, false, NF>), grid, dim3(TT), lds, stream, ev_start, ev_stop, 0, *jp, input, items, geoms, \
+        SET_LDS_ATTR((srla_autocorr<RR, TT, false, NF, WPV>));                                               \
+        hipExtLaunchKernelGGL((srla_autocorr<RR, TT, false, NF, WPV>), grid, dim3(TT), lds, stream, ev_start, ev_stop, 0, *jp, input, items, geoms, \
                            (const cplx *)twiddles, fft_bytes, pass, results, lags_ws, dbg, class_items, count, chain_pool, chain_tab); \
     } while (0)
+        /* classes of at most four wavefronts: the region layout with wave-private stages (fft_regions); SRLA_MI355X_FFT_WP=0: round 4's form */
+        const bool wp = g_tune.fft_wp != 0u;
         switch (rclass) {
-        case 0: LAUNCH_CT(1, 128, 1024); break;
-        case 1: LAUNCH_CT(1, 256, 2048); break;
-        case 2: LAUNCH_CT(2, 256, 4096); break;
-        case 4: LAUNCH_CT(2, 512, 8192); break;
+        case 0: if (wp) LAUNCH_CT(1, 128, 1024, true); else LAUNCH_CT(1, 128, 1024, false); break;
+        case 1: if (wp) LAUNCH_CT(1, 256, 2048, true); else LAUNCH_CT(1, 256, 2048, false); break;
+        case 2: if (wp) LAUNCH_CT(2, 256, 4096, true); else LAUNCH_CT(2, 256, 4096, false); break;
+        case 4: LAUNCH_CT(2, 512, 8192, false); break;
         default: return -1;
         }
 #undef LAUNCH_CT
@@ -4258,9 +4581,15 @@ extern "C" int srla_launch_autocorr_pair(hipStream_t stream, const SrlaJobParams
     if (count_4096 == 0 || count_2048 == 0) return -1;
     const uint32_t fft_bytes = 2048u * 16u, lds = fft_bytes + srla_kernel_small_a_bytes();
     dim3 grid(8u * ((count_4096 + 7u) >> 3) + 8u * ((count_2048 + 7u) >> 3));
-    SET_LDS_ATTR(srla_autocorr_pair);
-    hipExtLaunchKernelGGL(srla_autocorr_pair, grid, dim3(256), lds, stream, ev_start, ev_stop, 0, *jp, input, items, geoms, (const cplx *)twiddles,
-                          fft_bytes, pass, results, lags_ws, dbg, items_4096, count_4096, items_2048, count_2048);
+    if (g_tune.fft_wp) {
+        SET_LDS_ATTR(srla_autocorr_pair<true>);
+        hipExtLaunchKernelGGL(srla_autocorr_pair<true>, grid, dim3(256), lds, stream, ev_start, ev_stop, 0, *jp, input, items, geoms, (const cplx *)twiddles,
+                              fft_bytes, pass, results, lags_ws, dbg, items_4096, count_4096, items_2048, count_2048);
+    } else {
+        SET_LDS_ATTR(srla_autocorr_pair<false>);
+        hipExtLaunchKernelGGL(srla_autocorr_pair<false>, grid, dim3(256), lds, stream, ev_start, ev_stop, 0, *jp, input, items, geoms, (const cplx *)twiddles,
+                              fft_bytes, pass, results, lags_ws, dbg, items_4096, count_4096, items_2048, count_2048);
+    }
     return (hipGetLastError() == hipSuccess) ? 0 : -2;
 }
 
