@@ -14,7 +14,8 @@ encoded by one SRLAMI355X_EncodeBatch call per step).
 Timed region of `value`: SRLAEncoder_EncodeWhole -- planar int32 samples in ordinary (pageable) host
 memory in, the complete .srl stream in ordinary host memory out; staging, H2D, every kernel and the way back are
 inside.  K steps between barriers, max over ranks; value = sample instants encoded by all ranks / that time.  A step is
-`--calls-per-step` back-to-back calls (default: about 0.1 s of device work, 22 x 600 s at the metric configuration).
+`--calls-per-step` back-to-back calls (default: about 0.5 s of device work, 111 x 600 s at the metric configuration: 20 steps
+keep the GPU busy for 10 s without a pause; the CPU baseline leg runs BEFORE the timed region).
 Every rank encodes its own streams (windows and files are independent units: no collective on the data path), so
 scaling is weak.
 
@@ -29,6 +30,13 @@ Extra objects on the JSON line:
                    `end_to_end` = the whole path (algorithmic bytes of everything a rank encoded / its wall time).  A stage's
                    `kernels`, traffic, valu_util, lds_util, lds_bank_conflict_frac, wait_frac, fp64_inst_frac come from the committed
                    rocprofv3 PMC summary (profiles/pmc_summary.json): the kernels that RAN in that command, never a hand-kept list.
+                   `fp64` = the roof that actually bounds srla_autocorr (SURVEY 8d's honest note): the fp64 operations one job's
+                   transforms execute (counted from the configuration: items per FFT-size class x the butterflies of fft.c:71-198 that
+                   the pruned device transform runs, the Welch window, the spectrum pass) over the stage's measured time, against
+                   the 39.3 TFLOP/s an MI355X issues WITHOUT fused multiply-adds (the reference is C90: no FMA); `int_valu` = the
+                   wave-level VALU instructions of one srla_residual_cost launch (committed SQ_INSTS_VALU) x 64 lanes over the
+                   stage's measured time, against the 78.6 T lane-operations/s the SIMDs can issue.  `profile_stale`: the committed
+                   counters were collected from other device sources than the ones now in srla_amd/csrc (SHA-256 stamp).
   cpu_baseline     the compiled reference (oracle/_ref, "reference") or the oracle ("port") timed on ONE host core on
                    a bounded sample of the same workload (rank 0, N = 1 only); `all_cores`: for context, the same on
                    every usable core at once (one handle per thread).
@@ -36,6 +44,9 @@ Extra objects on the JSON line:
                    (SRLAMI355X_EncodeWholeDevice), median of a few calls outside the timed region -- never `value`.
   stream_60s, stream_10s   one 60 s (SURVEY 8d's own input length) / 10 s stream per SRLAEncoder_EncodeWhole call, pageable
                    host memory to pageable host memory, median of 20 calls outside the timed region -- never `value`.
+  alternating_inputs   the headline's calls again, alternating between TWO different streams of the same length (nothing a cache of
+                   the previous call could flatter); unequal_corpus: nine files of unequal lengths (120-420 s, fixed seed) in one
+                   SRLAMI355X_EncodeBatch call under config 5's flags -- tail jobs of ever new shapes.  Beside `value`, never it.
   per_rank         (N > 1) every rank's own time inside the library per step (min / max), how many ranks locked their input /
                    output in place instead of staging, how many ranks' streams decoded back to their input, pool threads.
 """
@@ -218,7 +229,60 @@ def dominant_kernel(stats_csv, algo_bytes_per_job, peak):
             "source": os.path.relpath(stats_csv, ROOT) + " (average over full and tail jobs of that run)"}
 
 
-def roofline_object(st, config, launches, instants_per_launch, algo_bytes, end_to_end_gbs, peak=8000.0):
+def next_pow2(v):
+    p = 1
+    while p < v:
+        p *= 2
+    return p
+
+
+def autocorr_item_flops(n, num_lags):
+    """fp64 additions + multiplications the device executes for ONE autocorrelation item of n samples (no FMA: the reference is
+    C90): Welch window (lpc.c:256-266: two exact index differences, the divisor times a times b, the sample's scaling, the product:
+    6 per sample), forward complex transform of nfft/2 points (fft.c:71-136: a radix-4 butterfly is 8 complex additions and 3
+    complex multiplications = 34, the closing radix-2 stage 4 per pair), the real-transform symmetry pass + |X|^2 + the inverse
+    symmetry pass (fft.c:147-198, lpc.c:357-365: 46 per bin pair), the inverse transform pruned to the outputs that reach the
+    first ceil(lags / 2) complex results (srla_amd/csrc/kernels.hip: fft_regions), one multiplication per lag."""
+    nfft = max(2, next_pow2(n))
+    m = nfft // 2
+    need = (min(num_lags, nfft) + 1) // 2
+    flops = 6.0 * n + 46.0 * (m // 2) + 8.0 + min(num_lags, nfft)
+    nn, s = m, 1
+    while nn > 2:
+        flops += 34.0 * (m // 4)                                        # forward stage
+        active = (m // 4) if s <= need else (m // 4 // s) * need       # butterflies with q < need
+        outs = sum(1 for k in (1, 2, 3) if k * s < need)
+        flops += active * (10.0 + 8.0 * outs)                           # pruned inverse stage
+        nn //= 4
+        s *= 4
+    if nn == 2:
+        flops += 4.0 * (m // 2) + 2.0 * min(m // 2, need)
+    return flops
+
+
+def autocorr_flops_per_job(cli, instants_per_launch):
+    """fp64 operations of one job's srla_autocorr launches at this configuration: windows per job x the candidates of every block
+    length of the block-division search (srla_encoder.c:336-389) x 4 variants (L, R, M, S) x the operations of one item.  With the
+    long-term predictor every item runs the LTP pass (263 lags) and -- an upper bound: items without a pitch skip it -- the LPC pass."""
+    maxb, minb = cli["max_block"], cli["max_block"] >> cli["divisions"]
+    window = 4 * maxb
+    nodes = window // minb + 1
+    order = (0, 8, 16, 32, 64, 128, 255)[cli["preset"]]
+    per_window, items = 0.0, 0
+    for k in range(1, maxb // minb + 1):
+        cands = nodes - k
+        n = k * minb
+        f = 0.0
+        if order > 0:
+            f += autocorr_item_flops(n, order + 1)
+        if cli["ltp_order"] > 0:
+            f += autocorr_item_flops(n, 263)
+        per_window += 4.0 * cands * f
+        items += 4 * cands
+    return per_window * (instants_per_launch / window), items * (instants_per_launch / window)
+
+
+def roofline_object(st, config, launches, instants_per_launch, algo_bytes, end_to_end_gbs, peak=8000.0, cli=None):
     """The roofline object of the JSON line.  Every stage of a job is priced against the same contract -- SURVEY 8d's 16 B per
     stereo sample instant x the instants one job (= one launch of every analysis kernel) covers, over the stage's average
     duration per job measured with HIP events attached to the dispatches inside the timed region (srla_residual_cost on every
@@ -271,9 +335,37 @@ def roofline_object(st, config, launches, instants_per_launch, algo_bytes, end_t
             # the whole path against the same contract: algorithmic bytes of everything one rank encoded / its wall time
             "end_to_end": {"achieved": round(end_to_end_gbs, 2), "frac": round(end_to_end_gbs / peak, 6)},
             "pmc_source": pmc.get("_source", "profiles/pmc_summary.json[%s] (rocprofv3 --pmc, separate passes)" % config) if pmc else None}
-    for key in ("valu_util", "fp64_inst_frac"):
-        if key in d:
-            roof[key] = d[key]
+    # the roofs that actually bound the two wide kernels (none of this path's kernels is HBM bound: SURVEY 8d's honest note)
+    ac = stages.get("srla_autocorr")
+    if cli is not None and ac and ac.get("ms_per_job"):
+        flops, items = autocorr_flops_per_job(cli, instants_per_launch)
+        tf = flops / (ac["ms_per_job"] * 1e-3) / 1e12
+        roof["fp64"] = {"kernel": "srla_autocorr", "flops_per_job": int(flops), "items_per_job": int(items),
+                        "achieved_tflops": round(tf, 3), "peak_no_fma_tflops": 39.3, "frac": round(tf / 39.3, 4),
+                        "peak_fma_tflops": 78.6,
+                        "note": "fp64 additions + multiplications executed (pruned inverse transform), no FMA as the reference is C90; "
+                                "stage time measured in flight with HIP events"}
+        counted = [v.get("fp64_flops_full_job") for k, v in kernels_seen.items() if kernel_stage(k) == "srla_autocorr" and v.get("fp64_flops_full_job")]
+        if counted:
+            roof["fp64"]["flops_per_full_job_from_counters"] = int(sum(counted))
+    rc = stages.get("srla_residual_cost")
+    rc_insts = [v.get("valu_wave_insts_full_job") for k, v in kernels_seen.items() if kernel_stage(k) == "srla_residual_cost" and v.get("valu_wave_insts_full_job")]
+    if rc and rc.get("ms_per_job") and rc_insts:
+        lane_ops = 64.0 * sum(rc_insts) * instants_per_launch / 4194304.0
+        tops = lane_ops / (rc["ms_per_job"] * 1e-3) / 1e12
+        roof["int_valu"] = {"kernel": "srla_residual_cost", "valu_wave_instructions_per_job": int(sum(rc_insts) * instants_per_launch / 4194304.0),
+                            "achieved_tera_lane_ops": round(tops, 3), "peak_tera_lane_ops": 78.6, "frac": round(tops / 78.6, 4),
+                            "note": "committed SQ_INSTS_VALU of a full job's launch x 64 lanes / this run's stage time; peak = 1024 SIMDs x 32 lanes x 2.4 GHz"}
+    # were the committed counters collected from the device sources this library was built from?
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import profiles as _profiles
+        now = _profiles.kernel_source_sha256()
+        stamp = pmc.get("_kernel_sha256")
+        roof["profile_stale"] = (stamp != now)
+        roof["profile_kernel_sha256"] = stamp
+    except Exception:
+        roof["profile_stale"] = None
     return roof
 
 
@@ -284,8 +376,8 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="M", choices=sorted(CONFIGS), help="M: the metric configuration; C1..C5: BASELINE.json's configs")
     ap.add_argument("--calls-per-step", type=int, default=0,
-                    help="encode calls per step, back to back (default: as many as make a step about 0.1 s of device work -- 24 x 600 s "
-                         "at the metric configuration --, so that 20 steps keep the GPU busy for 2 s and an outside sampler sees it)")
+                    help="encode calls per step, back to back (default: as many as make a step about 0.5 s of device work -- 111 x 600 s "
+                         "at the metric configuration --, so that 20 steps keep the GPU busy for 10 s and an outside sampler sees it)")
     ap.add_argument("--seconds", type=float, default=None, help="audio per stream (default: the configuration's)")
     ap.add_argument("--files", type=int, default=None, help="streams per GPU per step (> 1: one SRLAMI355X_EncodeBatch call per step)")
     ap.add_argument("--cpu-seconds", type=float, default=0.0,
@@ -352,9 +444,9 @@ def main(argv=None):
     files = args.files if args.files is not None else conf.get("files", 1)
     n = int(seconds * rate)
     n -= n % 2
-    # a step of about 0.1 s: calls of the same unchanged API, back to back (nominal pace of the configurations on one MI355X)
+    # a step of about 0.5 s: calls of the same unchanged API, back to back (nominal pace of the configurations on one MI355X)
     nominal = {"M": 6400.0, "C1": 300.0, "C2": 7000.0, "C3": 2300.0, "C4": 1300.0, "C5": 1800.0}[args.config]
-    calls = args.calls_per_step or max(1, int(round(0.1 * nominal * 1e6 / max(1.0, float(n) * files))))
+    calls = args.calls_per_step or max(1, int(round(0.5 * nominal * 1e6 / max(1.0, float(n) * files))))
     metric = "encode Msamples/s (-m %d -B %d -V %d -P %d, %s %g kHz %d-bit)" % (
         cli["preset"], cli["max_block"], cli["divisions"], cli["ltp_order"], "stereo" if nch == 2 else "%d ch" % nch, rate / 1000.0, bps)
 
@@ -458,6 +550,12 @@ def main(argv=None):
         for _ in range(calls):
             call()
 
+    # the CPU baseline leg FIRST (rank 0 at N = 1 only): the timed region below is then the last long thing this process does,
+    # and an outside GPU-busy sampler does not spend the run looking at a host-only phase
+    cpu_line = None
+    if not args.no_cpu_baseline and world == 1 and rank == 0:
+        cpu_line = cpu_baseline(pcms[0], cli, args.cpu_seconds, rate, bps)
+
     for _ in range(args.warmup):
         step()
     st = Stats()
@@ -503,7 +601,7 @@ def main(argv=None):
         instants_per_launch = float(n) * files * calls * args.steps / launches
         algo_bytes = 8.0 * nch * instants_per_launch            # 8 B per channel-sample
         roof = roofline_object(st, args.config, launches, instants_per_launch, algo_bytes,
-                               8.0 * nch * total_instants / world / elapsed / 1e9)
+                               8.0 * nch * total_instants / world / elapsed / 1e9, cli=cli if nch == 2 else None)
         total_out = sum(int(s.size) for s in streams)
         line = dict(base_line)
         line.update({
@@ -583,9 +681,63 @@ def main(argv=None):
                 line["stream_%ds" % secs] = {"value": round(m / dt / 1e6, 3), "unit": "Msamples/s", "ms_per_call": round(1e3 * dt, 3),
                                              "lossless_roundtrip": bool((helpers.oracle_decode(outs[0][:sz.value].copy()) == clip).all()),
                                              "note": "one %d s stream per SRLAEncoder_EncodeWhole call, pageable -> pageable; median of %d calls" % (secs, len(times))}
-        if not args.no_cpu_baseline and world == 1:        # rank 0 at N = 1 only
-            line["cpu_baseline"] = cpu_baseline(pcms[0], cli, args.cpu_seconds, rate, bps)
-            line["speedup_vs_cpu_1core"] = round(value / line["cpu_baseline"]["value"], 2)
+        if world == 1 and files == 1 and not args.no_extras:
+            # (a) the headline's calls alternating between two DIFFERENT streams of the same length: whatever the library keeps from
+            # the call before (descriptor tables by job shape, host_plan.cpp) is keyed by shape, never by content -- this leg shows it
+            other = helpers.synth(kind, 4242, rate, nch, n, bps)
+            oplanes = capi.planar_ptrs(other)
+            oout = np.zeros(cap, dtype=np.uint8)
+            osz = C.c_uint32(0)
+            reps = max(4, min(calls, 24))
+            reps -= reps % 2
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for k in range(reps):
+                if k & 1:
+                    rc = L.SRLAEncoder_EncodeWhole(enc, oplanes, n, oout.ctypes.data_as(C.c_void_p), cap, C.byref(osz), None)
+                else:
+                    rc = L.SRLAEncoder_EncodeWhole(enc, planes[0], n, outs[0].ctypes.data_as(C.c_void_p), cap, C.cast(out_sizes, C.POINTER(C.c_uint32)), None)
+                if rc != capi.OK:
+                    raise SystemExit("SRLAEncoder_EncodeWhole (alternating) -> %d" % rc)
+            dt = time.perf_counter() - t1
+            line["alternating_inputs"] = {"value": round(n * reps / dt / 1e6, 3), "unit": "Msamples/s", "calls": reps,
+                                          "same_bytes_first_stream": bool(np.array_equal(outs[0][:out_sizes[0]], streams[0])),
+                                          "lossless_roundtrip_second_stream": bool((helpers.oracle_decode(oout[:osz.value].copy()) == other).all()),
+                                          "note": "%d calls back to back, alternating between two different %d s streams (seeds 1000 / 4242), pageable -> pageable" % (reps, n // rate)}
+            del other, oout
+            # (b) a corpus of UNEQUAL files in one SRLAMI355X_EncodeBatch call under config 5's flags: every call plans tail jobs of
+            # shapes the equal-length C5 line never sees
+            import random
+            rnd = random.Random(20260930)
+            lens = [int(rnd.uniform(120.0, 420.0) * rate) & ~1 for _ in range(9)]
+            ucli = dict(CONFIGS["C5"]["cli"])
+            upcms = [helpers.synth(kind, 7000 + f, rate, nch, m_, bps) for f, m_ in enumerate(lens)]
+            uouts = [np.zeros(2 * p.size * (bps // 8) + 4096, dtype=np.uint8) for p in upcms]
+            ucfg, upar = capi.cli_setup(nch, bps, rate, **ucli)
+            uenc = lib.create(ucfg)
+            assert uenc and lib.set_parameter(uenc, upar) == capi.OK
+            L.SRLAMI355X_SetPackThreads(uenc, pack_threads)
+            ubatch = capi.BatchCall(lib, upcms, uouts)
+            usz = (C.c_uint32 * len(lens))()
+            times = []
+            for k in range(4):
+                t1 = time.perf_counter()
+                rc = ubatch.run(uenc, usz)
+                if rc != capi.OK:
+                    raise SystemExit("SRLAMI355X_EncodeBatch (unequal corpus) -> %d" % rc)
+                if k:
+                    times.append(time.perf_counter() - t1)
+            dt = sorted(times)[len(times) // 2]
+            line["unequal_corpus"] = {"value": round(sum(lens) / dt / 1e6, 3), "unit": "Msamples/s", "ms_per_call": round(1e3 * dt, 3),
+                                      "files": len(lens), "seconds": [round(m_ / rate, 1) for m_ in lens],
+                                      "flags": "-m %d -B %d -V %d -P %d" % (ucli["preset"], ucli["max_block"], ucli["divisions"], ucli["ltp_order"]),
+                                      "lossless_roundtrip_first_file": bool((helpers.oracle_decode(uouts[0][:usz[0]].copy()) == upcms[0]).all()),
+                                      "note": "nine files of unequal lengths (120-420 s, fixed seed) in one SRLAMI355X_EncodeBatch call, pageable -> pageable; median of 3 calls"}
+            lib.destroy(uenc)
+            del upcms, uouts
+        if cpu_line is not None:                           # rank 0 at N = 1 only; measured before the timed region
+            line["cpu_baseline"] = cpu_line
+            line["speedup_vs_cpu_1core"] = round(value / cpu_line["value"], 2)
     lib.destroy(enc)
     finish(line)
 

@@ -153,8 +153,15 @@ SRLAApiResult SRLAMI355X_OrMask(struct SRLAEncoder *encoder, const int32_t *cons
     Impl *im = impl_of(encoder);
     if (im == nullptr || input == NULL || mask == NULL) return SRLA_APIRESULT_INVALID_ARGUMENT;
     if (!im->set_parameter) return SRLA_APIRESULT_PARAMETER_NOT_SET;
-    if (!im->init_device()) return SRLA_APIRESULT_NG;
     const uint32_t nch = im->par.num_channels, chunk = 1u << 20, per_ch = (num_samples + chunk - 1) / chunk;
+    /* a host-only reduction: the pool threads where the handle has them (they come with the device), else this thread alone --
+     * the one call of the library that works without a GPU */
+    if (im->pool == nullptr && !im->init_device()) {
+        uint32_t m = 0;
+        for (uint32_t ch = 0; ch < nch; ch++) m |= srla::or_reduce(input[ch], num_samples);
+        *mask = m;
+        return SRLA_APIRESULT_OK;
+    }
     std::atomic<uint32_t> acc{ 0 };
     im->pool->parallel_for(per_ch * nch, [&](uint32_t i) {
         const uint32_t ch = i / per_ch, o = (i % per_ch) * chunk, len = std::min(chunk, num_samples - o);

@@ -468,6 +468,7 @@ struct Impl {
         uint32_t rewrites = 0;            /* every word below it is (0: not certain) */
         bool search = false;              /* EncodeOptimalPartitionedBlock / EncodeWhole with a block division search; else EncodeBlock's way */
         bool multi = false;               /* the tail of a stream of several windows: what its earlier windows left below `extent` is not kept */
+        bool raw_below_shift = false;     /* a block call on samples with bits below the handle's offset shift (StreamCtx::raw_below_shift) */
         PinBuf smp;                       /* nch planes of n samples */
     };
     struct TailState { bool copied = false, silent_stream = false, from_device = false, whole_stream = false; uint32_t longest = 0, window_len = 0; Capture c; } tail;    /* the running call's */

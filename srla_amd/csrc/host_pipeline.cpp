@@ -1046,8 +1046,9 @@ SRLAApiResult Impl::encode_streams(bool search)
     for (const StreamCtx &st : sx) if (st.with_header) note_nonidentical(st.num_samples);
     if (history) {
         overrides.clear();
+        pool->set_linger_us(0u);                                  /* (window by window with host round trips: nothing for the pool to wait for) */
         const SRLAApiResult rc = history_encode(search);
-        if (call_tainted) note_reasons(SRLAMI355X_NONIDENTICAL_HANDLE_HISTORY);
+        if (call_tainted && !replaying) note_reasons(SRLAMI355X_NONIDENTICAL_HANDLE_HISTORY);    /* (a replay's bytes are discarded; the taint reaches later real calls through hist_exact) */
         stats.total_ms += ms_since(t0);
         return rc;
     }
@@ -1074,7 +1075,7 @@ SRLAApiResult Impl::encode_streams(bool search)
         drain();
         for (auto &sl : slot) sl.busy = false;
         chain.active = false;
-        if (tracked) { drop_pending(); hist_exact = 0; }         /* (the reference's call stopped somewhere, too) */
+        if (tracked) { drop_pending(); hist_exact = 0; hist_fresh = false; }         /* (the reference's call stopped somewhere, too: its buffer is no longer the fresh handle's zeros) */
         return rc;
     };
     auto job_slot = [&](uint32_t k) -> Slot & { return slot[plan[k].slot]; };
@@ -1304,11 +1305,12 @@ SRLAApiResult Impl::encode_streams(bool search)
         if (ps.job.windows.empty() || !d2h(&rec, ps.d_blocks.as<SrlaBlockRecord>() + ps.job.windows[0].block_base, sizeof(rec)) || !rec.valid) return fail(SRLA_APIRESULT_NG);
         block_price = rec.price;
     }
-    if (tracked && worst != SRLA_APIRESULT_OK) { drop_pending(); hist_exact = 0; }             /* (a call that failed on the way) */
+    if (tracked && worst != SRLA_APIRESULT_OK) { drop_pending(); hist_exact = 0; hist_fresh = false; }             /* (a call that failed on the way) */
     else if (tracked && tail.copied) {
         /* what a later call on this handle may have to know (host_impl.h, Capture); the shift is final only now */
         if (sx[0].d_in && hipStreamSynchronize(upload) != hipSuccess) return fail(SRLA_APIRESULT_NG);
         tail.c.par = par; tail.c.lshift = sx[0].lshift; tail.c.search = search;
+        tail.c.raw_below_shift = sx[0].raw_below_shift;
         if (!push_capture()) return fail(SRLA_APIRESULT_NG);
     }   /* (a silent stream: no call of the reference's calculator, nothing to keep) */
     stats.total_ms += ms_since(t0);
@@ -1421,6 +1423,7 @@ bool Impl::push_capture()
     std::swap(c->smp, tail.c.smp);
     c->par = tail.c.par; c->lshift = tail.c.lshift; c->n = tail.c.n; c->nch = tail.c.nch;
     c->extent = tail.c.extent; c->rewrites = 0; c->search = tail.c.search; c->multi = tail.c.multi;
+    c->raw_below_shift = tail.c.raw_below_shift;
     if (tail.from_device) {
         /* digital silence at the end, as keep_tail does it for host planes: the last audible window and the one before it stay */
         const uint32_t wl = tail.window_len, n0 = c->n;
@@ -1489,7 +1492,9 @@ bool Impl::replay_one(Capture &c)
     const bool keep_price = want_block_price;
     want_block_price = false;
     par = c.par; param_generation++;
-    if (c.multi) hist_exact = 0;                /* (what the stream's earlier windows left below the kept windows' reach is not known) */
+    /* (what the stream's earlier windows left below the kept windows' reach is not known -- on a handle that has run nothing but
+     * regular calls, too: its buffer is then NOT the fresh handle's zeros any more, which history_encode would otherwise assume) */
+    if (c.multi) { hist_exact = 0; hist_fresh = false; }
     const uint32_t nch = c.nch, n = c.n;
     std::vector<const int32_t *> planes(nch);
     for (uint32_t ch = 0; ch < nch; ch++) planes[ch] = c.smp.as<int32_t>() + (size_t)ch * n;
@@ -1499,6 +1504,7 @@ bool Impl::replay_one(Capture &c)
     st.data = replay_out.data(); st.data_size = (uint32_t)std::min<size_t>(replay_out.size(), 0xFFFFFFFFu);
     st.with_header = false; st.reference_call = true;
     st.lshift = c.lshift; st.lshift_final = true;
+    st.raw_below_shift = c.raw_below_shift;     /* (a block call on samples with bits below the handle's shift: silence is decided on the raw samples, as in the call itself) */
     sx.clear();
     sx.push_back(st);
     replaying = true;

@@ -173,7 +173,7 @@ private:
     std::vector<std::thread> workers_;
     std::mutex m_;
     std::condition_variable cv_, done_cv_;
-    bool stop_;
+    std::atomic<bool> stop_;     /* read inside the unlocked spin loops */
     const std::function<void(uint32_t)> *fn_ = nullptr;
     std::atomic<uint32_t> next_{ 0 };
     uint32_t count_ = 0;

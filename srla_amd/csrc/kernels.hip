@@ -2130,6 +2130,10 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
     const uint32_t o4 = (order + 3u) & ~3u;
     const uint32_t s_base = (uint32_t)S * tid;
     PHASE_INIT();
+    /* (two more values that would otherwise be fetched late, in front of a barrier / of the record's last store: requested here,
+     * where their round trips run beside the sample loads) */
+    const double thr_mine = (tid >= 32 && tid < 64) ? rice_thresholds[tid - 32] : 0.0;
+    const uint32_t tap_bits = (tid == 0) ? out->pad[0] : 0u;       /* tap codes (srla_lpc_taps) */
 
     /* load + pre-emphasis (srla_utility.c:342) */
     int32_t y[S];
@@ -2143,6 +2147,20 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
         int32_t t4[4];
         load_chunk(in, iv, load_variant_as, s_base + 4 * c, n, aligned, t4);
         y[4 * c] = t4[0]; y[4 * c + 1] = t4[1]; y[4 * c + 2] = t4[2]; y[4 * c + 3] = t4[3];
+    }
+    /* FIR_DOT: the taps a thread will pack (group tid of four taps and its three neighbours on either side) are requested HERE,
+     * behind the sample loads and ahead of everything that waits for them, so that their round trip to the item record (which
+     * has to wait for the order) runs beside the samples' instead of standing between the planes and the barrier below */
+    uint32_t ctap[7] = { 0, 0, 0, 0, 0, 0, 0 };
+    if constexpr (DOT) {
+        if (tid <= (o4 >> 2)) {
+            const int b = 4 * (int)tid;
+#pragma unroll
+            for (int d = -3; d <= 3; d++) {
+                const int k = b + d;
+                ctap[3 + d] = (k < (int)(o4 - order) || k >= (int)o4) ? 0u : (uint32_t)(int32_t)out->lpc_coef[k - (int)(o4 - order)];
+            }
+        }
     }
     asm volatile("" :: "v"(y[0]), "v"(y[S - 1]));
     PHASE(1, 0);                                                      /* sample loads landed */
@@ -2194,13 +2212,11 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
         for (uint32_t i = tid; i < (uint32_t)(PADS / S) * (S + PADW); i += T) sig[i] = 0;    /* front padding */
     }
     if constexpr (DOT) {
-        /* tap k of the zero-padded, reversed filter (k outside [0, o4): zero) */
-        auto cq = [&](int k) -> uint32_t {
-            return (k < (int)(o4 - order) || k >= (int)o4) ? 0u : (uint32_t)(int32_t)out->lpc_coef[k - (int)(o4 - order)];
-        };
-        for (uint32_t g = tid; g <= (o4 >> 2); g += T) {
-            const int b = 4 * (int)g;
-            const uint32_t c[7] = { cq(b - 3), cq(b - 2), cq(b - 1), cq(b), cq(b + 1), cq(b + 2), cq(b + 3) };   /* c[3 + d] = tap b + d */
+        /* tap k of the zero-padded, reversed filter (k outside [0, o4): zero): ctap[3 + d] = tap 4 tid + d, fetched at the top */
+        static_assert(FIR_PAD / 4 < T, "one group of four taps per thread");
+        if (tid <= (o4 >> 2)) {
+            const int b = 4 * (int)tid;
+            const uint32_t (&c)[7] = ctap;
             /* low plane: outputs 0 and 2 of a chunk use (b, b+1) (b+2, b+3), outputs 1 and 3 (b-1, b) (b+1, b+2) */
             sm->cpack[0][b + 0] = (c[3] & 0xFFFFu) | (c[4] << 16);
             sm->cpack[0][b + 1] = (c[5] & 0xFFFFu) | (c[6] << 16);
@@ -2215,7 +2231,7 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
         for (uint32_t k = tid; k < o4; k += T) sm->coefq[k] = (k < o4 - order) ? 0 : (int32_t)out->lpc_coef[k - (o4 - order)];
     }
     if (tid < 16) sm->level_bits[tid] = 0;
-    if (tid >= 32 && tid < 64) sm->thr[tid - 32] = rice_thresholds[tid - 32];
+    if (tid >= 32 && tid < 64) sm->thr[tid - 32] = thr_mine;
     __syncthreads();
     PHASE(1, 1);                                                      /* pre-emphasis, planes + taps published, barrier */
 #ifdef SRLA_DIAG_STOP
@@ -2670,7 +2686,7 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
     }
     if (tid == 0) {
         const uint32_t res_bits = best_bits + 2u;
-        uint32_t bits = res_bits + (bps + 1u) + 5u + (8u + 4u + 1u) + out->pad[0] + 1u;   /* srla_encoder.c:1121-1187 */
+        uint32_t bits = res_bits + (bps + 1u) + 5u + (8u + 4u + 1u) + tap_bits + 1u;   /* srla_encoder.c:1121-1187 */
         if (period > 0) bits += 1u + 8u + jp.ltp_order * 6u;
         out->code_length = bits;
         out->res_code_type = code_type;
@@ -4548,7 +4564,7 @@ extern "C" int srla_launch_autocorr(hipStream_t stream, int rclass, const SrlaJo
         const bool wp = g_tune.fft_wp != 0u;
         switch (rclass) {
         case 0: if (wp) LAUNCH_CT(1, 128, 1024, true); else LAUNCH_CT(1, 128, 1024, false); break;
-        case 1: if (wp) LAUNCH_CT(1, 256, 2048, true); else LAUNCH_CT(1, 256, 2048, false); break;
+        case 1: if (wp && g_tune.fft_thin) LAUNCH_CT(2, 128, 2048, true); else if (wp) LAUNCH_CT(1, 256, 2048, true); else LAUNCH_CT(1, 256, 2048, false); break;
         case 2: if (wp) LAUNCH_CT(2, 256, 4096, true); else LAUNCH_CT(2, 256, 4096, false); break;
         case 4: LAUNCH_CT(2, 512, 8192, false); break;
         default: return -1;

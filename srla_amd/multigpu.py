@@ -78,7 +78,9 @@ def encode_stream_sharded(encode_range, pcm, header_fn, window_len, rank=0, worl
     elif or_mask is not None:
         mask = or_mask(mine)
     else:
-        mask = int(np.bitwise_or.reduce(mine.view(np.uint32), axis=None))
+        # (the low 32 bits of every sample, whatever integer type the caller's planes have: a view would OR the upper halves of
+        # negative int64 samples in)
+        mask = int(np.bitwise_or.reduce(mine.astype(np.int32, copy=False).view(np.uint32), axis=None))
     if world > 1:
         import torch.distributed as dist
         group = host_group(group)

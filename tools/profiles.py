@@ -35,6 +35,22 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def kernel_source_sha256():
+    """SHA-256 over the device sources a profile describes (every .hip file and the device headers under srla_amd/csrc, in name
+    order).  `collect` writes it next to the raw output, `summarize` copies it into profiles/<round>/<config>/ and into
+    pmc_summary.json; bench.py compares it with the sources it runs on and says `profile_stale` when they differ."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "srla_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith(".hip") or name in ("device_common.h", "device_layout.h", "huffman_codes.inc"):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()
+
+
 CLOCK_GHZ = 2.4
 SIMDS, CUS = 1024, 256
 PMC_SECONDS = 524.3                       # six jobs of 4 Mi sample instants at 48 kHz: more than three, so that the bytes leave by host-issued
@@ -67,6 +83,7 @@ def collect(tag, configs, passes, bench_only=False):
     for cfg in configs:
         d = os.path.join(out, cfg)
         os.makedirs(d, exist_ok=True)
+        open(os.path.join(d, "kernel_source_sha256.txt"), "w").write(kernel_source_sha256() + "\n")
         if not bench_only:
             sh("rocprofv3 --kernel-trace --stats --output-format csv -d %s/stats -o run -- %s --config %s --steps 3 --warmup 1 --no-cpu-baseline --no-extras"
                % (d, bench, cfg), d + "/bench_under_rocprof.log", 900)
@@ -176,6 +193,10 @@ def summarize(src, dst):
         st = os.path.join(cfg_dir, "stats", "run_kernel_stats.csv")
         if os.path.exists(st):
             shutil.copy(st, os.path.join(out, "kernel_stats.csv"))
+        stamp = None
+        if os.path.exists(os.path.join(cfg_dir, "kernel_source_sha256.txt")):
+            shutil.copy(os.path.join(cfg_dir, "kernel_source_sha256.txt"), os.path.join(out, "kernel_source_sha256.txt"))
+            stamp = open(os.path.join(cfg_dir, "kernel_source_sha256.txt")).read().strip()
         for name, log in (("bench_line.json", "bench.log"), ("bench_line_under_rocprof.json", "bench_under_rocprof.log")):
             line = last_json_line(os.path.join(cfg_dir, log))
             if line:
@@ -222,6 +243,11 @@ def summarize(src, dst):
                 f64 = sum(s4["avg"].get(c, 0.0) for c in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64"))
                 e["fp64_inst_frac"] = round(f64 / tot, 4) if tot else None
                 e["int_inst_frac"] = round((s4["avg"].get("SQ_INSTS_VALU_INT32", 0.0) + s4["avg"].get("SQ_INSTS_VALU_INT64", 0.0)) / tot, 4) if tot else None
+                # of ONE full job's dispatch: wave-level VALU instructions, and the fp64 flops they carry (64 lanes; an FMA counts two)
+                if s4.get("full"):
+                    fj = s4["full"]
+                    e["valu_wave_insts_full_job"] = fj.get("SQ_INSTS_VALU", 0.0)
+                    e["fp64_flops_full_job"] = 64.0 * (fj.get("SQ_INSTS_VALU_ADD_F64", 0.0) + fj.get("SQ_INSTS_VALU_MUL_F64", 0.0) + 2.0 * fj.get("SQ_INSTS_VALU_FMA_F64", 0.0))
             if e:
                 entry[k] = e
         # the PMC command's sample instants (its bench line says what one step was)
@@ -230,6 +256,7 @@ def summarize(src, dst):
             line = line or last_json_line(os.path.join(cfg_dir, p + ".log"))
         entry["_pmc_instants"] = float(line["config"]["samples_per_channel_per_step"]) if line else None
         entry["_source"] = "%s/%s/pmc_*.csv (rocprofv3 --pmc, separate passes)" % (os.path.relpath(dst, ROOT), cfg)
+        entry["_kernel_sha256"] = stamp
         summary[cfg] = entry
     json.dump(summary, open(spath, "w"), indent=1, sort_keys=True)
     print("wrote", dst, "and", os.path.relpath(spath, ROOT), "for", sorted(summary))
