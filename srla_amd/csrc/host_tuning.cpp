@@ -71,6 +71,7 @@ void Impl::read_environment()
     lt.pack_lds_cap_words = (uint32_t)std::max<long long>(0, number("SRLA_MI355X_PACK_LDS_WORDS", 0));   /* tests: reach the global-memory pack path */
     lt.out_wgs = (uint32_t)std::max<long long>(0, number("SRLA_MI355X_OUT_WGS", 0));
     lt.fft_wp = number("SRLA_MI355X_FFT_WP", 1) != 0 ? 1u : 0u;          /* 0: round 4's transform (a workgroup barrier per stage) */
+    lt.fir_mfma = number("SRLA_MI355X_FIR_MFMA", 1) != 0 ? 1u : 0u;          /* 0: the FIR on v_dot2 / v_dot4 (round 4) */
     lt.fft_thin = number("SRLA_MI355X_FFT_THIN", 0) != 0 ? 1u : 0u;
     lt.generic_fft = number("SRLA_MI355X_GENERIC_FFT", 0) != 0 ? 1u : 0u;
     lt.solve_onepass = number("SRLA_MI355X_SOLVE_ONEPASS", 0) != 0 ? 1u : 0u;   /* the solve chain as one launch (round 2's default) */

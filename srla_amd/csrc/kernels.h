@@ -126,6 +126,7 @@ typedef struct {
     uint32_t pack_lds_cap_words;   /* SRLA_MI355X_PACK_LDS_WORDS: 0 = the default cap (24 Ki words) */
     uint32_t out_wgs;              /* SRLA_MI355X_OUT_WGS: stream-out workgroups, 0 = by sample width */
     uint32_t fft_wp;               /* SRLA_MI355X_FFT_WP (default 1): the region layout with wave-private FFT stages for classes of at most 4096 points */
+    uint32_t fir_mfma;             /* SRLA_MI355X_FIR_MFMA: srla_residual_cost's FIR as a Toeplitz product on the matrix pipe (blocks <= 4096 samples) */
     uint32_t fft_thin;             /* SRLA_MI355X_FFT_THIN: the 2048-point class on 128 threads (two butterflies per thread and stage) */
     uint32_t generic_fft;          /* SRLA_MI355X_GENERIC_FFT: srla_autocorr without the FFT size compiled in, as in round 2 */
     uint32_t solve_onepass;        /* SRLA_MI355X_SOLVE_ONEPASS: srla_lpc_solve_regs instead of errvars + order_select + taps */

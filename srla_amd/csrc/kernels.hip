@@ -33,6 +33,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdlib.h>
+#include <stddef.h>
 #include <stdint.h>
 #include <string.h>
 #include <float.h>
@@ -1958,11 +1959,16 @@ extern "C" uint32_t srla_kernel_small_c_bytes(void) { return (uint32_t)((sizeof(
  * through four LDS words.  The residual never goes back to LDS; only the signal (for the FIR windows of
  * neighbouring threads) and the 2047-byte parameter table do.  LDS layout of the signal: four words of
  * padding after every S samples so that the 16-byte window loads of a wavefront are conflict free. */
+static_assert(offsetof(SrlaItemResult, lpc_coef) % 4 == 0 && sizeof(SrlaItemResult) % 4 == 0, "the taps of an item record can be read as aligned words");
+#define MF_PADB 256                 /* FIR_MFMA: zero bytes in front of every byte plane (>= the largest order rounded up to 16) */
+#define MF_OFFZ 144                 /* ... index of tap 0 in the zero-padded tap string (>= 16 FL + 14 + 15 for FL <= 8) */
+#define MF_TZB  544                 /* ... bytes of one copy of it: MF_OFFZ + 64 k-blocks' worth for order 255 (5 at FL <= 4) + a lane's reach */
 struct SmallF {
     union {
         int32_t  coefq[FIR_PAD + 8];          /* FIR_MAD24 / FIR_WIDE: taps, front padded with zeros to a multiple of four */
         uint32_t cpack[2][FIR_PAD + 4];       /* FIR_DOT: per group of four taps the four coefficient words of the low plane
                                                * ([0]: int16 pairs) and of the high plane ([1]: int8 quads), then the closing words */
+        uint8_t  tz[4][MF_TZB];               /* FIR_MFMA: the zero-padded tap string, four copies shifted by 0..3 bytes (see mfma_fir) */
     };
     uint32_t level_bits[16];
     uint8_t  ktab[2048];
@@ -2038,6 +2044,17 @@ __device__ __forceinline__ uint32_t mad24(int32_t a, int32_t b, uint32_t acc)
  *           packs the planes and then skips the high pass.  A thread's four outputs of a chunk lie at the four byte phases of the
  *           packed words, so the TAPS are packed in four phases (even / odd for the low plane) and the sample words are used as they
  *           lie; a tap pair that straddles two groups of four taps is closed by one more word after the loop.
+ * FIR_MFMA  (round 5; blocks of at most 4096 samples, input of at most 18 bits): the FIR as a Toeplitz product on the MATRIX pipe
+ *           (v_mfma_i32_16x16x64_i8), which is otherwise idle and issues beside the VALU.  The signal is split into signed byte
+ *           digits x = s0 + 256 s1 + 65536 x2 (s0, s1 in [-128, 127]; x2 = 0 wherever x + 128 stays within 16 bits) kept as three
+ *           byte planes; sum c x = sum c s0 + 2^8 sum c s1 + 2^16 sum c x2 modulo 2^32, every partial sum exact in the
+ *           accumulators (|sum| <= 64 * 128 * 128 * k-blocks).  One product gives 16 x 16 outputs: column cc = the 64-byte window of
+ *           the plane that starts 16 FL cc samples into the wavefront's run (minus the order rounded up to 16: 16-byte aligned
+ *           loads, conflict free), row 4 g + i = output 4 FL g + 4 T + i of that window for tile T -- so that lane 16 g + cc ends up
+ *           with chunk T of thread 4 cc + g: ONE fixed lane permutation (ds_bpermute) returns every chunk to its owner.  The tap
+ *           matrix of a lane is 16 consecutive bytes of the zero-padded tap string at a byte offset that depends on the lane's row;
+ *           four copies of the string shifted by 0..3 bytes make it four aligned words.  mfma_fir() below; tools/probes has the
+ *           operand-layout probe and the numpy model the index arithmetic was checked with.
  * FIR_MAD24 (what FIR_DOT replaced; -DSRLA_FIR_MAD24): one v_mad_i32_i24 per tap and sample on int32 words.
  * FIR_WIDE  samples beyond 24 bits (24-bit input: M/S, pre-emphasis and the LTP widen it to 28): every tap multiplies
  *           the two 16-bit halves of the sample separately on the 24-bit multiplier (x c = (x >> 16) c 2^16 + (x & 0xffff) c
@@ -2045,6 +2062,7 @@ __device__ __forceinline__ uint32_t mad24(int32_t a, int32_t b, uint32_t acc)
 #define FIR_MAD24 0
 #define FIR_WIDE  1
 #define FIR_DOT   2
+#define FIR_MFMA  3
 #ifdef SRLA_FIR_MAD24
 #define SRLA_FIR_NARROW FIR_MAD24
 #else
@@ -2112,7 +2130,10 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
     constexpr int PADS = ((PADMIN + S - 1) / S) * S;            /* front padding, a multiple of S: covers the FIR's reach back and the LTP's */
     constexpr int PADW = (CH & 1) ? 0 : 4;                      /* see sig_index */
     constexpr uint32_t SIG_WORDS = (uint32_t)((PADS + 1024 * FL) / S) * (S + PADW) + 8;
-    constexpr bool WIDE = MODE == FIR_WIDE, DOT = MODE == FIR_DOT;
+    constexpr bool WIDE = MODE == FIR_WIDE, MF = MODE == FIR_MFMA, DOT = MODE == FIR_DOT || MF;   /* (DOT: the signal lives as planes; MF: byte planes) */
+    constexpr uint32_t MF_PLS = MF_PADB + 1024u * FL;            /* bytes of one byte plane */
+    static_assert(!MF || (LG == 0 && FL <= 4), "FIR_MFMA: one item per workgroup, blocks of at most 4096 samples");
+    static_assert(!MF || 3u * MF_PLS <= fast_sig_bytes(FL, LG, true), "the byte planes fit where the int16 / int8 planes would lie");
     /* FIR_DOT: the two planes lie over the int32 signal (which then only the LTP uses, before them): PADF zeros + the block, in
      * the same padded element order as the int32 layout */
     constexpr int PADF = ((FIR_PAD + S - 1) / S) * S;
@@ -2152,7 +2173,33 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
      * behind the sample loads and ahead of everything that waits for them, so that their round trip to the item record (which
      * has to wait for the order) runs beside the samples' instead of standing between the planes and the barrier below */
     uint32_t ctap[7] = { 0, 0, 0, 0, 0, 0, 0 };
-    if constexpr (DOT) {
+    /* FIR_MFMA: the words of the four shifted copies of the zero-padded tap string this thread will store (wavefront s builds copy s,
+     * words lane, lane + 64, lane + 128; byte m of copy s = tap m - s - MF_OFFZ) */
+    constexpr int TZR = MF ? 3 : 1;                       /* up to 136 words per copy */
+    static_assert(!MF || T == 4 * WAVE, "one wavefront per copy");
+    uint32_t tzw[TZR] = { 0 };
+    const uint32_t mf_p2 = (order + 15u) & ~15u;          /* the order rounded up to 16: how far in front of a window the loads start */
+    const uint32_t mf_nkb = MF ? (uint32_t)__builtin_amdgcn_readfirstlane((16u * FL - 1u + mf_p2 + 63u) >> 6) : 0u;   /* k-blocks of 64 */
+    const uint32_t mf_ndw = (MF_OFFZ + 64u * mf_nkb + 16u) >> 2;   /* words of a copy that are read */
+    if constexpr (MF) {
+#pragma unroll
+        for (int r = 0; r < TZR; r++) {
+            const uint32_t sft = wave, dw = lane + 64u * (uint32_t)r;
+            if (dw < mf_ndw) {
+                /* bytes k0 .. k0 + 3 of the tap array (zero outside [0, order)): two aligned words of it -- the taps are a few dozen
+                 * bytes in one or two cache lines, whatever the lane -- funnel-shifted by the copy's shift, then masked */
+                const int k0 = (int)(4u * dw) - (int)sft - MF_OFFZ;
+                const int q0 = k0 >> 2, nq = (int)((order + 3u) >> 2);
+                const uint32_t *cw = reinterpret_cast<const uint32_t *>(out->lpc_coef);
+                const uint32_t lo = (q0 >= 0 && q0 < nq) ? cw[q0] : 0u, hi = (q0 + 1 >= 0 && q0 + 1 < nq) ? cw[q0 + 1] : 0u;
+                const uint32_t w = __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)(k0 & 3));
+                const int first = (k0 < 0) ? -k0 : 0, last = ((int)order - k0 < 4) ? (int)order - k0 : 4;     /* valid bytes [first, last) */
+                uint32_t mask = 0;
+                if (last > first && first < 4) mask = (0xFFFFFFFFu >> (8 * (4 - last))) & (0xFFFFFFFFu << (8 * first));
+                tzw[r] = w & mask;
+            }
+        }
+    } else if constexpr (DOT) {
         if (tid <= (o4 >> 2)) {
             const int b = 4 * (int)tid;
 #pragma unroll
@@ -2183,6 +2230,55 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
         *reinterpret_cast<int4 *>(sig + sig_index<CH>(PADS + (int)s_base + 4 * c)) = make_int4(y[4 * c], y[4 * c + 1], y[4 * c + 2], y[4 * c + 3]);
     /* FIR_DOT: the block as two planes, x = 2^16 h + l (the wavefront notes whether any of its h is not zero) */
     auto publish_planes = [&]() {
+        if constexpr (MF) {
+            /* signed byte digits: s0 = the low byte, x1 = (x + 128) >> 8 = s1 + 256 x2; as BYTES: plane 0 = x & 0xff, plane 1 = byte 1 of
+             * t = x + 128, plane 2 = x2 = (t + 32768) >> 16 -- zero unless t leaves 16 bits, which the wavefront notes */
+            int32_t t[S];
+            uint32_t high_any = 0;
+#pragma unroll
+            for (int i = 0; i < S; i++) { t[i] = y[i] + 128; high_any |= (uint32_t)((t[i] + 32768) >> 16); }
+            const bool wave_high = __any((int)(high_any != 0));
+            uint32_t w0[CH], w1[CH], w2[CH];
+#pragma unroll
+            for (int c = 0; c < CH; c++) {
+                /* one byte permute gives both planes' bytes of two samples: [t0.b0, t1.b0, t0.b1, t1.b1]; byte 0 of t is the low byte of x
+                 * with its top bit flipped (x + 128): one XOR per word puts it back */
+                const uint32_t q01 = __builtin_amdgcn_perm((uint32_t)t[4 * c + 1], (uint32_t)t[4 * c + 0], 0x05010400u);
+                const uint32_t q23 = __builtin_amdgcn_perm((uint32_t)t[4 * c + 3], (uint32_t)t[4 * c + 2], 0x05010400u);
+                w0[c] = __builtin_amdgcn_perm(q23, q01, 0x05040100u) ^ 0x80808080u;
+                w1[c] = __builtin_amdgcn_perm(q23, q01, 0x07060302u);
+                uint32_t hw = 0;
+                if (wave_high) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) hw |= ((uint32_t)((t[4 * c + i] + 32768) >> 16) & 0xFFu) << (8 * i);
+                }
+                w2[c] = hw;
+            }
+            unsigned char *p0 = lds + MF_PADB + s_base;
+            if constexpr (CH == 4) {
+                *reinterpret_cast<uint4 *>(p0) = make_uint4(w0[0], w0[1], w0[2], w0[3]);
+                *reinterpret_cast<uint4 *>(p0 + MF_PLS) = make_uint4(w1[0], w1[1], w1[2], w1[3]);
+                *reinterpret_cast<uint4 *>(p0 + 2 * MF_PLS) = make_uint4(w2[0], w2[1], w2[2], w2[3]);
+            } else if constexpr (CH == 2) {
+                *reinterpret_cast<uint2 *>(p0) = make_uint2(w0[0], w0[1]);
+                *reinterpret_cast<uint2 *>(p0 + MF_PLS) = make_uint2(w1[0], w1[1]);
+                *reinterpret_cast<uint2 *>(p0 + 2 * MF_PLS) = make_uint2(w2[0], w2[1]);
+            } else {
+#pragma unroll
+                for (int c = 0; c < CH; c++) {
+                    reinterpret_cast<uint32_t *>(p0)[c] = w0[c];
+                    reinterpret_cast<uint32_t *>(p0 + MF_PLS)[c] = w1[c];
+                    reinterpret_cast<uint32_t *>(p0 + 2 * MF_PLS)[c] = w2[c];
+                }
+            }
+            if (lane == 0) {
+                sm->wave_high[wave] = wave_high ? 1u : 0u;
+                if (WPI < NWAVES && wave == 0) for (int w = WPI; w < NWAVES; w++) sm->wave_high[w] = 0u;
+            }
+            /* front padding: zero samples */
+            for (uint32_t i = tid; i < 3u * (MF_PADB / 4); i += T) reinterpret_cast<uint32_t *>(lds + (i / (MF_PADB / 4)) * MF_PLS)[i % (MF_PADB / 4)] = 0;
+            return;
+        }
         uint32_t hq[S], high_any = 0;
 #pragma unroll
         for (int i = 0; i < S; i++) { hq[i] = (uint32_t)((y[i] + 0x8000) >> 16); high_any |= hq[i]; }
@@ -2211,7 +2307,13 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
         PUBLISH_Y();
         for (uint32_t i = tid; i < (uint32_t)(PADS / S) * (S + PADW); i += T) sig[i] = 0;    /* front padding */
     }
-    if constexpr (DOT) {
+    if constexpr (MF) {
+#pragma unroll
+        for (int r = 0; r < TZR; r++) {
+            const uint32_t dw = lane + 64u * (uint32_t)r;
+            if (dw < mf_ndw) reinterpret_cast<uint32_t *>(sm->tz[wave])[dw] = tzw[r];
+        }
+    } else if constexpr (DOT) {
         /* tap k of the zero-padded, reversed filter (k outside [0, o4): zero): ctap[3 + d] = tap 4 tid + d, fetched at the top */
         static_assert(FIR_PAD / 4 < T, "one group of four taps per thread");
         if (tid <= (o4 >> 2)) {
@@ -2287,7 +2389,66 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
 #pragma unroll
         for (int i = 0; i < S; i++) acc[i] = (uint32_t)half;
         int32_t yprev = 0;
-        if constexpr (DOT) {
+        if constexpr (MF) {
+            typedef int mf_v4i __attribute__((ext_vector_type(4)));
+            const uint32_t cc = lane & 15u, gk = lane >> 4;             /* column / row of the lane's operands, its k-group */
+            const uint32_t dpad = mf_p2 - order;
+            /* B: 16 bytes of a plane, 16-byte aligned (MF_PADB, the wavefront's base and the rounded order are multiples of 16) */
+            const unsigned char *bp = lds + MF_PADB + (uint32_t)(64 * S) * wave + 16u * FL * cc - mf_p2 + 16u * gk;
+            /* A: 16 bytes of the tap string from tap index 16 gk - 4 FL (cc >> 2) - (cc & 3) - dpad (+ 64 kb - 4 T): the copy shifted by
+             * sft makes that a word address */
+            const uint32_t sft = ((cc & 3u) + dpad) & 3u;
+            const uint32_t *az = reinterpret_cast<const uint32_t *>(sm->tz[sft]) + ((MF_OFFZ + 16u * gk - 4u * FL * (cc >> 2) - (cc & 3u) - dpad + sft) >> 2);
+            const uint4 wh = *reinterpret_cast<const uint4 *>(sm->wave_high);
+            const bool high = __builtin_amdgcn_readfirstlane(wh.x | wh.y | wh.z | wh.w) != 0;
+            mf_v4i a0[FL], a1[FL];
+#pragma unroll
+            for (int t = 0; t < FL; t++) { a0[t] = (mf_v4i){ half, half, half, half }; a1[t] = (mf_v4i){ 0, 0, 0, 0 }; }
+            for (uint32_t kb = 0; kb < mf_nkb; kb++) {
+                const mf_v4i b0 = *reinterpret_cast<const mf_v4i *>(bp + 64u * kb);
+                const mf_v4i b1 = *reinterpret_cast<const mf_v4i *>(bp + MF_PLS + 64u * kb);
+#pragma unroll
+                for (int t = 0; t < FL; t++) {
+                    const uint32_t *ap = az + 16u * kb - (uint32_t)t;
+                    const mf_v4i a = (mf_v4i){ (int)ap[0], (int)ap[1], (int)ap[2], (int)ap[3] };
+                    a0[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b0, a0[t], 0, 0, 0);
+                    a1[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b1, a1[t], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < FL; t++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) a0[t][i] = (int)((uint32_t)a0[t][i] + ((uint32_t)a1[t][i] << 8));
+            if (high) {
+                /* the third digit, where a sample left 16 bits (full-scale input): one more pass */
+#pragma unroll
+                for (int t = 0; t < FL; t++) a1[t] = (mf_v4i){ 0, 0, 0, 0 };
+                for (uint32_t kb = 0; kb < mf_nkb; kb++) {
+                    const mf_v4i b2 = *reinterpret_cast<const mf_v4i *>(bp + 2 * MF_PLS + 64u * kb);
+#pragma unroll
+                    for (int t = 0; t < FL; t++) {
+                        const uint32_t *ap = az + 16u * kb - (uint32_t)t;
+                        const mf_v4i a = (mf_v4i){ (int)ap[0], (int)ap[1], (int)ap[2], (int)ap[3] };
+                        a1[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b2, a1[t], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < FL; t++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) a0[t][i] = (int)((uint32_t)a0[t][i] + ((uint32_t)a1[t][i] << 16));
+            }
+            /* lane 16 g + cc holds chunk t of thread 4 cc + g: every thread fetches its own from lane 16 (lane & 3) + (lane >> 2) */
+            const int from = (int)(4u * (16u * (lane & 3u) + (lane >> 2)));
+#pragma unroll
+            for (int t = 0; t < FL; t++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) acc[4 * t + i] = (uint32_t)__builtin_amdgcn_ds_bpermute(from, a0[t][i]);
+            if (tid != 0 && s_base < order) {
+                const unsigned char *pe = lds + MF_PADB + s_base - 1u;
+                yprev = (int32_t)*reinterpret_cast<const int8_t *>(pe) + 256 * (int32_t)*reinterpret_cast<const int8_t *>(pe + MF_PLS)
+                      + 65536 * (int32_t)*reinterpret_cast<const int8_t *>(pe + 2 * MF_PLS);
+            }
+        } else if constexpr (DOT) {
             const int ng = (int)__builtin_amdgcn_readfirstlane(o4 >> 2);          /* groups of four taps */
             const uint2 *lgrp = reinterpret_cast<const uint2 *>(lds);               /* low plane: a group = four int16 */
             const uint32_t *hgrp = reinterpret_cast<const uint32_t *>(lds + HIGH_OFF);   /* high plane: a group = four int8 */
@@ -2848,13 +3009,13 @@ __device__ __forceinline__ void rice_search_finish(const uint32_t *u, const Srla
     }
 }
 
-template <int R>
 #ifndef SRLA_RC_WAVES
 #define SRLA_RC_WAVES 5       /* wavefronts per SIMD the forms for blocks of at most 4096 samples are compiled for (92 registers) */
 #endif
 #ifndef SRLA_RC4_WAVES
 #define SRLA_RC4_WAVES 3      /* wavefronts per SIMD the 8192-sample form is compiled for: 168 registers and 17 spilled dwords per lane; 2 (228 registers, no spills) was 9 % slower at -B 8192 -V 2 -P 3, profiles/r04/ab_residual_cost_split.txt */
 #endif
+template <int R, bool MFMA = false /* blocks of at most 4096 samples, narrow input: the FIR on the matrix pipe (FIR_MFMA) */>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(R >= 4 ? SRLA_RC4_WAVES : SRLA_RC_WAVES, 8))) void srla_residual_cost(
     SrlaJobParams jp, const int32_t *__restrict__ input, const SrlaItemDesc *__restrict__ items,
     const SrlaGeom *__restrict__ geoms, SrlaLdsPlan plan, const double *__restrict__ rice_thresholds,
@@ -2902,7 +3063,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(R >= 4 ? SRL
             SrlaItemResult *outf = &results[block];
 #define FAST(FLV)                                                                                                   \
             do {                                                                                                    \
-                if (jp.bits_per_sample <= 18) residual_cost_fast<FLV, SRLA_FIR_NARROW>(jp, iv, inf, itf, lds, rice_thresholds, res_ws, outf); \
+                if (jp.bits_per_sample <= 18) residual_cost_fast<FLV, (MFMA && FLV <= 4) ? FIR_MFMA : SRLA_FIR_NARROW>(jp, iv, inf, itf, lds, rice_thresholds, res_ws, outf); \
                 else residual_cost_fast<FLV, FIR_WIDE>(jp, iv, inf, itf, lds, rice_thresholds, res_ws, outf);       \
                 return;                                                                                             \
             } while (0)
@@ -4854,16 +5015,18 @@ extern "C" int srla_launch_residual_cost(hipStream_t stream, int rclass, const S
 {
     if (jp->num_items == 0) return 0;
     dim3 grid(8u * ((jp->num_items + 7u) >> 3)), block(NT);
-#define LAUNCH(RR)                                                                                           \
+#define LAUNCH(RR, MM)                                                                                       \
     do {                                                                                                     \
-        SET_LDS_ATTR(srla_residual_cost<RR>);                                                                \
-        hipExtLaunchKernelGGL(srla_residual_cost<RR>, grid, block, plan->total, stream, ev_start, ev_stop, 0, *jp, input, items, geoms, \
+        SET_LDS_ATTR((srla_residual_cost<RR, MM>));                                                          \
+        hipExtLaunchKernelGGL((srla_residual_cost<RR, MM>), grid, block, plan->total, stream, ev_start, ev_stop, 0, *jp, input, items, geoms, \
                            *plan, rice_thresholds, res_ws, results);                                         \
     } while (0)
+    /* SRLA_MI355X_FIR_MFMA: the FIR of blocks of at most 4096 samples on the matrix pipe */
+    const bool mf = g_tune.fir_mfma != 0u;
     switch (rclass) {
-    case 1: LAUNCH(1); break;
-    case 2: LAUNCH(2); break;
-    case 4: LAUNCH(4); break;
+    case 1: if (mf) LAUNCH(1, true); else LAUNCH(1, false); break;
+    case 2: if (mf) LAUNCH(2, true); else LAUNCH(2, false); break;
+    case 4: LAUNCH(4, false); break;
     default: return -1;
     }
 #undef LAUNCH
