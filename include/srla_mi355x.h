@@ -255,6 +255,13 @@ struct SRLAMI355XStats {
                                                     * samples, encoded once more when a later call is about to read the buffer); what stays
                                                     * unknown are words a stream's kept windows did not rewrite and the buffer after a call
                                                     * that failed.  Counted where it happens. */
+#define SRLAMI355X_NONIDENTICAL_SEARCH_BEYOND_PARAMETERS 8u  /* a block division search on an encoder CREATED for a larger maximum block than its
+                                                             * parameters name: the reference's search runs up to the configuration's maximum
+                                                             * (srla_encoder.c:598, :1669; SetEncodeParameter updates the minimum and the look-ahead
+                                                             * only, :745-746), SRLAEncoder_ComputeBlockSize refuses the candidates beyond the
+                                                             * parameters' (:1499) and SRLAEncoder_EncodeWhole returns SRLA_APIRESULT_NG -- in every
+                                                             * case tried.  This library searches within the parameters and succeeds: valid and
+                                                             * lossless bytes where the reference has none.  Counted per call. */
 /* The reasons for which a stream of `num_samples` samples per channel encoded under the handle's current parameters would not be
  * guaranteed bit-identical to the reference (0: it is); num_samples = 0 asks about the parameters alone. */
 uint32_t SRLAMI355X_NonIdenticalReasons(struct SRLAEncoder *encoder, uint32_t num_samples);

@@ -835,7 +835,9 @@ uint32_t Impl::nonidentical_reasons(uint32_t num_samples) const
     const bool search = search_enabled();
     /* (SVR refinement together with history-dependent blocks: modelled -- the refinement's residual is one more writer of the
      * reference's buffer in chain / history mode, host_chain.cpp.  The one exception is counted where it happens: arbitrate_svr) */
-    (void)search; (void)num_samples;
+    (void)num_samples;
+    /* the reference's search takes its maximum from the configuration and then fails on the candidates beyond the parameters' */
+    if (search && cfg.max_num_samples_per_block > par.max_num_samples_per_block) r |= SRLAMI355X_NONIDENTICAL_SEARCH_BEYOND_PARAMETERS;
     if (par.ltp_order > 0) {
         /* lpcc->buffer holds RoundUp2Powered(config max block) doubles (lpc.c:211): at most 256 of them => the 263 lags of
          * lpc.c:371-373 end in the transform's scratch buffer behind it */
@@ -873,6 +875,13 @@ std::string Impl::nonidentical_text(uint32_t r)
              "handle left there and that the library does not know: the last two windows of the stream before did not rewrite it (a "
              "stream that ends in digital silence, a call that failed) -- a fresh handle per stream (what the `srla` tool does) keeps the "
              "output bit-identical";
+    }
+    if (r & SRLAMI355X_NONIDENTICAL_SEARCH_BEYOND_PARAMETERS) {
+        if (!t.empty()) t += "; ";
+        t += "a block division search on an encoder created for a larger maximum block than its parameters name: the reference searches up "
+             "to the CONFIGURATION's maximum (srla_encoder.c:598, :1669), refuses those candidates (:1499) and returns SRLA_APIRESULT_NG; "
+             "this library searches within the parameters and succeeds -- create the encoder with the parameters' maximum block and the "
+             "output is the reference's";
     }
     if (r & SRLAMI355X_NONIDENTICAL_LTP_TINY_BUFFER) {
         if (!t.empty()) t += "; ";

@@ -108,11 +108,21 @@ UNKNOWN_WORDS = (dict(preset=4, max_block=4096, divisions=1), [
     dict(api="whole", input=_inp(VARIED, 442, 2047)), dict(api="whole", input=_inp(VARIED, 443, 1001))])
 
 
+# The same on a handle that has run NOTHING before (round 5, the advisor's case): the first window audible, the second silent, a third
+# of 100 samples -- a regular call of several windows, which leaves a capture and no tracked buffer -- and then an odd clip that
+# reads beyond what the kept windows rewrote.  The handle's buffer is not the fresh handle's zeros any more; the library must say so.
+UNKNOWN_WORDS_FRESH = (dict(preset=4, max_block=4096, divisions=1), [
+    dict(api="whole", input=_inp(MUSIC, 446, 2 * 16384 + 100, zero_mid=(16384, 2 * 16384))),
+    dict(api="whole", input=_inp(VARIED, 443, 1001))])
+COUNTED = {"unknown_words": UNKNOWN_WORDS, "unknown_words_fresh_handle": UNKNOWN_WORDS_FRESH}
+
+
 def make_input(sp):
     sp = dict(sp)
     same = sp.pop("same", False)
     zero_from = sp.pop("zero_from", None)
     zero_to = sp.pop("zero_to", None)
+    zero_mid = sp.pop("zero_mid", None)
     rshift = sp.pop("rshift", None)
     if same:                                   # identical channels: S = R - L is all zero
         one = dict(sp, nch=1)
@@ -126,6 +136,8 @@ def make_input(sp):
         a[:, zero_from:] = 0
     if zero_to is not None:                    # ... up to there
         a[:, :zero_to] = 0
+    if zero_mid is not None:                   # ... in between
+        a[:, zero_mid[0]:zero_mid[1]] = 0
     return a
 
 

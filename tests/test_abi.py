@@ -107,6 +107,31 @@ def test_set_parameter_validation(product):
     product.destroy(enc)
 
 
+def test_a_search_beyond_the_parameters_is_named_not_silent(product):
+    """An encoder CREATED for a larger maximum block than its parameters name: the reference's block division search runs up to the
+    configuration's maximum and SRLAEncoder_EncodeWhole returns SRLA_APIRESULT_NG (srla_encoder.c:598, :1499, :1669); this library
+    searches within the parameters and succeeds, so the call is named and counted -- from the parameters alone, no GPU."""
+    product.lib.SRLAMI355X_NonIdenticalReasons.argtypes = [C.c_void_p, C.c_uint32]
+    product.lib.SRLAMI355X_NonIdenticalReasons.restype = C.c_uint32
+    beyond = 8
+    big = capi.SRLAEncoderConfig(8, 2048, 8192, 32768, 255)
+    _, par = capi.cli_setup(2, 16, 48000, preset=4, max_block=4096, divisions=1)
+    enc = product.create(big)
+    assert product.set_parameter(enc, par) == capi.OK
+    assert product.lib.SRLAMI355X_NonIdenticalReasons(enc, 100000) & beyond
+    # without a block division search (-V 0) the reference never looks at the configuration's maximum: nothing to name
+    _, flat = capi.cli_setup(2, 16, 48000, preset=4, max_block=4096, divisions=0)
+    assert product.set_parameter(enc, flat) == capi.OK
+    assert product.lib.SRLAMI355X_NonIdenticalReasons(enc, 100000) & beyond == 0
+    product.destroy(enc)
+    # the `srla` tool's way -- configuration and parameters from the same flags -- is never concerned
+    cfg, par = capi.cli_setup(2, 16, 48000, preset=4, max_block=4096, divisions=1)
+    enc = product.create(cfg)
+    assert product.set_parameter(enc, par) == capi.OK
+    assert product.lib.SRLAMI355X_NonIdenticalReasons(enc, 100000) == 0
+    product.destroy(enc)
+
+
 def test_argument_errors_of_the_encode_calls(product):
     cfg, par = capi.cli_setup(2, 16, 48000, preset=4, max_block=4096, divisions=1)
     enc = product.create(cfg)

@@ -529,14 +529,22 @@ def test_pinned_input_planes_are_read_by_dma(product):
     assert np.array_equal(helpers.oracle_decode(got), pcm)
 
 
-def test_random_configurations_match_the_oracle(product):
-    """A slice of tools/gpu_sweep.py: random channel counts, bit depths, presets, block sizes, division depths,
-    look-ahead factors, LTP orders, lengths and signal kinds; bytes must equal the oracle's."""
+@pytest.mark.parametrize("count,seed,options,least", [
+    (170, 3, dict(), 110),                                                        # plain draws
+    (170, 71, dict(with_mutations=True, with_paths=True), 110),                   # mutated inputs, every way into the library
+    (600, 72, dict(with_mutations=True, only_history=True), 110),                 # the history / chain-mode regimes only
+])
+def test_random_configurations_match_the_oracle(product, count, seed, options, least):
+    """tools/gpu_sweep.py over three seeds (more than 300 compared streams in all): random channel counts, bit depths, presets,
+    block sizes (odd ones, explicit minimum / maximum / look-ahead triples), division depths, look-ahead factors, LTP orders,
+    lengths and signal kinds; with `--mutate` (spliced silence, full-scale bursts, identical channels ...), `--paths` (pageable,
+    pinned, device-resident input, block-by-block calls) and `--history` (only the regimes whose blocks depend on the handle's
+    history) draws; bytes must equal the oracle's."""
     import sys
     sys.path.insert(0, os.path.join(helpers.ROOT, "tools"))
     import gpu_sweep
-    done, bad = gpu_sweep.sweep(60, 3, max_samples=1_500_000)
-    assert done >= 40 and bad == 0
+    done, bad = gpu_sweep.sweep(count, seed, max_samples=1_500_000, **options)
+    assert done >= least and bad == 0
 
 
 @pytest.mark.parametrize("pinned", [False, True])

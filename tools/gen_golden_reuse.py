@@ -43,7 +43,7 @@ def fresh(cli, steps):
 def main():
     assert helpers.have_reference(), "needs the compiled reference (oracle/_ref)"
     out = {}
-    for name, (cli, steps) in list(reuse.SEQUENCES.items()) + [("unknown_words", reuse.UNKNOWN_WORDS)]:
+    for name, (cli, steps) in list(reuse.SEQUENCES.items()) + list(reuse.COUNTED.items()):
         got = fresh(cli, steps)
         # the same call alone on a fresh handle, under the parameters in force at that point
         cur = {k: v for k, v in cli.items() if k != "config"}
