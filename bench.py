@@ -168,11 +168,11 @@ def cpu_baseline(pcm, cli, seconds, rate, bps=16):
 # command (profiles/pmc_summary.json[config]): a stage is priced with the kernels that ran, never with a list kept by hand.
 # tests/test_bench_stages.py fails when a kernel of the library or of a committed profile belongs to no stage.
 STAGES = (
-    ("srla_stage_in",      None,          True,  ("srla_widen16", "srla_deinterleave", "srla_make_variants", "srla_or_reduce", "srla_mask_to_shift", "srla_chain_commit",
+    ("srla_stage_in",      None,          True,  ("srla_widen16", "srla_deinterleave", "srla_or_reduce", "srla_mask_to_shift", "srla_chain_commit",
                                                   "__amd_rocclr_fillBuffer")),
-    ("srla_autocorr",      "autocorr_ms", True,  ("srla_autocorr<", "srla_autocorr_big", "srla_autocorr_w", "srla_autocorr_pair")),
+    ("srla_autocorr",      "autocorr_ms", True,  ("srla_autocorr<", "srla_autocorr_big", "srla_autocorr_pair")),
     ("srla_pitch_solve",   "pitch_ms",    True,  ("srla_pitch_solve",)),
-    ("srla_lpc_solve",     "solve_ms",    True,  ("srla_lpc_errvars", "srla_order_select", "srla_lpc_taps", "srla_lpc_solve_regs", "srla_lpc_recursion",
+    ("srla_lpc_solve",     "solve_ms",    True,  ("srla_lpc_errvars", "srla_order_select", "srla_lpc_taps", "srla_lpc_recursion",
                                                   "srla_lpc_quantize", "srla_svr_refine")),
     ("srla_residual_cost", "residual_ms", False, ("srla_residual_cost<", "srla_residual_cost_big")),
     ("srla_price_windows", "price_ms",    True,  ("srla_price_windows",)),
@@ -242,7 +242,7 @@ def autocorr_item_flops(n, num_lags):
     6 per sample), forward complex transform of nfft/2 points (fft.c:71-136: a radix-4 butterfly is 8 complex additions and 3
     complex multiplications = 34, the closing radix-2 stage 4 per pair), the real-transform symmetry pass + |X|^2 + the inverse
     symmetry pass (fft.c:147-198, lpc.c:357-365: 46 per bin pair), the inverse transform pruned to the outputs that reach the
-    first ceil(lags / 2) complex results (srla_amd/csrc/kernels.hip: fft_regions), one multiplication per lag."""
+    first ceil(lags / 2) complex results (srla_amd/csrc/autocorr.hip: fft_regions), one multiplication per lag."""
     nfft = max(2, next_pow2(n))
     m = nfft // 2
     need = (min(num_lags, nfft) + 1) // 2

@@ -90,15 +90,9 @@ __device__ __forceinline__ uint32_t xcd_position(uint32_t b, uint32_t count)
     return (b & 7u) * chunk + (b >> 3);
 }
 
-/* what the sample loaders need from the job parameters (kept in registers; the by-value kernel argument
- * is never modified).  vstride != 0: the job's variant planes (SrlaJobParams::var16 / var32) are read instead of the channel planes;
- * `base` is then the kernel's input pointer, so that a pointer into the channel planes gives the sample's offset. */
+/* what the sample loaders need from the job parameters (kept in registers; the by-value kernel argument is never modified) */
 struct InputView {
     uint32_t nch, stride, sh;
-    uint32_t vstride;
-    const int16_t *v16;
-    const int32_t *v32;
-    const int32_t *base;
 };
 __device__ __forceinline__ InputView input_view(const SrlaJobParams &jp, uint32_t item_lshift)
 {
@@ -106,28 +100,14 @@ __device__ __forceinline__ InputView input_view(const SrlaJobParams &jp, uint32_
     v.nch = jp.num_channels;
     v.stride = jp.channel_stride;
     v.sh = jp.lshift_dev ? *jp.lshift_dev : item_lshift;
-    v.vstride = 0; v.v16 = nullptr; v.v32 = nullptr; v.base = nullptr;
     return v;
 }
-/* the same for the kernels that read the variant planes when the job has them */
-__device__ __forceinline__ InputView input_view(const SrlaJobParams &jp, uint32_t item_lshift, const int32_t *input)
-{
-    InputView v = input_view(jp, item_lshift);
-    v.vstride = (jp.var_stride != 0u && (jp.var_flag == nullptr || *jp.var_flag == 0u)) ? jp.var_stride : 0u;
-    v.v16 = jp.var16; v.v32 = jp.var32; v.base = input;
-    return v;
-}
+__device__ __forceinline__ InputView input_view(const SrlaJobParams &jp, uint32_t item_lshift, const int32_t *) { return input_view(jp, item_lshift); }
 
 /* variant sample i of the job input (srla_encoder.c:1229-1253, srla_utility.c:91-103) */
 __device__ __forceinline__ int32_t load_variant(const int32_t *__restrict__ in, const InputView &jp,
                                                 uint32_t variant, uint32_t idx)
 {
-    if (jp.vstride) {
-        const size_t o = (size_t)(in - jp.base) + idx;
-        if (jp.v16 == nullptr) return jp.v32[(size_t)variant * jp.vstride + o];
-        if (variant == jp.nch + 1) return jp.v32[o];
-        return (int32_t)jp.v16[(size_t)variant * jp.vstride + o];
-    }
     const uint32_t sh = jp.sh;
     if (variant < jp.nch) return in[(size_t)variant * jp.stride + idx] >> sh;
     const int32_t l = in[idx] >> sh;
@@ -137,22 +117,11 @@ __device__ __forceinline__ int32_t load_variant(const int32_t *__restrict__ in, 
     return (int32_t)((uint32_t)l + (uint32_t)(s >> 1));
 }
 
-/* four consecutive variant samples starting at i4 (zeros beyond n); 16-byte loads when possible (8-byte ones from an int16 plane) */
+/* four consecutive variant samples starting at i4 (zeros beyond n); 16-byte loads when possible */
 __device__ __forceinline__ void load_chunk(const int32_t *__restrict__ in, const InputView &jp, uint32_t variant,
                                            uint32_t i4, uint32_t n, bool aligned, int32_t out[4])
 {
     if (aligned && i4 + 4 <= n) {
-        if (jp.vstride) {
-            const size_t o = (size_t)(in - jp.base) + i4;
-            if (jp.v16 != nullptr && variant != jp.nch + 1) {
-                const short4 a = *reinterpret_cast<const short4 *>(jp.v16 + (size_t)variant * jp.vstride + o);
-                out[0] = a.x; out[1] = a.y; out[2] = a.z; out[3] = a.w;
-            } else {
-                const int4 a = *reinterpret_cast<const int4 *>(jp.v32 + ((jp.v16 != nullptr) ? (size_t)0 : (size_t)variant * jp.vstride) + o);
-                out[0] = a.x; out[1] = a.y; out[2] = a.z; out[3] = a.w;
-            }
-            return;
-        }
         const uint32_t sh = jp.sh;
         if (variant < jp.nch) {
             const int4 a = *reinterpret_cast<const int4 *>(in + (size_t)variant * jp.stride + i4);
@@ -176,9 +145,6 @@ __device__ __forceinline__ void load_chunk(const int32_t *__restrict__ in, const
 
 __device__ __forceinline__ bool input_aligned(const int32_t *in, const InputView &jp)
 {
-    /* (variant planes: allocated 256-byte aligned with a stride that is a multiple of 16 samples, so a chunk is aligned when its
-     * sample offset is a multiple of four) */
-    if (jp.vstride) return (((size_t)(in - jp.base)) & 3u) == 0;
     return ((reinterpret_cast<uintptr_t>(in) & 15u) == 0) && ((jp.stride & 3u) == 0);
 }
 

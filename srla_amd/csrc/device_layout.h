@@ -198,13 +198,6 @@ typedef struct SrlaBlockRecord {
                              * than two channels the reference prices only the first two (srla_encoder.c:1287-1301, :1519-1532) */
 } SrlaBlockRecord;          /* 64 bytes */
 
-/* segments of a job for srla_make_variants (by value: no table upload) */
-#define SRLA_VAR_SEGS 12
-typedef struct SrlaVarSegs {
-    uint32_t count;
-    uint32_t base[SRLA_VAR_SEGS], ns[SRLA_VAR_SEGS], sh[SRLA_VAR_SEGS];
-} SrlaVarSegs;
-
 typedef struct SrlaJobParams {
     uint32_t num_channels;
     uint32_t bits_per_sample;
@@ -228,19 +221,6 @@ typedef struct SrlaJobParams {
     uint32_t rc_lo, rc_hi;    /* srla_residual_cost: when rc_hi != 0 the launch takes the items with rc_lo < n <= rc_hi only (a job with blocks
                                * above 4096 samples is analysed by two launches: the register budget of the 8192-sample form, two
                                * wavefronts per SIMD, would otherwise be every item's) */
-    /* Variant planes (srla_make_variants): the job's analysed variants -- the channels, and for two or more channels M = L + ((R - L) >> 1)
-     * and S = R - L (srla_utility.c:91-103) -- with the offset shift applied, written once per job, so that the dozens of items that
-     * analyse the same samples load ONE plane each (int16 where the stream is at most 16 bits wide: every variant but S fits)
-     * instead of shifting and combining two int32 channel planes again.  var_stride != 0 switches the sample loaders of
-     * srla_autocorr and srla_residual_cost to them:  var16 != null: variant v != S at var16 + v * var_stride, S at var32;
-     * var16 == null: every variant at var32 + v * var_stride. */
-    const int16_t *var16;
-    const int32_t *var32;
-    const uint32_t *var_flag;   /* non-zero after srla_make_variants: a sample of a stream declared at most 16 bits wide does not fit
-                                 * int16 (the reference does not mind such input, srla_encoder.c reads int32) -- the loaders then keep
-                                 * to the channel planes */
-    uint32_t var_stride, var_pad;
-    uint32_t out_stride;      /* SRLA_DIAG_STOP builds only: where srla_residual_cost stops (kernel timing experiments) */
     const uint32_t *lshift_dev; /* when non-null the offset left shift is read from here (device memory) instead of the
                                * item's: lets a whole device-resident stream be enqueued before its OR-reduction has finished */
     /* near-tie detection (H2: decisions that hang on libm): an item is flagged, and arbitrated with the host libm, when the

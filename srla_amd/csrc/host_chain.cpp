@@ -143,7 +143,6 @@ bool Impl::chain_stage_a(Slot &s, uint32_t jobidx, const ChainJob &cj)
     /* many small dependent launches: on a stream of their own, so that the regular jobs' wide kernels do not queue
      * behind them */
     hipStream_t W = s.own_stream;
-    s.var_ready = false;                 /* (chain-mode launches read the channel planes) */
     s.ties_gathered = false;
     const SrlaJobParams &jp = s.jp;
     if (!d_chain_list[jobidx].ensure(std::max<size_t>(1, cj.list.size()) * sizeof(SrlaAutocorrItem))) return false;
@@ -393,7 +392,7 @@ bool Impl::chain_encode_ad()
     }
     q.busy = false;
     chain_build(2, e.job, c.ce);
-    e.out_boost = tail_boost; e.emits = true; e.merge_cb = true;
+    e.out_boost = kTailBoost; e.emits = true; e.merge_cb = true;
     e.job.uploaded = false;
     if (!prepare_job(e, false) || !chain_stage_a(e, 2, c.ce)) return false;
     for (int st2 = ST_B; st2 <= ST_D; st2++) if (!run_stage(e, st2)) return false;

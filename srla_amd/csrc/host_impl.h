@@ -117,7 +117,7 @@ struct Slot {
     bool want_dbg = false;
     bool split_a = false;                /* stage A was enqueued in two parts (run_stage) */
     bool timed = false;                  /* this job records start events for every stage (one job in four) */
-    bool last_job = false;               /* one of the last jobs of the call's plan (Impl::dma_tail_jobs) */
+    bool last_job = false;               /* one of the last jobs of the call's plan (Impl::kDmaTailJobs) */
     bool use_dma = false;                /* this job's bytes leave by a host-issued copy when it is collected (Impl::dma_out) */
     bool dma_pending = false;            /* ev_dma marks the end of the last copies out of this slot's staging buffer */
     hipEvent_t ev_dma = nullptr;
@@ -125,9 +125,6 @@ struct Slot {
     DevBuf d_pcm;                        /* PCM input: the job's frames as uploaded, de-interleaved into d_input by srla_deinterleave */
     DevBuf d_input16;                    /* host input of at most 16 bits crosses PCIe as int16 and is widened into d_input */
     DevBuf d_price_ws;                   /* srla_price_windows: two words per candidate, for windows whose candidates do not fit LDS */
-    DevBuf d_var16, d_var32, d_var_flag; /* the job's variant planes (srla_make_variants, SrlaJobParams::var16 / var32 / var_flag) */
-    hipEvent_t ev_var = nullptr;         /* ... are complete */
-    bool var_ready = false;              /* ... exist for the job in this slot (stage A of run_stage made them) */
     DevBuf d_input, d_items, d_cands, d_windows, d_results, d_res_ws, d_blocks, d_block_off, d_scratch, d_dbg, d_lags, d_err, d_gamma, d_class_index, d_stream;
     DevBuf d_segs, d_seg_ctl;            /* SrlaSegDesc per segment; device-side segment records of srla_block_offsets */
     DevBuf d_coef_ws;                    /* SVR refinement: 64 doubles per item, the predictor between solve and quantiser */
@@ -162,7 +159,6 @@ struct StreamCtx {
     uint8_t *out_direct = nullptr;             /* device-visible address of `data` (pinned / registered / device memory), or null */
     bool out_in_hbm = false;
     bool in_pinned = false;                    /* the input planes are pinned host memory: DMA reads them without staging */
-    bool in_mixed = false;                     /* ... locked in place by this call while the pool could also stage them: the jobs take turns */
     bool with_header = true;                   /* EncodeWhole / EncodeBatch: header + offset shift; block calls: neither */
     bool raw_below_shift = false;              /* a block call whose samples have bits below the handle's offset shift: silence is decided on the raw samples (SrlaCandDesc::raw_silence) */
     bool reference_call = false;               /* one of the reference's own entry points on this handle: the call reads and leaves the
@@ -199,12 +195,7 @@ struct Impl {
      * 0 / 1: never / always (SRLA_MI355X_PIN_INPLACE) */
     int pin_inplace = -1;
     bool pin_too_slow = false;          /* registration measured slower than staging would be (no huge pages): not tried again */
-    bool split_residual_cost = true;    /* SRLA_MI355X_SPLIT_RC=0: one srla_residual_cost launch per job whatever its block sizes (as before round 4) */
-    bool wave_fft = false;              /* SRLA_MI355X_WAVE_FFT=1: 1024- to 8192-point items on srla_autocorr_w (register-resident transform, autocorr_wave.hip)
-                                         * instead of srla_autocorr: bit-identical, measured slower -- an option, not the default */
-    uint32_t run_ahead = 8;             /* SRLA_MI355X_RUN_AHEAD: jobs the host may be ahead of the stage skew (bounded by the buffer sets) */
-    uint32_t mix_num = 0, mix_den = 0;  /* SRLA_MI355X_MIX="a,b": pageable planes are locked in place and of every b jobs a are read by DMA, b - a staged (measured at "1,2": M -5 %, config 2 -7 %: off) */
-    uint32_t mix_count = 0;
+    static constexpr uint32_t kRunAhead = 8;      /* jobs the host may be ahead of the stage skew (bounded by the buffer sets) */
     /* Output by host-issued copies (the default where it applies: a call of more than three jobs whose streams' buffers the
      * device can reach -- pinned, registered or locked in place for the call, or device memory -- and that has no encode
      * callback): the assembly stage of a job ends with srla_pack_blocks, and when the host collects the job it has the segments'
@@ -218,15 +209,10 @@ struct Impl {
     bool call_crowded = false;          /* this call: more than three jobs, so a job's narrow kernels run beside other jobs' wide ones (SrlaJobParams::crowded) */
     bool call_dma = false;              /* this call: see above */
     bool dma_used = false;              /* copies may be in flight on dma_stream */
-    bool out_stream_on = false;         /* SRLA_MI355X_OUT_STREAM=1: srla_stream_out on a (low-priority) stream of its own, so that the copy-out of job k runs beside the assembly of job k + 1 */
-    hipStream_t out_stream = nullptr;
-    bool pack_on_n = false;             /* SRLA_MI355X_PACK_ON_N=1: block offsets + assembly on stream N behind the pricing, only the stream-out on C (measured: M device-resident -4 %, config 2 +3 %, others equal -- not the default) */
     uint32_t short_min = 786432;        /* SRLA_MI355X_SHORT_MIN: ... and no piece shorter than this many samples */
     uint32_t mid_jobs = 1;              /* SRLA_MI355X_MID_JOBS: a stream of up to this many whole jobs (and a rest) is cut into pieces like a short one (0: only streams shorter than a job) */
     uint32_t short_div = 4;             /* SRLA_MI355X_SHORT_DIV: a stream shorter than one job is cut into pieces of a job / this */
     bool split_ltp_stage = true;        /* SRLA_MI355X_NO_LTP_SKEW: stage A of LTP jobs in one piece on W, as before */
-    bool keep_residuals_always = true;  /* false with SRLA_MI355X_RECOMPUTE_RESIDUALS */
-    bool res32 = false;                 /* SRLA_MI355X_RES32: the residual scratch always holds int32 (no uint16 form) */
     bool keep_residuals = false;      /* SRLAMI355X_ProbeBlock with a residual buffer: srla_residual_cost stores what it prices */
     uint32_t offset_lshift = 0;       /* encoder->header.offset_lshift of the reference: set by EncodeWhole, used by the block calls */
     uint32_t pack_threads = 0;
@@ -254,23 +240,18 @@ struct Impl {
     DevBuf d_svr_scratch;              /* srla_svr_refine_big (orders above 64, blocks above 8192 samples): kSvrGroups regions */
     static constexpr uint32_t kSvrGroups = 256;
     bool timing = true;               /* stage timing events (SRLA_MI355X_NO_TIMING drops them) */
-    bool variant_planes = false;        /* SRLA_MI355X_VARIANTS=0: srla_autocorr / srla_residual_cost combine and shift the channel planes themselves, item by item */
-    uint32_t pin_min_mb = 32;           /* SRLA_MI355X_PIN_MIN_MB: streams of fewer MB of samples are never page-locked in place (staging them costs less than the registration) */
-    bool pair_small_jobs = true;        /* SRLA_MI355X_PAIR=0: never merge a small job's 2048- and 4096-point autocorrelation launches */
-    uint32_t pair_max_items = 6144;     /* SRLA_MI355X_PAIR_MAX: ... jobs of at most this many items in the two classes */
-    bool spin_short_calls = true;       /* SRLA_MI355X_SPIN=0: never poll a job's last event, always sleep on it */
-    bool spin_collect = false;          /* this call: at most three jobs */
-    bool lazy_captures = true;          /* SRLA_MI355X_LAZY_CAPTURES=0: every call of at most one window runs in history mode (no captures of such calls) */
-    bool tie_gather = true;             /* SRLA_MI355X_TIE_GATHER=0: fetch a job's near-tie numbers with blocking copies, as before round 4 */
-    uint32_t pool_linger_us = 600;      /* SRLA_MI355X_POOL_LINGER_US: how long the pool's workers keep looking for the next round of such a call before they sleep */
-    uint32_t dma_tail_jobs = 1;         /* SRLA_MI355X_DMA_TAIL: the call's last n jobs leave by srla_stream_out even where the others leave by host-issued copies */
-    uint32_t tail_boost = 4, tail_boost_jobs = 3;   /* SRLA_MI355X_TAIL_BOOST="wgs,jobs" */
+    /* measured settings (profiles/r03, r04), constants since round 5 */
+    static constexpr uint32_t kPinMinMB = 32;         /* streams of fewer MB of samples are never page-locked in place (staging them costs less than the registration) */
+    static constexpr uint32_t kPairMaxItems = 6144;   /* a small job's 2048- and 4096-point autocorrelation classes go in one launch up to this many items */
+    static constexpr uint32_t kPoolLingerUs = 600;    /* how long the pool's workers keep looking for the next round of a short call before they sleep */
+    static constexpr uint32_t kDmaTailJobs = 1;       /* the call's last n jobs leave by srla_stream_out even where the others leave by host-issued copies */
+    static constexpr uint32_t kTailBoost = 4, kTailBoostJobs = 3;   /* stream-out workgroup multiplier of the call's last jobs */
+    bool spin_collect = false;          /* this call: at most three jobs (its last event is polled, not slept on) */
     uint32_t timing_stride = 4;       /* every n-th job carries start events on all stages (SRLA_MI355X_TIMING_STRIDE) */
     void read_environment();          /* host_tuning.cpp: the one place that reads the environment */
     bool no_chain = false;            /* SRLA_MI355X_NO_CHAIN */
     bool chain_trace = false;         /* SRLA_MI355X_CHAIN_TRACE */
     uint32_t env_pack_threads = 0;    /* SRLA_MI355X_PACK_THREADS (0: not set) */
-    uint32_t diag_stop = 0;           /* SRLA_MI355X_K3_STOP, builds with -DSRLA_DIAG_STOP only */
     bool no_speculation = false;      /* SRLA_MI355X_NO_SPECULATION: the OR of a stream is always gathered before its first job */
     bool force_staging = false;       /* SRLA_MI355X_STAGING: never write the caller's buffer from the device */
     bool no_pack16 = false;           /* SRLA_MI355X_NO_PACK16: host input always crosses PCIe as int32 */

@@ -35,8 +35,7 @@ Impl::~Impl()
             for (auto &e : s.t0) if (e) (void)hipEventDestroy(e);
             for (auto &e : s.t1) if (e) (void)hipEventDestroy(e);
             if (s.ev_in) (void)hipEventDestroy(s.ev_in);
-            if (s.ev_var) (void)hipEventDestroy(s.ev_var);
-            s.d_var16.release(); s.d_var32.release(); s.d_var_flag.release(); s.d_price_ws.release(); s.d_big_sig.release();
+            s.d_price_ws.release(); s.d_big_sig.release();
             for (hipEvent_t e : { s.ev_a1, s.ev_p0, s.ev_p, s.ev_a0, s.ev_pk, s.ev_dma }) if (e) (void)hipEventDestroy(e);
             s.d_input16.release(); s.d_pcm.release();
             DevBuf *db[] = { &s.d_input, &s.d_items, &s.d_cands, &s.d_windows, &s.d_results, &s.d_res_ws,
@@ -48,7 +47,6 @@ Impl::~Impl()
         }
         for (auto &st : streams) if (st) (void)hipStreamDestroy(st);
         if (upload) (void)hipStreamDestroy(upload);
-        if (out_stream) (void)hipStreamDestroy(out_stream);
         if (dma_stream) { (void)hipStreamSynchronize(dma_stream); (void)hipStreamDestroy(dma_stream); }
         if (chain_stream) { (void)hipStreamSynchronize(chain_stream); (void)hipStreamDestroy(chain_stream); }
         if (ev_or) (void)hipEventDestroy(ev_or);
@@ -97,18 +95,12 @@ bool Impl::init_device()
     /* (created last: the runtime hands out its hardware queues in the order the streams are made, and a stream made before
      * `upload` moved that one onto a queue it shares with a compute stream -- host input -12 %, measured) */
     if (dma_out) HIP_OK(hipStreamCreateWithFlags(&dma_stream, hipStreamNonBlocking));
-    if (out_stream_on) {
-        int lo = 0, hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        HIP_OK(hipStreamCreateWithPriority(&out_stream, hipStreamNonBlocking, lo));
-    }
     if (!h_or.ensure(64)) return false;
     for (uint32_t si = 0; si < kMaxSlots; si++) {
         Slot &s = slot[si];
         for (auto &e : s.t0) HIP_OK(hipEventCreate(&e));
         for (auto &e : s.t1) HIP_OK(hipEventCreate(&e));
         HIP_OK(hipEventCreateWithFlags(&s.ev_in, hipEventDisableTiming));
-        HIP_OK(hipEventCreateWithFlags(&s.ev_var, hipEventDisableTiming));
         HIP_OK(hipEventCreate(&s.ev_a1)); HIP_OK(hipEventCreate(&s.ev_p0)); HIP_OK(hipEventCreate(&s.ev_p)); HIP_OK(hipEventCreate(&s.ev_a0));
         HIP_OK(hipEventCreateWithFlags(&s.ev_pk, hipEventDisableTiming));
         HIP_OK(hipEventCreateWithFlags(&s.ev_dma, hipEventDisableTiming));
@@ -202,14 +194,6 @@ bool Impl::stage_input(Slot &s, const JobPlan &plan)
     if (!s.d_input.ensure((size_t)nch * total * 4)) return false;
     bool all_pinned = true;
     for (const SegPlan &sp : plan.segs) all_pinned = all_pinned && sx[sp.stream].in_pinned;
-    /* Planes that this call locked in place can be read by DMA as they are (4 bytes per sample on the link, no host work) or
-     * staged by the pool threads (2 bytes per 16-bit sample on the link, 6 bytes of host memory traffic per sample).  Neither
-     * resource alone keeps up with the device on a long stream; taking turns job by job uses both. */
-    if (all_pinned && mix_den > 0) {
-        bool ours = true;
-        for (const SegPlan &sp : plan.segs) ours = ours && sx[sp.stream].in_mixed;
-        if (ours && (mix_count++ % mix_den) >= mix_num) all_pinned = false;
-    }
     std::unique_ptr<std::atomic<uint32_t>[]> seg_or(new std::atomic<uint32_t>[nseg]);
     for (uint32_t k = 0; k < nseg; k++) seg_or[k].store(0);
     struct Task { uint32_t seg, ch, off, len; };
@@ -427,34 +411,8 @@ bool Impl::run_stage(Slot &s, int st, int part)
         if (part != 2) {
             if (on_device) HIP_OK(hipStreamWaitEvent(W, ev_or, 0));
             if (s.used_h2d) HIP_OK(hipStreamWaitEvent(W, s.ev_in, 0));
-            s.var_ready = false;
-            if (variant_planes && have_items && !job.seg_lshift.empty() && job.seg_lshift.size() == job.segs.size()) {
-                /* the job's variant planes, once, on the upload stream (behind the job's own upload; beside the other jobs' wide
-                 * kernels): the items of srla_autocorr and srla_residual_cost then load one plane each */
-                const uint32_t nch = par.num_channels, nv = num_variants(), vstride = job.total;
-                const bool narrow = par.bits_per_sample <= 16;
-                const size_t planes16 = narrow ? (size_t)(nch >= 2 ? nch + 1 : nch) : 0, planes32 = narrow ? (nch >= 2 ? 1u : 0u) : nv;
-                if (!s.d_var16.ensure(std::max<size_t>(16, planes16 * vstride * 2)) || !s.d_var32.ensure(std::max<size_t>(16, planes32 * vstride * 4)) ||
-                    !s.d_var_flag.ensure(16)) return false;
-                if (on_device) HIP_OK(hipStreamWaitEvent(upload, ev_or, 0));
-                HIP_OK(hipMemsetAsync(s.d_var_flag.p, 0, 4, upload));
-                for (size_t g0 = 0; g0 < job.segs.size(); g0 += SRLA_VAR_SEGS) {
-                    SrlaVarSegs vs{};
-                    vs.count = (uint32_t)std::min<size_t>(SRLA_VAR_SEGS, job.segs.size() - g0);
-                    for (uint32_t g = 0; g < vs.count; g++) { vs.base[g] = job.segs[g0 + g].base; vs.ns[g] = job.segs[g0 + g].ns; vs.sh[g] = job.seg_lshift[g0 + g]; }
-                    rc |= srla_launch_make_variants(upload, s.in_cur, s.stride_cur, nch, jp.lshift_dev, &vs, narrow ? s.d_var16.as<int16_t>() : nullptr,
-                                                    s.d_var32.as<int32_t>(), vstride, s.d_var_flag.as<uint32_t>());
-                }
-                HIP_OK(hipEventRecord(s.ev_var, upload));
-                HIP_OK(hipStreamWaitEvent(W, s.ev_var, 0));
-                s.var_ready = true;
-            }
         }
-        SrlaJobParams jv = jp;                                    /* what srla_autocorr sees: with the variant planes when the job has them */
-        if (s.var_ready) {
-            jv.var16 = (par.bits_per_sample <= 16) ? s.d_var16.as<int16_t>() : nullptr;
-            jv.var32 = s.d_var32.as<int32_t>(); jv.var_flag = s.d_var_flag.as<uint32_t>(); jv.var_stride = job.total;
-        }
+        const SrlaJobParams &jv = jp;
         struct L { int kind, cls, pass; };                       /* kind 0: autocorr class launch, 1: pitch solve */
         L seq[24]; int nl = 0;
         if (have_items) {
@@ -471,7 +429,6 @@ bool Impl::run_stage(Slot &s, int st, int part)
         if (split && part == 1) last = pitch_at;
         if (split && part == 2) { first = pitch_at + 1; HIP_OK(hipStreamWaitEvent(W, s.ev_p, 0)); }
         static const int kClass[8] = { 0, 1, 2, 4, 0, 0, 0, 0 };     /* FFT size / 2048 (0: at most 1024 points) */
-        static const uint32_t kWaveFft[8] = { 0u, 2048u, 4096u, 8192u, 0u, 0u, 1024u, 0u };   /* classes of ONE size that srla_autocorr_w takes */
         static const uint32_t kBigFft[8] = { 0u, 0u, 0u, 0u, 16384u, 32768u, 0u, 65536u };   /* classes of srla_autocorr_big */
         auto start_event = [&](int i) -> hipEvent_t {
             hipEvent_t e = (i == 0) ? ev0 : nullptr;
@@ -484,8 +441,7 @@ bool Impl::run_stage(Slot &s, int st, int part)
             return e;
         };
         /* a small job's 2048- and 4096-point classes in ONE launch (srla_autocorr_pair): a short stream is a latency chain */
-        const bool pair_ok = pair_small_jobs && !wave_fft && !srla_autocorr_pair_excluded() &&
-                             job.class_count[1] != 0 && job.class_count[2] != 0 && job.class_count[1] + job.class_count[2] <= pair_max_items;
+        const bool pair_ok = job.class_count[1] != 0 && job.class_count[2] != 0 && job.class_count[1] + job.class_count[2] <= kPairMaxItems;
         for (int i = first; i <= last; i++) {
             hipEvent_t e0 = start_event(i), e1 = stop_event(i);
             if (pair_ok && seq[i].kind == 0 && seq[i].cls == 1 && i + 1 <= last && seq[i + 1].kind == 0 && seq[i + 1].cls == 2 && seq[i + 1].pass == seq[i].pass) {
@@ -502,9 +458,6 @@ bool Impl::run_stage(Slot &s, int st, int part)
                     rc |= srla_launch_autocorr_big(W, &jp, s.in_cur, d_tw.p, (uint32_t)seq[i].pass, s.d_results.as<SrlaItemResult>(), s.d_lags.as<double>(), dbg,
                                                    s.d_class_index.as<SrlaAutocorrItem>() + job.class_first[c], job.class_count[c], kBigFft[c],
                                                    e0, e1, nullptr, nullptr, s.d_big_scratch.p, SRLA_BIG_GROUPS);
-                else if (wave_fft && kWaveFft[c])
-                    rc |= srla_launch_autocorr_wave(W, kWaveFft[c], &jp, s.in_cur, d_tw.p, (uint32_t)seq[i].pass, s.d_results.as<SrlaItemResult>(),
-                                                    s.d_lags.as<double>(), dbg, s.d_class_index.as<SrlaAutocorrItem>() + job.class_first[c], job.class_count[c], e0, e1);
                 else
                 rc |= srla_launch_autocorr(W, kClass[c], &jv, s.in_cur, s.d_items.as<SrlaItemDesc>(), d_geoms.as<SrlaGeom>(), d_tw.p,
                                            (uint32_t)seq[i].pass, s.d_results.as<SrlaItemResult>(), s.d_lags.as<double>(), dbg,
@@ -540,11 +493,7 @@ bool Impl::run_stage(Slot &s, int st, int part)
             const Group &g = job.groups[0];
             /* the roofline kernel: start event on every job */
             const bool big = !job.big_items.empty();
-            SrlaJobParams jv = jp;                                /* with the variant planes when stage A made them */
-            if (s.var_ready) {
-                jv.var16 = (par.bits_per_sample <= 16) ? s.d_var16.as<int16_t>() : nullptr;
-                jv.var32 = s.d_var32.as<int32_t>(); jv.var_flag = s.d_var_flag.as<uint32_t>(); jv.var_stride = job.total;
-            }
+            const SrlaJobParams &jv = jp;
             if (g.split) {
                 /* the large items first: they are what the launch waits for, the small ones fill in behind them */
                 SrlaJobParams jl = jv, js = jv;
@@ -587,7 +536,7 @@ bool Impl::run_stage(Slot &s, int st, int part)
          * for the tails of the wide kernels, 0.13-0.3 ms per job for 0.05 ms of work), the stream-out on C: the copy of job k
          * then also runs beside the assembly of job k + 1.  A job on a stream of its own keeps to it. */
         {
-        hipStream_t P = (pack_on_n && !s.own_stream) ? N : C;
+        hipStream_t P = C;
         if (P == C) HIP_OK(hipStreamWaitEvent(C, s.t1[ST_D], 0));
         s.use_dma = call_dma && !s.own_stream && s.emits && !s.last_job;   /* (the call's last job: the copy-out kernel follows its assembly without a host round trip) */
         if (s.dma_pending) { HIP_OK(hipStreamWaitEvent(P, s.ev_dma, 0)); s.dma_pending = false; }   /* the staging buffer's last job has left it */
@@ -602,9 +551,9 @@ bool Impl::run_stage(Slot &s, int st, int part)
                                    d_pos.as<uint32_t>(), s.d_segs.as<SrlaSegDesc>(), s.d_seg_ctl.as<uint32_t>(),
                                    s.d_stream.as<uint8_t>(), s.h_stream.as<uint8_t>(), s.d_scratch.as<uint8_t>(), info, wbytes,
                                    reinterpret_cast<SrlaSegInfo *>(wbytes + job.windows.size()), s.d_ties.as<uint32_t>(),
-                                   ev0, s.t1[ST_E], s.out_boost, (P == C) ? ((out_stream && !s.own_stream) ? out_stream : nullptr) : C, s.ev_pk,
+                                   ev0, s.t1[ST_E], s.out_boost, nullptr, s.ev_pk,
                                    s.use_dma ? 1u : 0u, &tg);
-            s.ties_gathered = tie_gather;
+            s.ties_gathered = true;
         } else { if (P != C) HIP_OK(hipStreamWaitEvent(C, s.t1[ST_D], 0)); if (ev0) HIP_OK(hipEventRecord(ev0, C)); HIP_OK(hipEventRecord(s.t1[ST_E], C)); }
         }
         break;
@@ -688,9 +637,6 @@ SRLAApiResult Impl::finish_job(Slot &s)
 {
     const auto t0 = Clock::now();
     const SrlaJobInfo info = *s.h_info.as<SrlaJobInfo>();
-#ifdef SRLA_DIAG_STOP
-    if (diag_stop) return SRLA_APIRESULT_OK;                  /* timing experiments: the stream is garbage */
-#endif
     if (info.error & ~SRLA_JOBERR_OVERFLOW) {
         fprintf(stderr, "[srla-mi355x] internal error: device pack reported 0x%x (%s%s)\n", info.error,
                 (info.error & SRLA_JOBERR_SIZE) ? "a packed block differs from its computed size " : "",
@@ -784,7 +730,7 @@ void Impl::classify_buffers(StreamCtx &st, std::vector<const void *> &held)
     /* memory that another handle's call locked in place (the process-wide registry of host_support.cpp) stays locked only as
      * long as somebody holds a reference: take one for this call before enqueueing DMA on it */
     auto keep = [&](const void *p) { if (const void *key = host_pin_addref(p)) held.push_back(key); };
-    st.in_pinned = false; st.in_mixed = false;
+    st.in_pinned = false;
     if (st.host_in && !force_staging) {
         st.in_pinned = true;
         const size_t before = held.size();
@@ -931,10 +877,9 @@ SRLAApiResult Impl::encode_streams(bool search)
         ~DmaGuard() { if (im->dma_stream && im->dma_used) { (void)hipStreamSynchronize(im->dma_stream); im->dma_used = false; } }
     } dma_guard{ this };
     /* pageable planes are locked in place when the pool is too small to stage them (all jobs by DMA then), and otherwise too
-     * when staging and DMA take turns (mix_den > 0: stage_input) */
+     */
     const bool few_threads = pool->size() < 6;
-    const bool want_pins = !force_staging && !pin_too_slow && (pin_inplace == 1 || (pin_inplace < 0 && (few_threads || mix_den > 0)));
-    mix_count = 0;
+    const bool want_pins = !force_staging && !pin_too_slow && (pin_inplace == 1 || (pin_inplace < 0 && few_threads));
     bool need_oracc = false;
     /* parameters under which blocks anywhere in the stream depend on the calls before them: window by window (host_chain.cpp) */
     /* ... and, for the reference's own entry points, calls of at most one window: they are where a handle's earlier calls can
@@ -942,7 +887,7 @@ SRLAApiResult Impl::encode_streams(bool search)
     const bool tracked = single && sx[0].reference_call && !no_chain;
     /* (a call of at most one window reads the buffer only through an odd-length or short long-term-predictor block: chain_tail) */
     const bool one_window = tracked && sx[0].num_samples <= (search ? par.num_lookahead_samples : par.max_num_samples_per_block);
-    const bool history = replaying || history_regime(search) || (one_window && (!lazy_captures || chain_tail(sx[0].num_samples, search) != 0));
+    const bool history = replaying || history_regime(search) || (one_window && chain_tail(sx[0].num_samples, search) != 0);
     if (history && tracked && !pending.empty() && !replaying) {
         /* this call may read the buffer: first what the regular calls on the handle left in it */
         std::vector<StreamCtx> mine;
@@ -960,7 +905,7 @@ SRLAApiResult Impl::encode_streams(bool search)
         /* ... when the pool is too small to stage (want_pins); where the threads could stage it as well, the OUTPUT buffer of a stream
          * below pin_min_mb MB of samples is not worth its registration either (releasing it cost 0.07 ms of a 60 s stream's 0.94 ms) */
         const uint64_t sample_bytes = (uint64_t)st.num_samples * nch * 4u;
-        const bool worth_pinning = sample_bytes >= (want_pins ? (uint64_t)(4u << 20) : ((uint64_t)pin_min_mb << 20));
+        const bool worth_pinning = sample_bytes >= (want_pins ? (uint64_t)(4u << 20) : ((uint64_t)kPinMinMB << 20));
         if (want_pins && worth_pinning && st.host_in && !st.in_pinned) {
             const size_t before = pins.held.size();
             bool ok = true;
@@ -972,7 +917,7 @@ SRLAApiResult Impl::encode_streams(bool search)
                 if (ok && us_per_mb > 40.0) { pin_too_slow = true; ok = false; }
             }
             if (!ok) { while (pins.held.size() > before) { host_pin_release(pins.held.back()); pins.held.pop_back(); } }
-            else { st.in_pinned = true; st.in_mixed = pin_inplace != 1 && !few_threads; }
+            else st.in_pinned = true;
         }
         /* the output buffer always (unless switched off): the blocks then land in it straight from the device, which saves the
          * copy out of the staging buffers that the calling thread would otherwise make job by job (M: +5 %, and steadier) */
@@ -1073,8 +1018,8 @@ SRLAApiResult Impl::encode_streams(bool search)
     const uint32_t njobs = (uint32_t)plan.size();
     overrides.clear();
     call_crowded = njobs > 3;
-    spin_collect = spin_short_calls && njobs <= 3;
-    pool->set_linger_us(spin_collect ? pool_linger_us : 0u);      /* (a short call's two rounds -- staging, copy-out -- are 0.3 ms apart) */
+    spin_collect = njobs <= 3;
+    pool->set_linger_us(spin_collect ? kPoolLingerUs : 0u);      /* (a short call's two rounds -- staging, copy-out -- are 0.3 ms apart) */
     /* (a stream of a few pieces is a latency chain: its copies would start only when the host has collected each piece) */
     call_dma = dma_out && dma_stream != nullptr && njobs > 3;
     for (const StreamCtx &st : sx) call_dma = call_dma && st.out_direct != nullptr && st.data != nullptr && st.cb == nullptr;
@@ -1101,8 +1046,8 @@ SRLAApiResult Impl::encode_streams(bool search)
         s.own_stream = (njobs == 1) ? streams[0] : nullptr;
         s.emits = true; s.merge_cb = false;
         s.timed = timing && (k % timing_stride == 0);
-        s.out_boost = (k + tail_boost_jobs >= njobs) ? tail_boost : 1u;
-        s.last_job = k + dma_tail_jobs >= njobs;              /* (the last jobs of the call: the copy-out kernel, no host round trip) */
+        s.out_boost = (k + kTailBoostJobs >= njobs) ? kTailBoost : 1u;
+        s.last_job = k + kDmaTailJobs >= njobs;              /* (the last jobs of the call: the copy-out kernel, no host round trip) */
         return prepare_job(s, false);
     };
     /* chain mode of the (single) stream, overlapped with the regular jobs */
@@ -1148,7 +1093,7 @@ SRLAApiResult Impl::encode_streams(bool search)
      * every buffer set beyond depth + 1 is one more job staged and uploaded while the device still works on older ones (host
      * input: staging 0.28 ms + upload 0.3 ms per 4 M-sample job on top of the 1.5 ms a job takes from its first kernel to its
      * last byte; with lag = depth the device waited for input about a tenth of the time). */
-    const uint32_t lag = depth + std::min<uint32_t>(run_ahead, (kSlots > depth + 1u) ? kSlots - 1u - depth : 0u);
+    const uint32_t lag = depth + std::min<uint32_t>(kRunAhead, (kSlots > depth + 1u) ? kSlots - 1u - depth : 0u);
     uint32_t base = 0, restarts = 0;
     auto in_flight = [&](uint32_t t, uint32_t back) { return t >= back && t - back < njobs && t - back >= base; };
     for (uint32_t t = 0; t < njobs + lag;) {

@@ -84,7 +84,7 @@ void Impl::build_job(Job &job, const JobPlan &plan, const std::vector<uint32_t> 
     const uint32_t window_len = search ? par.num_lookahead_samples : maxb;
     const uint32_t nv = num_variants(), pmax = preset_order();
     uint64_t key = 1469598103934665603ull;
-    key = fnv64(key, ((uint64_t)param_generation << 2) | ((keep_residuals || keep_residuals_always) ? 2u : 0u) | (search ? 1u : 0u));
+    key = fnv64(key, ((uint64_t)param_generation << 2) | 2u | (search ? 1u : 0u));
     key = fnv64(key, plan.total);
     for (size_t k = 0; k < plan.segs.size(); k++) {
         key = fnv64(key, ((uint64_t)plan.segs[k].ns << 32) | plan.segs[k].base);
@@ -102,7 +102,7 @@ void Impl::build_job(Job &job, const JobPlan &plan, const std::vector<uint32_t> 
     job.windows.clear(); job.cands.clear(); job.items.clear(); job.groups.clear(); job.class_index.clear(); job.svr_rows.clear();
     job.seg_first_window.clear();
     job.num_slots = 0; job.res_elems = 0; job.analyzed_samples = 0; job.max_nodes = 2; job.max_window_cands = 1;
-    job.keep_residuals = keep_residuals || keep_residuals_always;
+    job.keep_residuals = true;                  /* srla_pack_blocks reads the chosen blocks' residuals where srla_residual_cost left them */
 
     struct Pending { uint32_t cand; uint32_t nfft; uint32_t seg; };
     std::vector<Pending> analysed;
@@ -190,7 +190,7 @@ void Impl::build_job(Job &job, const JobPlan &plan, const std::vector<uint32_t> 
              * wavefronts per SIMD, against 228 and two for the 8192-sample form), with their own LDS size */
             bool any_small = false, any_large = false;
             for (const SrlaItemDesc &it : job.items) { if (it.n <= 4096u) any_small = true; else if (it.n <= 8192u) any_large = true; }
-            g.split = split_residual_cost && g.rclass == 4 && any_small && any_large;
+            g.split = g.rclass == 4 && any_small && any_large;
             if (g.split) {
                 g.plan_small = lds_plan(4096u);
                 bool small_fast = true;
@@ -246,12 +246,9 @@ SrlaJobParams Impl::job_params(const Job &job, uint32_t channel_stride, bool lsh
     jp.num_items = (uint32_t)job.items.size();
     jp.num_cands = (uint32_t)job.cands.size();
     jp.num_windows = (uint32_t)job.windows.size();
-#ifdef SRLA_DIAG_STOP
-    jp.out_stride = diag_stop;                               /* kernel timing experiments only */
-#endif
     jp.lshift_dev = lshift_on_device ? (d_or.as<uint32_t>() + 1) : nullptr;
     jp.crowded = call_crowded ? 1u : 0u;
-    jp.keep_residuals = job.keep_residuals ? ((keep_residuals || res32) ? 2u : 1u) : 0u;
+    jp.keep_residuals = job.keep_residuals ? (keep_residuals ? 2u : 1u) : 0u;
     jp.tie_rel = tie_rel; jp.tie_ltp = tie_ltp; jp.tie_logscale = tie_logscale; jp.tie_ltpbias = tie_ltpbias;
     return jp;
 }

@@ -41,42 +41,14 @@ void Impl::read_environment()
     { const long long v = number("SRLA_MI355X_MID_JOBS", -1); if (v >= 0 && v <= 16) mid_jobs = (uint32_t)v; }
     { const long long v = number("SRLA_MI355X_SHORT_DIV", 0); if (v >= 2 && v <= 64) short_div = (uint32_t)v; }
     { const long long v = number("SRLA_MI355X_PACK_THREADS", 0); if (v > 0) env_pack_threads = (uint32_t)v; }
-    { const long long v = number("SRLA_MI355X_PIN_MIN_MB", -1); if (v >= 0 && v <= 65536) pin_min_mb = (uint32_t)v; }
-    if (is_set("SRLA_MI355X_VARIANTS")) variant_planes = number("SRLA_MI355X_VARIANTS", 1) != 0;
-    if (is_set("SRLA_MI355X_PAIR")) pair_small_jobs = number("SRLA_MI355X_PAIR", 1) != 0;
-    { const long long v = number("SRLA_MI355X_PAIR_MAX", -1); if (v >= 0) pair_max_items = (uint32_t)v; }
-    if (is_set("SRLA_MI355X_SPIN")) spin_short_calls = number("SRLA_MI355X_SPIN", 1) != 0;
-    if (is_set("SRLA_MI355X_LAZY_CAPTURES")) lazy_captures = number("SRLA_MI355X_LAZY_CAPTURES", 1) != 0;
-    if (is_set("SRLA_MI355X_TIE_GATHER")) tie_gather = number("SRLA_MI355X_TIE_GATHER", 1) != 0;
-    if (is_set("SRLA_MI355X_POOL_LINGER_US")) pool_linger_us = (uint32_t)number("SRLA_MI355X_POOL_LINGER_US", 600);
-    { const long long v = number("SRLA_MI355X_DMA_TAIL", -1); if (v >= 1 && v <= 16) dma_tail_jobs = (uint32_t)v; }
-    if (const char *e = getenv("SRLA_MI355X_TAIL_BOOST")) {     /* "wgs,jobs": stream-out workgroup multiplier of the last jobs */
-        unsigned a = 0, b = 0;
-        if (sscanf(e, "%u,%u", &a, &b) == 2 && a >= 1) { tail_boost = a; tail_boost_jobs = b; }
-    }
 
     /* ---- measured alternatives kept as options -------------------------------------------------------- */
-    keep_residuals_always = !is_set("SRLA_MI355X_RECOMPUTE_RESIDUALS");   /* set: no residual scratch, the pack kernel recomputes */
-    res32 = is_set("SRLA_MI355X_RES32");                                  /* set: every residual kept as int32 (round 3's first form) */
-    if (is_set("SRLA_MI355X_SPLIT_RC")) split_residual_cost = number("SRLA_MI355X_SPLIT_RC", 1) != 0;
-    if (is_set("SRLA_MI355X_WAVE_FFT")) wave_fft = number("SRLA_MI355X_WAVE_FFT", 1) != 0;   /* 1: srla_autocorr_w for 1024..8192-point items */
     split_ltp_stage = !is_set("SRLA_MI355X_NO_LTP_SKEW");                 /* set: the pitch solve back on stream W */
     if (is_set("SRLA_MI355X_DMA_OUT")) dma_out = number("SRLA_MI355X_DMA_OUT", 1) != 0;
-    if (is_set("SRLA_MI355X_OUT_STREAM")) out_stream_on = number("SRLA_MI355X_OUT_STREAM", 1) != 0;
-    if (is_set("SRLA_MI355X_PACK_ON_N")) pack_on_n = number("SRLA_MI355X_PACK_ON_N", 1) != 0;
-    if (const char *e = getenv("SRLA_MI355X_MIX")) { unsigned a = 0, b = 0; if (sscanf(e, "%u,%u", &a, &b) == 2 && a <= b) { mix_num = a; mix_den = b; } }
-    { const long long v = number("SRLA_MI355X_RUN_AHEAD", -1); if (v >= 0 && v <= 8) run_ahead = (uint32_t)v; }
     SrlaLaunchTuning lt = {};
-    lt.fused_fft = number("SRLA_MI355X_FUSED_FFT", 0) != 0 ? 1u : 0u;     /* two FFT stages per LDS round trip */
     lt.pack_lds_cap_words = (uint32_t)std::max<long long>(0, number("SRLA_MI355X_PACK_LDS_WORDS", 0));   /* tests: reach the global-memory pack path */
-    lt.out_wgs = (uint32_t)std::max<long long>(0, number("SRLA_MI355X_OUT_WGS", 0));
     lt.fft_wp = number("SRLA_MI355X_FFT_WP", 1) != 0 ? 1u : 0u;          /* 0: round 4's transform (a workgroup barrier per stage) */
     lt.fir_mfma = number("SRLA_MI355X_FIR_MFMA", 1) != 0 ? 1u : 0u;          /* 0: the FIR on v_dot2 / v_dot4 (round 4) */
-    lt.fft_thin = number("SRLA_MI355X_FFT_THIN", 0) != 0 ? 1u : 0u;
-    lt.generic_fft = number("SRLA_MI355X_GENERIC_FFT", 0) != 0 ? 1u : 0u;
-    lt.solve_onepass = number("SRLA_MI355X_SOLVE_ONEPASS", 0) != 0 ? 1u : 0u;   /* the solve chain as one launch (round 2's default) */
-    lt.solve_lds = (uint32_t)std::max<long long>(0, number("SRLA_MI355X_SOLVE_LDS", 0));
-    lt.errvars_regs = number("SRLA_MI355X_ERRVARS_REGS", 0) != 0 ? 1u : 0u;
     srla_set_launch_tuning(&lt);
 
     /* ---- diagnostics ------------------------------------------------------------------------------------------------ */
@@ -90,7 +62,4 @@ void Impl::read_environment()
         double a = 0, b = 0, c = 1, d = 0;
         if (sscanf(e, "%lf,%lf,%lf,%lf", &a, &b, &c, &d) == 4) { tie_rel = a; tie_ltp = b; tie_logscale = c; tie_ltpbias = d; }
     }
-#ifdef SRLA_DIAG_STOP
-    diag_stop = (uint32_t)std::max<long long>(0, number("SRLA_MI355X_K3_STOP", 0));   /* kernel timing experiments: the stream is garbage */
-#endif
 }

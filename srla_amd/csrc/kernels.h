@@ -30,16 +30,11 @@ uint32_t srla_kernel_fast_lds_bytes(uint32_t fl, uint32_t ltp_order, uint32_t bi
 /* pass 0: LPC lags (initialises the item record unless an LTP pass ran first), pass 1: LTP lags.
  * One launch per FFT-size class (rclass = 0, 1, 2, 4 for N' <= 1024, 2048, 4096, 8192): class_items holds the `count`
  * items of the class. */
-/* the job's variant planes (SrlaJobParams::var16 / var32; v16 null: every variant as int32) from its channel planes, segment by segment */
-int srla_launch_make_variants(hipStream_t stream, const int32_t *src, uint32_t src_stride, uint32_t nch, const uint32_t *lshift_dev,
-                              const SrlaVarSegs *segs, int16_t *v16, int32_t *v32, uint32_t vstride, uint32_t *flag /* zeroed by the caller */);
-/* a small job's 4096- and 2048-point classes in one launch (not in chain mode); srla_autocorr_pair_excluded: a launch tuning
- * (fused / generic transform) asks for kernels the pair does not have */
+/* a small job's 4096- and 2048-point classes in one launch (not in chain mode) */
 int srla_launch_autocorr_pair(hipStream_t stream, const SrlaJobParams *jp, const int32_t *input, const SrlaItemDesc *items,
                               const SrlaGeom *geoms, const void *twiddles, uint32_t pass, SrlaItemResult *results, double *lags_ws,
                               double *dbg, const SrlaAutocorrItem *items_4096, uint32_t count_4096,
                               const SrlaAutocorrItem *items_2048, uint32_t count_2048, hipEvent_t ev_start, hipEvent_t ev_stop);
-int srla_autocorr_pair_excluded(void);
 int srla_launch_autocorr(hipStream_t stream, int rclass, const SrlaJobParams *jp, const int32_t *input,
                          const SrlaItemDesc *items, const SrlaGeom *geoms, const void *twiddles,
                          uint32_t pass, SrlaItemResult *results, double *lags_ws, double *dbg,
@@ -47,11 +42,6 @@ int srla_launch_autocorr(hipStream_t stream, int rclass, const SrlaJobParams *jp
                          double *chain_pool /* null outside chain mode (device_layout.h: chain_src / chain_dump) */,
                          const uint32_t *chain_tab /* gather table of chain_lags */,
                          int exact_nfft /* rclass 0 only: every item has exactly 1024 points */);
-/* The same for the items of ONE transform size nfft = 1024, 2048 or 4096 outside chain mode: nfft / 64 lanes of one wavefront per
- * item, the transform in registers, no barriers (autocorr_wave.hip). */
-int srla_launch_autocorr_wave(hipStream_t stream, uint32_t nfft, const SrlaJobParams *jp, const int32_t *input, const void *twiddles,
-                              uint32_t pass, SrlaItemResult *results, double *lags_ws, double *dbg,
-                              const SrlaAutocorrItem *class_items, uint32_t count, hipEvent_t ev_start, hipEvent_t ev_stop);
 /* items of 16384 / 32768 points (blocks above 8192 samples): the global-memory slow path; scratch: scratch_groups x nfft
  * complex doubles, one region per (persistent) workgroup */
 int srla_launch_autocorr_big(hipStream_t stream, const SrlaJobParams *jp, const int32_t *input, const void *twiddles, uint32_t pass,
@@ -122,16 +112,9 @@ int srla_launch_pack(hipStream_t stream, const SrlaJobParams *jp, uint32_t num_s
                      const SrlaTieGather *gather /* may be null */);
 /* What the launchers take from the environment (read in ONE place, host_tuning.cpp, and handed over here): */
 typedef struct {
-    uint32_t fused_fft;            /* SRLA_MI355X_FUSED_FFT: fft_complex_lds16 for 2048- and 4096-point items */
     uint32_t pack_lds_cap_words;   /* SRLA_MI355X_PACK_LDS_WORDS: 0 = the default cap (24 Ki words) */
-    uint32_t out_wgs;              /* SRLA_MI355X_OUT_WGS: stream-out workgroups, 0 = by sample width */
     uint32_t fft_wp;               /* SRLA_MI355X_FFT_WP (default 1): the region layout with wave-private FFT stages for classes of at most 4096 points */
     uint32_t fir_mfma;             /* SRLA_MI355X_FIR_MFMA: srla_residual_cost's FIR as a Toeplitz product on the matrix pipe (blocks <= 4096 samples) */
-    uint32_t fft_thin;             /* SRLA_MI355X_FFT_THIN: the 2048-point class on 128 threads (two butterflies per thread and stage) */
-    uint32_t generic_fft;          /* SRLA_MI355X_GENERIC_FFT: srla_autocorr without the FFT size compiled in, as in round 2 */
-    uint32_t solve_onepass;        /* SRLA_MI355X_SOLVE_ONEPASS: srla_lpc_solve_regs instead of errvars + order_select + taps */
-    uint32_t solve_lds;            /* SRLA_MI355X_SOLVE_LDS=8|16|32: orders up to 64 on the LDS chain with that many items per wavefront */
-    uint32_t errvars_regs;         /* SRLA_MI355X_ERRVARS_REGS: srla_lpc_errvars<64> entirely in registers (348 per lane) instead of the lean form */
 } SrlaLaunchTuning;
 void srla_set_launch_tuning(const SrlaLaunchTuning *t);
 #define SRLA_SEGCTL_WORDS_HOST 8

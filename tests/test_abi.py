@@ -195,6 +195,9 @@ def test_every_environment_variable_the_library_reads_is_documented():
     src = open(os.path.join(helpers.ROOT, "srla_amd", "csrc", "host_tuning.cpp")).read()
     doc = open(os.path.join(helpers.ROOT, "INTEGRATION.md")).read()
     names = sorted(set(re.findall(r'"(SRLA_MI355X_[A-Z0-9_]+)"', src)))
-    assert len(names) > 20
+    assert 15 <= len(names) <= 25           # (round 5 pruned the switches of measured losers: 47 -> 21)
     missing = [n for n in names if n not in doc]
     assert not missing, missing
+    # ... and nothing the library no longer reads (SRLAMI355X_ prefixes are API names, not variables)
+    stale = sorted(n for n in set(re.findall(r'SRLA_MI355X_[A-Z0-9_]+', doc)) if n not in names and n != 'SRLA_MI355X_DIR')   # (a CMake variable of section 3)
+    assert not stale, stale

@@ -12,8 +12,8 @@ import helpers
 
 def _library_kernels():
     names = set()
-    for src in ("kernels.hip", "autocorr_wave.hip"):
-        text = open(os.path.join(helpers.ROOT, "srla_amd", "csrc", src)).read()
+    for src in sorted(glob.glob(os.path.join(helpers.ROOT, "srla_amd", "csrc", "*.hip"))):
+        text = open(src).read()
         for m in re.finditer(r"__global__[^;{]*?\b(srla_[a-z0-9_]+)\s*\(", text, re.S):
             names.add(m.group(1))
     return names

@@ -274,7 +274,7 @@ def _full_scale(n, seed, partial=False):
                                                 (5120, "m4_B8192_V2_P3", True), (1000, "m6_B1024_V1_P1", False)])
 def test_full_scale_input_item_records_and_residuals(product, n, cli_name, partial):
     """srla_residual_cost keeps 16-bit input as an int16 plane plus an int8 plane that is only filtered where the signal leaves 16
-    bits (kernels.hip FIR_DOT); ordinary test signals never do, these always do.  Residuals and parameters per variant."""
+    bits (residual_cost.hip: FIR_DOT's int8 plane, FIR_MFMA's third byte plane); ordinary test signals never do, these always do.  Residuals and parameters per variant."""
     cli = CLIS[cli_name]
     pcm = _full_scale(n, 300 + n, partial)
     assert np.abs(pcm[1] - pcm[0]).max() > 40000
@@ -684,51 +684,19 @@ def test_too_few_job_buffer_sets_are_refused_not_raced(product, monkeypatch):
         assert np.array_equal(product.encode(pcm, **cli), want), slots
 
 
-@pytest.mark.parametrize("cli,bits,nch", [(dict(preset=4, max_block=4096, divisions=1), 16, 2),
-                                          (dict(preset=4, max_block=4096, divisions=2, ltp_order=3), 16, 2),
-                                          (dict(preset=6, max_block=8192, divisions=3, ltp_order=1), 24, 3),
-                                          (dict(preset=1, max_block=1024, divisions=0), 8, 1)],
-                         ids=["m4_V1", "m4_V2_P3", "m6_B8192_V3_P1_24bit_3ch", "m1_B1024_V0_8bit_mono"])
-def test_pack_side_residual_recompute_option_gives_the_same_bytes(product, monkeypatch, cli, bits, nch):
-    """SRLA_MI355X_RECOMPUTE_RESIDUALS: srla_residual_cost keeps no residuals, srla_pack_blocks recomputes the chosen blocks'
-    (pre-emphasis, LTP, FIR in LDS).  Same stream, odd length included (chain-mode tail)."""
-    monkeypatch.setenv("SRLA_MI355X_RECOMPUTE_RESIDUALS", "1")
-    monkeypatch.setenv("SRLA_MI355X_JOB_SAMPLES", "131072")
-    pcm = helpers.synth(helpers.MUSIC if nch == 2 else helpers.VARIED, 77, 48000, nch, 300_001)
-    if bits == 24:
-        pcm = pcm << 6
-    elif bits == 8:
-        pcm = pcm >> 8
-    want = helpers.Oracle(nch, bits_per_sample=bits, **cli).encode_whole(pcm)
-    assert np.array_equal(product.encode(pcm, bits_per_sample=bits, **cli), want)
-
-
-@pytest.mark.parametrize("cli", [dict(preset=4, max_block=4096, divisions=2, ltp_order=3), dict(preset=4, max_block=2048, divisions=0),
-                                 dict(preset=2, max_block=8192, divisions=1)], ids=["B4096_V2_P3", "B2048_V0", "B8192_V1"])
-def test_fused_fft_option_gives_the_same_bytes(product, monkeypatch, cli):
-    """SRLA_MI355X_FUSED_FFT: two radix-4 stages per LDS round trip (lane pairs exchanging through v_permlane32_swap) for the
-    2048- and 4096-point transforms, pruned inverse included; same butterflies, same bits.  Odd length: chain-mode tail."""
-    monkeypatch.setenv("SRLA_MI355X_FUSED_FFT", "1")
-    pcm = helpers.synth(helpers.MUSIC, 78, 48000, 2, 500_001)
-    want = helpers.Oracle(2, **cli).encode_whole(pcm)
-    assert np.array_equal(product.encode(pcm, **cli), want)
-
-
-ROUND4_OPTIONS = {
-    "variant_planes": {"SRLA_MI355X_VARIANTS": "1"},
-    "one_residual_cost_launch": {"SRLA_MI355X_SPLIT_RC": "0"},
-    "no_pair_no_spin": {"SRLA_MI355X_PAIR": "0", "SRLA_MI355X_SPIN": "0"},
-    "dma_tail_3_small_jobs": {"SRLA_MI355X_DMA_TAIL": "3", "SRLA_MI355X_JOB_SAMPLES": "131072"},
-    "pin_everything": {"SRLA_MI355X_PIN_MIN_MB": "0"},
+ROUND5_OPTIONS = {
+    "round_4_fft": {"SRLA_MI355X_FFT_WP": "0"},
+    "round_4_fir": {"SRLA_MI355X_FIR_MFMA": "0"},
+    "copy_out_kernel_everywhere_small_jobs": {"SRLA_MI355X_DMA_OUT": "0", "SRLA_MI355X_JOB_SAMPLES": "131072"},
 }
 
 
-@pytest.mark.parametrize("option", sorted(ROUND4_OPTIONS))
-def test_round_4_options_give_the_same_bytes(product, monkeypatch, option):
-    """the measured alternatives of round 4 are options, not dead code: each gives the oracle's bytes --
-    on 16-bit stereo with every block size class (-B 8192 -V 2 -P 3: both srla_residual_cost launches), on 24-bit 3-channel input
-    (variant planes as int32), on mono, and on a stream DECLARED 16 bits wide whose samples are not (the variant planes' fall-back)"""
-    for k, v in ROUND4_OPTIONS[option].items():
+@pytest.mark.parametrize("option", sorted(ROUND5_OPTIONS))
+def test_round_5_options_give_the_same_bytes(product, monkeypatch, option):
+    """the A/B switches of round 5 (the transform with a workgroup barrier per stage, the FIR on
+    v_dot2 / v_dot4) give the oracle's bytes like the defaults -- on 16-bit stereo with every block size class (-B 8192 -V 2 -P 3:
+    both srla_residual_cost launches), on 24-bit 3-channel input, on mono, and on a stream declared 16 bits wide whose samples are not"""
+    for k, v in ROUND5_OPTIONS[option].items():
         monkeypatch.setenv(k, v)
     cases = [(helpers.synth(helpers.MUSIC, 81, 48000, 2, 300_001), 16, dict(preset=4, max_block=8192, divisions=2, ltp_order=3)),
              (helpers.synth(helpers.VARIED, 82, 48000, 3, 120_000, 24), 24, dict(preset=4, max_block=4096, divisions=1)),

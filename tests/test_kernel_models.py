@@ -1,4 +1,4 @@
-"""CPU models of the integer / indexing tricks the round-3 kernels rest on (srla_amd/csrc/kernels.hip), each checked against the
+"""CPU models of the integer / indexing tricks the round-3 kernels rest on (srla_amd/csrc/*.hip), each checked against the
 plain formula it replaces.  No GPU: the GPU parity tests compare the kernels themselves with the oracle; these pin WHY they are
 exact, at sizes and corner values the audio never reaches.
 
@@ -117,7 +117,7 @@ def test_split_into_planes_is_exact_and_the_high_plane_vanishes_within_16_bits()
 
 
 def code_cost_var(u, k, rice):
-    """the sample-dependent part of srla_coder.c:327-347 (kernels.hip code_cost_var)"""
+    """the sample-dependent part of srla_coder.c:327-347 (residual_cost.hip code_cost_var)"""
     thr = 0 if rice else (2 << k)
     return max(u - thr, 0) >> k
 

@@ -1,11 +1,11 @@
 #!/bin/bash
 # A/B of compile-time variants on the GPU box (hipcc is in the image): for every argument -- a string of -D flags, "" for the
-# default build -- rebuild kernels.hip with it, run a quick parity subset, then print bench figures for the given configurations.
+# default build -- rebuild the kernel files with it, run a quick parity subset, then print bench figures for the given configurations.
 #   usage: CFGS="M C3" tools/ab_variants.sh "" "-DSRLA_FFT_SWZ12" "-DSRLA_TW_DERIVE"
 CFGS="${CFGS:-M C3}"
 REPS="${REPS:-2}"
 for v in "$@"; do
-  touch srla_amd/csrc/kernels.hip
+  touch srla_amd/csrc/kernels_common.h
   make -s -C srla_amd/csrc EXTRA="$v" -j8 2>&1 | grep -E "error" | head -5
   if [ "${PARITY:-1}" = "1" ]; then
     python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "golden or item_records or full_scale" 2>&1 | tail -1
@@ -29,4 +29,4 @@ P
   done
 done
 # leave the default build behind
-touch srla_amd/csrc/kernels.hip; make -s -C srla_amd/csrc -j8 2>&1 | grep -E "error" | head -5
+touch srla_amd/csrc/kernels_common.h; make -s -C srla_amd/csrc -j8 2>&1 | grep -E "error" | head -5

@@ -33,13 +33,23 @@ d = torch.from_numpy(pcm).cuda()
 out = torch.empty(cap, dtype=torch.uint8).pin_memory()
 run = lambda: L.SRLAMI355X_EncodeWholeDevice(enc, C.c_void_p(d.data_ptr()), n, n, C.c_void_p(out.data_ptr()), cap, C.byref(sz), None)
 tab = (C.c_ulonglong * 32)()
+
+
+def read_tables():
+    for k, name in enumerate(("autocorr", "residual_cost")):
+        part = (C.c_ulonglong * 16)()
+        assert getattr(L, "SRLAMI355X_DiagPhases_" + name)(part) == 0
+        for p in range(16):
+            tab[16 * k + p] = part[p]
+
+
 assert run() == 0
 torch.cuda.synchronize()
-assert L.SRLAMI355X_DiagPhases(tab) == 0        # discard the warm-up
+read_tables()                                   # discard the warm-up
 for _ in range(3):
     assert run() == 0
 torch.cuda.synchronize()
-assert L.SRLAMI355X_DiagPhases(tab) == 0
+read_tables()
 names = [["loads landed", "tap sums + tap", "pre-emphasis + window", "first forward stage", "forward stages 2..", "spectrum pass", "first inverse stage",
           "inverse stages 2..", "lag stores", "item record fetched"],
          ["loads landed", "pre-emphasis, planes, taps", "LTP", "FIR + residual", "partition means", "residual store", "Rice parameters", "code bits + reductions", "arg-min + record"]]
