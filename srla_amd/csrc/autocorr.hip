@@ -615,12 +615,25 @@ __device__ __forceinline__ void autocorr_item(
      * same sixteen cache lines as the chunk's own 16-byte load -- two thirds of the kernel's L1 work, and the wavefronts spent a
      * quarter of their lifetime waiting for their samples: profiles/r05/phases_*.txt.) */
     int32_t edge[CH];
+    /* a block that fills its transform (the bulk: every candidate but a stream's tail) with 16-byte aligned planes: every chunk is whole,
+     * so the loads need no per-lane bounds (a wave-uniform test instead of exec-mask bookkeeping on the path every wavefront starts with) */
+    const bool full = NFFT != 0 && n == (uint32_t)NFFT && aligned && 4u * CH * NTK == (uint32_t)NFFT;
+    if (full) {
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+            const uint32_t i4 = 4u * (tid + (uint32_t)c * NTK);
+            load_chunk(in, iv, it.variant, i4, i4 + 4u, true, v[c]);
+            const bool need_prev = lane == 0 && i4 != 0, need_next = lane == 63 && first_pass && i4 + 4 < n;
+            edge[c] = (need_prev || need_next) ? load_variant(in, iv, it.variant, need_prev ? i4 - 1 : i4 + 4) : 0;
+        }
+    } else {
 #pragma unroll
     for (int c = 0; c < CH; c++) {
         const uint32_t i4 = 4u * (tid + (uint32_t)c * NTK);
         load_chunk(in, iv, it.variant, i4, n, aligned, v[c]);
         const bool need_prev = lane == 0 && i4 != 0 && i4 < n, need_next = lane == 63 && first_pass && i4 + 4 < n;
         edge[c] = (need_prev || need_next) ? load_variant(in, iv, it.variant, need_prev ? i4 - 1 : i4 + 4) : 0;
+    }
     }
 #pragma unroll
     for (int c = 0; c < CH; c++) {
@@ -780,6 +793,7 @@ __device__ __forceinline__ void autocorr_item(
          * both factors are small integers, so they are formed as doubles by exact additions from one conversion per
          * thread instead of two int -> double conversions per sample (quarter-rate instructions) */
         const double d_tid4 = (double)(4u * tid), d_nm1 = (double)(n - 1u);
+        const double div_scaled = g.welch_divisor * norm_bps;      /* exact: norm_bps is a power of two */
 #pragma unroll
         for (int c = 0; c < CH; c++) {
             const uint32_t i4 = 4u * (tid + (uint32_t)c * NTK);
@@ -787,7 +801,16 @@ __device__ __forceinline__ void autocorr_item(
                 double w[4];
                 const double de0 = d_tid4 + (double)(4 * c * NTK);          /* (double)i4, exact */
                 const bool first = i4 + 4u <= half, second = i4 >= n - half && i4 + 4u <= n;
-                if (first || second) {
+                if (full) {
+                    /* chunk rounds c < CH / 2 lie in the first half, the others in the second: no selects.  The sample's scaling is
+                     * folded into the divisor (a power of two: every product keeps its rounding) */
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const double de = de0 + (double)i, dr = d_nm1 - de;
+                        const double a = (c < CH / 2) ? de : dr, b = (c < CH / 2) ? dr : de;
+                        w[i] = (double)v[c][i] * (div_scaled * a * b);
+                    }
+                } else if (first || second) {
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
                         const double de = de0 + (double)i, dr = d_nm1 - de;   /* (double)e and (double)(n - 1 - e), exact */

@@ -206,12 +206,21 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
 
     /* load + pre-emphasis (srla_utility.c:342) */
     int32_t y[S];
-    const uint32_t load_variant_as = it.variant;
+    /* (every chunk of these blocks is whole: with aligned planes -- a wave-uniform test -- the loads carry no per-lane bounds) */
+    if (aligned) {
 #pragma unroll
-    for (int c = 0; c < CH; c++) {
-        int32_t t4[4];
-        load_chunk(in, iv, load_variant_as, s_base + 4 * c, n, aligned, t4);
-        y[4 * c] = t4[0]; y[4 * c + 1] = t4[1]; y[4 * c + 2] = t4[2]; y[4 * c + 3] = t4[3];
+        for (int c = 0; c < CH; c++) {
+            int32_t t4[4];
+            load_chunk(in, iv, it.variant, s_base + 4 * c, s_base + 4 * c + 4, true, t4);
+            y[4 * c] = t4[0]; y[4 * c + 1] = t4[1]; y[4 * c + 2] = t4[2]; y[4 * c + 3] = t4[3];
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+            int32_t t4[4];
+            load_chunk(in, iv, it.variant, s_base + 4 * c, n, aligned, t4);
+            y[4 * c] = t4[0]; y[4 * c + 1] = t4[1]; y[4 * c + 2] = t4[2]; y[4 * c + 3] = t4[3];
+        }
     }
     /* FIR_DOT: the taps a thread will pack (group tid of four taps and its three neighbours on either side) are requested HERE,
      * behind the sample loads and ahead of everything that waits for them, so that their round trip to the item record (which

@@ -53,7 +53,7 @@ def test_a_rank_that_dies_ends_the_run_instead_of_hanging_it():
 @pytest.mark.gpu
 def test_two_ranks_on_one_shared_gpu():
     """the real flow, two ranks on the one GPU of the test box (SRLA_BENCH_SHARED_GPU: barrier / reduce over gloo)"""
-    line = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--seconds", "60", "--no-cpu-baseline"],
+    line = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--seconds", "60", "--calls-per-step", "20", "--no-cpu-baseline"],
                 env_extra={"SRLA_BENCH_SHARED_GPU": "1"}, timeout=600)
     assert line["n_gpus"] == 2 and line["lossless_roundtrip"] is True and line["value"] > 0
     assert "EncodeWhole" in line["config"]["workload"]
@@ -64,7 +64,7 @@ def test_four_ranks_with_the_host_budget_of_an_eight_gpu_node():
     """8 ranks share 16 CPUs on the pod: one pool thread per rank (--pack-threads 1).  Four ranks on the one GPU of the test box
     with that budget: every rank's streams decode back to its input, no rank stages its pageable planes (they are locked in
     place and read by DMA, the output is written in place by the device), and the line says so."""
-    line = _run(["--gpus", "4", "--steps", "2", "--warmup", "1", "--seconds", "120", "--no-cpu-baseline", "--pack-threads", "1"],
+    line = _run(["--gpus", "4", "--steps", "2", "--warmup", "1", "--seconds", "120", "--calls-per-step", "100", "--no-cpu-baseline", "--pack-threads", "1"],
                 env_extra={"SRLA_BENCH_SHARED_GPU": "1"}, timeout=900)
     assert line["n_gpus"] == 4 and line["lossless_roundtrip"] is True and line["value"] > 0
     pr = line["per_rank"]

@@ -539,12 +539,19 @@ def test_random_configurations_match_the_oracle(product, count, seed, options, l
     block sizes (odd ones, explicit minimum / maximum / look-ahead triples), division depths, look-ahead factors, LTP orders,
     lengths and signal kinds; with `--mutate` (spliced silence, full-scale bursts, identical channels ...), `--paths` (pageable,
     pinned, device-resident input, block-by-block calls) and `--history` (only the regimes whose blocks depend on the handle's
-    history) draws; bytes must equal the oracle's."""
+    history) draws; bytes must equal the oracle's.  Each sweep runs as the tool it is, in a process of its own (hundreds of
+    handles and streams of every shape: not something to pile onto the test process's heap), its output in the assertion."""
+    import subprocess
     import sys
-    sys.path.insert(0, os.path.join(helpers.ROOT, "tools"))
-    import gpu_sweep
-    done, bad = gpu_sweep.sweep(count, seed, max_samples=1_500_000, **options)
-    assert done >= least and bad == 0
+    flags = [f for f, on in (("--mutate", options.get("with_mutations")), ("--paths", options.get("with_paths")),
+                             ("--history", options.get("only_history"))) if on]
+    p = subprocess.run([sys.executable, os.path.join(helpers.ROOT, "tools", "gpu_sweep.py"), str(count), str(seed), "--max-samples=1500000"] + flags,
+                       capture_output=True, text=True, timeout=1500, cwd=helpers.ROOT)
+    tail = (p.stdout + p.stderr)[-3000:]
+    assert p.returncode == 0, tail
+    import re
+    m = re.search(r"sweep: (\d+) compared, (\d+) mismatches", p.stdout)
+    assert m and int(m.group(1)) >= least and int(m.group(2)) == 0, tail
 
 
 @pytest.mark.parametrize("pinned", [False, True])

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity sweep on an MI355X: library bytes vs oracle bytes over random configurations and lengths.
 
-    python tools/gpu_sweep.py [cases] [seed] [--mutate] [--history] [--paths]
+    python tools/gpu_sweep.py [cases] [seed] [--mutate] [--history] [--paths] [--max-samples=N]
 
 Any length, odd ones included (the last window of such a stream is history dependent in the reference and goes
 through the library's chain mode); LTP with any minimum block and odd block sizes (history mode: every
@@ -248,7 +248,8 @@ def sweep(count, seed, max_samples=6_000_000, with_mutations=False, only_history
 
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
-    done, bad = sweep(int(args[0]) if len(args) > 0 else 150, int(args[1]) if len(args) > 1 else 1, with_mutations="--mutate" in sys.argv,
+    cap = [int(a.split("=", 1)[1]) for a in sys.argv[1:] if a.startswith("--max-samples=")]
+    done, bad = sweep(int(args[0]) if len(args) > 0 else 150, int(args[1]) if len(args) > 1 else 1, **({"max_samples": cap[0]} if cap else {}), with_mutations="--mutate" in sys.argv,
                       only_history="--history" in sys.argv, with_paths="--paths" in sys.argv)
     print("sweep: %d compared, %d mismatches" % (done, bad))
     sys.exit(1 if bad else 0)
