@@ -690,6 +690,10 @@ def main(argv=None):
             osz = C.c_uint32(0)
             reps = max(4, min(calls, 24))
             reps -= reps % 2
+            # (one untimed call on the second stream: its pages and its output buffer's are touched for the first time there)
+            rc = L.SRLAEncoder_EncodeWhole(enc, oplanes, n, oout.ctypes.data_as(C.c_void_p), cap, C.byref(osz), None)
+            if rc != capi.OK:
+                raise SystemExit("SRLAEncoder_EncodeWhole (alternating, warm-up) -> %d" % rc)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             for k in range(reps):

@@ -5,6 +5,7 @@
  * bytes -> host memory where the host does not copy them itself).  DESIGN.md 3.4, 3.5.
  */
 #include "kernels_common.h"
+SRLA_DIAG_PHASE_READER(pack)
 
 /* ------------------------------------------------------------------------- pricing -------- */
 /* One wave per window.  Block cost: ComputeBlockSize (srla_encoder.c:1477-1546) on top of the
@@ -337,8 +338,10 @@ __device__ __forceinline__ void pack_block_body(
     const uint32_t nch = jp.num_channels, bps = jp.bits_per_sample, n = recp->n, T = recp->bytes;
     const uint32_t block_type = recp->block_type, sample_off = recp->sample_off;
     const uint32_t nwords = ((T + 3u) >> 2) + 1u;
+    PHASE_INIT();
     for (uint32_t i = tid; i < nwords; i += NT) w[i] = 0;
     __syncthreads();
+    PHASE(0);                                                       /* record fetched, words zeroed */
     if (tid == 0) {
         put_bits<G>(w, 0, 0xFFFFu, 16);                 /* sync code */
         put_bits<G>(w, 16, T - 11u + 5u, 32);           /* size of what follows the size field */
@@ -416,6 +419,7 @@ __device__ __forceinline__ void pack_block_body(
          * 16-byte loads and kept in registers for both passes. */
         constexpr uint32_t CACHE = 16;                                   /* residuals a thread can keep */
         uint32_t chan_base = 88u + hdr_bits;
+        PHASE(1);                                                   /* payload header (wave 0), the others wait at the first barrier below */
         for (uint32_t ch = 0; ch < nch; ch++) {
             const uint32_t item = recp->item[ch];
             const SrlaItemResult *ir = &results[item];
@@ -455,6 +459,7 @@ __device__ __forceinline__ void pack_block_body(
                     }
                 }
                 __syncthreads();                                         /* kp is complete */
+                PHASE(2);                                                /* parameters to LDS, residuals fetched */
                 /* pass 1: bits this thread will emit */
                 uint32_t mybits = 0;
                 {
@@ -484,6 +489,7 @@ __device__ __forceinline__ void pack_block_body(
                 __syncthreads();
                 uint32_t pos = chan_base + incl - mybits;
                 for (uint32_t k = 0; k < wave; k++) pos += aux[k];
+                PHASE(3);                                                /* pass 1 + prefix sum */
                 /* pass 2: emit */
                 {
                     uint32_t part = part0, next = (part0 + 1) * plen;
@@ -522,6 +528,7 @@ __device__ __forceinline__ void pack_block_body(
                 }
             }
             chan_base += total_bits;
+            PHASE(4);                                                    /* pass 2: emit */
         }
         end_bits = chan_base;
     }
@@ -555,6 +562,7 @@ __device__ __forceinline__ void pack_block_body(
         __syncthreads();
     }
 
+    PHASE(5);                                                       /* Fletcher-16 */
     /* store at the block's byte offset of the stream: bytes up to the first 16-byte boundary, 16-byte body, tail */
     {
         const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 15u);
@@ -581,6 +589,7 @@ __device__ __forceinline__ void pack_block_body(
             *reinterpret_cast<uint4 *>(dst + head + (v << 4)) = o;
         }
     }
+    PHASE(6);                                                       /* store */
 }
 
 __global__ __launch_bounds__(NT) void srla_pack_blocks(

@@ -166,10 +166,14 @@ __device__ __forceinline__ int group_offset(int d)
  * 2048-sample blocks on 256 threads) it outweighs the per-sample work (cut-short timing: 45 % of a -V 2 launch).  With 2^LG items
  * per workgroup an item has T = 256 >> LG threads of 4 FL << LG samples each; `lds`, `in`, `it`, `out` are the thread's own item's,
  * barriers are the workgroup's (the items run in lock step: every barrier below is reached by all of them). */
+/* what the analysis kernels before this one left in the item record and every thread needs at once: fetched by the kernel FIRST,
+ * beside the item descriptor (the record's address needs only the workgroup's index), not behind it */
+struct ItemHead { int32_t preemph_coef; uint32_t order, rshift, period; int32_t ltp_coef[3]; };
+
 template <int FL, int MODE, int LG = 0>
 __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, const InputView &iv, const int32_t *__restrict__ in, const SrlaItemDesc &it,
                                    unsigned char *lds, const double *__restrict__ rice_thresholds,
-                                   int32_t *__restrict__ res_ws, SrlaItemResult *__restrict__ out)
+                                   int32_t *__restrict__ res_ws, SrlaItemResult *__restrict__ out, const ItemHead &head)
 {
     constexpr int T = NT >> LG, WPI = T / WAVE;                  /* threads, wavefronts per item */
     constexpr int CH = FL << LG;                                /* chunks of four samples per thread */
@@ -194,11 +198,24 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
     const uint32_t tid = threadIdx.x & (uint32_t)(T - 1), lane = tid & 63, wave = tid >> 6;   /* thread, wavefront within the item */
     const uint32_t n = 1024u * FL, bps = jp.bits_per_sample;
     const bool aligned = input_aligned(in, iv);
-    const int32_t coef = out->preemph_coef;
-    const uint32_t order = out->lpc_order, rshift = out->lpc_rshift, period = out->ltp_period;
+    const int32_t coef = head.preemph_coef;
+    const uint32_t order = head.order, rshift = head.rshift, period = head.period;
     const uint32_t o4 = (order + 3u) & ~3u;
     const uint32_t s_base = (uint32_t)S * tid;
     PHASE_INIT();
+    /* FIR_MFMA: the words of the item record's tap array a thread's words of the shifted tap strings are made of (wavefront s builds
+     * copy s; words lane and lane + 64 of a copy can hold taps, the array's 64 words are always there to be read: no need to know the
+     * order yet, so these go out with the very first requests) */
+    uint32_t tap_lo[2] = { 0u, 0u }, tap_hi[2] = { 0u, 0u };
+    if constexpr (MODE == FIR_MFMA) {
+        const uint32_t *cw = reinterpret_cast<const uint32_t *>(out->lpc_coef);
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const int q0 = ((int)(4u * (lane + 64u * (uint32_t)r)) - (int)wave - MF_OFFZ) >> 2;
+            if (q0 >= 0 && q0 < 64) tap_lo[r] = cw[q0];
+            if (q0 + 1 >= 0 && q0 + 1 < 64) tap_hi[r] = cw[q0 + 1];
+        }
+    }
     /* (two more values that would otherwise be fetched late, in front of a barrier / of the record's last store: requested here,
      * where their round trips run beside the sample loads) */
     const double thr_mine = (tid >= 32 && tid < 64) ? rice_thresholds[tid - 32] : 0.0;
@@ -239,13 +256,10 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
         for (int r = 0; r < TZR; r++) {
             const uint32_t sft = wave, dw = lane + 64u * (uint32_t)r;
             if (dw < mf_ndw) {
-                /* bytes k0 .. k0 + 3 of the tap array (zero outside [0, order)): two aligned words of it -- the taps are a few dozen
-                 * bytes in one or two cache lines, whatever the lane -- funnel-shifted by the copy's shift, then masked */
+                /* bytes k0 .. k0 + 3 of the tap array (zero outside [0, order)): the two aligned words of it fetched at the top (tap_lo /
+                 * tap_hi), funnel-shifted by the copy's shift, then masked */
                 const int k0 = (int)(4u * dw) - (int)sft - MF_OFFZ;
-                const int q0 = k0 >> 2, nq = (int)((order + 3u) >> 2);
-                const uint32_t *cw = reinterpret_cast<const uint32_t *>(out->lpc_coef);
-                const uint32_t lo = (q0 >= 0 && q0 < nq) ? cw[q0] : 0u, hi = (q0 + 1 >= 0 && q0 + 1 < nq) ? cw[q0 + 1] : 0u;
-                const uint32_t w = __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)(k0 & 3));
+                const uint32_t w = (r < 2) ? __builtin_amdgcn_alignbyte(tap_hi[r < 2 ? r : 0], tap_lo[r < 2 ? r : 0], (uint32_t)(k0 & 3)) : 0u;
                 const int first = (k0 < 0) ? -k0 : 0, last = ((int)order - k0 < 4) ? (int)order - k0 : 4;     /* valid bytes [first, last) */
                 uint32_t mask = 0;
                 if (last > first && first < 4) mask = (0xFFFFFFFFu >> (8 * (4 - last))) & (0xFFFFFFFFu << (8 * first));
@@ -394,7 +408,7 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
         if (period > 0) {
         /* long-term predictor, srla_lpc_predict.c:267-294 (in place: read everything, barrier, rewrite) */
         const uint32_t taps = jp.ltp_order, half_order = taps >> 1;
-        const int32_t c0 = out->ltp_coef[0], c1 = out->ltp_coef[1], c2 = out->ltp_coef[2];
+        const int32_t c0 = head.ltp_coef[0], c1 = head.ltp_coef[1], c2 = head.ltp_coef[2];
         /* the thread's S + 2 source samples are consecutive: one division locates the first one in the padded
          * layout (a pad of four words after every S), the others follow by compare-and-step.  PADS >= the largest
          * period + 2, so the first source index is never negative. */
@@ -1048,6 +1062,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(R >= 4 ? SRL
      * the dozen items that read the same samples then share one L2 instead of pulling them into all eight */
     const uint32_t block = xcd_position(blockIdx.x, jp.num_items);
     if (block >= jp.num_items) return;
+    /* the item record's head and the item descriptor: two independent fetches, issued together */
+    ItemHead head;
+    {
+        const SrlaItemResult *r = &results[block];
+        head.preemph_coef = r->preemph_coef; head.order = r->lpc_order; head.rshift = r->lpc_rshift; head.period = r->ltp_period;
+        head.ltp_coef[0] = r->ltp_coef[0]; head.ltp_coef[1] = r->ltp_coef[1]; head.ltp_coef[2] = r->ltp_coef[2];
+    }
     const SrlaItemDesc itf = items[block];
     if (itf.n > 8192u) return;                       /* srla_residual_cost_big takes these */
     if (jp.rc_hi != 0u && (itf.n <= jp.rc_lo || itf.n > jp.rc_hi)) return;   /* the other launch of the job takes these */
@@ -1060,8 +1081,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(R >= 4 ? SRL
             SrlaItemResult *outf = &results[block];
 #define FAST(FLV)                                                                                                   \
             do {                                                                                                    \
-                if (jp.bits_per_sample <= 18) residual_cost_fast<FLV, (MFMA && FLV <= 4) ? FIR_MFMA : SRLA_FIR_NARROW>(jp, iv, inf, itf, lds, rice_thresholds, res_ws, outf); \
-                else residual_cost_fast<FLV, FIR_WIDE>(jp, iv, inf, itf, lds, rice_thresholds, res_ws, outf);       \
+                if (jp.bits_per_sample <= 18) residual_cost_fast<FLV, (MFMA && FLV <= 4) ? FIR_MFMA : SRLA_FIR_NARROW>(jp, iv, inf, itf, lds, rice_thresholds, res_ws, outf, head); \
+                else residual_cost_fast<FLV, FIR_WIDE>(jp, iv, inf, itf, lds, rice_thresholds, res_ws, outf, head); \
                 return;                                                                                             \
             } while (0)
             switch (fl) {

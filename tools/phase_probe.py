@@ -32,11 +32,11 @@ sz = C.c_uint32(0)
 d = torch.from_numpy(pcm).cuda()
 out = torch.empty(cap, dtype=torch.uint8).pin_memory()
 run = lambda: L.SRLAMI355X_EncodeWholeDevice(enc, C.c_void_p(d.data_ptr()), n, n, C.c_void_p(out.data_ptr()), cap, C.byref(sz), None)
-tab = (C.c_ulonglong * 32)()
+tab = (C.c_ulonglong * 48)()
 
 
 def read_tables():
-    for k, name in enumerate(("autocorr", "residual_cost")):
+    for k, name in enumerate(("autocorr", "residual_cost", "pack")):
         part = (C.c_ulonglong * 16)()
         assert getattr(L, "SRLAMI355X_DiagPhases_" + name)(part) == 0
         for p in range(16):
@@ -52,8 +52,9 @@ torch.cuda.synchronize()
 read_tables()
 names = [["loads landed", "tap sums + tap", "pre-emphasis + window", "first forward stage", "forward stages 2..", "spectrum pass", "first inverse stage",
           "inverse stages 2..", "lag stores", "item record fetched"],
-         ["loads landed", "pre-emphasis, planes, taps", "LTP", "FIR + residual", "partition means", "residual store", "Rice parameters", "code bits + reductions", "arg-min + record"]]
-for k, kn in enumerate(("srla_autocorr (all classes)", "srla_residual_cost (fast path)")):
+         ["loads landed", "pre-emphasis, planes, taps", "LTP", "FIR + residual", "partition means", "residual store", "Rice parameters", "code bits + reductions", "arg-min + record"],
+         ["record fetched, words zeroed", "payload header", "parameters + residuals fetched", "pass 1 + prefix sum", "pass 2: emit", "Fletcher-16", "store"]]
+for k, kn in enumerate(("srla_autocorr (all classes)", "srla_residual_cost (fast path)", "srla_pack_blocks")):
     row = [tab[16 * k + p] for p in range(16)]
     tot = float(sum(row)) or 1.0
     print("%s: %.3g wave-ticks" % (kn, tot))
