@@ -237,6 +237,7 @@ bool Impl::stage_input(Slot &s, const JobPlan &plan)
             if (!s.d_input16.ensure(nch * stride16 * 2)) return false;
             int16_t *dst = s.h_in.as<int16_t>();
             std::atomic<uint32_t> wide{ 0 };
+            const auto t_pack = Clock::now();
             pool->parallel_for((uint32_t)tasks.size(), [&](uint32_t i) {
                 const Task &t = tasks[i];
                 const SegPlan &sp = plan.segs[t.seg];
@@ -245,6 +246,7 @@ bool Impl::stage_input(Slot &s, const JobPlan &plan)
                 seg_or[t.seg].fetch_or(m, std::memory_order_relaxed);
                 if (w) wide.fetch_or(w, std::memory_order_relaxed);
             });
+            if (timeline) tl_printf("[timeline] host: %zu staging tasks took %.3f ms\n", tasks.size(), ms_since(t_pack));
             if (wide.load() == 0) {
                 HIP_OK(hipMemcpyAsync(s.d_input16.p, s.h_in.p, nch * stride16 * 2, hipMemcpyHostToDevice, upload));
                 if (srla_launch_widen16(upload, s.d_input16.as<int16_t>(), stride16, s.d_input.as<int32_t>(), total, nch) != 0) return false;
