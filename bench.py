@@ -85,7 +85,7 @@ class Stats(C.Structure):
                 ("num_tie_resolved", C.c_uint64), ("num_tie_overrides", C.c_uint64), ("num_restarts", C.c_uint64),
                 ("num_inplace_pins", C.c_uint64), ("num_inplace_out_pins", C.c_uint64),
                 ("num_nonidentical_calls", C.c_uint64), ("nonidentical_reasons", C.c_uint64), ("num_svr_tie_items", C.c_uint64),
-                ("num_history_windows", C.c_uint64), ("pitch_ms", C.c_double)]
+                ("num_history_windows", C.c_uint64), ("pitch_ms", C.c_double), ("num_hybrid_jobs", C.c_uint64)]
 
 
 def usable_cpus():
@@ -635,7 +635,8 @@ def main(argv=None):
             # how the pageable buffers reached the device: staged through pinned buffers by the pool threads, or -- when the
             # ranks' share of the CPU quota is too small for that -- page-locked in place for the call and read by DMA
             "host_buffers": ("pinned by the caller" if args.pinned_io else "input: %s; output: %s" % (
-                "page-locked in place per call (hipHostRegister), read by DMA" if st.num_inplace_pins else
+                ("page-locked in place per call (hipHostRegister), read by DMA" + (
+                    "; half of the channels packed to int16 on the way by %d host thread(s)" % pack_threads if st.num_hybrid_jobs else "")) if st.num_inplace_pins else
                 "staged through pinned buffers by %d host threads" % pack_threads,
                 "page-locked in place per call, written by the device" if st.num_inplace_out_pins else "copied out of pinned staging buffers")),
         })

@@ -237,6 +237,7 @@ struct SRLAMI355XStats {
     uint64_t num_svr_tie_items;     /* SVR refinement: items with an objective comparison inside the libm tolerance (arbitrated on the host) */
     uint64_t num_history_windows;   /* look-ahead windows encoded in history mode (in the reference's own call order, window by window) */
     double   pitch_ms;              /* srla_pitch_solve, timed jobs only (jobs whose stage A runs in two parts; otherwise inside autocorr_ms) */
+    uint64_t num_hybrid_jobs;       /* jobs of input planes locked in place of which half the channels went through the int16 staging buffer */
 };
 /* reasons (SRLAMI355XStats::nonidentical_reasons, SRLAMI355X_NonIdenticalReasons) */
 #define SRLAMI355X_NONIDENTICAL_SVR_HISTORY 1u  /* SVR refinement on, in a window whose blocks depend on the calls before them (odd lengths,

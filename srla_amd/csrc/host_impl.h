@@ -194,6 +194,7 @@ struct Impl {
      * buffers always, input planes when the pool has too few threads to stage at the GPU's pace (N ranks sharing a CPU quota);
      * 0 / 1: never / always (SRLA_MI355X_PIN_INPLACE) */
     int pin_inplace = -1;
+    bool hybrid_inplace = true;         /* SRLA_MI355X_HYBRID=0: planes locked in place cross the link as int32, all of them (stage_input) */
     bool pin_too_slow = false;          /* registration measured slower than staging would be (no huge pages): not tried again */
     static constexpr uint32_t kRunAhead = 8;      /* jobs the host may be ahead of the stage skew (bounded by the buffer sets) */
     /* Output by host-issued copies (the default where it applies: a call of more than three jobs whose streams' buffers the

@@ -216,10 +216,46 @@ bool Impl::stage_input(Slot &s, const JobPlan &plan)
         /* the caller's planes are pinned: DMA straight out of them (the OR of the samples, where it is still being
          * gathered, is computed by the pool threads meanwhile) */
         /* (one stream: the channels' copies spread over two streams / SDMA engines were 15 % slower) */
-        for (const SegPlan &sp : plan.segs)
-            for (uint32_t ch = 0; ch < nch; ch++)
-                HIP_OK(hipMemcpyAsync(s.d_input.as<int32_t>() + (size_t)ch * total + sp.base, sx[sp.stream].host_in[ch] + sp.s0,
-                                      (size_t)sp.ns * 4, hipMemcpyHostToDevice, upload));
+        /* Planes locked in place because the pool is too small to stage them (one host thread per rank on an 8-GPU node): as int32
+         * they are 8 bytes per stereo instant on a link that carries 53 GB/s, and the link sets the pace (5 460 instead of 7 200
+         * Msamples/s).  The one thread CAN pack half of them meanwhile (0.43 ms per channel of a 4 Mi-instant job at the
+         * 40 GB/s one core reads, while the other channel's 16.7 MB cross the link in 0.31 ms): the first nch / 2 channels of a stream
+         * of at most 16 bits go through the int16 staging buffer, the others are read where they lie -- 6 bytes per instant. */
+        /* (a pool of four and more threads packs all of them in less time than the link needs for the packed planes: planes pinned by
+         * the CALLER, 8 threads: 5 400 - 5 520 as they lie, 6 400 - 6 660 with half of them packed) */
+        uint32_t staged_ch = (hybrid_inplace && par.bits_per_sample <= 16 && !no_pack16) ? ((pool->size() >= 4) ? nch : nch / 2u) : 0u;
+        auto direct = [&](uint32_t ch0, uint32_t ch1) -> bool {
+            for (const SegPlan &sp : plan.segs)
+                for (uint32_t ch = ch0; ch < ch1; ch++)
+                    HIP_OK(hipMemcpyAsync(s.d_input.as<int32_t>() + (size_t)ch * total + sp.base, sx[sp.stream].host_in[ch] + sp.s0,
+                                          (size_t)sp.ns * 4, hipMemcpyHostToDevice, upload));
+            return true;
+        };
+        if (!direct(staged_ch, nch)) return false;
+        if (staged_ch != 0) {
+            const size_t stride16 = total;
+            if (!s.h_in.ensure((size_t)staged_ch * stride16 * 2 + 64u * nch) || !s.d_input16.ensure((size_t)staged_ch * stride16 * 2)) return false;
+            tasks.clear();
+            for (uint32_t k = 0; k < nseg; k++)
+                for (uint32_t ch = 0; ch < staged_ch; ch++)
+                    for (uint32_t o = 0; o < plan.segs[k].ns; o += chunk) tasks.push_back({ k, ch, o, std::min(chunk, plan.segs[k].ns - o) });
+            int16_t *dst = s.h_in.as<int16_t>();
+            std::atomic<uint32_t> wide{ 0 };
+            const auto t_pack = Clock::now();
+            pool->parallel_for((uint32_t)tasks.size(), [&](uint32_t i) {
+                const Task &t = tasks[i];
+                const SegPlan &sp = plan.segs[t.seg];
+                uint32_t w = 0;
+                (void)pack16_or(dst + (size_t)t.ch * stride16 + sp.base + t.off, sx[sp.stream].host_in[t.ch] + sp.s0 + t.off, t.len, &w);
+                if (w) wide.fetch_or(w, std::memory_order_relaxed);
+            });
+            if (timeline) tl_printf("[timeline] host: %zu staging tasks (%u of %u channels) took %.3f ms\n", tasks.size(), staged_ch, nch, ms_since(t_pack));
+            if (wide.load() == 0) {
+                HIP_OK(hipMemcpyAsync(s.d_input16.p, s.h_in.p, (size_t)staged_ch * stride16 * 2, hipMemcpyHostToDevice, upload));
+                if (srla_launch_widen16(upload, s.d_input16.as<int16_t>(), stride16, s.d_input.as<int32_t>(), total, staged_ch) != 0) return false;
+                stats.num_hybrid_jobs++;
+            } else if (!direct(0, staged_ch)) return false;   /* samples beyond 16 bits in a stream declared narrower: as they lie */
+        }
         /* the OR of the samples, where it is still being gathered: on the device, from the uploaded copy */
         for (const SegPlan &sp : plan.segs) {
             const StreamCtx &st = sx[sp.stream];
@@ -880,7 +916,7 @@ SRLAApiResult Impl::encode_streams(bool search)
     } dma_guard{ this };
     /* pageable planes are locked in place when the pool is too small to stage them (all jobs by DMA then), and otherwise too
      */
-    const bool few_threads = pool->size() < 6;
+    const bool few_threads = pool->size() < 4;     /* (round 5, with half of the channels packed on the way: 1 - 3 threads in place + 12 ... 30 %, 4 and more equal on long streams and staging ahead on short ones: profiles/r05/ab_hybrid_input.txt) */
     const bool want_pins = !force_staging && !pin_too_slow && (pin_inplace == 1 || (pin_inplace < 0 && few_threads));
     bool need_oracc = false;
     /* parameters under which blocks anywhere in the stream depend on the calls before them: window by window (host_chain.cpp) */
@@ -903,11 +939,12 @@ SRLAApiResult Impl::encode_streams(bool search)
     for (uint32_t si = 0; si < nst; si++) {
         StreamCtx &st = sx[si];
         classify_buffers(st, pins.held);
-        /* (streams of less than a few MB are not worth a registration: staging them costs microseconds) */
-        /* ... when the pool is too small to stage (want_pins); where the threads could stage it as well, the OUTPUT buffer of a stream
-         * below pin_min_mb MB of samples is not worth its registration either (releasing it cost 0.07 ms of a 60 s stream's 0.94 ms) */
+        /* (a stream below kPinMinMB MB of samples is not worth a registration, input or output: releasing it cost 0.07 ms of a 60 s
+         * stream's 0.94 ms, and even ONE thread stages such a stream as fast as the link carries it in place -- 60 s of stereo with 1 / 2
+         * / 3 pool threads: 3 170 / 3 400 - 3 530 / 3 650 - 3 700 Msamples/s staged, 2 940 - 3 170 / 3 090 / 3 100 in place; from 120 s on
+         * the planes in place win (profiles/r05/ab_hybrid_input.txt).  SRLA_MI355X_PIN_INPLACE=1 asks for it from 4 MB on.) */
         const uint64_t sample_bytes = (uint64_t)st.num_samples * nch * 4u;
-        const bool worth_pinning = sample_bytes >= (want_pins ? (uint64_t)(4u << 20) : ((uint64_t)kPinMinMB << 20));
+        const bool worth_pinning = sample_bytes >= ((pin_inplace == 1) ? (uint64_t)(4u << 20) : ((uint64_t)kPinMinMB << 20));
         if (want_pins && worth_pinning && st.host_in && !st.in_pinned) {
             const size_t before = pins.held.size();
             bool ok = true;

@@ -26,6 +26,7 @@ void Impl::read_environment()
     no_speculation = is_set("SRLA_MI355X_NO_SPECULATION");     /* host input: the OR pass for the offset shift always runs first */
     no_pack16 = is_set("SRLA_MI355X_NO_PACK16");               /* host input always crosses PCIe as int32 */
     force_staging = is_set("SRLA_MI355X_STAGING");             /* never let the device read / write the caller's buffers */
+    if (is_set("SRLA_MI355X_HYBRID")) hybrid_inplace = number("SRLA_MI355X_HYBRID", 1) != 0;
     if (is_set("SRLA_MI355X_PIN_INPLACE")) pin_inplace = number("SRLA_MI355X_PIN_INPLACE", 0) != 0 ? 1 : 0;   /* else by pool size */
 
     /* ---- sizing ---------------------------------------------------------------------------------------------------- */

@@ -714,6 +714,40 @@ def test_round_5_options_give_the_same_bytes(product, monkeypatch, option):
         assert np.array_equal(product.encode(pcm, bits_per_sample=bps, **cli), want), (option, pcm.shape, bps, cli)
 
 
+@pytest.mark.parametrize("hybrid,threads", [("1", "1"), ("1", "8"), ("0", "1")])
+def test_planes_locked_in_place_with_some_channels_packed_on_the_way(product, monkeypatch, hybrid, threads):
+    """Pageable planes locked in place for the call (what a rank with one host thread gets: DESIGN.md 8): of a stream of at most 16
+    bits the first nch / 2 channels (all of them with a pool of four and more threads) cross the link as int16 through the staging
+    buffer, the others are read where they lie; a stream declared 16 bits wide whose samples are not goes as it lies.  Same bytes
+    either way, stereo, three channels, mono, several jobs per call."""
+    import bench
+    monkeypatch.setenv("SRLA_MI355X_PIN_INPLACE", "1")
+    monkeypatch.setenv("SRLA_MI355X_HYBRID", hybrid)
+    monkeypatch.setenv("SRLA_MI355X_PACK_THREADS", threads)
+    monkeypatch.setenv("SRLA_MI355X_JOB_SAMPLES", "262144")
+    cli = dict(preset=4, max_block=4096, divisions=1)
+    cases = [(helpers.synth(helpers.MUSIC, 91, 48000, 2, 3_000_001), 16), (helpers.synth(helpers.VARIED, 92, 48000, 3, 1_500_000), 16),
+             (helpers.synth(helpers.MUSIC, 93, 44100, 1, 2_500_000), 16), (helpers.synth(helpers.NOISE, 94, 48000, 2, 1_500_000, 24), 16)]
+    locked = 0
+    for pcm, bps in cases:
+        want = helpers.Oracle(pcm.shape[0], bits_per_sample=bps, **cli).encode_whole(pcm)
+        cfg, par = capi.cli_setup(pcm.shape[0], bps, 48000, **cli)
+        enc = product.create(cfg)
+        assert product.set_parameter(enc, par) == capi.OK
+        rc, got = product.encode_whole(enc, pcm)
+        st = bench.Stats()
+        product.lib.SRLAMI355X_GetStats.argtypes = [C.c_void_p, C.POINTER(bench.Stats), C.c_int]
+        product.lib.SRLAMI355X_GetStats(enc, C.byref(st), 0)
+        product.destroy(enc)
+        assert rc == capi.OK and np.array_equal(got, want), (pcm.shape, bps)
+        if st.num_inplace_pins != pcm.shape[0]:
+            continue                                  # (the registration was measured too slow on this box: the stream was staged)
+        locked += 1
+        narrow = int(np.abs(pcm).max()) < 32768
+        assert (st.num_hybrid_jobs > 0) == (hybrid == "1" and narrow and (pcm.shape[0] >= 2 or threads == "8")), (pcm.shape, st.num_hybrid_jobs)
+    assert locked >= 2, "the planes were not locked in place: this test did not see the path it is about"
+
+
 def test_wrong_shift_guess_that_overflows_the_buffer_is_retried(product, monkeypatch):
     """Host input without callback is encoded with the offset shift of its FIRST job while the OR of the rest is still being
     gathered.  16-bit audio in a 24-bit container behind leading digital silence: the guess (0) makes the stream much larger
