@@ -951,12 +951,12 @@ SRLAApiResult Impl::encode_streams(bool search)
             double us_per_mb = 0.0;
             for (uint32_t ch = 0; ch < nch && ok; ch++) {
                 ok = host_pin_acquire(st.host_in[ch], (size_t)st.num_samples * 4, &us_per_mb);
-                if (ok) { pins.held.push_back(st.host_in[ch]); stats.num_inplace_pins++; }
+                if (ok) pins.held.push_back(st.host_in[ch]);
                 /* without huge pages locking costs more than the staging copy it saves: remember, stage */
                 if (ok && us_per_mb > 40.0) { pin_too_slow = true; ok = false; }
             }
             if (!ok) { while (pins.held.size() > before) { host_pin_release(pins.held.back()); pins.held.pop_back(); } }
-            else st.in_pinned = true;
+            else { st.in_pinned = true; stats.num_inplace_pins += nch; }     /* (counted when the stream is read in place, not when a plane's registration turned out too slow and was dropped again) */
         }
         /* the output buffer always (unless switched off): the blocks then land in it straight from the device, which saves the
          * copy out of the staging buffers that the calling thread would otherwise make job by job (M: +5 %, and steadier) */

@@ -81,8 +81,8 @@ def test_eight_ranks_on_one_shared_gpu_with_one_pool_thread_each():
     rank locks its planes and its output in place, and no rank is starved.  The slowest rank's time inside the library per step was
     1.35-1.68x the fastest's over three runs of 3 steps x 16 calls (profiles/r04/eight_ranks_one_gpu.txt) -- eight processes
     time-sharing ONE device's queues, which eight GPUs do not do -- so the bound here is 2x; with 2 steps x 4 calls a single slow
-    page-locking call makes it 2.4-4x, hence the longer steps."""
-    line = _run(["--gpus", "8", "--steps", "3", "--warmup", "1", "--seconds", "60", "--calls-per-step", "16", "--no-cpu-baseline", "--pack-threads", "1"],
+    page-locking call makes it 2.4-4x, hence the longer steps.  (120 s streams: below 32 MB of samples a stream is staged, not locked.)"""
+    line = _run(["--gpus", "8", "--steps", "3", "--warmup", "1", "--seconds", "120", "--calls-per-step", "10", "--no-cpu-baseline", "--pack-threads", "1"],
                 env_extra={"SRLA_BENCH_SHARED_GPU": "1"}, timeout=1200)
     assert line["n_gpus"] == 8 and line["lossless_roundtrip"] is True and line["value"] > 0
     pr = line["per_rank"]
