@@ -274,17 +274,31 @@ bool Impl::stage_input(Slot &s, const JobPlan &plan)
             int16_t *dst = s.h_in.as<int16_t>();
             std::atomic<uint32_t> wide{ 0 };
             const auto t_pack = Clock::now();
-            pool->parallel_for((uint32_t)tasks.size(), [&](uint32_t i) {
-                const Task &t = tasks[i];
-                const SegPlan &sp = plan.segs[t.seg];
-                uint32_t w = 0;
-                const uint32_t m = pack16_or(dst + (size_t)t.ch * stride16 + sp.base + t.off, sx[sp.stream].host_in[t.ch] + sp.s0 + t.off, t.len, &w);
-                seg_or[t.seg].fetch_or(m, std::memory_order_relaxed);
-                if (w) wide.fetch_or(w, std::memory_order_relaxed);
-            });
+            /* Channel by channel, each plane's upload enqueued as soon as it is packed: the link works on the first plane while the
+             * pool packs the second, and the job's samples are on the device half an upload earlier (0.14 ms of the 0.47 ms between a
+             * full job's first staged sample and its first kernel; the first three jobs of a call wait for their samples: host -> host
+             * 7 290 -> 7 400 Msamples/s). */
+            /* (calls of many jobs only: a short stream's one or three jobs lose more to the extra round than the link returns; halves and
+             * quarters of a plane: less, profiles/r05/ab_host_path.txt) */
+            const uint32_t rounds = (call_crowded && nch >= 2 && (size_t)total * 2 >= (512u << 10)) ? nch : 1u;
+            std::vector<uint32_t> mine;
+            for (uint32_t r = 0; r < rounds && wide.load() == 0; r++) {
+                mine.clear();
+                for (uint32_t i = 0; i < tasks.size(); i++) if (rounds == 1 || tasks[i].ch == r) mine.push_back(i);
+                pool->parallel_for((uint32_t)mine.size(), [&](uint32_t j) {
+                    const Task &t = tasks[mine[j]];
+                    const SegPlan &sp = plan.segs[t.seg];
+                    uint32_t w = 0;
+                    const uint32_t m = pack16_or(dst + (size_t)t.ch * stride16 + sp.base + t.off, sx[sp.stream].host_in[t.ch] + sp.s0 + t.off, t.len, &w);
+                    seg_or[t.seg].fetch_or(m, std::memory_order_relaxed);
+                    if (w) wide.fetch_or(w, std::memory_order_relaxed);
+                });
+                if (wide.load() != 0) break;
+                if (rounds == 1) HIP_OK(hipMemcpyAsync(s.d_input16.p, s.h_in.p, nch * stride16 * 2, hipMemcpyHostToDevice, upload));
+                else HIP_OK(hipMemcpyAsync(s.d_input16.as<int16_t>() + (size_t)r * stride16, dst + (size_t)r * stride16, stride16 * 2, hipMemcpyHostToDevice, upload));
+            }
             if (timeline) tl_printf("[timeline] host: %zu staging tasks took %.3f ms\n", tasks.size(), ms_since(t_pack));
             if (wide.load() == 0) {
-                HIP_OK(hipMemcpyAsync(s.d_input16.p, s.h_in.p, nch * stride16 * 2, hipMemcpyHostToDevice, upload));
                 if (srla_launch_widen16(upload, s.d_input16.as<int16_t>(), stride16, s.d_input.as<int32_t>(), total, nch) != 0) return false;
                 packed = true;
             }   /* else: samples beyond 16 bits in a stream declared narrower -- the reference does not mind, nor do we */

@@ -748,6 +748,21 @@ def test_planes_locked_in_place_with_some_channels_packed_on_the_way(product, mo
     assert locked >= 2, "the planes were not locked in place: this test did not see the path it is about"
 
 
+def test_staged_planes_are_uploaded_channel_by_channel(product, monkeypatch):
+    """A call of more than three jobs uploads every channel's packed plane as soon as the pool has packed it (stage_input).  Same
+    bytes as the oracle: stereo and three channels, and a stream declared 16 bits wide whose SECOND channel alone holds wider samples
+    (the first plane has been enqueued as int16 by then; the job is staged again as int32)."""
+    monkeypatch.setenv("SRLA_MI355X_JOB_SAMPLES", "524288")
+    monkeypatch.setenv("SRLA_MI355X_PIN_INPLACE", "0")
+    cli = dict(preset=4, max_block=4096, divisions=1)
+    odd = helpers.synth(helpers.MUSIC, 97, 48000, 2, 2_400_000)
+    odd[1, 1_300_000:1_300_100] = 40_000                         # beyond int16, in the third job's second channel only
+    cases = [helpers.synth(helpers.MUSIC, 95, 48000, 2, 2_700_001), helpers.synth(helpers.VARIED, 96, 48000, 3, 2_300_000), odd]
+    for pcm in cases:
+        want = helpers.Oracle(pcm.shape[0], bits_per_sample=16, **cli).encode_whole(pcm)
+        assert np.array_equal(product.encode(pcm, bits_per_sample=16, **cli), want), pcm.shape
+
+
 def test_wrong_shift_guess_that_overflows_the_buffer_is_retried(product, monkeypatch):
     """Host input without callback is encoded with the offset shift of its FIRST job while the OR of the rest is still being
     gathered.  16-bit audio in a 24-bit container behind leading digital silence: the guess (0) makes the stream much larger
