@@ -174,7 +174,7 @@ STAGES = (
     ("srla_pitch_solve",   "pitch_ms",    True,  ("srla_pitch_solve",)),
     ("srla_lpc_solve",     "solve_ms",    True,  ("srla_lpc_errvars", "srla_order_select", "srla_lpc_taps", "srla_lpc_recursion",
                                                   "srla_lpc_quantize", "srla_svr_refine")),
-    ("srla_residual_cost", "residual_ms", False, ("srla_residual_cost<", "srla_residual_cost_big")),
+    ("srla_residual_cost", "residual_ms", True,  ("srla_residual_cost<", "srla_residual_cost_big")),
     ("srla_price_windows", "price_ms",    True,  ("srla_price_windows",)),
     # block offsets + assembly + the way out: srla_stream_out where the device stores into the caller's buffer, the runtime's
     # copy kernel where the host issues the copies (it also carries the uploads of pageable input: they are the same dispatches
@@ -621,7 +621,7 @@ def main(argv=None):
             "roofline": roof,
             "phase_ms_per_step": {"autocorr": round(st.autocorr_ms / timed * launches / args.steps, 3),
                                   "solve": round(st.solve_ms / timed * launches / args.steps, 3),
-                                  "residual_cost": round(st.residual_ms / args.steps, 3), "price": round(st.price_ms / timed * launches / args.steps, 3),
+                                  "residual_cost": round(st.residual_ms / timed * launches / args.steps, 3), "price": round(st.price_ms / timed * launches / args.steps, 3),
                                   "pack_blocks": round(st.gather_ms / timed * launches / args.steps, 3),
                                   "enqueue_host": round(st.h2d_ms / args.steps, 3), "collect_host": round(st.pack_ms / args.steps, 3),
                                   "total_host": round(st.total_ms / args.steps, 3)},

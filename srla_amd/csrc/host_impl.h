@@ -249,6 +249,7 @@ struct Impl {
     static constexpr uint32_t kTailBoost = 4, kTailBoostJobs = 3;   /* stream-out workgroup multiplier of the call's last jobs */
     bool spin_collect = false;          /* this call: at most three jobs (its last event is polled, not slept on) */
     uint32_t timing_stride = 4;       /* every n-th job carries start events on all stages (SRLA_MI355X_TIMING_STRIDE) */
+    uint32_t short_call_jobs = 0;       /* jobs of calls of at most three jobs so far (which of them are timed: encode_streams) */
     void read_environment();          /* host_tuning.cpp: the one place that reads the environment */
     bool no_chain = false;            /* SRLA_MI355X_NO_CHAIN */
     bool chain_trace = false;         /* SRLA_MI355X_CHAIN_TRACE */

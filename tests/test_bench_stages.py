@@ -53,7 +53,7 @@ def test_the_solve_stage_is_priced_with_the_kernels_that_ran():
     """the default chain is srla_lpc_errvars(_lean) + srla_order_select + srla_lpc_taps"""
     class St:                                           # the fields roofline_object reads
         timed_jobs = 4; analyze_launches = 8; num_items = 8 * 15360
-        autocorr_ms = 0.8; pitch_ms = 0.0; solve_ms = 0.4; residual_ms = 1.6; price_ms = 0.04; gather_ms = 1.0
+        autocorr_ms = 0.8; pitch_ms = 0.0; solve_ms = 0.4; residual_ms = 0.8; price_ms = 0.04; gather_ms = 1.0
     roof = bench.roofline_object(St, "M", 8, 3.6e6, 16.0 * 3.6e6, 100.0)
     solve = roof["stages"]["srla_lpc_solve"]
     assert any(k.startswith("srla_lpc_errvars") for k in solve["kernels"]) and any(k.startswith("srla_lpc_taps") for k in solve["kernels"])
