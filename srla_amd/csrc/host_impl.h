@@ -115,6 +115,7 @@ struct Slot {
     uint32_t stride_cur = 0;
     SrlaJobParams jp{};
     bool want_dbg = false;
+    bool solo = false;                   /* the only job of a call without a chain-mode window: every stage, the block assembly too, on own_stream (run_stage) */
     bool split_a = false;                /* stage A was enqueued in two parts (run_stage) */
     bool timed = false;                  /* this job records start events for every stage (one job in four) */
     bool last_job = false;               /* one of the last jobs of the call's plan (Impl::kDmaTailJobs) */

@@ -457,6 +457,9 @@ bool Impl::run_stage(Slot &s, int st, int part)
      * launch, the start event (timed jobs only) on its first -- no separate marker packets between the kernels
      * of the critical stream.  A stage without launches records its end event the ordinary way. */
     hipEvent_t ev0 = s.timed ? s.t0[st] : nullptr;
+    /* The only job of a call (Slot::solo) runs every stage on ONE stream: its stages need no end events to wait for one another --
+     * an event on a launch costs about 3 us, a wait on it as much again, of a 10 s call's 0.34 ms -- except where the job is timed. */
+    const bool lean = s.solo && !s.timed;
     switch (st) {
     case ST_A: {
         s.ties_gathered = false;
@@ -488,7 +491,7 @@ bool Impl::run_stage(Slot &s, int st, int part)
             return e;
         };
         auto stop_event = [&](int i) -> hipEvent_t {
-            hipEvent_t e = (i == nl - 1) ? s.t1[ST_A] : nullptr;
+            hipEvent_t e = (i == nl - 1 && !lean) ? s.t1[ST_A] : nullptr;
             if (split) { if (i == pitch_at - 1) e = s.ev_a1; /* the last launch of the LTP pass */ if (i == pitch_at) e = s.ev_p; }
             return e;
         };
@@ -522,10 +525,11 @@ bool Impl::run_stage(Slot &s, int st, int part)
             }
         }
         s.split_a = split;
-        if (nl == 0) { if (ev0) HIP_OK(hipEventRecord(ev0, W)); HIP_OK(hipEventRecord(s.t1[ST_A], W)); }
+        if (nl == 0 && !lean) { if (ev0) HIP_OK(hipEventRecord(ev0, W)); HIP_OK(hipEventRecord(s.t1[ST_A], W)); }
         break; }
     case ST_B:
-        HIP_OK(hipStreamWaitEvent(N, s.t1[ST_A], 0));
+        if (!lean) HIP_OK(hipStreamWaitEvent(N, s.t1[ST_A], 0));
+        if (lean && !(have_items && jp.max_order > 0)) break;
         if (s.b_done) {
             /* chain mode with SVR on: the solve chain ran round by round inside stage A (host_chain.cpp) */
             if (ev0) HIP_OK(hipEventRecord(ev0, N));
@@ -534,14 +538,15 @@ bool Impl::run_stage(Slot &s, int st, int part)
             const SrlaSvrExtra ex = { s.d_ties.as<uint32_t>(), job.svr_rows.empty() ? nullptr : s.d_svr_rows.as<double>() };
             rc |= srla_launch_lpc_solve(N, &jp, s.d_items.as<SrlaItemDesc>(), d_geoms.as<SrlaGeom>(), s.d_lags.as<double>(),
                                         s.d_err.as<double>(), d_huff.as<uint8_t>(), s.d_results.as<SrlaItemResult>(), dbg,
-                                        s.d_ties.as<uint32_t>(), ev0, s.t1[ST_B], s.in_cur, s.d_coef_ws.as<double>(),
+                                        s.d_ties.as<uint32_t>(), ev0, lean ? nullptr : s.t1[ST_B], s.in_cur, s.d_coef_ws.as<double>(),
                                         par.num_svr_filter_learning_iteration, std::min<uint32_t>(par.max_num_samples_per_block, 8192u),
                                         d_svr_scratch.p, kSvrGroups, s.d_gamma.as<double>(), &ex);
         } else { if (ev0) HIP_OK(hipEventRecord(ev0, N)); HIP_OK(hipEventRecord(s.t1[ST_B], N)); }
         break;
     case ST_C:
-        HIP_OK(hipStreamWaitEvent(W, s.t1[ST_B], 0));
+        if (!lean) HIP_OK(hipStreamWaitEvent(W, s.t1[ST_B], 0));
         if (have_items) {
+            hipEvent_t c1 = lean ? nullptr : s.t1[ST_C];
             const Group &g = job.groups[0];
             /* the roofline kernel: start event on every job */
             const bool big = !job.big_items.empty();
@@ -556,20 +561,20 @@ bool Impl::run_stage(Slot &s, int st, int part)
                                                 s.timed ? s.t0[ST_C] : nullptr, nullptr);
                 rc |= srla_launch_residual_cost(W, 2, &js, s.in_cur, s.d_items.as<SrlaItemDesc>(), d_geoms.as<SrlaGeom>(), &g.plan_small,
                                                 d_thr.as<double>(), s.d_res_ws.as<int32_t>(), s.d_results.as<SrlaItemResult>(),
-                                                nullptr, big ? nullptr : s.t1[ST_C]);
+                                                nullptr, big ? nullptr : c1);
             } else
             rc |= srla_launch_residual_cost(W, g.rclass, &jv, s.in_cur, s.d_items.as<SrlaItemDesc>(), d_geoms.as<SrlaGeom>(), &g.plan,
                                             d_thr.as<double>(), s.d_res_ws.as<int32_t>(), s.d_results.as<SrlaItemResult>(),
-                                            s.timed ? s.t0[ST_C] : nullptr, big ? nullptr : s.t1[ST_C]);
+                                            s.timed ? s.t0[ST_C] : nullptr, big ? nullptr : c1);
             if (big)
                 rc |= srla_launch_residual_cost_big(W, &jp, s.in_cur, s.d_items.as<SrlaItemDesc>(), d_geoms.as<SrlaGeom>(), d_thr.as<double>(),
                                                     s.d_res_ws.as<int32_t>(), s.d_results.as<SrlaItemResult>(), s.d_big_items.as<uint32_t>(),
-                                                    (uint32_t)job.big_items.size(), job.big_max_n, nullptr, s.t1[ST_C],
+                                                    (uint32_t)job.big_items.size(), job.big_max_n, nullptr, c1,
                                                     job.big_max_n > 32768u ? s.d_big_sig.as<int32_t>() : nullptr);
-        } else { if (s.timed) HIP_OK(hipEventRecord(s.t0[ST_C], W)); HIP_OK(hipEventRecord(s.t1[ST_C], W)); }
+        } else if (!lean) { if (s.timed) HIP_OK(hipEventRecord(s.t0[ST_C], W)); HIP_OK(hipEventRecord(s.t1[ST_C], W)); }
         break;
     case ST_D:
-        HIP_OK(hipStreamWaitEvent(N, s.t1[ST_C], 0));
+        if (!lean) HIP_OK(hipStreamWaitEvent(N, s.t1[ST_C], 0));
         if (jp.num_windows) {
             uint32_t *price_ws = nullptr;
             if (job.max_window_cands > srla_price_lds_cands()) {
@@ -577,9 +582,9 @@ bool Impl::run_stage(Slot &s, int st, int part)
                 price_ws = s.d_price_ws.as<uint32_t>();
             }
             rc |= srla_launch_price(N, &jp, s.d_windows.as<SrlaWindowDesc>(), s.d_cands.as<SrlaCandDesc>(),
-                                    s.d_results.as<SrlaItemResult>(), s.d_blocks.as<SrlaBlockRecord>(), ev0, s.t1[ST_D],
+                                    s.d_results.as<SrlaItemResult>(), s.d_blocks.as<SrlaBlockRecord>(), ev0, lean ? nullptr : s.t1[ST_D],
                                     job.max_nodes, job.max_window_cands, price_ws);
-        } else { if (ev0) HIP_OK(hipEventRecord(ev0, N)); HIP_OK(hipEventRecord(s.t1[ST_D], N)); }
+        } else if (!lean) { if (ev0) HIP_OK(hipEventRecord(ev0, N)); HIP_OK(hipEventRecord(s.t1[ST_D], N)); }
         break;
     case ST_E:
         /* block offsets + complete blocks + stream-out to where the streams want them (their pinned buffers, or this
@@ -588,7 +593,7 @@ bool Impl::run_stage(Slot &s, int st, int part)
          * for the tails of the wide kernels, 0.13-0.3 ms per job for 0.05 ms of work), the stream-out on C: the copy of job k
          * then also runs beside the assembly of job k + 1.  A job on a stream of its own keeps to it. */
         {
-        hipStream_t P = C;
+        hipStream_t P = s.solo ? s.own_stream : C;       /* (the only job of a call: no other job's blocks to keep in order with) */
         if (P == C) HIP_OK(hipStreamWaitEvent(C, s.t1[ST_D], 0));
         s.use_dma = call_dma && !s.own_stream && s.emits && !s.last_job;   /* (the call's last job: the copy-out kernel follows its assembly without a host round trip) */
         if (s.dma_pending) { HIP_OK(hipStreamWaitEvent(P, s.ev_dma, 0)); s.dma_pending = false; }   /* the staging buffer's last job has left it */
@@ -606,7 +611,7 @@ bool Impl::run_stage(Slot &s, int st, int part)
                                    ev0, s.t1[ST_E], s.out_boost, nullptr, s.ev_pk,
                                    s.use_dma ? 1u : 0u, &tg);
             s.ties_gathered = true;
-        } else { if (P != C) HIP_OK(hipStreamWaitEvent(C, s.t1[ST_D], 0)); if (ev0) HIP_OK(hipEventRecord(ev0, C)); HIP_OK(hipEventRecord(s.t1[ST_E], C)); }
+        } else { if (ev0) HIP_OK(hipEventRecord(ev0, P)); HIP_OK(hipEventRecord(s.t1[ST_E], P)); }
         }
         break;
     default: return false;
@@ -1086,6 +1091,7 @@ SRLAApiResult Impl::encode_streams(bool search)
         return rc;
     };
     auto job_slot = [&](uint32_t k) -> Slot & { return slot[plan[k].slot]; };
+    const bool chain_any = single && sx[0].chain_n != 0;          /* a history-dependent last window: its jobs' blocks follow the regular jobs' on stream C */
     auto begin = [&](uint32_t k) -> bool {
         Slot &s = job_slot(k);
         if (!stage_input(s, plan[k])) return false;
@@ -1097,6 +1103,7 @@ SRLAApiResult Impl::encode_streams(bool search)
         /* a call of one job has nothing to overlap: its stages run on ONE stream, without the cross-stream hand-overs
          * (about 13 us each; a 10 s stream: 0.49 -> 0.465 ms) */
         s.own_stream = (njobs == 1) ? streams[0] : nullptr;
+        s.solo = njobs == 1 && !chain_any && !timeline;
         s.emits = true; s.merge_cb = false;
         /* One job in `timing_stride` carries start events on its launches (a start event costs a launch about 3 us: all of them on
          * every job were 2 % of a long call and 10 % of a 10 s call); the jobs of short calls are counted across calls, so that a
