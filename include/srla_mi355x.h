@@ -223,7 +223,7 @@ struct SRLAMI355XStats {
     double   autocorr_ms;        /* srla_autocorr launches (+ srla_pitch_solve), timed jobs only */
     double   solve_ms;           /* recursion + order selection + quantiser, timed jobs only  */
     double   residual_ms;        /* srla_residual_cost, timed jobs only (every job until round 5: a start event per launch is not free) */
-    uint64_t timed_jobs;         /* jobs on which every stage was timed (one in four; of calls of at most three jobs: one in four across calls) */
+    uint64_t timed_jobs;         /* jobs on which every stage was timed (one in four; a call of ONE job: every fourth such call) */
     uint64_t num_tie_resolved;   /* flagged items (any candidate, not only chosen ones) whose decision the host libm confirmed */
     uint64_t num_tie_overrides;  /* flagged items where the host libm decided otherwise: re-analysed with the host's decision */
     uint64_t num_restarts;       /* times the stream loop went back to a job because of such an override            */

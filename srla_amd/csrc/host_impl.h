@@ -117,6 +117,7 @@ struct Slot {
     bool want_dbg = false;
     bool solo = false;                   /* the only job of a call without a chain-mode window: every stage, the block assembly too, on own_stream (run_stage) */
     bool split_a = false;                /* stage A was enqueued in two parts (run_stage) */
+    bool c_start = false;                /* srla_residual_cost's launch carries a start event (timed jobs; every job of a call of two or three) */
     bool timed = false;                  /* this job records start events for every stage (one job in four) */
     bool last_job = false;               /* one of the last jobs of the call's plan (Impl::kDmaTailJobs) */
     bool use_dma = false;                /* this job's bytes leave by a host-issued copy when it is collected (Impl::dma_out) */
@@ -209,6 +210,7 @@ struct Impl {
     bool dma_out = true;
     hipStream_t dma_stream = nullptr;
     bool call_crowded = false;          /* this call: more than three jobs, so a job's narrow kernels run beside other jobs' wide ones (SrlaJobParams::crowded) */
+    bool call_solo = false;           /* the call is ONE job and no chain-mode window (Slot::solo) */
     bool call_dma = false;              /* this call: see above */
     bool dma_used = false;              /* copies may be in flight on dma_stream */
     uint32_t short_min = 786432;        /* SRLA_MI355X_SHORT_MIN: ... and no piece shorter than this many samples */
@@ -250,7 +252,7 @@ struct Impl {
     static constexpr uint32_t kTailBoost = 4, kTailBoostJobs = 3;   /* stream-out workgroup multiplier of the call's last jobs */
     bool spin_collect = false;          /* this call: at most three jobs (its last event is polled, not slept on) */
     uint32_t timing_stride = 4;       /* every n-th job carries start events on all stages (SRLA_MI355X_TIMING_STRIDE) */
-    uint32_t short_call_jobs = 0;       /* jobs of calls of at most three jobs so far (which of them are timed: encode_streams) */
+    uint32_t short_call_jobs = 0;       /* calls of ONE job so far (which of them are timed: encode_streams) */
     void read_environment();          /* host_tuning.cpp: the one place that reads the environment */
     bool no_chain = false;            /* SRLA_MI355X_NO_CHAIN */
     bool chain_trace = false;         /* SRLA_MI355X_CHAIN_TRACE */

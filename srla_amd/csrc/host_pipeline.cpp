@@ -281,6 +281,9 @@ bool Impl::stage_input(Slot &s, const JobPlan &plan)
             /* (calls of many jobs only: a short stream's one or three jobs lose more to the extra round than the link returns; halves and
              * quarters of a plane: less, profiles/r05/ab_host_path.txt) */
             const uint32_t rounds = (call_crowded && nch >= 2 && (size_t)total * 2 >= (512u << 10)) ? nch : 1u;
+            /* the only job of a call: srla_widen16 reads the packed planes out of the page-locked staging buffer itself -- one launch
+             * instead of the runtime's copy kernel and the widening behind it (a 10 s stream's 1.9 MB) */
+            const bool direct_widen = call_solo;
             std::vector<uint32_t> mine;
             for (uint32_t r = 0; r < rounds && wide.load() == 0; r++) {
                 mine.clear();
@@ -294,12 +297,13 @@ bool Impl::stage_input(Slot &s, const JobPlan &plan)
                     if (w) wide.fetch_or(w, std::memory_order_relaxed);
                 });
                 if (wide.load() != 0) break;
+                if (direct_widen) continue;
                 if (rounds == 1) HIP_OK(hipMemcpyAsync(s.d_input16.p, s.h_in.p, nch * stride16 * 2, hipMemcpyHostToDevice, upload));
                 else HIP_OK(hipMemcpyAsync(s.d_input16.as<int16_t>() + (size_t)r * stride16, dst + (size_t)r * stride16, stride16 * 2, hipMemcpyHostToDevice, upload));
             }
             if (timeline) tl_printf("[timeline] host: %zu staging tasks took %.3f ms\n", tasks.size(), ms_since(t_pack));
             if (wide.load() == 0) {
-                if (srla_launch_widen16(upload, s.d_input16.as<int16_t>(), stride16, s.d_input.as<int32_t>(), total, nch) != 0) return false;
+                if (srla_launch_widen16(upload, direct_widen ? dst : s.d_input16.as<int16_t>(), stride16, s.d_input.as<int32_t>(), total, nch) != 0) return false;
                 packed = true;
             }   /* else: samples beyond 16 bits in a stream declared narrower -- the reference does not mind, nor do we */
         }
@@ -558,20 +562,20 @@ bool Impl::run_stage(Slot &s, int st, int part)
                 js.rc_lo = 0u; js.rc_hi = 4096u;
                 rc |= srla_launch_residual_cost(W, 4, &jl, s.in_cur, s.d_items.as<SrlaItemDesc>(), d_geoms.as<SrlaGeom>(), &g.plan,
                                                 d_thr.as<double>(), s.d_res_ws.as<int32_t>(), s.d_results.as<SrlaItemResult>(),
-                                                s.timed ? s.t0[ST_C] : nullptr, nullptr);
+                                                s.c_start ? s.t0[ST_C] : nullptr, nullptr);
                 rc |= srla_launch_residual_cost(W, 2, &js, s.in_cur, s.d_items.as<SrlaItemDesc>(), d_geoms.as<SrlaGeom>(), &g.plan_small,
                                                 d_thr.as<double>(), s.d_res_ws.as<int32_t>(), s.d_results.as<SrlaItemResult>(),
                                                 nullptr, big ? nullptr : c1);
             } else
             rc |= srla_launch_residual_cost(W, g.rclass, &jv, s.in_cur, s.d_items.as<SrlaItemDesc>(), d_geoms.as<SrlaGeom>(), &g.plan,
                                             d_thr.as<double>(), s.d_res_ws.as<int32_t>(), s.d_results.as<SrlaItemResult>(),
-                                            s.timed ? s.t0[ST_C] : nullptr, big ? nullptr : c1);
+                                            s.c_start ? s.t0[ST_C] : nullptr, big ? nullptr : c1);
             if (big)
                 rc |= srla_launch_residual_cost_big(W, &jp, s.in_cur, s.d_items.as<SrlaItemDesc>(), d_geoms.as<SrlaGeom>(), d_thr.as<double>(),
                                                     s.d_res_ws.as<int32_t>(), s.d_results.as<SrlaItemResult>(), s.d_big_items.as<uint32_t>(),
                                                     (uint32_t)job.big_items.size(), job.big_max_n, nullptr, c1,
                                                     job.big_max_n > 32768u ? s.d_big_sig.as<int32_t>() : nullptr);
-        } else if (!lean) { if (s.timed) HIP_OK(hipEventRecord(s.t0[ST_C], W)); HIP_OK(hipEventRecord(s.t1[ST_C], W)); }
+        } else if (!lean) { if (s.c_start) HIP_OK(hipEventRecord(s.t0[ST_C], W)); HIP_OK(hipEventRecord(s.t1[ST_C], W)); }
         break;
     case ST_D:
         if (!lean) HIP_OK(hipStreamWaitEvent(N, s.t1[ST_C], 0));
@@ -669,12 +673,13 @@ bool Impl::wait_job(Slot &s)
 bool Impl::run_job_sync(Slot &s, const JobPlan &plan, bool search, bool want_dbg, uint32_t jobkey)
 {
     for (int attempt = 0; attempt < 6; attempt++) {
+        call_solo = false;
         if (!stage_input(s, plan)) return false;
         std::vector<uint32_t> lsh;
         settle_lshift(plan, lsh);
         build_job(s.job, plan, lsh, search);
         if (apply_overrides(s.job, jobkey)) { s.job.uploaded = false; s.job.key = 0; }
-        s.own_stream = nullptr; s.timed = timing; s.out_boost = 1; s.last_job = true; call_crowded = false;   /* (no DMA output: the copy-out kernel) */
+        s.own_stream = nullptr; s.solo = false; s.timed = timing; s.c_start = timing; s.out_boost = 1; s.last_job = true; call_crowded = false;   /* (no DMA output: the copy-out kernel) */
         for (const SegPlan &sp : plan.segs) sx[sp.stream].pass_started = false;
         if (!prepare_job(s, want_dbg)) return false;
         for (int st = 0; st < NUM_ST; st++) if (!run_stage(s, st)) return false;
@@ -1092,6 +1097,7 @@ SRLAApiResult Impl::encode_streams(bool search)
     };
     auto job_slot = [&](uint32_t k) -> Slot & { return slot[plan[k].slot]; };
     const bool chain_any = single && sx[0].chain_n != 0;          /* a history-dependent last window: its jobs' blocks follow the regular jobs' on stream C */
+    call_solo = njobs == 1 && !chain_any && !timeline;
     auto begin = [&](uint32_t k) -> bool {
         Slot &s = job_slot(k);
         if (!stage_input(s, plan[k])) return false;
@@ -1103,12 +1109,15 @@ SRLAApiResult Impl::encode_streams(bool search)
         /* a call of one job has nothing to overlap: its stages run on ONE stream, without the cross-stream hand-overs
          * (about 13 us each; a 10 s stream: 0.49 -> 0.465 ms) */
         s.own_stream = (njobs == 1) ? streams[0] : nullptr;
-        s.solo = njobs == 1 && !chain_any && !timeline;
+        s.solo = call_solo;
         s.emits = true; s.merge_cb = false;
         /* One job in `timing_stride` carries start events on its launches (a start event costs a launch about 3 us: all of them on
          * every job were 2 % of a long call and 10 % of a 10 s call); the jobs of short calls are counted across calls, so that a
-         * call of one job is timed every fourth time instead of always. */
-        s.timed = timing && ((njobs > 3 ? k : short_call_jobs++) % timing_stride == 0);
+         * call of ONE job is timed every fourth time instead of always. */
+        s.timed = timing && ((njobs > 1 ? k : short_call_jobs++) % timing_stride == 0);
+        /* (a call of two or three jobs keeps round 4's events -- its first job timed, srla_residual_cost's start event on every job:
+         * measured FASTER than fewer or none, 60 s: 3 910 against 3 790 / 3 850 Msamples/s; profiles/r05/ab_host_path.txt) */
+        s.c_start = s.timed || (timing && njobs >= 2 && njobs <= 3);
         s.out_boost = (k + kTailBoostJobs >= njobs) ? kTailBoost : 1u;
         s.last_job = k + kDmaTailJobs >= njobs;              /* (the last jobs of the call: the copy-out kernel, no host round trip) */
         return prepare_job(s, false);
