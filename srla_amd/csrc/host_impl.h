@@ -115,6 +115,7 @@ struct Slot {
     uint32_t stride_cur = 0;
     SrlaJobParams jp{};
     bool want_dbg = false;
+    bool piece = false;                  /* one of the two or three jobs of a short call: stages A - D on a stream of its own, no end events between them */
     bool solo = false;                   /* the only job of a call without a chain-mode window: every stage, the block assembly too, on own_stream (run_stage) */
     bool split_a = false;                /* stage A was enqueued in two parts (run_stage) */
     bool c_start = false;                /* srla_residual_cost's launch carries a start event (timed jobs; every job of a call of two or three) */
@@ -210,6 +211,7 @@ struct Impl {
     bool dma_out = true;
     hipStream_t dma_stream = nullptr;
     bool call_crowded = false;          /* this call: more than three jobs, so a job's narrow kernels run beside other jobs' wide ones (SrlaJobParams::crowded) */
+    bool planned_pieces = false;      /* plan_jobs cut the call's one short stream into pieces (Slot::piece) */
     bool call_solo = false;           /* the call is ONE job and no chain-mode window (Slot::solo) */
     bool call_dma = false;              /* this call: see above */
     bool dma_used = false;              /* copies may be in flight on dma_stream */

@@ -353,7 +353,8 @@ bool Impl::prepare_job(Slot &s, bool want_dbg)
 {
     Job &job = s.job;
     const uint32_t nch = par.num_channels;
-    hipStream_t W = streams[0], C = streams[2];
+    /* (a piece of a short call runs on a stream of its own: its tables and its cleared tie list go there, ahead of its kernels) */
+    hipStream_t W = (s.piece && s.own_stream) ? s.own_stream : streams[0], C = streams[2];
     if (!sync_tables()) return false;
     const size_t n_items = job.items.size(), n_cands = job.cands.size(), n_win = job.windows.size(), nseg = job.segs.size();
     {
@@ -436,7 +437,8 @@ bool Impl::prepare_job(Slot &s, bool want_dbg)
             sd[k].dst = (uint64_t)reinterpret_cast<uintptr_t>(st.out_direct);
             if (s.emits) st.pass_started = true;
         }
-        HIP_OK(hipMemcpyAsync(s.d_segs.p, s.h_segs.p, nseg * sizeof(SrlaSegDesc), hipMemcpyHostToDevice, C));
+        /* (on the stream the block assembly runs on: C, or the one stream of a call's only job) */
+        HIP_OK(hipMemcpyAsync(s.d_segs.p, s.h_segs.p, nseg * sizeof(SrlaSegDesc), hipMemcpyHostToDevice, (s.solo && s.own_stream) ? s.own_stream : C));
     }
     s.jp = job_params(job, s.stride_cur, sx[job.segs[0].stream].lshift_on_device);
     s.busy = true; s.b_done = false;
@@ -463,7 +465,8 @@ bool Impl::run_stage(Slot &s, int st, int part)
     hipEvent_t ev0 = s.timed ? s.t0[st] : nullptr;
     /* The only job of a call (Slot::solo) runs every stage on ONE stream: its stages need no end events to wait for one another --
      * an event on a launch costs about 3 us, a wait on it as much again, of a 10 s call's 0.34 ms -- except where the job is timed. */
-    const bool lean = s.solo && !s.timed;
+    const bool lean = (s.solo || s.piece) && !s.timed;
+    const bool lean_d = lean && s.solo;                          /* (a piece's block assembly runs on stream C: the pricing keeps its end event) */
     switch (st) {
     case ST_A: {
         s.ties_gathered = false;
@@ -586,9 +589,9 @@ bool Impl::run_stage(Slot &s, int st, int part)
                 price_ws = s.d_price_ws.as<uint32_t>();
             }
             rc |= srla_launch_price(N, &jp, s.d_windows.as<SrlaWindowDesc>(), s.d_cands.as<SrlaCandDesc>(),
-                                    s.d_results.as<SrlaItemResult>(), s.d_blocks.as<SrlaBlockRecord>(), ev0, lean ? nullptr : s.t1[ST_D],
+                                    s.d_results.as<SrlaItemResult>(), s.d_blocks.as<SrlaBlockRecord>(), ev0, lean_d ? nullptr : s.t1[ST_D],
                                     job.max_nodes, job.max_window_cands, price_ws);
-        } else if (!lean) { if (ev0) HIP_OK(hipEventRecord(ev0, N)); HIP_OK(hipEventRecord(s.t1[ST_D], N)); }
+        } else if (!lean_d) { if (ev0) HIP_OK(hipEventRecord(ev0, N)); HIP_OK(hipEventRecord(s.t1[ST_D], N)); }
         break;
     case ST_E:
         /* block offsets + complete blocks + stream-out to where the streams want them (their pinned buffers, or this
@@ -679,7 +682,7 @@ bool Impl::run_job_sync(Slot &s, const JobPlan &plan, bool search, bool want_dbg
         settle_lshift(plan, lsh);
         build_job(s.job, plan, lsh, search);
         if (apply_overrides(s.job, jobkey)) { s.job.uploaded = false; s.job.key = 0; }
-        s.own_stream = nullptr; s.solo = false; s.timed = timing; s.c_start = timing; s.out_boost = 1; s.last_job = true; call_crowded = false;   /* (no DMA output: the copy-out kernel) */
+        s.own_stream = nullptr; s.solo = false; s.piece = false; s.timed = timing; s.c_start = timing; s.out_boost = 1; s.last_job = true; call_crowded = false;   /* (no DMA output: the copy-out kernel) */
         for (const SegPlan &sp : plan.segs) sx[sp.stream].pass_started = false;
         if (!prepare_job(s, want_dbg)) return false;
         for (int st = 0; st < NUM_ST; st++) if (!run_stage(s, st)) return false;
@@ -1109,6 +1112,13 @@ SRLAApiResult Impl::encode_streams(bool search)
         /* a call of one job has nothing to overlap: its stages run on ONE stream, without the cross-stream hand-overs
          * (about 13 us each; a 10 s stream: 0.49 -> 0.465 ms) */
         s.own_stream = (njobs == 1) ? streams[0] : nullptr;
+        /* The pieces of a short stream (plan_jobs): each runs its stages A - D on ONE stream (two streams, taken in turn) without end
+         * events between them, only the block assembly stays on C, where the order of the stream's blocks is made -- one hand-over per
+         * piece instead of four, and a piece's pricing no longer queues behind the next piece's solve chain (40 s: 3 300 -> 3 440, 60 s:
+         * 3 880 -> 3 960, 90 s: 3 430 -> 3 980, 120 s: 3 890 -> 4 240 Msamples/s).  Full-size jobs keep the wide stream: two of them
+         * side by side lose (300 s: - 2 %). */
+        s.piece = planned_pieces && njobs >= 2 && !chain_any && !timeline;
+        if (s.piece) s.own_stream = streams[k & 1u];
         s.solo = call_solo;
         s.emits = true; s.merge_cb = false;
         /* One job in `timing_stride` carries start events on its launches (a start event costs a launch about 3 us: all of them on
@@ -1117,7 +1127,7 @@ SRLAApiResult Impl::encode_streams(bool search)
         s.timed = timing && ((njobs > 1 ? k : short_call_jobs++) % timing_stride == 0);
         /* (a call of two or three jobs keeps round 4's events -- its first job timed, srla_residual_cost's start event on every job:
          * measured FASTER than fewer or none, 60 s: 3 910 against 3 790 / 3 850 Msamples/s; profiles/r05/ab_host_path.txt) */
-        s.c_start = s.timed || (timing && njobs >= 2 && njobs <= 3);
+        s.c_start = s.timed || (timing && njobs >= 2 && njobs <= 3 && !s.piece);
         s.out_boost = (k + kTailBoostJobs >= njobs) ? kTailBoost : 1u;
         s.last_job = k + kDmaTailJobs >= njobs;              /* (the last jobs of the call: the copy-out kernel, no host round trip) */
         return prepare_job(s, false);

@@ -285,6 +285,7 @@ uint32_t Impl::windows_per_job(bool search) const
 void Impl::plan_jobs(std::vector<JobPlan> &plan, bool search)
 {
     plan.clear();
+    planned_pieces = false;
     const uint32_t window_len = search ? par.num_lookahead_samples : par.max_num_samples_per_block;
     const uint64_t job_len = (uint64_t)windows_per_job(search) * window_len;
     auto al16 = [](uint64_t v) { return (uint32_t)((v + 15u) & ~(uint64_t)15u); };
@@ -320,6 +321,7 @@ void Impl::plan_jobs(std::vector<JobPlan> &plan, bool search)
             uint32_t k = 0;
             for (uint64_t s0 = 0; s0 < rest; s0 += piece, k++)
                 one((uint32_t)s0, (uint32_t)std::min<uint64_t>(piece, rest - s0), k % kSlots);
+            planned_pieces = true;
         } else if (rest > 0) {
             one(tail0, (uint32_t)rest, nfull > 0 ? kSlots : 0u);
         }
