@@ -216,7 +216,7 @@ struct Impl {
     bool call_dma = false;              /* this call: see above */
     bool dma_used = false;              /* copies may be in flight on dma_stream */
     uint32_t short_min = 786432;        /* SRLA_MI355X_SHORT_MIN: ... and no piece shorter than this many samples */
-    uint32_t mid_jobs = 1;              /* SRLA_MI355X_MID_JOBS: a stream of up to this many whole jobs (and a rest) is cut into pieces like a short one (0: only streams shorter than a job) */
+    uint32_t mid_jobs = 2;              /* SRLA_MI355X_MID_JOBS: a stream of up to this many whole jobs (and a rest) is cut into pieces like a short one (0: only streams shorter than a job) */
     uint32_t short_div = 3;             /* SRLA_MI355X_SHORT_DIV: a stream shorter than one job is cut into pieces of a job / this (4 until the pieces ran on streams of their own: 120 s 3 860 - 4 050 -> 4 400) */
     bool split_ltp_stage = true;        /* SRLA_MI355X_NO_LTP_SKEW: stage A of LTP jobs in one piece on W, as before */
     bool keep_residuals = false;      /* SRLAMI355X_ProbeBlock with a residual buffer: srla_residual_cost stores what it prices */

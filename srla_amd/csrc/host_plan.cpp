@@ -296,7 +296,8 @@ void Impl::plan_jobs(std::vector<JobPlan> &plan, bool search)
         /* A stream of one job and a bit (up to `mid_jobs` jobs): as a whole job plus tail it starts with 0.55 ms of staging and
          * upload and ends with a full job's chain of stages; in pieces like a short stream the device starts after one piece's
          * staging and the last chain is a piece's.  Measured: 120 s of stereo 3 300 -> 3 560 Msamples/s; with TWO whole jobs
-         * (200 s) the pieces lose (4 500 -> 4 040: the host's staging of piece after piece sets the pace), hence 1. */
+         * (200 s) the pieces lost in round 4 (4 500 -> 4 040: the host's staging of piece after piece set the pace) and win since the
+         * pieces run on streams of their own (round 5: 4 630 -> 4 860); with three (300 s) they lose 2 %: hence 2. */
         /* (only where the pieces branch below takes the stream: otherwise it would fall through to ONE job of up to twice the
          * planned job length, which the buffer and LDS planning do not assume) */
         if (nfull > 0 && nfull <= mid_jobs && job_len >= 8 * (uint64_t)window_len && body >= 2 * (uint64_t)short_min) { nfull = 0; rest = body; }
