@@ -300,7 +300,9 @@ void Impl::plan_jobs(std::vector<JobPlan> &plan, bool search)
          * pieces run on streams of their own (round 5: 4 630 -> 4 860); with three (300 s) they lose 2 %: hence 2. */
         /* (only where the pieces branch below takes the stream: otherwise it would fall through to ONE job of up to twice the
          * planned job length, which the buffer and LDS planning do not assume) */
-        if (nfull > 0 && nfull <= mid_jobs && job_len >= 8 * (uint64_t)window_len && body >= 2 * (uint64_t)short_min) { nfull = 0; rest = body; }
+        /* (a stream with a history-dependent last window keeps the cross-stream pipeline, Slot::piece: one whole job at most) */
+        const uint32_t mid = (sx[0].chain_n != 0) ? std::min<uint32_t>(mid_jobs, 1u) : mid_jobs;
+        if (nfull > 0 && nfull <= mid && job_len >= 8 * (uint64_t)window_len && body >= 2 * (uint64_t)short_min) { nfull = 0; rest = body; }
         auto one = [&](uint32_t s0, uint32_t ns, uint32_t slot_index) {
             JobPlan jp; jp.segs.push_back({ 0u, s0, ns, 0u }); jp.total = al16(ns); jp.slot = slot_index; plan.push_back(jp);
         };
