@@ -322,8 +322,10 @@ void Impl::plan_jobs(std::vector<JobPlan> &plan, bool search)
             pieces = std::max<uint64_t>(pieces, std::min<uint64_t>(3u, rest / short_min));
             const uint64_t piece = (((rest + pieces - 1) / pieces + window_len - 1) / window_len) * window_len;
             uint32_t k = 0;
+            /* (the last piece, of a length of its own, in the first tail job's buffer set: where the pieces outnumber the rotating
+             * sets it would otherwise take turns with a whole piece's table in one of them, and both would be built again every call) */
             for (uint64_t s0 = 0; s0 < rest; s0 += piece, k++)
-                one((uint32_t)s0, (uint32_t)std::min<uint64_t>(piece, rest - s0), k % kSlots);
+                one((uint32_t)s0, (uint32_t)std::min<uint64_t>(piece, rest - s0), (s0 + piece >= rest && pieces > kSlots) ? kSlots : k % kSlots);
             planned_pieces = true;
         } else if (rest > 0) {
             one(tail0, (uint32_t)rest, nfull > 0 ? kSlots : 0u);
