@@ -295,6 +295,11 @@ uint32_t SRLAMI355X_TestSelectOrder(const double *error_vars, uint32_t max_order
 uint32_t SRLAMI355X_TestLtpTaps(const double *lags6, uint32_t ltp_order);
 void SRLAMI355X_TestSvrRefine(const double *data, uint32_t num_samples, double *coef, uint32_t order, uint32_t max_iter);
 void SRLAMI355X_TestLevinson(const double *lags_ridged, uint32_t order, double *coef);
+/*   TestPlanJobs     the job plan a call of these streams would get (host_plan.cpp: plan_jobs; handle with parameters set, no device):
+ *                    per job the words { buffer set, segments, samples per plane } and per segment { stream, first sample, samples, offset
+ *                    in the job's planes }; returns the number of words written, or -1 (out too small, no parameters) */
+int SRLAMI355X_TestPlanJobs(struct SRLAEncoder *encoder, uint32_t num_streams, const uint32_t *num_samples, int device_input,
+                            uint32_t *out, uint32_t cap_words);
 
 #ifdef __cplusplus
 }

@@ -460,4 +460,31 @@ SRLAApiResult SRLAMI355X_ProbeBlock(struct SRLAEncoder *encoder, const int32_t *
     return SRLA_APIRESULT_OK;
 }
 
+int SRLAMI355X_TestPlanJobs(struct SRLAEncoder *encoder, uint32_t num_streams, const uint32_t *num_samples, int device_input,
+                            uint32_t *out, uint32_t cap_words)
+{
+    Impl *im = impl_of(encoder);
+    if (im == nullptr || !im->set_parameter || num_streams == 0 || num_samples == nullptr || out == nullptr) return -1;
+    const bool search = im->search_enabled();
+    static const int32_t dummy = 0;
+    im->sx.assign(num_streams, StreamCtx());
+    for (uint32_t i = 0; i < num_streams; i++) {
+        StreamCtx &st = im->sx[i];
+        st.num_samples = num_samples[i];
+        st.chain_n = (num_streams == 1 && im->history_regime(search)) ? 0u : im->chain_tail(num_samples[i], search);   /* as encode_streams */
+        st.body = st.num_samples - st.chain_n;
+        st.d_in = device_input ? &dummy : nullptr;
+    }
+    std::vector<JobPlan> plan;
+    im->plan_jobs(plan, search);
+    im->sx.clear();
+    size_t w = 0;
+    for (const JobPlan &jp : plan) {
+        if (w + 3 + 4 * jp.segs.size() > cap_words) return -1;
+        out[w++] = jp.slot; out[w++] = (uint32_t)jp.segs.size(); out[w++] = jp.total;
+        for (const SegPlan &sp : jp.segs) { out[w++] = sp.stream; out[w++] = sp.s0; out[w++] = sp.ns; out[w++] = sp.base; }
+    }
+    return (int)w;
+}
+
 }  /* extern "C" */
