@@ -298,6 +298,9 @@ void SRLAMI355X_TestLevinson(const double *lags_ridged, uint32_t order, double *
 /*   TestPlanJobs     the job plan a call of these streams would get (host_plan.cpp: plan_jobs; handle with parameters set, no device):
  *                    per job the words { buffer set, segments, samples per plane } and per segment { stream, first sample, samples, offset
  *                    in the job's planes }; returns the number of words written, or -1 (out too small, no parameters) */
+/*   TestPack16       the staging copy of streams of at most 16 bits (host_support.cpp: pack16_or, AVX2 where the CPU has it): dst[i] =
+ *                    (int16) src[i]; returns the OR of the samples, *wide != 0 iff a sample does not fit 16 bits */
+uint32_t SRLAMI355X_TestPack16(int16_t *dst, const int32_t *src, uint32_t n, uint32_t *wide);
 int SRLAMI355X_TestPlanJobs(struct SRLAEncoder *encoder, uint32_t num_streams, const uint32_t *num_samples, int device_input,
                             uint32_t *out, uint32_t cap_words);
 

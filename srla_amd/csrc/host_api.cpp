@@ -460,6 +460,14 @@ SRLAApiResult SRLAMI355X_ProbeBlock(struct SRLAEncoder *encoder, const int32_t *
     return SRLA_APIRESULT_OK;
 }
 
+uint32_t SRLAMI355X_TestPack16(int16_t *dst, const int32_t *src, uint32_t n, uint32_t *wide)
+{
+    uint32_t w = 0;
+    const uint32_t m = srla::pack16_or(dst, src, n, &w);
+    if (wide) *wide = w;
+    return m;
+}
+
 int SRLAMI355X_TestPlanJobs(struct SRLAEncoder *encoder, uint32_t num_streams, const uint32_t *num_samples, int device_input,
                             uint32_t *out, uint32_t cap_words)
 {

@@ -114,3 +114,37 @@ def test_the_metric_stream_is_planned_as_documented():
     assert [segs[0][2] for _, _, segs in jobs[:6]] == [4 << 20] * 6 and jobs[-1][2][0][2] <= 300_000
     assert len(_plan(lib, enc, [2_880_000])) == 3 and len(_plan(lib, enc, [480_000])) == 1
     lib.destroy(enc)
+
+
+def test_the_staging_copy_packs_and_flags_what_does_not_fit():
+    """host_support.cpp: pack16_or -- every length around the vector width, every destination alignment, the values either side of
+    the int16 range (a stream declared 16 bits wide may hold wider samples: the job is then staged as int32)."""
+    lib = capi.EncoderLib(helpers.PRODUCT_SO)
+    fn = lib.lib.SRLAMI355X_TestPack16
+    fn.restype = C.c_uint32
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+    rng = np.random.default_rng(7)
+    for n in list(range(0, 70)) + [255, 256, 257, 4095, 65536 + 33]:
+        for shift in (0, 1, 7, 16):
+            src = rng.integers(-32768, 32768, size=n, dtype=np.int32)
+            buf = np.zeros(n + 64, dtype=np.int16)
+            dst = buf[shift:shift + n]
+            wide = C.c_uint32(0)
+            m = fn(dst.ctypes.data, src.ctypes.data, n, C.byref(wide))
+            assert np.array_equal(dst, src.astype(np.int16)) and wide.value == 0
+            assert m == (int(np.bitwise_or.reduce(src.view(np.uint32))) if n else 0)
+            assert not buf[:shift].any() and not buf[shift + n:].any()
+    for bad in (32768, -32769, 1 << 20, -(1 << 31)):
+        for at in (0, 5, 31, 32, 100, 999):
+            src = rng.integers(-32768, 32768, size=1000, dtype=np.int32)
+            src[at] = bad
+            dst = np.zeros(1000, dtype=np.int16)
+            wide = C.c_uint32(0)
+            fn(dst.ctypes.data, src.ctypes.data, 1000, C.byref(wide))
+            assert wide.value != 0, (bad, at)
+    for ok in (32767, -32768):
+        src = np.full(1000, ok, dtype=np.int32)
+        dst = np.zeros(1000, dtype=np.int16)
+        wide = C.c_uint32(0)
+        fn(dst.ctypes.data, src.ctypes.data, 1000, C.byref(wide))
+        assert wide.value == 0 and (dst == ok).all()
