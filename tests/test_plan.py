@@ -113,6 +113,18 @@ def test_the_metric_stream_is_planned_as_documented():
     assert [s for s, _, _ in jobs] == [0, 1, 2, 3, 4, 0, 5, 6]
     assert [segs[0][2] for _, _, segs in jobs[:6]] == [4 << 20] * 6 and jobs[-1][2][0][2] <= 300_000
     assert len(_plan(lib, enc, [2_880_000])) == 3 and len(_plan(lib, enc, [480_000])) == 1
+    # 200 s: two whole jobs' worth in seven pieces -- more than the five rotating sets, so the last piece (a length of its own) takes
+    # the first tail job's set and the six equal pieces keep finding their shared table
+    jobs = _plan(lib, enc, [9_600_000])
+    assert [s for s, _, _ in jobs] == [0, 1, 2, 3, 4, 0, 5] and len({segs[0][2] for _, _, segs in jobs[:6]}) == 1
+    lib.destroy(enc)
+    # nine 300 s files at config 5's flags: 27 whole jobs in the rotating sets, the four jobs of remainders in sets of their own
+    cfg, par = capi.cli_setup(2, 16, 48000, preset=4, max_block=4096, divisions=2, ltp_order=3)
+    enc = lib.create(cfg)
+    assert lib.set_parameter(enc, par) == capi.OK
+    jobs = _plan(lib, enc, [14_400_000] * 9)
+    assert [s for s, _, _ in jobs] == [k % 5 for k in range(27)] + [5, 6, 7, 8]
+    assert all(len(segs) == 1 for _, _, segs in jobs[:27]) and all(len(segs) > 1 for _, _, segs in jobs[27:])
     lib.destroy(enc)
 
 
