@@ -741,7 +741,8 @@ def main(argv=None):
                 if k:
                     times.append(time.perf_counter() - t1)
             for k in range(3):
-                if ubatch2.run(uenc, usz2) != capi.OK:
+                rc = ubatch2.run(uenc, usz2)
+                if rc != capi.OK:
                     raise SystemExit("SRLAMI355X_EncodeBatch (unequal corpus, second set) -> %d" % rc)
                 t1 = time.perf_counter()
                 rc = ubatch.run(uenc, usz)

@@ -268,6 +268,11 @@ struct SRLAMI355XStats {
 uint32_t SRLAMI355X_NonIdenticalReasons(struct SRLAEncoder *encoder, uint32_t num_samples);
 /* cumulative since Create or the last reset */
 void SRLAMI355X_GetStats(struct SRLAEncoder *encoder, struct SRLAMI355XStats *stats, int reset);
+/* The same for a caller that may have been built against another revision of this header (the structure only ever grows at its
+ * end): at most `stats_bytes` bytes are written; returns the structure's size in THIS library (0: no such handle), so a caller
+ * can tell which of its fields were filled.  SRLAMI355X_GetStats writes sizeof(struct SRLAMI355XStats) of the header it was
+ * compiled with -- rebuild against the current header when the library is updated. */
+uint32_t SRLAMI355X_GetStatsSized(struct SRLAEncoder *encoder, void *stats, uint32_t stats_bytes, int reset);
 
 /* Stage-level probe for the parity tests: analyses one block exactly as the block-division
  * search would and returns every channel variant.  variants = num_channels (+2 when >= 2:

@@ -417,10 +417,17 @@ void SRLAMI355X_SetPackThreads(struct SRLAEncoder *encoder, uint32_t num_threads
 
 void SRLAMI355X_GetStats(struct SRLAEncoder *encoder, struct SRLAMI355XStats *stats, int reset)
 {
+    (void)SRLAMI355X_GetStatsSized(encoder, stats, (uint32_t)sizeof(struct SRLAMI355XStats), reset);
+}
+
+uint32_t SRLAMI355X_GetStatsSized(struct SRLAEncoder *encoder, void *stats, uint32_t stats_bytes, int reset)
+{
     Impl *im = impl_of(encoder);
-    if (!im) return;
-    if (stats) *stats = im->stats;
+    if (!im) return 0;
+    const uint32_t n = std::min<uint32_t>(stats_bytes, (uint32_t)sizeof(im->stats));
+    if (stats && n) memcpy(stats, &im->stats, n);
     if (reset) memset(&im->stats, 0, sizeof(im->stats));
+    return (uint32_t)sizeof(im->stats);
 }
 
 SRLAApiResult SRLAMI355X_ProbeBlock(struct SRLAEncoder *encoder, const int32_t *const *input, uint32_t num_samples,
@@ -475,6 +482,7 @@ int SRLAMI355X_TestPlanJobs(struct SRLAEncoder *encoder, uint32_t num_streams, c
     if (im == nullptr || !im->set_parameter || num_streams == 0 || num_samples == nullptr || out == nullptr) return -1;
     const bool search = im->search_enabled();
     static const int32_t dummy = 0;
+    if (!im->dev_ready) im->read_environment();     /* (a handle that has not met its device yet: the sizing variables, SRLA_MI355X_SLOTS above all, as a call would see them) */
     im->sx.assign(num_streams, StreamCtx());
     for (uint32_t i = 0; i < num_streams; i++) {
         StreamCtx &st = im->sx[i];

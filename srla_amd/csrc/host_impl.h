@@ -225,7 +225,11 @@ struct Impl {
 
     int device = 0;                   /* HIP device of this handle (SRLAMI355X_SetDevice at the time of Create) */
     bool dev_ready = false, dev_failed = false;
-    static constexpr uint32_t kMaxSlots = 14;         /* up to 9 rotating + 2 tail + 3 chain-mode job buffer sets */
+    /* Buffer sets: [0, kSlots) rotate through a call's whole jobs; [kSlots, kSlots + 2) serve the tail jobs of ONE stream and
+     * [kSlots, 2 kSlots) the remainder jobs of a call of many (host_plan.cpp: only where 2 kSlots <= kChainSlot, i.e. kSlots = 5);
+     * [kChainSlot, kMaxSlots) are chain mode's seed / search / encode jobs.  kSlots = 5 .. 9 (SRLA_MI355X_SLOTS). */
+    static constexpr uint32_t kMaxSlots = 14;
+    static constexpr uint32_t kMaxRotating = kMaxSlots - 5;   /* 9: leaves the two tail sets and chain mode's three */
     static constexpr uint32_t kStreams = 3;   /* more streams than HW queues serialise badly (measured) */
     hipStream_t streams[kStreams] = {};
     hipStream_t chain_stream = nullptr; /* autocorrelation rounds of chain mode */
@@ -392,6 +396,7 @@ struct Impl {
         ChainJob cq, cs, ce;
     } chain;
     static constexpr uint32_t kChainSlot = kMaxSlots - 3;   /* seed, search, encode */
+    static_assert(kMaxRotating + 2 <= kChainSlot && 5 + 5 <= kChainSlot, "the tail sets (any kSlots) and the remainder sets (kSlots = 5) lie below the chain-mode sets");
     bool chain_silent(const std::vector<int32_t> &v, uint32_t total, uint32_t off, uint32_t n) const;
     void chain_slot_defaults(Slot &s);
     bool chain_make_job(Slot &s, uint32_t s0, uint32_t ns, bool search, const std::vector<uint32_t> *lens);

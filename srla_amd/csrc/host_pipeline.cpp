@@ -922,6 +922,7 @@ SRLAApiResult Impl::encode_streams(bool search)
     const auto t0 = Clock::now();
     const uint32_t nst = (uint32_t)sx.size(), nch = par.num_channels;
     const bool single = nst == 1;
+    call_solo = false; planned_pieces = false;      /* per-call state: the history branch below returns before either is decided, and stage_input reads call_solo */
     auto drain = [&]() {
         for (auto &st : streams) if (st) (void)hipStreamSynchronize(st);
         if (upload) (void)hipStreamSynchronize(upload);

@@ -345,11 +345,15 @@ void Impl::plan_jobs(std::vector<JobPlan> &plan, bool search)
             plan.push_back(jp);
         }
     }
-    /* The jobs of remainders rotate through buffer sets of their own (kSlots .. kSlots + 4, where there is room for them): in the
+    /* The jobs of remainders rotate through buffer sets of their own (kSlots .. 2 kSlots - 1, where there is room for them below the chain-mode sets): in the
      * whole jobs' sets each of them threw out the ONE table every whole job shares, and the next call's first jobs -- the very jobs
      * the idle device waits for -- built theirs again (1.5 - 2.3 ms of host time each at -V 2 -P 3; C5 1 916 -> 1 977, nine unequal files
      * 1 700 -> 1 776 Msamples/s: profiles/r05/ab_host_path.txt). */
-    const uint32_t rem_sets = (kSlots + 5u + 3u <= kMaxSlots) ? 5u : 0u;
+    /* (as many of them as there are rotating sets: a set is then taken again kSlots jobs later, which is what the pipeline's
+     * run-ahead -- lag + 1 <= kSlots, host_pipeline.cpp -- needs for ANY kSlots; with a fixed five, SRLA_MI355X_SLOTS=6 let remainder
+     * job r + 5 restage the set of job r while r was still in flight.  Where they do not fit below the chain-mode sets the
+     * remainders take turns with the whole jobs as before.) */
+    const uint32_t rem_sets = (kSlots + kSlots <= kChainSlot) ? kSlots : 0u;
     uint32_t rem_index = 0;
     JobPlan cur;
     auto close = [&]() {

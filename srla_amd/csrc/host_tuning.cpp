@@ -34,8 +34,8 @@ void Impl::read_environment()
         /* the software pipeline keeps up to depth + 1 = 5 jobs in flight: fewer buffer sets would be reused before their
          * job has been collected; + 2 slots for the tail jobs, + 3 for chain mode */
         const int v = (int)number("SRLA_MI355X_SLOTS", 0);
-        if (v >= 5 && v + 5 <= (int)kMaxSlots) kSlots = (uint32_t)v;
-        else fprintf(stderr, "[srla-mi355x] SRLA_MI355X_SLOTS=%d ignored: %d..%d job buffer sets are supported\n", v, 5, (int)kMaxSlots - 5);
+        if (v >= 5 && v <= (int)kMaxRotating) kSlots = (uint32_t)v;
+        else fprintf(stderr, "[srla-mi355x] SRLA_MI355X_SLOTS=%d ignored: %d..%d job buffer sets are supported\n", v, 5, (int)kMaxRotating);
     }
     { const long long v = number("SRLA_MI355X_JOB_SAMPLES", 0); if (v >= 65536) job_samples = (uint64_t)v; }
     { const long long v = number("SRLA_MI355X_SHORT_MIN", 0); if (v >= 16384) short_min = (uint32_t)v; }

@@ -27,6 +27,26 @@ def test_library_exports_every_declared_symbol(product):
         assert hasattr(product.lib, n), n
 
 
+def test_statistics_for_a_caller_built_against_an_older_header(product):
+    """SRLAMI355XStats grows at its end from round to round; SRLAMI355X_GetStatsSized writes no more than the caller's structure
+    holds and says how large the library's is (the advisor's finding of round 5: GetStats wrote sizeof of ITS header)."""
+    cfg, par = capi.cli_setup(2, 16, 48000, preset=4, max_block=4096, divisions=1)
+    enc = product.create(cfg)
+    fn = product.lib.SRLAMI355X_GetStatsSized
+    fn.restype = C.c_uint32
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]
+    text = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    body = re.search(r"struct SRLAMI355XStats\s*\{(.*?)\};", text, flags=re.S).group(1)
+    fields = re.findall(r"\b(uint64_t|double)\s+\w+;", body)
+    buf = np.full(1024, 0xAB, dtype=np.uint8)
+    size = fn(enc, buf.ctypes.data, 64, 0)
+    assert size == 8 * len(fields) and size >= 256            # every member is 8 bytes wide
+    assert not buf[:64].any() and (buf[64:] == 0xAB).all()    # a fresh handle's counters are zero; nothing beyond the caller's 64 bytes
+    assert fn(enc, buf.ctypes.data, 1024, 0) == size and not buf[:size].any() and (buf[size:] == 0xAB).all()
+    assert fn(None, buf.ctypes.data, 64, 0) == 0
+    product.destroy(enc)
+
+
 def test_struct_layouts_match_the_reference():
     assert C.sizeof(capi.SRLAHeader) == 32
     assert C.sizeof(capi.SRLAEncodeParameter) == 32

@@ -35,13 +35,13 @@ def _plan(lib, enc, lengths, device_input=False):
     return jobs
 
 
-def _check(jobs, lengths, window_len, tails):
+def _check(jobs, lengths, window_len, tails, reuse_distance=REUSE_DISTANCE):
     pos = [0] * len(lengths)
     last_use = {}
     for j, (slot, total, segs) in enumerate(jobs):
         assert slot < CHAIN_SETS_FROM, (j, slot)
         if slot in last_use:
-            assert j - last_use[slot] >= REUSE_DISTANCE, "buffer set %d taken by jobs %d and %d" % (slot, last_use[slot], j)
+            assert j - last_use[slot] >= reuse_distance, "buffer set %d taken by jobs %d and %d" % (slot, last_use[slot], j)
         last_use[slot] = j
         assert segs and total % 16 == 0
         end = 0
@@ -100,6 +100,32 @@ def test_every_plan_covers_its_streams_once_and_keeps_the_buffer_sets_apart(cli)
         tails = [_tail(n, window_len, grid, par.ltp_order) for n in lengths]
         _check(_plan(lib, enc, lengths), lengths, window_len, tails)
     lib.destroy(enc)
+
+
+@pytest.mark.parametrize("slots", [6, 7, 9])
+def test_more_rotating_sets_keep_every_set_apart_by_the_deeper_pipeline(slots, monkeypatch):
+    """SRLA_MI355X_SLOTS = 6 .. 9: the host runs further ahead (host_pipeline.cpp: lag = depth + min(8, kSlots - 1 - depth), a job
+    is collected lag iterations after it was begun), so a buffer set must not come round again before kSlots jobs have passed --
+    for the remainder jobs of a call of many streams too (round 5 gave them five sets of their own whatever kSlots was: with six
+    rotating sets remainder job r + 5 restaged the set of job r while r was still in flight; found by the advisor)."""
+    monkeypatch.setenv("SRLA_MI355X_SLOTS", str(slots))
+    lib = capi.EncoderLib(helpers.PRODUCT_SO)
+    rnd = random.Random(slots)
+    for cli in (CASES[0], CASES[1]):
+        cfg, par = capi.cli_setup(2, 16, 48000, **cli)
+        enc = lib.create(cfg)
+        assert lib.set_parameter(enc, par) == capi.OK
+        window_len, grid = par.num_lookahead_samples, par.min_num_samples_per_block
+        # many streams with remainders: whole jobs first, then at least a dozen remainder jobs
+        for _ in range(12):
+            lengths = [(4 << 20) * rnd.randrange(0, 3) + rnd.randrange(2_200_000, 4_000_000) for _ in range(rnd.randrange(14, 40))]
+            tails = [_tail(n, window_len, grid, par.ltp_order) for n in lengths]
+            jobs = _plan(lib, enc, lengths)
+            assert sum(1 for _, _, segs in jobs if segs[0][2] != 4 << 20) >= 7      # remainder jobs: more than the five sets round 5 gave them
+            _check(jobs, lengths, window_len, tails, reuse_distance=slots)
+        for n in (28_800_000, 2_880_000, 9_600_000, 86_400_000):
+            _check(_plan(lib, enc, [n]), [n], window_len, [_tail(n, window_len, grid, par.ltp_order)], reuse_distance=min(slots, 5))
+        lib.destroy(enc)
 
 
 def test_the_metric_stream_is_planned_as_documented():
