@@ -370,6 +370,114 @@ def roofline_object(st, config, launches, instants_per_launch, algo_bytes, end_t
     return roof
 
 
+# the other BASELINE configurations on the default line (round 6): a bounded leg each behind the metric's own legs, so that what the
+# driver records for the metric configuration comes with figures for C2 .. C5 measured by the same run on the same box, each next
+# to the compiled reference on one core at the same flags.  (seconds of audio the reference encodes for its figure: about 4 s of
+# CPU work each on the GPU boxes' hosts)
+LEG_CONFIGS = ("C2", "C3", "C4", "C5")
+LEG_CPU_SECONDS = {"C2": 100.0, "C3": 40.0, "C4": 28.0, "C5": 24.0}
+LEG_NOMINAL = {"C2": 7500.0, "C3": 2800.0, "C4": 1800.0, "C5": 2100.0}
+
+
+def leg_cpu_baseline(pcm, name, rate, bps):
+    """the compiled reference (the oracle where it did not travel) on ONE core at the configuration's flags: one timed
+    SRLAEncoder_EncodeWhole of the first LEG_CPU_SECONDS of the stream, in memory"""
+    import numpy as np
+    import helpers
+    from srla_amd import capi
+    cli = dict(CONFIGS[name]["cli"])
+    kind = "reference" if os.path.exists(helpers.REF_SO) else "port"
+    n = min(pcm.shape[1], int(LEG_CPU_SECONDS[name] * rate))
+    clip = np.ascontiguousarray(pcm[:, :n])
+    t0 = time.perf_counter()
+    if kind == "reference":
+        out = capi.EncoderLib(helpers.REF_SO).encode(clip, bits_per_sample=bps, sampling_rate=rate, **cli)
+    else:
+        out = helpers.Oracle(clip.shape[0], bits_per_sample=bps, sampling_rate=rate, **cli).encode_whole(clip)
+    dt = time.perf_counter() - t0
+    return {"value": round(n / dt / 1e6, 4), "unit": "Msamples/s", "cores": 1, "kind": kind,
+            "sample": "first %.0f s of the leg's first stream (%d samples/ch, %d ch), one run" % (n / rate, n, clip.shape[0]), "bytes": int(out.size)}
+
+
+def config_leg(lib, L, name, streams_src, rate, nch, bps, pack_threads, cpu_line, budget_s=2.0):
+    """One bounded leg of another BASELINE configuration: the same timed-region rule as the headline (calls of the unchanged API
+    back to back between device synchronisations, pageable host memory -> pageable host memory), its stages' HIP-event times
+    priced as the headline's are."""
+    import numpy as np
+    import torch
+    import helpers
+    from srla_amd import capi
+    conf = CONFIGS[name]
+    cli = dict(conf["cli"])
+    files = conf.get("files", 1)
+    n = int(conf["seconds"] * rate) & ~1
+    # the leg's streams are cut out of the run's two synthetic streams (seeds 1000 / 4242) at different offsets: nine files of
+    # 300 s are nine different 300 s windows -- synthesising nine more would cost the run ten seconds
+    pcms = []
+    per_src = -(-files // len(streams_src))                       # windows taken from each source stream
+    for f in range(files):
+        src = streams_src[f % len(streams_src)]
+        span = src.shape[1] - n
+        off = 0 if per_src == 1 else ((f // len(streams_src)) * (span // (per_src - 1))) & ~1
+        pcms.append(np.ascontiguousarray(src[:, off:off + n]))
+    cfg, par = capi.cli_setup(nch, bps, rate, **cli)
+    enc = lib.create(cfg)
+    assert enc and lib.set_parameter(enc, par) == capi.OK
+    L.SRLAMI355X_SetPackThreads(enc, pack_threads)
+    cap = 2 * pcms[0].size * (bps // 8) + 4096
+    outs = [np.zeros(cap, dtype=np.uint8) for _ in range(files)]
+    sizes = (C.c_uint32 * files)()
+    if files == 1:
+        planes = capi.planar_ptrs(pcms[0])
+
+        def call():
+            rc = L.SRLAEncoder_EncodeWhole(enc, planes, n, outs[0].ctypes.data_as(C.c_void_p), cap, C.cast(sizes, C.POINTER(C.c_uint32)), None)
+            if rc != capi.OK:
+                raise SystemExit("SRLAEncoder_EncodeWhole (%s leg) -> %d" % (name, rc))
+    else:
+        batch = capi.BatchCall(lib, pcms, outs)
+
+        def call():
+            rc = batch.run(enc, sizes)
+            if rc != capi.OK:
+                raise SystemExit("SRLAMI355X_EncodeBatch (%s leg) -> %d" % (name, rc))
+    calls = max(3, int(round(budget_s * LEG_NOMINAL[name] * 1e6 / (float(n) * files))))
+    for _ in range(2):
+        call()
+    st = Stats()
+    L.SRLAMI355X_GetStats(enc, C.byref(st), 1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(calls):
+        call()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    L.SRLAMI355X_GetStats(enc, C.byref(st), 0)
+    value = float(n) * files * calls / dt / 1e6
+    launches = max(1, st.analyze_launches)
+    instants_per_launch = float(n) * files * calls / launches
+    algo_bytes = 8.0 * nch * instants_per_launch
+    roof = roofline_object(st, name, launches, instants_per_launch, algo_bytes, 8.0 * nch * float(n) * files * calls / dt / 1e9, cli=cli if nch == 2 else None)
+    stream0 = outs[0][:sizes[0]].copy()
+    leg = {"value": round(value, 3), "unit": "Msamples/s", "ms_per_step": round(1e3 * dt / calls, 3), "calls": calls,
+           "workload": "%s: srla -e -m %d -B %d -V %d -L 4 -P %d; %d x %.0f s per %s call, %d calls back to back, pageable -> pageable" % (
+               name, cli["preset"], cli["max_block"], cli["divisions"], cli["ltp_order"], files, n / rate,
+               "SRLAEncoder_EncodeWhole" if files == 1 else "SRLAMI355X_EncodeBatch", calls),
+           "compression_ratio": round(sum(int(sizes[f]) for f in range(files)) / float(sum(p_.size for p_ in pcms) * (bps // 8)), 6),
+           "lossless_roundtrip_first_stream": bool((helpers.oracle_decode(stream0) == pcms[0]).all()),
+           "roofline": {"bound": "hbm", "kernel": roof["kernel"], "avg_launch_ms": roof["avg_launch_ms"], "achieved": roof["achieved"], "peak": roof["peak"],
+                        "unit": "GB/s", "frac": roof["frac"], "traffic": roof["traffic"],
+                        "stage_ms_per_job": {k: v["ms_per_job"] for k, v in roof["stages"].items() if v.get("ms_per_job")},
+                        "fp64": {k: roof["fp64"][k] for k in ("achieved_tflops", "peak_no_fma_tflops", "frac")} if roof.get("fp64") else None,
+                        "int_valu": {k: roof["int_valu"][k] for k in roof["int_valu"] if k != "note"} if roof.get("int_valu") else None,
+                        "end_to_end": roof["end_to_end"], "profile_stale": roof.get("profile_stale")},
+           "cpu_baseline": cpu_line}
+    if cpu_line is not None:
+        leg["speedup_vs_cpu_1core"] = round(value / cpu_line["value"], 2)
+    lib.destroy(enc)
+    return leg
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=None, help="ranks (one GPU each); default: WORLD_SIZE of the launcher, else 1")
@@ -392,7 +500,12 @@ def parse_args(argv=None):
     ap.add_argument("--no-numa-pin", action="store_true", help="do not restrict the process to the GPU-local NUMA node")
     ap.add_argument("--pack-threads", type=int, default=0, help="host pool threads (staging copies; default: min(8, usable CPUs / ranks))")
     ap.add_argument("--pinned-io", action="store_true", help="headline with pinned input planes and a pinned output buffer (reported in config.workload)")
+    ap.add_argument("--feed", default="planes", choices=["planes", "pcm"],
+                    help="planes (default, the metric's timed region): planar int32 through SRLAEncoder_EncodeWhole / SRLAMI355X_EncodeBatch; "
+                         "pcm: the same streams as interleaved 16-bit PCM frames -- what a WAV data chunk holds before libs/wav widens it -- "
+                         "through SRLAMI355X_EncodeBatchPcm, de-interleaved on the device: no per-sample host work (reported in config.workload)")
     ap.add_argument("--no-extras", action="store_true", help="only the timed steps: no device_resident / stream_60s / stream_10s sections (profiler runs)")
+    ap.add_argument("--no-config-legs", action="store_true", help="without the bounded legs of C2 .. C5 behind the metric's own (`configs` on the line)")
     ap.add_argument("--dry-run", action="store_true", help="launch / rendezvous / reduce only, no GPU work (CPU test of the N-rank flow)")
     return ap.parse_args(argv)
 
@@ -534,7 +647,21 @@ def main(argv=None):
     out_sizes = (C.c_uint32 * files)()
     planes = [capi.planar_ptrs(p) for p in pcms]
 
-    if files == 1:
+    if args.feed == "pcm":
+        if bps != 16:
+            raise SystemExit("bench.py --feed pcm: 16-bit input only")
+        # interleaved little-endian frames [n][nch] int16: the WAV data chunk of the same stream (libs/wav/src/wav.c:848-852 widens
+        # it to the planes the reference's API takes)
+        frames = [np.ascontiguousarray(p.T.astype(np.int16)) for p in pcms]
+        if args.pinned_io:
+            frames = [torch.from_numpy(f).pin_memory().numpy() for f in frames]
+        pbatch = capi.PcmBatchCall(lib, frames, [n] * files, 2, outs)
+
+        def call():
+            rc = pbatch.run(enc, out_sizes)
+            if rc != capi.OK:
+                raise SystemExit("SRLAMI355X_EncodeBatchPcm -> %d" % rc)
+    elif files == 1:
         def call():
             rc = L.SRLAEncoder_EncodeWhole(enc, planes[0], n, outs[0].ctypes.data_as(C.c_void_p), cap, C.cast(out_sizes, C.POINTER(C.c_uint32)), None)
             if rc != capi.OK:
@@ -556,6 +683,12 @@ def main(argv=None):
     cpu_line = None
     if not args.no_cpu_baseline and world == 1 and rank == 0:
         cpu_line = cpu_baseline(pcms[0], cli, args.cpu_seconds, rate, bps)
+    # ... and the reference at the other configurations' flags (the legs of `configs` below), host-only work as well
+    want_legs = world == 1 and files == 1 and args.config == "M" and not args.no_extras and not args.no_config_legs and bps == 16 and args.feed == "planes"
+    leg_cpu = {}
+    if want_legs and not args.no_cpu_baseline:
+        for name in LEG_CONFIGS:
+            leg_cpu[name] = leg_cpu_baseline(pcms[0], name, rate, bps)
 
     for _ in range(args.warmup):
         step()
@@ -609,10 +742,13 @@ def main(argv=None):
             "value": round(value, 3), "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "config": {"workload": "%s: srla -e -m %d -B %d -V %d -L 4 -P %d; %d x %.0f s synthetic %d-ch %g kHz/%d-bit (%s) per call, "
                                    "%d call(s) back to back per GPU per step; "
-                                   "%s: planar int32 in %s host memory -> complete .srl stream(s) in %s host memory" %
+                                   "%s: input in %s host memory -> complete .srl stream(s) in %s host memory" %
                                    (args.config, cli["preset"], cli["max_block"], cli["divisions"], cli["ltp_order"], files, n / rate, nch,
-                                    rate / 1000.0, bps, conf["kind"], calls, "SRLAEncoder_EncodeWhole" if files == 1 else "SRLAMI355X_EncodeBatch",
+                                    rate / 1000.0, bps, conf["kind"], calls,
+                                    "SRLAMI355X_EncodeBatchPcm (--feed pcm: interleaved 16-bit frames instead of planar int32)" if args.feed == "pcm" else
+                                    ("SRLAEncoder_EncodeWhole" if files == 1 else "SRLAMI355X_EncodeBatch"),
                                     "pinned" if args.pinned_io else "pageable", "pinned" if args.pinned_io else "pageable"),
+                       "feed": args.feed,
                        "samples_per_channel_per_step": n * files * calls, "samples_per_channel_per_call": n * files,
                        "calls_per_step": calls, "streams_per_step": files * calls,
                        "parallelism": "windows / files sharded per GPU, no collective"},
@@ -641,7 +777,7 @@ def main(argv=None):
                 "staged through pinned buffers by %d host threads" % pack_threads,
                 "page-locked in place per call, written by the device" if st.num_inplace_out_pins else "copied out of pinned staging buffers")),
         })
-        if world == 1 and files == 1 and not args.no_extras:
+        if world == 1 and files == 1 and not args.no_extras and args.feed == "planes":
             # the same encode with the samples resident in HBM and a pinned output buffer (what a caller that already holds
             # the samples on the device gets): reported beside `value`, never as `value`
             d_pcm = torch.from_numpy(pcms[0]).cuda()
@@ -661,7 +797,7 @@ def main(argv=None):
             line["device_resident"] = {"value": round(n / dt / 1e6, 3), "unit": "Msamples/s", "ms_per_call": round(1e3 * dt, 3),
                                        "same_bytes": bool(np.array_equal(out_t.numpy()[:dsz.value], streams[0])),
                                        "note": "SRLAMI355X_EncodeWholeDevice: samples resident in HBM, pinned output buffer; median of %d calls" % reps}
-        if world == 1 and files == 1 and not args.no_extras:
+        if world == 1 and files == 1 and not args.no_extras and args.feed == "planes":
             # SURVEY 8d's own input length (60 s; and 10 s) through the same unchanged SRLAEncoder_EncodeWhole, pageable host
             # memory to pageable host memory: short streams cannot hide the pipeline's fill and drain.  Beside `value`, never it.
             for secs in (60, 10):
@@ -683,7 +819,7 @@ def main(argv=None):
                 line["stream_%ds" % secs] = {"value": round(m / dt / 1e6, 3), "unit": "Msamples/s", "ms_per_call": round(1e3 * dt, 3),
                                              "lossless_roundtrip": bool((helpers.oracle_decode(outs[0][:sz.value].copy()) == clip).all()),
                                              "note": "one %d s stream per SRLAEncoder_EncodeWhole call, pageable -> pageable; median of %d calls" % (secs, len(times))}
-        if world == 1 and files == 1 and not args.no_extras:
+        if world == 1 and files == 1 and not args.no_extras and args.feed == "planes":
             # (a) the headline's calls alternating between two DIFFERENT streams of the same length: whatever the library keeps from
             # the call before (descriptor tables by job shape, host_plan.cpp) is keyed by shape, never by content -- this leg shows it
             other = helpers.synth(kind, 4242, rate, nch, n, bps)
@@ -710,7 +846,7 @@ def main(argv=None):
                                           "same_bytes_first_stream": bool(np.array_equal(outs[0][:out_sizes[0]], streams[0])),
                                           "lossless_roundtrip_second_stream": bool((helpers.oracle_decode(oout[:osz.value].copy()) == other).all()),
                                           "note": "%d calls back to back, alternating between two different %d s streams (seeds 1000 / 4242), pageable -> pageable" % (reps, n // rate)}
-            del other, oout
+            del oout
             # (b) a corpus of UNEQUAL files in one SRLAMI355X_EncodeBatch call under config 5's flags: every call plans tail jobs of
             # shapes the equal-length C5 line never sees
             import random
@@ -763,6 +899,10 @@ def main(argv=None):
             del upcms2, uouts2
             lib.destroy(uenc)
             del upcms, uouts
+            # (c) the other BASELINE configurations, a bounded leg each (LEG_CONFIGS): value, stage times, roofs, the reference beside it
+            if want_legs:
+                line["configs"] = {name: config_leg(lib, L, name, [pcms[0], other], rate, nch, bps, pack_threads, leg_cpu.get(name)) for name in LEG_CONFIGS}
+            del other
         if cpu_line is not None:                           # rank 0 at N = 1 only; measured before the timed region
             line["cpu_baseline"] = cpu_line
             line["speedup_vs_cpu_1core"] = round(value / cpu_line["value"], 2)

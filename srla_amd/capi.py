@@ -218,6 +218,28 @@ class BatchCall:
         return self.fn(enc, self.n, self.inputs, self.num_samples, self.data, self.data_size, out_sizes, self.results)
 
 
+class PcmBatchCall:
+    """SRLAMI355X_EncodeBatchPcm with a fixed set of streams (interleaved little-endian PCM frames, what a WAV data chunk holds) and
+    output buffers: the pointer tables are built once, so that repeated calls cost nothing on the Python side."""
+
+    def __init__(self, lib, frames, num_samples, bytes_per_sample, outs):
+        fn = lib.lib.SRLAMI355X_EncodeBatchPcm
+        fn.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        fn.restype = C.c_int
+        self.fn = fn
+        n = self.n = len(frames)
+        self._keep = (frames, outs)
+        self.ptrs = (C.c_void_p * n)(*[f.ctypes.data for f in frames])
+        self.num_samples = (C.c_uint32 * n)(*[int(x) for x in num_samples])
+        self.bytes_per_sample = int(bytes_per_sample)
+        self.data = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+        self.data_size = (C.c_uint32 * n)(*[o.size for o in outs])
+        self.results = (C.c_int * n)()
+
+    def run(self, enc, out_sizes):
+        return self.fn(enc, self.n, self.ptrs, self.num_samples, self.bytes_per_sample, self.data, self.data_size, out_sizes, self.results)
+
+
 def encode_batch(lib, enc, pcms, caps=None):
     """-> (rc, [stream bytes or None], [per-stream result codes])"""
     outs = [np.zeros(int(caps[i] if caps else 2 * p.size * 4 + 1024), dtype=np.uint8) for i, p in enumerate(pcms)]

@@ -245,6 +245,7 @@ __device__ __forceinline__ uint32_t complex_table_len(uint32_t m)
  * Lane -> butterfly: local index u = lane + 64 r; the wavefront's RPW = 4 / (NTK / 64) regions have BPR = M / 16 butterflies
  * each per stage: region = wave RPW + u / BPR, j = u % BPR. */
 __device__ __forceinline__ uint32_t fft_swz(uint32_t e) { return e ^ ((e >> 3) & 3u); }
+__device__ __forceinline__ uint32_t fft_swz16(uint32_t e) { return e ^ ((e >> 4) & 7u); }    /* the eight-wavefront class, see fft_subregions */
 
 template <int R, int NTK, int M, int FLAG, bool PRUNE, bool INSWZ>
 __device__ __forceinline__ void fft_regions(cplx *x, const cplx *__restrict__ tw, const uint32_t need)
@@ -338,7 +339,7 @@ __device__ __forceinline__ void fft_regions(cplx *x, const cplx *__restrict__ tw
  * the inverse -- at fft_swz of their index: what spectrum_power_pass_regions leaves) and puts output k where input k stood,
  * which is position bf (or fft_swz(bf)) of region k.  No thread touches another's slots, so there is no barrier between its loads
  * and stores; one barrier behind. */
-template <int R, int NTK, int M, int FLAG, bool SWZ>
+template <int R, int NTK, int M, int FLAG, int SWZ /* 0: natural order, 1: at fft_swz, 2: at fft_swz16 (the eight-wavefront class) */>
 __device__ __forceinline__ void fft_first_stage_regions(cplx *x, const cplx *__restrict__ tw)
 {
     constexpr uint32_t QM = (uint32_t)M >> 2;
@@ -348,7 +349,7 @@ __device__ __forceinline__ void fft_first_stage_regions(cplx *x, const cplx *__r
         const uint32_t bf = threadIdx.x + (uint32_t)r * NTK;
         const cplx *t = tw + bf;
         const cplx w1 = t[0], w2 = t[QM], w3 = t[2 * QM];
-        cplx *xi = x + (SWZ ? fft_swz(bf) : bf);
+        cplx *xi = x + ((SWZ == 2) ? fft_swz16(bf) : ((SWZ == 1) ? fft_swz(bf) : bf));
         const cplx a = xi[0], b = xi[QM], c = xi[2 * QM], d = xi[3 * QM];
         const cplx apc = c_add(a, c), amc = c_sub(a, c), bpd = c_add(b, d), bmd = c_sub(b, d);
         const cplx jbmd = (FLAG < 0) ? make_double2(-bmd.y, bmd.x) : make_double2(bmd.y, -bmd.x);
@@ -383,6 +384,130 @@ __device__ __forceinline__ void fft_first_stage_regs_regions(cplx *x, const doub
         xo[3 * QM] = c_mul(w3, c_add(amc, jbmd));
     }
     __syncthreads();
+}
+
+/* ---- The same idea one level deeper, for the class of EIGHT wavefronts (round 6: 8192 points, M = 4096 complex on 512 threads) ----
+ * Four regions cannot be dealt to eight wavefronts.  But the split repeats: after the SECOND radix-4 stage the data falls into
+ * sixteen independent sub-transforms by index mod 16 (a stage with stride s >= 16 keeps q = index mod s, fft.c:71-128), and
+ * inside a region the second stage is "the region's first stage", which is in place again on the region layout: butterfly j of
+ * region rho reads the region's positions j + k QM/4 and leaves output k = position 4 j + k where input k stood -- slot
+ * k QM/4 + j, i.e. position j of SUB-REGION k.  So: element e of the transform stands, after two stages, at
+ *     (e & 3) QM + ((e >> 2) & 3) SQ + (e >> 4)        QM = M / 4, SQ = M / 16 (256 complex points),
+ * every wavefront owns two whole sub-regions, and stages 3 .. last of either direction run without a workgroup barrier
+ * (fft_subregions: the butterflies of an ordinary 256-point transform with the table entries of the M-point one -- the twiddle
+ * index p of butterfly jj is the same number).  Barriers per item: behind the first and the second stage of either direction,
+ * in front of / inside / behind the spectrum pass, in front of the lag stores -- 8 instead of 26.
+ * The inverse's input is written by the spectrum pass, whose lanes run along a sub-region (bins 16 apart): natural order
+ * permuted by fft_swz16(e) = e ^ ((e >> 4) & 7) puts the eight lanes of a 16-byte store on eight columns; the inverse's first two
+ * stages work in place on that order (k QM and k SQ do not reach bits 0 .. 6), and its first wave-private stage reads position
+ * jj + 64 k of its sub-region at 64 k + (fft_swz(jj with bits 4, 5) ^ 4 (k & 1)) -- see fft_subregions.
+ * Same butterflies, same operands, same order of operations: the same bits (tests/test_kernel_models.py replays the addresses). */
+
+/* the second stage, in place inside every region, all wavefronts; one barrier behind.  SWZ: the regions' positions stand at fft_swz16 */
+template <int R, int NTK, int M, int FLAG, bool PRUNE, bool SWZ>
+__device__ __forceinline__ void fft_second_stage_regions(cplx *x, const cplx *__restrict__ tw, const uint32_t need)
+{
+    constexpr uint32_t QM = (uint32_t)M >> 2, SQ = (uint32_t)M >> 4;
+    static_assert(R * NTK == (int)QM, "one second-stage butterfly per thread and r");
+    constexpr uint32_t twoff = 3u * ((uint32_t)M >> 2), n1 = (uint32_t)M >> 4;     /* behind the first stage's tables; entries per table */
+    const bool k1 = !PRUNE || 4u < need, k2 = !PRUNE || 8u < need, k3 = !PRUNE || 12u < need;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const uint32_t u = threadIdx.x + (uint32_t)r * NTK;
+        const uint32_t rho = u / SQ, j = u % SQ;                                      /* q = rho, p = j */
+        if (!PRUNE || rho < need) {
+            const cplx *t = tw + twoff + j;
+            cplx w1, w2, w3;
+            if (k1) w1 = t[0];
+            if (k2) w2 = t[n1];
+            if (k3) w3 = t[2 * n1];
+            cplx *xi = x + rho * QM + (SWZ ? fft_swz16(j) : j);
+            const cplx a = xi[0], b = xi[SQ], c = xi[2 * SQ], d = xi[3 * SQ];
+            const cplx apc = c_add(a, c), amc = c_sub(a, c), bpd = c_add(b, d), bmd = c_sub(b, d);
+            const cplx jbmd = (FLAG < 0) ? make_double2(-bmd.y, bmd.x) : make_double2(bmd.y, -bmd.x);
+            xi[0] = c_add(apc, bpd);
+            if (k1) xi[SQ] = c_mul(w1, c_sub(amc, jbmd));
+            if (k2) xi[2 * SQ] = c_mul(w2, c_sub(apc, bpd));
+            if (k3) xi[3 * SQ] = c_mul(w3, c_add(amc, jbmd));
+        }
+    }
+    __syncthreads();
+}
+
+/* stages 3 .. last on the sub-region layout, wave-private.  Lane -> butterfly: u = lane + 64 r; the wavefront's GPW = 16 / (NTK / 64)
+ * sub-regions have BPG = M / 64 butterflies each per stage: sub-region g = wave GPW + u / BPG (region g >> 2, residue 4 (g & 3) + (g >> 2)
+ * of the element index mod 16), butterfly jj = u % BPG.  INSWZ (the inverse): the sub-regions' positions stand at fft_swz16. */
+template <int R, int NTK, int M, int FLAG, bool PRUNE, bool INSWZ>
+__device__ __forceinline__ void fft_subregions(cplx *x, const cplx *__restrict__ tw, const uint32_t need)
+{
+    constexpr int NW = NTK / 64, GPW = 16 / NW;
+    constexpr uint32_t SQ = (uint32_t)M >> 4, BPG = (uint32_t)M >> 6, SUB4 = (uint32_t)M >> 6;   /* sub-region size; butterflies per sub-region and stage; quarter of a sub-region */
+    static_assert(NW >= 1 && NW <= 16 && GPW * (int)BPG == 64 * R, "every wavefront owns whole sub-regions");
+    static_assert(SUB4 >= 64, "the swizzles below leave k SUB4 alone");
+    constexpr int NST = (M >= 4096) ? 6 : ((M >= 1024) ? 5 : ((M >= 256) ? 4 : 3));
+    static_assert(((uint32_t)M >> (2 * NST)) == 1, "log2 M even (no closing radix-2 stage): 4096 points");
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t twoff = 3u * ((uint32_t)M >> 2) + 3u * ((uint32_t)M >> 4);           /* behind the first two stages' tables */
+#pragma unroll
+    for (int st = 2; st < NST; st++) {
+        const uint32_t n = (uint32_t)M >> (2 * st), s = 1u << (2 * st), sl = s >> 4, log2sl = 2u * (uint32_t)(st - 2);
+        const uint32_t n1 = n >> 2;
+        const bool k1 = !PRUNE || s < need, k2 = !PRUNE || 2 * s < need, k3 = !PRUNE || 3 * s < need;
+        cplx a[R], b[R], c[R], d[R], w1[R], w2[R], w3[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const uint32_t u = lane + 64u * (uint32_t)r;
+            const uint32_t g = wave * (uint32_t)GPW + u / BPG, jj = u % BPG;
+            const uint32_t ql = jj & (sl - 1), qres = 4u * (g & 3u) + (g >> 2);
+            if (!PRUNE || 16u * ql + qres < need) {
+                const uint32_t p = jj >> log2sl;
+                const cplx *t = tw + twoff + p;
+                if (k1) w1[r] = t[0];
+                if (k2) w2[r] = t[n1];
+                if (k3) w3[r] = t[2 * n1];
+                if (INSWZ && st == 2) {
+                    /* position jj + SUB4 k stands at fft_swz16 of it: SUB4 k + ((jj ^ ((jj >> 4) & 3)) ^ 4 (k & 1))   (SUB4 = 64) */
+                    const uint32_t pe = jj ^ ((jj >> 4) & 3u);
+                    const cplx *xe = x + g * SQ + pe, *xo = x + g * SQ + (pe ^ 4u);
+                    a[r] = xe[0]; b[r] = xo[SUB4]; c[r] = xe[2 * SUB4]; d[r] = xo[3 * SUB4];
+                } else {
+                    const cplx *xi = x + g * SQ + ((st == 3) ? fft_swz(jj) : jj);
+                    a[r] = xi[0]; b[r] = xi[SUB4]; c[r] = xi[2 * SUB4]; d[r] = xi[3 * SUB4];
+                }
+            }
+        }
+        /* (no barrier: the wavefront's own loads above are executed before its stores below) */
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const uint32_t u = lane + 64u * (uint32_t)r;
+            const uint32_t g = wave * (uint32_t)GPW + u / BPG, jj = u % BPG;
+            const uint32_t ql = jj & (sl - 1), qres = 4u * (g & 3u) + (g >> 2);
+            if (!PRUNE || 16u * ql + qres < need) {
+                const cplx apc = c_add(a[r], c[r]), amc = c_sub(a[r], c[r]), bpd = c_add(b[r], d[r]);
+                const cplx bmd = c_sub(b[r], d[r]);
+                const cplx jbmd = (FLAG < 0) ? make_double2(-bmd.y, bmd.x) : make_double2(bmd.y, -bmd.x);
+                if (st == 2) {
+                    /* the sub-region's first stage: a thread's four outputs are the consecutive positions 4 jj .. 4 jj + 3, permuted among
+                     * themselves as in fft_regions (position e goes to fft_swz(e)); the next stage reads at fft_swz */
+                    const uint32_t kx = (jj >> 1) & 3u;
+                    cplx *xo = x + g * SQ + 4u * jj;
+                    xo[kx] = c_add(apc, bpd);
+                    if (k1) xo[1u ^ kx] = c_mul(w1[r], c_sub(amc, jbmd));
+                    if (k2) xo[2u ^ kx] = c_mul(w2[r], c_sub(apc, bpd));
+                    if (k3) xo[3u ^ kx] = c_mul(w3[r], c_add(amc, jbmd));
+                } else {
+                    cplx *xo = x + g * SQ + (4u * jj - 3u * ql);
+                    xo[0] = c_add(apc, bpd);
+                    if (k1) xo[sl] = c_mul(w1[r], c_sub(amc, jbmd));
+                    if (k2) xo[2 * sl] = c_mul(w2[r], c_sub(apc, bpd));
+                    if (k3) xo[3 * sl] = c_mul(w3[r], c_add(amc, jbmd));
+                }
+            }
+        }
+        asm volatile("" ::: "memory");
+        twoff += 3 * n1;
+    }
 }
 
 /* Between the two transforms, one pass over the spectrum: the symmetry pass of the forward real FFT
@@ -522,6 +647,85 @@ __device__ __forceinline__ void spectrum_power_pass_regions(cplx *x, const cplx 
     __syncthreads();
 }
 
+/* The same pass on the sub-region layout (fft_subregions): bin e stands at (e & 3) QM + ((e >> 2) & 3) SQ + (e >> 4).  Pair P = tid + it NTK:
+ * class P / (M / 32) = 4 rho + sigma, tt = P % (M / 32) stand for bin i = rho + 4 sigma + 16 (tt + first) (first = 1 for the class of
+ * the multiples of 16, which starts at 16 and ends with the self-paired bin M / 2) and its partner M - i in sub-region
+ * ((4 - rho) & 3, 3 - sigma) -- (0, (4 - sigma) & 3) for rho = 0 -- at position SQ - 1 - tt - first: both runs contiguous over the
+ * lanes.  The stores, 16 bins apart from lane to lane, go to fft_swz16 of their natural index: eight lanes, eight columns. */
+template <int NTK, int M>
+__device__ __forceinline__ void spectrum_power_pass_subregions(cplx *x, const cplx *__restrict__ rtw_fwd, const cplx *__restrict__ rtw_inv)
+{
+    constexpr uint32_t QM = (uint32_t)M >> 2, SQ = (uint32_t)M >> 4, PPC = (uint32_t)M >> 5;     /* pairs per class */
+    constexpr int ITS = (M / 2) / NTK;
+    static_assert(ITS * NTK == M / 2 && PPC % 64 == 0, "whole rounds; a wavefront stays inside one class");
+    const uint32_t tid = threadIdx.x;
+    cplx za[ITS], zb[ITS], wf[ITS], wi_[ITS];
+    cplx z0 = make_double2(0.0, 0.0);
+    if (tid == 0) z0 = x[0];
+#pragma unroll
+    for (int it = 0; it < ITS; it++) {
+        const uint32_t P = tid + (uint32_t)it * NTK;
+        const uint32_t cls = P / PPC, tt = P % PPC, rho = cls >> 2, sg = cls & 3u;
+        const uint32_t first = (cls == 0u) ? 1u : 0u;
+        const uint32_t i = rho + 4u * sg + 16u * (tt + first);
+        const uint32_t rho2 = (4u - rho) & 3u, sg2 = (rho != 0u) ? 3u - sg : ((4u - sg) & 3u);
+        wf[it] = rtw_fwd[i - 1]; wi_[it] = rtw_inv[i - 1];
+        za[it] = x[rho * QM + sg * SQ + tt + first];
+        zb[it] = x[rho2 * QM + sg2 * SQ + (SQ - 1u - tt)];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        /* DC / Nyquist bin: x0 = re + im, x1 = re - im, squared (fft.c:187-191, lpc.c:358-359); then the inverse's
+         * 0.5 (x0 + x1), 0.5 (x0 - x1) */
+        const double a = z0.x + z0.y, b = z0.x - z0.y;
+        const double pa = a * a, pb = b * b;
+        x[0] = make_double2(0.5 * (pa + pb), 0.5 * (pa - pb));
+    }
+#pragma unroll
+    for (int it = 0; it < ITS; it++) {
+        const uint32_t P = tid + (uint32_t)it * NTK;
+        const uint32_t cls = P / PPC, tt = P % PPC, rho = cls >> 2, sg = cls & 3u;
+        const uint32_t first = (cls == 0u) ? 1u : 0u;
+        const uint32_t i = rho + 4u * sg + 16u * (tt + first);
+        const bool self = (i == (uint32_t)M - i);                       /* the middle bin pairs with itself */
+        double p1, p3;
+        {
+            const double c2 = -0.5;                           /* flag = -1 */
+            const cplx w = wf[it];
+            const double x1 = za[it].x, x2 = za[it].y, x3 = zb[it].x, x4 = zb[it].y;
+            const double wr = w.x, wi = w.y;
+            const double h1r = 0.5 * (x1 + x3);
+            const double h1i = 0.5 * (x2 - x4);
+            const double h2r = -c2 * (x2 + x4);
+            const double h2i = c2 * (x1 - x3);
+            const double y1 = h1r + (wr * h2r) - (wi * h2i);
+            const double y2 = h1i + (wr * h2i) + (wi * h2r);
+            const double y3 = h1r - (wr * h2r) + (wi * h2i);
+            const double y4 = -h1i + (wr * h2i) + (wi * h2r);
+            p1 = y1 * y1 + y2 * y2;
+            p3 = y3 * y3 + y4 * y4;
+            if (self) p1 = p3;
+        }
+        {
+            const double c2 = 0.5;                            /* flag = +1 */
+            const cplx w = wi_[it];
+            const double x1 = p1, x2 = 0.0, x3 = p3, x4 = 0.0;
+            const double wr = w.x, wi = w.y;
+            const double h1r = 0.5 * (x1 + x3);
+            const double h1i = 0.5 * (x2 - x4);
+            const double h2r = -c2 * (x2 + x4);
+            const double h2i = c2 * (x1 - x3);
+            const double y1 = h1r + (wr * h2r) - (wi * h2i);
+            const double y2 = h1i + (wr * h2i) + (wi * h2r);
+            const double y3 = h1r - (wr * h2r) + (wi * h2i);
+            const double y4 = -h1i + (wr * h2i) + (wi * h2r);
+            if (!self) x[fft_swz16(i)] = make_double2(y1, y2);
+            x[fft_swz16((uint32_t)M - i)] = make_double2(y3, y4);
+        }
+    }
+    __syncthreads();
+}
+
 /* circular autocorrelation of the (already windowed, zero padded) signal in buf (lpc.c:330-376): on return
  * complex slot i/2 (fft_regions: position i/8 of region (i/2) & 3) component i&1 holds the unscaled lag i, for i < num_lags */
 template <int R, int NTK, int NFFT = 0, bool FIRSTREG = false, bool WP = false /* the region layout with wave-private stages: fft_regions */>
@@ -533,14 +737,28 @@ __device__ void autocorr_in_place(cplx *buf, uint32_t nfft, const cplx *__restri
     const cplx *tw_inv = twbase + ct;
     const cplx *rtw_fwd = twbase + 2 * ct;
     const cplx *rtw_inv = rtw_fwd + quarter;
-    if constexpr (WP) {
+    if constexpr (WP && NTK / 64 > 4) {
+        /* eight wavefronts: sixteen sub-regions (fft_subregions).  The first forward stage has been done from registers. */
+        fft_second_stage_regions<R, NTK, NFFT / 2, -1, false, false>(buf, tw_fwd, m);
+        PHASE(4);                                                  /* forward stage 2 + barrier */
+        fft_subregions<R, NTK, NFFT / 2, -1, false, false>(buf, tw_fwd, m);
+        __syncthreads();
+        spectrum_power_pass_subregions<NTK, NFFT / 2>(buf, rtw_fwd, rtw_inv);
+        PHASE(5);                                                  /* forward stages 3.., spectrum pass (three barriers) */
+        const uint32_t need = (num_lags + 1) >> 1;
+        fft_first_stage_regions<R, NTK, NFFT / 2, 1, 2>(buf, tw_inv);
+        fft_second_stage_regions<R, NTK, NFFT / 2, 1, true, true>(buf, tw_inv, need);
+        PHASE(6);                                                  /* first two inverse stages + barriers */
+        fft_subregions<R, NTK, NFFT / 2, 1, true, true>(buf, tw_inv, need);
+        __syncthreads();
+    } else if constexpr (WP) {
         /* the first forward stage has been done (from LDS in place, or from registers): the regions are complete behind its barrier */
         fft_regions<R, NTK, NFFT / 2, -1, false, false>(buf, tw_fwd, m);
         __syncthreads();
         PHASE(4);                                                  /* forward stages 2.. + barrier */
         spectrum_power_pass_regions<NTK, NFFT / 2>(buf, rtw_fwd, rtw_inv);
         PHASE(5);                                                  /* spectrum pass (two barriers) */
-        fft_first_stage_regions<R, NTK, NFFT / 2, 1, true>(buf, tw_inv);
+        fft_first_stage_regions<R, NTK, NFFT / 2, 1, 1>(buf, tw_inv);
         PHASE(6);                                                  /* first inverse stage + barrier */
         fft_regions<R, NTK, NFFT / 2, 1, true, true>(buf, tw_inv, (num_lags + 1) >> 1);
         __syncthreads();
@@ -645,6 +863,24 @@ __device__ __forceinline__ void autocorr_item(
 
     asm volatile("" :: "v"(v[0][0]), "v"(v[CH - 1][3]), "v"(pv[CH - 1]), "v"(nxv[CH - 1]));
     PHASE(0);                                                      /* item record fetched, sample loads landed */
+    /* The Welch window's weights of a block that fills its transform come from a table (round 6; SrlaJobParams::welch_tab: the
+     * products the window loop below would form, made once on the host in the same order -- the weight does not depend on the
+     * data): five of a sample's six fp64 operations gone.  Chunk rounds c < CH / 2 lie in the window's first half (entries
+     * i4 .. i4 + 3), the others in the second, which mirrors the first (entries n - 1 - i4 - i: an aligned group read backwards).
+     * Requested here, behind the samples, so that the round trip to L2 runs beside the integer correlations and their barrier. */
+    const bool tabled = full && jp.welch_tab != nullptr && NFFT >= 1024;
+    double wtab[CH][4];
+    if (tabled) {
+        const double *wt = jp.welch_tab + (NFFT / 2 - 512);
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+            const uint32_t i4 = 4u * (tid + (uint32_t)c * NTK);
+            const uint32_t e0 = (c < CH / 2) ? i4 : (uint32_t)NFFT - 4u - i4;
+            const double2 lo = *reinterpret_cast<const double2 *>(wt + e0), hi = *reinterpret_cast<const double2 *>(wt + e0 + 2);
+            if (c < CH / 2) { wtab[c][0] = lo.x; wtab[c][1] = lo.y; wtab[c][2] = hi.x; wtab[c][3] = hi.y; }
+            else { wtab[c][0] = hi.y; wtab[c][1] = hi.x; wtab[c][2] = lo.y; wtab[c][3] = lo.x; }
+        }
+    }
     int32_t coef;
     if (first_pass) {
         /* exact integer correlations r0 = sum x^2, r1 = sum x[i] x[i+1] (srla_utility.c:226-240) */
@@ -765,17 +1001,43 @@ __device__ __forceinline__ void autocorr_item(
                 if (i4 < nfft) *reinterpret_cast<int4 *>(ylds + i4) = make_int4(v[c][0], v[c][1], v[c][2], v[c][3]);
             }
             __syncthreads();
+            /* A chunk's sources are the six consecutive words from i4 - back (back = period + half_order): fetched as the two (three
+             * where they straddle: rr = 3 with three taps) ALIGNED groups of four words that hold them -- lanes 16 bytes apart:
+             * conflict free -- and picked out of the registers by rr = (-back) & 3, which the whole item shares (round 6; a load
+             * per word met a four-way bank conflict every time, lanes being four words apart).  A group in front of the block is
+             * only ever looked at by samples below back + 1, which are not filtered. */
+            const uint32_t back = period + half_order;
+            const uint32_t rr = (uint32_t)__builtin_amdgcn_readfirstlane((int)((0u - back) & 3u));
+            const bool third = rr == 3u && taps == 3u;
 #pragma unroll
             for (int c = 0; c < CH; c++) {
                 const uint32_t i4 = 4u * (tid + (uint32_t)c * NTK);
+                if (i4 < n && i4 + 3u >= back + 1u) {
+                    const int32_t g0 = ((int32_t)i4 - (int32_t)back) >> 2;
+                    int32_t W[12];
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const uint32_t s = i4 + i;
-                    if (s < n && s >= period + half_order + 1) {
-                        const uint32_t base = s - period - half_order;
-                        uint32_t acc = 16u + (uint32_t)c0 * (uint32_t)ylds[base];
-                        if (taps == 3) acc += (uint32_t)c1 * (uint32_t)ylds[base + 1] + (uint32_t)c2 * (uint32_t)ylds[base + 2];
-                        v[c][i] = (int32_t)((uint32_t)v[c][i] - (uint32_t)((int32_t)acc >> 5));
+                    for (int j = 0; j < 3; j++) {
+                        int4 w = make_int4(0, 0, 0, 0);
+                        if (j < 2 || third) w = *reinterpret_cast<const int4 *>(ylds + 4 * ((g0 + j > 0) ? g0 + j : 0));
+                        W[4 * j] = w.x; W[4 * j + 1] = w.y; W[4 * j + 2] = w.z; W[4 * j + 3] = w.w;
+                    }
+                    auto filter = [&](auto rc) {
+                        constexpr int RR = decltype(rc)::value;
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            const uint32_t s = i4 + i;
+                            if (s < n && s >= back + 1u) {
+                                uint32_t acc = 16u + (uint32_t)c0 * (uint32_t)W[RR + i];
+                                if (taps == 3) acc += (uint32_t)c1 * (uint32_t)W[RR + i + 1] + (uint32_t)c2 * (uint32_t)W[RR + i + 2];
+                                v[c][i] = (int32_t)((uint32_t)v[c][i] - (uint32_t)((int32_t)acc >> 5));
+                            }
+                        }
+                    };
+                    switch (rr) {
+                    case 0: filter(std::integral_constant<int, 0>()); break;
+                    case 1: filter(std::integral_constant<int, 1>()); break;
+                    case 2: filter(std::integral_constant<int, 2>()); break;
+                    default: filter(std::integral_constant<int, 3>()); break;
                     }
                 }
             }
@@ -801,7 +1063,10 @@ __device__ __forceinline__ void autocorr_item(
                 double w[4];
                 const double de0 = d_tid4 + (double)(4 * c * NTK);          /* (double)i4, exact */
                 const bool first = i4 + 4u <= half, second = i4 >= n - half && i4 + 4u <= n;
-                if (full) {
+                if (tabled) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) w[i] = (double)v[c][i] * wtab[c][i];
+                } else if (full) {
                     /* chunk rounds c < CH / 2 lie in the first half, the others in the second: no selects.  The sample's scaling is
                      * folded into the divisor (a power of two: every product keeps its rounding) */
 #pragma unroll
@@ -857,7 +1122,7 @@ __device__ __forceinline__ void autocorr_item(
     static_assert(!WP || NFFT != 0, "the region layout needs the transform's length at compile time");
     if constexpr (WP) {
         if constexpr (FIRSTREG) fft_first_stage_regs_regions<NFFT / 2>(buf, wreg, twiddles + g.tw_off);
-        else fft_first_stage_regions<R, NTK, NFFT / 2, -1, false>(buf, twiddles + g.tw_off);
+        else fft_first_stage_regions<R, NTK, NFFT / 2, -1, 0>(buf, twiddles + g.tw_off);
     } else {
         if constexpr (FIRSTREG) fft_first_stage_regs<NFFT / 2>(buf, wreg, twiddles + g.tw_off);
     }
@@ -865,7 +1130,10 @@ __device__ __forceinline__ void autocorr_item(
     autocorr_in_place<R, NTK, NFFT, FIRSTREG, WP>(buf, nfft, twiddles + g.tw_off, (num_lags < nfft && !dump) ? num_lags : nfft PHASE_ARG);
     PHASE(7);                                                      /* inverse stages 2.. + barrier (4-6: inside autocorr_in_place) */
     /* where complex element e of the result stands */
-    auto slot = [&](uint32_t e) -> uint32_t { return WP ? ((e & 3u) * (uint32_t)(NFFT / 8) + (e >> 2)) : e; };
+    auto slot = [&](uint32_t e) -> uint32_t {
+        if (WP && NTK / 64 > 4) return (e & 3u) * (uint32_t)(NFFT / 8) + ((e >> 2) & 3u) * (uint32_t)(NFFT / 32) + (e >> 4);     /* fft_subregions */
+        return WP ? ((e & 3u) * (uint32_t)(NFFT / 8) + (e >> 2)) : e;
+    };
     if (dump) {
         double *dst = chain_pool + (it.chain_dump - 1u);
         for (uint32_t i = tid; i < nfft; i += NTK) { const cplx z = buf[slot(i >> 1)]; dst[i] = (i & 1u) ? z.y : z.x; }
@@ -1133,13 +1401,16 @@ extern "C" int srla_launch_autocorr(hipStream_t stream, int rclass, const SrlaJo
     /* outside chain mode the items of a launch (classes of more than 1024 points; `exact_nfft`: also the 1024-point class) all
      * have the class's FFT size: the kernel with the transform's length compiled in */
     if (chain_pool == nullptr && (rclass != 0 || exact_nfft)) {
-        /* classes of at most four wavefronts: the region layout with wave-private stages (fft_regions); SRLA_MI355X_FFT_WP=0: round 4's form */
+        /* the region layout with wave-private stages (fft_regions; the 8192-point class on eight wavefronts: fft_subregions); SRLA_MI355X_FFT_WP=0: round 4's form */
         const bool wp = g_srla_tune.fft_wp != 0u;
         switch (rclass) {
         case 0: if (wp) LAUNCH(1, 128, 1024, true); else LAUNCH(1, 128, 1024, false); break;
         case 1: if (wp) LAUNCH(1, 256, 2048, true); else LAUNCH(1, 256, 2048, false); break;
         case 2: if (wp) LAUNCH(2, 256, 4096, true); else LAUNCH(2, 256, 4096, false); break;
-        case 4: LAUNCH(2, 512, 8192, false); break;
+        /* the 8192-point class on sixteen sub-regions (fft_subregions, round 6): 9 barriers per item instead of 26 and the same bits, but
+         * measured 5 % SLOWER stand-alone (164 -> 172 us per job of -B 8192 -V 2 -P 3, profiles/r06/ab_kernels.txt) -- like the
+         * 4096-point class's barriers in round 5, this class's were not what its wavefronts wait for.  SRLA_MI355X_FFT_WP=2 selects it. */
+        case 4: if (g_srla_tune.fft_wp >= 2u) LAUNCH(2, 512, 8192, true); else LAUNCH(2, 512, 8192, false); break;
         default: return -1;
         }
         return (hipGetLastError() == hipSuccess) ? 0 : -2;

@@ -20,6 +20,7 @@
 #define SRLA_MAX_NODES       1025    /* lookahead / min block + 1 (`srla -e -V 8` at the default look-ahead factor 4; 129 until round 4) */
 #define SRLA_MAX_PORDER      10      /* srla_coder.c:18 */
 #define SRLA_LTP_MIN_PERIOD  8
+#define SRLA_WELCH_TAB_WORDS 7680   /* 512 + 1024 + 2048 + 4096 doubles: SrlaJobParams::welch_tab */
 #define SRLA_LTP_MAX_PERIOD  262
 #define SRLA_LTP_LAGS        (SRLA_LTP_MAX_PERIOD + 1)
 #define SRLA_BIG_WEIGHT      (1u << 24)
@@ -221,6 +222,10 @@ typedef struct SrlaJobParams {
     uint32_t rc_lo, rc_hi;    /* srla_residual_cost: when rc_hi != 0 the launch takes the items with rc_lo < n <= rc_hi only (a job with blocks
                                * above 4096 samples is analysed by two launches: the register budget of the 8192-sample form, two
                                * wavefronts per SIMD, would otherwise be every item's) */
+    const double *welch_tab;  /* when non-null: the Welch window's weights of the blocks that fill their transform, n = 1024, 2048, 4096,
+                               * 8192 (lpc.c:256-266 with the sample's scaling folded in: (4 (n-1)^-2 2^-(bps-1) e) (n-1-e), e < n / 2 -- the
+                               * second half mirrors the first), n / 2 doubles each from word n / 2 - 512: the same products the kernel
+                               * would form, made once on the host (SRLA_WELCH_TAB_WORDS) */
     const uint32_t *lshift_dev; /* when non-null the offset left shift is read from here (device memory) instead of the
                                * item's: lets a whole device-resident stream be enqueued before its OR-reduction has finished */
     /* near-tie detection (H2: decisions that hang on libm): an item is flagged, and arbitrated with the host libm, when the

@@ -244,6 +244,9 @@ struct Impl {
     uint64_t job_samples = 4ull << 20; /* samples per job (SRLA_MI355X_JOB_SAMPLES): fixed per-job latencies (serial solve chain, launch gaps) favour large jobs; measured best for long streams, and never worse than smaller ones for short streams */
     Slot slot[kMaxSlots];
     DevBuf d_tw, d_geoms, d_thr, d_huff, d_huffcode, d_pos, d_or, d_oracc;
+    DevBuf d_welch;                    /* SrlaJobParams::welch_tab, built for welch_bps bits per sample (sync_tables) */
+    uint32_t welch_bps = 0;
+    bool welch_table = true;           /* SRLA_MI355X_WELCH_TABLE=0: the window's weights formed per sample in the kernel (round 5) */
     DevBuf d_svr_scratch_chain;        /* the same for the chain-mode jobs: they run on the narrow stream BESIDE a regular job that keeps to the
                                         * wide stream (a call of one job, Slot::own_stream), so the two refinements may be in flight at once --
                                         * one shared region let them overwrite each other's matrices (tools/gpu_sweep.py, seed 48 case 60, round 4) */

@@ -52,7 +52,7 @@ Impl::~Impl()
         if (ev_or) (void)hipEventDestroy(ev_or);
         if (ev_ref) (void)hipEventDestroy(ev_ref);
         h_or.release();
-        d_tw.release(); d_geoms.release(); d_thr.release(); d_huff.release(); d_huffcode.release(); d_pos.release(); d_or.release(); d_oracc.release(); d_svr_scratch.release(); d_svr_scratch_chain.release();
+        d_tw.release(); d_welch.release(); welch_bps = 0; d_geoms.release(); d_thr.release(); d_huff.release(); d_huffcode.release(); d_pos.release(); d_or.release(); d_oracc.release(); d_svr_scratch.release(); d_svr_scratch_chain.release();
         d_chain_pool.release(); d_chain_tab.release(); d_hist.release(); tail.c.smp.release(); drop_pending(); for (Capture *c : spare) { c->smp.release(); delete c; } spare.clear(); for (auto &h : h_chain_up) h.release(); h_chain_recs.release(); h_bounce.release();
         for (auto &b : d_chain_list) b.release();
         for (auto &b : d_chain_select) b.release();

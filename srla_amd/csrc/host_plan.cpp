@@ -5,6 +5,8 @@
 #include "host_impl.h"
 
 #include <algorithm>
+#include <math.h>
+#include <vector>
 #include <stdlib.h>
 #include <string.h>
 
@@ -36,6 +38,24 @@ uint32_t Impl::geom_for(uint32_t n)
 
 bool Impl::sync_tables()
 {
+    if (welch_bps != par.bits_per_sample) {
+        /* the Welch weights of the four block lengths that fill a transform of the LDS classes (lpc.c:256-266), with the products
+         * in the kernel's own order -- (divisor 2^-(bps-1) smpl) (n - 1 - smpl): scaling by a power of two commutes with every
+         * rounding -- so that a thread multiplies its sample by a table entry instead of forming five operations per sample */
+        for (auto &st : streams) if (st) HIP_OK(hipStreamSynchronize(st));
+        std::vector<double> tab(SRLA_WELCH_TAB_WORDS);
+        const double norm_bps = ldexp(1.0, -(int)(par.bits_per_sample - 1));
+        for (uint32_t n = 1024; n <= 8192; n <<= 1) {
+            SrlaGeom g;
+            srla::fill_geom(n, &g);
+            const double div_scaled = g.welch_divisor * norm_bps, d_nm1 = (double)(n - 1u);
+            double *t = tab.data() + (n / 2 - 512);
+            for (uint32_t e = 0; e < n / 2; e++) { const double de = (double)e, dr = d_nm1 - de; t[e] = div_scaled * de * dr; }
+        }
+        if (!d_welch.ensure(tab.size() * sizeof(double))) return false;
+        HIP_OK(hipMemcpy(d_welch.p, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
+        welch_bps = par.bits_per_sample;
+    }
     if (!tw_dirty && !geom_dirty) return true;
     for (auto &st : streams) if (st) HIP_OK(hipStreamSynchronize(st));
     if (tw_dirty) {
@@ -247,6 +267,7 @@ SrlaJobParams Impl::job_params(const Job &job, uint32_t channel_stride, bool lsh
     jp.num_cands = (uint32_t)job.cands.size();
     jp.num_windows = (uint32_t)job.windows.size();
     jp.lshift_dev = lshift_on_device ? (d_or.as<uint32_t>() + 1) : nullptr;
+    jp.welch_tab = (welch_bps == par.bits_per_sample && welch_table) ? d_welch.as<double>() : nullptr;
     jp.crowded = call_crowded ? 1u : 0u;
     jp.keep_residuals = job.keep_residuals ? (keep_residuals ? 2u : 1u) : 0u;
     jp.tie_rel = tie_rel; jp.tie_ltp = tie_ltp; jp.tie_logscale = tie_logscale; jp.tie_ltpbias = tie_ltpbias;

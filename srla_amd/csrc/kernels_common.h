@@ -15,6 +15,7 @@
 #include <string.h>
 #include <float.h>
 #include <algorithm>
+#include <type_traits>
 
 #include "device_layout.h"
 #include "kernels.h"

@@ -28,8 +28,9 @@ extern "C" uint32_t srla_kernel_small_c_bytes(void) { return (uint32_t)((sizeof(
  * padding after every S samples so that the 16-byte window loads of a wavefront are conflict free. */
 static_assert(offsetof(SrlaItemResult, lpc_coef) % 4 == 0 && sizeof(SrlaItemResult) % 4 == 0, "the taps of an item record can be read as aligned words");
 #define MF_PADB 256                 /* FIR_MFMA: zero bytes in front of every byte plane (>= the largest order rounded up to 16) */
-#define MF_OFFZ 144                 /* ... index of tap 0 in the zero-padded tap string (>= 16 FL + 14 + 15 for FL <= 8) */
-#define MF_TZB  544                 /* ... bytes of one copy of it: MF_OFFZ + 64 k-blocks' worth for order 255 (5 at FL <= 4) + a lane's reach */
+#define MF_OFFZ 160                 /* ... index of tap 0 in the zero-padded tap string: the lowest byte a lane reads is MF_OFFZ - 16 FL - 14 (row 15 of the
+                                     * last tile, the order rounded up by 15), >= 0 for FL <= 8 (144 until round 6, when the form stopped at FL = 4) */
+#define MF_TZB  576                 /* ... bytes of one copy of it: MF_OFFZ + 64 k-blocks' worth for order 255 (6 at FL = 8) + a lane's 16 bytes, rounded up */
 struct SmallF {
     union {
         int32_t  coefq[FIR_PAD + 8];          /* FIR_WIDE: taps, front padded with zeros to a multiple of four */
@@ -143,6 +144,17 @@ __host__ __device__ constexpr uint32_t fast_sig_bytes(int fl, int lg, bool plane
     const uint32_t planes = ((plane_elems * 2u + 15u) & ~15u) + plane_elems;
     return ((planes_only ? planes : sig_words * 4u) + 15u) & ~15u;
 }
+/* The level sums of the Rice search leave the registers through LDS (round 6): every wavefront lays its lanes' eleven sums out as
+ * eleven rows of 64 words (68 with the pad that keeps the column reads conflict free) over the signal's planes -- which nobody
+ * reads any more behind the barrier in front of the search -- and four lanes per level add a row up.  The region in front of the
+ * small structure is therefore at least four wavefronts' worth of rows, whatever the block length. */
+#define RC_RED_ROW 68u
+#define RC_RED_WAVE_WORDS (11u * RC_RED_ROW)
+__host__ __device__ constexpr uint32_t fast_region_bytes(int fl, int lg, bool planes_only)
+{
+    const uint32_t sig = fast_sig_bytes(fl, lg, planes_only), red = (uint32_t)NWAVES * RC_RED_WAVE_WORDS * 4u;
+    return (lg == 0 && red > sig) ? red : sig;
+}
 typedef short srla_short2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t dot2_i16(uint32_t a, uint32_t b, uint32_t acc)
 {
@@ -184,7 +196,8 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
     constexpr uint32_t SIG_WORDS = (uint32_t)((PADS + 1024 * FL) / S) * (S + PADW) + 8;
     constexpr bool WIDE = MODE == FIR_WIDE, MF = MODE == FIR_MFMA, DOT = MODE == FIR_DOT || MF;   /* (DOT: the signal lives as planes; MF: byte planes) */
     constexpr uint32_t MF_PLS = MF_PADB + 1024u * FL;            /* bytes of one byte plane */
-    static_assert(!MF || (LG == 0 && FL <= 4), "FIR_MFMA: one item per workgroup, blocks of at most 4096 samples");
+    static_assert(!MF || (LG == 0 && FL <= 8), "FIR_MFMA: one item per workgroup, blocks of at most 8192 samples");
+    static_assert(!MF || (MF_OFFZ >= 16 * FL + 14 && MF_OFFZ % 16 == 0 && MF_OFFZ + 64 * 6 + 16 <= MF_TZB && MF_TZB % 4 == 0), "the tap string covers every lane's reach");
     static_assert(!MF || 3u * MF_PLS <= fast_sig_bytes(FL, LG, true), "the byte planes fit where the int16 / int8 planes would lie");
     /* FIR_DOT: the two planes lie over the int32 signal (which then only the LTP uses, before them): PADF zeros + the block, in
      * the same padded element order as the int32 layout */
@@ -194,7 +207,7 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
     static_assert(HIGH_OFF + PLANE_ELEMS <= SIG_WORDS * 4, "the planes fit the int32 signal's LDS");
     int32_t *sig = (int32_t *)lds;
     static_assert(fast_sig_bytes(FL, LG, false) == ((SIG_WORDS * 4 + 15) & ~15u) && fast_sig_bytes(FL, LG, true) == ((HIGH_OFF + PLANE_ELEMS + 15) & ~15u), "one layout");
-    SmallF *sm = (SmallF *)(lds + fast_sig_bytes(FL, LG, DOT && jp.ltp_order == 0));
+    SmallF *sm = (SmallF *)(lds + fast_region_bytes(FL, LG, DOT && jp.ltp_order == 0));
     const uint32_t tid = threadIdx.x & (uint32_t)(T - 1), lane = tid & 63, wave = tid >> 6;   /* thread, wavefront within the item */
     const uint32_t n = 1024u * FL, bps = jp.bits_per_sample;
     const bool aligned = input_aligned(in, iv);
@@ -322,14 +335,20 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
                 w2[c] = hw;
             }
             unsigned char *p0 = lds + MF_PADB + s_base;
-            if constexpr (CH == 4) {
-                *reinterpret_cast<uint4 *>(p0) = make_uint4(w0[0], w0[1], w0[2], w0[3]);
-                *reinterpret_cast<uint4 *>(p0 + MF_PLS) = make_uint4(w1[0], w1[1], w1[2], w1[3]);
-                *reinterpret_cast<uint4 *>(p0 + 2 * MF_PLS) = make_uint4(w2[0], w2[1], w2[2], w2[3]);
-            } else if constexpr (CH == 2) {
-                *reinterpret_cast<uint2 *>(p0) = make_uint2(w0[0], w0[1]);
-                *reinterpret_cast<uint2 *>(p0 + MF_PLS) = make_uint2(w1[0], w1[1]);
-                *reinterpret_cast<uint2 *>(p0 + 2 * MF_PLS) = make_uint2(w2[0], w2[1]);
+            if constexpr (CH % 4 == 0) {
+#pragma unroll
+                for (int c = 0; c < CH; c += 4) {
+                    *reinterpret_cast<uint4 *>(p0 + 4 * c) = make_uint4(w0[c], w0[c + 1], w0[c + 2], w0[c + 3]);
+                    *reinterpret_cast<uint4 *>(p0 + MF_PLS + 4 * c) = make_uint4(w1[c], w1[c + 1], w1[c + 2], w1[c + 3]);
+                    *reinterpret_cast<uint4 *>(p0 + 2 * MF_PLS + 4 * c) = make_uint4(w2[c], w2[c + 1], w2[c + 2], w2[c + 3]);
+                }
+            } else if constexpr (CH % 2 == 0) {
+#pragma unroll
+                for (int c = 0; c < CH; c += 2) {
+                    *reinterpret_cast<uint2 *>(p0 + 4 * c) = make_uint2(w0[c], w0[c + 1]);
+                    *reinterpret_cast<uint2 *>(p0 + MF_PLS + 4 * c) = make_uint2(w1[c], w1[c + 1]);
+                    *reinterpret_cast<uint2 *>(p0 + 2 * MF_PLS + 4 * c) = make_uint2(w2[c], w2[c + 1]);
+                }
             } else {
 #pragma unroll
                 for (int c = 0; c < CH; c++) {
@@ -409,32 +428,50 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
         /* long-term predictor, srla_lpc_predict.c:267-294 (in place: read everything, barrier, rewrite) */
         const uint32_t taps = jp.ltp_order, half_order = taps >> 1;
         const int32_t c0 = head.ltp_coef[0], c1 = head.ltp_coef[1], c2 = head.ltp_coef[2];
-        /* the thread's S + 2 source samples are consecutive: one division locates the first one in the padded
-         * layout (a pad of four words after every S), the others follow by compare-and-step.  PADS >= the largest
-         * period + 2, so the first source index is never negative. */
+        /* The thread's S + 2 source samples are consecutive words of the padded layout (a pad of four words behind every S samples,
+         * sig_index) from an index that is a multiple of four plus a remainder `rr` the whole item shares (s_base and PADS are
+         * multiples of four).  They are fetched as the CH + 1 (rr = 3 with three taps: CH + 2) ALIGNED groups of four words that
+         * hold them -- 16-byte loads, a lane stride of S (+ 4) words: conflict free -- and picked out of the registers by rr, one
+         * of four copies of the loop chosen by a scalar branch.  (Until round 6 every word was a load of its own: with lanes 16 or
+         * 20 words apart each of them met a four-way bank conflict, S + 2 times per thread -- what doubled this kernel's conflict
+         * share under -P 3: profiles/r06/README.md.)  PADS >= the largest period + 2, so the first group is never negative, and
+         * the period is at least 8, so the last one lies inside the thread's own run. */
         const uint32_t base0 = (uint32_t)PADS + s_base - period - half_order;
-        const uint32_t q0 = base0 / (uint32_t)S, r0 = base0 - q0 * (uint32_t)S;
-        int32_t src[S + 2];
+        const uint32_t rr = (uint32_t)__builtin_amdgcn_readfirstlane((int)(base0 & 3u));
+        const uint32_t g0 = base0 >> 2, gq = g0 / (uint32_t)CH, gr = g0 - gq * (uint32_t)CH;   /* group of four words; the run of CH groups it lies in */
+        const bool last_group = rr == 3u && taps == 3u;
+        int32_t W[4 * (CH + 2)];
 #pragma unroll
-        for (int i = 0; i < S + 2; i++) {
-            const uint32_t step = (r0 + (uint32_t)i >= 2u * S) ? 2u * PADW : ((r0 + (uint32_t)i >= (uint32_t)S) ? (uint32_t)PADW : 0u);
-            src[i] = (i < S || taps == 3) ? sig[base0 + (uint32_t)PADW * q0 + (uint32_t)i + step] : 0;
+        for (int j = 0; j < CH + 2; j++) {
+            const uint32_t pads = (PADW != 0) ? gq + ((gr + (uint32_t)j >= 2u * CH) ? 2u : ((gr + (uint32_t)j >= (uint32_t)CH) ? 1u : 0u)) : 0u;
+            int4 w = make_int4(0, 0, 0, 0);
+            if (j <= CH || last_group) w = *reinterpret_cast<const int4 *>(sig + 4u * (g0 + (uint32_t)j + pads));
+            W[4 * j] = w.x; W[4 * j + 1] = w.y; W[4 * j + 2] = w.z; W[4 * j + 3] = w.w;
         }
+        auto filter = [&](auto rc) {
+            constexpr int RR = decltype(rc)::value;
 #pragma unroll
-        for (int i = 0; i < S; i++) {
-            const uint32_t s = s_base + i;
-            if (s >= period + half_order + 1) {
-                uint32_t acc;
-                if constexpr (!WIDE) {
-                    /* 6-bit taps, samples within 24 bits (see the FIR below): the full-rate 24-bit multiplier */
-                    acc = mad24(c0, src[i], 16u);
-                    if (taps == 3) acc = mad24(c2, src[i + 2], mad24(c1, src[i + 1], acc));
-                } else {
-                    acc = 16u + (uint32_t)c0 * (uint32_t)src[i];
-                    if (taps == 3) acc += (uint32_t)c1 * (uint32_t)src[i + 1] + (uint32_t)c2 * (uint32_t)src[i + 2];
+            for (int i = 0; i < S; i++) {
+                const uint32_t s = s_base + i;
+                if (s >= period + half_order + 1) {
+                    uint32_t acc;
+                    if constexpr (!WIDE) {
+                        /* 6-bit taps, samples within 24 bits (see the FIR below): the full-rate 24-bit multiplier */
+                        acc = mad24(c0, W[RR + i], 16u);
+                        if (taps == 3) acc = mad24(c2, W[RR + i + 2], mad24(c1, W[RR + i + 1], acc));
+                    } else {
+                        acc = 16u + (uint32_t)c0 * (uint32_t)W[RR + i];
+                        if (taps == 3) acc += (uint32_t)c1 * (uint32_t)W[RR + i + 1] + (uint32_t)c2 * (uint32_t)W[RR + i + 2];
+                    }
+                    y[i] = (int32_t)((uint32_t)y[i] - (uint32_t)((int32_t)acc >> 5));
                 }
-                y[i] = (int32_t)((uint32_t)y[i] - (uint32_t)((int32_t)acc >> 5));
             }
+        };
+        switch (rr) {
+        case 0: filter(std::integral_constant<int, 0>()); break;
+        case 1: filter(std::integral_constant<int, 1>()); break;
+        case 2: filter(std::integral_constant<int, 2>()); break;
+        default: filter(std::integral_constant<int, 3>()); break;
         }
         }
         __syncthreads();
@@ -465,48 +502,63 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
             const uint32_t *az = reinterpret_cast<const uint32_t *>(sm->tz[sft]) + ((MF_OFFZ + 16u * gk - 4u * FL * (cc >> 2) - (cc & 3u) - dpad + sft) >> 2);
             const uint4 wh = *reinterpret_cast<const uint4 *>(sm->wave_high);
             const bool high = __builtin_amdgcn_readfirstlane(wh.x | wh.y | wh.z | wh.w) != 0;
-            mf_v4i a0[FL], a1[FL];
+            /* lane 16 g + cc holds chunk t of thread 4 cc + g: every thread fetches its own from lane 16 (lane & 3) + (lane >> 2) */
+            const int from = (int)(4u * (16u * (lane & 3u) + (lane >> 2)));
+            /* The tiles in groups of at most four (round 6: blocks above 4096 samples, FL = 5 .. 8, take this form too): two accumulator
+             * sets of a group are 8 TG registers, and a group's outputs go back to their owners before the next group starts -- all eight
+             * tiles of an 8192-sample block at once would be 64 accumulator registers beside the 32 samples and 32 outputs a thread
+             * holds.  The B operands (one aligned 16-byte load per plane and k-block) are fetched once per group. */
+            constexpr int TG = (FL > 4) ? (FL + 1) / 2 : FL, NTG = (FL + TG - 1) / TG;
 #pragma unroll
-            for (int t = 0; t < FL; t++) { a0[t] = (mf_v4i){ half, half, half, half }; a1[t] = (mf_v4i){ 0, 0, 0, 0 }; }
-            for (uint32_t kb = 0; kb < mf_nkb; kb++) {
-                const mf_v4i b0 = *reinterpret_cast<const mf_v4i *>(bp + 64u * kb);
-                const mf_v4i b1 = *reinterpret_cast<const mf_v4i *>(bp + MF_PLS + 64u * kb);
+            for (int tg = 0; tg < NTG; tg++) {
+                const int t0 = tg * TG;
+                mf_v4i a0[TG], a1[TG];
 #pragma unroll
-                for (int t = 0; t < FL; t++) {
-                    const uint32_t *ap = az + 16u * kb - (uint32_t)t;
-                    const mf_v4i a = (mf_v4i){ (int)ap[0], (int)ap[1], (int)ap[2], (int)ap[3] };
-                    a0[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b0, a0[t], 0, 0, 0);
-                    a1[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b1, a1[t], 0, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int t = 0; t < FL; t++)
-#pragma unroll
-                for (int i = 0; i < 4; i++) a0[t][i] = (int)((uint32_t)a0[t][i] + ((uint32_t)a1[t][i] << 8));
-            if (high) {
-                /* the third digit, where a sample left 16 bits (full-scale input): one more pass */
-#pragma unroll
-                for (int t = 0; t < FL; t++) a1[t] = (mf_v4i){ 0, 0, 0, 0 };
+                for (int t = 0; t < TG; t++) { a0[t] = (mf_v4i){ half, half, half, half }; a1[t] = (mf_v4i){ 0, 0, 0, 0 }; }
                 for (uint32_t kb = 0; kb < mf_nkb; kb++) {
-                    const mf_v4i b2 = *reinterpret_cast<const mf_v4i *>(bp + 2 * MF_PLS + 64u * kb);
+                    const mf_v4i b0 = *reinterpret_cast<const mf_v4i *>(bp + 64u * kb);
+                    const mf_v4i b1 = *reinterpret_cast<const mf_v4i *>(bp + MF_PLS + 64u * kb);
 #pragma unroll
-                    for (int t = 0; t < FL; t++) {
-                        const uint32_t *ap = az + 16u * kb - (uint32_t)t;
-                        const mf_v4i a = (mf_v4i){ (int)ap[0], (int)ap[1], (int)ap[2], (int)ap[3] };
-                        a1[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b2, a1[t], 0, 0, 0);
+                    for (int t = 0; t < TG; t++) {
+                        if (t0 + t < FL) {
+                            const uint32_t *ap = az + 16u * kb - (uint32_t)(t0 + t);
+                            const mf_v4i a = (mf_v4i){ (int)ap[0], (int)ap[1], (int)ap[2], (int)ap[3] };
+                            a0[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b0, a0[t], 0, 0, 0);
+                            a1[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b1, a1[t], 0, 0, 0);
+                        }
                     }
                 }
 #pragma unroll
-                for (int t = 0; t < FL; t++)
+                for (int t = 0; t < TG; t++)
 #pragma unroll
-                    for (int i = 0; i < 4; i++) a0[t][i] = (int)((uint32_t)a0[t][i] + ((uint32_t)a1[t][i] << 16));
+                    for (int i = 0; i < 4; i++) a0[t][i] = (int)((uint32_t)a0[t][i] + ((uint32_t)a1[t][i] << 8));
+                if (high) {
+                    /* the third digit, where a sample left 16 bits (full-scale input): one more pass */
+#pragma unroll
+                    for (int t = 0; t < TG; t++) a1[t] = (mf_v4i){ 0, 0, 0, 0 };
+                    for (uint32_t kb = 0; kb < mf_nkb; kb++) {
+                        const mf_v4i b2 = *reinterpret_cast<const mf_v4i *>(bp + 2 * MF_PLS + 64u * kb);
+#pragma unroll
+                        for (int t = 0; t < TG; t++) {
+                            if (t0 + t < FL) {
+                                const uint32_t *ap = az + 16u * kb - (uint32_t)(t0 + t);
+                                const mf_v4i a = (mf_v4i){ (int)ap[0], (int)ap[1], (int)ap[2], (int)ap[3] };
+                                a1[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b2, a1[t], 0, 0, 0);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int t = 0; t < TG; t++)
+#pragma unroll
+                        for (int i = 0; i < 4; i++) a0[t][i] = (int)((uint32_t)a0[t][i] + ((uint32_t)a1[t][i] << 16));
+                }
+#pragma unroll
+                for (int t = 0; t < TG; t++)
+                    if (t0 + t < FL) {
+#pragma unroll
+                        for (int i = 0; i < 4; i++) acc[4 * (t0 + t) + i] = (uint32_t)__builtin_amdgcn_ds_bpermute(from, a0[t][i]);
+                    }
             }
-            /* lane 16 g + cc holds chunk t of thread 4 cc + g: every thread fetches its own from lane 16 (lane & 3) + (lane >> 2) */
-            const int from = (int)(4u * (16u * (lane & 3u) + (lane >> 2)));
-#pragma unroll
-            for (int t = 0; t < FL; t++)
-#pragma unroll
-                for (int i = 0; i < 4; i++) acc[4 * t + i] = (uint32_t)__builtin_amdgcn_ds_bpermute(from, a0[t][i]);
             if (tid != 0 && s_base < order) {
                 const unsigned char *pe = lds + MF_PADB + s_base - 1u;
                 yprev = (int32_t)*reinterpret_cast<const int8_t *>(pe) + 256 * (int32_t)*reinterpret_cast<const int8_t *>(pe + MF_PLS)
@@ -864,10 +916,29 @@ __device__ __forceinline__ void residual_cost_fast(const SrlaJobParams &jp, cons
                 acc[TL + d] += td;
             }
         }
+        if constexpr (LG == 0) {
+            /* Eleven sums over the wavefront's 64 lanes: through LDS (see RC_RED_ROW) instead of eleven DPP reductions in the
+             * VALU, which this kernel keeps busy four cycles out of five while LDS idles three out of four: 11 word stores a lane,
+             * then lane 4 l + g adds up quarter g of row l -- four 16-byte loads whose columns (l + 4 g + i) mod 16 differ in every
+             * lane group a load is served in (tests/test_kernel_models.py) -- and ONE atomic adds the 44 partial sums to the item's
+             * eleven totals.  A wavefront's LDS operations execute in order: no barrier between its stores and its loads. */
+            uint32_t *red = reinterpret_cast<uint32_t *>(lds) + wave * RC_RED_WAVE_WORDS;
+#pragma unroll
+            for (int l = 0; l <= 10; l++) red[(uint32_t)l * RC_RED_ROW + lane] = acc[l];
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            const uint32_t lv = lane >> 2, seg = lane & 3u;
+            if (lv <= 10u) {
+                const uint4 *row = reinterpret_cast<const uint4 *>(red + lv * RC_RED_ROW + 16u * seg);
+                const uint4 q0 = row[0], q1 = row[1], q2 = row[2], q3 = row[3];
+                const uint32_t sum = ((q0.x + q0.y) + (q0.z + q0.w)) + ((q1.x + q1.y) + (q1.z + q1.w)) + ((q2.x + q2.y) + (q2.z + q2.w)) + ((q3.x + q3.y) + (q3.z + q3.w));
+                atomicAdd(&sm->level_bits[lv], sum);
+            }
+        } else {
 #pragma unroll
         for (int l = 0; l <= 10; l++) {
             const uint32_t sum = wave_sum_u32(acc[l]);
             if (lane == 0) atomicAdd(&sm->level_bits[l], sum);
+        }
         }
     }
     __syncthreads();
@@ -896,7 +967,7 @@ extern "C" uint32_t srla_kernel_fast_lds_bytes(uint32_t fl, uint32_t ltp_order, 
 {
     const bool dot = bits_per_sample <= 18;
     const int lg = 0;
-    const uint32_t item = fast_sig_bytes((int)fl, lg, dot && ltp_order == 0) + (uint32_t)((sizeof(SmallF) + 15) & ~15u);
+    const uint32_t item = fast_region_bytes((int)fl, lg, dot && ltp_order == 0) + (uint32_t)((sizeof(SmallF) + 15) & ~15u);
     return item << lg;
 }
 
@@ -1050,7 +1121,7 @@ __device__ __forceinline__ void rice_search_finish(const uint32_t *u, const Srla
 #ifndef SRLA_RC4_WAVES
 #define SRLA_RC4_WAVES 3      /* wavefronts per SIMD the 8192-sample form is compiled for: 168 registers and 17 spilled dwords per lane; 2 (228 registers, no spills) was 9 % slower at -B 8192 -V 2 -P 3, profiles/r04/ab_residual_cost_split.txt */
 #endif
-template <int R, bool MFMA = false /* blocks of at most 4096 samples, narrow input: the FIR on the matrix pipe (FIR_MFMA) */>
+template <int R, bool MFMA = false /* narrow input: the FIR on the matrix pipe (FIR_MFMA) */>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(R >= 4 ? SRLA_RC4_WAVES : SRLA_RC_WAVES, 8))) void srla_residual_cost(
     SrlaJobParams jp, const int32_t *__restrict__ input, const SrlaItemDesc *__restrict__ items,
     const SrlaGeom *__restrict__ geoms, SrlaLdsPlan plan, const double *__restrict__ rice_thresholds,
@@ -1081,7 +1152,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(R >= 4 ? SRL
             SrlaItemResult *outf = &results[block];
 #define FAST(FLV)                                                                                                   \
             do {                                                                                                    \
-                if (jp.bits_per_sample <= 18) residual_cost_fast<FLV, (MFMA && FLV <= 4) ? FIR_MFMA : SRLA_FIR_NARROW>(jp, iv, inf, itf, lds, rice_thresholds, res_ws, outf, head); \
+                if (jp.bits_per_sample <= 18) residual_cost_fast<FLV, MFMA ? FIR_MFMA : SRLA_FIR_NARROW>(jp, iv, inf, itf, lds, rice_thresholds, res_ws, outf, head); \
                 else residual_cost_fast<FLV, FIR_WIDE>(jp, iv, inf, itf, lds, rice_thresholds, res_ws, outf, head); \
                 return;                                                                                             \
             } while (0)
@@ -1352,7 +1423,7 @@ extern "C" int srla_launch_residual_cost(hipStream_t stream, int rclass, const S
     switch (rclass) {
     case 1: if (mf) LAUNCH(1, true); else LAUNCH(1, false); break;
     case 2: if (mf) LAUNCH(2, true); else LAUNCH(2, false); break;
-    case 4: LAUNCH(4, false); break;
+    case 4: if (mf) LAUNCH(4, true); else LAUNCH(4, false); break;
     default: return -1;
     }
 #undef LAUNCH

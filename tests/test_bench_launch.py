@@ -90,3 +90,16 @@ def test_eight_ranks_on_one_shared_gpu_with_one_pool_thread_each():
     assert pr["ranks_input_locked_in_place"] == 8 and pr["ranks_output_locked_in_place"] == 8
     assert pr["host_pool_threads_per_rank"] == 1
     assert pr["encode_ms_per_step_max"] <= 3.0 * pr["encode_ms_per_step_min"], pr
+
+
+@pytest.mark.gpu
+def test_two_ranks_fed_with_interleaved_pcm_frames():
+    """`--feed pcm`: the same streams as 16-bit interleaved frames through SRLAMI355X_EncodeBatchPcm (de-interleaved on the device), the
+    feed a rank with one host thread wants; the bytes decode back to the input on every rank, and the compression
+    ratio is the planar feed's (the bytes are the same stream)."""
+    common = ["--steps", "2", "--warmup", "1", "--seconds", "60", "--calls-per-step", "10", "--no-cpu-baseline", "--pack-threads", "1"]
+    pcm = _run(["--gpus", "2", "--feed", "pcm"] + common, env_extra={"SRLA_BENCH_SHARED_GPU": "1"}, timeout=600)
+    assert pcm["n_gpus"] == 2 and pcm["lossless_roundtrip"] is True and pcm["config"]["feed"] == "pcm"
+    assert pcm["per_rank"]["ranks_lossless_roundtrip"] == 2
+    planes = _run(["--gpus", "1"] + common + ["--no-extras"])
+    assert planes["config"]["feed"] == "planes" and planes["compression_ratio"] == pcm["compression_ratio"]

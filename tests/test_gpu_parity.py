@@ -543,6 +543,12 @@ def test_random_configurations_match_the_oracle(product, count, seed, options, l
     handles and streams of every shape: not something to pile onto the test process's heap), its output in the assertion."""
     import subprocess
     import sys
+    if os.environ.get("SRLA_TEST_SWEEPS_INPROCESS"):
+        sys.path.insert(0, os.path.join(helpers.ROOT, "tools"))
+        import gpu_sweep
+        done, bad = gpu_sweep.sweep(count, seed, max_samples=1_500_000, **options)
+        assert done >= least and bad == 0
+        return
     flags = [f for f, on in (("--mutate", options.get("with_mutations")), ("--paths", options.get("with_paths")),
                              ("--history", options.get("only_history"))) if on]
     p = subprocess.run([sys.executable, os.path.join(helpers.ROOT, "tools", "gpu_sweep.py"), str(count), str(seed), "--max-samples=1500000"] + flags,
@@ -694,6 +700,8 @@ def test_too_few_job_buffer_sets_are_refused_not_raced(product, monkeypatch):
 ROUND5_OPTIONS = {
     "round_4_fft": {"SRLA_MI355X_FFT_WP": "0"},
     "round_4_fir": {"SRLA_MI355X_FIR_MFMA": "0"},
+    "round_5_window": {"SRLA_MI355X_WELCH_TABLE": "0"},
+    "sixteen_sub_regions_for_the_8192_point_class": {"SRLA_MI355X_FFT_WP": "2"},
     "copy_out_kernel_everywhere_small_jobs": {"SRLA_MI355X_DMA_OUT": "0", "SRLA_MI355X_JOB_SAMPLES": "131072"},
 }
 

@@ -11,8 +11,11 @@ exact, at sizes and corner values the audio never reaches.
   store is served in, and invisible to the 16-byte loads of the second stage (lane groups made of whole quads).
 * The group offsets of the padded LDS layout (a pad group behind every FL groups for even FL) against the plain index formula.
 """
+import os
+
 import numpy as np
 import pytest
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 M32 = (1 << 32) - 1
 
@@ -221,3 +224,232 @@ def test_group_offsets_of_the_padded_layout(fl):
                 continue
             assert sig_index(fl, sample) % 4 == 0
             assert own + group_offset(fl, d) == sig_index(fl, sample) >> 2, (fl, tid, d)
+
+
+@pytest.mark.parametrize("fl,order", [(1, 1), (2, 17), (4, 64), (5, 33), (6, 64), (7, 55), (8, 64), (8, 16), (8, 255), (5, 128)])
+def test_fir_as_toeplitz_tiles_on_the_matrix_pipe(fl, order):
+    """residual_cost.hip: FIR_MFMA -- tools/probes/mfma_fir_model.py replays the kernel's operand indices (byte planes, the four
+    shifted copies of the zero-padded tap string, k-blocks, tile groups' rows and columns, the lane permutation that returns every
+    chunk to its owner) for a block of 1024 fl samples and compares with the direct wrap-around sum; the model also asserts that
+    no lane reaches outside the tap string (MF_OFFZ, MF_TZB) -- round 6 widened the form from fl <= 4 to fl <= 8."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mfma_fir_model", os.path.join(REPO, "tools", "probes", "mfma_fir_model.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    src = open(os.path.join(REPO, "srla_amd", "csrc", "residual_cost.hip")).read()
+    assert "#define MF_OFFZ %d " % m.MF_OFFZ in src and "#define MF_TZB  %d " % m.MF_TZB in src
+    assert m.emul(fl, order)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# autocorr.hip, round 6: the 8192-point class (M = 4096 complex points on eight wavefronts) on SIXTEEN sub-regions
+# (fft_second_stage_regions, fft_subregions, spectrum_power_pass_subregions).  The model replays every LDS address of the kernel
+# functions -- which slot every butterfly of every stage reads and writes -- on an array of complex numbers, with the
+# reference's butterfly (fft.c:71-128) in Python floats, and compares bit for bit with the plain Stockham transform the
+# older kernel form (fft_complex_lds) is; it also checks every 16-byte access against the lane groups LDS serves it in.
+WRITE_GROUPS = [list(range(g, g + 8)) for g in range(0, 64, 8)]
+
+
+def _tables(m, flag):
+    """per stage (sub-size n) three tables of n/4 entries: w^p, w^2p, w^3p with w = exp(flag 2 pi i / n) (any values would do for an
+    address model; these make the result an FFT, which the test also checks against numpy)"""
+    tabs, n = [], m
+    while n > 2:
+        w1 = [complex(np.cos(2 * np.pi * p / n), flag * np.sin(2 * np.pi * p / n)) for p in range(n // 4)]
+        tabs.append((w1, [a * a for a in w1], [a * a * a for a in w1]))
+        n //= 4
+    return tabs
+
+
+def _bfly(a, b, c, d, w1, w2, w3, flag):
+    apc, amc, bpd, bmd = a + c, a - c, b + d, b - d
+    jbmd = complex(-bmd.imag, bmd.real) if flag < 0 else complex(bmd.imag, -bmd.real)
+    return apc + bpd, w1 * (amc - jbmd), w2 * (apc - bpd), w3 * (amc + jbmd)
+
+
+def _stockham(x, flag, tabs):
+    m, x, s, st = len(x), list(x), 1, 0
+    n = m
+    while n > 2:
+        y = [0j] * m
+        for bf in range(m // 4):
+            q, p = bf & (s - 1), bf // s
+            o = _bfly(x[bf], x[bf + m // 4], x[bf + 2 * m // 4], x[bf + 3 * m // 4], tabs[st][0][p], tabs[st][1][p], tabs[st][2][p], flag)
+            for k in range(4):
+                y[4 * bf - 3 * q + k * s] = o[k]
+        x, n, s, st = y, n // 4, s * 4, st + 1
+    assert n == 1
+    return x
+
+
+def _conflict_free(addrs_by_lane, groups, columns):
+    for grp in groups:
+        lanes = [l for l in grp if addrs_by_lane[l] is not None]
+        cols = {}
+        for l in lanes:
+            cols.setdefault(addrs_by_lane[l] % columns, set()).add(addrs_by_lane[l])
+        if any(len(v) > 1 for v in cols.values()):
+            return False
+    return True
+
+
+def _subregion_transform(lds, flag, tabs, need, inswz, stats):
+    """fft_second_stage_regions + fft_subregions on `lds` (the first stage done), M = len(lds), 512 threads, R = 2."""
+    m = len(lds)
+    qm, sq, ntk, r_count = m // 4, m // 16, 512, 2
+    swz = lambda e: e ^ ((e >> 3) & 3)
+    swz16 = lambda e: e ^ ((e >> 4) & 7)
+    prune = need is not None
+    need = m if need is None else need
+    # ---- second stage, in place inside every region
+    k_on = [True, (not prune) or 4 < need, (not prune) or 8 < need, (not prune) or 12 < need]
+    for r in range(r_count):
+        for wave0 in range(0, ntk, 64):
+            addr = [None] * 64
+            for lane in range(64):
+                u = wave0 + lane + r * ntk
+                rho, j = u // sq, u % sq
+                if prune and not rho < need:
+                    continue
+                base = rho * qm + (swz16(j) if inswz else j)
+                addr[lane] = base
+                o = _bfly(lds[base], lds[base + sq], lds[base + 2 * sq], lds[base + 3 * sq], tabs[1][0][j], tabs[1][1][j], tabs[1][2][j], flag)
+                for k in range(4):
+                    if k_on[k]:
+                        lds[base + k * sq] = o[k]
+            stats["second_read"] &= _conflict_free(addr, READ_GROUPS, 16)
+            stats["second_write"] &= _conflict_free(addr, WRITE_GROUPS, 8)
+    # ---- stages 3 .. 6, every wavefront on its own two sub-regions (loads of a stage before its stores, per wavefront)
+    bpg = sub4 = m // 64
+    for wave in range(8):
+        for st in range(2, 6):
+            s = 1 << (2 * st)
+            sl = s >> 4
+            k_on = [True, (not prune) or s < need, (not prune) or 2 * s < need, (not prune) or 3 * s < need]
+            work = []
+            for r in range(r_count):
+                rd = [[None] * 64 for _ in range(4)]
+                for lane in range(64):
+                    u = lane + 64 * r
+                    g, jj = wave * 2 + u // bpg, u % bpg
+                    ql, qres = jj & (sl - 1), 4 * (g & 3) + (g >> 2)
+                    if prune and not 16 * ql + qres < need:
+                        continue
+                    p = jj // sl
+                    if inswz and st == 2:
+                        pe = jj ^ ((jj >> 4) & 3)
+                        src = [g * sq + pe, g * sq + (pe ^ 4) + sub4, g * sq + pe + 2 * sub4, g * sq + (pe ^ 4) + 3 * sub4]
+                        assert src == [g * sq + swz16(jj + k * sub4) for k in range(4)]
+                    else:
+                        b0 = g * sq + (swz(jj) if st == 3 else jj)
+                        src = [b0 + k * sub4 for k in range(4)]
+                    for k in range(4):
+                        rd[k][lane] = src[k]
+                    work.append((lane, r, g, jj, ql, _bfly(*(lds[a] for a in src), tabs[st][0][p], tabs[st][1][p], tabs[st][2][p], flag)))
+                for k in range(4):
+                    stats["sub_read_%d" % st] &= _conflict_free(rd[k], READ_GROUPS, 16)
+            for r in range(r_count):
+                wr = [[None] * 64 for _ in range(4)]
+                for lane, rr, g, jj, ql, o in work:
+                    if rr != r:
+                        continue
+                    for k in range(4):
+                        if not k_on[k]:
+                            continue
+                        dst = g * sq + 4 * jj + (k ^ ((jj >> 1) & 3)) if st == 2 else g * sq + 4 * jj - 3 * ql + k * sl
+                        wr[k][lane] = dst
+                        lds[dst] = o[k]
+                for k in range(4):
+                    stats["sub_write_%d" % st] &= _conflict_free(wr[k], WRITE_GROUPS, 8)
+
+
+def test_sixteen_sub_regions_of_the_eight_wavefront_class():
+    m, rng = 4096, np.random.default_rng(6)
+    qm, sq = m // 4, m // 16
+    slot = lambda e: (e & 3) * qm + ((e >> 2) & 3) * sq + (e >> 4)
+    swz16 = lambda e: e ^ ((e >> 4) & 7)
+    assert sorted(slot(e) for e in range(m)) == list(range(m)) and sorted(swz16(e) for e in range(m)) == list(range(m))
+    x = [complex(a, b) for a, b in rng.standard_normal((m, 2))]
+    stats = {}
+    for key in ["second_read", "second_write", "first_inv_read", "first_inv_write"] + ["sub_%s_%d" % (w, st) for w in ("read", "write") for st in range(2, 6)]:
+        stats[key] = True
+    # ---- forward: first stage from registers (fft_first_stage_regs_regions: outputs k of butterfly bf at k QM + bf), the rest on the layout
+    tf = _tables(m, -1)
+    lds = [0j] * m
+    for bf in range(qm):
+        o = _bfly(x[bf], x[bf + qm], x[bf + 2 * qm], x[bf + 3 * qm], tf[0][0][bf], tf[0][1][bf], tf[0][2][bf], -1)
+        for k in range(4):
+            lds[k * qm + bf] = o[k]
+    _subregion_transform(lds, -1, tf, None, False, stats)
+    want = _stockham(x, -1, tf)
+    assert all(lds[slot(e)] == want[e] for e in range(m))                                  # the same bits, element by element
+    assert np.allclose(want, np.fft.fft(np.array(x)), rtol=0, atol=1e-9)                   # (and it is the transform)
+    # ---- the spectrum pass's pairs: every bin 1 .. M/2 once with its partner, both read where the forward transform left them,
+    # contiguous over the lanes; the stores 16 bins apart on eight columns
+    seen = []
+    for it in range(4):
+        for wave0 in range(0, 512, 64):
+            ra, rb, wa, wb = [None] * 64, [None] * 64, [None] * 64, [None] * 64
+            for lane in range(64):
+                P = wave0 + lane + it * 512
+                cls, tt = P // (m // 32), P % (m // 32)
+                rho, sg, first = cls >> 2, cls & 3, 1 if cls == 0 else 0
+                i = rho + 4 * sg + 16 * (tt + first)
+                rho2, sg2 = (4 - rho) & 3, (3 - sg) if rho else ((4 - sg) & 3)
+                ra[lane] = rho * qm + sg * sq + tt + first
+                rb[lane] = rho2 * qm + sg2 * sq + (sq - 1 - tt)
+                assert ra[lane] == slot(i) and rb[lane] == slot((m - i) % m if i != m - i else i), (P, i)
+                wa[lane], wb[lane] = (None if i == m - i else swz16(i)), swz16(m - i)
+                seen.append(i)
+            assert _conflict_free(ra, READ_GROUPS, 16) and _conflict_free(rb, READ_GROUPS, 16)
+            assert _conflict_free(wa, WRITE_GROUPS, 8) and _conflict_free(wb, WRITE_GROUPS, 8)
+    assert sorted(seen) == list(range(1, m // 2 + 1))
+    # ---- inverse: input in natural order at fft_swz16, first stage in place (fft_first_stage_regions<.., 2>), pruned to `need` outputs
+    ti = _tables(m, 1)
+    z = [complex(a, b) for a, b in rng.standard_normal((m, 2))]
+    want = _stockham(z, 1, ti)
+    for need in (None, 132, 33, 5, 1):
+        lds = [0j] * m
+        for e in range(m):
+            lds[swz16(e)] = z[e]
+        for r in range(2):
+            for wave0 in range(0, 512, 64):
+                addr = [None] * 64
+                for lane in range(64):
+                    bf = wave0 + lane + r * 512
+                    b0 = swz16(bf)
+                    addr[lane] = b0
+                    o = _bfly(lds[b0], lds[b0 + qm], lds[b0 + 2 * qm], lds[b0 + 3 * qm], ti[0][0][bf], ti[0][1][bf], ti[0][2][bf], 1)
+                    for k in range(4):
+                        lds[b0 + k * qm] = o[k]
+                    assert [b0 + k * qm for k in range(4)] == [swz16(bf + k * qm) for k in range(4)]
+                stats["first_inv_read"] &= _conflict_free(addr, READ_GROUPS, 16)
+                stats["first_inv_write"] &= _conflict_free(addr, WRITE_GROUPS, 8)
+        _subregion_transform(lds, 1, ti, need, True, stats)
+        assert all(lds[slot(e)] == want[e] for e in range(m if need is None else need)), need
+    # ---- bank conflicts: which accesses are free of them (the rest are the known two-way cases of the strided stores)
+    free = {k for k, v in stats.items() if v}
+    assert {"second_read", "second_write", "first_inv_write", "sub_read_2", "sub_read_4", "sub_read_5", "sub_write_2", "sub_write_4", "sub_write_5"} <= free, sorted(stats.items())
+
+
+def test_level_sums_through_lds():
+    """residual_cost.hip (round 6): a wavefront lays its lanes' eleven level sums out as rows of RC_RED_ROW = 68 words; lane 4 l + g
+    adds up words 16 g .. 16 g + 15 of row l with four 16-byte loads.  Every (level, lane) word is added exactly once, the loads are
+    16-byte aligned, and load i of the lanes of every group a ds_read_b128 is served in lands on sixteen different columns."""
+    row = 68
+    src = open(os.path.join(REPO, "srla_amd", "csrc", "residual_cost.hip")).read()
+    assert "#define RC_RED_ROW %du" % row in src
+    seen = {}
+    for lane in range(44):
+        lv, seg = lane >> 2, lane & 3
+        for i in range(4):
+            base = lv * row + 16 * seg + 4 * i
+            assert base % 4 == 0
+            for w in range(4):
+                seen[(lv, 16 * seg + 4 * i + w)] = seen.get((lv, 16 * seg + 4 * i + w), 0) + 1
+                assert base + w == lv * row + (16 * seg + 4 * i + w)           # row lv, word = the lane that stored it
+    assert seen == {(l, lane): 1 for l in range(11) for lane in range(64)}
+    for i in range(4):
+        for grp in READ_GROUPS:
+            cols = [((lane >> 2) * row + 16 * (lane & 3) + 4 * i) // 4 % 16 for lane in grp if lane >> 2 <= 10]
+            assert len(set(cols)) == len(cols), (i, grp)
