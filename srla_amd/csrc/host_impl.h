@@ -210,6 +210,9 @@ struct Impl {
      * trace: stream C back to back).  SRLA_MI355X_DMA_OUT=0: the copy-out kernel everywhere. */
     bool dma_out = true;
     hipStream_t dma_stream = nullptr;
+    hipStream_t rc_stream = nullptr;    /* SRLA_MI355X_RC_STREAM=1 (experiment, round 6): srla_residual_cost of a crowded call's jobs on a wide stream of its
+                                         * own, so that it runs BESIDE the next job's srla_autocorr (integer VALU + matrix pipe beside fp64 + LDS) instead of behind it */
+    bool rc_own_stream = false;
     bool call_crowded = false;          /* this call: more than three jobs, so a job's narrow kernels run beside other jobs' wide ones (SrlaJobParams::crowded) */
     bool planned_pieces = false;      /* plan_jobs cut the call's one short stream into pieces (Slot::piece) */
     bool call_solo = false;           /* the call is ONE job and no chain-mode window (Slot::solo) */

@@ -48,6 +48,7 @@ Impl::~Impl()
         for (auto &st : streams) if (st) (void)hipStreamDestroy(st);
         if (upload) (void)hipStreamDestroy(upload);
         if (dma_stream) { (void)hipStreamSynchronize(dma_stream); (void)hipStreamDestroy(dma_stream); }
+        if (rc_stream) { (void)hipStreamSynchronize(rc_stream); (void)hipStreamDestroy(rc_stream); }
         if (chain_stream) { (void)hipStreamSynchronize(chain_stream); (void)hipStreamDestroy(chain_stream); }
         if (ev_or) (void)hipEventDestroy(ev_or);
         if (ev_ref) (void)hipEventDestroy(ev_ref);
@@ -95,6 +96,11 @@ bool Impl::init_device()
     /* (created last: the runtime hands out its hardware queues in the order the streams are made, and a stream made before
      * `upload` moved that one onto a queue it shares with a compute stream -- host input -12 %, measured) */
     if (dma_out) HIP_OK(hipStreamCreateWithFlags(&dma_stream, hipStreamNonBlocking));
+    if (rc_own_stream) {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        HIP_OK(hipStreamCreateWithPriority(&rc_stream, hipStreamNonBlocking, hi));
+    }
     if (!h_or.ensure(64)) return false;
     for (uint32_t si = 0; si < kMaxSlots; si++) {
         Slot &s = slot[si];
@@ -551,6 +557,7 @@ bool Impl::run_stage(Slot &s, int st, int part)
         } else { if (ev0) HIP_OK(hipEventRecord(ev0, N)); HIP_OK(hipEventRecord(s.t1[ST_B], N)); }
         break;
     case ST_C:
+        if (rc_stream && !s.own_stream && call_crowded && !lean) W = rc_stream;       /* (experiment: beside the other jobs' srla_autocorr, not behind it) */
         if (!lean) HIP_OK(hipStreamWaitEvent(W, s.t1[ST_B], 0));
         if (have_items) {
             hipEvent_t c1 = lean ? nullptr : s.t1[ST_C];
@@ -928,6 +935,7 @@ SRLAApiResult Impl::encode_streams(bool search)
         if (upload) (void)hipStreamSynchronize(upload);
         if (chain_stream) (void)hipStreamSynchronize(chain_stream);
         if (dma_stream && dma_used) { (void)hipStreamSynchronize(dma_stream); dma_used = false; }
+        if (rc_stream) (void)hipStreamSynchronize(rc_stream);
     };
     if (timeline) (void)hipEventRecord(ev_ref, streams[0]);
     if ((size_t)8 * nst > d_pos.cap) { drain(); if (!d_pos.ensure((size_t)8 * nst)) return SRLA_APIRESULT_NG; }

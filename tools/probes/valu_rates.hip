@@ -55,6 +55,29 @@
 #define A_BPERM(i) asm volatile("ds_bpermute_b32 %0, %1, %0\n\ts_waitcnt lgkmcnt(0)" : "+v"(a##i) : "v"(b));
 #define A_SWZ(i)   asm volatile("ds_swizzle_b32 %0, %0 offset:0x041F\n\ts_waitcnt lgkmcnt(0)" : "+v"(a##i));
 
+#define A_MOV(i)   asm volatile("v_mov_b32 %0, %1" : "=v"(a##i) : "v"(b));
+#define A_AND(i)   asm volatile("v_and_b32 %0, %0, %1" : "+v"(a##i) : "v"(b));
+#define A_OR(i)    asm volatile("v_or_b32 %0, %0, %1" : "+v"(a##i) : "v"(b));
+#define A_SHL(i)   asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(a##i));
+#define A_ASHR(i)  asm volatile("v_ashrrev_i32 %0, 1, %0" : "+v"(a##i));
+#define A_SUB(i)   asm volatile("v_sub_u32 %0, %0, %1" : "+v"(a##i) : "v"(b));
+#define A_MINU(i)  asm volatile("v_min_u32 %0, %0, %1" : "+v"(a##i) : "v"(b));
+#define A_ANDOR(i) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(a##i) : "v"(b), "v"(c));
+#define A_LSHLOR(i) asm volatile("v_lshl_or_b32 %0, %0, 1, %1" : "+v"(a##i) : "v"(b));
+#define A_OR3(i)   asm volatile("v_or3_b32 %0, %0, %1, %2" : "+v"(a##i) : "v"(b), "v"(c));
+#define A_BFE(i)   asm volatile("v_bfe_u32 %0, %0, 1, 30" : "+v"(a##i));
+#define A_ALIGNBIT(i) asm volatile("v_alignbit_b32 %0, %0, %1, 1" : "+v"(a##i) : "v"(b));
+#define A_MULU24(i) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(a##i) : "v"(b));
+#define A_MULHI(i) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(a##i) : "v"(b));
+#define A_ADDCO(i) asm volatile("v_add_co_u32 %0, vcc, %0, %1" : "+v"(a##i) : "v"(b) : "vcc");
+#define A_CMP(i)   asm volatile("v_cmp_gt_u32 vcc, %0, %1" :: "v"(a##i), "v"(b) : "vcc");
+#define A_CNDS(i)  asm volatile("v_cndmask_b32 %0, %0, %1, s[20:21]" : "+v"(a##i) : "v"(b));
+#define A_CMPCND(i) asm volatile("v_cmp_gt_u32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(a##i) : "v"(b) : "vcc");
+#define A_CVTU(i)  asm volatile("v_cvt_f32_u32 %0, %0" : "+v"(a##i));
+KERNEL32(k_mov, A_MOV) KERNEL32(k_and, A_AND) KERNEL32(k_or, A_OR) KERNEL32(k_shl, A_SHL) KERNEL32(k_ashr, A_ASHR) KERNEL32(k_sub, A_SUB)
+KERNEL32(k_minu, A_MINU) KERNEL32(k_andor, A_ANDOR) KERNEL32(k_lshlor, A_LSHLOR) KERNEL32(k_or3, A_OR3) KERNEL32(k_bfe, A_BFE)
+KERNEL32(k_alignbit, A_ALIGNBIT) KERNEL32(k_mulu24, A_MULU24) KERNEL32(k_mulhi, A_MULHI) KERNEL32(k_addco, A_ADDCO) KERNEL32(k_cmp, A_CMP)
+KERNEL32(k_cnds, A_CNDS) KERNEL32(k_cmpcnd, A_CMPCND) KERNEL32(k_cvtu, A_CVTU)
 KERNEL32(k_add, A_ADD) KERNEL32(k_shr, A_SHR) KERNEL32(k_xor, A_XOR) KERNEL32(k_add3, A_ADD3) KERNEL32(k_lshladd, A_LSHLADD)
 KERNEL32(k_cndmask, A_CNDMASK) KERNEL32(k_mullo, A_MULLO) KERNEL32(k_mul24, A_MUL24) KERNEL32(k_mad24, A_MAD24)
 KERNEL32(k_pksub, A_PKSUB) KERNEL32(k_pkshr, A_PKSHR) KERNEL32(k_dot2u, A_DOT2U) KERNEL32(k_dot2i, A_DOT2I) KERNEL32(k_dot4i, A_DOT4I)
@@ -137,7 +160,10 @@ int main()
     hipEventCreate(&e0); hipEventCreate(&e1);
     std::vector<Test> tests = {
         { "v_add_u32", k_add, 64 }, { "v_lshrrev_b32", k_shr, 64 }, { "v_xor_b32", k_xor, 64 }, { "v_add3_u32", k_add3, 64 }, { "v_lshl_add_u32", k_lshladd, 64 },
-        { "v_cndmask_b32", k_cndmask, 64 }, { "v_max_u32", k_maxu, 64 }, { "v_sub_u32 clamp", k_subsat, 64 }, { "v_ffbh_u32", k_clz, 64 },
+        { "v_cndmask_b32 (vcc)", k_cndmask, 64 }, { "v_cndmask_b32 (sgpr pair)", k_cnds, 64 }, { "v_cmp_gt_u32", k_cmp, 64 }, { "v_cmp_gt_u32 + v_cndmask_b32 (pair)", k_cmpcnd, 128 },
+        { "v_mov_b32", k_mov, 64 }, { "v_and_b32", k_and, 64 }, { "v_or_b32", k_or, 64 }, { "v_lshlrev_b32", k_shl, 64 }, { "v_ashrrev_i32", k_ashr, 64 }, { "v_sub_u32", k_sub, 64 },
+        { "v_min_u32", k_minu, 64 }, { "v_and_or_b32", k_andor, 64 }, { "v_lshl_or_b32", k_lshlor, 64 }, { "v_or3_b32", k_or3, 64 }, { "v_bfe_u32", k_bfe, 64 },
+        { "v_alignbit_b32", k_alignbit, 64 }, { "v_mul_u32_u24", k_mulu24, 64 }, { "v_mul_hi_u32", k_mulhi, 64 }, { "v_add_co_u32", k_addco, 64 }, { "v_cvt_f32_u32", k_cvtu, 64 }, { "v_max_u32", k_maxu, 64 }, { "v_sub_u32 clamp", k_subsat, 64 }, { "v_ffbh_u32", k_clz, 64 },
         { "v_mul_lo_u32", k_mullo, 64 }, { "v_mul_i32_i24", k_mul24, 64 }, { "v_mad_i32_i24", k_mad24, 64 }, { "v_mad_i64_i32", k_mad_i64_i32, 64 },
         { "v_pk_sub_u16 clamp", k_pksub, 64 }, { "v_pk_lshrrev_b16", k_pkshr, 64 }, { "v_dot2_u32_u16", k_dot2u, 64 }, { "v_dot2_i32_i16", k_dot2i, 64 },
         { "v_dot4_i32_i8", k_dot4i, 64 }, { "v_perm_b32", k_perm, 64 }, { "v_alignbyte_b32", k_alignb, 64 },
@@ -166,9 +192,9 @@ int main()
                 hipEventElapsedTime(&ms, e0, e1);
                 if (ms < best) best = ms;
             }
-            const double insts_per_simd = (double)ITER * 64.0 * wps;
+            const double insts_per_simd = (double)ITER * 64.0 * wps * (t.lanes_per_inst / 64.0);
             const double cyc = best * 1e-3 * 2.4e9 / insts_per_simd;
-            const double tlops = insts_per_simd * pr.multiProcessorCount * 4.0 * t.lanes_per_inst / (best * 1e-3) / 1e12;
+            const double tlops = insts_per_simd * pr.multiProcessorCount * 4.0 * 64.0 / (best * 1e-3) / 1e12;
             printf("%-30s %6d %12.4f %14.2f %16.2f\n", t.name, wps, best, cyc, tlops);
         }
     }
