@@ -354,9 +354,23 @@ def roofline_object(st, config, launches, instants_per_launch, algo_bytes, end_t
     if rc and rc.get("ms_per_job") and rc_insts:
         lane_ops = 64.0 * sum(rc_insts) * instants_per_launch / 4194304.0
         tops = lane_ops / (rc["ms_per_job"] * 1e-3) / 1e12
+        # the roof: what THIS kernel's instruction mix can issue -- measured cycles per wave-instruction of every instruction class
+        # (tools/probes/valu_rates.hip on an MI355X) weighted with the kernel's own ISA histogram (tools/valu_roof.py); the data
+        # sheet's 32 lanes per clock and SIMD (78.6 T lane-ops/s) is reached by no instruction of the mix
+        peak, peak_src = 78.6, "data sheet: 1024 SIMDs x 32 lanes x 2.4 GHz (no measured rates committed)"
+        try:
+            vr = json.load(open(os.path.join(ROOT, "profiles", "r06", "valu_roof.json")))
+            ent = vr.get("srla_residual_cost<2, true>")
+            if ent:
+                peak = float(ent["peak_tera_lane_ops"])
+                peak_src = ("profiles/r06/valu_roof.json: %.2f cycles per VALU instruction of srla_residual_cost<2, true>'s mix (static ISA histogram x "
+                            "profiles/r06/valu_rates.txt, measured issue rates) -> 64 lanes / that x 1024 SIMDs x 2.4 GHz" % ent["cycles_per_valu_instruction"])
+        except Exception:
+            pass
         roof["int_valu"] = {"kernel": "srla_residual_cost", "valu_wave_instructions_per_job": int(sum(rc_insts) * instants_per_launch / 4194304.0),
-                            "achieved_tera_lane_ops": round(tops, 3), "peak_tera_lane_ops": 78.6, "frac": round(tops / 78.6, 4),
-                            "note": "committed SQ_INSTS_VALU of a full job's launch x 64 lanes / this run's stage time; peak = 1024 SIMDs x 32 lanes x 2.4 GHz"}
+                            "achieved_tera_lane_ops": round(tops, 3), "peak_tera_lane_ops": round(peak, 2), "frac": round(tops / peak, 4),
+                            "peak_source": peak_src, "peak_datasheet_tera_lane_ops": 78.6, "frac_of_datasheet": round(tops / 78.6, 4),
+                            "note": "committed SQ_INSTS_VALU of a full job's launch x 64 lanes / this run's stage time"}
     # were the committed counters collected from the device sources this library was built from?
     try:
         sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -399,7 +413,7 @@ def leg_cpu_baseline(pcm, name, rate, bps):
             "sample": "first %.0f s of the leg's first stream (%d samples/ch, %d ch), one run" % (n / rate, n, clip.shape[0]), "bytes": int(out.size)}
 
 
-def config_leg(lib, L, name, streams_src, rate, nch, bps, pack_threads, cpu_line, budget_s=2.0):
+def config_leg(lib, L, name, streams_src, rate, nch, bps, pack_threads, cpu_line, budget_s=3.0):
     """One bounded leg of another BASELINE configuration: the same timed-region rule as the headline (calls of the unchanged API
     back to back between device synchronisations, pageable host memory -> pageable host memory), its stages' HIP-event times
     priced as the headline's are."""
@@ -442,7 +456,7 @@ def config_leg(lib, L, name, streams_src, rate, nch, bps, pack_threads, cpu_line
             if rc != capi.OK:
                 raise SystemExit("SRLAMI355X_EncodeBatch (%s leg) -> %d" % (name, rc))
     calls = max(3, int(round(budget_s * LEG_NOMINAL[name] * 1e6 / (float(n) * files))))
-    for _ in range(2):
+    for _ in range(3):
         call()
     st = Stats()
     L.SRLAMI355X_GetStats(enc, C.byref(st), 1)

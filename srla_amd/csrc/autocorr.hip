@@ -1406,7 +1406,7 @@ extern "C" int srla_launch_autocorr(hipStream_t stream, int rclass, const SrlaJo
         switch (rclass) {
         case 0: if (wp) LAUNCH(1, 128, 1024, true); else LAUNCH(1, 128, 1024, false); break;
         case 1: if (wp) LAUNCH(1, 256, 2048, true); else LAUNCH(1, 256, 2048, false); break;
-        case 2: if (g_srla_tune.ac_wide & 1u) LAUNCH(1, 512, 4096, false); else if (wp) LAUNCH(2, 256, 4096, true); else LAUNCH(2, 256, 4096, false); break;
+        case 2: if (wp) LAUNCH(2, 256, 4096, true); else LAUNCH(2, 256, 4096, false); break;
         /* the 8192-point class on sixteen sub-regions (fft_subregions, round 6): 9 barriers per item instead of 26 and the same bits, but
          * measured 5 % SLOWER stand-alone (164 -> 172 us per job of -B 8192 -V 2 -P 3, profiles/r06/ab_kernels.txt) -- like the
          * 4096-point class's barriers in round 5, this class's were not what its wavefronts wait for.  SRLA_MI355X_FFT_WP=2 selects it. */

@@ -210,9 +210,6 @@ struct Impl {
      * trace: stream C back to back).  SRLA_MI355X_DMA_OUT=0: the copy-out kernel everywhere. */
     bool dma_out = true;
     hipStream_t dma_stream = nullptr;
-    hipStream_t rc_stream = nullptr;    /* SRLA_MI355X_RC_STREAM=1 (experiment, round 6): srla_residual_cost of a crowded call's jobs on a wide stream of its
-                                         * own, so that it runs BESIDE the next job's srla_autocorr (integer VALU + matrix pipe beside fp64 + LDS) instead of behind it */
-    bool rc_own_stream = false;
     bool call_crowded = false;          /* this call: more than three jobs, so a job's narrow kernels run beside other jobs' wide ones (SrlaJobParams::crowded) */
     bool planned_pieces = false;      /* plan_jobs cut the call's one short stream into pieces (Slot::piece) */
     bool call_solo = false;           /* the call is ONE job and no chain-mode window (Slot::solo) */
@@ -258,7 +255,8 @@ struct Impl {
     bool timing = true;               /* stage timing events (SRLA_MI355X_NO_TIMING drops them) */
     /* measured settings (profiles/r03, r04), constants since round 5 */
     static constexpr uint32_t kPinMinMB = 32;         /* streams of fewer MB of samples are never page-locked in place (staging them costs less than the registration) */
-    static constexpr uint32_t kPairMaxItems = 6144;   /* a small job's 2048- and 4096-point autocorrelation classes go in one launch up to this many items */
+    uint32_t c_skew_jobs = 0;           /* SRLA_MI355X_C_SKEW: iterations between a job's solve chain and its srla_residual_cost beyond the one the stages need (encode_streams) */
+    static constexpr uint32_t kPairMaxItems = 6144;   /* a small job's 2048- and 4096-point autocorrelation classes go in one launch up to this many items (every job's: the autocorr stage 0.195 -> 0.21 ms per job at M, round 6, profiles/r06/ab_launch_shapes.txt) */
     static constexpr uint32_t kPoolLingerUs = 600;    /* how long the pool's workers keep looking for the next round of a short call before they sleep */
     static constexpr uint32_t kDmaTailJobs = 1;       /* the call's last n jobs leave by srla_stream_out even where the others leave by host-issued copies */
     static constexpr uint32_t kTailBoost = 4, kTailBoostJobs = 3;   /* stream-out workgroup multiplier of the call's last jobs */

@@ -48,7 +48,6 @@ Impl::~Impl()
         for (auto &st : streams) if (st) (void)hipStreamDestroy(st);
         if (upload) (void)hipStreamDestroy(upload);
         if (dma_stream) { (void)hipStreamSynchronize(dma_stream); (void)hipStreamDestroy(dma_stream); }
-        if (rc_stream) { (void)hipStreamSynchronize(rc_stream); (void)hipStreamDestroy(rc_stream); }
         if (chain_stream) { (void)hipStreamSynchronize(chain_stream); (void)hipStreamDestroy(chain_stream); }
         if (ev_or) (void)hipEventDestroy(ev_or);
         if (ev_ref) (void)hipEventDestroy(ev_ref);
@@ -96,11 +95,6 @@ bool Impl::init_device()
     /* (created last: the runtime hands out its hardware queues in the order the streams are made, and a stream made before
      * `upload` moved that one onto a queue it shares with a compute stream -- host input -12 %, measured) */
     if (dma_out) HIP_OK(hipStreamCreateWithFlags(&dma_stream, hipStreamNonBlocking));
-    if (rc_own_stream) {
-        int lo = 0, hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        HIP_OK(hipStreamCreateWithPriority(&rc_stream, hipStreamNonBlocking, hi));
-    }
     if (!h_or.ensure(64)) return false;
     for (uint32_t si = 0; si < kMaxSlots; si++) {
         Slot &s = slot[si];
@@ -557,7 +551,6 @@ bool Impl::run_stage(Slot &s, int st, int part)
         } else { if (ev0) HIP_OK(hipEventRecord(ev0, N)); HIP_OK(hipEventRecord(s.t1[ST_B], N)); }
         break;
     case ST_C:
-        if (rc_stream && !s.own_stream && call_crowded && !lean) W = rc_stream;       /* (experiment: beside the other jobs' srla_autocorr, not behind it) */
         if (!lean) HIP_OK(hipStreamWaitEvent(W, s.t1[ST_B], 0));
         if (have_items) {
             hipEvent_t c1 = lean ? nullptr : s.t1[ST_C];
@@ -935,7 +928,6 @@ SRLAApiResult Impl::encode_streams(bool search)
         if (upload) (void)hipStreamSynchronize(upload);
         if (chain_stream) (void)hipStreamSynchronize(chain_stream);
         if (dma_stream && dma_used) { (void)hipStreamSynchronize(dma_stream); dma_used = false; }
-        if (rc_stream) (void)hipStreamSynchronize(rc_stream);
     };
     if (timeline) (void)hipEventRecord(ev_ref, streams[0]);
     if ((size_t)8 * nst > d_pos.cap) { drain(); if (!d_pos.ensure((size_t)8 * nst)) return SRLA_APIRESULT_NG; }
@@ -1179,7 +1171,13 @@ SRLAApiResult Impl::encode_streams(bool search)
      * `base`: the jobs before it are complete; a job whose near-ties the host libm decides differently from the device
      * (arbitrate) sends the loop back to it. */
     const uint32_t ltp_skew = (par.ltp_order > 0 && split_ltp_stage) ? 1u : 0u;
-    const uint32_t depth = 3 + ltp_skew;
+    /* One step more between a job's solve chain (N) and its srla_residual_cost (W): the chain in flight (errvars + order + taps, 0.2 ms
+     * beside the wide kernels) is about as long as the next job's srla_autocorr, so W reached residual_cost(t - 1) before solve(t - 1)
+     * had ended and idled -- a kernel trace of the metric configuration showed the wide stream 85 % busy between a call's first and
+     * last job (profiles/r06/wide_stream_busy.txt).  With the step the chain has a whole autocorr + residual_cost to finish in.
+     * Needs one buffer set more in flight: where there is room (SRLA_MI355X_C_SKEW, calls of many jobs). */
+    const uint32_t c_skew = (c_skew_jobs != 0u && call_crowded && kSlots >= 3u + ltp_skew + c_skew_jobs + 1u) ? c_skew_jobs : 0u;
+    const uint32_t depth = 3 + ltp_skew + c_skew;
     /* The host may run further ahead than the stages' skew asks for: a job is collected `lag` iterations after it was begun, and
      * every buffer set beyond depth + 1 is one more job staged and uploaded while the device still works on older ones (host
      * input: staging 0.28 ms + upload 0.3 ms per 4 M-sample job on top of the 1.5 ms a job takes from its first kernel to its
@@ -1194,16 +1192,16 @@ SRLAApiResult Impl::encode_streams(bool search)
         }
         /* (the block assembly first: on stream N it must not queue behind this iteration's solve and pricing, which wait for
          * wide kernels that have only just been enqueued) */
-        if (in_flight(t, 2 + ltp_skew)) {
-            Slot &s = job_slot(t - 2 - ltp_skew);
+        if (in_flight(t, 2 + ltp_skew + c_skew)) {
+            Slot &s = job_slot(t - 2 - ltp_skew - c_skew);
             if (!run_stage(s, ST_E)) return fail(SRLA_APIRESULT_NG);
         }
         if (in_flight(t, ltp_skew)) {
             Slot &s = job_slot(t - ltp_skew);
             if ((ltp_skew && !run_stage(s, ST_A, 2)) || !run_stage(s, ST_B)) return fail(SRLA_APIRESULT_NG);
         }
-        if (in_flight(t, 1 + ltp_skew)) {
-            Slot &s = job_slot(t - 1 - ltp_skew);
+        if (in_flight(t, 1 + ltp_skew + c_skew)) {
+            Slot &s = job_slot(t - 1 - ltp_skew - c_skew);
             if (!run_stage(s, ST_C) || !run_stage(s, ST_D)) return fail(SRLA_APIRESULT_NG);
         }
         if (single && chain.active && chain.early) {

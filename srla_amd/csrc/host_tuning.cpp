@@ -42,17 +42,16 @@ void Impl::read_environment()
     { const long long v = number("SRLA_MI355X_MID_JOBS", -1); if (v >= 0 && v <= 16) mid_jobs = (uint32_t)v; }
     { const long long v = number("SRLA_MI355X_SHORT_DIV", 0); if (v >= 2 && v <= 64) short_div = (uint32_t)v; }
     { const long long v = number("SRLA_MI355X_PACK_THREADS", 0); if (v > 0) env_pack_threads = (uint32_t)v; }
+    { const long long v = number("SRLA_MI355X_C_SKEW", -1); if (v >= 0 && v <= 2) c_skew_jobs = (uint32_t)v; }
 
     /* ---- measured alternatives kept as options -------------------------------------------------------- */
     split_ltp_stage = !is_set("SRLA_MI355X_NO_LTP_SKEW");                 /* set: the pitch solve back on stream W */
     if (is_set("SRLA_MI355X_DMA_OUT")) dma_out = number("SRLA_MI355X_DMA_OUT", 1) != 0;
     welch_table = number("SRLA_MI355X_WELCH_TABLE", 1) != 0;            /* 0: the Welch window's weights formed per sample in the kernel (round 5) */
-    rc_own_stream = number("SRLA_MI355X_RC_STREAM", 0) != 0;          /* experiment: srla_residual_cost on a wide stream of its own */
     SrlaLaunchTuning lt = {};
     lt.pack_lds_cap_words = (uint32_t)std::max<long long>(0, number("SRLA_MI355X_PACK_LDS_WORDS", 0));   /* tests: reach the global-memory pack path */
     lt.fft_wp = (uint32_t)std::min<long long>(2, std::max<long long>(0, number("SRLA_MI355X_FFT_WP", 1)));   /* 0: round 4's transform (a workgroup barrier per stage); 2: the 8192-point class on sixteen sub-regions too (round 6: slower) */
     lt.fir_mfma = number("SRLA_MI355X_FIR_MFMA", 1) != 0 ? 1u : 0u;          /* 0: the FIR on v_dot2 / v_dot4 (round 4) */
-    lt.ac_wide = (uint32_t)std::max<long long>(0, number("SRLA_MI355X_AC_WIDE", 0));   /* 1: srla_autocorr's 4096-point class on 512 threads */
     srla_set_launch_tuning(&lt);
 
     /* ---- diagnostics ------------------------------------------------------------------------------------------------ */

@@ -115,8 +115,6 @@ typedef struct {
     uint32_t pack_lds_cap_words;   /* SRLA_MI355X_PACK_LDS_WORDS: 0 = the default cap (24 Ki words) */
     uint32_t fft_wp;               /* SRLA_MI355X_FFT_WP (default 1): the region layout with wave-private FFT stages for classes of at most 4096 points */
     uint32_t fir_mfma;             /* SRLA_MI355X_FIR_MFMA: srla_residual_cost's FIR as a Toeplitz product on the matrix pipe */
-    uint32_t ac_wide;              /* SRLA_MI355X_AC_WIDE: 1 = the 4096-point class of srla_autocorr on 512 threads (one butterfly per thread and stage,
-                                    * eight wavefronts per SIMD instead of four; the transform with a barrier per stage) */
 } SrlaLaunchTuning;
 void srla_set_launch_tuning(const SrlaLaunchTuning *t);
 #define SRLA_SEGCTL_WORDS_HOST 8

@@ -1116,7 +1116,8 @@ __device__ __forceinline__ void rice_search_finish(const uint32_t *u, const Srla
 }
 
 #ifndef SRLA_RC_WAVES
-#define SRLA_RC_WAVES 5       /* wavefronts per SIMD the forms for blocks of at most 4096 samples are compiled for (92 registers) */
+#define SRLA_RC_WAVES 6       /* wavefronts per SIMD the forms for blocks of at most 4096 samples are compiled for: 80 registers and 10 spilled dwords per lane
+                               * (round 6; 5 = 92 registers, no spills, until then: the stage 5 % slower at -V 2, 1 % at -V 1, profiles/r06/ab_launch_shapes.txt) */
 #endif
 #ifndef SRLA_RC4_WAVES
 #define SRLA_RC4_WAVES 3      /* wavefronts per SIMD the 8192-sample form is compiled for: 168 registers and 17 spilled dwords per lane; 2 (228 registers, no spills) was 9 % slower at -B 8192 -V 2 -P 3, profiles/r04/ab_residual_cost_split.txt */

@@ -87,6 +87,10 @@ def price(mn, table):
         return table["v_add_u32 dpp row_shr"], True, "dpp"
     if base.startswith("v_mfma"):
         return None, True, "matrix pipe (issues beside the VALU)"
+    if base == "v_cndmask_b32" and mn.endswith("_e32") and "v_cmp_gt_u32 + v_cndmask_b32 (pair)" in table:
+        # the VOP2 form behind a compare: what the pair test leaves after the compare's own cycles (alone, reading a VCC nobody wrote
+        # in the loop, the probe's v_cndmask_b32 takes 23 cycles -- an artefact of the probe, not of the kernels)
+        return 2.0 * table["v_cmp_gt_u32 + v_cndmask_b32 (pair)"] - table["v_cmp_gt_u32"], True, "measured (pair)"
     names = {"v_cndmask_b32": "v_cndmask_b32 (sgpr pair)", "v_sub_u32": "v_sub_u32", "v_pk_sub_u16": "v_pk_sub_u16 clamp"}
     key = names.get(base, base)
     if key in table:
