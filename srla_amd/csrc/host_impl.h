@@ -255,7 +255,6 @@ struct Impl {
     bool timing = true;               /* stage timing events (SRLA_MI355X_NO_TIMING drops them) */
     /* measured settings (profiles/r03, r04), constants since round 5 */
     static constexpr uint32_t kPinMinMB = 32;         /* streams of fewer MB of samples are never page-locked in place (staging them costs less than the registration) */
-    uint32_t c_skew_jobs = 0;           /* SRLA_MI355X_C_SKEW: iterations between a job's solve chain and its srla_residual_cost beyond the one the stages need (encode_streams) */
     static constexpr uint32_t kPairMaxItems = 6144;   /* a small job's 2048- and 4096-point autocorrelation classes go in one launch up to this many items (every job's: the autocorr stage 0.195 -> 0.21 ms per job at M, round 6, profiles/r06/ab_launch_shapes.txt) */
     static constexpr uint32_t kPoolLingerUs = 600;    /* how long the pool's workers keep looking for the next round of a short call before they sleep */
     static constexpr uint32_t kDmaTailJobs = 1;       /* the call's last n jobs leave by srla_stream_out even where the others leave by host-issued copies */

@@ -1171,13 +1171,7 @@ SRLAApiResult Impl::encode_streams(bool search)
      * `base`: the jobs before it are complete; a job whose near-ties the host libm decides differently from the device
      * (arbitrate) sends the loop back to it. */
     const uint32_t ltp_skew = (par.ltp_order > 0 && split_ltp_stage) ? 1u : 0u;
-    /* One step more between a job's solve chain (N) and its srla_residual_cost (W): the chain in flight (errvars + order + taps, 0.2 ms
-     * beside the wide kernels) is about as long as the next job's srla_autocorr, so W reached residual_cost(t - 1) before solve(t - 1)
-     * had ended and idled -- a kernel trace of the metric configuration showed the wide stream 85 % busy between a call's first and
-     * last job (profiles/r06/wide_stream_busy.txt).  With the step the chain has a whole autocorr + residual_cost to finish in.
-     * Needs one buffer set more in flight: where there is room (SRLA_MI355X_C_SKEW, calls of many jobs). */
-    const uint32_t c_skew = (c_skew_jobs != 0u && call_crowded && kSlots >= 3u + ltp_skew + c_skew_jobs + 1u) ? c_skew_jobs : 0u;
-    const uint32_t depth = 3 + ltp_skew + c_skew;
+    const uint32_t depth = 3 + ltp_skew;
     /* The host may run further ahead than the stages' skew asks for: a job is collected `lag` iterations after it was begun, and
      * every buffer set beyond depth + 1 is one more job staged and uploaded while the device still works on older ones (host
      * input: staging 0.28 ms + upload 0.3 ms per 4 M-sample job on top of the 1.5 ms a job takes from its first kernel to its
@@ -1192,16 +1186,16 @@ SRLAApiResult Impl::encode_streams(bool search)
         }
         /* (the block assembly first: on stream N it must not queue behind this iteration's solve and pricing, which wait for
          * wide kernels that have only just been enqueued) */
-        if (in_flight(t, 2 + ltp_skew + c_skew)) {
-            Slot &s = job_slot(t - 2 - ltp_skew - c_skew);
+        if (in_flight(t, 2 + ltp_skew)) {
+            Slot &s = job_slot(t - 2 - ltp_skew);
             if (!run_stage(s, ST_E)) return fail(SRLA_APIRESULT_NG);
         }
         if (in_flight(t, ltp_skew)) {
             Slot &s = job_slot(t - ltp_skew);
             if ((ltp_skew && !run_stage(s, ST_A, 2)) || !run_stage(s, ST_B)) return fail(SRLA_APIRESULT_NG);
         }
-        if (in_flight(t, 1 + ltp_skew + c_skew)) {
-            Slot &s = job_slot(t - 1 - ltp_skew - c_skew);
+        if (in_flight(t, 1 + ltp_skew)) {
+            Slot &s = job_slot(t - 1 - ltp_skew);
             if (!run_stage(s, ST_C) || !run_stage(s, ST_D)) return fail(SRLA_APIRESULT_NG);
         }
         if (single && chain.active && chain.early) {

@@ -42,7 +42,6 @@ void Impl::read_environment()
     { const long long v = number("SRLA_MI355X_MID_JOBS", -1); if (v >= 0 && v <= 16) mid_jobs = (uint32_t)v; }
     { const long long v = number("SRLA_MI355X_SHORT_DIV", 0); if (v >= 2 && v <= 64) short_div = (uint32_t)v; }
     { const long long v = number("SRLA_MI355X_PACK_THREADS", 0); if (v > 0) env_pack_threads = (uint32_t)v; }
-    { const long long v = number("SRLA_MI355X_C_SKEW", -1); if (v >= 0 && v <= 2) c_skew_jobs = (uint32_t)v; }
 
     /* ---- measured alternatives kept as options -------------------------------------------------------- */
     split_ltp_stage = !is_set("SRLA_MI355X_NO_LTP_SKEW");                 /* set: the pitch solve back on stream W */

@@ -706,7 +706,6 @@ ROUND5_OPTIONS = {
     "round_4_fir": {"SRLA_MI355X_FIR_MFMA": "0"},
     "round_5_window": {"SRLA_MI355X_WELCH_TABLE": "0"},
     "sixteen_sub_regions_for_the_8192_point_class": {"SRLA_MI355X_FFT_WP": "2"},
-    "one_more_pipeline_step_before_residual_cost": {"SRLA_MI355X_C_SKEW": "1", "SRLA_MI355X_JOB_SAMPLES": "131072"},
     "copy_out_kernel_everywhere_small_jobs": {"SRLA_MI355X_DMA_OUT": "0", "SRLA_MI355X_JOB_SAMPLES": "131072"},
 }
 
