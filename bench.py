@@ -915,12 +915,17 @@ def main(argv=None):
             del upcms, uouts
             # (c) the other BASELINE configurations, a bounded leg each (LEG_CONFIGS): value, stage times, roofs, the reference beside it
             if want_legs:
+                # (the metric's own handle goes first: a second handle's streams share the device's few hardware queues with the first
+                # one's, and which stream lands beside which costs the later handle 5 - 10 % -- what the first legs of round 6 showed)
+                lib.destroy(enc)
+                enc = None
                 line["configs"] = {name: config_leg(lib, L, name, [pcms[0], other], rate, nch, bps, pack_threads, leg_cpu.get(name)) for name in LEG_CONFIGS}
             del other
         if cpu_line is not None:                           # rank 0 at N = 1 only; measured before the timed region
             line["cpu_baseline"] = cpu_line
             line["speedup_vs_cpu_1core"] = round(value / cpu_line["value"], 2)
-    lib.destroy(enc)
+    if enc is not None:
+        lib.destroy(enc)
     finish(line)
 
 
