@@ -246,6 +246,7 @@ struct Impl {
     DevBuf d_tw, d_geoms, d_thr, d_huff, d_huffcode, d_pos, d_or, d_oracc;
     DevBuf d_welch;                    /* SrlaJobParams::welch_tab, built for welch_bps bits per sample (sync_tables) */
     uint32_t welch_bps = 0;
+    bool direct_tail = true;           /* SRLA_MI355X_DIRECT_TAIL=0: a call's last job leaves through srla_stream_out like the others (round 5) */
     bool welch_table = true;           /* SRLA_MI355X_WELCH_TABLE=0: the window's weights formed per sample in the kernel (round 5) */
     DevBuf d_svr_scratch_chain;        /* the same for the chain-mode jobs: they run on the narrow stream BESIDE a regular job that keeps to the
                                         * wide stream (a call of one job, Slot::own_stream), so the two refinements may be in flight at once --

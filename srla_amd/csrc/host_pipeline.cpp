@@ -616,7 +616,7 @@ bool Impl::run_stage(Slot &s, int st, int part)
                                    s.d_stream.as<uint8_t>(), s.h_stream.as<uint8_t>(), s.d_scratch.as<uint8_t>(), info, wbytes,
                                    reinterpret_cast<SrlaSegInfo *>(wbytes + job.windows.size()), s.d_ties.as<uint32_t>(),
                                    ev0, s.t1[ST_E], s.out_boost, nullptr, s.ev_pk,
-                                   s.use_dma ? 1u : 0u, &tg);
+                                   s.use_dma ? 1u : ((direct_tail && s.last_job && s.emits && !s.merge_cb) ? 2u : 0u), &tg);
             s.ties_gathered = true;
         } else { if (ev0) HIP_OK(hipEventRecord(ev0, P)); HIP_OK(hipEventRecord(s.t1[ST_E], P)); }
         }

@@ -46,6 +46,7 @@ void Impl::read_environment()
     /* ---- measured alternatives kept as options -------------------------------------------------------- */
     split_ltp_stage = !is_set("SRLA_MI355X_NO_LTP_SKEW");                 /* set: the pitch solve back on stream W */
     if (is_set("SRLA_MI355X_DMA_OUT")) dma_out = number("SRLA_MI355X_DMA_OUT", 1) != 0;
+    direct_tail = number("SRLA_MI355X_DIRECT_TAIL", 1) != 0;            /* 0: a call's last job leaves through srla_stream_out (round 5) */
     welch_table = number("SRLA_MI355X_WELCH_TABLE", 1) != 0;            /* 0: the Welch window's weights formed per sample in the kernel (round 5) */
     SrlaLaunchTuning lt = {};
     lt.pack_lds_cap_words = (uint32_t)std::max<long long>(0, number("SRLA_MI355X_PACK_LDS_WORDS", 0));   /* tests: reach the global-memory pack path */

@@ -108,7 +108,7 @@ int srla_launch_pack(hipStream_t stream, const SrlaJobParams *jp, uint32_t num_s
                      uint32_t *window_bytes, SrlaSegInfo *seg_info, const uint32_t *ties,
                      hipEvent_t ev_start, hipEvent_t ev_stop, uint32_t out_boost,
                      hipStream_t out_stream /* null: srla_stream_out on `stream` too */, hipEvent_t ev_packed /* the hand-over to out_stream */,
-                     uint32_t no_stream_out /* 1: the launch ends with the assembly (ev_stop behind it); the host has the segments' bytes copied (hipMemcpyAsync) when it collects the job */,
+                     uint32_t no_stream_out /* 1: the launch ends with the assembly (ev_stop behind it); the host has the segments' bytes copied (hipMemcpyAsync) when it collects the job; 2: it ends with the assembly too, which stores every block where its stream wants it (a call's last job) */,
                      const SrlaTieGather *gather /* may be null */);
 /* What the launchers take from the environment (read in ONE place, host_tuning.cpp, and handed over here): */
 typedef struct {

@@ -597,7 +597,8 @@ __global__ __launch_bounds__(NT) void srla_pack_blocks(
     const SrlaBlockRecord *__restrict__ blocks, const SrlaItemResult *__restrict__ results,
     const int32_t *__restrict__ res_ws, const uint32_t *__restrict__ huff_code, const uint8_t *__restrict__ huff_len,
     const uint32_t *__restrict__ block_off, const uint32_t *__restrict__ seg_ctl, uint8_t *__restrict__ out,
-    uint8_t *__restrict__ scratch, SrlaJobInfo *__restrict__ info, uint32_t lds_words)
+    uint8_t *__restrict__ scratch, SrlaJobInfo *__restrict__ info, uint32_t lds_words,
+    const SrlaSegDesc *__restrict__ segs /* non-null: store the block where the stream wants it (below) */, uint8_t *__restrict__ host_stage)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     uint32_t *aux = (uint32_t *)lds;                         /* 32 words: wave sums */
@@ -607,6 +608,16 @@ __global__ __launch_bounds__(NT) void srla_pack_blocks(
     const SrlaBlockRecord *recp = &blocks[slot];
     if (!recp->valid || seg_ctl[(size_t)SRLA_SEGCTL_WORDS * recp->seg + 3u]) return;
     uint8_t *dst = out + block_off[slot];
+    if (segs != nullptr) {
+        /* The LAST job of a call (round 6): nothing runs behind it that its workgroups could slow down by staying resident for the
+         * link's stores, so every block goes straight to its place in host memory -- its segment's destination (the stream's buffer
+         * where the device reaches it, else the job's pinned staging buffer) plus its distance from the segment's start in the
+         * staging layout, which has the destination's 16-byte phase -- and srla_stream_out with its launch boundary (14 us of a
+         * 10 s stream's 0.29 ms) is not launched. */
+        const uint32_t *c = seg_ctl + (size_t)SRLA_SEGCTL_WORDS * recp->seg;
+        uint8_t *seg_dst = segs[recp->seg].dst ? reinterpret_cast<uint8_t *>(segs[recp->seg].dst) + c[1] : host_stage + c[2];
+        dst = seg_dst + (block_off[slot] - c[2]);
+    }
     const uint32_t nwords = ((recp->bytes + 3u) >> 2) + 1u;
     if (nwords <= lds_words) {
         pack_block_body<false>(jp, recp, input, items, results, res_ws, huff_code, huff_len, words, aux, kpar, dst, info);
@@ -716,9 +727,10 @@ extern "C" int srla_launch_pack(hipStream_t stream, const SrlaJobParams *jp, uin
     const uint32_t lds_words = srla_pack_lds_words(jp);
     const uint32_t lds = (lds_words + 32 + 512) * 4;
     SET_LDS_ATTR(srla_pack_blocks);
+    const bool direct = no_stream_out == 2u;      /* 2: no copy at all -- the assembly stores every block where the stream wants it */
     hipExtLaunchKernelGGL(srla_pack_blocks, dim3(num_slots), dim3(NT), lds, stream, nullptr, no_stream_out ? ev_stop : nullptr, 0,
                           *jp, input, items, blocks, results, res_ws, huff_code, huff_len, block_off, seg_ctl, stage, scratch, info,
-                          lds_words);
+                          lds_words, direct ? segs : nullptr, host_stage);
     if (no_stream_out) return (hipGetLastError() == hipSuccess) ? 0 : -2;
     /* Two workgroups (three for 24-bit streams, which carry more bytes).  One moves a 4 M-sample job's 6.5 MB in 0.45-0.57 ms
      * beside the other kernels -- longer than the job's wide kernels take (0.46 ms), so the block assembly stream, not stream W,

@@ -705,6 +705,7 @@ ROUND5_OPTIONS = {
     "round_4_fft": {"SRLA_MI355X_FFT_WP": "0"},
     "round_4_fir": {"SRLA_MI355X_FIR_MFMA": "0"},
     "round_5_window": {"SRLA_MI355X_WELCH_TABLE": "0"},
+    "last_job_through_the_copy_out_kernel": {"SRLA_MI355X_DIRECT_TAIL": "0"},
     "sixteen_sub_regions_for_the_8192_point_class": {"SRLA_MI355X_FFT_WP": "2"},
     "copy_out_kernel_everywhere_small_jobs": {"SRLA_MI355X_DMA_OUT": "0", "SRLA_MI355X_JOB_SAMPLES": "131072"},
 }
