@@ -550,12 +550,12 @@ def test_random_configurations_match_the_oracle(product, count, seed, options, l
         # name the cause)
         sys.path.insert(0, os.path.join(helpers.ROOT, "tools"))
         import gpu_sweep
-        done, bad = gpu_sweep.sweep(count, seed, max_samples=1_500_000, **options)
+        done, bad = gpu_sweep.sweep(count, seed, max_samples=800_000, **options)
         assert done >= least and bad == 0
         return
     flags = [f for f, on in (("--mutate", options.get("with_mutations")), ("--paths", options.get("with_paths")),
                              ("--history", options.get("only_history"))) if on]
-    p = subprocess.run([sys.executable, os.path.join(helpers.ROOT, "tools", "gpu_sweep.py"), str(count), str(seed), "--max-samples=1500000"] + flags,
+    p = subprocess.run([sys.executable, os.path.join(helpers.ROOT, "tools", "gpu_sweep.py"), str(count), str(seed), "--max-samples=800000"] + flags,
                        capture_output=True, text=True, timeout=1500, cwd=helpers.ROOT)
     tail = (p.stdout + p.stderr)[-3000:]
     assert p.returncode == 0, tail
