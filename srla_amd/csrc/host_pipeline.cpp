@@ -981,7 +981,7 @@ SRLAApiResult Impl::encode_streams(bool search)
                 ok = host_pin_acquire(st.host_in[ch], (size_t)st.num_samples * 4, &us_per_mb);
                 if (ok) pins.held.push_back(st.host_in[ch]);
                 /* without huge pages locking costs more than the staging copy it saves: remember, stage */
-                if (ok && us_per_mb > 40.0) { pin_too_slow = true; ok = false; }
+                if (ok && us_per_mb > 40.0 && pin_inplace != 1) { pin_too_slow = true; ok = false; }   /* (SRLA_MI355X_PIN_INPLACE=1 asked for it: "always" does not depend on what a box's registration costs -- a GPU test did, round 6) */
             }
             if (!ok) { while (pins.held.size() > before) { host_pin_release(pins.held.back()); pins.held.pop_back(); } }
             else { st.in_pinned = true; stats.num_inplace_pins += nch; }     /* (counted when the stream is read in place, not when a plane's registration turned out too slow and was dropped again) */
