@@ -35,7 +35,10 @@ Extra objects on the JSON line:
                    the pruned device transform runs, the Welch window, the spectrum pass) over the stage's measured time, against
                    the 39.3 TFLOP/s an MI355X issues WITHOUT fused multiply-adds (the reference is C90: no FMA); `int_valu` = the
                    wave-level VALU instructions of one srla_residual_cost launch (committed SQ_INSTS_VALU) x 64 lanes over the
-                   stage's measured time, against the 78.6 T lane-operations/s the SIMDs can issue.  `profile_stale`: the committed
+                   stage's measured time, against the rate THIS kernel's instruction mix can issue (round 6: cycles per instruction
+                   class measured on the device, tools/probes/valu_rates.hip, weighted with the kernel's ISA histogram,
+                   tools/valu_roof.py -> profiles/r06/valu_roof.json: 46.1 T lane-ops/s; the data sheet's 78.6 T, which no instruction
+                   of the mix reaches, is carried beside it as peak_datasheet_tera_lane_ops).  `profile_stale`: the committed
                    counters were collected from other device sources than the ones now in srla_amd/csrc (SHA-256 stamp).
   cpu_baseline     the compiled reference (oracle/_ref, "reference") or the oracle ("port") timed on ONE host core on
                    a bounded sample of the same workload (rank 0, N = 1 only); `all_cores`: for context, the same on
@@ -48,6 +51,13 @@ Extra objects on the JSON line:
                    the previous call could flatter); unequal_corpus: nine files of unequal lengths (120-420 s, fixed seed) in one
                    SRLAMI355X_EncodeBatch call under config 5's flags, each timed call behind one of nine OTHER lengths -- tail jobs of ever new
                    shapes (value_same_corpus_repeated: the same nine back to back).  Beside `value`, never it.
+  configs          (the metric configuration's default run only) BASELINE.json's other configurations, C2 .. C5, as bounded legs
+                   behind the metric's own: ~3 s of calls each under the same timed-region rule (value, ms_per_step = per call), the
+                   stage times priced like the headline's (roofline: frac, fp64, int_valu, end_to_end), compression_ratio, a lossless
+                   round trip of the first stream, and cpu_baseline = the compiled reference on ONE core at the same flags on a
+                   bounded sample (measured before the timed region; speedup_vs_cpu_1core).  --no-config-legs drops them.
+  config.feed      "planes" (the metric: planar int32 through the reference's API) or "pcm" (--feed pcm: the same streams as
+                   interleaved 16-bit frames through SRLAMI355X_EncodeBatchPcm, de-interleaved on the device -- DESIGN.md 8).
   per_rank         (N > 1) every rank's own time inside the library per step (min / max), how many ranks locked their input /
                    output in place instead of staging, how many ranks' streams decoded back to their input, pool threads.
 """
@@ -413,6 +423,22 @@ def leg_cpu_baseline(pcm, name, rate, bps):
             "sample": "first %.0f s of the leg's first stream (%d samples/ch, %d ch), one run" % (n / rate, n, clip.shape[0]), "bytes": int(out.size)}
 
 
+def leg_windows(files, src_lengths, n):
+    """(source stream, first sample) of the `files` windows of n samples a leg cuts out of the run's source streams: the sources
+    take turns, a source's windows are spread evenly over what it holds beyond one window (even offsets: whole stereo frames of
+    16-bit pairs stay aligned the same way), one window per source starts at 0"""
+    nsrc = len(src_lengths)
+    per_src = -(-files // nsrc)
+    out = []
+    for f in range(files):
+        k = f % nsrc
+        span = src_lengths[k] - n
+        assert span >= 0, "a source stream is shorter than the leg's stream"
+        off = 0 if per_src == 1 else ((f // nsrc) * (span // (per_src - 1))) & ~1
+        out.append((k, off))
+    return out
+
+
 def config_leg(lib, L, name, streams_src, rate, nch, bps, pack_threads, cpu_line, budget_s=3.0):
     """One bounded leg of another BASELINE configuration: the same timed-region rule as the headline (calls of the unchanged API
     back to back between device synchronisations, pageable host memory -> pageable host memory), its stages' HIP-event times
@@ -427,13 +453,7 @@ def config_leg(lib, L, name, streams_src, rate, nch, bps, pack_threads, cpu_line
     n = int(conf["seconds"] * rate) & ~1
     # the leg's streams are cut out of the run's two synthetic streams (seeds 1000 / 4242) at different offsets: nine files of
     # 300 s are nine different 300 s windows -- synthesising nine more would cost the run ten seconds
-    pcms = []
-    per_src = -(-files // len(streams_src))                       # windows taken from each source stream
-    for f in range(files):
-        src = streams_src[f % len(streams_src)]
-        span = src.shape[1] - n
-        off = 0 if per_src == 1 else ((f // len(streams_src)) * (span // (per_src - 1))) & ~1
-        pcms.append(np.ascontiguousarray(src[:, off:off + n]))
+    pcms = [np.ascontiguousarray(streams_src[k][:, off:off + n]) for k, off in leg_windows(files, [p_.shape[1] for p_ in streams_src], n)]
     cfg, par = capi.cli_setup(nch, bps, rate, **cli)
     enc = lib.create(cfg)
     assert enc and lib.set_parameter(enc, par) == capi.OK

@@ -63,3 +63,17 @@ def test_the_solve_stage_is_priced_with_the_kernels_that_ran():
     assert roof["kernel"] == "srla_pack_blocks"
     assert roof["dominant_kernel"]["name"].startswith("srla_")
     assert roof["dominant_kernel"]["stage"] in roof["stages"]
+
+
+def test_the_config_legs_cut_distinct_windows_out_of_the_runs_streams():
+    """bench.py: leg_windows -- C5's nine 300 s files are nine different windows of the run's two 600 s streams, every window inside
+    its source; a single-stream leg starts at 0; the legs exist for every configuration but the metric's own and C1"""
+    import bench
+    n600, n300 = 600 * 48000, 300 * 48000
+    w = bench.leg_windows(9, [n600, n600], n300)
+    assert len(set(w)) == 9 and all(k in (0, 1) and 0 <= off <= n600 - n300 and off % 2 == 0 for k, off in w)
+    assert bench.leg_windows(1, [n600, n600], n300) == [(0, 0)] and bench.leg_windows(1, [n600], n600) == [(0, 0)]
+    assert set(bench.LEG_CONFIGS) == set(bench.CONFIGS) - {"M", "C1"}
+    assert set(bench.LEG_CPU_SECONDS) == set(bench.LEG_CONFIGS) == set(bench.LEG_NOMINAL)
+    for name in bench.LEG_CONFIGS:
+        assert bench.CONFIGS[name]["seconds"] <= 600.0 and bench.LEG_CPU_SECONDS[name] <= bench.CONFIGS[name]["seconds"]
