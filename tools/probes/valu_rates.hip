@@ -149,6 +149,28 @@ __global__ __launch_bounds__(256) void k_ds_write_b128(uint32_t *out, uint32_t s
     out[blockIdx.x * blockDim.x + threadIdx.x] = buf[threadIdx.x][0];
 }
 
+// Do a wavefront's LDS stores run beside ANOTHER wavefront's fp64 arithmetic on the same SIMD?  Workgroups alternate (by blockIdx / 8, so
+// that neighbours on an XCD differ): mode 0 = every workgroup fp64 only, 1 = every workgroup 16-byte LDS stores only, 2 = they alternate
+// (with two and four workgroups per CU every SIMD then hosts both kinds), 3 = every wavefront does both, interleaved 8 : 1 as a butterfly
+// stage does.  If mode 2 takes the longer of modes 0 and 1 at half the workgroups each, the two overlap; if it takes their sum, they do not.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_mix(uint32_t *out, uint32_t seed)
+{
+    __shared__ v4u buf[1024];
+    double a0 = 1.0 + 1e-9 * (seed + threadIdx.x), a1 = a0 * 1.1, a2 = a0 * 1.2, a3 = a0 * 1.3, a4 = a0 * 1.4, a5 = a0 * 1.5, a6 = a0 * 1.6, a7 = a0 * 1.7;
+    double b = 1.0 + 1e-12 * seed;
+    v4u v = { seed, threadIdx.x, 2, 3 };
+    v4u *p = buf + (threadIdx.x & 63);
+    const bool valu = MODE == 0 || MODE == 3 || (MODE == 2 && ((blockIdx.x >> 3) & 1) == 0);
+    const bool lds = MODE == 1 || MODE == 3 || (MODE == 2 && ((blockIdx.x >> 3) & 1) == 1);
+    for (int it = 0; it < ITER; it++) {
+        if (valu) { REP64(D_MUL) }
+        if (lds) { REP8(C_LDW) asm volatile("s_waitcnt lgkmcnt(0)"); }
+    }
+    __syncthreads();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)(a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7) + buf[threadIdx.x][0];
+}
+
 typedef void (*kern_t)(uint32_t *, uint32_t);
 struct Test { const char *name; kern_t k; double lanes_per_inst; };
 
@@ -196,6 +218,28 @@ int main()
             const double cyc = best * 1e-3 * 2.4e9 / insts_per_simd;
             const double tlops = insts_per_simd * pr.multiProcessorCount * 4.0 * 64.0 / (best * 1e-3) / 1e12;
             printf("%-30s %6d %12.4f %14.2f %16.2f\n", t.name, wps, best, cyc, tlops);
+        }
+    }
+    printf("# fp64 arithmetic beside 16-byte LDS stores (per iteration: 64 v_mul_f64 and / or 8 ds_write_b128 per wavefront; time in ms)\n");
+    printf("# %-44s %6s %12s\n", "mode", "WG/CU", "time ms");
+    struct { const char *name; kern_t k; } mix[4] = { { "every workgroup: 64 v_mul_f64", k_mix<0> }, { "every workgroup: 8 ds_write_b128", k_mix<1> },
+                                                      { "workgroups alternate between the two", k_mix<2> }, { "every wavefront: both, 64 : 8", k_mix<3> } };
+    for (auto &m : mix) {
+        for (int wps : { 2, 4 }) {
+            dim3 grid(pr.multiProcessorCount * wps), block(256);
+            hipLaunchKernelGGL(m.k, grid, block, 0, 0, out, 1u);
+            hipDeviceSynchronize();
+            float best = 1e30f;
+            for (int rep = 0; rep < 3; rep++) {
+                hipEventRecord(e0, 0);
+                hipLaunchKernelGGL(m.k, grid, block, 0, 0, out, 2u + rep);
+                hipEventRecord(e1, 0);
+                hipEventSynchronize(e1);
+                float ms = 0;
+                hipEventElapsedTime(&ms, e0, e1);
+                if (ms < best) best = ms;
+            }
+            printf("%-46s %6d %12.4f\n", m.name, wps, best);
         }
     }
     return 0;
